@@ -1,0 +1,298 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE in the build container.
+
+TEST INFRASTRUCTURE ONLY.  Needs /root/reference (absent on the GPU box); only
+the resulting data files are committed, never reference source.
+
+How the reference is made importable here:
+  * cwd = /root/reference, sys.argv = ['x'] (modules.config parses argv and reads
+    ./config.yml at import),
+  * ``numba`` is absent -> a stub whose ``njit`` is the identity (the body of
+    ``group`` is plain Python),
+  * ``torchvision`` is absent -> a stub exposing the two names imhead/Pipe.py:1
+    imports (the frozen extractor is out of scope; FPN maps are inputs),
+  * ``modules.Extension`` would JIT-build into ~/.cache; instead it is
+    pre-seeded with the same source compiled by oracle/Makefile into oracle/_ref/.
+
+Usage:  python oracle/gen_golden.py
+"""
+import glob
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = os.environ.get('MVX_REFERENCE', '/root/reference')
+OUT = os.path.join(REPO, 'tests', 'golden')
+sys.path.insert(0, HERE)
+import mvx_oracle as O  # noqa: E402
+
+
+def import_reference():
+    os.chdir(REF)
+    sys.argv = ['x']
+    sys.path.insert(0, REF)
+    nb = types.ModuleType('numba')
+    nb.njit = lambda f=None, *a, **k: f if callable(f) else (lambda g: g)
+    core = types.ModuleType('numba.core')
+    errs = types.ModuleType('numba.core.errors')
+    errs.NumbaDeprecationWarning = type('NumbaDeprecationWarning', (Warning,), {})
+    errs.NumbaPendingDeprecationWarning = type('NumbaPendingDeprecationWarning', (Warning,), {})
+    sys.modules.update({'numba': nb, 'numba.core': core, 'numba.core.errors': errs})
+    tv = types.ModuleType('torchvision')
+    tvm = types.ModuleType('torchvision.models')
+    tvd = types.ModuleType('torchvision.models.detection')
+    tvf = types.ModuleType('torchvision.models.detection.faster_rcnn')
+
+    class _W:
+        DEFAULT = None
+    tvf.FasterRCNN_ResNet50_FPN_V2_Weights = _W
+    tvf.fasterrcnn_resnet50_fpn_v2 = lambda weights=None: types.SimpleNamespace(
+        transform=torch.nn.Identity(), backbone=torch.nn.Identity())
+    sys.modules.update({'torchvision': tv, 'torchvision.models': tvm,
+                        'torchvision.models.detection': tvd,
+                        'torchvision.models.detection.faster_rcnn': tvf})
+    so = glob.glob(os.path.join(HERE, '_ref', 'voxelutil*.so'))
+    assert so, 'run `make -C oracle ref` first'
+    spec = importlib.util.spec_from_file_location('voxelutil', so[0])
+    vu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(vu)
+    ext = types.ModuleType('modules.Extension')
+    ext.cpp = vu
+    sys.modules['modules.Extension'] = ext
+    import modules.config as cfg
+    cfg.config['device'] = 'cpu'
+    return cfg
+
+
+def hash_tensor(shape, seed, dtype=torch.float32):
+    n = int(np.prod(shape))
+    return torch.from_numpy(O.fast_uniform(n, seed).reshape(shape)).to(dtype)
+
+
+def np_perm_like_shuffle(seed, n):
+    """np.random.shuffle on an (n, k) array draws exactly what it draws for arange(n)."""
+    np.random.seed(seed)
+    a = np.arange(n)
+    np.random.shuffle(a)
+    return a.astype(np.int32)
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **arrs)
+    print('%-28s %8.1f KB' % (name, os.path.getsize(path) / 1024), {k: v.shape for k, v in arrs.items()})
+
+
+def small_cloud(seed, P, rng, clusters=0, ncol=4):
+    """Points inside `rng`; `clusters` extra dense blobs that overflow T=35."""
+    g = np.random.default_rng(seed)
+    lo, hi = np.asarray(rng[:3]), np.asarray(rng[3:])
+    xyz = g.random((P, 3)) * (hi - lo) * 0.999 + lo
+    for c in range(clusters):
+        ctr = g.random(3) * (hi - lo) * 0.8 + lo + 0.1 * (hi - lo)
+        n = 60 + 25 * c
+        xyz[c * 100:c * 100 + n] = ctr + g.random((n, 3)) * 0.05
+    r = g.random((P, 1))
+    return np.concatenate([xyz, r], axis=1).astype(np.float32)
+
+
+def main():
+    cfg = import_reference()
+    from modules.data import Preprocessing as pre
+    from modules.utils.Calib import lidar2Img
+    from modules.layers import FCN, CRB3d
+    from modules.voxelnet import Pipe as VP
+    from modules.voxelnet import VoxelNet
+    import modules.imhead.Pipe as IP
+    from MVXNet import MVXNet
+
+    calib64 = O.KITTI_CALIB
+    calib32 = {k: torch.Tensor(v) for k, v in calib64.items()}
+
+    # ---- a1/a2: crop + cropToSight (numpy path, cropdata.py:30-65) ---------------------
+    raw = O.synth_raw(0, 6000)
+    c1 = pre.crop(raw.copy(), cfg.velorange)
+    c2 = pre.cropToSight(c1.copy(), {k: v.copy() for k, v in calib64.items()}, cfg.imsize[::-1])
+    ct = pre.cropTensor(torch.Tensor(raw.copy()), cfg.velorange).numpy()
+    c2t = pre.cropToSight(torch.Tensor(c1.copy()), calib32, cfg.imsize[::-1]).numpy()
+    save('crop', raw=raw, crop=c1, crop_to_sight=c2, crop_tensor=ct, crop_to_sight_tensor=c2t,
+         velorange=np.array(cfg.velorange), imsize_wh=np.array(cfg.imsize[::-1]))
+
+    # ---- a3: lidar2Img, torch f32 (train.py:31-33) and numpy f64 (train.py:37-40) ------
+    pts = c2[:1500].copy()
+    proj32 = lidar2Img(torch.Tensor(pts), calib32, True).numpy()
+    proj64 = lidar2Img(pts.copy(), {k: v.copy() for k, v in calib64.items()}, True)
+    save('lidar2img', pcd=pts, proj_f32=proj32, proj_f64=proj64)
+
+    # ---- a4/a5: group (9-ch) and group_ (7-ch, native _group) --------------------------
+    cases = {}
+    full_rng, full_size = cfg.velorange, cfg.voxelsize
+    small_rng = [0.0, -2.4, -3.0, 3.2, 2.4, 1.0]
+    small_shape = [16, 24, 10]
+    small_size = [(small_rng[i + 3] - small_rng[i]) / small_shape[i] for i in range(3)]
+    for tag, rng, size, P, ncl, seed in (('small', small_rng, small_size, 700, 3, 11),
+                                         ('full', full_rng, full_size, 3000, 2, 12)):
+        pc4 = small_cloud(seed, P, rng, ncl)
+        pr = lidar2Img(torch.Tensor(pc4), calib32, True).numpy()[:, [1, 0]]
+        pc6 = np.concatenate([pc4, pr], axis=1).astype(np.float32)
+        perm = np_perm_like_shuffle(100 + seed, P)
+        np.random.seed(100 + seed)
+        work = pc6.copy()
+        voxel, uidx = pre.group(work, list(rng), list(size), 35)
+        assert np.array_equal(work, pc6[perm])
+        np.random.seed(100 + seed)
+        work4 = pc4.copy()
+        voxel7, uidx7 = pre.group_(work4, rng, size, 35)
+        assert np.array_equal(work4, pc4[perm])
+        cases[tag] = (pc6, perm, voxel, uidx)
+        save('group_' + tag, pcd=pc6, perm=perm, rng=np.array(rng), size=np.array(size),
+             voxel=voxel, uidx=uidx, voxel7=voxel7, uidx7=uidx7)
+    # T smaller than typical occupancy + empty input edge cases
+    pc6, perm, _, _ = cases['small']
+    np.random.seed(111)
+    work = pc6.copy()
+    v5, u5 = pre.group(work, list(small_rng), list(small_size), 5)
+    save('group_T5', pcd=pc6, perm=np_perm_like_shuffle(111, pc6.shape[0]), rng=np.array(small_rng),
+         size=np.array(small_size), voxel=v5, uidx=u5)
+
+    # ---- a6: featureMaping ---------------------------------------------------------------
+    pc6, perm, voxel, uidx = cases['small']
+    # points must project inside the image: replace proj by in-image coordinates (row, col)
+    g = np.random.default_rng(5)
+    vox = voxel.copy()
+    real = ~np.all(vox[..., :3] == 0, axis=-1)
+    vox[..., 7] = np.where(real, g.uniform(0, 369.0, real.shape), vox[..., 7])
+    vox[..., 8] = np.where(real, g.uniform(0, 1223.0, real.shape), vox[..., 8])
+    vox[3, 0, 7:9] = 0.0                                  # proj exactly 0 (Q7)
+    vox32 = torch.Tensor(vox)
+    feats = [hash_tensor((1, 16, 26, 84), 31), hash_tensor((1, 16, 13, 42), 32), hash_tensor((1, 16, 7, 21), 33)]
+    imsize = torch.Tensor(cfg.imsize)
+    vin = vox32.clone()
+    mapped = IP.featureMaping([vin], [f.clone() for f in feats], [calib32], imsize)[0]
+    save('feature_mapping', voxels_in=vox32.numpy(), voxels_after=vin.numpy(),
+         f0=feats[0][0].numpy(), f1=feats[1][0].numpy(), f2=feats[2][0].numpy(),
+         imsize_hw=imsize.numpy(), out=mapped.numpy())
+
+    # ---- a9/a10/a11: FCN, VFE, SVFE, head ------------------------------------------------
+    P = O.make_params(7)
+    V = 37
+    x23 = hash_tensor((1, V, 35, 23), 41) * 2.0
+    # make padded rows look like the real thing: some voxels have identical trailing rows
+    for v in range(0, V, 3):
+        k = 1 + (v * 7) % 34
+        x23[0, v, k:] = x23[0, v, k]
+    m = FCN(23, 16)
+    m.load_state_dict({'fc.weight': P['backbone.svfe.vfe1.fcn.fc.weight'], 'fc.bias': P['backbone.svfe.vfe1.fcn.fc.bias']})
+    fcn_out = m(x23)
+    vfe1 = VP.VFE(23, 16, 35)
+    vfe1.load_state_dict({'fcn.fc.weight': P['backbone.svfe.vfe1.fcn.fc.weight'], 'fcn.fc.bias': P['backbone.svfe.vfe1.fcn.fc.bias']})
+    vfe_out = vfe1(x23)
+    net = VoxelNet()
+    sd = net.state_dict()
+    for k in sd:
+        if 'backbone.' + k in P:
+            sd[k] = P['backbone.' + k]
+        else:                                             # rpn.* : deterministic too
+            sd[k] = O.make_rpn_param(k, tuple(sd[k].shape))
+    net.load_state_dict(sd)
+    svfe_out = net.svfe(x23)
+    head = torch.max(net.fcn(svfe_out), dim=2)[0][0]
+    save('vfe', x=x23[0].numpy(), fcn_out=fcn_out[0].detach().numpy(), vfe_out=vfe_out[0].detach().numpy(),
+         svfe_out=svfe_out[0].detach().numpy(), head_out=head.detach().numpy())
+
+    # ---- a12/a13 + full VoxelNet on the small grid, with parameter gradients -------------
+    cfg.config['voxelshape'] = small_shape
+    idx4 = np.concatenate([np.zeros((uidx.shape[0], 1)), uidx], axis=1)
+    idx4 = torch.LongTensor(idx4)
+    Vs = idx4.shape[0]
+    xs = hash_tensor((1, Vs, 35, 23), 43)
+    for v in range(0, Vs, 2):
+        k = 1 + (v * 5) % 34
+        xs[0, v, k:] = xs[0, v, k]
+    xs.requires_grad_(True)
+    net.zero_grad()
+    feat = torch.max(net.fcn(net.svfe(xs)), dim=2)[0].reshape(-1, 128)
+    grid = VoxelNet.reindex(feat, idx4)
+    c1o = net.cml.conv1(grid)
+    c2o = net.cml.conv2(c1o)
+    c3o = net.cml.conv3(c2o)
+    mid = c3o.reshape((1, -1, small_shape[0], small_shape[1]))
+    score, reg = net.rpn(mid)
+    G = hash_tensor(tuple(mid.shape), 77)
+    (mid * G).sum().backward()
+    grads = {('grad.' + k): v.grad.detach().numpy() for k, v in net.named_parameters()
+             if v.grad is not None and not k.startswith('rpn')}
+    save('voxelnet_small', x=xs[0].detach().numpy(), idx=idx4.numpy(), voxelshape=np.array(small_shape),
+         feat=feat.detach().numpy(), conv1=c1o[0].detach().numpy(), conv2=c2o[0].detach().numpy(),
+         conv3=c3o[0].detach().numpy(), mid=mid[0].detach().numpy(), score=score[0].detach().numpy(),
+         reg=reg[0].detach().numpy(), G=G[0].numpy(), grad_x=xs.grad[0].numpy(), **grads)
+    save('rpn_shapes', names=np.array([k for k in sd if k.startswith('rpn')]),
+         shapes=np.array([list(sd[k].shape) + [0] * (4 - sd[k].dim()) for k in sd if k.startswith('rpn')]))
+
+    # ---- a7: ImageFeatureFusion with gradients -------------------------------------------
+    fus = IP.ImageFeatureFusion()
+    fus.load_state_dict({k[len('head.fusion.'):]: v for k, v in P.items() if k.startswith('head.fusion.')})
+    Vf = 5
+    xf = hash_tensor((1, Vf, 35, 768), 51)
+    xf[0, :, 20:] = 0.0                                   # padded rows are exact zeros (Pipe.py:80)
+    xf.requires_grad_(True)
+    yf = fus(xf)
+    Gf = hash_tensor(tuple(yf.shape), 52)
+    (yf * Gf).sum().backward()
+    # gradients of the big matrices are summarised by a fixed random projection
+    gsum = {}
+    for k, v in fus.named_parameters():
+        gnp = v.grad.detach().numpy()
+        if gnp.size > 20000:
+            pr = O.fast_uniform(gnp.size, 900 + len(k)).reshape(gnp.shape)
+            gsum['gradproj.' + k] = np.array([(gnp.astype(np.float64) * pr).sum(), np.abs(gnp).sum()])
+            gsum['gradslice.' + k] = gnp.reshape(gnp.shape[0], -1)[:8, :64].copy()
+        else:
+            gsum['grad.' + k] = gnp
+    save('fusion', x=xf[0].detach().numpy(), out=yf[0].detach().numpy(), G=Gf[0].numpy(),
+         grad_x=xf.grad[0].numpy()[:, :, :32].copy(), **gsum)
+
+    # ---- a8: MVXNet.forward minus the frozen extractor, small grid, gradients ------------
+    model = MVXNet()
+    msd = model.state_dict()
+    for k in msd:
+        if k in P:
+            msd[k] = P[k]
+        elif k.startswith('backbone.'):
+            msd[k] = sd[k[len('backbone.'):]]
+    model.load_state_dict(msd)
+    feats_full = [hash_tensor((1, 256, 13, 42), 61), hash_tensor((1, 256, 7, 21), 62), hash_tensor((1, 256, 4, 11), 63)]
+    vox_e2e = torch.Tensor(vox)[None].clone()
+    model.zero_grad()
+    vclone = vox_e2e.clone()
+    imf = IP.featureMaping(vclone, [f.clone() for f in feats_full], [calib32], imsize)
+    imf = model.head.fusion(imf[0][None])
+    v23 = torch.concat([vclone[..., :7], imf], dim=-1)
+    feat2 = torch.max(model.backbone.fcn(model.backbone.svfe(v23)), dim=2)[0].reshape(-1, 128)
+    grid2 = VoxelNet.reindex(feat2, idx4)
+    mid2 = model.backbone.cml(grid2).reshape((1, -1, small_shape[0], small_shape[1]))
+    (mid2 * G).sum().backward()
+    g2 = {}
+    for k, v in model.named_parameters():
+        if v.grad is None or 'rpn' in k:
+            continue
+        gnp = v.grad.detach().numpy()
+        if gnp.size > 20000:
+            pr = O.fast_uniform(gnp.size, 900 + len(k)).reshape(gnp.shape)
+            g2['gradproj.' + k] = np.array([(gnp.astype(np.float64) * pr).sum(), np.abs(gnp).sum()])
+        else:
+            g2['grad.' + k] = gnp
+    save('mvxnet_small', voxels=vox_e2e[0].numpy(), idx=idx4.numpy(), voxelshape=np.array(small_shape),
+         f0=feats_full[0][0].numpy(), f1=feats_full[1][0].numpy(), f2=feats_full[2][0].numpy(),
+         imsize_hw=imsize.numpy(), v23=v23[0].detach().numpy(), feat=feat2.detach().numpy(),
+         mid=mid2[0].detach().numpy(), G=G[0].numpy(), **g2)
+
+
+if __name__ == '__main__':
+    main()

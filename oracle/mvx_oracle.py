@@ -1,0 +1,531 @@
+"""CPU oracle for the MVXNet hot path -- TEST INFRASTRUCTURE ONLY.
+
+This file is a CPU restatement (numpy for the integer / index work, torch-CPU
+functional ops for the floating-point layers) of the reference algorithm on
+the hot path.  It exists so that the HIP path can be checked; it is never the
+thing shipped or measured.  Only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import it.
+
+Parity pin: the reference ships no tests or golden vectors,
+so this oracle is pinned by fixtures generated *from the reference itself*
+run in the build container (``oracle/gen_golden.py`` -> ``tests/golden/*.npz``)
+and checked in ``tests/test_oracle_golden.py``.
+
+Every function cites the reference lines it follows (paths relative to the
+reference root).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------
+# configuration constants (config.yml:3-26, modules/config/Config.py:7-13)
+# ----------------------------------------------------------------------------
+VELORANGE = [0.0, -40.0, -3.0, 70.4, 40.0, 1.0]
+VOXELSHAPE = [352, 400, 10]
+SAMPLENUM = 35
+IMSIZE_HW = [370, 1224]
+EPS = 1e-6
+
+
+def voxelsize(velorange=VELORANGE, voxelshape=VOXELSHAPE):
+    """modules/config/Config.py:7 -- python-float (f64) true division."""
+    return [(velorange[i + 3] - velorange[i]) / voxelshape[i] for i in range(3)]
+
+
+# ----------------------------------------------------------------------------
+# a1: crop / cropTensor  (modules/data/Preprocessing.py:12-17, :19-24)
+# ----------------------------------------------------------------------------
+def crop_mask(pcd: np.ndarray, rng: Sequence[float], bounds_f32: bool = False) -> np.ndarray:
+    """Boolean keep-mask ``low <= xyz < high``.
+
+    numpy path compares the f32 coordinates promoted to f64 with f64 bounds
+    (Preprocessing.py:13-16); the torch path rounds the bounds to f32 first
+    (Preprocessing.py:20-23) -> ``bounds_f32=True``.
+    """
+    low = np.asarray(rng[0:3], dtype=np.float64)
+    high = np.asarray(rng[3:6], dtype=np.float64)
+    if bounds_f32:
+        low = low.astype(np.float32).astype(np.float64)
+        high = high.astype(np.float32).astype(np.float64)
+    roi = pcd[:, :3].astype(np.float64)
+    return np.all((low <= roi) & (roi < high), axis=1)
+
+
+def crop(pcd: np.ndarray, rng: Sequence[float], bounds_f32: bool = False) -> np.ndarray:
+    return pcd[crop_mask(pcd, rng, bounds_f32)]
+
+
+# ----------------------------------------------------------------------------
+# a2: cropToSight  (modules/data/Preprocessing.py:26-55)
+# ----------------------------------------------------------------------------
+def project_cam(pcd: np.ndarray, calib: Dict[str, np.ndarray], dtype=np.float64):
+    """(R0_rect @ Tr_velo_to_cam) @ [x y z 1]^T, then P2 @ cam.
+
+    Returns (cam_z, u, v) in ``dtype``.  Association order follows
+    Preprocessing.py:46,50 (left-associated matmuls).
+    """
+    pts = np.ones((4, pcd.shape[0]), dtype=np.float32)
+    pts[:3] = pcd[:, :3].T
+    r0 = np.asarray(calib['R0_rect'], dtype=dtype)
+    tr = np.asarray(calib['Tr_velo_to_cam'], dtype=dtype)
+    p2 = np.asarray(calib['P2'], dtype=dtype)
+    cam = (r0 @ tr) @ pts.astype(dtype)
+    img = p2 @ cam
+    with np.errstate(divide='ignore', invalid='ignore'):
+        u = img[0] / img[2]
+        v = img[1] / img[2]
+    return cam[2], u, v
+
+
+def crop_to_sight_mask(pcd, calib, imsize_wh, dtype=np.float64):
+    """Keep-mask of cropToSight; ``imsize_wh`` is (w, h) (Preprocessing.py:28).
+
+    numpy path -> f64 math (calib is f64, cropdata.py:46-56); torch path -> f32.
+    """
+    lim = np.asarray(imsize_wh, dtype=dtype) - dtype(1e-3)
+    z, u, v = project_cam(pcd, calib, dtype)
+    front = z > 0
+    inside = (u >= 0) & (v >= 0) & (u < lim[0]) & (v < lim[1])
+    return front & inside
+
+
+def crop_to_sight(pcd, calib, imsize_wh, dtype=np.float64):
+    return pcd[crop_to_sight_mask(pcd, calib, imsize_wh, dtype)]
+
+
+# ----------------------------------------------------------------------------
+# a3: lidar2Img(uncheck=True)  (modules/utils/Calib.py:47-69)
+# ----------------------------------------------------------------------------
+def lidar2img(pcd: np.ndarray, calib, dtype=np.float32) -> np.ndarray:
+    """(P,2) projected (u, v) = (width coord, height coord); no filtering.
+
+    train.py:31-33 runs this in torch f32 and then swaps to (row, col).
+    """
+    _, u, v = project_cam(pcd, calib, dtype)
+    return np.stack([u, v], axis=1)
+
+
+# ----------------------------------------------------------------------------
+# a4: group  (modules/data/Preprocessing.py:75-116) -- the voxelizer train.py uses
+# ----------------------------------------------------------------------------
+def voxel_index(xyz: np.ndarray, rng, size) -> np.ndarray:
+    """int32 voxel index, f64 true division, truncation toward zero
+    (Preprocessing.py:87-90)."""
+    low = np.asarray(rng[0:3], dtype=np.float64)
+    size = np.asarray(size, dtype=np.float64)
+    return ((xyz.astype(np.float64) - low) / size).astype(np.int32)
+
+
+def _first_appearance(idx: np.ndarray):
+    """voxel id per stream point in first-appearance order, plus the rank of
+    each point inside its voxel in stream order."""
+    n = idx.shape[0]
+    if n == 0:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64), 0
+    uniq, first, inv = np.unique(idx, axis=0, return_index=True, return_inverse=True)
+    inv = inv.reshape(-1)
+    order = np.argsort(first, kind='stable')            # unique-row -> appearance order
+    vid_of_uniq = np.empty_like(order)
+    vid_of_uniq[order] = np.arange(order.size)
+    vid = vid_of_uniq[inv]
+    srt = np.argsort(vid, kind='stable')                # stream order kept inside a voxel
+    counts = np.bincount(vid, minlength=order.size)
+    start = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    rank = np.empty(n, np.int64)
+    rank[srt] = np.arange(n) - np.repeat(start, counts)
+    return vid, rank, order.size
+
+
+def group(pcd: np.ndarray, perm: np.ndarray, rng, size, T: int
+          ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """9-channel voxelizer.
+
+    ``pcd`` (P,6) [x y z r row col]; ``perm`` is the shuffle permutation that
+    the reference draws with np.random.shuffle (Preprocessing.py:86) -- an
+    explicit input here.  Returns (voxel f64 (V,T,9), uidx f64
+    (V,3), cnt int64 (V,)) exactly as Preprocessing.py:105-116: first <=T
+    points per voxel in stream order, voxels in first-appearance order,
+    centroid over kept points, cols 3:6 = xyz - centroid for all T rows.
+    """
+    s = pcd[perm]
+    idx = voxel_index(s[:, :3], rng, size)
+    vid, rank, V = _first_appearance(idx)
+    voxel = np.zeros((V, T, 9), dtype=np.float64)
+    keep = rank < T
+    sv, sr = vid[keep], rank[keep]
+    sk = s[keep].astype(np.float64)
+    voxel[sv, sr, 0] = sk[:, 0]
+    voxel[sv, sr, 1] = sk[:, 1]
+    voxel[sv, sr, 2] = sk[:, 2]
+    voxel[sv, sr, 6] = sk[:, 3]
+    voxel[sv, sr, 7] = sk[:, 4]
+    voxel[sv, sr, 8] = sk[:, 5]
+    cnt = np.minimum(np.bincount(vid, minlength=V), T).astype(np.int64)
+    uidx = np.zeros((V, 3), dtype=np.float64)
+    firstpos = np.nonzero(rank == 0)[0]
+    uidx[vid[firstpos]] = idx[firstpos]
+    if V:
+        center = voxel[..., :3].sum(axis=1) / cnt[:, None].astype(np.float64)
+        voxel[..., 3:6] = voxel[..., :3] - center[:, None, :]
+    return voxel, uidx, cnt
+
+
+# ----------------------------------------------------------------------------
+# a5: group_ + native _group  (Preprocessing.py:57-73, cpp/voxelutil.cpp:325-360)
+# ----------------------------------------------------------------------------
+def group7(pcd: np.ndarray, perm: np.ndarray, rng, size, T: int):
+    """Legacy 7-channel path.  ``pcd`` (P,>=4) f32.  The native part returns
+    f32 (V,T,7) with xyz->0:3, r->6 (voxelutil.cpp:345-357); python adds the
+    centroid columns: f32 sum over T / int64 cnt (-> f64) and f32 store
+    (Preprocessing.py:71-72)."""
+    s = pcd[perm]
+    idx = voxel_index(s[:, :3], rng, size)
+    vid, rank, V = _first_appearance(idx)
+    voxel = np.zeros((V, T, 7), dtype=np.float32)
+    keep = rank < T
+    sv, sr = vid[keep], rank[keep]
+    voxel[sv, sr, 0:3] = s[keep, 0:3]
+    voxel[sv, sr, 6] = s[keep, 3]
+    cnt = np.minimum(np.bincount(vid, minlength=V), T).astype(np.int64)
+    uidx = np.zeros((V, 3), dtype=np.int64)
+    firstpos = np.nonzero(rank == 0)[0]
+    uidx[vid[firstpos]] = idx[firstpos]
+    if V:
+        center = voxel[..., :3].sum(axis=1) / cnt[:, None]
+        voxel[..., 3:6] = voxel[..., :3] - center[:, None, :]
+    return voxel, uidx, cnt
+
+
+# ----------------------------------------------------------------------------
+# a6: featureMaping  (modules/imhead/Pipe.py:23-82)
+# ----------------------------------------------------------------------------
+def feature_mapping(voxels: torch.Tensor, features: Sequence[torch.Tensor],
+                    imsize_hw: torch.Tensor, eps: float = EPS):
+    """One frame.  ``voxels`` (V,T,9) is MODIFIED IN PLACE like the reference
+    (rows with x==y==z==0 get all 9 channels zeroed, Pipe.py:54-59).
+    ``features`` = levels of (C,H,W) maps (un-padded).  Returns (V,T,C*levels).
+
+    Sampling (Pipe.py:61-75): q = proj/region - eps, i = trunc(q), f = q - i,
+    out = F[i,j] fx fy + F[i+1,j] (1-fx) fy + F[i,j+1] fx (1-fy)
+        + F[i+1,j+1] (1-fx)(1-fy)   -- weights as written, not textbook bilinear.
+    """
+    V, T, _ = voxels.shape
+    xyz = voxels[..., :3].reshape(-1, 3)
+    zero = torch.all(xyz == 0, dim=1)
+    proj = voxels[..., -2:].reshape(-1, 2)
+    proj[zero] = 0
+    voxels[zero.reshape(V, T)] = 0
+    outs = []
+    for feat in features:
+        C, H, W = feat.shape
+        region = imsize_hw / torch.tensor([float(H), float(W)], dtype=imsize_hw.dtype)
+        fp = F.pad(feat, (0, 1, 0, 1))
+        q = proj / region - eps
+        i = q.long()
+        fx = (q[:, 0] - i[:, 0])[None]
+        fy = (q[:, 1] - i[:, 1])[None]
+        r, c = i[:, 0], i[:, 1]
+        if r.numel():
+            assert int(r.max()) + 1 < fp.shape[-2] and int(c.max()) + 1 < fp.shape[-1]
+        o = fp[:, r, c] * fx * fy
+        o = o + fp[:, r + 1, c] * (1 - fx) * fy
+        o = o + fp[:, r, c + 1] * fx * (1 - fy)
+        o = o + fp[:, r + 1, c + 1] * (1 - fx) * (1 - fy)
+        outs.append(o)
+    out = torch.cat(outs, dim=0).T.reshape(V, T, -1).clone()
+    out[zero.reshape(V, T)] = 0
+    return out
+
+
+# ----------------------------------------------------------------------------
+# a9: FCN / CRB blocks  (modules/layers/Blocks.py:5-29)
+# ----------------------------------------------------------------------------
+def _bn_rows(y: torch.Tensor, eps: float) -> torch.Tensor:
+    """BatchNorm with batch statistics over every leading dim, per last-dim
+    channel, biased variance, no affine (Blocks.py:10; config.yml:19-20).
+
+    A (V,T,C) input is normalised through the same permuted (1,C,V,T) view the
+    reference builds (Blocks.py:15-18), so torch-CPU takes the same kernel and
+    the fp32 rounding matches the fixtures; in float64 the layout is immaterial.
+    """
+    if y.dim() == 3:
+        out = F.batch_norm(y[None].permute(0, 3, 1, 2), None, None, None, None, True, 0.0, eps)
+        return out.permute(0, 2, 3, 1)[0]
+    c = y.shape[-1]
+    flat = y.reshape(-1, c).T[None]                      # (1, C, R)
+    out = F.batch_norm(flat, None, None, None, None, True, 0.0, eps)
+    return out[0].T.reshape(y.shape)
+
+
+def fcn(x, w, b, eps=EPS):
+    """Linear -> ReLU -> BN (Blocks.py:14-18)."""
+    return _bn_rows(F.relu(F.linear(x, w, b)), eps)
+
+
+def crb2d_1x1(x, w, b, eps=EPS):
+    """CRB2d with a 1x1 kernel on channel-last rows (Blocks.py:31-40, used by
+    imhead/Pipe.py:89,91): identical arithmetic to a Linear layer."""
+    if x.dim() == 3:                                     # same NCHW view as imhead/Pipe.py:97-99
+        y = F.relu(F.conv2d(x[None].permute(0, 3, 1, 2), w, b))
+        y = F.batch_norm(y, None, None, None, None, True, 0.0, eps)
+        return y.permute(0, 2, 3, 1)[0]
+    return _bn_rows(F.relu(F.linear(x, w.reshape(w.shape[0], -1), b)), eps)
+
+
+def crb3d(x, w, b, stride, pad, eps=EPS):
+    """Conv3d -> ReLU -> BN3d on NCDHW (Blocks.py:20-29)."""
+    y = F.relu(F.conv3d(x, w, b, stride, pad))
+    return F.batch_norm(y, None, None, None, None, True, 0.0, eps)
+
+
+# ----------------------------------------------------------------------------
+# a10/a11: VFE, SVFE, head FCN + max  (modules/voxelnet/Pipe.py:5-29, VoxelNet.py:27-33)
+# ----------------------------------------------------------------------------
+def vfe(x, w, b, eps=EPS):
+    """x (V,T,cin) -> (V,T,2*cout); max over all T rows, no mask (Pipe.py:14-18)."""
+    y = fcn(x, w, b, eps)
+    s = y.max(dim=1, keepdim=True)[0].expand(-1, y.shape[1], -1)
+    return torch.cat([y, s], dim=-1)
+
+
+def svfe(x, p, prefix='svfe.', eps=EPS):
+    x = vfe(x, p[prefix + 'vfe1.fcn.fc.weight'], p[prefix + 'vfe1.fcn.fc.bias'], eps)
+    return vfe(x, p[prefix + 'vfe2.fcn.fc.weight'], p[prefix + 'vfe2.fcn.fc.bias'], eps)
+
+
+def voxel_features(x, p, eps=EPS):
+    """(V,T,23) -> (V,128): SVFE -> FCN(128,128) -> max over T (VoxelNet.py:27-33)."""
+    x = svfe(x, p, 'svfe.', eps)
+    x = fcn(x, p['fcn.fc.weight'], p['fcn.fc.bias'], eps)
+    return x.max(dim=1)[0]
+
+
+# ----------------------------------------------------------------------------
+# a12: reindex  (modules/voxelnet/VoxelNet.py:16-22)
+# ----------------------------------------------------------------------------
+def reindex(x, idx, voxelshape=VOXELSHAPE):
+    """(V,128), idx (V,4) long [b ix iy iz] -> (1,128,D,H,W) with D=shape[2],
+    H=shape[0], W=shape[1]."""
+    res = torch.zeros((1, x.shape[1], voxelshape[2], voxelshape[0], voxelshape[1]), dtype=x.dtype)
+    res[idx[:, 0], :, idx[:, 3], idx[:, 1], idx[:, 2]] = x
+    return res
+
+
+# ----------------------------------------------------------------------------
+# a13: CML  (modules/voxelnet/Pipe.py:31-43)
+# ----------------------------------------------------------------------------
+CML_GEOM = (
+    ('cml.conv1.conv', (2, 1, 1), (1, 1, 1)),
+    ('cml.conv2.conv', (1, 1, 1), (0, 1, 1)),
+    ('cml.conv3.conv', (2, 1, 1), (1, 1, 1)),
+)
+
+
+def cml(x, p, eps=EPS):
+    for name, stride, pad in CML_GEOM:
+        x = crb3d(x, p[name + '.weight'], p[name + '.bias'], stride, pad, eps)
+    return x
+
+
+def voxelnet_middle(x, idx, p, voxelshape=VOXELSHAPE, eps=EPS):
+    """VoxelNet.forward up to the RPN input (VoxelNet.py:27-36):
+    (V,T,23), (V,4) -> (1,128,H,W) with channel = c*2+d."""
+    f = voxel_features(x, p, eps)
+    g = reindex(f, idx, voxelshape)
+    y = cml(g, p, eps)
+    return y.reshape(1, -1, voxelshape[0], voxelshape[1])
+
+
+# ----------------------------------------------------------------------------
+# a7: ImageFeatureFusion  (modules/imhead/Pipe.py:84-104)
+# ----------------------------------------------------------------------------
+def image_feature_fusion(x, p, prefix='', eps=EPS):
+    """(V,T,768) -> (V,T,16)."""
+    x = fcn(x, p[prefix + 'fcn1.fc.weight'], p[prefix + 'fcn1.fc.bias'], eps)
+    x = crb2d_1x1(x, p[prefix + 'conv1.conv.weight'], p[prefix + 'conv1.conv.bias'], eps)
+    x = fcn(x, p[prefix + 'fcn2.fc.weight'], p[prefix + 'fcn2.fc.bias'], eps)
+    x = crb2d_1x1(x, p[prefix + 'conv2.conv.weight'], p[prefix + 'conv2.conv.bias'], eps)
+    x = fcn(x, p[prefix + 'fcn3.fc.weight'], p[prefix + 'fcn3.fc.bias'], eps)
+    return x
+
+
+# ----------------------------------------------------------------------------
+# a8: MVXNet.forward glue minus the frozen extractor  (MVXNet.py:21-27, Head.py:14-22)
+# ----------------------------------------------------------------------------
+def mvx_point_features(voxels, features, imsize_hw, p, eps=EPS):
+    """voxels (V,T,9) (modified in place), FPN levels -> (V,T,23)."""
+    imf = feature_mapping(voxels, features, imsize_hw, eps)
+    imf = image_feature_fusion(imf, p, 'head.fusion.', eps)
+    return torch.cat([voxels[..., :7], imf], dim=-1)
+
+
+# ----------------------------------------------------------------------------
+# deterministic parameters and synthetic frames
+# ----------------------------------------------------------------------------
+PARAM_SHAPES = {
+    'backbone.svfe.vfe1.fcn.fc.weight': (16, 23), 'backbone.svfe.vfe1.fcn.fc.bias': (16,),
+    'backbone.svfe.vfe2.fcn.fc.weight': (64, 32), 'backbone.svfe.vfe2.fcn.fc.bias': (64,),
+    'backbone.fcn.fc.weight': (128, 128), 'backbone.fcn.fc.bias': (128,),
+    'backbone.cml.conv1.conv.weight': (64, 128, 3, 3, 3), 'backbone.cml.conv1.conv.bias': (64,),
+    'backbone.cml.conv2.conv.weight': (64, 64, 3, 3, 3), 'backbone.cml.conv2.conv.bias': (64,),
+    'backbone.cml.conv3.conv.weight': (64, 64, 3, 3, 3), 'backbone.cml.conv3.conv.bias': (64,),
+    'head.fusion.fcn1.fc.weight': (768, 768), 'head.fusion.fcn1.fc.bias': (768,),
+    'head.fusion.conv1.conv.weight': (128, 768, 1, 1), 'head.fusion.conv1.conv.bias': (128,),
+    'head.fusion.fcn2.fc.weight': (128, 128), 'head.fusion.fcn2.fc.bias': (128,),
+    'head.fusion.conv2.conv.weight': (16, 128, 1, 1), 'head.fusion.conv2.conv.bias': (16,),
+    'head.fusion.fcn3.fc.weight': (16, 16), 'head.fusion.fcn3.fc.bias': (16,),
+}
+
+
+def lcg_uniform(n: int, seed: int) -> np.ndarray:
+    """torch-independent integer PRNG -> uniform f64 in [-1, 1).  A 64-bit LCG
+    (Knuth MMIX constants) so fixtures can be regenerated anywhere."""
+    a = np.uint64(6364136223846793005)
+    c = np.uint64(1442695040888963407)
+    out = np.empty(n, dtype=np.float64)
+    # vectorised jump-free generation: iterate in python for small n only
+    s = np.uint64(seed * 2654435761 % (1 << 63) + 1)
+    with np.errstate(over='ignore'):
+        for i in range(n):
+            s = s * a + c
+            out[i] = float(int(s >> np.uint64(11))) / float(1 << 53)
+    return out * 2.0 - 1.0
+
+
+def fast_uniform(n: int, seed: int) -> np.ndarray:
+    """Counter-based integer hash (splitmix64) -> uniform f64 in [-1,1);
+    vectorised, used for the larger parameter tensors."""
+    with np.errstate(over='ignore'):
+        z = (np.arange(n, dtype=np.uint64) + np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) / float(1 << 53) * 2.0 - 1.0
+
+
+def make_params(seed: int = 7, dtype=torch.float32, names=None) -> Dict[str, torch.Tensor]:
+    """Deterministic weights: uniform(-k, k), k = 1/sqrt(fan_in) (the scale of
+    PyTorch's default Linear/Conv init), from the integer hash above."""
+    out = {}
+    for j, (name, shape) in enumerate(PARAM_SHAPES.items()):
+        if names is not None and name not in names:
+            continue
+        n = int(np.prod(shape))
+        if name.endswith('weight'):
+            fan_in = int(np.prod(shape[1:]))
+        else:
+            fan_in = int(np.prod(PARAM_SHAPES[name[:-4] + 'weight'][1:]))
+        k = 1.0 / math.sqrt(fan_in)
+        vals = fast_uniform(n, seed * 1000 + j) * k
+        out[name] = torch.from_numpy(vals.reshape(shape)).to(dtype)
+    return out
+
+
+def make_rpn_param(name: str, shape) -> torch.Tensor:
+    """Deterministic RPN tensor (modules/voxelnet/Pipe.py:45-75 shapes) for fixtures."""
+    n = int(np.prod(shape))
+    seed = 500 + sum(ord(ch) * (i + 1) for i, ch in enumerate(name)) % 100003
+    fan = int(np.prod(shape[1:])) if len(shape) > 1 else 64
+    return torch.from_numpy((fast_uniform(n, seed) / math.sqrt(max(1, fan))).reshape(shape)).float()
+
+
+def strip_prefix(p: Dict[str, torch.Tensor], prefix: str) -> Dict[str, torch.Tensor]:
+    return {k[len(prefix):]: v for k, v in p.items() if k.startswith(prefix)}
+
+
+KITTI_CALIB = {
+    # public KITTI 2011_09_26 object calibration, padded to 4x4 as
+    # modules/data/Load.py:24-41 does (values parsed as float32 there).
+    'P2': np.array([[721.5377, 0.0, 609.5593, 44.85728],
+                    [0.0, 721.5377, 172.854, 0.2163791],
+                    [0.0, 0.0, 1.0, 0.002745884],
+                    [0.0, 0.0, 0.0, 1.0]], dtype=np.float32).astype(np.float64),
+    'R0_rect': np.array([[0.9999239, 0.00983776, -0.007445048, 0.0],
+                         [-0.009869795, 0.9999421, -0.004278459, 0.0],
+                         [0.007402527, 0.004351614, 0.9999631, 0.0],
+                         [0.0, 0.0, 0.0, 1.0]], dtype=np.float32).astype(np.float64),
+    'Tr_velo_to_cam': np.array([[0.007533745, -0.9999714, -0.000616602, -0.004069766],
+                                [0.01480249, 0.0007280733, -0.9998902, -0.07631618],
+                                [0.9998621, 0.00752379, 0.01480755, -0.2717806],
+                                [0.0, 0.0, 0.0, 1.0]], dtype=np.float32).astype(np.float64),
+}
+
+
+def synth_uniform(frame_id: int, P: int = 20000, rng=VELORANGE) -> np.ndarray:
+    """S1 'uniform' frame: (P,4) f32 inside the crop range."""
+    g = np.random.default_rng(1000 + frame_id)
+    lo = np.asarray(rng[:3], np.float32)
+    hi = np.asarray(rng[3:], np.float32)
+    xyz = (g.random((P, 3)) * (hi - lo) + lo).astype(np.float32)
+    xyz = np.minimum(xyz, np.nextafter(hi, -np.inf, dtype=np.float32))
+    xyz = np.maximum(xyz, lo)
+    r = g.random((P, 1)).astype(np.float32)
+    return np.concatenate([xyz, r], axis=1)
+
+
+def synth_raw(frame_id: int, P: int = 120000) -> np.ndarray:
+    """Raw un-cropped cloud for the crop/cropToSight config."""
+    g = np.random.default_rng(1000 + frame_id)
+    x = g.uniform(-80, 80, P)
+    y = g.uniform(-80, 80, P)
+    z = g.uniform(-4, 3, P)
+    r = g.random(P)
+    return np.stack([x, y, z, r], axis=1).astype(np.float32)
+
+
+def synth_ring(frame_id: int, P: int = 20000, rng=VELORANGE, calib=None,
+               imsize_wh=(1224, 370)) -> np.ndarray:
+    """S2 'ring' frame: 64-beam spinning-lidar model over flat ground with box
+    occluders, cropped to range + camera frustum, subsampled to P points."""
+    calib = KITTI_CALIB if calib is None else calib
+    g = np.random.default_rng(1000 + frame_id)
+    elev = np.deg2rad(np.linspace(-24.8, 2.0, 64))
+    azim = np.deg2rad(np.arange(-45.0, 45.0, 0.09))
+    pts = []
+    nbox = 12
+    bc = np.stack([g.uniform(5, 60, nbox), g.uniform(-20, 20, nbox)], 1)
+    bs = np.stack([g.uniform(1.5, 4.5, nbox), g.uniform(1.5, 2.5, nbox), g.uniform(1.4, 2.5, nbox)], 1)
+    h = 1.73
+    for rep in range(4):                                 # several sweeps with jitter -> enough points
+        az = (azim + g.normal(0, 2e-4, azim.size))[None, :]
+        el = (elev + g.normal(0, 2e-4, elev.size))[:, None]
+        dx, dy, dz = np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el) * np.ones_like(az)
+        with np.errstate(divide='ignore'):
+            t = np.where(dz < 0, -h / dz, np.inf)
+        t = np.minimum(t, 120.0)
+        for k in range(nbox):                            # ray/AABB slab test
+            lo = np.array([bc[k, 0] - bs[k, 0] / 2, bc[k, 1] - bs[k, 1] / 2, -h])
+            hi = np.array([bc[k, 0] + bs[k, 0] / 2, bc[k, 1] + bs[k, 1] / 2, -h + bs[k, 2]])
+            with np.errstate(divide='ignore', invalid='ignore'):
+                t1 = np.stack([lo[0] / dx, lo[1] / dy, lo[2] / dz])
+                t2 = np.stack([hi[0] / dx, hi[1] / dy, hi[2] / dz])
+            tn = np.nanmax(np.minimum(t1, t2), axis=0)
+            tf = np.nanmin(np.maximum(t1, t2), axis=0)
+            hit = (tn <= tf) & (tn > 0)
+            t = np.where(hit & (tn < t), tn, t)
+        t = t * (1 + g.normal(0, 2e-3, t.shape))
+        ok = np.isfinite(t) & (t < 119.0)
+        p = np.stack([(t * dx)[ok], (t * dy)[ok], (t * dz)[ok], g.random(int(ok.sum()))], 1)
+        pts.append(p.astype(np.float32))
+    pcd = np.concatenate(pts, 0)
+    pcd = crop(pcd, rng)
+    pcd = crop_to_sight(pcd, calib, imsize_wh)
+    if pcd.shape[0] >= P:
+        sel = np.sort(g.choice(pcd.shape[0], P, replace=False))
+        pcd = pcd[sel]
+    return np.ascontiguousarray(pcd)
+
+
+def synth_perm(frame_id: int, P: int) -> np.ndarray:
+    return np.random.default_rng(2000 + frame_id).permutation(P).astype(np.int32)
+
+
+def synth_fpn(frame_id: int, shapes=((256, 104, 336), (256, 52, 168), (256, 26, 84))):
+    g = np.random.default_rng(3000 + frame_id)
+    return [g.standard_normal(s, dtype=np.float32) for s in shapes]
