@@ -1,0 +1,118 @@
+"""Loader of the HIP C-ABI library -- the drop-in boundary.
+
+Stands where the reference's ``modules/Extension.py:1-3`` JIT-built the pybind11
+module ``cpp/voxelutil.cpp``: importing this module gives ``lib`` (ctypes handle
+of ``libmvx_hip.so``, prototypes from ``include/mvx_hip.h``) and ``cpp``, an
+object with the reference extension's ``_group`` signature
+(``cpp/voxelutil.cpp:325,365``) implemented on the GPU.
+
+There is no CPU fallback: a missing library or a call without a GPU raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get('MVX_HIP_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'libmvx_hip.so'))
+ABI_VERSION = 1
+
+_p = ctypes.c_void_p
+_i32 = ctypes.c_int32
+_i64 = ctypes.c_int64
+_f64 = ctypes.c_double
+_f32 = ctypes.c_float
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/mvx_hip.h one to one
+PROTOTYPES = {
+    'mvx_abi_version': (_i32, []),
+    'mvx_voxelize_workspace_bytes': (_sz, [_i32, _i32]),
+    'mvx_voxelize': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _f64, _f64, _f64, _f64, _f64, _f64,
+                            _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'libmvx_hip.so not found at %s -- build it with `python __graft_entry__.py` '
+            '(or `make -C mvxnet-makise_amd/csrc`). There is no CPU fallback.' % LIB_PATH)
+    handle = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(handle, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    got = handle.mvx_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError('libmvx_hip ABI %d != expected %d: rebuild the library' % (got, ABI_VERSION))
+    return handle
+
+
+lib = _load()
+
+
+class MvxHipError(RuntimeError):
+    pass
+
+
+def check(status, what):
+    if status != 0:
+        kind = 'argument error' if status < 0 else 'hipError_t'
+        raise MvxHipError('%s failed: %s %d' % (what, kind, status))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MvxHipError('libmvx_hip needs device tensors; got a %s tensor (no CPU fallback)' % t.device)
+    if not t.is_contiguous():
+        raise MvxHipError('libmvx_hip needs contiguous tensors')
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def device():
+    if not torch.cuda.is_available():
+        raise MvxHipError('no GPU visible: the MVXNet hot path has no CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+class _Cpp:
+    """The reference extension's python-visible surface (cpp/voxelutil.cpp:362-368) for the
+    hot path.  Only ``_group`` is on the path; the anchor/IoU helpers are CPU label
+    preparation and stay out of scope."""
+
+    @staticmethod
+    def _group(pcd, idx, samplesPerVoxel):
+        """``_group(pcd f32[P,>=4], idx i32[P,3], T) -> (voxel f32[V,T,7], (x,y,z) i64[V] x3,
+        cnt i64[V])`` -- same contract as cpp/voxelutil.cpp:325-360 (numpy in, numpy out,
+        inputs cast like pybind's forcecast)."""
+        from modules import _hip
+        pcd = np.ascontiguousarray(pcd, dtype=np.float32)
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        dev = device()
+        P = pcd.shape[0]
+        if P == 0:
+            z = np.zeros(0, np.int64)
+            return np.zeros((0, samplesPerVoxel, 7), np.float32), (z, z.copy(), z.copy()), z.copy()
+        res = _hip.voxelize(torch.from_numpy(pcd).to(dev)[None], None, None,
+                            (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), int(samplesPerVoxel), 7,
+                            ext_idx=torch.from_numpy(idx).to(dev)[None])
+        V = int(res.n_voxels[0])
+        voxel = res.voxels[0, :V].cpu().numpy()
+        c = res.coords[0, :V].cpu().numpy()
+        # the native function leaves cols 3:6 zero; the centroid columns are added by the
+        # python caller (Preprocessing.py:71-72)
+        voxel[..., 3:6] = 0
+        cnt = res.counts[0, :V].cpu().numpy().astype(np.int64)
+        return voxel, (c[:, 1].copy(), c[:, 2].copy(), c[:, 3].copy()), cnt
+
+
+cpp = _Cpp()
