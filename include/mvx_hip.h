@@ -71,6 +71,71 @@ int mvx_voxelize(const float *pcd, const int32_t *perm, const int32_t *n_points,
                  float *voxels, int64_t *coords, int32_t *counts, int32_t *n_voxels,
                  int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Sparse voxel rows <-> dense grid.  Replaces VoxelNet.reindex (modules/voxelnet/VoxelNet.py:16-22,
+ * `res[b,:,iz,ix,iy] = x[v,:]`) and its autograd gather.  The grid is channels-last:
+ *   grid f32 [d=iz][h=ix][w=iy][channels]   (logical NCDHW (1,C,D,H,W) with C innermost)
+ *   feat f32 [n_voxels][channels], coords i64 [n_voxels][4] = (b, ix, iy, iz)
+ * zero_grid != 0 clears the whole grid first (the reference allocates zeros every call).
+ * status (optional) bit0 = a coordinate fell outside the grid (row skipped).
+ */
+int mvx_scatter_voxels(const float *feat, const int64_t *coords, float *grid, int32_t n_voxels,
+                       int32_t channels, int32_t d, int32_t h, int32_t w, int32_t zero_grid,
+                       int32_t *status, void *stream);
+int mvx_gather_voxels(const float *grid, const int64_t *coords, float *feat, int32_t n_voxels,
+                      int32_t channels, int32_t d, int32_t h, int32_t w, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm with batch statistics, fused with the preceding ReLU.  Replaces the
+ * nn.BatchNorm2d/3d(affine=False, track_running_stats=False) calls of
+ * modules/layers/Blocks.py:10,16,25,29 (forward) and their autograd (backward).
+ * All matrices are row-major [rows][channels] f32 (channels-last), channels % 4 == 0.
+ *
+ *   mvx_row_stats       stats f64 [2][C] = per-channel (sum, sum of squares) over the rows
+ *   mvx_bn_finalize     mean_inv f32 [2][C] = (mean, 1/sqrt(biased var + eps)), count = #rows
+ *   mvx_bn_apply        out = (y - mean) * inv          (out may alias y)
+ *   mvx_bn_relu_backward
+ *        given dyhat = dL/d(BN output) and y = ReLU output (BN input):
+ *        dz = (y > 0) ? inv * (dyhat - mean(dyhat) - yhat * mean(dyhat * yhat)) : 0
+ *        dbias (optional) f32 [C] = column sums of dz;  scratch f64 [3][C];  dz may alias dyhat.
+ */
+int mvx_row_stats(const float *y, double *stats, int64_t rows, int32_t channels, void *stream);
+int mvx_bn_finalize(const double *stats, double count, double eps, float *mean_inv, int32_t channels,
+                    void *stream);
+int mvx_bn_apply(const float *y, const float *mean_inv, float *out, int64_t rows, int32_t channels,
+                 void *stream);
+int mvx_bn_relu_backward(const float *dyhat, const float *y, const float *mean_inv, double count,
+                         float *dz, float *dbias, double *scratch, int64_t rows, int32_t channels,
+                         void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense 3x3x3 convolution on the matrix cores (fp32 MFMA), one frame, channels-last
+ * activations [D][H][W][C].  Replaces the nn.Conv3d forward/backward that CML obtains from
+ * ATen/cuDNN (modules/voxelnet/Pipe.py:36-43, modules/layers/Blocks.py:24,28): kernel 3,
+ * stride (stride_d,1,1), padding (pad_d,1,1); cin % 32 == 0, cout % 64 == 0.
+ *
+ *   mvx_conv3d_pack_weights  torch layout W[cout][cin][3][3][3] -> kernel layout
+ *                            (for_dgrad = 0: forward operand, 1: transposed/flipped operand)
+ *   mvx_conv3d_forward       out = [ReLU](conv(in) + bias); stats (optional) f64 [2][cout] =
+ *                            per-channel (sum, sum of squares) of `out` for the BatchNorm that
+ *                            follows (Blocks.py:28-29)
+ *   mvx_conv3d_dgrad         dx [din][h][w][cin] from dz [dout][h][w][cout]
+ *   mvx_conv3d_wgrad         dw in torch layout [cout][cin][3][3][3]; cout == 64
+ */
+size_t mvx_conv3d_packed_weight_bytes(int32_t cout, int32_t cin);
+int mvx_conv3d_pack_weights(const float *w, float *wpk, int32_t cout, int32_t cin, int32_t for_dgrad,
+                            void *stream);
+int mvx_conv3d_forward(const float *in, const float *wpk, const float *bias, float *out, double *stats,
+                       int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                       int32_t stride_d, int32_t pad_d, int32_t relu, void *stream);
+int mvx_conv3d_dgrad(const float *dz, const float *wpk_dgrad, float *dx, int32_t din, int32_t dout,
+                     int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
+                     void *stream);
+size_t mvx_conv3d_wgrad_workspace_bytes(int32_t h, int32_t w, int32_t cin, int32_t cout);
+int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
+                     int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

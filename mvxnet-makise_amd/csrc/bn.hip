@@ -1,0 +1,216 @@
+// BatchNorm with batch statistics (no affine, biased variance) on channels-last rows, forward
+// and backward, fused with the ReLU that precedes it in every block of the reference
+// (modules/layers/Blocks.py:14-16 and :28-29: Linear/Conv -> ReLU -> BN).
+//
+// All kernels see a row-major [rows][C] f32 matrix (C % 4 == 0).  Reductions keep f32
+// partials per thread, f64 across the block and f64 atomics across blocks, so the batch
+// statistics do not depend on the launch geometry beyond f64 rounding.
+#include "common.h"
+
+namespace {
+
+// stats[0][C] = sum, stats[1][C] = sum of squares  ->  mi[0][C] = mean, mi[1][C] = 1/sqrt(var+eps)
+__global__ void bn_finalize(const double *__restrict__ stats, double count, double eps, float *__restrict__ mi, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = stats[c] / count;
+    double var = stats[C + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mi[c] = (float)mean;
+    mi[C + c] = (float)(1.0 / sqrt(var + eps));
+}
+
+__global__ void bn_apply(const float *__restrict__ y, const float *__restrict__ mi, float *__restrict__ out,
+                         size_t n4, int C) {
+    const int c4 = C >> 2;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % c4) * 4;
+        const float4 v = ((const float4 *)y)[e];
+        const float4 m = *(const float4 *)(mi + c), s = *(const float4 *)(mi + C + c);
+        float4 o;
+        o.x = (v.x - m.x) * s.x; o.y = (v.y - m.y) * s.y; o.z = (v.z - m.z) * s.z; o.w = (v.w - m.w) * s.w;
+        ((float4 *)out)[e] = o;
+    }
+}
+
+// per-channel sum / sum of squares of a [rows][C] matrix (used when the producer did not
+// already reduce them in its epilogue)
+__global__ __launch_bounds__(256) void row_stats(const float *__restrict__ y, double *__restrict__ stats, size_t rows, int C) {
+    __shared__ double red[2][256][4];
+    const int c4 = C >> 2;
+    const int rpi = max(1, 256 / c4);                 // rows per block iteration
+    const int ct = threadIdx.x % c4, rt = threadIdx.x / c4;
+    for (int cb = 0; cb < c4; cb += 256) {             // C > 1024 -> several column blocks
+        const int col = cb + ct;
+        float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+        if (rt < rpi && col < c4) {
+            for (size_t r = blockIdx.x * (size_t)rpi + rt; r < rows; r += (size_t)gridDim.x * rpi) {
+                const float4 v = *(const float4 *)(y + r * C + col * 4);
+                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+            }
+        }
+        red[0][threadIdx.x][0] = s1.x; red[0][threadIdx.x][1] = s1.y; red[0][threadIdx.x][2] = s1.z; red[0][threadIdx.x][3] = s1.w;
+        red[1][threadIdx.x][0] = s2.x; red[1][threadIdx.x][1] = s2.y; red[1][threadIdx.x][2] = s2.z; red[1][threadIdx.x][3] = s2.w;
+        __syncthreads();
+        if (rt == 0 && col < c4) {
+            for (int k = 0; k < 2; ++k)
+                for (int j = 0; j < 4; ++j) {
+                    double t = 0.0;
+                    for (int r = 0; r < rpi; ++r) t += red[k][r * c4 + ct][j];
+                    atomicAdd(stats + (size_t)k * C + col * 4 + j, t);
+                }
+        }
+        __syncthreads();
+    }
+}
+
+// backward, pass 1: sums[0][c] = sum dyh, sums[1][c] = sum dyh * yhat   (yhat = (y - mean) * inv)
+__global__ __launch_bounds__(256) void bn_bwd_reduce(const float *__restrict__ dyh, const float *__restrict__ y,
+                                                     const float *__restrict__ mi, double *__restrict__ sums,
+                                                     size_t rows, int C) {
+    __shared__ double red[2][256][4];
+    const int c4 = C >> 2;
+    const int rpi = max(1, 256 / c4);
+    const int ct = threadIdx.x % c4, rt = threadIdx.x / c4;
+    for (int cb = 0; cb < c4; cb += 256) {
+        const int col = cb + ct;
+        float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+        if (rt < rpi && col < c4) {
+            const float4 m = *(const float4 *)(mi + col * 4), iv = *(const float4 *)(mi + C + col * 4);
+            for (size_t r = blockIdx.x * (size_t)rpi + rt; r < rows; r += (size_t)gridDim.x * rpi) {
+                const float4 g = *(const float4 *)(dyh + r * C + col * 4);
+                const float4 v = *(const float4 *)(y + r * C + col * 4);
+                s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+                s2.x += g.x * ((v.x - m.x) * iv.x); s2.y += g.y * ((v.y - m.y) * iv.y);
+                s2.z += g.z * ((v.z - m.z) * iv.z); s2.w += g.w * ((v.w - m.w) * iv.w);
+            }
+        }
+        red[0][threadIdx.x][0] = s1.x; red[0][threadIdx.x][1] = s1.y; red[0][threadIdx.x][2] = s1.z; red[0][threadIdx.x][3] = s1.w;
+        red[1][threadIdx.x][0] = s2.x; red[1][threadIdx.x][1] = s2.y; red[1][threadIdx.x][2] = s2.z; red[1][threadIdx.x][3] = s2.w;
+        __syncthreads();
+        if (rt == 0 && col < c4) {
+            for (int k = 0; k < 2; ++k)
+                for (int j = 0; j < 4; ++j) {
+                    double t = 0.0;
+                    for (int r = 0; r < rpi; ++r) t += red[k][r * c4 + ct][j];
+                    atomicAdd(sums + (size_t)k * C + col * 4 + j, t);
+                }
+        }
+        __syncthreads();
+    }
+}
+
+// backward, pass 2: dz = (y > 0) ? inv * (dyh - s1/N - yhat * s2/N) : 0 ; dbias[c] += sum dz
+__global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dyh, const float *__restrict__ y,
+                                                    const float *__restrict__ mi, const double *__restrict__ sums,
+                                                    double count, float *__restrict__ dz, double *__restrict__ dbias,
+                                                    size_t rows, int C) {
+    __shared__ double red[256][4];
+    const int c4 = C >> 2;
+    const int rpi = max(1, 256 / c4);
+    const int ct = threadIdx.x % c4, rt = threadIdx.x / c4;
+    for (int cb = 0; cb < c4; cb += 256) {
+        const int col = cb + ct;
+        float4 sb = make_float4(0, 0, 0, 0);
+        if (rt < rpi && col < c4) {
+            const float4 m = *(const float4 *)(mi + col * 4), iv = *(const float4 *)(mi + C + col * 4);
+            float a[4], b[4];
+            for (int j = 0; j < 4; ++j) {
+                a[j] = (float)(sums[col * 4 + j] / count);
+                b[j] = (float)(sums[C + col * 4 + j] / count);
+            }
+            for (size_t r = blockIdx.x * (size_t)rpi + rt; r < rows; r += (size_t)gridDim.x * rpi) {
+                const float4 g = *(const float4 *)(dyh + r * C + col * 4);
+                const float4 v = *(const float4 *)(y + r * C + col * 4);
+                float4 o;
+                o.x = v.x > 0.f ? iv.x * (g.x - a[0] - ((v.x - m.x) * iv.x) * b[0]) : 0.f;
+                o.y = v.y > 0.f ? iv.y * (g.y - a[1] - ((v.y - m.y) * iv.y) * b[1]) : 0.f;
+                o.z = v.z > 0.f ? iv.z * (g.z - a[2] - ((v.z - m.z) * iv.z) * b[2]) : 0.f;
+                o.w = v.w > 0.f ? iv.w * (g.w - a[3] - ((v.w - m.w) * iv.w) * b[3]) : 0.f;
+                *(float4 *)(dz + r * C + col * 4) = o;
+                sb.x += o.x; sb.y += o.y; sb.z += o.z; sb.w += o.w;
+            }
+        }
+        if (dbias) {
+            red[threadIdx.x][0] = sb.x; red[threadIdx.x][1] = sb.y; red[threadIdx.x][2] = sb.z; red[threadIdx.x][3] = sb.w;
+            __syncthreads();
+            if (rt == 0 && col < c4) {
+                for (int j = 0; j < 4; ++j) {
+                    double t = 0.0;
+                    for (int r = 0; r < rpi; ++r) t += red[r * c4 + ct][j];
+                    atomicAdd(dbias + col * 4 + j, t);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void f64_to_f32(const double *__restrict__ a, float *__restrict__ b, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) b[i] = (float)a[i];
+}
+
+inline unsigned row_grid(size_t rows, int C) {
+    const int rpi = (256 / (C / 4)) > 1 ? 256 / (C / 4) : 1;
+    size_t b = (rows + rpi - 1) / rpi;
+    return (unsigned)(b > 1024 ? 1024 : (b ? b : 1));
+}
+
+}  // namespace
+
+extern "C" int mvx_bn_finalize(const double *stats, double count, double eps, float *mean_inv, int32_t channels,
+                               void *stream) {
+    MVX_CHECK_ARG(stats && mean_inv && channels > 0 && count > 0);
+    hipLaunchKernelGGL(bn_finalize, dim3(mvx_cdiv(channels, 128)), dim3(128), 0, (hipStream_t)stream, stats, count, eps,
+                       mean_inv, channels);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+extern "C" int mvx_bn_apply(const float *y, const float *mean_inv, float *out, int64_t rows, int32_t channels,
+                            void *stream) {
+    MVX_CHECK_ARG(y && mean_inv && out && rows >= 0 && channels > 0 && channels % 4 == 0);
+    if (rows == 0) return MVX_OK;
+    const size_t n4 = (size_t)rows * channels / 4;
+    const unsigned grid = (unsigned)(mvx_cdiv(n4, 256) > 4096 ? 4096 : mvx_cdiv(n4, 256));
+    hipLaunchKernelGGL(bn_apply, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, mean_inv, out, n4, channels);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+extern "C" int mvx_row_stats(const float *y, double *stats, int64_t rows, int32_t channels, void *stream) {
+    MVX_CHECK_ARG(y && stats && rows >= 0 && channels > 0 && channels % 4 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * channels, st);
+    if (e != hipSuccess) return (int)e;
+    if (rows == 0) return MVX_OK;
+    hipLaunchKernelGGL(row_stats, dim3(row_grid(rows, channels)), dim3(256), 0, st, y, stats, (size_t)rows, channels);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+extern "C" int mvx_bn_relu_backward(const float *dyhat, const float *y, const float *mean_inv, double count,
+                                    float *dz, float *dbias, double *scratch, int64_t rows, int32_t channels,
+                                    void *stream) {
+    MVX_CHECK_ARG(dyhat && y && mean_inv && dz && scratch && rows >= 0 && channels > 0 && channels % 4 == 0);
+    MVX_CHECK_ARG(count > 0);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * 3 * channels, st);
+    if (e != hipSuccess) return (int)e;
+    if (rows > 0) {
+        const unsigned grid = row_grid(rows, channels);
+        hipLaunchKernelGGL(bn_bwd_reduce, dim3(grid), dim3(256), 0, st, dyhat, y, mean_inv, scratch, (size_t)rows, channels);
+        MVX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(bn_bwd_apply, dim3(grid), dim3(256), 0, st, dyhat, y, mean_inv, (const double *)scratch, count,
+                           dz, dbias ? scratch + 2 * channels : (double *)nullptr, (size_t)rows, channels);
+        MVX_LAUNCH_CHECK();
+    }
+    if (dbias) {
+        hipLaunchKernelGGL(f64_to_f32, dim3(mvx_cdiv(channels, 128)), dim3(128), 0, st,
+                           (const double *)(scratch + 2 * channels), dbias, channels);
+        MVX_LAUNCH_CHECK();
+    }
+    return MVX_OK;
+}

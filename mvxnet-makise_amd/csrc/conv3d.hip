@@ -1,0 +1,384 @@
+// Dense 3-D convolution (3x3x3, stride/pad in depth only) as an implicit GEMM on the CDNA4
+// matrix cores, channels-last.  Stands for the three cuDNN Conv3d calls of the reference's
+// CML (modules/voxelnet/Pipe.py:31-43, modules/layers/Blocks.py:20-29) and their autograd
+// (dgrad / wgrad).
+//
+// Layout: activations [D][H][W][C] f32 (one frame), C contiguous -> one filter tap of one
+// site is a contiguous run of C floats.  fp32 parity mode uses v_mfma_f32_32x32x2_f32
+// (exact f32 fma chain, 64 FLOP/clk/SIMD).
+//
+// Gather kernel (forward and dgrad):  out[d][y][x][n] = sum_{kd,a,b,c} in[src(d,kd)][y+a-1][x+b-1][c]
+//                                                       * wpk[kd][a][b][c][n]
+//   - one workgroup (4 waves) owns an 8x16 patch of output sites of one depth plane and a
+//     block of 64 output channels; wave w owns rows 2w,2w+1 of the patch (32 sites) x 64 n;
+//   - K loop = (kd) x (32-channel chunk) x (9 in-plane taps): the 10x18-site halo of the
+//     patch is staged in LDS once per (kd, chunk) and all 9 taps read it in place; the
+//     64x32 weight tile of each tap is prefetched into registers under the previous tap's MFMAs;
+//   - LDS rows are padded to 36 floats so the ds_read_b128 operand reads (4 consecutive k per
+//     lane, k order permuted identically for A and B) spread over all 64 banks;
+//   - epilogue: + bias, ReLU, per-channel sum / sum-of-squares for the following BatchNorm
+//     (block partials -> f64 atomics), 128-byte row-segment stores.
+//
+// Wgrad kernel:  dW[kd][a][b][c][n] = sum_{d,y,x} in[src(d,kd)][y+a-1][x+b-1][c] * dz[d][y][x][n]
+//   - one workgroup of 9 waves per (strip of patches, kd, 32-channel chunk); wave t owns tap t
+//     and a 32(c) x 64(n) accumulator; the reduction runs over sites; per-strip partial slabs
+//     are summed by a second, deterministic kernel (no float atomics).
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TH = 8, TW = 16;          // output patch of a workgroup
+constexpr int HH = TH + 2, HW = TW + 2; // halo
+constexpr int BK = 32;                  // channels per K chunk
+constexpr int PITCH = BK + 4;           // LDS row pitch in floats (bank-conflict padding)
+constexpr int BN = 64;                  // output channels per workgroup
+
+struct Geom {
+    int Din, Dout, H, W, Cin, Cout;     // gather view: in has Cin channels, out has Cout
+    int sd, pd;                         // depth stride / padding of the FORWARD conv
+    int mode;                           // 0 forward gather, 1 dgrad gather
+};
+
+// source depth plane of output plane d for depth tap kd; -1 if the tap falls outside
+__device__ __forceinline__ int src_depth(const Geom &g, int d, int kd) {
+    if (g.mode == 0) {
+        const int s = d * g.sd - g.pd + kd;
+        return (s >= 0 && s < g.Din) ? s : -1;
+    }
+    const int t = d + g.pd - kd;
+    if (t < 0 || (t % g.sd) != 0) return -1;
+    const int s = t / g.sd;
+    return s < g.Din ? s : -1;
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing: torch layout W[co][ci][kd][kh][kw] -> wpk[kd][a][b][chunk][n][BK]
+//   forward: n = co, k = ci, (a,b) = (kh,kw)
+//   dgrad  : n = ci, k = co, (a,b) = (2-kh, 2-kw)
+// ------------------------------------------------------------------------------------------
+__global__ void pack_weights(const float *__restrict__ w, float *__restrict__ wpk, int Co, int Ci, int dgrad) {
+    const int K = dgrad ? Co : Ci, N = dgrad ? Ci : Co;
+    const int nch = K / BK;
+    const long long total = 27ll * K * N;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(e % BK);
+        long long r = e / BK;
+        const int n = (int)(r % N); r /= N;
+        const int ch = (int)(r % nch); r /= nch;
+        const int tap = (int)(r % 9);
+        const int kd = (int)(r / 9);
+        const int a = tap / 3, b = tap % 3;
+        const int kk = ch * BK + k;
+        const int co = dgrad ? kk : n, ci = dgrad ? n : kk;
+        const int kh = dgrad ? 2 - a : a, kw = dgrad ? 2 - b : b;
+        wpk[e] = w[((((long long)co * Ci + ci) * 3 + kd) * 3 + kh) * 3 + kw];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// gather convolution (forward / dgrad)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void conv3d_gather(const float *__restrict__ in,
+                                                        const float *__restrict__ wpk,
+                                                        const float *__restrict__ bias,
+                                                        float *__restrict__ out, double *__restrict__ stats,
+                                                        Geom g, int relu) {
+    __shared__ __attribute__((aligned(16))) float s_halo[HH * HW * PITCH];
+    __shared__ __attribute__((aligned(16))) float s_w[BN * PITCH];
+    __shared__ float s_red[4][2 * BN];
+
+    const int tiles_x = (g.W + TW - 1) / TW;
+    const int tx0 = (blockIdx.x % tiles_x) * TW, ty0 = (blockIdx.x / tiles_x) * TH;
+    const int d = blockIdx.y, nb = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int nchunks = g.Cin / BK;
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+    // operand addresses (floats) inside the LDS images for tap (0,0), k-quad 0
+    const int my_ty = 2 * wv + (li >> 4), my_tx = li & 15;
+    const int a_base = (my_ty * HW + my_tx) * PITCH + 4 * lh;
+    const int b_base0 = li * PITCH + 4 * lh;
+    const int b_base1 = (32 + li) * PITCH + 4 * lh;
+
+    float4 wreg[2];
+    auto load_w = [&](int kd, int tap, int cc) {
+        const float *tile = wpk + ((((size_t)kd * 9 + tap) * nchunks + cc) * g.Cout + (size_t)nb * BN) * BK;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) wreg[u] = *(const float4 *)(tile + (size_t)(tid + 256 * u) * 4);
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int c = tid + 256 * u;
+            *(float4 *)(s_w + (c >> 3) * PITCH + (c & 7) * 4) = wreg[u];
+        }
+    };
+
+    for (int kd = 0; kd < 3; ++kd) {
+        const int ds = src_depth(g, d, kd);
+        if (ds < 0) continue;                      // block-uniform
+        for (int cc = 0; cc < nchunks; ++cc) {
+            __syncthreads();                       // previous stage's LDS reads are done
+            // ---- stage the halo of this (depth plane, channel chunk)
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int c = tid + 256 * u;
+                if (c < HH * HW * 8) {
+                    const int r = c >> 3, part = c & 7;
+                    const int gy = ty0 - 1 + r / HW, gx = tx0 - 1 + r % HW;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W)
+                        v = *(const float4 *)(in + (((size_t)ds * g.H + gy) * g.W + gx) * g.Cin + cc * BK + part * 4);
+                    *(float4 *)(s_halo + r * PITCH + part * 4) = v;
+                }
+            }
+            load_w(kd, 0, cc);
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap) __syncthreads();          // everyone finished reading the previous weight tile
+                store_w();
+                __syncthreads();
+                if (tap < 8) load_w(kd, tap + 1, cc);   // prefetch under the MFMAs below
+                const int a_off = a_base + ((tap / 3) * HW + (tap % 3)) * PITCH;
+#pragma unroll
+                for (int q = 0; q < BK / 8; ++q) {
+                    const float4 av = *(const float4 *)(s_halo + a_off + 8 * q);
+                    const float4 b0 = *(const float4 *)(s_w + b_base0 + 8 * q);
+                    const float4 b1 = *(const float4 *)(s_w + b_base1 + 8 * q);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b1.z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b1.w, acc1, 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: bias, ReLU, store, BatchNorm statistics
+    const int n0 = nb * BN + li, n1 = n0 + 32;
+    const float bias0 = bias ? bias[n0] : 0.f, bias1 = bias ? bias[n1] : 0.f;
+    float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;          // A-row of this accumulator register
+        const int gy = ty0 + 2 * wv + (row >> 4), gx = tx0 + (row & 15);
+        float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
+        if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+        if (gy < g.H && gx < g.W) {
+            float *o = out + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout;
+            o[n0] = v0;
+            o[n1] = v1;
+            s1a += v0; s2a += v0 * v0;
+            s1b += v1; s2b += v1 * v1;
+        }
+    }
+    if (stats) {
+        s1a += __shfl_xor(s1a, 32, 64); s2a += __shfl_xor(s2a, 32, 64);
+        s1b += __shfl_xor(s1b, 32, 64); s2b += __shfl_xor(s2b, 32, 64);
+        __syncthreads();
+        if (lh == 0) {
+            s_red[wv][li] = s1a; s_red[wv][32 + li] = s1b;
+            s_red[wv][BN + li] = s2a; s_red[wv][BN + 32 + li] = s2b;
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const double t = (double)s_red[0][tid] + (double)s_red[1][tid] + (double)s_red[2][tid] + (double)s_red[3][tid];
+            const int which = tid / BN, c = tid % BN;
+            atomicAdd(stats + (size_t)which * g.Cout + nb * BN + c, t);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------
+constexpr int WG_THREADS = 9 * 64;
+constexpr int XP = BK;                 // halo pitch (conflict-free for lane-consecutive b32 reads)
+constexpr int ZP = BN;                 // dz pitch
+
+__global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad(const float *__restrict__ in,
+                                                           const float *__restrict__ dz,
+                                                           float *__restrict__ slabs, Geom g,
+                                                           int tiles_per_strip) {
+    __shared__ __attribute__((aligned(16))) float s_x[HH * HW * XP];
+    __shared__ __attribute__((aligned(16))) float s_z[TH * TW * ZP];
+    const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
+    const int ntiles = tiles_x * tiles_y;
+    const int strip = blockIdx.x;
+    const int nchunks = g.Cin / BK;
+    const int kd = blockIdx.y / nchunks, cc = blockIdx.y % nchunks;
+    const int tid = threadIdx.x, lane = tid & 63, tap = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int ta = tap / 3, tb = tap % 3;
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+    const int t_beg = strip * tiles_per_strip;
+    const int t_end = min(ntiles, t_beg + tiles_per_strip);
+    for (int d = 0; d < g.Dout; ++d) {
+        const int ds = d * g.sd - g.pd + kd;
+        if (ds < 0 || ds >= g.Din) continue;
+        for (int t = t_beg; t < t_end; ++t) {
+            const int tx0 = (t % tiles_x) * TW, ty0 = (t / tiles_x) * TH;
+            __syncthreads();
+            for (int c = tid; c < HH * HW * 8; c += WG_THREADS) {
+                const int r = c >> 3, part = c & 7;
+                const int gy = ty0 - 1 + r / HW, gx = tx0 - 1 + r % HW;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W)
+                    v = *(const float4 *)(in + (((size_t)ds * g.H + gy) * g.W + gx) * g.Cin + cc * BK + part * 4);
+                *(float4 *)(s_x + r * XP + part * 4) = v;
+            }
+            for (int c = tid; c < TH * TW * 16; c += WG_THREADS) {
+                const int r = c >> 4, part = c & 15;
+                const int gy = ty0 + (r >> 4), gx = tx0 + (r & 15);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gy < g.H && gx < g.W)
+                    v = *(const float4 *)(dz + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout + part * 4);
+                *(float4 *)(s_z + r * ZP + part * 4) = v;
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int kk = 0; kk < TH * TW / 2; ++kk) {
+                const int s = 2 * kk + lh;
+                const float a = s_x[(((s >> 4) + ta) * HW + (s & 15) + tb) * XP + li];
+                const float b0 = s_z[s * ZP + li], b1 = s_z[s * ZP + 32 + li];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+            }
+        }
+    }
+    // slab[strip][kd][tap][c (Cin)][n (64)]
+    float *o = slabs + ((((size_t)strip * 3 + kd) * 9 + tap) * g.Cin + cc * BK) * BN;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        o[(size_t)row * BN + li] = acc0[r];
+        o[(size_t)row * BN + 32 + li] = acc1[r];
+    }
+}
+
+// dW[co][ci][kd][kh][kw] = sum_strips slab[strip][kd][tap][ci][co]
+__global__ void wgrad_reduce(const float *__restrict__ slabs, float *__restrict__ dw, int nstrips, int Ci) {
+    const size_t per = (size_t)27 * Ci * BN;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < per; e += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nstrips; ++k) s += slabs[(size_t)k * per + e];
+        const int co = (int)(e % BN);
+        size_t r = e / BN;
+        const int ci = (int)(r % Ci); r /= Ci;
+        const int tap = (int)(r % 9);
+        const int kd = (int)(r / 9);
+        dw[((((size_t)co * Ci + ci) * 3 + kd) * 3 + tap / 3) * 3 + tap % 3] = s;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t mvx_conv3d_packed_weight_bytes(int32_t cout, int32_t cin) {
+    return (size_t)27 * cout * cin * sizeof(float);
+}
+
+extern "C" int mvx_conv3d_pack_weights(const float *w, float *wpk, int32_t cout, int32_t cin,
+                                       int32_t for_dgrad, void *stream) {
+    MVX_CHECK_ARG(w && wpk && cout > 0 && cin > 0);
+    MVX_CHECK_ARG((for_dgrad ? cout : cin) % BK == 0);
+    const long long total = 27ll * cout * cin;
+    hipLaunchKernelGGL(pack_weights, dim3(mvx_cdiv(total, 256) > 2048 ? 2048 : mvx_cdiv(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, w, wpk, cout, cin, for_dgrad);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+static int check_geom(int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t sd,
+                      int32_t pd) {
+    if (din <= 0 || dout <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return MVX_EINVAL;
+    if (sd < 1 || sd > 2 || pd < 0 || pd > 1) return MVX_EINVAL;
+    if (cin % BK || cout % BN) return MVX_ESIZE;
+    return MVX_OK;
+}
+
+extern "C" int mvx_conv3d_forward(const float *in, const float *wpk, const float *bias, float *out,
+                                  double *stats, int32_t din, int32_t dout, int32_t h, int32_t w,
+                                  int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
+                                  int32_t relu, void *stream) {
+    MVX_CHECK_ARG(in && wpk && out);
+    int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
+    if (rc) return rc;
+    MVX_CHECK_ARG(dout == (din + 2 * pad_d - 3) / stride_d + 1);
+    hipStream_t st = (hipStream_t)stream;
+    if (stats) {
+        hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * cout, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
+    const dim3 grid(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), dout, cout / BN);
+    hipLaunchKernelGGL(conv3d_gather, grid, dim3(256), 0, st, in, wpk, bias, out, stats, g, relu);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+extern "C" int mvx_conv3d_dgrad(const float *dz, const float *wpk_dgrad, float *dx, int32_t din,
+                                int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                                int32_t stride_d, int32_t pad_d, void *stream) {
+    MVX_CHECK_ARG(dz && wpk_dgrad && dx);
+    // gather view: source = dz (dout planes, cout channels), result = dx (din planes, cin channels)
+    int rc = check_geom(din, dout, h, w, cout, cin, stride_d, pad_d);
+    if (rc) return rc;
+    Geom g{dout, din, h, w, cout, cin, stride_d, pad_d, 1};
+    const dim3 grid(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), din, cin / BN);
+    hipLaunchKernelGGL(conv3d_gather, grid, dim3(256), 0, (hipStream_t)stream, dz, wpk_dgrad, (const float *)nullptr,
+                       dx, (double *)nullptr, g, 0);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+static int wgrad_strips(int h, int w) {
+    const int ntiles = (int)(mvx_cdiv(w, TW) * mvx_cdiv(h, TH));
+    int per = (ntiles + 127) / 128;      // about 128 strips per (kd, chunk)
+    if (per < 1) per = 1;
+    return per;
+}
+
+extern "C" size_t mvx_conv3d_wgrad_workspace_bytes(int32_t h, int32_t w, int32_t cin, int32_t cout) {
+    if (h <= 0 || w <= 0 || cin <= 0 || cout != BN) return 0;
+    const int ntiles = (int)(mvx_cdiv(w, TW) * mvx_cdiv(h, TH));
+    const int per = wgrad_strips(h, w);
+    const int nstrips = (ntiles + per - 1) / per;
+    return (size_t)nstrips * 27 * cin * BN * sizeof(float);
+}
+
+extern "C" int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int32_t din, int32_t dout,
+                                int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d,
+                                int32_t pad_d, void *workspace, size_t workspace_bytes, void *stream) {
+    MVX_CHECK_ARG(in && dz && dw && workspace);
+    int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
+    if (rc) return rc;
+    if (cout != BN) return MVX_ESIZE;
+    const int ntiles = (int)(mvx_cdiv(w, TW) * mvx_cdiv(h, TH));
+    const int per = wgrad_strips(h, w);
+    const int nstrips = (ntiles + per - 1) / per;
+    MVX_CHECK_ARG(workspace_bytes >= (size_t)nstrips * 27 * cin * BN * sizeof(float));
+    Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv3d_wgrad, dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz,
+                       (float *)workspace, g, per);
+    MVX_LAUNCH_CHECK();
+    const size_t per_slab = (size_t)27 * cin * BN;
+    hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)workspace, dw,
+                       nstrips, cin);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}

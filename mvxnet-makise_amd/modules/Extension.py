@@ -31,6 +31,18 @@ PROTOTYPES = {
     'mvx_voxelize_workspace_bytes': (_sz, [_i32, _i32]),
     'mvx_voxelize': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _f64, _f64, _f64, _f64, _f64, _f64,
                             _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    'mvx_scatter_voxels': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
+    'mvx_gather_voxels': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    'mvx_row_stats': (_i32, [_p, _p, _i64, _i32, _p]),
+    'mvx_bn_finalize': (_i32, [_p, _f64, _f64, _p, _i32, _p]),
+    'mvx_bn_apply': (_i32, [_p, _p, _p, _i64, _i32, _p]),
+    'mvx_bn_relu_backward': (_i32, [_p, _p, _p, _f64, _p, _p, _p, _i64, _i32, _p]),
+    'mvx_conv3d_packed_weight_bytes': (_sz, [_i32, _i32]),
+    'mvx_conv3d_pack_weights': (_i32, [_p, _p, _i32, _i32, _i32, _p]),
+    'mvx_conv3d_forward': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    'mvx_conv3d_dgrad': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    'mvx_conv3d_wgrad_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32]),
+    'mvx_conv3d_wgrad': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _sz, _p]),
 }
 
 

@@ -44,3 +44,111 @@ def voxelize(pcd, perm, n_points, lo, size, T, out_channels, cap_voxels=None, ex
                             X.ptr(ws), ws.numel(), X.stream())
     X.check(rc, 'mvx_voxelize')
     return VoxelizeResult(voxels, coords, counts, n_vox, status)
+
+
+# ---------------------------------------------------------------------------------------------
+# dense grid scatter / gather
+# ---------------------------------------------------------------------------------------------
+def scatter_voxels(feat, coords, dhw, grid=None, zero=True):
+    D, H, W = dhw
+    V, C = feat.shape
+    if grid is None:
+        grid = torch.empty((D, H, W, C), dtype=torch.float32, device=feat.device)
+    status = torch.zeros((1,), dtype=torch.int32, device=feat.device)
+    X.check(X.lib.mvx_scatter_voxels(X.ptr(feat), X.ptr(coords), X.ptr(grid), V, C, D, H, W, int(zero),
+                                     X.ptr(status), X.stream()), 'mvx_scatter_voxels')
+    return grid, status
+
+
+def gather_voxels(grid, coords, V):
+    D, H, W, C = grid.shape
+    feat = torch.empty((V, C), dtype=torch.float32, device=grid.device)
+    X.check(X.lib.mvx_gather_voxels(X.ptr(grid), X.ptr(coords), X.ptr(feat), V, C, D, H, W, X.stream()),
+            'mvx_gather_voxels')
+    return feat
+
+
+# ---------------------------------------------------------------------------------------------
+# BatchNorm (batch statistics) + ReLU
+# ---------------------------------------------------------------------------------------------
+def row_stats(y2d):
+    rows, C = y2d.shape
+    stats = torch.empty((2, C), dtype=torch.float64, device=y2d.device)
+    X.check(X.lib.mvx_row_stats(X.ptr(y2d), X.ptr(stats), rows, C, X.stream()), 'mvx_row_stats')
+    return stats
+
+
+def bn_finalize(stats, count, eps):
+    C = stats.shape[1]
+    mi = torch.empty((2, C), dtype=torch.float32, device=stats.device)
+    X.check(X.lib.mvx_bn_finalize(X.ptr(stats), float(count), float(eps), X.ptr(mi), C, X.stream()),
+            'mvx_bn_finalize')
+    return mi
+
+
+def bn_apply(y, mi, out=None):
+    C = mi.shape[1]
+    rows = y.numel() // C
+    if out is None:
+        out = torch.empty_like(y)
+    X.check(X.lib.mvx_bn_apply(X.ptr(y), X.ptr(mi), X.ptr(out), rows, C, X.stream()), 'mvx_bn_apply')
+    return out
+
+
+def bn_relu_backward(dyhat, y, mi, count, want_dbias=True, dz=None):
+    C = mi.shape[1]
+    rows = y.numel() // C
+    if dz is None:
+        dz = torch.empty_like(y)
+    dbias = torch.empty((C,), dtype=torch.float32, device=y.device) if want_dbias else None
+    scratch = torch.empty((3, C), dtype=torch.float64, device=y.device)
+    X.check(X.lib.mvx_bn_relu_backward(X.ptr(dyhat), X.ptr(y), X.ptr(mi), float(count), X.ptr(dz),
+                                       X.ptr(dbias), X.ptr(scratch), rows, C, X.stream()),
+            'mvx_bn_relu_backward')
+    return dz, dbias
+
+
+# ---------------------------------------------------------------------------------------------
+# dense 3x3x3 convolution (channels-last, one frame)
+# ---------------------------------------------------------------------------------------------
+def conv3d_pack(weight, for_dgrad):
+    cout, cin = weight.shape[0], weight.shape[1]
+    assert tuple(weight.shape[2:]) == (3, 3, 3)
+    wpk = torch.empty((27 * cout * cin,), dtype=torch.float32, device=weight.device)
+    X.check(X.lib.mvx_conv3d_pack_weights(X.ptr(weight.contiguous()), X.ptr(wpk), cout, cin, int(for_dgrad),
+                                          X.stream()), 'mvx_conv3d_pack_weights')
+    return wpk
+
+
+def conv_out_depth(din, sd, pd):
+    return (din + 2 * pd - 3) // sd + 1
+
+
+def conv3d_forward(x, wpk, bias, cout, sd, pd, relu=True, want_stats=True):
+    din, H, W, cin = x.shape
+    dout = conv_out_depth(din, sd, pd)
+    out = torch.empty((dout, H, W, cout), dtype=torch.float32, device=x.device)
+    stats = torch.empty((2, cout), dtype=torch.float64, device=x.device) if want_stats else None
+    X.check(X.lib.mvx_conv3d_forward(X.ptr(x), X.ptr(wpk), X.ptr(bias), X.ptr(out), X.ptr(stats),
+                                     din, dout, H, W, cin, cout, sd, pd, int(relu), X.stream()),
+            'mvx_conv3d_forward')
+    return out, stats
+
+
+def conv3d_dgrad(dz, wpk_d, din, cin, sd, pd):
+    dout, H, W, cout = dz.shape
+    dx = torch.empty((din, H, W, cin), dtype=torch.float32, device=dz.device)
+    X.check(X.lib.mvx_conv3d_dgrad(X.ptr(dz), X.ptr(wpk_d), X.ptr(dx), din, dout, H, W, cin, cout, sd, pd,
+                                   X.stream()), 'mvx_conv3d_dgrad')
+    return dx
+
+
+def conv3d_wgrad(x, dz, sd, pd):
+    din, H, W, cin = x.shape
+    dout, _, _, cout = dz.shape
+    dw = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device=x.device)
+    nbytes = X.lib.mvx_conv3d_wgrad_workspace_bytes(H, W, cin, cout)
+    ws = workspace(nbytes, x.device, 'wgrad')
+    X.check(X.lib.mvx_conv3d_wgrad(X.ptr(x), X.ptr(dz), X.ptr(dw), din, dout, H, W, cin, cout, sd, pd,
+                                   X.ptr(ws), ws.numel(), X.stream()), 'mvx_conv3d_wgrad')
+    return dw
