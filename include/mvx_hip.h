@@ -98,6 +98,8 @@ int mvx_gather_voxels(const float *grid, const int64_t *coords, float *feat, int
  *        given dyhat = dL/d(BN output) and y = ReLU output (BN input):
  *        dz = (y > 0) ? inv * (dyhat - mean(dyhat) - yhat * mean(dyhat * yhat)) : 0
  *        dbias (optional) f32 [C] = column sums of dz;  scratch f64 [3][C];  dz may alias dyhat.
+ *        row_w (optional) f32 [rows]: row r stands for row_w[r] identical rows of the dense tensor
+ *        and dyhat[r] is already the SUM of their gradients; `count` is the dense row count.
  */
 int mvx_row_stats(const float *y, double *stats, int64_t rows, int32_t channels, void *stream);
 int mvx_bn_finalize(const double *stats, double count, double eps, float *mean_inv, int32_t channels,
@@ -105,8 +107,8 @@ int mvx_bn_finalize(const double *stats, double count, double eps, float *mean_i
 int mvx_bn_apply(const float *y, const float *mean_inv, float *out, int64_t rows, int32_t channels,
                  void *stream);
 int mvx_bn_relu_backward(const float *dyhat, const float *y, const float *mean_inv, double count,
-                         float *dz, float *dbias, double *scratch, int64_t rows, int32_t channels,
-                         void *stream);
+                         float *dz, float *dbias, double *scratch, const float *row_w, int64_t rows,
+                         int32_t channels, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense 3x3x3 convolution on the matrix cores (fp32 MFMA), one frame, channels-last
@@ -135,6 +137,40 @@ size_t mvx_conv3d_wgrad_workspace_bytes(int32_t h, int32_t w, int32_t cin, int32
 int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
                      int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row-wise fully connected layer on the matrix cores (fp32 MFMA).  Replaces the nn.Linear /
+ * 1x1 nn.Conv2d GEMMs of FCN and CRB2d (modules/layers/Blocks.py:9,14,35,39) and their autograd.
+ *   x f32 [rows][ldx] (k columns used), w f32 [n][ldw] (or [k][ldw] when w_transposed),
+ *   y f32 [rows][ldy] (n columns written) = [ReLU](x w^T + bias)
+ *   stats (optional) f64 [2][n]: per-column (sum, sum of squares) of y weighted by row_w
+ *   row_w (optional) f32 [rows]: multiplicity of each row in the reference's dense tensor
+ * mvx_linear_wgrad: dw f32 [n][k] = dz^T x  (dz f32 [rows][lddz]).
+ */
+int mvx_linear_forward(const float *x, int32_t ldx, const float *w, int32_t ldw, int32_t w_transposed,
+                       const float *bias, float *y, int32_t ldy, double *stats, const float *row_w,
+                       int64_t rows, int32_t k, int32_t n, int32_t relu, void *stream);
+size_t mvx_linear_wgrad_workspace_bytes(int64_t rows, int32_t k, int32_t n);
+int mvx_linear_wgrad(const float *x, int32_t ldx, const float *dz, int32_t lddz, float *dw, int64_t rows,
+                     int32_t k, int32_t n, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * VFE glue on [n_voxels][t][channels] rows.  Replaces modules/voxelnet/Pipe.py:14-18
+ * (BN -> max over t -> repeat -> concat) and modules/voxelnet/VoxelNet.py:30 (max over t),
+ * with their autograd.  The max covers all t rows, padded ones included (no mask).
+ *   mvx_vfe_bn_max_concat        out [V][t][2C] = [BN(y), max_t BN(y)], argmax i32 [V][C]
+ *   mvx_vfe_max_concat_backward  dyhat [V][t][C] from grad_out [V][t][2C]
+ *   mvx_bn_segment_max           out [V][C] = max_t BN(y), argmax i32 [V][C]
+ *   mvx_segment_max_backward     dyhat [V][t][C] from dfeat [V][C]
+ */
+int mvx_vfe_bn_max_concat(const float *y, const float *mean_inv, float *out, int32_t *argmax,
+                          int32_t n_voxels, int32_t t, int32_t channels, void *stream);
+int mvx_vfe_max_concat_backward(const float *grad_out, const int32_t *argmax, float *dyhat,
+                                int32_t n_voxels, int32_t t, int32_t channels, void *stream);
+int mvx_bn_segment_max(const float *y, const float *mean_inv, float *out, int32_t *argmax,
+                       int32_t n_voxels, int32_t t, int32_t channels, void *stream);
+int mvx_segment_max_backward(const float *dfeat, const int32_t *argmax, float *dyhat, int32_t n_voxels,
+                             int32_t t, int32_t channels, void *stream);
 
 #ifdef __cplusplus
 }

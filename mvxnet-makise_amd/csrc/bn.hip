@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const float *__restrict__ d
 __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dyh, const float *__restrict__ y,
                                                     const float *__restrict__ mi, const double *__restrict__ sums,
                                                     double count, float *__restrict__ dz, double *__restrict__ dbias,
-                                                    size_t rows, int C) {
+                                                    const float *__restrict__ row_w, size_t rows, int C) {
     __shared__ double red[256][4];
     const int c4 = C >> 2;
     const int rpi = max(1, 256 / c4);
@@ -123,11 +123,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dy
             for (size_t r = blockIdx.x * (size_t)rpi + rt; r < rows; r += (size_t)gridDim.x * rpi) {
                 const float4 g = *(const float4 *)(dyh + r * C + col * 4);
                 const float4 v = *(const float4 *)(y + r * C + col * 4);
+                const float rw = row_w ? row_w[r] : 1.f;   // a compact row standing for rw dense rows
                 float4 o;
-                o.x = v.x > 0.f ? iv.x * (g.x - a[0] - ((v.x - m.x) * iv.x) * b[0]) : 0.f;
-                o.y = v.y > 0.f ? iv.y * (g.y - a[1] - ((v.y - m.y) * iv.y) * b[1]) : 0.f;
-                o.z = v.z > 0.f ? iv.z * (g.z - a[2] - ((v.z - m.z) * iv.z) * b[2]) : 0.f;
-                o.w = v.w > 0.f ? iv.w * (g.w - a[3] - ((v.w - m.w) * iv.w) * b[3]) : 0.f;
+                o.x = v.x > 0.f ? iv.x * (g.x - rw * (a[0] + ((v.x - m.x) * iv.x) * b[0])) : 0.f;
+                o.y = v.y > 0.f ? iv.y * (g.y - rw * (a[1] + ((v.y - m.y) * iv.y) * b[1])) : 0.f;
+                o.z = v.z > 0.f ? iv.z * (g.z - rw * (a[2] + ((v.z - m.z) * iv.z) * b[2])) : 0.f;
+                o.w = v.w > 0.f ? iv.w * (g.w - rw * (a[3] + ((v.w - m.w) * iv.w) * b[3])) : 0.f;
                 *(float4 *)(dz + r * C + col * 4) = o;
                 sb.x += o.x; sb.y += o.y; sb.z += o.z; sb.w += o.w;
             }
@@ -192,8 +193,8 @@ extern "C" int mvx_row_stats(const float *y, double *stats, int64_t rows, int32_
 }
 
 extern "C" int mvx_bn_relu_backward(const float *dyhat, const float *y, const float *mean_inv, double count,
-                                    float *dz, float *dbias, double *scratch, int64_t rows, int32_t channels,
-                                    void *stream) {
+                                    float *dz, float *dbias, double *scratch, const float *row_w, int64_t rows,
+                                    int32_t channels, void *stream) {
     MVX_CHECK_ARG(dyhat && y && mean_inv && dz && scratch && rows >= 0 && channels > 0 && channels % 4 == 0);
     MVX_CHECK_ARG(count > 0);
     hipStream_t st = (hipStream_t)stream;
@@ -204,7 +205,7 @@ extern "C" int mvx_bn_relu_backward(const float *dyhat, const float *y, const fl
         hipLaunchKernelGGL(bn_bwd_reduce, dim3(grid), dim3(256), 0, st, dyhat, y, mean_inv, scratch, (size_t)rows, channels);
         MVX_LAUNCH_CHECK();
         hipLaunchKernelGGL(bn_bwd_apply, dim3(grid), dim3(256), 0, st, dyhat, y, mean_inv, (const double *)scratch, count,
-                           dz, dbias ? scratch + 2 * channels : (double *)nullptr, (size_t)rows, channels);
+                           dz, dbias ? scratch + 2 * channels : (double *)nullptr, row_w, (size_t)rows, channels);
         MVX_LAUNCH_CHECK();
     }
     if (dbias) {

@@ -36,7 +36,14 @@ PROTOTYPES = {
     'mvx_row_stats': (_i32, [_p, _p, _i64, _i32, _p]),
     'mvx_bn_finalize': (_i32, [_p, _f64, _f64, _p, _i32, _p]),
     'mvx_bn_apply': (_i32, [_p, _p, _p, _i64, _i32, _p]),
-    'mvx_bn_relu_backward': (_i32, [_p, _p, _p, _f64, _p, _p, _p, _i64, _i32, _p]),
+    'mvx_bn_relu_backward': (_i32, [_p, _p, _p, _f64, _p, _p, _p, _p, _i64, _i32, _p]),
+    'mvx_linear_forward': (_i32, [_p, _i32, _p, _i32, _i32, _p, _p, _i32, _p, _p, _i64, _i32, _i32, _i32, _p]),
+    'mvx_linear_wgrad_workspace_bytes': (_sz, [_i64, _i32, _i32]),
+    'mvx_linear_wgrad': (_i32, [_p, _i32, _p, _i32, _p, _i64, _i32, _i32, _p, _sz, _p]),
+    'mvx_vfe_bn_max_concat': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p]),
+    'mvx_vfe_max_concat_backward': (_i32, [_p, _p, _p, _i32, _i32, _i32, _p]),
+    'mvx_bn_segment_max': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p]),
+    'mvx_segment_max_backward': (_i32, [_p, _p, _p, _i32, _i32, _i32, _p]),
     'mvx_conv3d_packed_weight_bytes': (_sz, [_i32, _i32]),
     'mvx_conv3d_pack_weights': (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     'mvx_conv3d_forward': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),

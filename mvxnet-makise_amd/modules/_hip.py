@@ -95,7 +95,7 @@ def bn_apply(y, mi, out=None):
     return out
 
 
-def bn_relu_backward(dyhat, y, mi, count, want_dbias=True, dz=None):
+def bn_relu_backward(dyhat, y, mi, count, want_dbias=True, dz=None, row_w=None):
     C = mi.shape[1]
     rows = y.numel() // C
     if dz is None:
@@ -103,7 +103,7 @@ def bn_relu_backward(dyhat, y, mi, count, want_dbias=True, dz=None):
     dbias = torch.empty((C,), dtype=torch.float32, device=y.device) if want_dbias else None
     scratch = torch.empty((3, C), dtype=torch.float64, device=y.device)
     X.check(X.lib.mvx_bn_relu_backward(X.ptr(dyhat), X.ptr(y), X.ptr(mi), float(count), X.ptr(dz),
-                                       X.ptr(dbias), X.ptr(scratch), rows, C, X.stream()),
+                                       X.ptr(dbias), X.ptr(scratch), X.ptr(row_w), rows, C, X.stream()),
             'mvx_bn_relu_backward')
     return dz, dbias
 
@@ -152,3 +152,82 @@ def conv3d_wgrad(x, dz, sd, pd):
     X.check(X.lib.mvx_conv3d_wgrad(X.ptr(x), X.ptr(dz), X.ptr(dw), din, dout, H, W, cin, cout, sd, pd,
                                    X.ptr(ws), ws.numel(), X.stream()), 'mvx_conv3d_wgrad')
     return dw
+
+
+# ---------------------------------------------------------------------------------------------
+# row-wise linear layers (2-D views with explicit leading dimensions)
+# ---------------------------------------------------------------------------------------------
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1, 'need a row-major 2-D view'
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def _vptr(t):
+    """Pointer of a (possibly column-sliced) row-major view."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise X.MvxHipError('libmvx_hip needs device tensors (no CPU fallback)')
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def linear_forward(x, w, bias, relu=True, want_stats=True, w_transposed=False, row_w=None, out=None):
+    """x (R,K) view, w (N,K) [or (K,N) if w_transposed] -> y (R,N), stats f64 (2,N) or None."""
+    R, K = x.shape
+    N = w.shape[1] if w_transposed else w.shape[0]
+    if out is None:
+        out = torch.empty((R, N), dtype=torch.float32, device=x.device)
+    stats = torch.empty((2, N), dtype=torch.float64, device=x.device) if want_stats else None
+    X.check(X.lib.mvx_linear_forward(_vptr(x), _ld(x), _vptr(w), _ld(w), int(w_transposed), X.ptr(bias),
+                                     _vptr(out), _ld(out), X.ptr(stats), X.ptr(row_w), R, K, N, int(relu),
+                                     X.stream()), 'mvx_linear_forward')
+    return out, stats
+
+
+def linear_wgrad(x, dz):
+    R, K = x.shape
+    N = dz.shape[1]
+    dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
+    nbytes = X.lib.mvx_linear_wgrad_workspace_bytes(R, K, N)
+    ws = workspace(nbytes, x.device, 'lwgrad')
+    X.check(X.lib.mvx_linear_wgrad(_vptr(x), _ld(x), _vptr(dz), _ld(dz), X.ptr(dw), R, K, N, X.ptr(ws),
+                                   ws.numel(), X.stream()), 'mvx_linear_wgrad')
+    return dw
+
+
+# ---------------------------------------------------------------------------------------------
+# VFE glue
+# ---------------------------------------------------------------------------------------------
+def vfe_bn_max_concat(y, mi, V, T):
+    C = mi.shape[1]
+    out = torch.empty((V * T, 2 * C), dtype=torch.float32, device=y.device)
+    am = torch.empty((V, C), dtype=torch.int32, device=y.device)
+    X.check(X.lib.mvx_vfe_bn_max_concat(X.ptr(y), X.ptr(mi), X.ptr(out), X.ptr(am), V, T, C, X.stream()),
+            'mvx_vfe_bn_max_concat')
+    return out, am
+
+
+def vfe_max_concat_backward(g, am, V, T):
+    C = am.shape[1]
+    dyh = torch.empty((V * T, C), dtype=torch.float32, device=g.device)
+    X.check(X.lib.mvx_vfe_max_concat_backward(X.ptr(g), X.ptr(am), X.ptr(dyh), V, T, C, X.stream()),
+            'mvx_vfe_max_concat_backward')
+    return dyh
+
+
+def bn_segment_max(y, mi, V, T):
+    C = mi.shape[1]
+    out = torch.empty((V, C), dtype=torch.float32, device=y.device)
+    am = torch.empty((V, C), dtype=torch.int32, device=y.device)
+    X.check(X.lib.mvx_bn_segment_max(X.ptr(y), X.ptr(mi), X.ptr(out), X.ptr(am), V, T, C, X.stream()),
+            'mvx_bn_segment_max')
+    return out, am
+
+
+def segment_max_backward(dfeat, am, V, T):
+    C = am.shape[1]
+    dyh = torch.empty((V * T, C), dtype=torch.float32, device=dfeat.device)
+    X.check(X.lib.mvx_segment_max_backward(X.ptr(dfeat), X.ptr(am), X.ptr(dyh), V, T, C, X.stream()),
+            'mvx_segment_max_backward')
+    return dyh

@@ -1,0 +1,172 @@
+"""Building blocks with the reference's names and sub-module attributes (``fc`` / ``conv`` /
+``deconv`` / ``bn``), computing on hand-written HIP kernels.
+
+Reference: modules/layers/Blocks.py -- every block is  affine -> ReLU -> BatchNorm  with
+batch statistics in train and eval, biased variance, eps = cfg.eps, no affine, no buffers
+(Blocks.py:10,16; config.yml:19-20).  State-dict keys are unchanged (``fc.weight`` ...), so
+reference checkpoints load.
+"""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+import modules.config as cfg
+from modules import _hip
+
+
+def _as_rows(x):
+    """(..., C) -> contiguous 2-D (R, C) view."""
+    c = x.shape[-1]
+    return x.reshape(-1, c) if x.is_contiguous() else x.contiguous().reshape(-1, c)
+
+
+class FCNFunction(torch.autograd.Function):
+    """rows -> BN(ReLU(rows W^T + b)).  ``row_w``: optional multiplicity of each row (a compact
+    row standing for several identical rows of the reference's dense tensor)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps, row_w, count):
+        w2 = w.reshape(w.shape[0], -1)
+        y, stats = _hip.linear_forward(x, w2, b, relu=True, want_stats=True, row_w=row_w)
+        mi = _hip.bn_finalize(stats, count, eps)
+        out = _hip.bn_apply(y, mi)
+        ctx.save_for_backward(x, w, y, mi, row_w)
+        ctx.count = count
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, y, mi, row_w = ctx.saved_tensors
+        w2 = w.reshape(w.shape[0], -1)
+        dz, db = _hip.bn_relu_backward(g.contiguous(), y, mi, ctx.count, True, row_w=row_w)
+        dw = _hip.linear_wgrad(x, dz).reshape(w.shape)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx, _ = _hip.linear_forward(dz, w2, None, relu=False, want_stats=False, w_transposed=True)
+        return dx, dw, db, None, None, None
+
+
+def fcn_rows(x2d, weight, bias, row_w=None, count=None):
+    count = x2d.shape[0] if count is None else count
+    return FCNFunction.apply(x2d, weight, bias, cfg.eps, row_w, float(count))
+
+
+class FCN(nn.Module):
+    """Linear -> ReLU -> BN over (batch, h, w) per channel (reference Blocks.py:5-18)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.fc = nn.Linear(cin, cout)
+        self.bn = nn.BatchNorm2d(cout, eps=cfg.eps, affine=cfg.bnaffine, track_running_stats=cfg.bntrack)
+
+    def forward(self, x):
+        # input (batch, h, w, c) -> output (batch, h, w, cout)
+        out = fcn_rows(_as_rows(x), self.fc.weight, self.fc.bias)
+        return out.reshape(x.shape[:-1] + (out.shape[-1],))
+
+
+def _pack_cached(module, weight, for_dgrad):
+    """Kernel-layout copy of a conv weight, refreshed whenever the parameter changes."""
+    key = '_wpk_d' if for_dgrad else '_wpk_f'
+    tag = (weight._version, weight.data_ptr())
+    cached = getattr(module, key, None)
+    if cached is None or cached[0] != tag:
+        cached = (tag, _hip.conv3d_pack(weight.detach(), for_dgrad))
+        object.__setattr__(module, key, cached)
+    return cached[1]
+
+
+class CRB3dFunction(torch.autograd.Function):
+    """channels-last (D,H,W,Cin) -> BN(ReLU(conv3d)) (Dout,H,W,Cout), one frame."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, sd, pd, eps):
+        cout = w.shape[0]
+        wpk = _hip.conv3d_pack(w, False)
+        y, stats = _hip.conv3d_forward(x, wpk, b, cout, sd, pd, relu=True, want_stats=True)
+        count = y.numel() // cout
+        mi = _hip.bn_finalize(stats, count, eps)
+        out = _hip.bn_apply(y, mi)
+        ctx.save_for_backward(x, w, y, mi)
+        ctx.geom = (sd, pd, count)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, y, mi = ctx.saved_tensors
+        sd, pd, count = ctx.geom
+        dz, db = _hip.bn_relu_backward(g.contiguous(), y, mi, count, True)
+        dw = _hip.conv3d_wgrad(x, dz, sd, pd)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _hip.conv3d_dgrad(dz, _hip.conv3d_pack(w, True), x.shape[0], x.shape[3], sd, pd)
+        return dx, dw, db, None, None, None
+
+
+def _triple(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v, v)
+
+
+class CRB3d(nn.Module):
+    """Conv3d -> ReLU -> BN3d (reference Blocks.py:20-29) on the MFMA implicit-GEMM kernel.
+
+    Supports what CML uses: kernel 3, stride (s,1,1), padding (p,1,1), batch 1.  The input may be
+    logical NCDHW in any memory format; internally the data is channels-last and the result is
+    returned as a logical NCDHW view of channels-last storage (no copy)."""
+
+    def __init__(self, cin, cout, k, s, p):
+        super().__init__()
+        self.conv = nn.Conv3d(cin, cout, k, s, p)
+        self.bn = nn.BatchNorm3d(cout, eps=cfg.eps, affine=cfg.bnaffine, track_running_stats=cfg.bntrack)
+        k3, s3, p3 = _triple(k), _triple(s), _triple(p)
+        if k3 != (3, 3, 3) or s3[1:] != (1, 1) or p3[1:] != (1, 1) or s3[0] not in (1, 2) or p3[0] not in (0, 1):
+            raise NotImplementedError('CRB3d HIP kernel: kernel 3, stride (s,1,1), padding (p,1,1) only')
+        self._sd, self._pd = s3[0], p3[0]
+
+    def forward(self, x):
+        if x.shape[0] != 1:
+            raise NotImplementedError('batch size 1 only (reference VoxelNet.py:19)')
+        xc = x[0].permute(1, 2, 3, 0).contiguous()          # no-op when already channels-last
+        out = CRB3dFunction.apply(xc, self.conv.weight, self.conv.bias, self._sd, self._pd, cfg.eps)
+        return out.permute(3, 0, 1, 2)[None]
+
+
+class _TorchBN2d(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.c = c
+
+    def forward(self, x):
+        return F.batch_norm(x, None, None, None, None, True, 0.0, cfg.eps)
+
+
+class CRB2d(nn.Module):
+    """Conv2d -> ReLU -> BN2d (reference Blocks.py:31-40).  1x1 kernels (the fusion MLP,
+    imhead/Pipe.py:89,91) run on the HIP row-GEMM; 3x3 kernels belong to the RPN, which is the
+    next scope row and stays on PyTorch-ROCm/MIOpen for now."""
+
+    def __init__(self, cin, cout, k, s, p):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, s, p)
+        self.bn = nn.BatchNorm2d(cout, eps=cfg.eps, affine=cfg.bnaffine, track_running_stats=cfg.bntrack)
+        self._pointwise = (k == 1 and s == 1 and p == 0)
+
+    def forward(self, x):
+        if self._pointwise and x.is_cuda:
+            # (b, c, h, w) -> rows (b*h*w, c); a permuted channels-last input costs no copy
+            rows = x.permute(0, 2, 3, 1)
+            out = fcn_rows(_as_rows(rows), self.conv.weight, self.conv.bias)
+            return out.reshape(rows.shape[:-1] + (out.shape[-1],)).permute(0, 3, 1, 2)
+        return F.batch_norm(F.relu(self.conv(x)), None, None, None, None, True, 0.0, cfg.eps)
+
+
+class DeCRB2d(nn.Module):
+    """ConvTranspose2d -> ReLU -> BN2d (reference Blocks.py:42-51); RPN only (next scope row)."""
+
+    def __init__(self, cin, cout, k, s, p):
+        super().__init__()
+        self.deconv = nn.ConvTranspose2d(cin, cout, k, s, p)
+        self.bn = nn.BatchNorm2d(cout, eps=cfg.eps, affine=cfg.bnaffine, track_running_stats=cfg.bntrack)
+
+    def forward(self, x):
+        return F.batch_norm(F.relu(self.deconv(x)), None, None, None, None, True, 0.0, cfg.eps)

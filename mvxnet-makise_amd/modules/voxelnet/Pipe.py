@@ -1,0 +1,123 @@
+"""VFE / SVFE / CML / RPN with the reference's class names and attributes
+(modules/voxelnet/Pipe.py), on HIP kernels.
+
+A VFE layer is ONE autograd node: row GEMM (+ReLU, + BatchNorm sums in the epilogue) ->
+fused normalise + per-voxel max + concat.  Its backward is the mirrored chain.  The max runs
+over all T rows, padded rows included, exactly like Pipe.py:14-16."""
+import torch
+from torch import nn
+
+import modules.config as cfg
+from modules import _hip
+from modules.layers import FCN, CRB2d, CRB3d, DeCRB2d
+from modules.layers.Blocks import _as_rows
+
+
+class VFEFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, V, T, eps):
+        y, stats = _hip.linear_forward(x, w, b, relu=True, want_stats=True)
+        mi = _hip.bn_finalize(stats, V * T, eps)
+        out, am = _hip.vfe_bn_max_concat(y, mi, V, T)
+        ctx.save_for_backward(x, w, y, mi, am)
+        ctx.vt = (V, T)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, y, mi, am = ctx.saved_tensors
+        V, T = ctx.vt
+        dyh = _hip.vfe_max_concat_backward(g.contiguous(), am, V, T)
+        dz, db = _hip.bn_relu_backward(dyh, y, mi, V * T, True, dz=dyh)
+        dw = _hip.linear_wgrad(x, dz)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx, _ = _hip.linear_forward(dz, w, None, relu=False, want_stats=False, w_transposed=True)
+        return dx, dw, db, None, None, None
+
+
+class FCNMaxFunction(torch.autograd.Function):
+    """rows (V*T, K) -> max_t BN(ReLU(fc)) (V, N): VoxelNet.py:28-33 as one node."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, V, T, eps):
+        y, stats = _hip.linear_forward(x, w, b, relu=True, want_stats=True)
+        mi = _hip.bn_finalize(stats, V * T, eps)
+        out, am = _hip.bn_segment_max(y, mi, V, T)
+        ctx.save_for_backward(x, w, y, mi, am)
+        ctx.vt = (V, T)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, y, mi, am = ctx.saved_tensors
+        V, T = ctx.vt
+        dyh = _hip.segment_max_backward(g.contiguous(), am, V, T)
+        dz, db = _hip.bn_relu_backward(dyh, y, mi, V * T, True, dz=dyh)
+        dw = _hip.linear_wgrad(x, dz)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx, _ = _hip.linear_forward(dz, w, None, relu=False, want_stats=False, w_transposed=True)
+        return dx, dw, db, None, None, None
+
+
+class VFE(nn.Module):
+    """(batch=1, N, T, cin) -> (1, N, T, 2*cout) (reference Pipe.py:5-18)."""
+
+    def __init__(self, cin, cout, sampleNum):
+        super().__init__()
+        self.fcn = FCN(cin, cout)
+        self.sampleNum = sampleNum
+
+    def forward(self, x):
+        b, n, t, _ = x.shape
+        out = VFEFunction.apply(_as_rows(x), self.fcn.fc.weight, self.fcn.fc.bias, b * n, t, cfg.eps)
+        return out.reshape(b, n, t, out.shape[-1])
+
+
+class SVFE(nn.Module):
+    """VFE(23->16) then VFE(32->64): (1, N, T, 23) -> (1, N, T, 128) (reference Pipe.py:20-29)."""
+
+    def __init__(self, sampleNum=35):
+        super().__init__()
+        self.vfe1 = VFE(7 + 16, 16, sampleNum)
+        self.vfe2 = VFE(32, 64, sampleNum)
+
+    def forward(self, x):
+        return self.vfe2(self.vfe1(x))
+
+
+class CML(nn.Module):
+    """Three Conv3d-ReLU-BN blocks (reference Pipe.py:31-43)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = CRB3d(128, 64, 3, (2, 1, 1), (1, 1, 1))
+        self.conv2 = CRB3d(64, 64, 3, 1, (0, 1, 1))
+        self.conv3 = CRB3d(64, 64, 3, (2, 1, 1), 1)
+
+    def forward(self, x):
+        return self.conv3(self.conv2(self.conv1(x)))
+
+
+class RPN(nn.Module):
+    """Region proposal network (reference Pipe.py:45-75).  Next scope row: runs on
+    PyTorch-ROCm/MIOpen through CRB2d/DeCRB2d, same topology and state-dict keys."""
+
+    def __init__(self):
+        super().__init__()
+        self.blk1 = nn.Sequential(CRB2d(128, 128, 3, 2, 1), *[CRB2d(128, 128, 3, 1, 1) for _ in range(3)])
+        self.blk2 = nn.Sequential(CRB2d(128, 128, 3, 2, 1), *[CRB2d(128, 128, 3, 1, 1) for _ in range(5)])
+        self.blk3 = nn.Sequential(CRB2d(128, 256, 3, 2, 1), *[CRB2d(256, 256, 3, 1, 1) for _ in range(5)])
+        self.deconv1 = DeCRB2d(128, 256, 3, 1, 1)
+        self.deconv2 = DeCRB2d(128, 256, 2, 2, 0)
+        self.deconv3 = DeCRB2d(256, 256, 4, 4, 0)
+        self.cls = nn.Conv2d(768, 2, 1, 1, 0)
+        self.reg = nn.Conv2d(768, 14, 1, 1, 0)
+
+    def forward(self, x):
+        x1 = self.blk1(x)
+        x2 = self.blk2(x1)
+        x3 = self.blk3(x2)
+        up = torch.concat([self.deconv1(x1), self.deconv2(x2), self.deconv3(x3)], dim=1)
+        return torch.sigmoid(self.cls(up)), self.reg(up)
