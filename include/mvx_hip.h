@@ -172,6 +172,38 @@ int mvx_bn_segment_max(const float *y, const float *mean_inv, float *out, int32_
 int mvx_segment_max_backward(const float *dfeat, const int32_t *argmax, float *dyhat, int32_t n_voxels,
                              int32_t t, int32_t channels, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Point <-> image fusion sampling.  Replaces featureMaping (modules/imhead/Pipe.py:23-82).
+ *   voxels   f32 [rows][vox_channels]  dense (V*T) voxel rows: xyz in columns 0..2, projected
+ *            (row, col) in the LAST two columns; rows with x == y == z == 0 are padding and get
+ *            all their columns zeroed IN PLACE (Pipe.py:54-59)
+ *   feats_host[l]  device pointer of FPN level l, channels-last f32 [h_l][w_l][channels];
+ *            feat_hw_host = {h_0, w_0, h_1, w_1, ...} (both arrays live on the HOST)
+ *   out      f32 [rows or n_real(+1)][n_levels*channels]: level l in columns [l*C, (l+1)*C)
+ *   row_map  NULL: dense output, padded rows written as zeros (Pipe.py:80);
+ *            else i32 [rows] from mvx_row_compact_map: only real rows are sampled, into their
+ *            compact row; the caller keeps one shared zero row for all padded rows
+ *   status   bit0 = a sample index left the (zero-padded) map: the reference's assert, Pipe.py:71
+ * mvx_row_compact_map: row_map[r] = rank of real row r among real rows, -1 for padded rows;
+ *            rows_sel (optional) i32 [rows]: inverse list; n_real i32 [1] on the device.
+ * mvx_expand_rows / _backward: compact [n][C] <-> dense [rows][C]; every padded row reads the
+ *            shared row `pad_row`, whose gradient is the sum over the padded rows (C <= 256;
+ *            scratch f64 [C]).
+ */
+size_t mvx_row_compact_workspace_bytes(int64_t rows);
+int mvx_row_compact_map(const float *voxels, int32_t vox_channels, int64_t rows, int32_t *row_map,
+                        int32_t *rows_sel, int32_t *n_real, void *workspace, size_t workspace_bytes,
+                        void *stream);
+int mvx_feature_sample(float *voxels, int32_t vox_channels, int64_t rows, const int32_t *row_map,
+                       const float *const *feats_host, const int32_t *feat_hw_host, int32_t n_levels,
+                       int32_t channels, float imsize_h, float imsize_w, float eps, float *out,
+                       int32_t *status, void *stream);
+int mvx_expand_rows(const float *compact, const int32_t *row_map, int32_t pad_row, float *out,
+                    int64_t rows, int32_t channels, void *stream);
+int mvx_expand_rows_backward(const float *grad_out, const int32_t *row_map, int32_t pad_row,
+                             float *dcompact, double *scratch, int64_t rows, int32_t channels,
+                             void *stream);
+
 #ifdef __cplusplus
 }
 #endif

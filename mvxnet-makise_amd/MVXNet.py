@@ -1,0 +1,38 @@
+"""MVXNet top module with the reference's interface (MVXNet.py:13-27):
+``forward(voxels (1,N,T,9), imgs, idx (N,4), calibs, imsize) -> (score, reg)``."""
+import torch
+from torch import nn
+
+from modules.imhead import ImageHead
+from modules.voxelnet import VoxelNet
+
+__all__ = ['MVXNet']
+
+
+def initWeights(m):
+    # the reference re-initialises nn.Conv2d only (MVXNet.py:8-11): Linear / Conv3d /
+    # ConvTranspose2d keep PyTorch's defaults
+    if isinstance(m, nn.Conv2d):
+        nn.init.xavier_uniform_(m.weight.data)
+        m.bias.data.zero_()
+
+
+class MVXNet(nn.Module):
+
+    def __init__(self):
+        super().__init__()
+        self.head = ImageHead()
+        self.backbone = VoxelNet()
+        self.backbone.apply(initWeights)
+
+    def point_features(self, voxels, imgs, calibs, imsize):
+        """(1,N,T,9) -> (1,N,T,23): 7 geometric channels + 16 fused image channels
+        (MVXNet.py:25-26).  Padded rows of ``voxels`` are zeroed in place by the head."""
+        imfeatures = self.head(imgs, voxels, calibs, imsize)
+        return torch.concat([voxels[..., :7], imfeatures], dim=-1)
+
+    def middle(self, voxels, imgs, idx, calibs, imsize):
+        return self.backbone.middle(self.point_features(voxels, imgs, calibs, imsize), idx)
+
+    def forward(self, voxels, imgs, idx, calibs, imsize):
+        return self.backbone(self.point_features(voxels, imgs, calibs, imsize), idx)

@@ -231,3 +231,55 @@ def segment_max_backward(dfeat, am, V, T):
     X.check(X.lib.mvx_segment_max_backward(X.ptr(dfeat), X.ptr(am), X.ptr(dyh), V, T, C, X.stream()),
             'mvx_segment_max_backward')
     return dyh
+
+
+# ---------------------------------------------------------------------------------------------
+# point <-> image fusion
+# ---------------------------------------------------------------------------------------------
+def row_compact_map(vox2d):
+    """vox2d (R, vc) -> row_map i32 (R,), rows_sel i32 (R,), n_real i32 (1,) (all on the device)."""
+    R, vc = vox2d.shape
+    dev = vox2d.device
+    row_map = torch.empty((R,), dtype=torch.int32, device=dev)
+    rows_sel = torch.empty((R,), dtype=torch.int32, device=dev)
+    n_real = torch.empty((1,), dtype=torch.int32, device=dev)
+    nbytes = X.lib.mvx_row_compact_workspace_bytes(R)
+    ws = workspace(nbytes, dev, 'compact')
+    X.check(X.lib.mvx_row_compact_map(X.ptr(vox2d), vc, R, X.ptr(row_map), X.ptr(rows_sel), X.ptr(n_real),
+                                      X.ptr(ws), ws.numel(), X.stream()), 'mvx_row_compact_map')
+    return row_map, rows_sel, n_real
+
+
+def feature_sample(vox2d, feats_cl, imsize_hw, eps, out, row_map=None):
+    """vox2d (R, vc) modified in place; feats_cl: list of channels-last (H, W, C) maps."""
+    import ctypes
+    R, vc = vox2d.shape
+    L = len(feats_cl)
+    C = feats_cl[0].shape[2]
+    ptrs = (ctypes.c_void_p * L)(*[f.data_ptr() for f in feats_cl])
+    hw = (ctypes.c_int32 * (2 * L))(*[int(v) for f in feats_cl for v in f.shape[:2]])
+    status = torch.zeros((1,), dtype=torch.int32, device=vox2d.device)
+    for f in feats_cl:
+        assert f.is_contiguous() and f.dtype == torch.float32 and f.shape[2] == C
+    X.check(X.lib.mvx_feature_sample(X.ptr(vox2d), vc, R, X.ptr(row_map), ptrs, hw, L, C,
+                                     float(imsize_hw[0]), float(imsize_hw[1]), float(eps), X.ptr(out),
+                                     X.ptr(status), X.stream()), 'mvx_feature_sample')
+    return status
+
+
+def expand_rows(compact, row_map, pad_row):
+    R = row_map.shape[0]
+    C = compact.shape[1]
+    out = torch.empty((R, C), dtype=torch.float32, device=compact.device)
+    X.check(X.lib.mvx_expand_rows(X.ptr(compact), X.ptr(row_map), int(pad_row), X.ptr(out), R, C, X.stream()),
+            'mvx_expand_rows')
+    return out
+
+
+def expand_rows_backward(g, row_map, pad_row, n_compact):
+    R, C = g.shape
+    dc = torch.empty((n_compact, C), dtype=torch.float32, device=g.device)
+    scratch = torch.empty((C,), dtype=torch.float64, device=g.device)
+    X.check(X.lib.mvx_expand_rows_backward(X.ptr(g), X.ptr(row_map), int(pad_row), X.ptr(dc), X.ptr(scratch),
+                                           R, C, X.stream()), 'mvx_expand_rows_backward')
+    return dc

@@ -1,0 +1,44 @@
+"""ImageHead with the reference's interface (modules/imhead/Head.py): frozen extractor +
+trainable fusion MLP; ``forward(img, voxels, calibs, imsize) -> (1, N, T, 16)``."""
+import torch
+from torch import nn
+
+import modules.config as cfg
+from modules import _hip
+from .Pipe import ExpandRowsFunction, ImageFeatureExtractor, ImageFeatureFusion, _channels_last_levels
+
+
+class ImageHead(nn.Module):
+
+    def __init__(self):
+        super().__init__()
+        self.extractor = ImageFeatureExtractor()
+        self.extractor.train(False)
+        for p in self.extractor.parameters():
+            p.requires_grad = False
+        self.fusion = ImageFeatureFusion()
+
+    def forward(self, x, voxels, calibs, imsize):
+        """``x``: image (1,3,H,W) or the list of FPN maps; ``voxels``: (1,N,T,9), zeroed in place on
+        padded rows like the reference (imhead/Pipe.py:54-59)."""
+        feats = self.extractor(x)
+        v = voxels[0]
+        if not v.is_contiguous():
+            raise ValueError('ImageHead needs a contiguous voxel tensor (zeroed in place)')
+        n, t, c = v.shape
+        rows = n * t
+        vox2d = v.view(rows, c)
+        row_map, _, n_real = _hip.row_compact_map(vox2d)
+        nr = int(n_real)                                   # one host sync, where the reference asserts
+        levels = _channels_last_levels(feats, 0)
+        width = levels[0].shape[2] * len(levels)
+        compact = torch.empty((nr + 1, width), dtype=torch.float32, device=v.device)
+        compact[nr].zero_()                                # the shared padded row (Pipe.py:80)
+        status = _hip.feature_sample(vox2d, levels, (float(imsize[0]), float(imsize[1])), cfg.eps, compact, row_map)
+        row_w = torch.ones((nr + 1,), dtype=torch.float32, device=v.device)
+        row_w[nr] = float(rows - nr)
+        y = self.fusion.forward_rows(compact, row_w, rows)
+        if int(status) & 1:
+            raise AssertionError('projected point outside the feature map')
+        dense = ExpandRowsFunction.apply(y, row_map, nr)
+        return dense.view(1, n, t, -1)
