@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: KITTI-shaped frames/s through the MVXNet hot path
+(voxelize + fusion + VFE + dense 3-D conv, forward + backward) on N MI355X GPUs.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one batch of `--frames` synthetic ring frames PER GPU (weak scaling): batched GPU
+voxelizer, then per frame fusion sampling + fusion MLP + VFE stack + scatter + CML forward and
+the full backward (dL/d(middle) is a fixed resident tensor standing for RPN + loss), one flat
+gradient all-reduce over RCCL, one AdamW step.  Inputs are resident in HBM before the timed
+region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, 'mvxnet-makise_amd'))
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters (matrix f32, dense)
+
+
+def host_projection(pts, calib):
+    """lidar2Img(uncheck=True) + swap to (row, col) in f32 (train.py:31-33), host numpy: input
+    preparation outside the timed region."""
+    p = np.ones((4, pts.shape[0]), np.float32)
+    p[:3] = pts[:, :3].T
+    m = (calib['R0_rect'].astype(np.float32) @ calib['Tr_velo_to_cam'].astype(np.float32))
+    img = calib['P2'].astype(np.float32) @ (m @ p)
+    uv = (img[:2] / img[2]).T
+    return uv[:, ::-1].astype(np.float32)
+
+
+def make_batch(frame_ids, dev, points_per_frame):
+    from modules.data import Synthetic as S
+    from modules.pipeline import FrameBatch
+    cap = points_per_frame
+    B = len(frame_ids)
+    pts6 = np.zeros((B, cap, 6), np.float32)
+    perms = np.zeros((B, cap), np.int32)
+    n = np.zeros((B,), np.int32)
+    fpn = []
+    for k, fid in enumerate(frame_ids):
+        pc = S.synth_ring(fid, cap)
+        m = min(cap, pc.shape[0])
+        pts6[k, :m, :4] = pc[:m]
+        pts6[k, :m, 4:] = host_projection(pc[:m], S.KITTI_CALIB)
+        perms[k, :m] = S.synth_perm(fid, m)
+        n[k] = m
+        g = torch.Generator(device='cpu').manual_seed(3000 + fid)
+        fpn.append([torch.randn((1, 256, h, w), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+                    for h, w in ((104, 336), (52, 168), (26, 84))])
+    return FrameBatch(torch.from_numpy(pts6).to(dev), torch.from_numpy(perms).to(dev),
+                      torch.from_numpy(n).to(dev), fpn)
+
+
+def host_threads():
+    """Host threads this process may really use: affinity mask, then the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as fh:
+            quota, period = fh.read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get('MVX_CPU_THREADS', '64'))))
+
+
+def cpu_baseline(frame_id, points_per_frame):
+    """The CPU oracle (torch-CPU / oneDNN + the plain-C voxelizer) on ONE frame of the same
+    workload, all host cores.  A reported baseline, not the target."""
+    import ctypes
+    sys.path.insert(0, os.path.join(REPO, 'oracle'))
+    import mvx_oracle as O
+    from modules.data import Synthetic as S
+    torch.set_num_threads(host_threads())
+    pc = S.synth_ring(frame_id, points_per_frame)
+    pcd = np.ascontiguousarray(np.concatenate([pc, host_projection(pc, S.KITTI_CALIB)], 1), np.float32)
+    perm = S.synth_perm(frame_id, pcd.shape[0])
+    P = {k: v.requires_grad_(True) for k, v in O.make_params(7).items()}
+    feats = [torch.from_numpy(f) for f in S.synth_fpn(frame_id)]
+    G = torch.ones((1, 128, O.VOXELSHAPE[0], O.VOXELSHAPE[1]))
+    lib = ctypes.CDLL(os.path.join(REPO, 'oracle', 'liboracle_c.so'))
+    lib.oracle_group9.restype = ctypes.c_int64
+    t0 = time.perf_counter()
+    Pn = pcd.shape[0]
+    voxel = np.empty((Pn, 35, 9), np.float64)
+    uidx = np.empty((Pn, 3), np.float64)
+    cnt = np.empty(Pn, np.int64)
+    rng = np.asarray(O.VELORANGE, np.float64)
+    size = np.asarray(O.voxelsize(), np.float64)
+    V = lib.oracle_group9(pcd.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(6), perm.ctypes.data_as(ctypes.c_void_p),
+                          ctypes.c_int64(Pn), rng.ctypes.data_as(ctypes.c_void_p), size.ctypes.data_as(ctypes.c_void_p),
+                          ctypes.c_int32(35), voxel.ctypes.data_as(ctypes.c_void_p),
+                          uidx.ctypes.data_as(ctypes.c_void_p), cnt.ctypes.data_as(ctypes.c_void_p))
+    vox = torch.from_numpy(voxel[:V].astype(np.float32))
+    idx = torch.from_numpy(np.concatenate([np.zeros((V, 1)), uidx[:V]], 1).astype(np.int64))
+    v23 = O.mvx_point_features(vox, feats, torch.tensor([370.0, 1224.0]), P)
+    mid = O.voxelnet_middle(v23, idx, O.strip_prefix(P, 'backbone.'))
+    mid.backward(G)
+    dt = time.perf_counter() - t0
+    return {'value': 1.0 / dt, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '1 ring frame (%d pts, V=%d): C voxelizer + torch-CPU fusion/VFE/CML fwd+bwd, %.1f s' % (Pn, V, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--frames', type=int, default=4, help='frames per GPU per step')
+    ap.add_argument('--points', type=int, default=20000)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from modules import parallel
+    rank, world, local = parallel.init_from_env()
+    assert world == args.gpus or world == 1, 'launch with torchrun --nproc-per-node = --gpus'
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+
+    import modules.config as cfg
+    from modules import _hip
+    from modules.pipeline import train_step_frames
+    from MVXNet import MVXNet
+
+    torch.manual_seed(0)
+    model = MVXNet().to(dev)
+    hot = [p for k, p in model.named_parameters() if p.requires_grad and '.rpn.' not in k]
+    bucket = parallel.GradBucket(hot)
+    opt = torch.optim.AdamW(hot, lr=1e-3, eps=cfg.eps)
+    frame_ids = [rank + world * j for j in range(args.frames)]
+    batch = make_batch(frame_ids, dev, args.points)
+    g = torch.Generator(device='cpu').manual_seed(77)
+    grad_mid = (torch.randn((1, 128, cfg.voxelshape[0], cfg.voxelshape[1]), generator=g) * 1e-3).to(dev)
+    imsize = torch.tensor([float(v) for v in cfg.imsize], device=dev)
+    frames_total = args.frames * world
+
+    def step():
+        bucket.zero()
+        nv, status = train_step_frames(model, batch, grad_mid, imsize)
+        bucket.all_reduce_mean(frames_total)
+        opt.step()
+        return nv
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    nvox = None
+    for _ in range(args.warmup):
+        nvox = step()
+    fence()
+    _hip.KERNEL_TIMERS = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        nvox = step()
+    fence()
+    dt = time.perf_counter() - t0
+    timers, _hip.KERNEL_TIMERS = _hip.KERNEL_TIMERS, None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+
+    if rank == 0:
+        ev = timers.get('conv3d_gather', [])
+        ms = sum(s.elapsed_time(e) for s, e, _ in ev)
+        fl = sum(f for _, _, f in ev)
+        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(REPO, 'profiles', 'traffic.json')
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic = json.load(fh).get('conv3d_gather_hbm_bytes_per_launch')
+        out = {
+            'metric': 'KITTI frames/sec (voxelize+VFE+fusion+3Dconv fwd+bwd)',
+            'value': frames_total * args.steps / dt,
+            'unit': 'frames/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': 'S2 ring frames, %d pts, grid 10x352x400, T=35, %d frames/GPU/step, '
+                                   'MVXNet middle (fusion on) fwd+bwd + AdamW, fp32 MFMA' % (args.points, args.frames),
+                       'frames_per_gpu': args.frames, 'voxels_per_frame': nvox, 'parallelism': 'dp%d' % world},
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
+                         'kernel': 'conv3d_gather (fwd+dgrad launches)', 'launches': len(ev),
+                         'avg_launch_ms': ms / max(1, len(ev)), 'flop_per_launch': fl / max(1, len(ev))},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            del model, batch
+            torch.cuda.empty_cache()
+            out['cpu_baseline'] = cpu_baseline(0, args.points)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -85,6 +85,12 @@ int mvx_scatter_voxels(const float *feat, const int64_t *coords, float *grid, in
 int mvx_gather_voxels(const float *grid, const int64_t *coords, float *feat, int32_t n_voxels,
                       int32_t channels, int32_t d, int32_t h, int32_t w, void *stream);
 
+/* CML output -> bird's-eye-view map: the reshape of VoxelNet.py:36, (1,C,D,H,W) -> (1,C*D,H,W).
+ *   cl  f32 [d][h][w][channels] (channels-last),  bev f32 [channels*d][h][w], bev channel = c*d_total + d
+ *   reverse = 0: cl -> bev (forward);  reverse = 1: bev -> cl (its gradient).  `cl` is written then. */
+int mvx_cl_to_bev(const float *cl, float *bev, int32_t d, int32_t h, int32_t w, int32_t channels,
+                  int32_t reverse, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * BatchNorm with batch statistics, fused with the preceding ReLU.  Replaces the
  * nn.BatchNorm2d/3d(affine=False, track_running_stats=False) calls of

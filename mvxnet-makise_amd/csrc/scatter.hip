@@ -72,3 +72,57 @@ extern "C" int mvx_gather_voxels(const float *grid, const int64_t *coords, float
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// CML output <-> bird's-eye-view map.  The reference reshapes the NCDHW result (1,64,2,H,W) to
+// (1,128,H,W) (modules/voxelnet/VoxelNet.py:36): BEV channel = c*D + d.  With channels-last
+// storage [D][H][W][C] this is a transposition, done here through a padded LDS tile so both the
+// reads (C contiguous) and the writes (W contiguous) are coalesced.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+// cl [D][H][W][C]  ->  bev [C*D][H][W]   (dir = 0)   or back (dir = 1)
+__global__ __launch_bounds__(256) void cl_bev_transpose(const float *__restrict__ src, float *__restrict__ dst,
+                                                        int D, int H, int W, int C, int dir) {
+    __shared__ float tile[32][33];
+    const int w0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int dh = blockIdx.z, d = dh / H, h = dh % H;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    if (dir == 0) {
+        for (int j = ty; j < 32; j += 8) {
+            const int w = w0 + j, c = c0 + tx;
+            tile[j][tx] = (w < W && c < C) ? src[(((size_t)d * H + h) * W + w) * C + c] : 0.f;
+        }
+        __syncthreads();
+        for (int j = ty; j < 32; j += 8) {
+            const int c = c0 + j, w = w0 + tx;
+            if (w < W && c < C) dst[(((size_t)c * D + d) * H + h) * W + w] = tile[tx][j];
+        }
+    } else {
+        for (int j = ty; j < 32; j += 8) {
+            const int c = c0 + j, w = w0 + tx;
+            tile[j][tx] = (w < W && c < C) ? src[(((size_t)c * D + d) * H + h) * W + w] : 0.f;
+        }
+        __syncthreads();
+        for (int j = ty; j < 32; j += 8) {
+            const int w = w0 + j, c = c0 + tx;
+            if (w < W && c < C) dst[(((size_t)d * H + h) * W + w) * C + c] = tile[tx][j];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mvx_cl_to_bev(const float *cl, float *bev, int32_t d, int32_t h, int32_t w, int32_t channels,
+                             int32_t reverse, void *stream) {
+    MVX_CHECK_ARG(cl && bev && d > 0 && h > 0 && w > 0 && channels > 0);
+    MVX_CHECK_ARG((long long)d * h <= 65535);
+    const dim3 grid(mvx_cdiv(w, 32), mvx_cdiv(channels, 32), d * h);
+    if (!reverse)
+        hipLaunchKernelGGL(cl_bev_transpose, grid, dim3(256), 0, (hipStream_t)stream, cl, bev, d, h, w, channels, 0);
+    else
+        hipLaunchKernelGGL(cl_bev_transpose, grid, dim3(256), 0, (hipStream_t)stream, (const float *)bev, (float *)cl, d,
+                           h, w, channels, 1);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}

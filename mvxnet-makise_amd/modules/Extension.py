@@ -33,6 +33,7 @@ PROTOTYPES = {
                             _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
     'mvx_scatter_voxels': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     'mvx_gather_voxels': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    'mvx_cl_to_bev': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_row_stats': (_i32, [_p, _p, _i64, _i32, _p]),
     'mvx_bn_finalize': (_i32, [_p, _f64, _f64, _p, _i32, _p]),
     'mvx_bn_apply': (_i32, [_p, _p, _p, _i64, _i32, _p]),

@@ -9,6 +9,44 @@ VoxelizeResult = collections.namedtuple('VoxelizeResult', 'voxels coords counts 
 
 _ws_cache = {}
 
+# Optional live kernel timing (bench.py): name -> list of (start_event, end_event, algorithmic_flops).
+# Events are recorded on the current stream, the stream every kernel of this library is launched on.
+KERNEL_TIMERS = None
+
+
+class _Timed:
+    def __init__(self, name, flops):
+        self.name, self.flops = name, flops
+
+    def __enter__(self):
+        if KERNEL_TIMERS is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *exc):
+        if KERNEL_TIMERS is not None:
+            self.e.record()
+            KERNEL_TIMERS.setdefault(self.name, []).append((self.s, self.e, self.flops))
+        return False
+
+
+def conv_flops(d_out_planes, d_src_planes, H, W, cin, cout, sd, pd, dgrad=False):
+    """Executed multiply-add FLOPs of one gather launch: depth taps that fall outside the source
+    volume are skipped by the kernel and are NOT counted (in-plane zero padding is computed and
+    is counted)."""
+    taps = 0
+    for d in range(d_out_planes):
+        for kd in range(3):
+            if not dgrad:
+                s = d * sd - pd + kd
+                taps += 0 <= s < d_src_planes
+            else:
+                t = d + pd - kd
+                taps += t >= 0 and t % sd == 0 and t // sd < d_src_planes
+    return 2.0 * taps * 9 * H * W * cin * cout
+
 
 def workspace(nbytes, dev, tag):
     """Grow-only scratch buffer per (device, tag); stream-ordered reuse on the current stream."""
@@ -66,6 +104,22 @@ def gather_voxels(grid, coords, V):
     X.check(X.lib.mvx_gather_voxels(X.ptr(grid), X.ptr(coords), X.ptr(feat), V, C, D, H, W, X.stream()),
             'mvx_gather_voxels')
     return feat
+
+
+def cl_to_bev(cl):
+    """channels-last (D,H,W,C) -> (C*D,H,W) contiguous, channel = c*D + d."""
+    D, H, W, C = cl.shape
+    bev = torch.empty((C * D, H, W), dtype=torch.float32, device=cl.device)
+    X.check(X.lib.mvx_cl_to_bev(X.ptr(cl), X.ptr(bev), D, H, W, C, 0, X.stream()), 'mvx_cl_to_bev')
+    return bev
+
+
+def bev_to_cl(bev, D):
+    CD, H, W = bev.shape
+    C = CD // D
+    cl = torch.empty((D, H, W, C), dtype=torch.float32, device=bev.device)
+    X.check(X.lib.mvx_cl_to_bev(X.ptr(cl), X.ptr(bev), D, H, W, C, 1, X.stream()), 'mvx_cl_to_bev')
+    return cl
 
 
 # ---------------------------------------------------------------------------------------------
@@ -129,17 +183,19 @@ def conv3d_forward(x, wpk, bias, cout, sd, pd, relu=True, want_stats=True):
     dout = conv_out_depth(din, sd, pd)
     out = torch.empty((dout, H, W, cout), dtype=torch.float32, device=x.device)
     stats = torch.empty((2, cout), dtype=torch.float64, device=x.device) if want_stats else None
-    X.check(X.lib.mvx_conv3d_forward(X.ptr(x), X.ptr(wpk), X.ptr(bias), X.ptr(out), X.ptr(stats),
-                                     din, dout, H, W, cin, cout, sd, pd, int(relu), X.stream()),
-            'mvx_conv3d_forward')
+    with _Timed('conv3d_gather', conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None else 0):
+        X.check(X.lib.mvx_conv3d_forward(X.ptr(x), X.ptr(wpk), X.ptr(bias), X.ptr(out), X.ptr(stats),
+                                         din, dout, H, W, cin, cout, sd, pd, int(relu), X.stream()),
+                'mvx_conv3d_forward')
     return out, stats
 
 
 def conv3d_dgrad(dz, wpk_d, din, cin, sd, pd):
     dout, H, W, cout = dz.shape
     dx = torch.empty((din, H, W, cin), dtype=torch.float32, device=dz.device)
-    X.check(X.lib.mvx_conv3d_dgrad(X.ptr(dz), X.ptr(wpk_d), X.ptr(dx), din, dout, H, W, cin, cout, sd, pd,
-                                   X.stream()), 'mvx_conv3d_dgrad')
+    with _Timed('conv3d_gather', conv_flops(din, dout, H, W, cout, cin, sd, pd, True) if KERNEL_TIMERS is not None else 0):
+        X.check(X.lib.mvx_conv3d_dgrad(X.ptr(dz), X.ptr(wpk_d), X.ptr(dx), din, dout, H, W, cin, cout, sd, pd,
+                                       X.stream()), 'mvx_conv3d_dgrad')
     return dx
 
 
@@ -149,8 +205,9 @@ def conv3d_wgrad(x, dz, sd, pd):
     dw = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device=x.device)
     nbytes = X.lib.mvx_conv3d_wgrad_workspace_bytes(H, W, cin, cout)
     ws = workspace(nbytes, x.device, 'wgrad')
-    X.check(X.lib.mvx_conv3d_wgrad(X.ptr(x), X.ptr(dz), X.ptr(dw), din, dout, H, W, cin, cout, sd, pd,
-                                   X.ptr(ws), ws.numel(), X.stream()), 'mvx_conv3d_wgrad')
+    with _Timed('conv3d_wgrad', conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None else 0):
+        X.check(X.lib.mvx_conv3d_wgrad(X.ptr(x), X.ptr(dz), X.ptr(dw), din, dout, H, W, cin, cout, sd, pd,
+                                       X.ptr(ws), ws.numel(), X.stream()), 'mvx_conv3d_wgrad')
     return dw
 
 

@@ -22,7 +22,8 @@ class ImageHead(nn.Module):
         """``x``: image (1,3,H,W) or the list of FPN maps; ``voxels``: (1,N,T,9), zeroed in place on
         padded rows like the reference (imhead/Pipe.py:54-59)."""
         feats = self.extractor(x)
-        v = voxels[0]
+        v = voxels.squeeze(0) if voxels.dim() == 4 else voxels[0]
+        hw = imsize.tolist() if torch.is_tensor(imsize) else list(imsize)
         if not v.is_contiguous():
             raise ValueError('ImageHead needs a contiguous voxel tensor (zeroed in place)')
         n, t, c = v.shape
@@ -34,7 +35,7 @@ class ImageHead(nn.Module):
         width = levels[0].shape[2] * len(levels)
         compact = torch.empty((nr + 1, width), dtype=torch.float32, device=v.device)
         compact[nr].zero_()                                # the shared padded row (Pipe.py:80)
-        status = _hip.feature_sample(vox2d, levels, (float(imsize[0]), float(imsize[1])), cfg.eps, compact, row_map)
+        status = _hip.feature_sample(vox2d, levels, (float(hw[0]), float(hw[1])), cfg.eps, compact, row_map)
         row_w = torch.ones((nr + 1,), dtype=torch.float32, device=v.device)
         row_w[nr] = float(rows - nr)
         y = self.fusion.forward_rows(compact, row_w, rows)

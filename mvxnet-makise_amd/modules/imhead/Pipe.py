@@ -57,7 +57,7 @@ def featureMaping(voxels, features, calibs, imsize):
     the projected (row, col) in the last two channels, ``features`` = levels of (batch,C1,H,W),
     ``imsize`` = (h, w) tensor.  Returns a list of (N,T,C1*levels); padded rows (x=y=z=0) are
     zeroed IN PLACE in ``voxels`` and yield zero features, like the reference."""
-    hw = [float(imsize[0]), float(imsize[1])]
+    hw = imsize.tolist() if torch.is_tensor(imsize) else [float(imsize[0]), float(imsize[1])]
     res = []
     for i in range(len(voxels)):
         v = voxels[i]

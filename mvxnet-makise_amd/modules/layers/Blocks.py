@@ -126,9 +126,10 @@ class CRB3d(nn.Module):
     def forward(self, x):
         if x.shape[0] != 1:
             raise NotImplementedError('batch size 1 only (reference VoxelNet.py:19)')
-        xc = x[0].permute(1, 2, 3, 0).contiguous()          # no-op when already channels-last
+        # squeeze, not x[0]: the backward of a select allocates zeros and copies the whole gradient
+        xc = x.squeeze(0).permute(1, 2, 3, 0).contiguous()  # no-op when already channels-last
         out = CRB3dFunction.apply(xc, self.conv.weight, self.conv.bias, self._sd, self._pd, cfg.eps)
-        return out.permute(3, 0, 1, 2)[None]
+        return out.permute(3, 0, 1, 2).unsqueeze(0)
 
 
 class _TorchBN2d(nn.Module):

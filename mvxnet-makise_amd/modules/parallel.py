@@ -1,0 +1,52 @@
+"""Data-parallel gradient exchange: one process per GPU, frames sharded across ranks, ONE
+all-reduce (RCCL over xGMI, `nccl` backend; `gloo` on CPU for tests) of a flat fp32 gradient
+bucket per step.  The reference has no distributed code; this is the
+MI355X-native addition of SURVEY section 8e.  Ring all-reduce is per-link bound on xGMI, so the
+whole trainable gradient (<= 29.5 MB) goes out as a single large bucket."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun).  Returns
+    (rank, world, local_rank); a plain single-process run returns (0, 1, 0)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_frames(n_frames_total, rank, world):
+    """Frames {i : i mod world == rank}."""
+    return list(range(rank, n_frames_total, world))
+
+
+class GradBucket:
+    """Flat view over the gradients of the trainable parameters that took part in the step."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device if self.params else torch.device('cpu')
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:                 # parameters' .grad become views of the bucket
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self, frames_total):
+        """Sum over ranks, then divide by the global number of frames."""
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self.flat.mul_(1.0 / float(frames_total))

@@ -1,0 +1,49 @@
+"""Frame pipeline of the hot path: resident point clouds -> GPU voxelizer -> MVXNet middle
+(fusion sampling + fusion MLP + VFE stack + scatter + CML) forward and backward.
+
+This reproduces the per-frame call sequence of the reference's training loop (train.py:31-44
+CPU preprocessing, :113-131 forward, :161 backward) for a batch of independent frames: the
+reference is strictly batch-1 (config.yml:18), so a batch of B frames is B forwards with
+per-frame BatchNorm statistics and summed gradients."""
+import torch
+
+import modules.config as cfg
+from modules import _hip
+
+
+class FrameBatch:
+    """B frames resident in HBM with a fixed point capacity per frame."""
+
+    def __init__(self, points6, perms, n_points, fpn_levels):
+        self.points6 = points6          # f32 (B, capP, 6)  x y z r row col
+        self.perms = perms              # i32 (B, capP)
+        self.n_points = n_points        # i32 (B,)
+        self.fpn_levels = fpn_levels    # list over frames of [f0, f1, f2], each (1, C, H, W)
+
+    @property
+    def n_frames(self):
+        return self.points6.shape[0]
+
+
+def voxelize_batch(batch, T=None):
+    """One batched voxelizer call for all frames; a single host read of the voxel counts."""
+    T = cfg.samplenum if T is None else T
+    res = _hip.voxelize(batch.points6, batch.perms, batch.n_points, cfg.velorange[0:3], cfg.voxelsize, T, 9)
+    counts = res.n_voxels.tolist()      # host sync: output sizes are data dependent
+    frames = []
+    for f, v in enumerate(counts):
+        frames.append((res.voxels[f, :v].unsqueeze(0), res.coords[f, :v]))
+    return frames, res.status
+
+
+def train_step_frames(model, batch, grad_mid, imsize):
+    """Forward + backward of every frame of the batch through ``model.middle``; gradients
+    accumulate in the parameters.  ``grad_mid`` is dL/d(middle output) (1,128,H,W), standing for
+    the RPN + loss that follow the hot path.  Returns the number of voxels per frame."""
+    frames, status = voxelize_batch(batch)
+    nvox = []
+    for f, (voxels, idx) in enumerate(frames):
+        mid = model.middle(voxels, batch.fpn_levels[f], idx, [None], imsize)
+        mid.backward(grad_mid)
+        nvox.append(voxels.shape[1])
+    return nvox, status

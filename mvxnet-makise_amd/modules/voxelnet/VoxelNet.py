@@ -26,6 +26,21 @@ class ReindexFunction(torch.autograd.Function):
         return _hip.gather_voxels(g.contiguous(), idx, ctx.n), None, None
 
 
+class BEVFunction(torch.autograd.Function):
+    """(1,C,D,H,W) logical / channels-last physical -> (1,C*D,H,W) contiguous: the reshape of
+    reference VoxelNet.py:36 as one tiled transposition kernel (and its inverse for the gradient)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        cl = x[0].permute(1, 2, 3, 0).contiguous()       # no copy for channels-last storage
+        ctx.d = cl.shape[0]
+        return _hip.cl_to_bev(cl)[None]
+
+    @staticmethod
+    def backward(ctx, g):
+        return _hip.bev_to_cl(g[0].contiguous(), ctx.d).permute(3, 0, 1, 2)[None]
+
+
 class VoxelNet(nn.Module):
 
     def __init__(self):
@@ -43,7 +58,7 @@ class VoxelNet(nn.Module):
         d, h, w = cfg.voxelshape[2], cfg.voxelshape[0], cfg.voxelshape[1]
         idx = idx.contiguous()
         grid = ReindexFunction.apply(x, idx, (d, h, w))
-        return grid.permute(3, 0, 1, 2)[None]
+        return grid.permute(3, 0, 1, 2).unsqueeze(0)
 
     def voxel_features(self, x):
         """SVFE -> FCN(128,128) -> max over T: (1,N,T,23) -> (N,128) (VoxelNet.py:27-33)."""
@@ -55,8 +70,7 @@ class VoxelNet(nn.Module):
         """Everything before the RPN: (1,N,T,23), (N,4) -> (1,128,H,W), channel = c*2+d."""
         x = self.voxel_features(x)
         x = self.reindex(x, idx)
-        x = self.cml(x)
-        return x.reshape((1, -1, cfg.voxelshape[0], cfg.voxelshape[1]))
+        return BEVFunction.apply(self.cml(x))
 
     def forward(self, x, idx):
         score, reg = self.rpn(self.middle(x, idx))

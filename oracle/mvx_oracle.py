@@ -439,93 +439,12 @@ def strip_prefix(p: Dict[str, torch.Tensor], prefix: str) -> Dict[str, torch.Ten
     return {k[len(prefix):]: v for k, v in p.items() if k.startswith(prefix)}
 
 
-KITTI_CALIB = {
-    # public KITTI 2011_09_26 object calibration, padded to 4x4 as
-    # modules/data/Load.py:24-41 does (values parsed as float32 there).
-    'P2': np.array([[721.5377, 0.0, 609.5593, 44.85728],
-                    [0.0, 721.5377, 172.854, 0.2163791],
-                    [0.0, 0.0, 1.0, 0.002745884],
-                    [0.0, 0.0, 0.0, 1.0]], dtype=np.float32).astype(np.float64),
-    'R0_rect': np.array([[0.9999239, 0.00983776, -0.007445048, 0.0],
-                         [-0.009869795, 0.9999421, -0.004278459, 0.0],
-                         [0.007402527, 0.004351614, 0.9999631, 0.0],
-                         [0.0, 0.0, 0.0, 1.0]], dtype=np.float32).astype(np.float64),
-    'Tr_velo_to_cam': np.array([[0.007533745, -0.9999714, -0.000616602, -0.004069766],
-                                [0.01480249, 0.0007280733, -0.9998902, -0.07631618],
-                                [0.9998621, 0.00752379, 0.01480755, -0.2717806],
-                                [0.0, 0.0, 0.0, 1.0]], dtype=np.float32).astype(np.float64),
-}
-
-
-def synth_uniform(frame_id: int, P: int = 20000, rng=VELORANGE) -> np.ndarray:
-    """S1 'uniform' frame: (P,4) f32 inside the crop range."""
-    g = np.random.default_rng(1000 + frame_id)
-    lo = np.asarray(rng[:3], np.float32)
-    hi = np.asarray(rng[3:], np.float32)
-    xyz = (g.random((P, 3)) * (hi - lo) + lo).astype(np.float32)
-    xyz = np.minimum(xyz, np.nextafter(hi, -np.inf, dtype=np.float32))
-    xyz = np.maximum(xyz, lo)
-    r = g.random((P, 1)).astype(np.float32)
-    return np.concatenate([xyz, r], axis=1)
-
-
-def synth_raw(frame_id: int, P: int = 120000) -> np.ndarray:
-    """Raw un-cropped cloud for the crop/cropToSight config."""
-    g = np.random.default_rng(1000 + frame_id)
-    x = g.uniform(-80, 80, P)
-    y = g.uniform(-80, 80, P)
-    z = g.uniform(-4, 3, P)
-    r = g.random(P)
-    return np.stack([x, y, z, r], axis=1).astype(np.float32)
-
-
-def synth_ring(frame_id: int, P: int = 20000, rng=VELORANGE, calib=None,
-               imsize_wh=(1224, 370)) -> np.ndarray:
-    """S2 'ring' frame: 64-beam spinning-lidar model over flat ground with box
-    occluders, cropped to range + camera frustum, subsampled to P points."""
-    calib = KITTI_CALIB if calib is None else calib
-    g = np.random.default_rng(1000 + frame_id)
-    elev = np.deg2rad(np.linspace(-24.8, 2.0, 64))
-    azim = np.deg2rad(np.arange(-45.0, 45.0, 0.09))
-    pts = []
-    nbox = 12
-    bc = np.stack([g.uniform(5, 60, nbox), g.uniform(-20, 20, nbox)], 1)
-    bs = np.stack([g.uniform(1.5, 4.5, nbox), g.uniform(1.5, 2.5, nbox), g.uniform(1.4, 2.5, nbox)], 1)
-    h = 1.73
-    for rep in range(4):                                 # several sweeps with jitter -> enough points
-        az = (azim + g.normal(0, 2e-4, azim.size))[None, :]
-        el = (elev + g.normal(0, 2e-4, elev.size))[:, None]
-        dx, dy, dz = np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el) * np.ones_like(az)
-        with np.errstate(divide='ignore'):
-            t = np.where(dz < 0, -h / dz, np.inf)
-        t = np.minimum(t, 120.0)
-        for k in range(nbox):                            # ray/AABB slab test
-            lo = np.array([bc[k, 0] - bs[k, 0] / 2, bc[k, 1] - bs[k, 1] / 2, -h])
-            hi = np.array([bc[k, 0] + bs[k, 0] / 2, bc[k, 1] + bs[k, 1] / 2, -h + bs[k, 2]])
-            with np.errstate(divide='ignore', invalid='ignore'):
-                t1 = np.stack([lo[0] / dx, lo[1] / dy, lo[2] / dz])
-                t2 = np.stack([hi[0] / dx, hi[1] / dy, hi[2] / dz])
-            tn = np.nanmax(np.minimum(t1, t2), axis=0)
-            tf = np.nanmin(np.maximum(t1, t2), axis=0)
-            hit = (tn <= tf) & (tn > 0)
-            t = np.where(hit & (tn < t), tn, t)
-        t = t * (1 + g.normal(0, 2e-3, t.shape))
-        ok = np.isfinite(t) & (t < 119.0)
-        p = np.stack([(t * dx)[ok], (t * dy)[ok], (t * dz)[ok], g.random(int(ok.sum()))], 1)
-        pts.append(p.astype(np.float32))
-    pcd = np.concatenate(pts, 0)
-    pcd = crop(pcd, rng)
-    pcd = crop_to_sight(pcd, calib, imsize_wh)
-    if pcd.shape[0] >= P:
-        sel = np.sort(g.choice(pcd.shape[0], P, replace=False))
-        pcd = pcd[sel]
-    return np.ascontiguousarray(pcd)
-
-
-def synth_perm(frame_id: int, P: int) -> np.ndarray:
-    return np.random.default_rng(2000 + frame_id).permutation(P).astype(np.int32)
-
-
-def synth_fpn(frame_id: int, shapes=((256, 104, 336), (256, 52, 168), (256, 26, 84))):
-    g = np.random.default_rng(3000 + frame_id)
-    return [g.standard_normal(s, dtype=np.float32) for s in shapes]
+# Synthetic KITTI-shaped frames and the calibration live in the package (bench.py uses them and
+# may not import oracle/); re-exported here for the tests.
+import os as _os
+import sys as _sys
+_PKG = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'mvxnet-makise_amd')
+if _PKG not in _sys.path:
+    _sys.path.insert(0, _PKG)
+from modules.data.Synthetic import (KITTI_CALIB, synth_fpn, synth_perm, synth_raw, synth_ring,  # noqa: E402,F401
+                                    synth_uniform)
