@@ -210,6 +210,32 @@ int mvx_expand_rows_backward(const float *grad_out, const int32_t *row_map, int3
                              float *dcompact, double *scratch, int64_t rows, int32_t channels,
                              void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Range crop, camera-frustum crop, lidar -> image projection.  Replaces
+ * modules/data/Preprocessing.py:12-24 (crop / cropTensor), :26-55 (cropToSight) and
+ * modules/utils/Calib.py:47-69 (lidar2Img).
+ *
+ * mvx_crop_points: order-preserving compaction of the points that pass the enabled filters.
+ *   pcd f32 [F][cap_points][ncol], n_in i32 [F] (device, NULL = all cap_points live)
+ *   range6_host  (lo xyz, hi xyz) f64 on the HOST or NULL: keep lo <= xyz < hi; bounds_f32 rounds
+ *                the bounds to f32 first (cropTensor semantics)
+ *   cam_from_velo_host = R0_rect @ Tr_velo_to_cam and p2_host = P2, row-major 4x4 f64 on the HOST,
+ *                or NULL: keep cam.z > 0 and 0 <= (u, v) < (imsize_w, imsize_h) - 1e-3;
+ *                math_f32 selects the torch-path (f32) arithmetic instead of the numpy-path (f64)
+ *   out f32 [F][cap_points][ncol], n_out i32 [F]; src_index (optional) i32 [F][cap_points]
+ * mvx_lidar2img: out[i][col_offset + 0..1] = (u, v), or (v, u) = (row, col) when swap_to_row_col
+ *   (train.py:33); cam_z (optional) f32 [n] = depth in the camera frame.
+ */
+size_t mvx_crop_workspace_bytes(int32_t n_frames, int32_t cap_points);
+int mvx_crop_points(const float *pcd, const int32_t *n_in, int32_t n_frames, int32_t cap_points,
+                    int32_t ncol, const double *range6_host, int32_t bounds_f32,
+                    const double *cam_from_velo_host, const double *p2_host, double imsize_w,
+                    double imsize_h, int32_t math_f32, float *out, int32_t *n_out, int32_t *src_index,
+                    void *workspace, size_t workspace_bytes, void *stream);
+int mvx_lidar2img(const float *pcd, int32_t ncol, int64_t n_points, const double *cam_from_velo_host,
+                  const double *p2_host, int32_t math_f32, float *out, int32_t ld_out, int32_t col_offset,
+                  int32_t swap_to_row_col, float *cam_z, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

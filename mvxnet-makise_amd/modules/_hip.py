@@ -340,3 +340,47 @@ def expand_rows_backward(g, row_map, pad_row, n_compact):
     X.check(X.lib.mvx_expand_rows_backward(X.ptr(g), X.ptr(row_map), int(pad_row), X.ptr(dc), X.ptr(scratch),
                                            R, C, X.stream()), 'mvx_expand_rows_backward')
     return dc
+
+
+# ---------------------------------------------------------------------------------------------
+# crops and projection
+# ---------------------------------------------------------------------------------------------
+def _host_f64(a, n):
+    import ctypes
+    import numpy as np
+    if a is None:
+        return None, None
+    arr = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
+    assert arr.size == n
+    return arr, arr.ctypes.data_as(ctypes.c_void_p)
+
+
+def crop_points(pcd, n_in=None, range6=None, bounds_f32=False, cam_from_velo=None, p2=None, imsize_wh=(0.0, 0.0),
+                math_f32=False, want_index=False):
+    """pcd f32 (F, cap, ncol) on the GPU -> (out (F, cap, ncol), n_out i32 (F,), src_index or None)."""
+    F, cap, ncol = pcd.shape
+    dev = pcd.device
+    out = torch.empty_like(pcd)
+    n_out = torch.empty((F,), dtype=torch.int32, device=dev)
+    src = torch.empty((F, cap), dtype=torch.int32, device=dev) if want_index else None
+    ws = workspace(X.lib.mvx_crop_workspace_bytes(F, cap), dev, 'crop')
+    k1, r_ptr = _host_f64(range6, 6)
+    k2, m_ptr = _host_f64(cam_from_velo, 16)
+    k3, p_ptr = _host_f64(p2, 16)
+    X.check(X.lib.mvx_crop_points(X.ptr(pcd), X.ptr(n_in), F, cap, ncol, r_ptr, int(bounds_f32), m_ptr, p_ptr,
+                                  float(imsize_wh[0]), float(imsize_wh[1]), int(math_f32), X.ptr(out), X.ptr(n_out),
+                                  X.ptr(src), X.ptr(ws), ws.numel(), X.stream()), 'mvx_crop_points')
+    return out, n_out, src
+
+
+def lidar2img(pcd2d, cam_from_velo, p2, math_f32=True, out=None, col_offset=0, swap_rc=False, want_z=False):
+    """pcd2d f32 (n, ncol) -> out (n, 2) = (u, v) [or written into columns col_offset.. of `out`]."""
+    n, ncol = pcd2d.shape
+    if out is None:
+        out = torch.empty((n, 2), dtype=torch.float32, device=pcd2d.device)
+    z = torch.empty((n,), dtype=torch.float32, device=pcd2d.device) if want_z else None
+    k2, m_ptr = _host_f64(cam_from_velo, 16)
+    k3, p_ptr = _host_f64(p2, 16)
+    X.check(X.lib.mvx_lidar2img(X.ptr(pcd2d), ncol, n, m_ptr, p_ptr, int(math_f32), _vptr(out), _ld(out), col_offset,
+                                int(swap_rc), X.ptr(z), X.stream()), 'mvx_lidar2img')
+    return out, z

@@ -17,6 +17,66 @@ from modules import _hip
 from modules import Extension as X
 
 
+def _calib_products(calib, f32):
+    """(R0_rect @ Tr_velo_to_cam, P2) as float64 host arrays.  The 4x4 product is formed on the host
+    with the same operator the reference uses (numpy f64 @ for the numpy path, torch f32 @ for the
+    tensor path, Preprocessing.py:46), so the kernel starts from identical matrices."""
+    if f32:
+        r0, tr, p2 = (torch.as_tensor(calib[k]).detach().cpu().float() for k in ('R0_rect', 'Tr_velo_to_cam', 'P2'))
+        return (r0 @ tr).double().numpy(), p2.double().numpy()
+    r0, tr, p2 = (np.asarray(calib[k], dtype=np.float64) for k in ('R0_rect', 'Tr_velo_to_cam', 'P2'))
+    return r0 @ tr, p2
+
+
+def _crop_generic(pcd, range6, bounds_f32, calib, imsize_wh, math_f32):
+    is_np = isinstance(pcd, np.ndarray)
+    dev = X.device() if is_np else pcd.device
+    src = torch.from_numpy(np.ascontiguousarray(pcd, dtype=np.float32)).to(dev) if is_np else pcd.float().contiguous()
+    if src.shape[0] == 0:
+        return pcd[:0]
+    m, p2 = _calib_products(calib, math_f32) if calib is not None else (None, None)
+    out, n_out, _ = _hip.crop_points(src[None], None, range6, bounds_f32, m, p2,
+                                     imsize_wh if imsize_wh is not None else (0.0, 0.0), math_f32)
+    n = int(n_out[0])
+    res = out[0, :n]
+    return res.cpu().numpy() if is_np else res
+
+
+def crop(pcd: np.ndarray, range: Sequence[float]):
+    """Keep points with low <= xyz < high (reference Preprocessing.py:12-17; numpy in/out)."""
+    return _crop_generic(pcd, list(range), False, None, None, False)
+
+
+def cropTensor(pcd: torch.Tensor, range: Sequence[float]):
+    """Tensor variant (reference Preprocessing.py:19-24): bounds rounded to f32 like torch.Tensor(range)."""
+    return _crop_generic(pcd, list(range), True, None, None, False)
+
+
+def cropToSight(pcd: Union[np.ndarray, torch.Tensor], calib: dict, imsize: Sequence[int]):
+    """Keep points in front of the camera that project inside the image; ``imsize`` is (w, h)
+    (reference Preprocessing.py:26-55).  numpy input -> f64 arithmetic, tensor input -> f32."""
+    return _crop_generic(pcd, None, False, calib, (float(imsize[0]), float(imsize[1])), not isinstance(pcd, np.ndarray))
+
+
+def cropFused(pcd, range, calib, imsize):
+    """crop + cropToSight in ONE compaction pass (same result as cropToSight(crop(pcd)))."""
+    return _crop_generic(pcd, list(range), not isinstance(pcd, np.ndarray), calib,
+                         (float(imsize[0]), float(imsize[1])), not isinstance(pcd, np.ndarray))
+
+
+def createAnchors(l, w, range, size):
+    """(l, w, 14) anchor grid: two 7-dof anchors (yaw 0 and pi/2) per BEV cell at z = -1
+    (reference Preprocessing.py:118-142).  Label preparation, outside the hot path; plain torch."""
+    ls, ws = (range[3] - range[0]) / l, (range[4] - range[1]) / w
+    x = torch.linspace(range[0] + ls / 2, range[3] - ls / 2, l)
+    y = torch.linspace(range[1] + ws / 2, range[4] - ws / 2, w)
+    gx, gy = torch.meshgrid(x, y, indexing='ij')
+    base = torch.stack([gx, gy, torch.full_like(gx, -1.0)], dim=2)
+    dims = torch.Tensor(size).expand(l, w, 3)
+    yaw0, yaw1 = torch.zeros((l, w, 1)), torch.full((l, w, 1), torch.pi / 2)
+    return torch.concat([base, dims, yaw0, base, dims, yaw1], dim=2)
+
+
 def _draw_perm(n: int) -> np.ndarray:
     """The permutation np.random.shuffle would apply to an (n, k) array (same RNG draws)."""
     a = np.arange(n, dtype=np.int32)
