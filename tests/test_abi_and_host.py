@@ -1,0 +1,114 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol that include/mvx_hip.h
+declares (no compute calls without a GPU), the ctypes table mirrors the header, the host-side
+configuration / sharding logic, and the product path never imports the oracle."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(REPO, 'include', 'mvx_hip.h')
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(mvx_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from modules import Extension as X
+    lib = ctypes.CDLL(X.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), 'libmvx_hip.so lacks %s declared in include/mvx_hip.h' % n
+    assert set(names) == set(X.PROTOTYPES), set(names) ^ set(X.PROTOTYPES)
+    assert lib.mvx_abi_version() == X.ABI_VERSION
+
+
+def test_argument_counts_match_header():
+    from modules import Extension as X
+    text = re.sub(r'/\*.*?\*/', '', open(HEADER).read(), flags=re.S)
+    for name, (_, args) in X.PROTOTYPES.items():
+        m = re.search(r'\b%s\s*\(([^;]*?)\)\s*;' % name, text, flags=re.S)
+        assert m, name
+        params = m.group(1).strip()
+        n = 0 if params in ('', 'void') else params.count(',') + 1
+        assert n == len(args), (name, n, len(args))
+
+
+def test_no_cpu_fallback_and_loud_failure():
+    from modules import Extension as X
+    with pytest.raises(X.MvxHipError):
+        X.ptr(torch.zeros(4))                      # CPU tensor -> refused, never silently computed
+    if not torch.cuda.is_available():
+        with pytest.raises(X.MvxHipError):
+            X.device()
+    # size queries are pure host code and must work without a GPU
+    assert X.lib.mvx_voxelize_workspace_bytes(2, 20000) > 0
+    assert X.lib.mvx_conv3d_packed_weight_bytes(64, 128) == 27 * 64 * 128 * 4
+    assert X.lib.mvx_conv3d_wgrad_workspace_bytes(352, 400, 128, 64) > 0
+    # argument validation happens before any launch
+    assert X.lib.mvx_voxelize(None, None, None, None, 1, 10, 4, 0., 0., 0., 1., 1., 1., 35, 9, 10,
+                              None, None, None, None, None, None, 0, None) == -1
+
+
+def test_product_path_never_imports_the_oracle():
+    pkg = os.path.join(REPO, 'mvxnet-makise_amd')
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(root, f)).read()
+                assert 'mvx_oracle' not in src and 'liboracle' not in src and 'oracle/' not in src, f
+
+
+def test_config_surface():
+    import modules.config as cfg
+    assert cfg.voxelshape == [352, 400, 10] and cfg.samplenum == 35
+    assert cfg.voxelsize == [0.2, 0.2, 0.4]            # exactly the reference's doubles (Config.py:7)
+    assert cfg.eps == 1e-6 and cfg.dtype == torch.float32
+    with pytest.raises(AttributeError):
+        cfg.no_such_key
+
+
+def test_state_dict_keys_and_param_counts():
+    from MVXNet import MVXNet
+    m = MVXNet()
+    sd = m.state_dict()
+    assert sum(p.numel() for k, p in sd.items() if k.startswith('backbone.')) == 6670608
+    assert sum(p.numel() for k, p in sd.items() if k.startswith('head.fusion.')) == 707872
+    assert 'head.fusion.conv1.conv.weight' in sd and sd['head.fusion.conv1.conv.weight'].shape == (128, 768, 1, 1)
+
+
+def test_shard_frames_partition():
+    from modules.parallel import shard_frames
+    for world in (1, 2, 4, 8):
+        got = sorted(sum((shard_frames(16, r, world) for r in range(world)), []))
+        assert got == list(range(16))
+
+
+def test_synthetic_frames_are_deterministic():
+    from modules.data import Synthetic as S
+    a, b = S.synth_uniform(5, 2000), S.synth_uniform(5, 2000)
+    assert np.array_equal(a, b) and a.dtype == np.float32
+    lo, hi = np.array(S.VELORANGE[:3]), np.array(S.VELORANGE[3:])
+    assert np.all(a[:, :3] >= lo) and np.all(a[:, :3] < hi)
+    assert sorted(S.synth_perm(3, 100).tolist()) == list(range(100))
+
+
+def test_data_parallel_gradient_exchange_gloo_world2():
+    """Two CPU processes over gloo: the flat bucket all-reduce gives the mean over all frames."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29731')
+    worker = os.path.join(REPO, 'tests', '_dp_worker.py')
+    procs = [subprocess.Popen([sys.executable, worker], env=dict(env, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert 'DP_OK' in o, o
