@@ -78,10 +78,13 @@ int mvx_voxelize(const float *pcd, const int32_t *perm, const int32_t *n_points,
  *   feat f32 [n_voxels][channels], coords i64 [n_voxels][4] = (b, ix, iy, iz)
  * zero_grid != 0 clears the whole grid first (the reference allocates zeros every call).
  * status (optional) bit0 = a coordinate fell outside the grid (row skipped).
+ * occupancy (optional) i32 [d][ceil(h/tile_h)][ceil(w/tile_w)]: number of voxels per tile, for the
+ * input-sparse first convolution (tile shape from mvx_conv3d_tile_shape).
  */
 int mvx_scatter_voxels(const float *feat, const int64_t *coords, float *grid, int32_t n_voxels,
                        int32_t channels, int32_t d, int32_t h, int32_t w, int32_t zero_grid,
-                       int32_t *status, void *stream);
+                       int32_t *status, int32_t *occupancy, int32_t tile_h, int32_t tile_w,
+                       void *stream);
 int mvx_gather_voxels(const float *grid, const int64_t *coords, float *feat, int32_t n_voxels,
                       int32_t channels, int32_t d, int32_t h, int32_t w, void *stream);
 
@@ -127,18 +130,36 @@ int mvx_bn_relu_backward(const float *dyhat, const float *y, const float *mean_i
  *   mvx_conv3d_forward       out = [ReLU](conv(in) + bias); stats (optional) f64 [2][cout] =
  *                            per-channel (sum, sum of squares) of `out` for the BatchNorm that
  *                            follows (Blocks.py:28-29)
+ *                            occupancy (optional, from mvx_scatter_voxels): the input is the scattered
+ *                            voxel grid; depth taps whose 3x3 tile neighbourhood is empty and wave
+ *                            operand fragments that are all zero are skipped -- only exact-zero
+ *                            products are dropped, the result is the dense result.  exec_quads
+ *                            (optional) u64 [1] += executed operand quads (1 quad = 8 MFMAs = 32,768 FLOP)
  *   mvx_conv3d_dgrad         dx [din][h][w][cin] from dz [dout][h][w][cout]
+ *   mvx_conv3d_dgrad_sites   dfeat [n_voxels][cin] = rows of dx at the voxel sites only (what
+ *                            reindex's backward reads); coords i64 [n_voxels][4] = (b, ix, iy, iz)
+ *   mvx_conv3d_wgrad_sites   dw from the n_voxels non-zero input rows feat [n_voxels][cin] only
  *   mvx_conv3d_wgrad         dw in torch layout [cout][cin][3][3][3]; cout == 64
  */
 size_t mvx_conv3d_packed_weight_bytes(int32_t cout, int32_t cin);
 int mvx_conv3d_pack_weights(const float *w, float *wpk, int32_t cout, int32_t cin, int32_t for_dgrad,
                             void *stream);
+void mvx_conv3d_tile_shape(int32_t *tile_h, int32_t *tile_w);
 int mvx_conv3d_forward(const float *in, const float *wpk, const float *bias, float *out, double *stats,
                        int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
-                       int32_t stride_d, int32_t pad_d, int32_t relu, void *stream);
+                       int32_t stride_d, int32_t pad_d, int32_t relu, const int32_t *occupancy,
+                       uint64_t *exec_quads, void *stream);
 int mvx_conv3d_dgrad(const float *dz, const float *wpk_dgrad, float *dx, int32_t din, int32_t dout,
                      int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
                      void *stream);
+int mvx_conv3d_dgrad_sites(const float *dz, const float *wpk_dgrad, const int64_t *coords, float *dfeat,
+                           int32_t n_voxels, int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin,
+                           int32_t cout, int32_t stride_d, int32_t pad_d, void *stream);
+size_t mvx_conv3d_wgrad_sites_workspace_bytes(int32_t n_voxels, int32_t cin, int32_t cout);
+int mvx_conv3d_wgrad_sites(const float *feat, const int64_t *coords, const float *dz, float *dw,
+                           int32_t n_voxels, int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin,
+                           int32_t cout, int32_t stride_d, int32_t pad_d, void *workspace,
+                           size_t workspace_bytes, void *stream);
 size_t mvx_conv3d_wgrad_workspace_bytes(int32_t h, int32_t w, int32_t cin, int32_t cout);
 int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
                      int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,

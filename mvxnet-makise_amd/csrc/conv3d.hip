@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather(const float *__restrict_
                                                         const float *__restrict__ wpk,
                                                         const float *__restrict__ bias,
                                                         float *__restrict__ out, double *__restrict__ stats,
-                                                        Geom g, int relu) {
+                                                        Geom g, int relu, const int *__restrict__ occ,
+                                                        unsigned long long *__restrict__ exec_quads) {
     __shared__ __attribute__((aligned(16))) float s_halo[HH * HW * PITCH];
     __shared__ __attribute__((aligned(16))) float s_w[BN * PITCH];
     __shared__ float s_red[4][2 * BN];
@@ -121,9 +122,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather(const float *__restrict_
         }
     };
 
+    const int tiles_y = (g.H + TH - 1) / TH;
+    const int tcx = blockIdx.x % tiles_x, tcy = blockIdx.x / tiles_x;
+    unsigned nquads = 0;
     for (int kd = 0; kd < 3; ++kd) {
         const int ds = src_depth(g, d, kd);
         if (ds < 0) continue;                      // block-uniform
+        if (occ) {
+            // Input-sparse source (the scattered voxel grid): occ[plane][tile] counts the non-zero
+            // sites of each 8x16 tile.  The halo of this patch lies inside the 3x3 tile
+            // neighbourhood; if that is empty every product of this depth tap is an exact zero.
+            int any = 0;
+            for (int yy = max(tcy - 1, 0); yy <= min(tcy + 1, tiles_y - 1); ++yy)
+                for (int xx = max(tcx - 1, 0); xx <= min(tcx + 1, tiles_x - 1); ++xx)
+                    any |= occ[((size_t)ds * tiles_y + yy) * tiles_x + xx];
+            if (!any) continue;                    // block-uniform
+        }
         for (int cc = 0; cc < nchunks; ++cc) {
             __syncthreads();                       // previous stage's LDS reads are done
             // ---- stage the halo of this (depth plane, channel chunk)
@@ -149,6 +163,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather(const float *__restrict_
 #pragma unroll
                 for (int q = 0; q < BK / 8; ++q) {
                     const float4 av = *(const float4 *)(s_halo + a_off + 8 * q);
+                    if (occ) {
+                        // wave-uniform: this wave's 32 source sites hold only zeros for these 8 channels
+                        const bool nz = av.x != 0.f || av.y != 0.f || av.z != 0.f || av.w != 0.f;
+                        if (__ballot(nz) == 0ull) continue;
+                        ++nquads;
+                    }
                     const float4 b0 = *(const float4 *)(s_w + b_base0 + 8 * q);
                     const float4 b1 = *(const float4 *)(s_w + b_base1 + 8 * q);
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc0, 0, 0, 0);
@@ -163,6 +183,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather(const float *__restrict_
             }
         }
     }
+
+    if (exec_quads && occ && lane == 0 && nquads) atomicAdd(exec_quads, (unsigned long long)nquads);
 
     // ---- epilogue: bias, ReLU, store, BatchNorm statistics
     const int n0 = nb * BN + li, n1 = n0 + 32;
@@ -270,6 +292,143 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad(const float *__restri
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Input-sparse first layer: gradients evaluated only where they are used.
+// The dense grid that feeds conv1 is zero except at the V scattered voxels, and its gradient is
+// only ever read back at those voxels (reindex backward).  So
+//   dgrad : dfeat[v][ci] = sum_{kd,a,b,co} dz[do(v,kd)][ix+a-1][iy+b-1][co] * wpk_d[kd][a][b][co][ci]
+//           -- the same gather as the dense kernel, on a list of sites instead of a patch;
+//   wgrad : dW[kd][a][b][ci][co] = sum_v feat[v][ci] * dz[do(v,kd)][ix+1-a][iy+1-b][co]
+//           -- only the V non-zero input rows contribute.
+// Both are exact (they drop products whose input factor is an exact zero or whose result is never read).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void conv3d_dgrad_sites(const float *__restrict__ dz,
+                                                             const float *__restrict__ wpk,
+                                                             const long long *__restrict__ coords,
+                                                             float *__restrict__ dfeat, int V, Geom g) {
+    // gather view: g.Din = planes of dz, g.Cin = channels of dz, g.Cout = channels of dfeat
+    __shared__ __attribute__((aligned(16))) float s_a[128 * PITCH];
+    __shared__ __attribute__((aligned(16))) float s_w[BN * PITCH];
+    __shared__ int s_site[128][3];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int v0 = blockIdx.x * 128, nb = blockIdx.y;
+    const int nchunks = g.Cin / BK;
+    if (tid < 128) {
+        const int v = v0 + tid;
+        s_site[tid][0] = v < V ? (int)coords[(size_t)v * 4 + 3] : -1000;   // depth (iz)
+        s_site[tid][1] = v < V ? (int)coords[(size_t)v * 4 + 1] : -1000;   // row   (ix)
+        s_site[tid][2] = v < V ? (int)coords[(size_t)v * 4 + 2] : -1000;   // col   (iy)
+    }
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const int a_base = (wv * 32 + li) * PITCH + 4 * lh;
+    const int b_base0 = li * PITCH + 4 * lh, b_base1 = (32 + li) * PITCH + 4 * lh;
+    for (int kd = 0; kd < 3; ++kd)
+        for (int cc = 0; cc < nchunks; ++cc)
+            for (int tap = 0; tap < 9; ++tap) {
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = tid + 256 * u, r = c >> 3, part = c & 7;
+                    const int iz = s_site[r][0], y = s_site[r][1] + tap / 3 - 1, x = s_site[r][2] + tap % 3 - 1;
+                    const int t = iz + g.pd - kd;
+                    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (t >= 0 && (t % g.sd) == 0 && t / g.sd < g.Din && y >= 0 && y < g.H && x >= 0 && x < g.W)
+                        val = *(const float4 *)(dz + (((size_t)(t / g.sd) * g.H + y) * g.W + x) * g.Cin + cc * BK + part * 4);
+                    *(float4 *)(s_a + r * PITCH + part * 4) = val;
+                }
+                const float *tile = wpk + ((((size_t)kd * 9 + tap) * nchunks + cc) * g.Cout + (size_t)nb * BN) * BK;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int c = tid + 256 * u;
+                    *(float4 *)(s_w + (c >> 3) * PITCH + (c & 7) * 4) = *(const float4 *)(tile + (size_t)c * 4);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < BK / 8; ++q) {
+                    const float4 av = *(const float4 *)(s_a + a_base + 8 * q);
+                    const float4 b0 = *(const float4 *)(s_w + b_base0 + 8 * q);
+                    const float4 b1 = *(const float4 *)(s_w + b_base1 + 8 * q);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b1.z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b1.w, acc1, 0, 0, 0);
+                }
+            }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int v = v0 + wv * 32 + row;
+        if (v < V) {
+            dfeat[(size_t)v * g.Cout + nb * BN + li] = acc0[r];
+            dfeat[(size_t)v * g.Cout + nb * BN + 32 + li] = acc1[r];
+        }
+    }
+}
+
+constexpr int SV = 64;     // voxel rows per LDS step of the sparse wgrad
+__global__ __launch_bounds__(256) void conv3d_wgrad_sites(const float *__restrict__ feat,
+                                                          const long long *__restrict__ coords,
+                                                          const float *__restrict__ dz, float *__restrict__ slabs,
+                                                          int V, int rows_per_strip, Geom g) {
+    // forward geometry: g.Cin = channels of feat (128), g.Cout = channels of dz (64)
+    __shared__ float s_x[SV * 128];
+    __shared__ float s_z[SV * BN];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int kd = blockIdx.y / 9, tap = blockIdx.y % 9, ta = tap / 3, tb = tap % 3;
+    const int vbeg = blockIdx.x * rows_per_strip, vend = min(V, vbeg + rows_per_strip);
+    const int cin = g.Cin;       // <= 128, multiple of 32
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const bool active = wv * 32 < cin;
+    for (int v0 = vbeg; v0 < vend; v0 += SV) {
+        __syncthreads();
+        for (int c = tid; c < SV * (cin / 4); c += 256) {
+            const int r = c / (cin / 4), part = c % (cin / 4);
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v0 + r < vend) val = *(const float4 *)(feat + (size_t)(v0 + r) * cin + part * 4);
+            *(float4 *)(s_x + r * 128 + part * 4) = val;
+        }
+        for (int c = tid; c < SV * 16; c += 256) {
+            const int r = c >> 4, part = c & 15;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v0 + r < vend) {
+                const long long *cd = coords + (size_t)(v0 + r) * 4;
+                const int t = (int)cd[3] + g.pd - kd, y = (int)cd[1] + 1 - ta, x = (int)cd[2] + 1 - tb;
+                if (t >= 0 && (t % g.sd) == 0 && t / g.sd < g.Dout && y >= 0 && y < g.H && x >= 0 && x < g.W)
+                    val = *(const float4 *)(dz + (((size_t)(t / g.sd) * g.H + y) * g.W + x) * BN + part * 4);
+            }
+            *(float4 *)(s_z + r * BN + part * 4) = val;
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll 8
+            for (int kk = 0; kk < SV / 2; ++kk) {
+                const int row = 2 * kk + lh;
+                const float a = s_x[row * 128 + wv * 32 + li];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s_z[row * BN + li], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s_z[row * BN + 32 + li], acc1, 0, 0, 0);
+            }
+        }
+    }
+    if (active) {
+        float *o = slabs + ((((size_t)blockIdx.x * 3 + kd) * 9 + tap) * cin + wv * 32) * BN;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            o[(size_t)row * BN + li] = acc0[r];
+            o[(size_t)row * BN + 32 + li] = acc1[r];
+        }
+    }
+}
+
 // dW[co][ci][kd][kh][kw] = sum_strips slab[strip][kd][tap][ci][co]
 __global__ void wgrad_reduce(const float *__restrict__ slabs, float *__restrict__ dw, int nstrips, int Ci) {
     const size_t per = (size_t)27 * Ci * BN;
@@ -310,10 +469,16 @@ static int check_geom(int32_t din, int32_t dout, int32_t h, int32_t w, int32_t c
     return MVX_OK;
 }
 
+extern "C" void mvx_conv3d_tile_shape(int32_t *tile_h, int32_t *tile_w) {
+    if (tile_h) *tile_h = TH;
+    if (tile_w) *tile_w = TW;
+}
+
 extern "C" int mvx_conv3d_forward(const float *in, const float *wpk, const float *bias, float *out,
                                   double *stats, int32_t din, int32_t dout, int32_t h, int32_t w,
                                   int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
-                                  int32_t relu, void *stream) {
+                                  int32_t relu, const int32_t *occupancy, uint64_t *exec_quads,
+                                  void *stream) {
     MVX_CHECK_ARG(in && wpk && out);
     int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
     if (rc) return rc;
@@ -325,7 +490,8 @@ extern "C" int mvx_conv3d_forward(const float *in, const float *wpk, const float
     }
     Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
     const dim3 grid(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), dout, cout / BN);
-    hipLaunchKernelGGL(conv3d_gather, grid, dim3(256), 0, st, in, wpk, bias, out, stats, g, relu);
+    hipLaunchKernelGGL(conv3d_gather, grid, dim3(256), 0, st, in, wpk, bias, out, stats, g, relu, occupancy,
+                       (unsigned long long *)exec_quads);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -340,7 +506,7 @@ extern "C" int mvx_conv3d_dgrad(const float *dz, const float *wpk_dgrad, float *
     Geom g{dout, din, h, w, cout, cin, stride_d, pad_d, 1};
     const dim3 grid(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), din, cin / BN);
     hipLaunchKernelGGL(conv3d_gather, grid, dim3(256), 0, (hipStream_t)stream, dz, wpk_dgrad, (const float *)nullptr,
-                       dx, (double *)nullptr, g, 0);
+                       dx, (double *)nullptr, g, 0, (const int *)nullptr, (unsigned long long *)nullptr);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -375,6 +541,61 @@ extern "C" int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(conv3d_wgrad, dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz,
                        (float *)workspace, g, per);
+    MVX_LAUNCH_CHECK();
+    const size_t per_slab = (size_t)27 * cin * BN;
+    hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)workspace, dw,
+                       nstrips, cin);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+extern "C" int mvx_conv3d_dgrad_sites(const float *dz, const float *wpk_dgrad, const int64_t *coords, float *dfeat,
+                                      int32_t n_voxels, int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin,
+                                      int32_t cout, int32_t stride_d, int32_t pad_d, void *stream) {
+    MVX_CHECK_ARG(dz && wpk_dgrad && dfeat && n_voxels >= 0);
+    int rc = check_geom(din, dout, h, w, cout, cin, stride_d, pad_d);
+    if (rc) return rc;
+    if (n_voxels == 0) return MVX_OK;
+    MVX_CHECK_ARG(coords);
+    Geom g{dout, din, h, w, cout, cin, stride_d, pad_d, 1};
+    hipLaunchKernelGGL(conv3d_dgrad_sites, dim3(mvx_cdiv(n_voxels, 128), cin / BN), dim3(256), 0, (hipStream_t)stream, dz,
+                       wpk_dgrad, (const long long *)coords, dfeat, n_voxels, g);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+static int sites_rows_per_strip(int n_voxels) {
+    int rows = (n_voxels + 15) / 16;           // about 16 strips x 27 taps = 432 workgroups
+    rows = ((rows + SV - 1) / SV) * SV;
+    return rows < SV ? SV : rows;
+}
+
+extern "C" size_t mvx_conv3d_wgrad_sites_workspace_bytes(int32_t n_voxels, int32_t cin, int32_t cout) {
+    if (n_voxels <= 0 || cin <= 0 || cout != BN) return 256;
+    const int per = sites_rows_per_strip(n_voxels);
+    return (size_t)((n_voxels + per - 1) / per) * 27 * cin * BN * sizeof(float);
+}
+
+extern "C" int mvx_conv3d_wgrad_sites(const float *feat, const int64_t *coords, const float *dz, float *dw,
+                                      int32_t n_voxels, int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin,
+                                      int32_t cout, int32_t stride_d, int32_t pad_d, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
+    MVX_CHECK_ARG(dz && dw && workspace && n_voxels >= 0);
+    int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
+    if (rc) return rc;
+    if (cout != BN || cin > 128) return MVX_ESIZE;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_voxels == 0) {
+        hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * 27 * (size_t)cin * cout, st);
+        return e == hipSuccess ? MVX_OK : (int)e;
+    }
+    MVX_CHECK_ARG(feat && coords);
+    const int per = sites_rows_per_strip(n_voxels);
+    const int nstrips = (n_voxels + per - 1) / per;
+    MVX_CHECK_ARG(workspace_bytes >= (size_t)nstrips * 27 * cin * BN * sizeof(float));
+    Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
+    hipLaunchKernelGGL(conv3d_wgrad_sites, dim3(nstrips, 27), dim3(256), 0, st, feat, (const long long *)coords, dz,
+                       (float *)workspace, n_voxels, per, g);
     MVX_LAUNCH_CHECK();
     const size_t per_slab = (size_t)27 * cin * BN;
     hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)workspace, dw,

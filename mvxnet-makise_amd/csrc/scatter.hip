@@ -10,7 +10,8 @@
 namespace {
 
 __global__ void scatter_rows(const float *__restrict__ feat, const long long *__restrict__ coords,
-                             float *__restrict__ grid, int V, int C, int D, int H, int W, int *status) {
+                             float *__restrict__ grid, int V, int C, int D, int H, int W, int *status,
+                             int *__restrict__ occ, int tile_h, int tile_w) {
     const int c4 = C >> 2;
     const size_t total = (size_t)V * c4;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -22,6 +23,10 @@ __global__ void scatter_rows(const float *__restrict__ feat, const long long *__
         }
         const size_t site = ((size_t)iz * H + ix) * W + iy;
         *(float4 *)(grid + site * C + part * 4) = *(const float4 *)(feat + (size_t)v * C + part * 4);
+        if (occ && part == 0) {
+            const int ty = (H + tile_h - 1) / tile_h, tx = (W + tile_w - 1) / tile_w;
+            atomicAdd(&occ[((size_t)iz * ty + ix / tile_h) * tx + iy / tile_w], 1);
+        }
     }
 }
 
@@ -45,18 +50,24 @@ __global__ void gather_rows(const float *__restrict__ grid, const long long *__r
 
 extern "C" int mvx_scatter_voxels(const float *feat, const int64_t *coords, float *grid, int32_t n_voxels,
                                   int32_t channels, int32_t d, int32_t h, int32_t w, int32_t zero_grid,
-                                  int32_t *status, void *stream) {
+                                  int32_t *status, int32_t *occupancy, int32_t tile_h, int32_t tile_w,
+                                  void *stream) {
     MVX_CHECK_ARG(grid && channels > 0 && channels % 4 == 0 && d > 0 && h > 0 && w > 0 && n_voxels >= 0);
     hipStream_t st = (hipStream_t)stream;
     if (zero_grid) {
         hipError_t e = hipMemsetAsync(grid, 0, (size_t)d * h * w * channels * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
     }
+    if (occupancy) {
+        MVX_CHECK_ARG(tile_h > 0 && tile_w > 0);
+        hipError_t e = hipMemsetAsync(occupancy, 0, sizeof(int32_t) * (size_t)d * mvx_cdiv(h, tile_h) * mvx_cdiv(w, tile_w), st);
+        if (e != hipSuccess) return (int)e;
+    }
     if (n_voxels == 0) return MVX_OK;
     MVX_CHECK_ARG(feat && coords);
     const size_t total = (size_t)n_voxels * (channels / 4);
     hipLaunchKernelGGL(scatter_rows, dim3(mvx_cdiv(total, 256) > 4096 ? 4096 : mvx_cdiv(total, 256)), dim3(256), 0, st,
-                       feat, (const long long *)coords, grid, n_voxels, channels, d, h, w, status);
+                       feat, (const long long *)coords, grid, n_voxels, channels, d, h, w, status, occupancy, tile_h, tile_w);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

@@ -87,14 +87,33 @@ def voxelize(pcd, perm, n_points, lo, size, T, out_channels, cap_voxels=None, ex
 # ---------------------------------------------------------------------------------------------
 # dense grid scatter / gather
 # ---------------------------------------------------------------------------------------------
-def scatter_voxels(feat, coords, dhw, grid=None, zero=True):
+_TILE = None
+
+
+def conv_tile_shape():
+    global _TILE
+    if _TILE is None:
+        import ctypes
+        th, tw = ctypes.c_int32(0), ctypes.c_int32(0)
+        X.lib.mvx_conv3d_tile_shape(ctypes.byref(th), ctypes.byref(tw))
+        _TILE = (th.value, tw.value)
+    return _TILE
+
+
+def scatter_voxels(feat, coords, dhw, grid=None, zero=True, want_occupancy=False):
     D, H, W = dhw
     V, C = feat.shape
     if grid is None:
         grid = torch.empty((D, H, W, C), dtype=torch.float32, device=feat.device)
     status = torch.zeros((1,), dtype=torch.int32, device=feat.device)
+    th, tw = conv_tile_shape()
+    occ = None
+    if want_occupancy:
+        occ = torch.empty((D, -(-H // th), -(-W // tw)), dtype=torch.int32, device=feat.device)
     X.check(X.lib.mvx_scatter_voxels(X.ptr(feat), X.ptr(coords), X.ptr(grid), V, C, D, H, W, int(zero),
-                                     X.ptr(status), X.stream()), 'mvx_scatter_voxels')
+                                     X.ptr(status), X.ptr(occ), th, tw, X.stream()), 'mvx_scatter_voxels')
+    if want_occupancy:
+        return grid, status, occ
     return grid, status
 
 
@@ -178,16 +197,49 @@ def conv_out_depth(din, sd, pd):
     return (din + 2 * pd - 3) // sd + 1
 
 
-def conv3d_forward(x, wpk, bias, cout, sd, pd, relu=True, want_stats=True):
+SPARSE_QUADS = None      # u64 device counter of executed operand quads of input-sparse launches
+
+
+def conv3d_forward(x, wpk, bias, cout, sd, pd, relu=True, want_stats=True, occupancy=None):
+    """occupancy: per-tile voxel counts of the scattered input grid -> exact zero-skipping."""
+    global SPARSE_QUADS
     din, H, W, cin = x.shape
     dout = conv_out_depth(din, sd, pd)
     out = torch.empty((dout, H, W, cout), dtype=torch.float32, device=x.device)
     stats = torch.empty((2, cout), dtype=torch.float64, device=x.device) if want_stats else None
-    with _Timed('conv3d_gather', conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None else 0):
+    counter = None
+    if occupancy is not None and KERNEL_TIMERS is not None:
+        if SPARSE_QUADS is None:
+            SPARSE_QUADS = torch.zeros((1,), dtype=torch.int64, device=x.device)
+        counter = SPARSE_QUADS
+    name = 'conv3d_gather' if occupancy is None else 'conv3d_gather_sparse_input'
+    flops = conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None and occupancy is None else 0
+    with _Timed(name, flops):
         X.check(X.lib.mvx_conv3d_forward(X.ptr(x), X.ptr(wpk), X.ptr(bias), X.ptr(out), X.ptr(stats),
-                                         din, dout, H, W, cin, cout, sd, pd, int(relu), X.stream()),
-                'mvx_conv3d_forward')
+                                         din, dout, H, W, cin, cout, sd, pd, int(relu), X.ptr(occupancy),
+                                         X.ptr(counter), X.stream()), 'mvx_conv3d_forward')
     return out, stats
+
+
+def conv3d_dgrad_sites(dz, wpk_d, coords, n_voxels, din, cin, sd, pd):
+    """Rows of the input gradient at the voxel sites only: (V, cin)."""
+    dout, H, W, cout = dz.shape
+    dfeat = torch.empty((n_voxels, cin), dtype=torch.float32, device=dz.device)
+    with _Timed('conv3d_dgrad_sites', 2.0 * n_voxels * 27 * cin * cout if KERNEL_TIMERS is not None else 0):
+        X.check(X.lib.mvx_conv3d_dgrad_sites(X.ptr(dz), X.ptr(wpk_d), X.ptr(coords), X.ptr(dfeat), n_voxels, din, dout,
+                                             H, W, cin, cout, sd, pd, X.stream()), 'mvx_conv3d_dgrad_sites')
+    return dfeat
+
+
+def conv3d_wgrad_sites(feat, coords, dz, din, sd, pd):
+    V, cin = feat.shape
+    dout, H, W, cout = dz.shape
+    dw = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device=dz.device)
+    ws = workspace(X.lib.mvx_conv3d_wgrad_sites_workspace_bytes(V, cin, cout), dz.device, 'wgrad_sites')
+    with _Timed('conv3d_wgrad_sites', 2.0 * V * 27 * cin * cout if KERNEL_TIMERS is not None else 0):
+        X.check(X.lib.mvx_conv3d_wgrad_sites(X.ptr(feat), X.ptr(coords), X.ptr(dz), X.ptr(dw), V, din, dout, H, W, cin,
+                                             cout, sd, pd, X.ptr(ws), ws.numel(), X.stream()), 'mvx_conv3d_wgrad_sites')
+    return dw
 
 
 def conv3d_dgrad(dz, wpk_d, din, cin, sd, pd):

@@ -49,6 +49,7 @@ class VoxelNet(nn.Module):
         self.fcn = Pipe.FCN(128, 128)
         self.cml = Pipe.CML()
         self.rpn = Pipe.RPN()
+        self.sparse_first_layer = True     # exact input-sparse evaluation of reindex + cml.conv1
 
     @staticmethod
     def reindex(x, idx):
@@ -69,8 +70,14 @@ class VoxelNet(nn.Module):
     def middle(self, x, idx):
         """Everything before the RPN: (1,N,T,23), (N,4) -> (1,128,H,W), channel = c*2+d."""
         x = self.voxel_features(x)
-        x = self.reindex(x, idx)
-        return BEVFunction.apply(self.cml(x))
+        if self.sparse_first_layer:
+            # reindex + cml.conv1 fused on the sparse rows (same numbers as the dense path below)
+            d, h, w = cfg.voxelshape[2], cfg.voxelshape[0], cfg.voxelshape[1]
+            x = self.cml.conv1.forward_voxels(x, idx.contiguous(), (d, h, w))
+            x = self.cml.conv3(self.cml.conv2(x))
+        else:
+            x = self.cml(self.reindex(x, idx))
+        return BEVFunction.apply(x)
 
     def forward(self, x, idx):
         score, reg = self.rpn(self.middle(x, idx))

@@ -102,6 +102,25 @@ def test_voxelnet_vs_f64_oracle(golden, small_cfg):
     assert rel_err(mid, ref_mid) < 1e-4
 
 
+def test_sparse_and_dense_first_layer_paths_agree(golden, small_cfg):
+    from modules.voxelnet import VoxelNet
+    g = golden('voxelnet_small')
+    net = load_backbone(VoxelNet())
+    x = torch.from_numpy(g['x'])[None].to(DEV)
+    idx = torch.from_numpy(g['idx']).to(DEV)
+    G = torch.from_numpy(g['G']).to(DEV)
+    res = {}
+    for mode in (True, False):
+        net.sparse_first_layer = mode
+        net.zero_grad()
+        mid = net.middle(x, idx)
+        (mid[0] * G).sum().backward()
+        res[mode] = (mid.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    assert rel_err(res[True][0], res[False][0]) < 1e-6
+    for k in res[True][1]:
+        assert rel_err(res[True][1][k], res[False][1][k]) < 2e-4, k
+
+
 def test_reindex_layout_and_state_dict_keys(small_cfg):
     from modules.voxelnet import VoxelNet
     net = VoxelNet()
