@@ -78,12 +78,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const float *__restrict__ d
         float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
         if (rt < rpi && col < c4) {
             const float4 m = *(const float4 *)(mi + col * 4), iv = *(const float4 *)(mi + C + col * 4);
-            for (size_t r = blockIdx.x * (size_t)rpi + rt; r < rows; r += (size_t)gridDim.x * rpi) {
-                const float4 g = *(const float4 *)(dyh + r * C + col * 4);
-                const float4 v = *(const float4 *)(y + r * C + col * 4);
-                s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
-                s2.x += g.x * ((v.x - m.x) * iv.x); s2.y += g.y * ((v.y - m.y) * iv.y);
-                s2.z += g.z * ((v.z - m.z) * iv.z); s2.w += g.w * ((v.w - m.w) * iv.w);
+            const size_t stride = (size_t)gridDim.x * rpi;
+            for (size_t r = blockIdx.x * (size_t)rpi + rt; r < rows; r += 4 * stride) {
+                float4 g[4], v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {              // 8 independent 16-byte loads in flight
+                    const size_t rr = r + j * stride;
+                    const bool ok = rr < rows;
+                    g[j] = ok ? *(const float4 *)(dyh + rr * C + col * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    v[j] = ok ? *(const float4 *)(y + rr * C + col * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s1.x += g[j].x; s1.y += g[j].y; s1.z += g[j].z; s1.w += g[j].w;
+                    s2.x += g[j].x * ((v[j].x - m.x) * iv.x); s2.y += g[j].y * ((v[j].y - m.y) * iv.y);
+                    s2.z += g[j].z * ((v[j].z - m.z) * iv.z); s2.w += g[j].w * ((v[j].w - m.w) * iv.w);
+                }
             }
         }
         red[0][threadIdx.x][0] = s1.x; red[0][threadIdx.x][1] = s1.y; red[0][threadIdx.x][2] = s1.z; red[0][threadIdx.x][3] = s1.w;
@@ -120,17 +130,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dy
                 a[j] = (float)(sums[col * 4 + j] / count);
                 b[j] = (float)(sums[C + col * 4 + j] / count);
             }
-            for (size_t r = blockIdx.x * (size_t)rpi + rt; r < rows; r += (size_t)gridDim.x * rpi) {
-                const float4 g = *(const float4 *)(dyh + r * C + col * 4);
-                const float4 v = *(const float4 *)(y + r * C + col * 4);
-                const float rw = row_w ? row_w[r] : 1.f;   // a compact row standing for rw dense rows
-                float4 o;
-                o.x = v.x > 0.f ? iv.x * (g.x - rw * (a[0] + ((v.x - m.x) * iv.x) * b[0])) : 0.f;
-                o.y = v.y > 0.f ? iv.y * (g.y - rw * (a[1] + ((v.y - m.y) * iv.y) * b[1])) : 0.f;
-                o.z = v.z > 0.f ? iv.z * (g.z - rw * (a[2] + ((v.z - m.z) * iv.z) * b[2])) : 0.f;
-                o.w = v.w > 0.f ? iv.w * (g.w - rw * (a[3] + ((v.w - m.w) * iv.w) * b[3])) : 0.f;
-                *(float4 *)(dz + r * C + col * 4) = o;
-                sb.x += o.x; sb.y += o.y; sb.z += o.z; sb.w += o.w;
+            const size_t stride = (size_t)gridDim.x * rpi;
+            for (size_t r = blockIdx.x * (size_t)rpi + rt; r < rows; r += 4 * stride) {
+                float4 g[4], v[4];
+                float rw[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const size_t rr = r + j * stride;
+                    const bool ok = rr < rows;
+                    g[j] = ok ? *(const float4 *)(dyh + rr * C + col * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    v[j] = ok ? *(const float4 *)(y + rr * C + col * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    rw[j] = (ok && row_w) ? row_w[rr] : 1.f;   // a compact row standing for rw dense rows
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const size_t rr = r + j * stride;
+                    if (rr >= rows) break;
+                    float4 o;
+                    o.x = v[j].x > 0.f ? iv.x * (g[j].x - rw[j] * (a[0] + ((v[j].x - m.x) * iv.x) * b[0])) : 0.f;
+                    o.y = v[j].y > 0.f ? iv.y * (g[j].y - rw[j] * (a[1] + ((v[j].y - m.y) * iv.y) * b[1])) : 0.f;
+                    o.z = v[j].z > 0.f ? iv.z * (g[j].z - rw[j] * (a[2] + ((v[j].z - m.z) * iv.z) * b[2])) : 0.f;
+                    o.w = v[j].w > 0.f ? iv.w * (g[j].w - rw[j] * (a[3] + ((v[j].w - m.w) * iv.w) * b[3])) : 0.f;
+                    *(float4 *)(dz + rr * C + col * 4) = o;
+                    sb.x += o.x; sb.y += o.y; sb.z += o.z; sb.w += o.w;
+                }
             }
         }
         if (dbias) {
@@ -155,8 +178,8 @@ __global__ void f64_to_f32(const double *__restrict__ a, float *__restrict__ b, 
 
 inline unsigned row_grid(size_t rows, int C) {
     const int rpi = (256 / (C / 4)) > 1 ? 256 / (C / 4) : 1;
-    size_t b = (rows + rpi - 1) / rpi;
-    return (unsigned)(b > 1024 ? 1024 : (b ? b : 1));
+    size_t b = (rows + 4 * (size_t)rpi - 1) / (4 * (size_t)rpi);   // kernels take 4 rows per thread and trip
+    return (unsigned)(b > 768 ? 768 : (b ? b : 1));
 }
 
 }  // namespace

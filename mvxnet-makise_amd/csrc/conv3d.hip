@@ -249,38 +249,75 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad(const float *__restri
 
     const int t_beg = strip * tiles_per_strip;
     const int t_end = min(ntiles, t_beg + tiles_per_strip);
-    for (int d = 0; d < g.Dout; ++d) {
+    // (depth plane, patch) work list of this workgroup, walked with a one-step register prefetch:
+    // the next patch's halo and dz tile are loaded under the current patch's 128 MFMAs per wave.
+    constexpr int NX = (HH * HW * 8 + WG_THREADS - 1) / WG_THREADS;     // float4 per thread, halo
+    constexpr int NZ = (TH * TW * 16 + WG_THREADS - 1) / WG_THREADS;    // float4 per thread, dz
+    float4 xr[NX], zr[NZ];
+    auto load_step = [&](int d, int t) {
         const int ds = d * g.sd - g.pd + kd;
-        if (ds < 0 || ds >= g.Din) continue;
-        for (int t = t_beg; t < t_end; ++t) {
-            const int tx0 = (t % tiles_x) * TW, ty0 = (t / tiles_x) * TH;
-            __syncthreads();
-            for (int c = tid; c < HH * HW * 8; c += WG_THREADS) {
+        const int tx0 = (t % tiles_x) * TW, ty0 = (t / tiles_x) * TH;
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int c = tid + WG_THREADS * u;
+            xr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < HH * HW * 8) {
                 const int r = c >> 3, part = c & 7;
                 const int gy = ty0 - 1 + r / HW, gx = tx0 - 1 + r % HW;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W)
-                    v = *(const float4 *)(in + (((size_t)ds * g.H + gy) * g.W + gx) * g.Cin + cc * BK + part * 4);
-                *(float4 *)(s_x + r * XP + part * 4) = v;
-            }
-            for (int c = tid; c < TH * TW * 16; c += WG_THREADS) {
-                const int r = c >> 4, part = c & 15;
-                const int gy = ty0 + (r >> 4), gx = tx0 + (r & 15);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gy < g.H && gx < g.W)
-                    v = *(const float4 *)(dz + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout + part * 4);
-                *(float4 *)(s_z + r * ZP + part * 4) = v;
-            }
-            __syncthreads();
-#pragma unroll 4
-            for (int kk = 0; kk < TH * TW / 2; ++kk) {
-                const int s = 2 * kk + lh;
-                const float a = s_x[(((s >> 4) + ta) * HW + (s & 15) + tb) * XP + li];
-                const float b0 = s_z[s * ZP + li], b1 = s_z[s * ZP + 32 + li];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+                    xr[u] = *(const float4 *)(in + (((size_t)ds * g.H + gy) * g.W + gx) * g.Cin + cc * BK + part * 4);
             }
         }
+#pragma unroll
+        for (int u = 0; u < NZ; ++u) {
+            const int c = tid + WG_THREADS * u;
+            zr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < TH * TW * 16) {
+                const int r = c >> 4, part = c & 15;
+                const int gy = ty0 + (r >> 4), gx = tx0 + (r & 15);
+                if (gy < g.H && gx < g.W)
+                    zr[u] = *(const float4 *)(dz + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout + part * 4);
+            }
+        }
+    };
+    // first valid output plane for this depth tap
+    auto next_valid = [&](int d) {
+        while (d < g.Dout) {
+            const int ds = d * g.sd - g.pd + kd;
+            if (ds >= 0 && ds < g.Din) break;
+            ++d;
+        }
+        return d;
+    };
+    int d = next_valid(0), t = t_beg;
+    const bool any = d < g.Dout && t_beg < t_end;
+    if (any) load_step(d, t);
+    while (any && d < g.Dout) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int c = tid + WG_THREADS * u;
+            if (c < HH * HW * 8) *(float4 *)(s_x + (c >> 3) * XP + (c & 7) * 4) = xr[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NZ; ++u) {
+            const int c = tid + WG_THREADS * u;
+            if (c < TH * TW * 16) *(float4 *)(s_z + (c >> 4) * ZP + (c & 15) * 4) = zr[u];
+        }
+        __syncthreads();
+        // advance the work list and prefetch
+        int nt = t + 1, nd = d;
+        if (nt >= t_end) { nt = t_beg; nd = next_valid(d + 1); }
+        if (nd < g.Dout) load_step(nd, nt);
+#pragma unroll 4
+        for (int kk = 0; kk < TH * TW / 2; ++kk) {
+            const int s = 2 * kk + lh;
+            const float a = s_x[(((s >> 4) + ta) * HW + (s & 15) + tb) * XP + li];
+            const float b0 = s_z[s * ZP + li], b1 = s_z[s * ZP + 32 + li];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+        }
+        t = nt; d = nd;
     }
     // slab[strip][kd][tap][c (Cin)][n (64)]
     float *o = slabs + ((((size_t)strip * 3 + kd) * 9 + tap) * g.Cin + cc * BK) * BN;

@@ -12,143 +12,244 @@
 // reference's dense (V,35,C) tensor contributes w times to the BatchNorm sums.
 // Matrices have explicit leading dimensions so layers can read/write column slices of the
 // VFE concat buffers in place.
+//
+// Forward tile: 128 rows x (32*NT) columns per workgroup (NT = 2 or 4), wave w owns 32 rows x all
+// columns; K in chunks of 32 staged through LDS (rows padded to 36 floats, one ds_read_b128 = 4
+// consecutive k per lane, same k permutation for both operands); the next chunk's global loads
+// are issued before the current chunk's MFMAs (register prefetch).  16-byte global loads when the
+// leading dimensions allow it, scalar otherwise (only the 23-column VFE input).
 #include "common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int BM = 128, BN = 64, BK = 32, PITCH = BK + 4;
+constexpr int BM = 128, BK = 32, PITCH = BK + 4;
 
-template <bool WT>
-__global__ __launch_bounds__(256, 2) void linear_fwd(const float *__restrict__ x, int ldx,
-                                                     const float *__restrict__ w, int ldw,
-                                                     const float *__restrict__ bias, float *__restrict__ y,
-                                                     int ldy, double *__restrict__ stats,
-                                                     const float *__restrict__ row_w, long long R, int K, int N,
-                                                     int relu) {
+template <bool WT, int NT, bool VEC>
+__global__ __launch_bounds__(256) void linear_fwd(const float *__restrict__ x, int ldx, const float *__restrict__ w,
+                                                  int ldw, const float *__restrict__ bias, float *__restrict__ y,
+                                                  int ldy, double *__restrict__ stats, const float *__restrict__ row_w,
+                                                  long long R, int K, int N, int relu) {
+    constexpr int BNL = 32 * NT;
+    constexpr int XV = BM * BK / 4 / 256;          // float4 per thread for the x tile (4)
+    constexpr int WV = BNL * BK / 4 / 256;         // float4 per thread for the w tile (NT)
     __shared__ __attribute__((aligned(16))) float s_x[BM * PITCH];
-    __shared__ __attribute__((aligned(16))) float s_w[BN * PITCH];
-    __shared__ float s_red[4][2 * BN];
+    __shared__ __attribute__((aligned(16))) float s_w[BNL * PITCH];
+    __shared__ float s_red[4][2 * BNL];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
     const long long r0 = (long long)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = blockIdx.y * BNL;
 
-    f32x16 acc0, acc1;
+    f32x16 acc[NT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const int a_base = (wv * 32 + li) * PITCH + 4 * lh;
-    const int b_base0 = li * PITCH + 4 * lh, b_base1 = (32 + li) * PITCH + 4 * lh;
+    const int b_base = li * PITCH + 4 * lh;
 
+    float4 xr[XV], wr[WV];
+    auto load_tiles = [&](int k0) {
+        if (VEC) {
+#pragma unroll
+            for (int u = 0; u < XV; ++u) {
+                const int c = tid + 256 * u, r = c >> 3, part = c & 7;
+                const long long gr = r0 + r;
+                xr[u] = (gr < R && k0 + part * 4 < K) ? *(const float4 *)(x + gr * ldx + k0 + part * 4)
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < WV; ++u) {
+                const int c = tid + 256 * u;
+                if (!WT) {
+                    const int n = c >> 3, part = c & 7;
+                    wr[u] = (n0 + n < N && k0 + part * 4 < K) ? *(const float4 *)(w + (long long)(n0 + n) * ldw + k0 + part * 4)
+                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    const int k = c / (BNL / 4), n4 = c % (BNL / 4);
+                    wr[u] = (k0 + k < K && n0 + n4 * 4 < N) ? *(const float4 *)(w + (long long)(k0 + k) * ldw + n0 + n4 * 4)
+                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+    };
+    auto store_tiles = [&](int k0) {
+        if (VEC) {
+#pragma unroll
+            for (int u = 0; u < XV; ++u) {
+                const int c = tid + 256 * u;
+                *(float4 *)(s_x + (c >> 3) * PITCH + (c & 7) * 4) = xr[u];
+            }
+#pragma unroll
+            for (int u = 0; u < WV; ++u) {
+                const int c = tid + 256 * u;
+                if (!WT) {
+                    *(float4 *)(s_w + (c >> 3) * PITCH + (c & 7) * 4) = wr[u];
+                } else {
+                    const int k = c / (BNL / 4), n4 = c % (BNL / 4);
+                    s_w[(n4 * 4 + 0) * PITCH + k] = wr[u].x;
+                    s_w[(n4 * 4 + 1) * PITCH + k] = wr[u].y;
+                    s_w[(n4 * 4 + 2) * PITCH + k] = wr[u].z;
+                    s_w[(n4 * 4 + 3) * PITCH + k] = wr[u].w;
+                }
+            }
+        } else {
+            // scalar path (leading dimension not a multiple of 4): no prefetch
+            for (int e = tid; e < BM * BK; e += 256) {
+                const int r = e >> 5, k = e & 31;
+                const long long gr = r0 + r;
+                s_x[r * PITCH + k] = (gr < R && k0 + k < K) ? x[gr * ldx + k0 + k] : 0.f;
+            }
+            for (int e = tid; e < BNL * BK; e += 256) {
+                int n, k;
+                if (WT) { n = e % BNL; k = e / BNL; } else { n = e >> 5; k = e & 31; }
+                float v = 0.f;
+                if (n0 + n < N && k0 + k < K)
+                    v = WT ? w[(long long)(k0 + k) * ldw + n0 + n] : w[(long long)(n0 + n) * ldw + k0 + k];
+                s_w[n * PITCH + k] = v;
+            }
+        }
+    };
+
+    load_tiles(0);
     for (int k0 = 0; k0 < K; k0 += BK) {
         __syncthreads();
-#pragma unroll 4
-        for (int u = 0; u < BM * BK / 256; ++u) {
-            const int e = tid + 256 * u, r = e >> 5, k = e & 31;
-            const long long gr = r0 + r;
-            s_x[r * PITCH + k] = (gr < R && k0 + k < K) ? x[gr * ldx + k0 + k] : 0.f;
-        }
-#pragma unroll 4
-        for (int u = 0; u < BN * BK / 256; ++u) {
-            const int e = tid + 256 * u;
-            int n, k;
-            if (WT) { n = e & 63; k = e >> 6; } else { n = e >> 5; k = e & 31; }
-            float v = 0.f;
-            if (n0 + n < N && k0 + k < K)
-                v = WT ? w[(long long)(k0 + k) * ldw + n0 + n] : w[(long long)(n0 + n) * ldw + k0 + k];
-            s_w[n * PITCH + k] = v;
-        }
+        store_tiles(k0);
         __syncthreads();
+        if (k0 + BK < K) load_tiles(k0 + BK);
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
             const float4 av = *(const float4 *)(s_x + a_base + 8 * q);
-            const float4 b0 = *(const float4 *)(s_w + b_base0 + 8 * q);
-            const float4 b1 = *(const float4 *)(s_w + b_base1 + 8 * q);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b1.z, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b1.w, acc1, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float4 bv = *(const float4 *)(s_w + b_base + t * 32 * PITCH + 8 * q);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[t], 0, 0, 0);
+            }
         }
     }
 
-    const int c0 = n0 + li, c1 = c0 + 32;
-    const float bias0 = (bias && c0 < N) ? bias[c0] : 0.f, bias1 = (bias && c1 < N) ? bias[c1] : 0.f;
-    float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+    float s1[NT], s2[NT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const long long gr = r0 + wv * 32 + row;
-        float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
-        if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-        if (gr < R) {
-            const float rw = row_w ? row_w[gr] : 1.f;
-            if (c0 < N) { y[gr * ldy + c0] = v0; s1a += rw * v0; s2a += rw * v0 * v0; }
-            if (c1 < N) { y[gr * ldy + c1] = v1; s1b += rw * v1; s2b += rw * v1 * v1; }
+    for (int t = 0; t < NT; ++t) {
+        const int c = n0 + t * 32 + li;
+        const float bs = (bias && c < N) ? bias[c] : 0.f;
+        s1[t] = 0.f; s2[t] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const long long gr = r0 + wv * 32 + row;
+            float v = acc[t][r] + bs;
+            if (relu) v = fmaxf(v, 0.f);
+            if (gr < R && c < N) {
+                y[gr * ldy + c] = v;
+                const float rw = row_w ? row_w[gr] : 1.f;
+                s1[t] += rw * v;
+                s2[t] += rw * v * v;
+            }
         }
     }
     if (stats) {
-        s1a += __shfl_xor(s1a, 32, 64); s2a += __shfl_xor(s2a, 32, 64);
-        s1b += __shfl_xor(s1b, 32, 64); s2b += __shfl_xor(s2b, 32, 64);
         __syncthreads();
-        if (lh == 0) {
-            s_red[wv][li] = s1a; s_red[wv][32 + li] = s1b;
-            s_red[wv][BN + li] = s2a; s_red[wv][BN + 32 + li] = s2b;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float a = s1[t] + __shfl_xor(s1[t], 32, 64), b = s2[t] + __shfl_xor(s2[t], 32, 64);
+            if (lh == 0) { s_red[wv][t * 32 + li] = a; s_red[wv][BNL + t * 32 + li] = b; }
         }
         __syncthreads();
-        if (tid < 2 * BN) {
-            const int which = tid / BN, c = tid % BN;
+        for (int e = tid; e < 2 * BNL; e += 256) {
+            const int which = e / BNL, c = e % BNL;
             if (n0 + c < N) {
-                const double t = (double)s_red[0][tid] + (double)s_red[1][tid] + (double)s_red[2][tid] +
-                                 (double)s_red[3][tid];
+                const double t = (double)s_red[0][e] + (double)s_red[1][e] + (double)s_red[2][e] + (double)s_red[3][e];
                 atomicAdd(stats + (size_t)which * N + n0 + c, t);
             }
         }
     }
 }
 
-// dW partial: slab[strip][n][k] over the rows of the strip.  Block = 64(n) x 64(k), wave (wn, wk).
-constexpr int WR = 64;   // rows per LDS step
-__global__ __launch_bounds__(256) void linear_wgrad(const float *__restrict__ x, int ldx,
-                                                    const float *__restrict__ dz, int lddz,
-                                                    float *__restrict__ slabs, long long R, int K, int N,
+// dW partial: slab[strip][n][k] over the rows of the strip.  Workgroup block = 128(n) x 128(k),
+// wave (wn, wk) owns 64 x 64 = 2 x 2 MFMA tiles; the reduction runs over rows, 32 per LDS step.
+constexpr int WR = 32;
+template <bool VEC>
+__global__ __launch_bounds__(256) void linear_wgrad(const float *__restrict__ x, int ldx, const float *__restrict__ dz,
+                                                    int lddz, float *__restrict__ slabs, long long R, int K, int N,
                                                     long long rows_per_strip) {
-    __shared__ float s_z[WR * 64];
-    __shared__ float s_x[WR * 64];
+    __shared__ __attribute__((aligned(16))) float s_z[WR * 128];
+    __shared__ __attribute__((aligned(16))) float s_x[WR * 128];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int wn = wv >> 1, wk = wv & 1;
-    const int n0 = blockIdx.y * 64, k0 = blockIdx.z * 64;
+    const int n0 = blockIdx.y * 128, k0 = blockIdx.z * 128;
     const long long rbeg = (long long)blockIdx.x * rows_per_strip;
     const long long rend = rbeg + rows_per_strip < R ? rbeg + rows_per_strip : R;
-    f32x16 acc;
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (long long rr = rbeg; rr < rend; rr += WR) {
-        __syncthreads();
-#pragma unroll 4
-        for (int u = 0; u < WR * 64 / 256; ++u) {
-            const int e = tid + 256 * u, r = e >> 6, c = e & 63;
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const bool wave_on = (n0 + wn * 64 < N) && (k0 + wk * 64 < K);
+
+    float4 zr[4], xr[4];
+    auto load_tiles = [&](long long rr) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = tid + 256 * u, r = c >> 5, part = c & 31;
             const long long gr = rr + r;
             const bool ok = gr < rend;
-            s_z[e] = (ok && n0 + c < N) ? dz[gr * lddz + n0 + c] : 0.f;
-            s_x[e] = (ok && k0 + c < K) ? x[gr * ldx + k0 + c] : 0.f;
+            if (VEC) {
+                zr[u] = (ok && n0 + part * 4 < N) ? *(const float4 *)(dz + gr * lddz + n0 + part * 4) : make_float4(0, 0, 0, 0);
+                xr[u] = (ok && k0 + part * 4 < K) ? *(const float4 *)(x + gr * ldx + k0 + part * 4) : make_float4(0, 0, 0, 0);
+            } else {
+                float zz[4], xx[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    zz[j] = (ok && n0 + part * 4 + j < N) ? dz[gr * lddz + n0 + part * 4 + j] : 0.f;
+                    xx[j] = (ok && k0 + part * 4 + j < K) ? x[gr * ldx + k0 + part * 4 + j] : 0.f;
+                }
+                zr[u] = make_float4(zz[0], zz[1], zz[2], zz[3]);
+                xr[u] = make_float4(xx[0], xx[1], xx[2], xx[3]);
+            }
+        }
+    };
+    load_tiles(rbeg);
+    for (long long rr = rbeg; rr < rend; rr += WR) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = tid + 256 * u;
+            *(float4 *)(s_z + c * 4) = zr[u];
+            *(float4 *)(s_x + c * 4) = xr[u];
         }
         __syncthreads();
-#pragma unroll 8
-        for (int kk = 0; kk < WR / 2; ++kk) {
-            const int row = 2 * kk + lh;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s_z[row * 64 + wn * 32 + li], s_x[row * 64 + wk * 32 + li],
-                                                      acc, 0, 0, 0);
+        if (rr + WR < rend) load_tiles(rr + WR);
+        if (wave_on) {
+#pragma unroll 4
+            for (int kk = 0; kk < WR / 2; ++kk) {
+                const int row = 2 * kk + lh;
+                const float a0 = s_z[row * 128 + wn * 64 + li], a1 = s_z[row * 128 + wn * 64 + 32 + li];
+                const float b0 = s_x[row * 128 + wk * 64 + li], b1 = s_x[row * 128 + wk * 64 + 32 + li];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
         }
     }
-    float *o = slabs + (size_t)blockIdx.x * N * K;
+    if (wave_on) {
+        float *o = slabs + (size_t)blockIdx.x * N * K;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int k = k0 + wk * 32 + li;
-        if (n < N && k < K) o[(size_t)n * K + k] = acc[r];
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + wn * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int k = k0 + wk * 64 + b * 32 + li;
+                    if (n < N && k < K) o[(size_t)n * K + k] = acc[a][b][r];
+                }
     }
 }
 
@@ -161,13 +262,16 @@ __global__ void slab_reduce(const float *__restrict__ slabs, float *__restrict__
 }
 
 inline long long strip_rows(long long R, int N, int K) {
-    const long long blocks = (long long)mvx_cdiv(N, 64) * mvx_cdiv(K, 64);
-    long long strips = 2048 / blocks;
+    const long long blocks = (long long)mvx_cdiv(N, 128) * mvx_cdiv(K, 128);
+    long long strips = 1536 / blocks;            // enough workgroups to fill 256 CUs a few times over
+    if (strips > 96) strips = 96;                // ... without making the slab sum long
     if (strips < 1) strips = 1;
     long long rows = (R + strips - 1) / strips;
-    if (rows < 256) rows = 256;
+    if (rows < 4 * WR) rows = 4 * WR;
     return ((rows + WR - 1) / WR) * WR;
 }
+
+inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
 
@@ -182,13 +286,22 @@ extern "C" int mvx_linear_forward(const float *x, int32_t ldx, const float *w, i
         if (e != hipSuccess) return (int)e;
     }
     if (rows == 0) return MVX_OK;
-    const dim3 grid(mvx_cdiv(rows, BM), mvx_cdiv(n, BN));
-    if (w_transposed)
-        hipLaunchKernelGGL(linear_fwd<true>, grid, dim3(256), 0, st, x, ldx, w, ldw, bias, y, ldy, stats, row_w,
-                           (long long)rows, k, n, relu);
-    else
-        hipLaunchKernelGGL(linear_fwd<false>, grid, dim3(256), 0, st, x, ldx, w, ldw, bias, y, ldy, stats, row_w,
-                           (long long)rows, k, n, relu);
+    // 16-byte loads need: aligned bases, leading dimensions and (for chunk tails) K, N multiples of 4
+    const bool vec = aligned16(x) && aligned16(w) && ldx % 4 == 0 && ldw % 4 == 0 && k % 4 == 0 &&
+                     (!w_transposed || n % 4 == 0);
+    const bool wide = n > 64;
+    const dim3 grid(mvx_cdiv(rows, BM), mvx_cdiv(n, wide ? 128 : 64));
+#define MVX_LAUNCH_LIN(WT, NT, VEC)                                                                               \
+    hipLaunchKernelGGL((linear_fwd<WT, NT, VEC>), grid, dim3(256), 0, st, x, ldx, w, ldw, bias, y, ldy, stats, row_w, \
+                       (long long)rows, k, n, relu)
+    if (w_transposed) {
+        if (wide) { if (vec) MVX_LAUNCH_LIN(true, 4, true); else MVX_LAUNCH_LIN(true, 4, false); }
+        else      { if (vec) MVX_LAUNCH_LIN(true, 2, true); else MVX_LAUNCH_LIN(true, 2, false); }
+    } else {
+        if (wide) { if (vec) MVX_LAUNCH_LIN(false, 4, true); else MVX_LAUNCH_LIN(false, 4, false); }
+        else      { if (vec) MVX_LAUNCH_LIN(false, 2, true); else MVX_LAUNCH_LIN(false, 2, false); }
+    }
+#undef MVX_LAUNCH_LIN
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -212,8 +325,14 @@ extern "C" int mvx_linear_wgrad(const float *x, int32_t ldx, const float *dz, in
     const long long per = strip_rows(rows, n, k);
     const long long strips = (rows + per - 1) / per;
     MVX_CHECK_ARG(workspace_bytes >= (size_t)strips * n * k * sizeof(float));
-    hipLaunchKernelGGL(linear_wgrad, dim3((unsigned)strips, mvx_cdiv(n, 64), mvx_cdiv(k, 64)), dim3(256), 0, st, x, ldx,
-                       dz, lddz, (float *)workspace, (long long)rows, k, n, per);
+    const bool vec = aligned16(x) && aligned16(dz) && ldx % 4 == 0 && lddz % 4 == 0 && k % 4 == 0 && n % 4 == 0;
+    const dim3 grid((unsigned)strips, mvx_cdiv(n, 128), mvx_cdiv(k, 128));
+    if (vec)
+        hipLaunchKernelGGL(linear_wgrad<true>, grid, dim3(256), 0, st, x, ldx, dz, lddz, (float *)workspace,
+                           (long long)rows, k, n, per);
+    else
+        hipLaunchKernelGGL(linear_wgrad<false>, grid, dim3(256), 0, st, x, ldx, dz, lddz, (float *)workspace,
+                           (long long)rows, k, n, per);
     MVX_LAUNCH_CHECK();
     const size_t total = (size_t)n * k;
     hipLaunchKernelGGL(slab_reduce, dim3(mvx_cdiv(total, 256) > 1024 ? 1024 : mvx_cdiv(total, 256)), dim3(256), 0, st,
