@@ -106,7 +106,8 @@ int mvx_cl_to_bev(const float *cl, float *bev, int32_t d, int32_t h, int32_t w, 
  *   mvx_bn_relu_backward
  *        given dyhat = dL/d(BN output) and y = ReLU output (BN input):
  *        dz = (y > 0) ? inv * (dyhat - mean(dyhat) - yhat * mean(dyhat * yhat)) : 0
- *        dbias (optional) f32 [C] = column sums of dz;  scratch f64 [3][C];  dz may alias dyhat.
+ *        dbias (optional) f32 [C] = column sums of dz;  scratch: mvx_bn_backward_scratch_bytes(C)
+ *        bytes (replicated f64 accumulators);  dz may alias dyhat.
  *        row_w (optional) f32 [rows]: row r stands for row_w[r] identical rows of the dense tensor
  *        and dyhat[r] is already the SUM of their gradients; `count` is the dense row count.
  */
@@ -115,6 +116,7 @@ int mvx_bn_finalize(const double *stats, double count, double eps, float *mean_i
                     void *stream);
 int mvx_bn_apply(const float *y, const float *mean_inv, float *out, int64_t rows, int32_t channels,
                  void *stream);
+size_t mvx_bn_backward_scratch_bytes(int32_t channels);
 int mvx_bn_relu_backward(const float *dyhat, const float *y, const float *mean_inv, double count,
                          float *dz, float *dbias, double *scratch, const float *row_w, int64_t rows,
                          int32_t channels, void *stream);

@@ -9,6 +9,8 @@
 
 namespace {
 
+constexpr int REP = 32;   // replicas of the cross-block accumulators (spreads same-address atomics)
+
 // stats[0][C] = sum, stats[1][C] = sum of squares  ->  mi[0][C] = mean, mi[1][C] = 1/sqrt(var+eps)
 __global__ void bn_finalize(const double *__restrict__ stats, double count, double eps, float *__restrict__ mi, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const float *__restrict__ d
                 for (int j = 0; j < 4; ++j) {
                     double t = 0.0;
                     for (int r = 0; r < rpi; ++r) t += red[k][r * c4 + ct][j];
-                    atomicAdd(sums + (size_t)k * C + col * 4 + j, t);
+                    atomicAdd(sums + ((size_t)(blockIdx.x % REP) * 3 + k) * C + col * 4 + j, t);
                 }
         }
         __syncthreads();
@@ -127,8 +129,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dy
             const float4 m = *(const float4 *)(mi + col * 4), iv = *(const float4 *)(mi + C + col * 4);
             float a[4], b[4];
             for (int j = 0; j < 4; ++j) {
-                a[j] = (float)(sums[col * 4 + j] / count);
-                b[j] = (float)(sums[C + col * 4 + j] / count);
+                double sa = 0.0, sbb = 0.0;
+                for (int rp = 0; rp < REP; ++rp) {
+                    sa += sums[((size_t)rp * 3 + 0) * C + col * 4 + j];
+                    sbb += sums[((size_t)rp * 3 + 1) * C + col * 4 + j];
+                }
+                a[j] = (float)(sa / count);
+                b[j] = (float)(sbb / count);
             }
             const size_t stride = (size_t)gridDim.x * rpi;
             for (size_t r = blockIdx.x * (size_t)rpi + rt; r < rows; r += 4 * stride) {
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dy
                 for (int j = 0; j < 4; ++j) {
                     double t = 0.0;
                     for (int r = 0; r < rpi; ++r) t += red[r * c4 + ct][j];
-                    atomicAdd(dbias + col * 4 + j, t);
+                    atomicAdd(dbias + (size_t)(blockIdx.x % REP) * 3 * C + col * 4 + j, t);
                 }
             }
             __syncthreads();
@@ -171,9 +178,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dy
     }
 }
 
-__global__ void f64_to_f32(const double *__restrict__ a, float *__restrict__ b, int n) {
+// dbias[c] = sum over replicas of scratch[rep][2][c]
+__global__ void dbias_finish(const double *__restrict__ scratch, float *__restrict__ b, int C) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) b[i] = (float)a[i];
+    if (i >= C) return;
+    double t = 0.0;
+    for (int rp = 0; rp < REP; ++rp) t += scratch[((size_t)rp * 3 + 2) * C + i];
+    b[i] = (float)t;
 }
 
 inline unsigned row_grid(size_t rows, int C) {
@@ -215,13 +226,17 @@ extern "C" int mvx_row_stats(const float *y, double *stats, int64_t rows, int32_
     return MVX_OK;
 }
 
+extern "C" size_t mvx_bn_backward_scratch_bytes(int32_t channels) {
+    return channels > 0 ? sizeof(double) * REP * 3 * (size_t)channels : 0;
+}
+
 extern "C" int mvx_bn_relu_backward(const float *dyhat, const float *y, const float *mean_inv, double count,
                                     float *dz, float *dbias, double *scratch, const float *row_w, int64_t rows,
                                     int32_t channels, void *stream) {
     MVX_CHECK_ARG(dyhat && y && mean_inv && dz && scratch && rows >= 0 && channels > 0 && channels % 4 == 0);
     MVX_CHECK_ARG(count > 0);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * 3 * channels, st);
+    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * REP * 3 * channels, st);
     if (e != hipSuccess) return (int)e;
     if (rows > 0) {
         const unsigned grid = row_grid(rows, channels);
@@ -232,8 +247,8 @@ extern "C" int mvx_bn_relu_backward(const float *dyhat, const float *y, const fl
         MVX_LAUNCH_CHECK();
     }
     if (dbias) {
-        hipLaunchKernelGGL(f64_to_f32, dim3(mvx_cdiv(channels, 128)), dim3(128), 0, st,
-                           (const double *)(scratch + 2 * channels), dbias, channels);
+        hipLaunchKernelGGL(dbias_finish, dim3(mvx_cdiv(channels, 128)), dim3(128), 0, st, (const double *)scratch, dbias,
+                           channels);
         MVX_LAUNCH_CHECK();
     }
     return MVX_OK;

@@ -40,6 +40,7 @@ PROTOTYPES = {
     'mvx_row_stats': (_i32, [_p, _p, _i64, _i32, _p]),
     'mvx_bn_finalize': (_i32, [_p, _f64, _f64, _p, _i32, _p]),
     'mvx_bn_apply': (_i32, [_p, _p, _p, _i64, _i32, _p]),
+    'mvx_bn_backward_scratch_bytes': (_sz, [_i32]),
     'mvx_bn_relu_backward': (_i32, [_p, _p, _p, _f64, _p, _p, _p, _p, _i64, _i32, _p]),
     'mvx_linear_forward': (_i32, [_p, _i32, _p, _i32, _i32, _p, _p, _i32, _p, _p, _i64, _i32, _i32, _i32, _p]),
     'mvx_linear_wgrad_workspace_bytes': (_sz, [_i64, _i32, _i32]),

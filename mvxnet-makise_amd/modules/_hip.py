@@ -174,7 +174,7 @@ def bn_relu_backward(dyhat, y, mi, count, want_dbias=True, dz=None, row_w=None):
     if dz is None:
         dz = torch.empty_like(y)
     dbias = torch.empty((C,), dtype=torch.float32, device=y.device) if want_dbias else None
-    scratch = torch.empty((3, C), dtype=torch.float64, device=y.device)
+    scratch = torch.empty((X.lib.mvx_bn_backward_scratch_bytes(C) // 8,), dtype=torch.float64, device=y.device)
     X.check(X.lib.mvx_bn_relu_backward(X.ptr(dyhat), X.ptr(y), X.ptr(mi), float(count), X.ptr(dz),
                                        X.ptr(dbias), X.ptr(scratch), X.ptr(row_w), rows, C, X.stream()),
             'mvx_bn_relu_backward')
