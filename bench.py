@@ -169,6 +169,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     timers, _hip.KERNEL_TIMERS = _hip.KERNEL_TIMERS, None
+    sparse_quads = int(_hip.SPARSE_QUADS) if _hip.SPARSE_QUADS is not None else 0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -205,6 +206,18 @@ def main():
                          'kernel': 'conv3d_gather (fwd+dgrad launches)', 'launches': len(ev),
                          'avg_launch_ms': ms / max(1, len(ev)), 'flop_per_launch': fl / max(1, len(ev))},
         }
+        other = {}
+        for name in ('conv3d_gather_sparse_input', 'conv3d_wgrad', 'conv3d_dgrad_sites', 'conv3d_wgrad_sites'):
+            evs = timers.get(name, [])
+            if evs:
+                tms = sum(s.elapsed_time(e) for s, e, _ in evs)
+                tfl = sum(f for _, _, f in evs)
+                if name == 'conv3d_gather_sparse_input':
+                    tfl = sparse_quads * 8 * 4096.0          # executed MFMAs only (exact-zero blocks skipped)
+                other[name] = {'launches': len(evs), 'avg_launch_ms': tms / len(evs),
+                               'executed_tflops': tfl / (tms * 1e-3) / 1e12 if tms > 0 else 0.0,
+                               'executed_gflop_per_launch': tfl / len(evs) / 1e9}
+        out['other_kernels'] = other
         if world == 1 and not args.no_cpu_baseline:
             del model, batch
             torch.cuda.empty_cache()

@@ -23,6 +23,12 @@
 extern "C" {
 #endif
 
+/* Per-channel BatchNorm accumulators are kept in MVX_STATS_REPLICAS replicas (workgroup b adds to
+ * replica b mod R) so that the f64 atomics of concurrently finishing workgroups do not pile up on
+ * one address; every `stats` buffer below is f64 [MVX_STATS_REPLICAS][2][channels] and
+ * mvx_bn_finalize sums the replicas. */
+#define MVX_STATS_REPLICAS 32
+
 #define MVX_OK 0
 #define MVX_EINVAL (-1)   /* bad argument (null pointer, size, unsupported combination) */
 #define MVX_ESIZE (-2)    /* a size exceeds what the kernel supports */
@@ -100,7 +106,7 @@ int mvx_cl_to_bev(const float *cl, float *bev, int32_t d, int32_t h, int32_t w, 
  * modules/layers/Blocks.py:10,16,25,29 (forward) and their autograd (backward).
  * All matrices are row-major [rows][channels] f32 (channels-last), channels % 4 == 0.
  *
- *   mvx_row_stats       stats f64 [2][C] = per-channel (sum, sum of squares) over the rows
+ *   mvx_row_stats       stats (replicated, see MVX_STATS_REPLICAS) = per-channel (sum, sum of squares)
  *   mvx_bn_finalize     mean_inv f32 [2][C] = (mean, 1/sqrt(biased var + eps)), count = #rows
  *   mvx_bn_apply        out = (y - mean) * inv          (out may alias y)
  *   mvx_bn_relu_backward
@@ -129,7 +135,7 @@ int mvx_bn_relu_backward(const float *dyhat, const float *y, const float *mean_i
  *
  *   mvx_conv3d_pack_weights  torch layout W[cout][cin][3][3][3] -> kernel layout
  *                            (for_dgrad = 0: forward operand, 1: transposed/flipped operand)
- *   mvx_conv3d_forward       out = [ReLU](conv(in) + bias); stats (optional) f64 [2][cout] =
+ *   mvx_conv3d_forward       out = [ReLU](conv(in) + bias); stats (optional, replicated f64 [R][2][cout]) =
  *                            per-channel (sum, sum of squares) of `out` for the BatchNorm that
  *                            follows (Blocks.py:28-29)
  *                            occupancy (optional, from mvx_scatter_voxels): the input is the scattered
@@ -172,7 +178,7 @@ int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int32_t din, i
  * 1x1 nn.Conv2d GEMMs of FCN and CRB2d (modules/layers/Blocks.py:9,14,35,39) and their autograd.
  *   x f32 [rows][ldx] (k columns used), w f32 [n][ldw] (or [k][ldw] when w_transposed),
  *   y f32 [rows][ldy] (n columns written) = [ReLU](x w^T + bias)
- *   stats (optional) f64 [2][n]: per-column (sum, sum of squares) of y weighted by row_w
+ *   stats (optional, replicated f64 [R][2][n]): per-column (sum, sum of squares) of y weighted by row_w
  *   row_w (optional) f32 [rows]: multiplicity of each row in the reference's dense tensor
  * mvx_linear_wgrad: dw f32 [n][k] = dz^T x  (dz f32 [rows][lddz]).
  */

@@ -15,8 +15,13 @@ constexpr int REP = 32;   // replicas of the cross-block accumulators (spreads s
 __global__ void bn_finalize(const double *__restrict__ stats, double count, double eps, float *__restrict__ mi, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double mean = stats[c] / count;
-    double var = stats[C + c] / count - mean * mean;
+    double s1 = 0.0, s2 = 0.0;
+    for (int rp = 0; rp < MVX_REP; ++rp) {
+        s1 += stats[((size_t)rp * 2) * C + c];
+        s2 += stats[((size_t)rp * 2 + 1) * C + c];
+    }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
     mi[c] = (float)mean;
     mi[C + c] = (float)(1.0 / sqrt(var + eps));
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(256) void row_stats(const float *__restrict__ y, do
                 for (int j = 0; j < 4; ++j) {
                     double t = 0.0;
                     for (int r = 0; r < rpi; ++r) t += red[k][r * c4 + ct][j];
-                    atomicAdd(stats + (size_t)k * C + col * 4 + j, t);
+                    atomicAdd(stats + ((size_t)(blockIdx.x % MVX_REP) * 2 + k) * C + col * 4 + j, t);
                 }
         }
         __syncthreads();
@@ -218,7 +223,7 @@ extern "C" int mvx_bn_apply(const float *y, const float *mean_inv, float *out, i
 extern "C" int mvx_row_stats(const float *y, double *stats, int64_t rows, int32_t channels, void *stream) {
     MVX_CHECK_ARG(y && stats && rows >= 0 && channels > 0 && channels % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * channels, st);
+    hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * MVX_REP * 2 * channels, st);
     if (e != hipSuccess) return (int)e;
     if (rows == 0) return MVX_OK;
     hipLaunchKernelGGL(row_stats, dim3(row_grid(rows, channels)), dim3(256), 0, st, y, stats, (size_t)rows, channels);

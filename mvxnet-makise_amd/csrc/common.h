@@ -5,6 +5,7 @@
 #include "../../include/mvx_hip.h"
 
 #define MVX_WAVE 64
+#define MVX_REP MVX_STATS_REPLICAS
 
 #define MVX_CHECK_ARG(cond)            \
     do {                               \

@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather(const float *__restrict_
         if (tid < 2 * BN) {
             const double t = (double)s_red[0][tid] + (double)s_red[1][tid] + (double)s_red[2][tid] + (double)s_red[3][tid];
             const int which = tid / BN, c = tid % BN;
-            atomicAdd(stats + (size_t)which * g.Cout + nb * BN + c, t);
+            const unsigned rep = (blockIdx.x + blockIdx.y * gridDim.x) % MVX_REP;
+            atomicAdd(stats + ((size_t)rep * 2 + which) * g.Cout + nb * BN + c, t);
         }
     }
 }
@@ -522,7 +523,7 @@ extern "C" int mvx_conv3d_forward(const float *in, const float *wpk, const float
     MVX_CHECK_ARG(dout == (din + 2 * pad_d - 3) / stride_d + 1);
     hipStream_t st = (hipStream_t)stream;
     if (stats) {
-        hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * cout, st);
+        hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * MVX_REP * 2 * cout, st);
         if (e != hipSuccess) return (int)e;
     }
     Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void linear_fwd(const float *__restrict__ x, i
             const int which = e / BNL, c = e % BNL;
             if (n0 + c < N) {
                 const double t = (double)s_red[0][e] + (double)s_red[1][e] + (double)s_red[2][e] + (double)s_red[3][e];
-                atomicAdd(stats + (size_t)which * N + n0 + c, t);
+                atomicAdd(stats + ((size_t)(blockIdx.x % MVX_REP) * 2 + which) * N + n0 + c, t);
             }
         }
     }
@@ -282,7 +282,7 @@ extern "C" int mvx_linear_forward(const float *x, int32_t ldx, const float *w, i
     MVX_CHECK_ARG(ldw >= (w_transposed ? n : k));
     hipStream_t st = (hipStream_t)stream;
     if (stats) {
-        hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * n, st);
+        hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * MVX_REP * 2 * n, st);
         if (e != hipSuccess) return (int)e;
     }
     if (rows == 0) return MVX_OK;

@@ -8,6 +8,7 @@ from modules import Extension as X
 VoxelizeResult = collections.namedtuple('VoxelizeResult', 'voxels coords counts n_voxels status')
 
 _ws_cache = {}
+STATS_REPLICAS = 32      # MVX_STATS_REPLICAS of include/mvx_hip.h
 
 # Optional live kernel timing (bench.py): name -> list of (start_event, end_event, algorithmic_flops).
 # Events are recorded on the current stream, the stream every kernel of this library is launched on.
@@ -146,13 +147,13 @@ def bev_to_cl(bev, D):
 # ---------------------------------------------------------------------------------------------
 def row_stats(y2d):
     rows, C = y2d.shape
-    stats = torch.empty((2, C), dtype=torch.float64, device=y2d.device)
+    stats = torch.empty((STATS_REPLICAS, 2, C), dtype=torch.float64, device=y2d.device)
     X.check(X.lib.mvx_row_stats(X.ptr(y2d), X.ptr(stats), rows, C, X.stream()), 'mvx_row_stats')
     return stats
 
 
 def bn_finalize(stats, count, eps):
-    C = stats.shape[1]
+    C = stats.shape[-1]
     mi = torch.empty((2, C), dtype=torch.float32, device=stats.device)
     X.check(X.lib.mvx_bn_finalize(X.ptr(stats), float(count), float(eps), X.ptr(mi), C, X.stream()),
             'mvx_bn_finalize')
@@ -206,7 +207,7 @@ def conv3d_forward(x, wpk, bias, cout, sd, pd, relu=True, want_stats=True, occup
     din, H, W, cin = x.shape
     dout = conv_out_depth(din, sd, pd)
     out = torch.empty((dout, H, W, cout), dtype=torch.float32, device=x.device)
-    stats = torch.empty((2, cout), dtype=torch.float64, device=x.device) if want_stats else None
+    stats = torch.empty((STATS_REPLICAS, 2, cout), dtype=torch.float64, device=x.device) if want_stats else None
     counter = None
     if occupancy is not None and KERNEL_TIMERS is not None:
         if SPARSE_QUADS is None:
@@ -287,7 +288,7 @@ def linear_forward(x, w, bias, relu=True, want_stats=True, w_transposed=False, r
     N = w.shape[1] if w_transposed else w.shape[0]
     if out is None:
         out = torch.empty((R, N), dtype=torch.float32, device=x.device)
-    stats = torch.empty((2, N), dtype=torch.float64, device=x.device) if want_stats else None
+    stats = torch.empty((STATS_REPLICAS, 2, N), dtype=torch.float64, device=x.device) if want_stats else None
     X.check(X.lib.mvx_linear_forward(_vptr(x), _ld(x), _vptr(w), _ld(w), int(w_transposed), X.ptr(bias),
                                      _vptr(out), _ld(out), X.ptr(stats), X.ptr(row_w), R, K, N, int(relu),
                                      X.stream()), 'mvx_linear_forward')
