@@ -199,13 +199,35 @@ int mvx_linear_wgrad(const float *x, int32_t ldx, const float *dz, int32_t lddz,
  *   mvx_segment_max_backward     dyhat [V][t][C] from dfeat [V][C]
  */
 int mvx_vfe_bn_max_concat(const float *y, const float *mean_inv, float *out, int32_t *argmax,
-                          int32_t n_voxels, int32_t t, int32_t channels, void *stream);
+                          int32_t n_voxels, int32_t t, int32_t channels, const int32_t *voff,
+                          const int32_t *vcnt, int32_t n_real, void *stream);
 int mvx_vfe_max_concat_backward(const float *grad_out, const int32_t *argmax, float *dyhat,
-                                int32_t n_voxels, int32_t t, int32_t channels, void *stream);
+                                int32_t n_voxels, int32_t t, int32_t channels, const int32_t *voff,
+                                const int32_t *vcnt, int32_t n_real, void *stream);
 int mvx_bn_segment_max(const float *y, const float *mean_inv, float *out, int32_t *argmax,
-                       int32_t n_voxels, int32_t t, int32_t channels, void *stream);
+                       int32_t n_voxels, int32_t t, int32_t channels, const int32_t *voff,
+                       const int32_t *vcnt, int32_t n_real, void *stream);
 int mvx_segment_max_backward(const float *dfeat, const int32_t *argmax, float *dyhat, int32_t n_voxels,
-                             int32_t t, int32_t channels, void *stream);
+                             int32_t t, int32_t channels, const int32_t *voff, const int32_t *vcnt,
+                             int32_t n_real, void *stream);
+
+/* Compact rows: inside MVXNet all padded rows of a voxel are identical, so the t rows
+ * of voxel v are stored as its vcnt[v] real rows (matrix rows voff[v] ...) plus ONE padded row
+ * (matrix row n_real + v) that stands for the t - vcnt[v] identical padded rows: weight
+ * row_w = t - vcnt[v] in the BatchNorm sums, gradient = sum over the rows it stands for.  The four
+ * entry points above take voff/vcnt/n_real (NULL/NULL/0 = the dense [V][t][C] layout).
+ *   mvx_voxel_row_offsets          row_map (mvx_row_compact_map) -> voff, vcnt i32 [V], row_w f32 [n_real+V]
+ *   mvx_vfe_compact_input          VFE-1 input rows [n_real+V][7+F]: real row j = [voxels[rows_sel[j]][0:7],
+ *                                  imfeat[j]], padded rows = [0 x 7, imfeat[n_real]]  (MVXNet.py:26)
+ *   mvx_vfe_compact_input_backward dimfeat [n_real+1][F] from grad_out [n_real+V][7+F]; scratch f64 [F]
+ */
+int mvx_voxel_row_offsets(const int32_t *row_map, int32_t n_voxels, int32_t t, int32_t n_real,
+                          int32_t *voff, int32_t *vcnt, float *row_w, void *stream);
+int mvx_vfe_compact_input(const float *voxels, int32_t vox_channels, const int32_t *rows_sel,
+                          const float *imfeat, int32_t feat_channels, int32_t n_real, int32_t n_voxels,
+                          float *out, void *stream);
+int mvx_vfe_compact_input_backward(const float *grad_out, int32_t feat_channels, int32_t n_real,
+                                   int32_t n_voxels, float *dimfeat, double *scratch, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Point <-> image fusion sampling.  Replaces featureMaping (modules/imhead/Pipe.py:23-82).

@@ -8,56 +8,78 @@
 // they reduce and never materialise the intermediate tensor separately.
 // Rows are [V][T][C] row-major; one thread owns one (voxel, channel) column, so loads and
 // stores are coalesced across channels.
+//
+// Compact rows.  Inside MVXNet every padded row of a voxel is identical, so the T rows
+// of voxel v can be stored as its vcnt[v] real rows (rows voff[v] .. voff[v]+vcnt[v]-1 of the
+// matrix) plus ONE padded row (row n_real + v) that stands for the T - vcnt[v] identical padded
+// rows.  With voff/vcnt given, the kernels below walk that layout; the padded row takes part in
+// the max only if T - vcnt[v] > 0, and its gradient is the SUM over the rows it stands for.
+// argmax holds the local row (0..vcnt-1) or vcnt[v] for the padded row.
 #include "common.h"
 
 namespace {
 
+struct Rows {            // row addressing of one voxel
+    const int *voff, *vcnt;
+    int T, n_real;
+    __device__ __forceinline__ int count(int v) const { return vcnt ? vcnt[v] : T; }
+    __device__ __forceinline__ bool has_pad(int v) const { return vcnt && vcnt[v] < T; }
+    // row index of local row t (t == count -> the padded row)
+    __device__ __forceinline__ size_t row(int v, int t) const {
+        if (!vcnt) return (size_t)v * T + t;
+        return t < vcnt[v] ? (size_t)voff[v] + t : (size_t)n_real + v;
+    }
+};
+
 __global__ __launch_bounds__(256) void vfe_bn_max_concat(const float *__restrict__ y, const float *__restrict__ mi,
                                                          float *__restrict__ out, int *__restrict__ argmax,
-                                                         int V, int T, int C) {
+                                                         int V, int C, Rows R) {
     const long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (e >= (long long)V * C) return;
     const int v = (int)(e / C), c = (int)(e % C);
     const float m = mi[c], iv = mi[C + c];
-    const float *src = y + (size_t)v * T * C + c;
+    const int n = R.count(v) + (R.has_pad(v) ? 1 : 0);
     float best = -INFINITY;
     int bi = 0;
-    for (int t = 0; t < T; ++t) {
-        const float val = (src[(size_t)t * C] - m) * iv;
+    for (int t = 0; t < n; ++t) {
+        const float val = (y[R.row(v, t) * C + c] - m) * iv;
         if (val > best) { best = val; bi = t; }
     }
-    float *dst = out + (size_t)v * T * 2 * C + c;
-    for (int t = 0; t < T; ++t) {
-        dst[(size_t)t * 2 * C] = (src[(size_t)t * C] - m) * iv;
-        dst[(size_t)t * 2 * C + C] = best;
+    const int nw = R.vcnt ? R.count(v) + 1 : n;          // the padded row is always written
+    for (int t = 0; t < nw; ++t) {
+        const size_t r = R.row(v, t);
+        out[r * 2 * C + c] = (y[r * C + c] - m) * iv;
+        out[r * 2 * C + C + c] = best;
     }
     argmax[e] = bi;
 }
 
 __global__ __launch_bounds__(256) void vfe_max_concat_bwd(const float *__restrict__ g, const int *__restrict__ argmax,
-                                                          float *__restrict__ dyh, int V, int T, int C) {
+                                                          float *__restrict__ dyh, int V, int C, Rows R) {
     const long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (e >= (long long)V * C) return;
     const int v = (int)(e / C), c = (int)(e % C);
-    const float *src = g + (size_t)v * T * 2 * C + c;
+    const int nw = R.vcnt ? R.count(v) + 1 : R.T;        // rows stored for this voxel
     float s = 0.f;
-    for (int t = 0; t < T; ++t) s += src[(size_t)t * 2 * C + C];
+    for (int t = 0; t < nw; ++t) s += g[R.row(v, t) * 2 * C + C + c];   // padded row: already summed
     const int am = argmax[e];
-    float *dst = dyh + (size_t)v * T * C + c;
-    for (int t = 0; t < T; ++t) dst[(size_t)t * C] = src[(size_t)t * 2 * C] + (t == am ? s : 0.f);
+    for (int t = 0; t < nw; ++t) {
+        const size_t r = R.row(v, t);
+        dyh[r * C + c] = g[r * 2 * C + c] + (t == am ? s : 0.f);
+    }
 }
 
 __global__ __launch_bounds__(256) void bn_segmax(const float *__restrict__ y, const float *__restrict__ mi,
-                                                 float *__restrict__ out, int *__restrict__ argmax, int V, int T, int C) {
+                                                 float *__restrict__ out, int *__restrict__ argmax, int V, int C, Rows R) {
     const long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (e >= (long long)V * C) return;
     const int v = (int)(e / C), c = (int)(e % C);
     const float m = mi[c], iv = mi[C + c];
-    const float *src = y + (size_t)v * T * C + c;
+    const int n = R.count(v) + (R.has_pad(v) ? 1 : 0);
     float best = -INFINITY;
     int bi = 0;
-    for (int t = 0; t < T; ++t) {
-        const float val = (src[(size_t)t * C] - m) * iv;
+    for (int t = 0; t < n; ++t) {
+        const float val = (y[R.row(v, t) * C + c] - m) * iv;
         if (val > best) { best = val; bi = t; }
     }
     out[e] = best;
@@ -65,14 +87,78 @@ __global__ __launch_bounds__(256) void bn_segmax(const float *__restrict__ y, co
 }
 
 __global__ __launch_bounds__(256) void segmax_bwd(const float *__restrict__ dfeat, const int *__restrict__ argmax,
-                                                  float *__restrict__ dyh, int V, int T, int C) {
+                                                  float *__restrict__ dyh, int V, int C, Rows R) {
     const long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (e >= (long long)V * C) return;
     const int v = (int)(e / C), c = (int)(e % C);
     const float gval = dfeat[e];
     const int am = argmax[e];
-    float *dst = dyh + (size_t)v * T * C + c;
-    for (int t = 0; t < T; ++t) dst[(size_t)t * C] = (t == am) ? gval : 0.f;
+    const int nw = R.vcnt ? R.count(v) + 1 : R.T;
+    for (int t = 0; t < nw; ++t) dyh[R.row(v, t) * C + c] = (t == am) ? gval : 0.f;
+}
+
+// ---- compact row bookkeeping --------------------------------------------------------------------
+// row_map [V*T] (dense row -> compact real row or -1)  ->  voff[v] = first compact row of voxel v,
+// vcnt[v] = number of real rows, row_w[n_real + v] = T - vcnt[v] (weight of the padded row),
+// row_w[real rows] = 1.
+__global__ void voxel_row_offsets(const int *__restrict__ row_map, int V, int T, int n_real, int *__restrict__ voff,
+                                  int *__restrict__ vcnt, float *__restrict__ row_w) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    int first = -1, n = 0;
+    for (int t = 0; t < T; ++t) {
+        const int j = row_map[(size_t)v * T + t];
+        if (j >= 0) { if (first < 0) first = j; row_w[j] = 1.f; ++n; }
+    }
+    voff[v] = first < 0 ? 0 : first;
+    vcnt[v] = n;
+    row_w[n_real + v] = (float)(T - n);
+}
+
+// VFE-1 input in compact form: real row j = [voxels[r][0:7], imfeat[j][0:F]], padded row of voxel v =
+// [0 x 7, imfeat[n_real][0:F]] (imfeat's last row is the fusion output of the shared padded row).
+__global__ void vfe_compact_input(const float *__restrict__ vox, int vc, const int *__restrict__ rows_sel,
+                                  const float *__restrict__ imfeat, int F, int n_real, int V, float *__restrict__ out) {
+    const int W = 7 + F;
+    const long long total = (long long)(n_real + V) * W;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(e / W), c = (int)(e % W);
+        float val;
+        if (j < n_real) val = c < 7 ? vox[(size_t)rows_sel[j] * vc + c] : imfeat[(size_t)j * F + c - 7];
+        else val = c < 7 ? 0.f : imfeat[(size_t)n_real * F + c - 7];
+        out[e] = val;
+    }
+}
+
+// gradient wrt imfeat: real rows copy columns 7.., the shared padded row sums them over the voxels
+__global__ __launch_bounds__(256) void vfe_compact_input_bwd(const float *__restrict__ g, int F, int n_real, int V,
+                                                             float *__restrict__ dimfeat, double *__restrict__ padsum) {
+    const int W = 7 + F;
+    const long long total = (long long)n_real * F;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(e / F), c = (int)(e % F);
+        dimfeat[e] = g[(size_t)j * W + 7 + c];
+    }
+    // padded rows: F columns, block-strided over voxels
+    __shared__ float red[256];
+    const int rpi = 256 / F;
+    const int ct = threadIdx.x % F, rt = threadIdx.x / F;
+    float s = 0.f;
+    if (rt < rpi)
+        for (long long v = blockIdx.x * (long long)rpi + rt; v < V; v += (long long)gridDim.x * rpi)
+            s += g[(size_t)(n_real + v) * W + 7 + ct];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rt == 0) {
+        double t = 0.0;
+        for (int k = 0; k < rpi; ++k) t += (double)red[k * F + ct];
+        atomicAdd(padsum + ct, t);
+    }
+}
+
+__global__ void vfe_compact_pad_finish(const double *__restrict__ padsum, float *__restrict__ dimfeat, int n_real, int F) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < F) dimfeat[(size_t)n_real * F + c] = (float)padsum[c];
 }
 
 }  // namespace
@@ -80,38 +166,84 @@ __global__ __launch_bounds__(256) void segmax_bwd(const float *__restrict__ dfea
 #define VFE_ARGS_OK (n_voxels >= 0 && t > 0 && channels > 0)
 #define VFE_GRID dim3(mvx_cdiv((long long)n_voxels * channels, 256)), dim3(256), 0, (hipStream_t)stream
 
+#define VFE_ROWS Rows{voff, vcnt, t, n_real}
+#define VFE_ROWS_OK ((voff == nullptr) == (vcnt == nullptr))
+
 extern "C" int mvx_vfe_bn_max_concat(const float *y, const float *mean_inv, float *out, int32_t *argmax,
-                                     int32_t n_voxels, int32_t t, int32_t channels, void *stream) {
-    MVX_CHECK_ARG(y && mean_inv && out && argmax && VFE_ARGS_OK);
+                                     int32_t n_voxels, int32_t t, int32_t channels, const int32_t *voff,
+                                     const int32_t *vcnt, int32_t n_real, void *stream) {
+    MVX_CHECK_ARG(y && mean_inv && out && argmax && VFE_ARGS_OK && VFE_ROWS_OK);
     if (n_voxels == 0) return MVX_OK;
-    hipLaunchKernelGGL(vfe_bn_max_concat, VFE_GRID, y, mean_inv, out, argmax, n_voxels, t, channels);
+    hipLaunchKernelGGL(vfe_bn_max_concat, VFE_GRID, y, mean_inv, out, argmax, n_voxels, channels, VFE_ROWS);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
 
 extern "C" int mvx_vfe_max_concat_backward(const float *grad_out, const int32_t *argmax, float *dyhat,
-                                           int32_t n_voxels, int32_t t, int32_t channels, void *stream) {
-    MVX_CHECK_ARG(grad_out && argmax && dyhat && VFE_ARGS_OK);
+                                           int32_t n_voxels, int32_t t, int32_t channels, const int32_t *voff,
+                                           const int32_t *vcnt, int32_t n_real, void *stream) {
+    MVX_CHECK_ARG(grad_out && argmax && dyhat && VFE_ARGS_OK && VFE_ROWS_OK);
     if (n_voxels == 0) return MVX_OK;
-    hipLaunchKernelGGL(vfe_max_concat_bwd, VFE_GRID, grad_out, argmax, dyhat, n_voxels, t, channels);
+    hipLaunchKernelGGL(vfe_max_concat_bwd, VFE_GRID, grad_out, argmax, dyhat, n_voxels, channels, VFE_ROWS);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
 
 extern "C" int mvx_bn_segment_max(const float *y, const float *mean_inv, float *out, int32_t *argmax,
-                                  int32_t n_voxels, int32_t t, int32_t channels, void *stream) {
-    MVX_CHECK_ARG(y && mean_inv && out && argmax && VFE_ARGS_OK);
+                                  int32_t n_voxels, int32_t t, int32_t channels, const int32_t *voff,
+                                  const int32_t *vcnt, int32_t n_real, void *stream) {
+    MVX_CHECK_ARG(y && mean_inv && out && argmax && VFE_ARGS_OK && VFE_ROWS_OK);
     if (n_voxels == 0) return MVX_OK;
-    hipLaunchKernelGGL(bn_segmax, VFE_GRID, y, mean_inv, out, argmax, n_voxels, t, channels);
+    hipLaunchKernelGGL(bn_segmax, VFE_GRID, y, mean_inv, out, argmax, n_voxels, channels, VFE_ROWS);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
 
 extern "C" int mvx_segment_max_backward(const float *dfeat, const int32_t *argmax, float *dyhat, int32_t n_voxels,
-                                        int32_t t, int32_t channels, void *stream) {
-    MVX_CHECK_ARG(dfeat && argmax && dyhat && VFE_ARGS_OK);
+                                        int32_t t, int32_t channels, const int32_t *voff, const int32_t *vcnt,
+                                        int32_t n_real, void *stream) {
+    MVX_CHECK_ARG(dfeat && argmax && dyhat && VFE_ARGS_OK && VFE_ROWS_OK);
     if (n_voxels == 0) return MVX_OK;
-    hipLaunchKernelGGL(segmax_bwd, VFE_GRID, dfeat, argmax, dyhat, n_voxels, t, channels);
+    hipLaunchKernelGGL(segmax_bwd, VFE_GRID, dfeat, argmax, dyhat, n_voxels, channels, VFE_ROWS);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+extern "C" int mvx_voxel_row_offsets(const int32_t *row_map, int32_t n_voxels, int32_t t, int32_t n_real,
+                                     int32_t *voff, int32_t *vcnt, float *row_w, void *stream) {
+    MVX_CHECK_ARG(row_map && voff && vcnt && row_w && n_voxels >= 0 && t > 0 && n_real >= 0);
+    if (n_voxels == 0) return MVX_OK;
+    hipLaunchKernelGGL(voxel_row_offsets, dim3(mvx_cdiv(n_voxels, 256)), dim3(256), 0, (hipStream_t)stream, row_map,
+                       n_voxels, t, n_real, voff, vcnt, row_w);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+extern "C" int mvx_vfe_compact_input(const float *voxels, int32_t vox_channels, const int32_t *rows_sel,
+                                     const float *imfeat, int32_t feat_channels, int32_t n_real, int32_t n_voxels,
+                                     float *out, void *stream) {
+    MVX_CHECK_ARG(voxels && rows_sel && imfeat && out && vox_channels >= 7 && feat_channels > 0);
+    MVX_CHECK_ARG(n_real >= 0 && n_voxels >= 0);
+    const long long total = (long long)(n_real + n_voxels) * (7 + feat_channels);
+    if (total == 0) return MVX_OK;
+    hipLaunchKernelGGL(vfe_compact_input, dim3(mvx_cdiv(total, 256) > 2048 ? 2048 : mvx_cdiv(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, voxels, vox_channels, rows_sel, imfeat, feat_channels, n_real, n_voxels, out);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+extern "C" int mvx_vfe_compact_input_backward(const float *grad_out, int32_t feat_channels, int32_t n_real,
+                                              int32_t n_voxels, float *dimfeat, double *scratch, void *stream) {
+    MVX_CHECK_ARG(grad_out && dimfeat && scratch && feat_channels > 0 && feat_channels <= 256);
+    MVX_CHECK_ARG(n_real >= 0 && n_voxels >= 0);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * feat_channels, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(vfe_compact_input_bwd, dim3(256), dim3(256), 0, st, grad_out, feat_channels, n_real, n_voxels,
+                       dimfeat, scratch);
+    MVX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(vfe_compact_pad_finish, dim3(mvx_cdiv(feat_channels, 64)), dim3(64), 0, st,
+                       (const double *)scratch, dimfeat, n_real, feat_channels);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

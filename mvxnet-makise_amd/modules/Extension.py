@@ -45,10 +45,13 @@ PROTOTYPES = {
     'mvx_linear_forward': (_i32, [_p, _i32, _p, _i32, _i32, _p, _p, _i32, _p, _p, _i64, _i32, _i32, _i32, _p]),
     'mvx_linear_wgrad_workspace_bytes': (_sz, [_i64, _i32, _i32]),
     'mvx_linear_wgrad': (_i32, [_p, _i32, _p, _i32, _p, _i64, _i32, _i32, _p, _sz, _p]),
-    'mvx_vfe_bn_max_concat': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p]),
-    'mvx_vfe_max_concat_backward': (_i32, [_p, _p, _p, _i32, _i32, _i32, _p]),
-    'mvx_bn_segment_max': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p]),
-    'mvx_segment_max_backward': (_i32, [_p, _p, _p, _i32, _i32, _i32, _p]),
+    'mvx_vfe_bn_max_concat': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p]),
+    'mvx_vfe_max_concat_backward': (_i32, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p]),
+    'mvx_bn_segment_max': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p]),
+    'mvx_segment_max_backward': (_i32, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p]),
+    'mvx_voxel_row_offsets': (_i32, [_p, _i32, _i32, _i32, _p, _p, _p, _p]),
+    'mvx_vfe_compact_input': (_i32, [_p, _i32, _p, _p, _i32, _i32, _i32, _p, _p]),
+    'mvx_vfe_compact_input_backward': (_i32, [_p, _i32, _i32, _i32, _p, _p, _p]),
     'mvx_row_compact_workspace_bytes': (_sz, [_i64]),
     'mvx_row_compact_map': (_i32, [_p, _i32, _i64, _p, _p, _p, _p, _sz, _p]),
     'mvx_feature_sample': (_i32, [_p, _i32, _i64, _p, _p, _p, _i32, _i32, _f32, _f32, _f32, _p, _p, _p]),

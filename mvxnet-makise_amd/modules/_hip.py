@@ -307,40 +307,90 @@ def linear_wgrad(x, dz):
 
 
 # ---------------------------------------------------------------------------------------------
-# VFE glue
+# VFE glue (dense [V][T][C] rows, or compact rows described by a CompactRows)
 # ---------------------------------------------------------------------------------------------
-def vfe_bn_max_concat(y, mi, V, T):
+class CompactRows:
+    """Row layout of one frame in compact form: n_real real rows followed by one padded row per
+    voxel (see include/mvx_hip.h, 'Compact rows')."""
+
+    def __init__(self, row_map, rows_sel, n_real, V, T):
+        dev = row_map.device
+        self.row_map, self.rows_sel = row_map, rows_sel
+        self.n_real, self.V, self.T = int(n_real), int(V), int(T)
+        self.voff = torch.empty((V,), dtype=torch.int32, device=dev)
+        self.vcnt = torch.empty((V,), dtype=torch.int32, device=dev)
+        self.row_w = torch.empty((self.n_real + V,), dtype=torch.float32, device=dev)
+        X.check(X.lib.mvx_voxel_row_offsets(X.ptr(row_map), V, T, self.n_real, X.ptr(self.voff), X.ptr(self.vcnt),
+                                            X.ptr(self.row_w), X.stream()), 'mvx_voxel_row_offsets')
+
+    @property
+    def rows(self):
+        return self.n_real + self.V
+
+    @property
+    def count(self):                     # rows of the dense tensor this layout stands for
+        return self.V * self.T
+
+
+def _rows_args(cr):
+    if cr is None:
+        return None, None, 0
+    return X.ptr(cr.voff), X.ptr(cr.vcnt), cr.n_real
+
+
+def vfe_bn_max_concat(y, mi, V, T, cr=None):
     C = mi.shape[1]
-    out = torch.empty((V * T, 2 * C), dtype=torch.float32, device=y.device)
+    out = torch.empty((y.shape[0], 2 * C), dtype=torch.float32, device=y.device)
     am = torch.empty((V, C), dtype=torch.int32, device=y.device)
-    X.check(X.lib.mvx_vfe_bn_max_concat(X.ptr(y), X.ptr(mi), X.ptr(out), X.ptr(am), V, T, C, X.stream()),
+    vo, vc, nr = _rows_args(cr)
+    X.check(X.lib.mvx_vfe_bn_max_concat(X.ptr(y), X.ptr(mi), X.ptr(out), X.ptr(am), V, T, C, vo, vc, nr, X.stream()),
             'mvx_vfe_bn_max_concat')
     return out, am
 
 
-def vfe_max_concat_backward(g, am, V, T):
+def vfe_max_concat_backward(g, am, V, T, cr=None):
     C = am.shape[1]
-    dyh = torch.empty((V * T, C), dtype=torch.float32, device=g.device)
-    X.check(X.lib.mvx_vfe_max_concat_backward(X.ptr(g), X.ptr(am), X.ptr(dyh), V, T, C, X.stream()),
+    dyh = torch.empty((g.shape[0], C), dtype=torch.float32, device=g.device)
+    vo, vc, nr = _rows_args(cr)
+    X.check(X.lib.mvx_vfe_max_concat_backward(X.ptr(g), X.ptr(am), X.ptr(dyh), V, T, C, vo, vc, nr, X.stream()),
             'mvx_vfe_max_concat_backward')
     return dyh
 
 
-def bn_segment_max(y, mi, V, T):
+def bn_segment_max(y, mi, V, T, cr=None):
     C = mi.shape[1]
     out = torch.empty((V, C), dtype=torch.float32, device=y.device)
     am = torch.empty((V, C), dtype=torch.int32, device=y.device)
-    X.check(X.lib.mvx_bn_segment_max(X.ptr(y), X.ptr(mi), X.ptr(out), X.ptr(am), V, T, C, X.stream()),
+    vo, vc, nr = _rows_args(cr)
+    X.check(X.lib.mvx_bn_segment_max(X.ptr(y), X.ptr(mi), X.ptr(out), X.ptr(am), V, T, C, vo, vc, nr, X.stream()),
             'mvx_bn_segment_max')
     return out, am
 
 
-def segment_max_backward(dfeat, am, V, T):
+def segment_max_backward(dfeat, am, V, T, cr=None):
     C = am.shape[1]
-    dyh = torch.empty((V * T, C), dtype=torch.float32, device=dfeat.device)
-    X.check(X.lib.mvx_segment_max_backward(X.ptr(dfeat), X.ptr(am), X.ptr(dyh), V, T, C, X.stream()),
+    rows = cr.rows if cr is not None else V * T
+    dyh = torch.empty((rows, C), dtype=torch.float32, device=dfeat.device)
+    vo, vc, nr = _rows_args(cr)
+    X.check(X.lib.mvx_segment_max_backward(X.ptr(dfeat), X.ptr(am), X.ptr(dyh), V, T, C, vo, vc, nr, X.stream()),
             'mvx_segment_max_backward')
     return dyh
+
+
+def vfe_compact_input(vox2d, imfeat_c, cr):
+    F = imfeat_c.shape[1]
+    out = torch.empty((cr.rows, 7 + F), dtype=torch.float32, device=vox2d.device)
+    X.check(X.lib.mvx_vfe_compact_input(X.ptr(vox2d), vox2d.shape[1], X.ptr(cr.rows_sel), X.ptr(imfeat_c), F,
+                                        cr.n_real, cr.V, X.ptr(out), X.stream()), 'mvx_vfe_compact_input')
+    return out
+
+
+def vfe_compact_input_backward(g, F, cr):
+    d = torch.empty((cr.n_real + 1, F), dtype=torch.float32, device=g.device)
+    scratch = torch.empty((F,), dtype=torch.float64, device=g.device)
+    X.check(X.lib.mvx_vfe_compact_input_backward(X.ptr(g), F, cr.n_real, cr.V, X.ptr(d), X.ptr(scratch), X.stream()),
+            'mvx_vfe_compact_input_backward')
+    return d
 
 
 # ---------------------------------------------------------------------------------------------

@@ -18,9 +18,10 @@ class ImageHead(nn.Module):
             p.requires_grad = False
         self.fusion = ImageFeatureFusion()
 
-    def forward(self, x, voxels, calibs, imsize):
-        """``x``: image (1,3,H,W) or the list of FPN maps; ``voxels``: (1,N,T,9), zeroed in place on
-        padded rows like the reference (imhead/Pipe.py:54-59)."""
+    def forward_compact(self, x, voxels, calibs, imsize):
+        """Fusion branch on compact rows: returns (imfeat (n_real+1, 16), CompactRows).  Row n_real is
+        the shared padded row.  ``voxels`` (1,N,T,9) is zeroed in place on padded rows like the
+        reference (imhead/Pipe.py:54-59)."""
         feats = self.extractor(x)
         v = voxels.squeeze(0) if voxels.dim() == 4 else voxels[0]
         hw = imsize.tolist() if torch.is_tensor(imsize) else list(imsize)
@@ -29,7 +30,7 @@ class ImageHead(nn.Module):
         n, t, c = v.shape
         rows = n * t
         vox2d = v.view(rows, c)
-        row_map, _, n_real = _hip.row_compact_map(vox2d)
+        row_map, rows_sel, n_real = _hip.row_compact_map(vox2d)
         nr = int(n_real)                                   # one host sync, where the reference asserts
         levels = _channels_last_levels(feats, 0)
         width = levels[0].shape[2] * len(levels)
@@ -41,5 +42,11 @@ class ImageHead(nn.Module):
         y = self.fusion.forward_rows(compact, row_w, rows)
         if int(status) & 1:
             raise AssertionError('projected point outside the feature map')
-        dense = ExpandRowsFunction.apply(y, row_map, nr)
-        return dense.view(1, n, t, -1)
+        return y, _hip.CompactRows(row_map, rows_sel, nr, n, t), vox2d
+
+    def forward(self, x, voxels, calibs, imsize):
+        """``x``: image (1,3,H,W) or the list of FPN maps; ``voxels``: (1,N,T,9), zeroed in place on
+        padded rows like the reference.  Returns the dense (1,N,T,16) tensor of the reference."""
+        y, cr, _ = self.forward_compact(x, voxels, calibs, imsize)
+        dense = ExpandRowsFunction.apply(y, cr.row_map, cr.n_real)
+        return dense.view(1, cr.V, cr.T, -1)

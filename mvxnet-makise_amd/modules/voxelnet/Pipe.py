@@ -14,51 +14,70 @@ from modules.layers.Blocks import _as_rows
 
 
 class VFEFunction(torch.autograd.Function):
+    """rows -> [BN(ReLU(fc rows)), per-voxel max].  ``cr``: CompactRows or None (dense [V][T] rows)."""
+
     @staticmethod
-    def forward(ctx, x, w, b, V, T, eps):
-        y, stats = _hip.linear_forward(x, w, b, relu=True, want_stats=True)
+    def forward(ctx, x, w, b, V, T, eps, cr):
+        row_w = cr.row_w if cr is not None else None
+        y, stats = _hip.linear_forward(x, w, b, relu=True, want_stats=True, row_w=row_w)
         mi = _hip.bn_finalize(stats, V * T, eps)
-        out, am = _hip.vfe_bn_max_concat(y, mi, V, T)
+        out, am = _hip.vfe_bn_max_concat(y, mi, V, T, cr)
         ctx.save_for_backward(x, w, y, mi, am)
-        ctx.vt = (V, T)
+        ctx.vt = (V, T, cr)
         return out
 
     @staticmethod
     def backward(ctx, g):
         x, w, y, mi, am = ctx.saved_tensors
-        V, T = ctx.vt
-        dyh = _hip.vfe_max_concat_backward(g.contiguous(), am, V, T)
-        dz, db = _hip.bn_relu_backward(dyh, y, mi, V * T, True, dz=dyh)
+        V, T, cr = ctx.vt
+        dyh = _hip.vfe_max_concat_backward(g.contiguous(), am, V, T, cr)
+        dz, db = _hip.bn_relu_backward(dyh, y, mi, V * T, True, dz=dyh, row_w=cr.row_w if cr is not None else None)
         dw = _hip.linear_wgrad(x, dz)
         dx = None
         if ctx.needs_input_grad[0]:
             dx, _ = _hip.linear_forward(dz, w, None, relu=False, want_stats=False, w_transposed=True)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class FCNMaxFunction(torch.autograd.Function):
-    """rows (V*T, K) -> max_t BN(ReLU(fc)) (V, N): VoxelNet.py:28-33 as one node."""
+    """rows (V*T or compact, K) -> max_t BN(ReLU(fc)) (V, N): VoxelNet.py:28-33 as one node."""
 
     @staticmethod
-    def forward(ctx, x, w, b, V, T, eps):
-        y, stats = _hip.linear_forward(x, w, b, relu=True, want_stats=True)
+    def forward(ctx, x, w, b, V, T, eps, cr):
+        row_w = cr.row_w if cr is not None else None
+        y, stats = _hip.linear_forward(x, w, b, relu=True, want_stats=True, row_w=row_w)
         mi = _hip.bn_finalize(stats, V * T, eps)
-        out, am = _hip.bn_segment_max(y, mi, V, T)
+        out, am = _hip.bn_segment_max(y, mi, V, T, cr)
         ctx.save_for_backward(x, w, y, mi, am)
-        ctx.vt = (V, T)
+        ctx.vt = (V, T, cr)
         return out
 
     @staticmethod
     def backward(ctx, g):
         x, w, y, mi, am = ctx.saved_tensors
-        V, T = ctx.vt
-        dyh = _hip.segment_max_backward(g.contiguous(), am, V, T)
-        dz, db = _hip.bn_relu_backward(dyh, y, mi, V * T, True, dz=dyh)
+        V, T, cr = ctx.vt
+        dyh = _hip.segment_max_backward(g.contiguous(), am, V, T, cr)
+        dz, db = _hip.bn_relu_backward(dyh, y, mi, V * T, True, dz=dyh, row_w=cr.row_w if cr is not None else None)
         dw = _hip.linear_wgrad(x, dz)
         dx = None
         if ctx.needs_input_grad[0]:
             dx, _ = _hip.linear_forward(dz, w, None, relu=False, want_stats=False, w_transposed=True)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
+
+
+class CompactInputFunction(torch.autograd.Function):
+    """VFE-1 input in compact form from the voxel rows and the compact fusion output
+    (the concat of MVXNet.py:26, without materialising the dense (1,N,T,23) tensor)."""
+
+    @staticmethod
+    def forward(ctx, imfeat_c, vox2d, cr):
+        ctx.cr = cr
+        ctx.F = imfeat_c.shape[1]
+        return _hip.vfe_compact_input(vox2d, imfeat_c.contiguous(), cr)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _hip.vfe_compact_input_backward(g.contiguous(), ctx.F, ctx.cr), None, None
 
 
 class VFE(nn.Module):
@@ -71,8 +90,12 @@ class VFE(nn.Module):
 
     def forward(self, x):
         b, n, t, _ = x.shape
-        out = VFEFunction.apply(_as_rows(x), self.fcn.fc.weight, self.fcn.fc.bias, b * n, t, cfg.eps)
+        out = VFEFunction.apply(_as_rows(x), self.fcn.fc.weight, self.fcn.fc.bias, b * n, t, cfg.eps, None)
         return out.reshape(b, n, t, out.shape[-1])
+
+    def forward_compact(self, rows, cr):
+        """Compact rows (n_real + V, cin) -> (n_real + V, 2*cout); exact inside MVXNet."""
+        return VFEFunction.apply(rows, self.fcn.fc.weight, self.fcn.fc.bias, cr.V, cr.T, cfg.eps, cr)
 
 
 class SVFE(nn.Module):
@@ -85,6 +108,9 @@ class SVFE(nn.Module):
 
     def forward(self, x):
         return self.vfe2(self.vfe1(x))
+
+    def forward_compact(self, rows, cr):
+        return self.vfe2.forward_compact(self.vfe1.forward_compact(rows, cr), cr)
 
 
 class CML(nn.Module):

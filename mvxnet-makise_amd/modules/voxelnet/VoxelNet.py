@@ -65,11 +65,17 @@ class VoxelNet(nn.Module):
         """SVFE -> FCN(128,128) -> max over T: (1,N,T,23) -> (N,128) (VoxelNet.py:27-33)."""
         b, n, t, _ = x.shape
         x = self.svfe(x)
-        return Pipe.FCNMaxFunction.apply(_as_rows(x), self.fcn.fc.weight, self.fcn.fc.bias, b * n, t, cfg.eps)
+        return Pipe.FCNMaxFunction.apply(_as_rows(x), self.fcn.fc.weight, self.fcn.fc.bias, b * n, t, cfg.eps, None)
 
-    def middle(self, x, idx):
-        """Everything before the RPN: (1,N,T,23), (N,4) -> (1,128,H,W), channel = c*2+d."""
-        x = self.voxel_features(x)
+    def voxel_features_compact(self, rows, cr):
+        """The same on compact rows (n_real + V, 23) -> (V,128); exact inside MVXNet."""
+        x = self.svfe.forward_compact(rows, cr)
+        return Pipe.FCNMaxFunction.apply(x, self.fcn.fc.weight, self.fcn.fc.bias, cr.V, cr.T, cfg.eps, cr)
+
+    def middle(self, x, idx, compact_rows=None):
+        """Everything before the RPN: (1,N,T,23), (N,4) -> (1,128,H,W), channel = c*2+d.
+        With ``compact_rows`` x is the compact row matrix instead of the dense tensor."""
+        x = self.voxel_features(x) if compact_rows is None else self.voxel_features_compact(x, compact_rows)
         if self.sparse_first_layer:
             # reindex + cml.conv1 fused on the sparse rows (same numbers as the dense path below)
             d, h, w = cfg.voxelshape[2], cfg.voxelshape[0], cfg.voxelshape[1]

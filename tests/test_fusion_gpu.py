@@ -115,6 +115,22 @@ def test_mvxnet_without_extractor_matches_reference(golden):
                 _, l1 = g['gradproj.' + k]
                 gn = p.grad.cpu().numpy().astype(np.float64)
                 assert abs(np.abs(gn).sum() - l1) / l1 < 3e-2, k
+        # compact evaluation of fusion + VFE (real rows + one padded row per voxel) == dense evaluation
+        dense_grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        model.zero_grad()
+        vox2 = torch.from_numpy(g['voxels'].copy())[None].to(DEV)
+        mid_c = model.middle(vox2, feats, idx, [None], imsize, compact=True)
+        assert rel_err(mid_c, mid) < 2e-5
+        (mid_c[0] * torch.from_numpy(g['G']).to(DEV)).sum().backward()
+        for k, p in model.named_parameters():
+            if k not in dense_grads:
+                continue
+            if 'grad.' + k in g64.files:                   # same float64 yardstick as above
+                e_ref = rel_err(g['grad.' + k], g64['grad.' + k])
+                e_hip = rel_err(p.grad, g64['grad.' + k])
+                assert e_hip < 3 * e_ref + 1e-3, (k, e_hip, e_ref)
+            else:
+                assert rel_err(p.grad, dense_grads[k]) < 2e-2, k
         # f64 oracle: the 1e-4 bar against exact arithmetic
         P64 = {k: v.double() for k, v in P.items()}
         vox64 = torch.from_numpy(g['voxels'].copy()).double()

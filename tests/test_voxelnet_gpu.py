@@ -121,6 +121,51 @@ def test_sparse_and_dense_first_layer_paths_agree(golden, small_cfg):
         assert rel_err(res[True][1][k], res[False][1][k]) < 2e-4, k
 
 
+def test_compact_vfe_equals_dense_vfe():
+    """VFE stack on compact rows (real rows + one padded row per voxel, weighted BatchNorm) against
+    the dense (1,N,T,23) evaluation: outputs, weight gradients and the gradient that flows back to
+    the fusion features."""
+    from modules import _hip
+    from modules.imhead.Pipe import ExpandRowsFunction
+    from modules.voxelnet import VoxelNet
+    from modules.voxelnet.Pipe import CompactInputFunction
+    gen = torch.Generator().manual_seed(11)
+    V, T = 700, 35
+    cnt = torch.randint(1, T + 1, (V,), generator=gen)
+    cnt[:40] = T                                            # some voxels without padding
+    vox = torch.zeros(V, T, 9)
+    for v in range(V):
+        vox[v, :cnt[v]] = torch.randn(int(cnt[v]), 9, generator=gen) + 0.1
+    vox = vox.to(DEV)
+    net = VoxelNet().to(DEV)
+    vox2d = vox.view(V * T, 9)
+    row_map, rows_sel, n_real = _hip.row_compact_map(vox2d)
+    nr = int(n_real)
+    assert nr == int(cnt.sum())
+    cr = _hip.CompactRows(row_map, rows_sel, nr, V, T)
+    assert torch.equal(cr.vcnt.cpu(), cnt.int())
+    G = torch.randn(V, 128, generator=gen).to(DEV)
+    imf0 = torch.randn(nr + 1, 16, generator=gen).to(DEV)
+    out = {}
+    for mode in ('dense', 'compact'):
+        net.zero_grad()
+        imf = imf0.clone().requires_grad_(True)
+        if mode == 'dense':
+            dense16 = ExpandRowsFunction.apply(imf, row_map, nr).view(1, V, T, 16)
+            x = torch.cat([vox.view(1, V, T, 9)[..., :7], dense16], -1)
+            feat = net.voxel_features(x)
+        else:
+            feat = net.voxel_features_compact(CompactInputFunction.apply(imf, vox2d, cr), cr)
+        (feat * G).sum().backward()
+        out[mode] = (feat.detach().clone(), imf.grad.clone(),
+                     {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    assert rel_err(out['compact'][0], out['dense'][0]) < 2e-5
+    assert rel_err(out['compact'][1], out['dense'][1]) < 1e-3
+    for k in out['dense'][2]:
+        tol = 2e-2 if k.endswith('bias') else 1e-3     # bias gradients before a BatchNorm are pure cancellation
+        assert rel_err(out['compact'][2][k], out['dense'][2][k]) < tol, k
+
+
 def test_reindex_layout_and_state_dict_keys(small_cfg):
     from modules.voxelnet import VoxelNet
     net = VoxelNet()
