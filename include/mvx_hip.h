@@ -86,11 +86,12 @@ int mvx_voxelize(const float *pcd, const int32_t *perm, const int32_t *n_points,
  * status (optional) bit0 = a coordinate fell outside the grid (row skipped).
  * occupancy (optional) i32 [d][ceil(h/tile_h)][ceil(w/tile_w)]: number of voxels per tile, for the
  * input-sparse first convolution (tile shape from mvx_conv3d_tile_shape).
+ * site_bits (optional) u32 [d][h][ceil(w/32)]: one bit per site that holds a voxel.
  */
 int mvx_scatter_voxels(const float *feat, const int64_t *coords, float *grid, int32_t n_voxels,
                        int32_t channels, int32_t d, int32_t h, int32_t w, int32_t zero_grid,
                        int32_t *status, int32_t *occupancy, int32_t tile_h, int32_t tile_w,
-                       void *stream);
+                       uint32_t *site_bits, void *stream);
 int mvx_gather_voxels(const float *grid, const int64_t *coords, float *feat, int32_t n_voxels,
                       int32_t channels, int32_t d, int32_t h, int32_t w, void *stream);
 
@@ -141,7 +142,9 @@ int mvx_bn_relu_backward(const float *dyhat, const float *y, const float *mean_i
  *                            occupancy (optional, from mvx_scatter_voxels): the input is the scattered
  *                            voxel grid; depth taps whose 3x3 tile neighbourhood is empty and wave
  *                            operand fragments that are all zero are skipped -- only exact-zero
- *                            products are dropped, the result is the dense result.  exec_quads
+ *                            products are dropped, the result is the dense result.  With site_bits
+ *                            too, the wave-autonomous sparse kernel runs (no workgroup barriers,
+ *                            per-wave halo, weight fragments from L2; same result).  exec_quads
  *                            (optional) u64 [1] += executed operand quads (1 quad = 8 MFMAs = 32,768 FLOP)
  *   mvx_conv3d_dgrad         dx [din][h][w][cin] from dz [dout][h][w][cout]
  *   mvx_conv3d_dgrad_sites   dfeat [n_voxels][cin] = rows of dx at the voxel sites only (what
@@ -156,7 +159,7 @@ void mvx_conv3d_tile_shape(int32_t *tile_h, int32_t *tile_w);
 int mvx_conv3d_forward(const float *in, const float *wpk, const float *bias, float *out, double *stats,
                        int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
                        int32_t stride_d, int32_t pad_d, int32_t relu, const int32_t *occupancy,
-                       uint64_t *exec_quads, void *stream);
+                       const uint32_t *site_bits, uint64_t *exec_quads, void *stream);
 int mvx_conv3d_dgrad(const float *dz, const float *wpk_dgrad, float *dx, int32_t din, int32_t dout,
                      int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
                      void *stream);

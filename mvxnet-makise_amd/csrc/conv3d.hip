@@ -222,6 +222,164 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather(const float *__restrict_
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Forward of the input-sparse first layer, wave-autonomous form.
+// Same patch decomposition and accumulator layout as conv3d_gather, but the waves of a
+// workgroup never synchronise inside the K loop: each wave owns 2 rows x 16 sites, keeps a
+// private 4 x 18-site halo in LDS and fetches the weight fragments it needs straight from
+// L2.  A per-site occupancy bitmap (built by the scatter) tells a wave (i) whether its halo holds
+// any voxel for this depth tap and (ii) which of the 9 in-plane taps can see one; everything else
+// is skipped.  Only products with an exact-zero input factor are dropped: the output equals the
+// dense kernel's bit for bit.
+// ------------------------------------------------------------------------------------------
+constexpr int WHH = 4, WHS = WHH * HW;           // wave halo: 4 rows x 18 sites
+
+__global__ __launch_bounds__(256, 2) void conv3d_fwd_sparse_in(const float *__restrict__ in,
+                                                               const float *__restrict__ wpk,
+                                                               const float *__restrict__ bias,
+                                                               float *__restrict__ out, double *__restrict__ stats,
+                                                               Geom g, int relu, const int *__restrict__ occ,
+                                                               const unsigned *__restrict__ bits, int wwords,
+                                                               unsigned long long *__restrict__ exec_quads) {
+    __shared__ __attribute__((aligned(16))) float s_h[4][WHS * PITCH];
+    __shared__ float s_red[4][2 * BN];
+    const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
+    const int tcx = blockIdx.x % tiles_x, tcy = blockIdx.x / tiles_x;
+    const int tx0 = tcx * TW, ty0 = tcy * TH;
+    const int d = blockIdx.y, nb = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int nchunks = g.Cin / BK;
+    float *sh = s_h[wv];
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const int a_base = ((li >> 4) * HW + (li & 15)) * PITCH + 4 * lh;     // local halo row 0 = global row ty0+2wv-1
+    unsigned nquads = 0;
+
+    for (int kd = 0; kd < 3; ++kd) {
+        const int ds = src_depth(g, d, kd);
+        if (ds < 0) continue;
+        int any = 0;
+        for (int yy = max(tcy - 1, 0); yy <= min(tcy + 1, tiles_y - 1); ++yy)
+            for (int xx = max(tcx - 1, 0); xx <= min(tcx + 1, tiles_x - 1); ++xx)
+                any |= occ[((size_t)ds * tiles_y + yy) * tiles_x + xx];
+        if (!any) continue;                                   // block-uniform, exact
+        // ---- occupancy bits of this wave's 4 x 18 halo (lanes 0..3 hold one row each)
+        unsigned rowbits = 0;
+        if (lane < WHH) {
+            const int gy = ty0 + 2 * wv - 1 + lane;
+            if (gy >= 0 && gy < g.H) {
+                const unsigned *rowp = bits + ((size_t)ds * g.H + gy) * wwords;
+                const int gx0 = tx0 - 1;                      // first halo column, may be -1
+                const int base = gx0 < 0 ? 0 : gx0;
+                const int w0 = base >> 5;
+                unsigned long long win = rowp[w0];
+                if (w0 + 1 < wwords) win |= (unsigned long long)rowp[w0 + 1] << 32;
+                win >>= (base & 31);
+                if (gx0 < 0) win <<= 1;                       // column -1 does not exist
+                rowbits = (unsigned)(win & 0x3FFFFull);
+            }
+        }
+        const unsigned rb0 = __shfl(rowbits, 0, 64), rb1 = __shfl(rowbits, 1, 64), rb2 = __shfl(rowbits, 2, 64),
+                       rb3 = __shfl(rowbits, 3, 64);
+        if ((rb0 | rb1 | rb2 | rb3) == 0u) continue;          // wave-uniform: no voxel in this wave's halo
+        unsigned tapmask = 0;
+        {
+            const unsigned pr[3] = {rb0 | rb1, rb1 | rb2, rb2 | rb3};
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+                    if ((pr[a] >> b) & 0xFFFFu) tapmask |= 1u << (a * 3 + b);
+        }
+        for (int cc = 0; cc < nchunks; ++cc) {
+            // ---- stage the wave's halo chunk (72 sites x 32 channels), zero where no voxel / outside
+            for (int c = lane; c < WHS * 8; c += 64) {
+                const int r = c >> 3, part = c & 7;
+                const int hy = r / HW, hx = r % HW;
+                const int gy = ty0 + 2 * wv - 1 + hy, gx = tx0 - 1 + hx;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                const unsigned rb = hy == 0 ? rb0 : (hy == 1 ? rb1 : (hy == 2 ? rb2 : rb3));
+                if ((rb >> hx) & 1u)
+                    v = *(const float4 *)(in + (((size_t)ds * g.H + gy) * g.W + gx) * g.Cin + cc * BK + part * 4);
+                *(float4 *)(sh + r * PITCH + part * 4) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int tap = 0; tap < 9; ++tap) {
+                if (!((tapmask >> tap) & 1u)) continue;       // wave-uniform
+                const int a_off = a_base + ((tap / 3) * HW + (tap % 3)) * PITCH;
+                const float *wt = wpk + ((((size_t)kd * 9 + tap) * nchunks + cc) * g.Cout + (size_t)nb * BN) * BK;
+                float4 av[BK / 8], b0[BK / 8], b1[BK / 8];
+                unsigned qmask = 0;
+#pragma unroll
+                for (int q = 0; q < BK / 8; ++q) {
+                    av[q] = *(const float4 *)(sh + a_off + 8 * q);
+                    const bool nz = av[q].x != 0.f || av[q].y != 0.f || av[q].z != 0.f || av[q].w != 0.f;
+                    if (__ballot(nz) != 0ull) qmask |= 1u << q;
+                }
+                if (!qmask) continue;
+#pragma unroll
+                for (int q = 0; q < BK / 8; ++q) {            // weight fragments straight from L2
+                    b0[q] = *(const float4 *)(wt + (size_t)li * BK + 4 * lh + 8 * q);
+                    b1[q] = *(const float4 *)(wt + (size_t)(32 + li) * BK + 4 * lh + 8 * q);
+                }
+#pragma unroll
+                for (int q = 0; q < BK / 8; ++q) {
+                    if (!((qmask >> q) & 1u)) continue;
+                    ++nquads;
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].x, b0[q].x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].x, b1[q].x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].y, b0[q].y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].y, b1[q].y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].z, b0[q].z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].z, b1[q].z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].w, b0[q].w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].w, b1[q].w, acc1, 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (exec_quads && lane == 0 && nquads) atomicAdd(exec_quads, (unsigned long long)nquads);
+
+    // ---- epilogue: identical to conv3d_gather
+    const int n0 = nb * BN + li, n1 = n0 + 32;
+    const float bias0 = bias ? bias[n0] : 0.f, bias1 = bias ? bias[n1] : 0.f;
+    float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int gy = ty0 + 2 * wv + (row >> 4), gx = tx0 + (row & 15);
+        float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
+        if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+        if (gy < g.H && gx < g.W) {
+            float *o = out + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout;
+            o[n0] = v0;
+            o[n1] = v1;
+            s1a += v0; s2a += v0 * v0;
+            s1b += v1; s2b += v1 * v1;
+        }
+    }
+    if (stats) {
+        s1a += __shfl_xor(s1a, 32, 64); s2a += __shfl_xor(s2a, 32, 64);
+        s1b += __shfl_xor(s1b, 32, 64); s2b += __shfl_xor(s2b, 32, 64);
+        if (lh == 0) {
+            s_red[wv][li] = s1a; s_red[wv][32 + li] = s1b;
+            s_red[wv][BN + li] = s2a; s_red[wv][BN + 32 + li] = s2b;
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const double t = (double)s_red[0][tid] + (double)s_red[1][tid] + (double)s_red[2][tid] + (double)s_red[3][tid];
+            const int which = tid / BN, c = tid % BN;
+            const unsigned rep = (blockIdx.x + blockIdx.y * gridDim.x) % MVX_REP;
+            atomicAdd(stats + ((size_t)rep * 2 + which) * g.Cout + nb * BN + c, t);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // weight gradient
 // ------------------------------------------------------------------------------------------
@@ -515,8 +673,8 @@ extern "C" void mvx_conv3d_tile_shape(int32_t *tile_h, int32_t *tile_w) {
 extern "C" int mvx_conv3d_forward(const float *in, const float *wpk, const float *bias, float *out,
                                   double *stats, int32_t din, int32_t dout, int32_t h, int32_t w,
                                   int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
-                                  int32_t relu, const int32_t *occupancy, uint64_t *exec_quads,
-                                  void *stream) {
+                                  int32_t relu, const int32_t *occupancy, const uint32_t *site_bits,
+                                  uint64_t *exec_quads, void *stream) {
     MVX_CHECK_ARG(in && wpk && out);
     int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
     if (rc) return rc;
@@ -528,8 +686,12 @@ extern "C" int mvx_conv3d_forward(const float *in, const float *wpk, const float
     }
     Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
     const dim3 grid(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), dout, cout / BN);
-    hipLaunchKernelGGL(conv3d_gather, grid, dim3(256), 0, st, in, wpk, bias, out, stats, g, relu, occupancy,
-                       (unsigned long long *)exec_quads);
+    if (occupancy && site_bits)
+        hipLaunchKernelGGL(conv3d_fwd_sparse_in, grid, dim3(256), 0, st, in, wpk, bias, out, stats, g, relu, occupancy,
+                           (const unsigned *)site_bits, (int)mvx_cdiv(w, 32), (unsigned long long *)exec_quads);
+    else
+        hipLaunchKernelGGL(conv3d_gather, grid, dim3(256), 0, st, in, wpk, bias, out, stats, g, relu, occupancy,
+                           (unsigned long long *)exec_quads);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

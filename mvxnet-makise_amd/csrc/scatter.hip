@@ -11,7 +11,7 @@ namespace {
 
 __global__ void scatter_rows(const float *__restrict__ feat, const long long *__restrict__ coords,
                              float *__restrict__ grid, int V, int C, int D, int H, int W, int *status,
-                             int *__restrict__ occ, int tile_h, int tile_w) {
+                             int *__restrict__ occ, int tile_h, int tile_w, unsigned *__restrict__ bits) {
     const int c4 = C >> 2;
     const size_t total = (size_t)V * c4;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -27,6 +27,7 @@ __global__ void scatter_rows(const float *__restrict__ feat, const long long *__
             const int ty = (H + tile_h - 1) / tile_h, tx = (W + tile_w - 1) / tile_w;
             atomicAdd(&occ[((size_t)iz * ty + ix / tile_h) * tx + iy / tile_w], 1);
         }
+        if (bits && part == 0) atomicOr(&bits[((size_t)iz * H + ix) * ((W + 31) / 32) + (iy >> 5)], 1u << (iy & 31));
     }
 }
 
@@ -51,7 +52,7 @@ __global__ void gather_rows(const float *__restrict__ grid, const long long *__r
 extern "C" int mvx_scatter_voxels(const float *feat, const int64_t *coords, float *grid, int32_t n_voxels,
                                   int32_t channels, int32_t d, int32_t h, int32_t w, int32_t zero_grid,
                                   int32_t *status, int32_t *occupancy, int32_t tile_h, int32_t tile_w,
-                                  void *stream) {
+                                  uint32_t *site_bits, void *stream) {
     MVX_CHECK_ARG(grid && channels > 0 && channels % 4 == 0 && d > 0 && h > 0 && w > 0 && n_voxels >= 0);
     hipStream_t st = (hipStream_t)stream;
     if (zero_grid) {
@@ -63,11 +64,15 @@ extern "C" int mvx_scatter_voxels(const float *feat, const int64_t *coords, floa
         hipError_t e = hipMemsetAsync(occupancy, 0, sizeof(int32_t) * (size_t)d * mvx_cdiv(h, tile_h) * mvx_cdiv(w, tile_w), st);
         if (e != hipSuccess) return (int)e;
     }
+    if (site_bits) {
+        hipError_t e = hipMemsetAsync(site_bits, 0, sizeof(uint32_t) * (size_t)d * h * mvx_cdiv(w, 32), st);
+        if (e != hipSuccess) return (int)e;
+    }
     if (n_voxels == 0) return MVX_OK;
     MVX_CHECK_ARG(feat && coords);
     const size_t total = (size_t)n_voxels * (channels / 4);
     hipLaunchKernelGGL(scatter_rows, dim3(mvx_cdiv(total, 256) > 4096 ? 4096 : mvx_cdiv(total, 256)), dim3(256), 0, st,
-                       feat, (const long long *)coords, grid, n_voxels, channels, d, h, w, status, occupancy, tile_h, tile_w);
+                       feat, (const long long *)coords, grid, n_voxels, channels, d, h, w, status, occupancy, tile_h, tile_w, site_bits);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

@@ -34,7 +34,7 @@ PROTOTYPES = {
     'mvx_crop_workspace_bytes': (_sz, [_i32, _i32]),
     'mvx_crop_points': (_i32, [_p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _f64, _f64, _i32, _p, _p, _p, _p, _sz, _p]),
     'mvx_lidar2img': (_i32, [_p, _i32, _i64, _p, _p, _i32, _p, _i32, _i32, _i32, _p, _p]),
-    'mvx_scatter_voxels': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _i32, _i32, _p]),
+    'mvx_scatter_voxels': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _i32, _i32, _p, _p]),
     'mvx_gather_voxels': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_cl_to_bev': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_row_stats': (_i32, [_p, _p, _i64, _i32, _p]),
@@ -60,7 +60,7 @@ PROTOTYPES = {
     'mvx_conv3d_packed_weight_bytes': (_sz, [_i32, _i32]),
     'mvx_conv3d_pack_weights': (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     'mvx_conv3d_tile_shape': (None, [_p, _p]),
-    'mvx_conv3d_forward': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p]),
+    'mvx_conv3d_forward': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
     'mvx_conv3d_dgrad_sites': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_conv3d_wgrad_sites_workspace_bytes': (_sz, [_i32, _i32, _i32]),
     'mvx_conv3d_wgrad_sites': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _sz, _p]),

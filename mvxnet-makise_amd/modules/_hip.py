@@ -108,13 +108,14 @@ def scatter_voxels(feat, coords, dhw, grid=None, zero=True, want_occupancy=False
         grid = torch.empty((D, H, W, C), dtype=torch.float32, device=feat.device)
     status = torch.zeros((1,), dtype=torch.int32, device=feat.device)
     th, tw = conv_tile_shape()
-    occ = None
+    occ = bits = None
     if want_occupancy:
         occ = torch.empty((D, -(-H // th), -(-W // tw)), dtype=torch.int32, device=feat.device)
+        bits = torch.empty((D, H, -(-W // 32)), dtype=torch.int32, device=feat.device)
     X.check(X.lib.mvx_scatter_voxels(X.ptr(feat), X.ptr(coords), X.ptr(grid), V, C, D, H, W, int(zero),
-                                     X.ptr(status), X.ptr(occ), th, tw, X.stream()), 'mvx_scatter_voxels')
+                                     X.ptr(status), X.ptr(occ), th, tw, X.ptr(bits), X.stream()), 'mvx_scatter_voxels')
     if want_occupancy:
-        return grid, status, occ
+        return grid, status, (occ, bits)
     return grid, status
 
 
@@ -209,6 +210,7 @@ def conv3d_forward(x, wpk, bias, cout, sd, pd, relu=True, want_stats=True, occup
     out = torch.empty((dout, H, W, cout), dtype=torch.float32, device=x.device)
     stats = torch.empty((STATS_REPLICAS, 2, cout), dtype=torch.float64, device=x.device) if want_stats else None
     counter = None
+    occ_t, bits_t = occupancy if isinstance(occupancy, tuple) else (occupancy, None)
     if occupancy is not None and KERNEL_TIMERS is not None:
         if SPARSE_QUADS is None:
             SPARSE_QUADS = torch.zeros((1,), dtype=torch.int64, device=x.device)
@@ -217,7 +219,7 @@ def conv3d_forward(x, wpk, bias, cout, sd, pd, relu=True, want_stats=True, occup
     flops = conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None and occupancy is None else 0
     with _Timed(name, flops):
         X.check(X.lib.mvx_conv3d_forward(X.ptr(x), X.ptr(wpk), X.ptr(bias), X.ptr(out), X.ptr(stats),
-                                         din, dout, H, W, cin, cout, sd, pd, int(relu), X.ptr(occupancy),
+                                         din, dout, H, W, cin, cout, sd, pd, int(relu), X.ptr(occ_t), X.ptr(bits_t),
                                          X.ptr(counter), X.stream()), 'mvx_conv3d_forward')
     return out, stats
 

@@ -133,12 +133,13 @@ def test_input_sparse_first_layer_equals_dense(golden):
     w = (torch.randn((64, C, 3, 3, 3), generator=g) / np.sqrt(27 * C)).to(DEV)
     b = (torch.randn((64,), generator=g) * 0.1).to(DEV)
     grid, _, occ = _hip.scatter_voxels(feat, coords, (D, H, W), want_occupancy=True)
-    assert int(occ.sum()) == V
+    assert int(occ[0].sum()) == V
     wpk = _hip.conv3d_pack(w, False)
     dense, st_d = _hip.conv3d_forward(grid, wpk, b, 64, 2, 1)
-    sparse, st_s = _hip.conv3d_forward(grid, wpk, b, 64, 2, 1, occupancy=occ)
-    assert torch.equal(dense, sparse)                      # only exact-zero products were dropped
-    assert torch.allclose(st_d.sum(0), st_s.sum(0), rtol=1e-12)
+    for mode in (occ, occ[0]):                             # wave-autonomous kernel / tile-skipping dense kernel
+        sparse, st_s = _hip.conv3d_forward(grid, wpk, b, 64, 2, 1, occupancy=mode)
+        assert torch.equal(dense, sparse)                  # only exact-zero products were dropped
+        assert torch.allclose(st_d.sum(0), st_s.sum(0), rtol=1e-12)
     dz = torch.randn(dense.shape, generator=g).to(DEV)
     dw_d = _hip.conv3d_wgrad(grid, dz, 2, 1)
     dw_s = _hip.conv3d_wgrad_sites(feat, coords, dz, D, 2, 1)

@@ -43,4 +43,4 @@ for name, mask in (('plane 3 only', iz == 3), ('all but plane 3', iz != 3), ('pl
     q = int(_hip.SPARSE_QUADS)
     _hip.KERNEL_TIMERS = None
     t = timeit(lambda: _hip.conv3d_forward(grid, wpk, b, 64, 2, 1, occupancy=occ))
-    print('%-16s V=%5d  %.1f us   executed %.2f GFLOP  active tiles(occ>0) %d' % (name, c2.shape[0], t, q * 8 * 4096 / 1e9, int((occ > 0).sum())))
+    print('%-16s V=%5d  %.1f us   executed %.2f GFLOP  active tiles(occ>0) %d' % (name, c2.shape[0], t, q * 8 * 4096 / 1e9, int((occ[0] > 0).sum())))
