@@ -290,6 +290,31 @@ int mvx_lidar2img(const float *pcd, int32_t ncol, int64_t n_points, const double
                   const double *p2_host, int32_t math_f32, float *out, int32_t ld_out, int32_t col_offset,
                   int32_t swap_to_row_col, float *cam_z, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Input-sparse first convolution as voxel GEMMs + index-grid gathers (exact up to fp32 summation
+ * order).  Replaces VoxelNet.reindex + cml.conv1 (VoxelNet.py:16-22, Pipe.py:36) and their autograd
+ * without ever building the 721 MB dense input grid:
+ *   mvx_index_grid            grid i32 [d][h][w] = voxel id at occupied sites, -1 elsewhere, followed in the
+ *                             same buffer by a coarse per-tile occupancy count (buffer size:
+ *                             mvx_index_grid_bytes)
+ *   forward:  P = X W_all^T   via mvx_linear_forward (X f32 [V][cin], W_all f32 [27*cout][cin],
+ *                             row (kd*9+a*3+b)*cout + co = W[co][:][kd][a][b])
+ *             mvx_sparse_conv_output:  out [dout][h][w][cout] = [ReLU](bias + sum of the P rows of the
+ *                             <= 27 source voxels of each site), stats as in mvx_conv3d_forward
+ *   backward: mvx_sparse_conv_gather_dz:  G f32 [V][27*cout], G[v][tap*cout + c] = dz at the output site
+ *                             that read voxel v through tap (zero if none)
+ *             dX = G W_all (mvx_linear_forward, w_transposed), dW_all = G^T X (mvx_linear_wgrad)
+ */
+size_t mvx_index_grid_bytes(int32_t d, int32_t h, int32_t w);
+int mvx_index_grid(const int64_t *coords, int32_t n_voxels, int32_t d, int32_t h, int32_t w,
+                   int32_t *grid, int32_t *status, void *stream);
+int mvx_sparse_conv_output(const float *p, const int32_t *index_grid, const float *bias, float *out,
+                           double *stats, int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cout,
+                           int32_t stride_d, int32_t pad_d, int32_t relu, void *stream);
+int mvx_sparse_conv_gather_dz(const float *dz, const int64_t *coords, int32_t n_voxels, float *g_rows,
+                              int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cout,
+                              int32_t stride_d, int32_t pad_d, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

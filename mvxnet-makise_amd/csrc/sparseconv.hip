@@ -1,0 +1,225 @@
+// Input-sparse 3x3x3 convolution as voxel GEMMs + index-grid gathers.
+//
+// The first CML layer (modules/voxelnet/Pipe.py:36, Conv3d 128->64, stride (2,1,1), pad 1) reads the
+// grid that VoxelNet.reindex (VoxelNet.py:16-22) just filled: zero except at the V voxel sites.  Its
+// three passes therefore factor through a [V x 27*Cout] matrix:
+//
+//   forward : P = X W_all^T            (row GEMM, linear.hip; X = voxel rows [V][Cin],
+//                                       W_all[(tap)*Cout + co][ci] = W[co][ci][kd][a][b])
+//             out[site][co] = ReLU(b[co] + sum over the <=27 taps whose source site holds voxel v of
+//                             P[v][tap*Cout + co])            -- `sparse_conv_output` below
+//   dgrad   : G[v][tap*Cout + co] = dz[site that used v through tap][co]  -- `sparse_conv_gather_dz`
+//             dX = G W_all             (row GEMM)
+//   wgrad   : dW_all = G^T X           (row GEMM wgrad)
+//
+// The dense 721 MB input grid is never built: a 5.6 MB int32 index grid (voxel id or -1 per site)
+// stands for it.  The output IS dense (every site gets ReLU(bias) at least), as the reference's.
+// Sums run in a fixed order (k inside the GEMM, then taps in ascending order): deterministic, and
+// equal to the dense convolution up to fp32 summation order.
+#include "common.h"
+
+namespace {
+
+struct SGeom { int Din, Dout, H, W, Cout, sd, pd; };
+constexpr int OTH = 8, OTW = 16;      // coarse occupancy tiles (sites)
+
+__global__ void index_grid_fill(const long long *__restrict__ coords, int V, int D, int H, int W, int *__restrict__ grid,
+                                int *__restrict__ occ, int *__restrict__ status) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const long long ix = coords[(size_t)v * 4 + 1], iy = coords[(size_t)v * 4 + 2], iz = coords[(size_t)v * 4 + 3];
+    if (ix < 0 || ix >= H || iy < 0 || iy >= W || iz < 0 || iz >= D) {
+        if (status) atomicOr(status, 1);
+        return;
+    }
+    grid[((size_t)iz * H + ix) * W + iy] = v;
+    const int ty = (H + OTH - 1) / OTH, tx = (W + OTW - 1) / OTW;
+    atomicAdd(&occ[((size_t)iz * ty + ix / OTH) * tx + iy / OTW], 1);
+}
+
+// One workgroup = one 8 x 16-site occupancy tile of one output plane; a thread = 4 channels of one
+// site per row step (16 sites x Cout/4 threads), walking the 8 rows of the tile.  The coarse
+// occupancy of the 3x3 tile neighbourhood is tested ONCE per workgroup: empty neighbourhoods (about
+// 95 % on lidar frames) are a pure ReLU(bias) fill.
+__global__ __launch_bounds__(256) void sparse_conv_output(const float *__restrict__ P, const int *__restrict__ idx,
+                                                          const int *__restrict__ occ,
+                                                          const float *__restrict__ bias, float *__restrict__ out,
+                                                          double *__restrict__ stats, SGeom g, int relu,
+                                                          int *__restrict__ active_sites) {
+    __shared__ float red[2][256][4];
+    __shared__ int s_idx[3][OTH + 2][OTW + 2];         // voxel ids of the tile's halo, per depth tap
+    const int c4n = g.Cout >> 2;                       // threads per site (16 at Cout = 64)
+    const int ct = threadIdx.x % c4n, st = threadIdx.x / c4n;       // st: site column inside the tile (0..15)
+    const int tyn = (g.H + OTH - 1) / OTH, txn = (g.W + OTW - 1) / OTW;
+    const int tcx = blockIdx.x % txn, tcy = blockIdx.x / txn, d = blockIdx.y;
+    const int x = tcx * OTW + st;
+    int any = 0;
+    for (int kd = 0; kd < 3; ++kd) {
+        const int ds = d * g.sd - g.pd + kd;
+        if (ds < 0 || ds >= g.Din) continue;
+        for (int ty = max(tcy - 1, 0); ty <= min(tcy + 1, tyn - 1); ++ty)
+            for (int tx = max(tcx - 1, 0); tx <= min(tcx + 1, txn - 1); ++tx) any |= occ[((size_t)ds * tyn + ty) * txn + tx];
+    }
+    if (any) {                                         // block-uniform: stage the index halo once
+        for (int e = threadIdx.x; e < 3 * (OTH + 2) * (OTW + 2); e += 256) {
+            const int kd = e / ((OTH + 2) * (OTW + 2)), rem = e % ((OTH + 2) * (OTW + 2));
+            const int hy = rem / (OTW + 2), hx = rem % (OTW + 2);
+            const int ds = d * g.sd - g.pd + kd, gy = tcy * OTH - 1 + hy, gx = tcx * OTW - 1 + hx;
+            int v = -1;
+            if (ds >= 0 && ds < g.Din && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) v = idx[((size_t)ds * g.H + gy) * g.W + gx];
+            s_idx[kd][hy][hx] = v;
+        }
+        __syncthreads();
+    }
+    float4 bs = bias ? *(const float4 *)(bias + ct * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool col_live = st < OTW && x < g.W;
+    int live_sites = 0;
+    for (int r = 0; r < OTH; ++r) {
+        const int y = tcy * OTH + r;
+        if (y >= g.H || !col_live) continue;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (any) {
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        const int v = s_idx[kd][r + a][st + b];       // -1 outside the grid / invalid depth tap
+                        if (v >= 0) {
+                            const float4 p = *(const float4 *)(P + ((size_t)v * 27 + (kd * 9 + a * 3 + b)) * g.Cout + ct * 4);
+                            acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+                        }
+                    }
+        }
+        acc.x += bs.x; acc.y += bs.y; acc.z += bs.z; acc.w += bs.w;
+        if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+        *(float4 *)(out + (((size_t)d * g.H + y) * g.W + x) * g.Cout + ct * 4) = acc;
+        s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
+        s2.x += acc.x * acc.x; s2.y += acc.y * acc.y; s2.z += acc.z * acc.z; s2.w += acc.w * acc.w;
+        ++live_sites;
+    }
+    // Tiles without any source voxel wrote ReLU(bias) everywhere: their share of the BatchNorm sums
+    // is added in closed form by sparse_stats_fix, so only the few active tiles touch the atomics.
+    if (stats && any) {
+        red[0][threadIdx.x][0] = s1.x; red[0][threadIdx.x][1] = s1.y; red[0][threadIdx.x][2] = s1.z; red[0][threadIdx.x][3] = s1.w;
+        red[1][threadIdx.x][0] = s2.x; red[1][threadIdx.x][1] = s2.y; red[1][threadIdx.x][2] = s2.z; red[1][threadIdx.x][3] = s2.w;
+        __syncthreads();
+        const int spb = 256 / c4n;
+        if (ct == 0) atomicAdd(active_sites, live_sites);
+        if (st == 0) {
+            const unsigned rep = (blockIdx.x + blockIdx.y * gridDim.x) % MVX_REP;
+            for (int k = 0; k < 2; ++k)
+                for (int j = 0; j < 4; ++j) {
+                    double t = 0.0;
+                    for (int q = 0; q < spb; ++q) t += (double)red[k][q * c4n + ct][j];
+                    atomicAdd(stats + ((size_t)rep * 2 + k) * g.Cout + ct * 4 + j, t);
+                }
+        }
+    }
+}
+
+__global__ void sparse_stats_fix(double *__restrict__ stats, const float *__restrict__ bias, const int *__restrict__ active_sites,
+                                 long long total_sites, int C, int relu) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double v = bias ? (double)bias[c] : 0.0;
+    if (relu && v < 0.0) v = 0.0;
+    const double n = (double)(total_sites - (long long)*active_sites);
+    stats[c] += n * v;               // replica 0, sum
+    stats[C + c] += n * v * v;       // replica 0, sum of squares
+}
+
+// G[v][tap*Cout + c] = dz[do][ix+1-a][iy+1-b][c] for the output site that read voxel v through tap
+// (kd,a,b): do*sd - pd + kd = iz; zero where that site does not exist.
+__global__ void sparse_conv_gather_dz(const float *__restrict__ dz, const long long *__restrict__ coords, int V,
+                                      float *__restrict__ G, SGeom g) {
+    const int c4n = g.Cout >> 2;
+    const long long total = (long long)V * 27 * c4n;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int ct = (int)(e % c4n);
+        const long long r = e / c4n;
+        const int tap = (int)(r % 27), v = (int)(r / 27);
+        const int kd = tap / 9, a = (tap % 9) / 3, b = tap % 3;
+        const long long *cd = coords + (size_t)v * 4;
+        const int t = (int)cd[3] + g.pd - kd, y = (int)cd[1] + 1 - a, x = (int)cd[2] + 1 - b;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && (t % g.sd) == 0 && t / g.sd < g.Dout && y >= 0 && y < g.H && x >= 0 && x < g.W)
+            val = *(const float4 *)(dz + (((size_t)(t / g.sd) * g.H + y) * g.W + x) * g.Cout + ct * 4);
+        *(float4 *)(G + ((size_t)v * 27 + tap) * g.Cout + ct * 4) = val;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t mvx_index_grid_bytes(int32_t d, int32_t h, int32_t w) {
+    if (d <= 0 || h <= 0 || w <= 0) return 0;
+    return sizeof(int32_t) * ((size_t)d * h * w + (size_t)d * mvx_cdiv(h, OTH) * mvx_cdiv(w, OTW) + 4);
+}
+
+extern "C" int mvx_index_grid(const int64_t *coords, int32_t n_voxels, int32_t d, int32_t h, int32_t w,
+                              int32_t *grid, int32_t *status, void *stream) {
+    MVX_CHECK_ARG(grid && d > 0 && h > 0 && w > 0 && n_voxels >= 0);
+    hipStream_t st = (hipStream_t)stream;
+    int32_t *occ = grid + (size_t)d * h * w;             // coarse occupancy follows the site grid
+    hipError_t e = hipMemsetAsync(grid, 0xFF, sizeof(int32_t) * (size_t)d * h * w, st);   // every site = -1
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(occ, 0, sizeof(int32_t) * (size_t)d * mvx_cdiv(h, OTH) * mvx_cdiv(w, OTW), st);
+    if (e != hipSuccess) return (int)e;
+    if (n_voxels == 0) return MVX_OK;
+    MVX_CHECK_ARG(coords);
+    hipLaunchKernelGGL(index_grid_fill, dim3(mvx_cdiv(n_voxels, 256)), dim3(256), 0, st, (const long long *)coords,
+                       n_voxels, d, h, w, grid, occ, status);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+static int sgeom_ok(int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cout, int32_t sd, int32_t pd) {
+    if (din <= 0 || dout <= 0 || h <= 0 || w <= 0 || cout <= 0 || cout % 4 || cout > 1024) return 0;
+    if (sd < 1 || sd > 2 || pd < 0 || pd > 1) return 0;
+    return dout == (din + 2 * pd - 3) / sd + 1;
+}
+
+extern "C" int mvx_sparse_conv_output(const float *p, const int32_t *index_grid, const float *bias, float *out,
+                                      double *stats, int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cout,
+                                      int32_t stride_d, int32_t pad_d, int32_t relu, void *stream) {
+    MVX_CHECK_ARG(index_grid && out && sgeom_ok(din, dout, h, w, cout, stride_d, pad_d));
+    MVX_CHECK_ARG(cout / 4 * OTW <= 256 && 256 % (cout / 4) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (stats) {
+        hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * MVX_REP * 2 * cout, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    SGeom g{din, dout, h, w, cout, stride_d, pad_d};
+    // the buffer of mvx_index_grid: site grid, coarse occupancy, then a scratch counter
+    int32_t *occ = (int32_t *)index_grid + (size_t)din * h * w;
+    int32_t *active = occ + (size_t)din * mvx_cdiv(h, OTH) * mvx_cdiv(w, OTW);
+    if (stats) {
+        hipError_t e = hipMemsetAsync(active, 0, sizeof(int32_t), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(sparse_conv_output, dim3(mvx_cdiv(w, OTW) * mvx_cdiv(h, OTH), dout), dim3(256), 0, st, p, index_grid,
+                       (const int *)occ, bias, out, stats, g, relu, active);
+    MVX_LAUNCH_CHECK();
+    if (stats) {
+        hipLaunchKernelGGL(sparse_stats_fix, dim3(mvx_cdiv(cout, 64)), dim3(64), 0, st, stats, bias, (const int *)active,
+                           (long long)dout * h * w, cout, relu);
+        MVX_LAUNCH_CHECK();
+    }
+    return MVX_OK;
+}
+
+extern "C" int mvx_sparse_conv_gather_dz(const float *dz, const int64_t *coords, int32_t n_voxels, float *g_rows,
+                                         int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cout,
+                                         int32_t stride_d, int32_t pad_d, void *stream) {
+    MVX_CHECK_ARG(dz && g_rows && n_voxels >= 0 && sgeom_ok(din, dout, h, w, cout, stride_d, pad_d));
+    if (n_voxels == 0) return MVX_OK;
+    MVX_CHECK_ARG(coords);
+    SGeom g{din, dout, h, w, cout, stride_d, pad_d};
+    const long long total = (long long)n_voxels * 27 * (cout / 4);
+    hipLaunchKernelGGL(sparse_conv_gather_dz, dim3(mvx_cdiv(total, 256) > 4096 ? 4096 : mvx_cdiv(total, 256)), dim3(256),
+                       0, (hipStream_t)stream, dz, (const long long *)coords, n_voxels, g_rows, g);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}

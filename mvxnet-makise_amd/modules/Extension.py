@@ -37,6 +37,10 @@ PROTOTYPES = {
     'mvx_scatter_voxels': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _i32, _i32, _p, _p]),
     'mvx_gather_voxels': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_cl_to_bev': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    'mvx_index_grid_bytes': (_sz, [_i32, _i32, _i32]),
+    'mvx_index_grid': (_i32, [_p, _i32, _i32, _i32, _i32, _p, _p, _p]),
+    'mvx_sparse_conv_output': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    'mvx_sparse_conv_gather_dz': (_i32, [_p, _p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_row_stats': (_i32, [_p, _p, _i64, _i32, _p]),
     'mvx_bn_finalize': (_i32, [_p, _f64, _f64, _p, _i32, _p]),
     'mvx_bn_apply': (_i32, [_p, _p, _p, _i64, _i32, _p]),

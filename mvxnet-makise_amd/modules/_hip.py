@@ -489,3 +489,35 @@ def lidar2img(pcd2d, cam_from_velo, p2, math_f32=True, out=None, col_offset=0, s
     X.check(X.lib.mvx_lidar2img(X.ptr(pcd2d), ncol, n, m_ptr, p_ptr, int(math_f32), _vptr(out), _ld(out), col_offset,
                                 int(swap_rc), X.ptr(z), X.stream()), 'mvx_lidar2img')
     return out, z
+
+
+# ---------------------------------------------------------------------------------------------
+# input-sparse convolution as voxel GEMMs + index-grid gathers
+# ---------------------------------------------------------------------------------------------
+def index_grid(coords, dhw):
+    D, H, W = dhw
+    buf = torch.empty((X.lib.mvx_index_grid_bytes(D, H, W) // 4,), dtype=torch.int32, device=coords.device)
+    status = torch.zeros((1,), dtype=torch.int32, device=coords.device)
+    X.check(X.lib.mvx_index_grid(X.ptr(coords), coords.shape[0], D, H, W, X.ptr(buf), X.ptr(status), X.stream()),
+            'mvx_index_grid')
+    return buf, status
+
+
+def sparse_conv_output(P, idx_grid, dhw, bias, cout, sd, pd, relu=True, want_stats=True):
+    din, H, W = dhw
+    dout = conv_out_depth(din, sd, pd)
+    out = torch.empty((dout, H, W, cout), dtype=torch.float32, device=P.device)
+    stats = torch.empty((STATS_REPLICAS, 2, cout), dtype=torch.float64, device=P.device) if want_stats else None
+    with _Timed('sparse_conv_output', 0):
+        X.check(X.lib.mvx_sparse_conv_output(X.ptr(P), X.ptr(idx_grid), X.ptr(bias), X.ptr(out), X.ptr(stats), din, dout,
+                                             H, W, cout, sd, pd, int(relu), X.stream()), 'mvx_sparse_conv_output')
+    return out, stats
+
+
+def sparse_conv_gather_dz(dz, coords, din, sd, pd):
+    dout, H, W, cout = dz.shape
+    V = coords.shape[0]
+    G = torch.empty((V, 27 * cout), dtype=torch.float32, device=dz.device)
+    X.check(X.lib.mvx_sparse_conv_gather_dz(X.ptr(dz), X.ptr(coords), V, X.ptr(G), din, dout, H, W, cout, sd, pd,
+                                            X.stream()), 'mvx_sparse_conv_gather_dz')
+    return G

@@ -139,6 +139,41 @@ class SparseInputCRB3dFunction(torch.autograd.Function):
         return dfeat, None, dw, db, None, None, None, None
 
 
+class VoxelGemmCRB3dFunction(torch.autograd.Function):
+    """reindex + first CRB3d through the [V x 27*Cout] factorisation (csrc/sparseconv.hip): one row
+    GEMM + one index-grid gather per pass, no dense input grid.  Equal to the dense evaluation up to
+    fp32 summation order."""
+
+    @staticmethod
+    def forward(ctx, feat, coords, w, b, dhw, sd, pd, eps):
+        cout, cin = w.shape[0], w.shape[1]
+        feat = feat.contiguous()
+        w_all = w.permute(2, 3, 4, 0, 1).reshape(27 * cout, cin).contiguous()
+        P, _ = _hip.linear_forward(feat, w_all, None, relu=False, want_stats=False)
+        idx_grid, status = _hip.index_grid(coords, dhw)
+        y, stats = _hip.sparse_conv_output(P, idx_grid, dhw, b, cout, sd, pd, relu=True, want_stats=True)
+        count = y.numel() // cout
+        mi = _hip.bn_finalize(stats, count, eps)
+        out = _hip.bn_apply(y, mi)
+        ctx.save_for_backward(feat, coords, w_all, y, mi)
+        ctx.geom = (dhw[0], sd, pd, count, tuple(w.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        feat, coords, w_all, y, mi = ctx.saved_tensors
+        din, sd, pd, count, wshape = ctx.geom
+        cout, cin = wshape[0], wshape[1]
+        dz, db = _hip.bn_relu_backward(g.contiguous(), y, mi, count, True)
+        G = _hip.sparse_conv_gather_dz(dz, coords, din, sd, pd)
+        dw_all = _hip.linear_wgrad(feat, G)                                   # (27*cout, cin)
+        dw = dw_all.reshape(3, 3, 3, cout, cin).permute(3, 4, 0, 1, 2).contiguous()
+        dfeat = None
+        if ctx.needs_input_grad[0]:
+            dfeat, _ = _hip.linear_forward(G, w_all, None, relu=False, want_stats=False, w_transposed=True)
+        return dfeat, None, dw, db, None, None, None, None
+
+
 def _triple(v):
     return tuple(v) if isinstance(v, (tuple, list)) else (v, v, v)
 
@@ -158,11 +193,12 @@ class CRB3d(nn.Module):
         if k3 != (3, 3, 3) or s3[1:] != (1, 1) or p3[1:] != (1, 1) or s3[0] not in (1, 2) or p3[0] not in (0, 1):
             raise NotImplementedError('CRB3d HIP kernel: kernel 3, stride (s,1,1), padding (p,1,1) only')
         self._sd, self._pd = s3[0], p3[0]
+        self.voxel_gemm = True          # forward_voxels: voxel-GEMM factorisation (else zero-skipping dense kernels)
 
     def forward_voxels(self, feat, coords, dhw):
         """Fused reindex + this block on sparse voxel rows (exact, see SparseInputCRB3dFunction)."""
-        out = SparseInputCRB3dFunction.apply(feat, coords, self.conv.weight, self.conv.bias, tuple(dhw), self._sd,
-                                             self._pd, cfg.eps)
+        fn = VoxelGemmCRB3dFunction if self.voxel_gemm else SparseInputCRB3dFunction
+        out = fn.apply(feat, coords, self.conv.weight, self.conv.bias, tuple(dhw), self._sd, self._pd, cfg.eps)
         return out.permute(3, 0, 1, 2).unsqueeze(0)
 
     def forward(self, x):

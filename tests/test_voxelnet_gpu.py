@@ -110,15 +110,17 @@ def test_sparse_and_dense_first_layer_paths_agree(golden, small_cfg):
     idx = torch.from_numpy(g['idx']).to(DEV)
     G = torch.from_numpy(g['G']).to(DEV)
     res = {}
-    for mode in (True, False):
-        net.sparse_first_layer = mode
+    for mode in ('gemm', 'skip', 'dense'):
+        net.sparse_first_layer = mode != 'dense'
+        net.cml.conv1.voxel_gemm = mode == 'gemm'
         net.zero_grad()
         mid = net.middle(x, idx)
         (mid[0] * G).sum().backward()
         res[mode] = (mid.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
-    assert rel_err(res[True][0], res[False][0]) < 1e-6
-    for k in res[True][1]:
-        assert rel_err(res[True][1][k], res[False][1][k]) < 2e-4, k
+    for mode in ('gemm', 'skip'):
+        assert rel_err(res[mode][0], res['dense'][0]) < 2e-6
+        for k in res[mode][1]:
+            assert rel_err(res[mode][1][k], res['dense'][1][k]) < 2e-4, (mode, k)
 
 
 def test_compact_vfe_equals_dense_vfe():
