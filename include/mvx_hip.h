@@ -315,6 +315,22 @@ int mvx_sparse_conv_gather_dz(const float *dz, const int64_t *coords, int32_t n_
                               int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cout,
                               int32_t stride_d, int32_t pad_d, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * "bf16x3" variants of the dense convolution: every f32 operand is split into hi + lo bf16 and a
+ * product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with f32 accumulation (per-product
+ * relative error ~2e-5, i.e. fp32-grade for the 1e-4 feature bar; ~5x the rate of the exact-f32
+ * MFMA).  Same arguments and layouts as the f32 entry points; weights are packed (and pre-split) by
+ * mvx_conv3d_pack_weights_split (same byte size as mvx_conv3d_packed_weight_bytes).
+ */
+int mvx_conv3d_pack_weights_split(const float *w, void *wsplit, int32_t cout, int32_t cin, int32_t for_dgrad,
+                                  void *stream);
+int mvx_conv3d_forward_split(const float *in, const void *wsplit, const float *bias, float *out, double *stats,
+                             int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                             int32_t stride_d, int32_t pad_d, int32_t relu, void *stream);
+int mvx_conv3d_dgrad_split(const float *dz, const void *wsplit_dgrad, float *dx, int32_t din, int32_t dout,
+                           int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
+                           void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,263 @@
+// Dense 3x3x3 convolution on the bf16 matrix cores with fp32-grade accuracy ("bf16x3" split).
+//
+// Every f32 operand x is split on the fly into two bf16 numbers, hi = bf16(x) and
+// lo = bf16(x - hi) (together 16 mantissa bits), and a product is evaluated as
+//     x*w  ~=  hi_x*hi_w + hi_x*lo_w + lo_x*hi_w            (3 v_mfma_f32_32x32x16_bf16, f32 accumulate)
+// The dropped terms are O(2^-16 |x w|): per-product relative error ~2e-5, far inside the 1e-4 bar of
+// the fp32 features (tests compare against the float64 oracle).  A bf16 MFMA retires 16x the MACs
+// per cycle of the exact-f32 MFMA, so three of them are ~5x faster than one f32 MFMA step.
+//
+// Structure = conv3d.hip's gather kernel (8x16-site patch x 64 output channels per workgroup, wave w
+// owns rows 2w,2w+1; halo staged once per (depth tap, 32-channel chunk)), with:
+//   - LDS rows of 144 bytes: 32 hi (64 B) | 32 lo (64 B) | 16 B pad -> ds_read_b128 operand fetches
+//     (8 consecutive k per lane, the native 32x32x16 A/B fragment) are bank-conflict free;
+//   - the f32 -> (hi, lo) split of the activations happens while the halo is staged;
+//   - weights are pre-split by the pack kernel and staged three taps (one kernel row) at a time, so a
+//     barrier pair covers 3 taps x 12 MFMAs per wave instead of one tap.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int TH = 8, TW = 16, HH = TH + 2, HW = TW + 2;
+constexpr int BK = 32, BN = 64;
+constexpr int ROWB = 144;                         // bytes per LDS row: 64 hi + 64 lo + 16 pad
+constexpr int WTILE = BN * 2 * BK * 2;            // bytes of one packed weight tile in global memory (8 KB)
+
+struct Geom {
+    int Din, Dout, H, W, Cin, Cout, sd, pd, mode;
+};
+
+__device__ __forceinline__ int src_depth(const Geom &g, int d, int kd) {
+    if (g.mode == 0) {
+        const int s = d * g.sd - g.pd + kd;
+        return (s >= 0 && s < g.Din) ? s : -1;
+    }
+    const int t = d + g.pd - kd;
+    if (t < 0 || (t % g.sd) != 0) return -1;
+    const int s = t / g.sd;
+    return s < g.Din ? s : -1;
+}
+
+__device__ __forceinline__ void split4(const float4 v, uint2 *hi, uint2 *lo) {
+    // hi = bf16(x) (round to nearest even), lo = bf16(x - hi)
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    unsigned short h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const __bf16 hb = (__bf16)x[j];
+        const __bf16 lb = (__bf16)(x[j] - (float)hb);
+        h[j] = __builtin_bit_cast(unsigned short, hb);
+        l[j] = __builtin_bit_cast(unsigned short, lb);
+    }
+    hi->x = (unsigned)h[0] | ((unsigned)h[1] << 16); hi->y = (unsigned)h[2] | ((unsigned)h[3] << 16);
+    lo->x = (unsigned)l[0] | ((unsigned)l[1] << 16); lo->y = (unsigned)l[2] | ((unsigned)l[3] << 16);
+}
+
+// torch W[co][ci][kd][kh][kw] -> wsp[kd][tap][chunk][n][hi 32 | lo 32] (bf16), forward or dgrad view
+__global__ void pack_weights_split(const float *__restrict__ w, unsigned short *__restrict__ wsp, int Co, int Ci, int dgrad) {
+    const int K = dgrad ? Co : Ci, N = dgrad ? Ci : Co;
+    const int nch = K / BK;
+    const long long total = 27ll * K * N;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(e % BK);
+        long long r = e / BK;
+        const int n = (int)(r % N); r /= N;
+        const int ch = (int)(r % nch); r /= nch;
+        const int tap = (int)(r % 9);
+        const int kd = (int)(r / 9);
+        const int a = tap / 3, b = tap % 3;
+        const int kk = ch * BK + k;
+        const int co = dgrad ? kk : n, ci = dgrad ? n : kk;
+        const int kh = dgrad ? 2 - a : a, kw = dgrad ? 2 - b : b;
+        const float x = w[((((long long)co * Ci + ci) * 3 + kd) * 3 + kh) * 3 + kw];
+        const __bf16 hb = (__bf16)x;
+        const __bf16 lb = (__bf16)(x - (float)hb);
+        const long long row = (((long long)kd * 9 + tap) * nch + ch) * N + n;
+        wsp[row * 2 * BK + k] = __builtin_bit_cast(unsigned short, hb);
+        wsp[row * 2 * BK + BK + k] = __builtin_bit_cast(unsigned short, lb);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void conv3d_gather_split(const float *__restrict__ in,
+                                                              const unsigned short *__restrict__ wsp,
+                                                              const float *__restrict__ bias,
+                                                              float *__restrict__ out, double *__restrict__ stats,
+                                                              Geom g, int relu) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_halo[HH * HW * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char s_w[3][BN * ROWB];
+    __shared__ float s_red[4][2 * BN];
+    const int tiles_x = (g.W + TW - 1) / TW;
+    const int tx0 = (blockIdx.x % tiles_x) * TW, ty0 = (blockIdx.x / tiles_x) * TH;
+    const int d = blockIdx.y, nb = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int nchunks = g.Cin / BK;
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const int my_ty = 2 * wv + (li >> 4), my_tx = li & 15;
+    const int a_base = (my_ty * HW + my_tx) * ROWB + lh * 16;     // bytes; + part*64 + kstep*32
+    const int b_base = li * ROWB + lh * 16;
+
+    // three weight tiles (one kernel row) = 3 x 8 KB = 1536 x 16 B -> 6 per thread
+    uint4 wreg[6];
+    auto load_w3 = [&](int kd, int a, int cc) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int c = tid + 256 * u;              // 0..1535
+            const int t = c >> 9, rem = c & 511;      // tap in row, 16-byte piece of the tile
+            const unsigned char *tile = (const unsigned char *)wsp +
+                ((((size_t)kd * 9 + a * 3 + t) * nchunks + cc) * g.Cout + (size_t)nb * BN) * (2 * BK * 2);
+            wreg[u] = *(const uint4 *)(tile + (size_t)rem * 16);
+        }
+    };
+    auto store_w3 = [&]() {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int c = tid + 256 * u;
+            const int t = c >> 9, rem = c & 511;
+            const int n = rem >> 3, piece = rem & 7;  // 8 pieces of 16 B per 128-B row
+            *(uint4 *)(s_w[t] + n * ROWB + piece * 16) = wreg[u];
+        }
+    };
+
+    for (int kd = 0; kd < 3; ++kd) {
+        const int ds = src_depth(g, d, kd);
+        if (ds < 0) continue;
+        for (int cc = 0; cc < nchunks; ++cc) {
+            __syncthreads();
+            // ---- stage the halo, splitting f32 -> (hi, lo) bf16
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int c = tid + 256 * u;
+                if (c < HH * HW * 8) {
+                    const int r = c >> 3, part = c & 7;
+                    const int gy = ty0 - 1 + r / HW, gx = tx0 - 1 + r % HW;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W)
+                        v = *(const float4 *)(in + (((size_t)ds * g.H + gy) * g.W + gx) * g.Cin + cc * BK + part * 4);
+                    uint2 hi, lo;
+                    split4(v, &hi, &lo);
+                    *(uint2 *)(s_halo + r * ROWB + part * 8) = hi;
+                    *(uint2 *)(s_halo + r * ROWB + 64 + part * 8) = lo;
+                }
+            }
+            load_w3(kd, 0, cc);
+            for (int a = 0; a < 3; ++a) {
+                if (a) __syncthreads();
+                store_w3();
+                __syncthreads();
+                if (a < 2) load_w3(kd, a + 1, cc);
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const int a_off = a_base + (a * HW + b) * ROWB;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_halo + a_off + s * 32));
+                        const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_halo + a_off + 64 + s * 32));
+                        const bf16x8 b0h = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_w[b] + b_base + s * 32));
+                        const bf16x8 b0l = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_w[b] + b_base + 64 + s * 32));
+                        const bf16x8 b1h = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_w[b] + b_base + 32 * ROWB + s * 32));
+                        const bf16x8 b1l = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_w[b] + b_base + 32 * ROWB + 64 + s * 32));
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b0h, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b1h, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0l, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1l, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0h, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1h, acc1, 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    const int n0 = nb * BN + li, n1 = n0 + 32;
+    const float bias0 = bias ? bias[n0] : 0.f, bias1 = bias ? bias[n1] : 0.f;
+    float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int gy = ty0 + 2 * wv + (row >> 4), gx = tx0 + (row & 15);
+        float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
+        if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+        if (gy < g.H && gx < g.W) {
+            float *o = out + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout;
+            o[n0] = v0;
+            o[n1] = v1;
+            s1a += v0; s2a += v0 * v0;
+            s1b += v1; s2b += v1 * v1;
+        }
+    }
+    if (stats) {
+        s1a += __shfl_xor(s1a, 32, 64); s2a += __shfl_xor(s2a, 32, 64);
+        s1b += __shfl_xor(s1b, 32, 64); s2b += __shfl_xor(s2b, 32, 64);
+        __syncthreads();
+        if (lh == 0) {
+            s_red[wv][li] = s1a; s_red[wv][32 + li] = s1b;
+            s_red[wv][BN + li] = s2a; s_red[wv][BN + 32 + li] = s2b;
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const double t = (double)s_red[0][tid] + (double)s_red[1][tid] + (double)s_red[2][tid] + (double)s_red[3][tid];
+            const int which = tid / BN, c = tid % BN;
+            const unsigned rep = (blockIdx.x + blockIdx.y * gridDim.x) % MVX_REP;
+            atomicAdd(stats + ((size_t)rep * 2 + which) * g.Cout + nb * BN + c, t);
+        }
+    }
+}
+
+int check_geom(int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t sd, int32_t pd) {
+    if (din <= 0 || dout <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return MVX_EINVAL;
+    if (sd < 1 || sd > 2 || pd < 0 || pd > 1) return MVX_EINVAL;
+    if (cin % BK || cout % BN) return MVX_ESIZE;
+    return MVX_OK;
+}
+
+}  // namespace
+
+extern "C" int mvx_conv3d_pack_weights_split(const float *w, void *wsplit, int32_t cout, int32_t cin, int32_t for_dgrad,
+                                             void *stream) {
+    MVX_CHECK_ARG(w && wsplit && cout > 0 && cin > 0);
+    MVX_CHECK_ARG((for_dgrad ? cout : cin) % BK == 0);
+    const long long total = 27ll * cout * cin;
+    hipLaunchKernelGGL(pack_weights_split, dim3(mvx_cdiv(total, 256) > 2048 ? 2048 : mvx_cdiv(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, w, (unsigned short *)wsplit, cout, cin, for_dgrad);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+extern "C" int mvx_conv3d_forward_split(const float *in, const void *wsplit, const float *bias, float *out, double *stats,
+                                        int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                                        int32_t stride_d, int32_t pad_d, int32_t relu, void *stream) {
+    MVX_CHECK_ARG(in && wsplit && out);
+    int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
+    if (rc) return rc;
+    MVX_CHECK_ARG(dout == (din + 2 * pad_d - 3) / stride_d + 1);
+    hipStream_t st = (hipStream_t)stream;
+    if (stats) {
+        hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * MVX_REP * 2 * cout, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
+    hipLaunchKernelGGL(conv3d_gather_split, dim3(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), dout, cout / BN), dim3(256), 0, st, in,
+                       (const unsigned short *)wsplit, bias, out, stats, g, relu);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+extern "C" int mvx_conv3d_dgrad_split(const float *dz, const void *wsplit_dgrad, float *dx, int32_t din, int32_t dout,
+                                      int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
+                                      void *stream) {
+    MVX_CHECK_ARG(dz && wsplit_dgrad && dx);
+    int rc = check_geom(din, dout, h, w, cout, cin, stride_d, pad_d);
+    if (rc) return rc;
+    Geom g{dout, din, h, w, cout, cin, stride_d, pad_d, 1};
+    hipLaunchKernelGGL(conv3d_gather_split, dim3(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), din, cin / BN), dim3(256), 0,
+                       (hipStream_t)stream, dz, (const unsigned short *)wsplit_dgrad, (const float *)nullptr, dx,
+                       (double *)nullptr, g, 0);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}

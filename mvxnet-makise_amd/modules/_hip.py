@@ -186,12 +186,13 @@ def bn_relu_backward(dyhat, y, mi, count, want_dbias=True, dz=None, row_w=None):
 # ---------------------------------------------------------------------------------------------
 # dense 3x3x3 convolution (channels-last, one frame)
 # ---------------------------------------------------------------------------------------------
-def conv3d_pack(weight, for_dgrad):
+def conv3d_pack(weight, for_dgrad, split=False):
+    """Kernel-layout weights; split=True: pre-split (hi, lo) bf16 pairs for the bf16x3 kernels."""
     cout, cin = weight.shape[0], weight.shape[1]
     assert tuple(weight.shape[2:]) == (3, 3, 3)
     wpk = torch.empty((27 * cout * cin,), dtype=torch.float32, device=weight.device)
-    X.check(X.lib.mvx_conv3d_pack_weights(X.ptr(weight.contiguous()), X.ptr(wpk), cout, cin, int(for_dgrad),
-                                          X.stream()), 'mvx_conv3d_pack_weights')
+    fn = X.lib.mvx_conv3d_pack_weights_split if split else X.lib.mvx_conv3d_pack_weights
+    X.check(fn(X.ptr(weight.contiguous()), X.ptr(wpk), cout, cin, int(for_dgrad), X.stream()), 'mvx_conv3d_pack_weights')
     return wpk
 
 
@@ -202,13 +203,21 @@ def conv_out_depth(din, sd, pd):
 SPARSE_QUADS = None      # u64 device counter of executed operand quads of input-sparse launches
 
 
-def conv3d_forward(x, wpk, bias, cout, sd, pd, relu=True, want_stats=True, occupancy=None):
-    """occupancy: per-tile voxel counts of the scattered input grid -> exact zero-skipping."""
+def conv3d_forward(x, wpk, bias, cout, sd, pd, relu=True, want_stats=True, occupancy=None, split=False):
+    """occupancy: per-tile voxel counts of the scattered input grid -> exact zero-skipping.
+    split=True: bf16x3 kernel (wpk from conv3d_pack(..., split=True))."""
     global SPARSE_QUADS
     din, H, W, cin = x.shape
     dout = conv_out_depth(din, sd, pd)
     out = torch.empty((dout, H, W, cout), dtype=torch.float32, device=x.device)
     stats = torch.empty((STATS_REPLICAS, 2, cout), dtype=torch.float64, device=x.device) if want_stats else None
+    if split:
+        assert occupancy is None
+        with _Timed('conv3d_gather_split', conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None else 0):
+            X.check(X.lib.mvx_conv3d_forward_split(X.ptr(x), X.ptr(wpk), X.ptr(bias), X.ptr(out), X.ptr(stats), din, dout,
+                                                   H, W, cin, cout, sd, pd, int(relu), X.stream()),
+                    'mvx_conv3d_forward_split')
+        return out, stats
     counter = None
     occ_t, bits_t = occupancy if isinstance(occupancy, tuple) else (occupancy, None)
     if occupancy is not None and KERNEL_TIMERS is not None:
@@ -245,9 +254,14 @@ def conv3d_wgrad_sites(feat, coords, dz, din, sd, pd):
     return dw
 
 
-def conv3d_dgrad(dz, wpk_d, din, cin, sd, pd):
+def conv3d_dgrad(dz, wpk_d, din, cin, sd, pd, split=False):
     dout, H, W, cout = dz.shape
     dx = torch.empty((din, H, W, cin), dtype=torch.float32, device=dz.device)
+    if split:
+        with _Timed('conv3d_gather_split', conv_flops(din, dout, H, W, cout, cin, sd, pd, True) if KERNEL_TIMERS is not None else 0):
+            X.check(X.lib.mvx_conv3d_dgrad_split(X.ptr(dz), X.ptr(wpk_d), X.ptr(dx), din, dout, H, W, cin, cout, sd, pd,
+                                                 X.stream()), 'mvx_conv3d_dgrad_split')
+        return dx
     with _Timed('conv3d_gather', conv_flops(din, dout, H, W, cout, cin, sd, pd, True) if KERNEL_TIMERS is not None else 0):
         X.check(X.lib.mvx_conv3d_dgrad(X.ptr(dz), X.ptr(wpk_d), X.ptr(dx), din, dout, H, W, cin, cout, sd, pd,
                                        X.stream()), 'mvx_conv3d_dgrad')

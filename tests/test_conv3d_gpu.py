@@ -148,3 +148,25 @@ def test_input_sparse_first_layer_equals_dense(golden):
     df_d = _hip.gather_voxels(dx, coords, V)
     df_s = _hip.conv3d_dgrad_sites(dz, _hip.conv3d_pack(w, True), coords, V, D, C, 2, 1)
     assert rel_err(df_s.cpu(), df_d.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize('cin,cout,din,H,W,sd,pd', GEOMS[:4])
+def test_conv3d_bf16x3_split_accuracy(cin, cout, din, H, W, sd, pd):
+    """bf16x3 kernels against float64: fp32-grade accuracy (well inside the 1e-4 feature bar)."""
+    from modules import _hip
+    g = torch.Generator().manual_seed(cin + 3 * H)
+    x = torch.randn((cin, din, H, W), generator=g)
+    w = torch.randn((cout, cin, 3, 3, 3), generator=g) / np.sqrt(27 * cin)
+    b = torch.randn((cout,), generator=g) * 0.1
+    y = F.relu(F.conv3d(x[None].double(), w.double(), b.double(), (sd, 1, 1), (pd, 1, 1)))[0]
+    xc = to_cl(x).to(DEV)
+    wd = w.to(DEV)
+    out, stats = _hip.conv3d_forward(xc, _hip.conv3d_pack(wd, False, split=True), b.to(DEV), cout, sd, pd, split=True)
+    assert rel_err(out.cpu().permute(3, 0, 1, 2), y) < 2e-5
+    np.testing.assert_allclose(stats.sum(0)[0].cpu().numpy(), y.numpy().reshape(cout, -1).sum(1), rtol=1e-4, atol=5e-2)
+    if cin % 64 == 0:
+        dz = torch.randn(y.shape, generator=g)
+        xg = x[None].double().requires_grad_(True)
+        F.conv3d(xg, w.double(), None, (sd, 1, 1), (pd, 1, 1)).backward(dz[None].double())
+        dx = _hip.conv3d_dgrad(to_cl(dz).to(DEV), _hip.conv3d_pack(wd, True, split=True), din, cin, sd, pd, split=True)
+        assert rel_err(dx.cpu().permute(3, 0, 1, 2), xg.grad[0]) < 2e-5
