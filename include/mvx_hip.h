@@ -330,6 +330,9 @@ int mvx_conv3d_forward_split(const float *in, const void *wsplit, const float *b
 int mvx_conv3d_dgrad_split(const float *dz, const void *wsplit_dgrad, float *dx, int32_t din, int32_t dout,
                            int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
                            void *stream);
+int mvx_conv3d_wgrad_split(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
+                           int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
+                           void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

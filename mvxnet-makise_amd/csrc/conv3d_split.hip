@@ -24,7 +24,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int TH = 8, TW = 16, HH = TH + 2, HW = TW + 2;
 constexpr int BK = 32, BN = 64;
 constexpr int ROWB = 144;                         // bytes per LDS row: 64 hi + 64 lo + 16 pad
-constexpr int WTILE = BN * 2 * BK * 2;            // bytes of one packed weight tile in global memory (8 KB)
 
 struct Geom {
     int Din, Dout, H, W, Cin, Cout, sd, pd, mode;
@@ -209,6 +208,162 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_split(const float *__res
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// weight gradient, bf16x3.  dW[kd][a][b][c][n] = sum_sites x[site + tap][c] * dz[site][n]: the MFMA
+// reduction index is the SITE, so both operands are needed "k-major" while memory is channel-major.
+// The tiles are staged as [site][32 channels] bf16 rows (64 B) and fetched with ds_read_b64_tr_b16,
+// the LDS transpose read: a 16-lane group reads a 4-site x 16-channel block and each lane receives
+// 4 consecutive sites of its own channel -- exactly half of a 32x32x16 operand fragment, for any tap
+// shift (the shift only changes which rows are addressed).  One 9-wave workgroup per (strip of
+// patches, depth tap, 32-channel chunk); wave t owns in-plane tap t and a 32(c) x 64(n) accumulator.
+// ------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+constexpr int WG_THREADS = 9 * 64;
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned short *row0, const unsigned short *row1) {
+    typedef __attribute__((address_space(3))) s16x4 lds4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4 *)row0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4 *)row1);
+    s16x8 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_split(const float *__restrict__ in,
+                                                                 const float *__restrict__ dz,
+                                                                 float *__restrict__ slabs, Geom g,
+                                                                 int tiles_per_strip) {
+    __shared__ __attribute__((aligned(16))) unsigned short s_xh[HH * HW][BK], s_xl[HH * HW][BK];
+    __shared__ __attribute__((aligned(16))) unsigned short s_zh[2][TH * TW][32], s_zl[2][TH * TW][32];
+    const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
+    const int ntiles = tiles_x * tiles_y;
+    const int strip = blockIdx.x;
+    const int nchunks = g.Cin / BK;
+    const int kd = blockIdx.y / nchunks, cc = blockIdx.y % nchunks;
+    const int tid = threadIdx.x, lane = tid & 63, tap = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int ta = tap / 3, tb = tap % 3;
+    // transpose-read roles of this lane
+    const int grp = lane >> 4, i16 = lane & 15, q = i16 >> 2, pcol = (grp & 1) * 16 + 4 * (i16 & 3), kbase = (grp >> 1) * 8;
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+    const int t_beg = strip * tiles_per_strip;
+    const int t_end = min(ntiles, t_beg + tiles_per_strip);
+    constexpr int NX = (HH * HW * 8 + WG_THREADS - 1) / WG_THREADS;
+    constexpr int NZ = (TH * TW * 16 + WG_THREADS - 1) / WG_THREADS;
+    float4 xr[NX], zr[NZ];
+    auto load_step = [&](int d, int t) {
+        const int ds = d * g.sd - g.pd + kd;
+        const int tx0 = (t % tiles_x) * TW, ty0 = (t / tiles_x) * TH;
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int c = tid + WG_THREADS * u;
+            xr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < HH * HW * 8) {
+                const int r = c >> 3, part = c & 7;
+                const int gy = ty0 - 1 + r / HW, gx = tx0 - 1 + r % HW;
+                if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W)
+                    xr[u] = *(const float4 *)(in + (((size_t)ds * g.H + gy) * g.W + gx) * g.Cin + cc * BK + part * 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NZ; ++u) {
+            const int c = tid + WG_THREADS * u;
+            zr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < TH * TW * 16) {
+                const int r = c >> 4, part = c & 15;
+                const int gy = ty0 + (r >> 4), gx = tx0 + (r & 15);
+                if (gy < g.H && gx < g.W)
+                    zr[u] = *(const float4 *)(dz + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout + part * 4);
+            }
+        }
+    };
+    auto next_valid = [&](int d) {
+        while (d < g.Dout) {
+            const int ds = d * g.sd - g.pd + kd;
+            if (ds >= 0 && ds < g.Din) break;
+            ++d;
+        }
+        return d;
+    };
+    int d = next_valid(0), t = t_beg;
+    const bool any = d < g.Dout && t_beg < t_end;
+    if (any) load_step(d, t);
+    while (any && d < g.Dout) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int c = tid + WG_THREADS * u;
+            if (c < HH * HW * 8) {
+                uint2 hi, lo;
+                split4(xr[u], &hi, &lo);
+                *(uint2 *)(&s_xh[c >> 3][(c & 7) * 4]) = hi;
+                *(uint2 *)(&s_xl[c >> 3][(c & 7) * 4]) = lo;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NZ; ++u) {
+            const int c = tid + WG_THREADS * u;
+            if (c < TH * TW * 16) {
+                const int r = c >> 4, part = c & 15;
+                uint2 hi, lo;
+                split4(zr[u], &hi, &lo);
+                *(uint2 *)(&s_zh[part >> 3][r][(part & 7) * 4]) = hi;
+                *(uint2 *)(&s_zl[part >> 3][r][(part & 7) * 4]) = lo;
+            }
+        }
+        __syncthreads();
+        int nt = t + 1, nd = d;
+        if (nt >= t_end) { nt = t_beg; nd = next_valid(d + 1); }
+        if (nd < g.Dout) load_step(nd, nt);
+#pragma unroll 2
+        for (int ks = 0; ks < TH; ++ks) {                 // 16 sites (one patch row) per MFMA k-step
+            const int hr0 = (ks + ta) * HW + tb + kbase + q, hr1 = hr0 + 4;      // halo rows of sites kbase+q, +4
+            const int zr0 = ks * TW + kbase + q, zr1 = zr0 + 4;
+            const bf16x8 ah = tr_frag(&s_xh[hr0][pcol], &s_xh[hr1][pcol]);
+            const bf16x8 al = tr_frag(&s_xl[hr0][pcol], &s_xl[hr1][pcol]);
+            const bf16x8 b0h = tr_frag(&s_zh[0][zr0][pcol], &s_zh[0][zr1][pcol]);
+            const bf16x8 b0l = tr_frag(&s_zl[0][zr0][pcol], &s_zl[0][zr1][pcol]);
+            const bf16x8 b1h = tr_frag(&s_zh[1][zr0][pcol], &s_zh[1][zr1][pcol]);
+            const bf16x8 b1l = tr_frag(&s_zl[1][zr0][pcol], &s_zl[1][zr1][pcol]);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b0h, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b1h, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0l, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1l, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0h, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1h, acc1, 0, 0, 0);
+        }
+        t = nt; d = nd;
+    }
+    float *o = slabs + ((((size_t)strip * 3 + kd) * 9 + tap) * g.Cin + cc * BK) * BN;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        o[(size_t)row * BN + li] = acc0[r];
+        o[(size_t)row * BN + 32 + li] = acc1[r];
+    }
+}
+
+__global__ void wgrad_reduce_split(const float *__restrict__ slabs, float *__restrict__ dw, int nstrips, int Ci) {
+    const size_t per = (size_t)27 * Ci * BN;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < per; e += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nstrips; ++k) s += slabs[(size_t)k * per + e];
+        const int co = (int)(e % BN);
+        size_t r = e / BN;
+        const int ci = (int)(r % Ci); r /= Ci;
+        const int tap = (int)(r % 9);
+        const int kd = (int)(r / 9);
+        dw[((((size_t)co * Ci + ci) * 3 + kd) * 3 + tap / 3) * 3 + tap % 3] = s;
+    }
+}
+
 int check_geom(int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t sd, int32_t pd) {
     if (din <= 0 || dout <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return MVX_EINVAL;
     if (sd < 1 || sd > 2 || pd < 0 || pd > 1) return MVX_EINVAL;
@@ -258,6 +413,31 @@ extern "C" int mvx_conv3d_dgrad_split(const float *dz, const void *wsplit_dgrad,
     hipLaunchKernelGGL(conv3d_gather_split, dim3(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), din, cin / BN), dim3(256), 0,
                        (hipStream_t)stream, dz, (const unsigned short *)wsplit_dgrad, (const float *)nullptr, dx,
                        (double *)nullptr, g, 0);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+extern "C" int mvx_conv3d_wgrad_split(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
+                                      int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
+                                      void *workspace, size_t workspace_bytes, void *stream) {
+    MVX_CHECK_ARG(in && dz && dw && workspace);
+    int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
+    if (rc) return rc;
+    if (cout != BN) return MVX_ESIZE;
+    // same strip decomposition (and workspace size) as mvx_conv3d_wgrad
+    const int ntiles = (int)(mvx_cdiv(w, TW) * mvx_cdiv(h, TH));
+    int per = (ntiles + 127) / 128;
+    if (per < 1) per = 1;
+    const int nstrips = (ntiles + per - 1) / per;
+    MVX_CHECK_ARG(workspace_bytes >= (size_t)nstrips * 27 * cin * BN * sizeof(float));
+    Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv3d_wgrad_split, dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz,
+                       (float *)workspace, g, per);
+    MVX_LAUNCH_CHECK();
+    const size_t per_slab = (size_t)27 * cin * BN;
+    hipLaunchKernelGGL(wgrad_reduce_split, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)workspace, dw,
+                       nstrips, cin);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

@@ -68,6 +68,7 @@ PROTOTYPES = {
     'mvx_conv3d_pack_weights_split': (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     'mvx_conv3d_forward_split': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_conv3d_dgrad_split': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    'mvx_conv3d_wgrad_split': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _sz, _p]),
     'mvx_conv3d_dgrad_sites': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_conv3d_wgrad_sites_workspace_bytes': (_sz, [_i32, _i32, _i32]),
     'mvx_conv3d_wgrad_sites': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _sz, _p]),

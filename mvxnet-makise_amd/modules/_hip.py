@@ -268,12 +268,17 @@ def conv3d_dgrad(dz, wpk_d, din, cin, sd, pd, split=False):
     return dx
 
 
-def conv3d_wgrad(x, dz, sd, pd):
+def conv3d_wgrad(x, dz, sd, pd, split=False):
     din, H, W, cin = x.shape
     dout, _, _, cout = dz.shape
     dw = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device=x.device)
     nbytes = X.lib.mvx_conv3d_wgrad_workspace_bytes(H, W, cin, cout)
     ws = workspace(nbytes, x.device, 'wgrad')
+    if split:
+        with _Timed('conv3d_wgrad_split', conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None else 0):
+            X.check(X.lib.mvx_conv3d_wgrad_split(X.ptr(x), X.ptr(dz), X.ptr(dw), din, dout, H, W, cin, cout, sd, pd,
+                                                 X.ptr(ws), ws.numel(), X.stream()), 'mvx_conv3d_wgrad_split')
+        return dw
     with _Timed('conv3d_wgrad', conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None else 0):
         X.check(X.lib.mvx_conv3d_wgrad(X.ptr(x), X.ptr(dz), X.ptr(dw), din, dout, H, W, cin, cout, sd, pd,
                                        X.ptr(ws), ws.numel(), X.stream()), 'mvx_conv3d_wgrad')

@@ -170,3 +170,9 @@ def test_conv3d_bf16x3_split_accuracy(cin, cout, din, H, W, sd, pd):
         F.conv3d(xg, w.double(), None, (sd, 1, 1), (pd, 1, 1)).backward(dz[None].double())
         dx = _hip.conv3d_dgrad(to_cl(dz).to(DEV), _hip.conv3d_pack(wd, True, split=True), din, cin, sd, pd, split=True)
         assert rel_err(dx.cpu().permute(3, 0, 1, 2), xg.grad[0]) < 2e-5
+    if cout == 64:
+        dz = torch.randn(y.shape, generator=g)
+        wg = w.double().requires_grad_(True)
+        F.conv3d(x[None].double(), wg, None, (sd, 1, 1), (pd, 1, 1)).backward(dz[None].double())
+        dw = _hip.conv3d_wgrad(xc, to_cl(dz).to(DEV), sd, pd, split=True)
+        assert rel_err(dw.cpu(), wg.grad) < 2e-5

@@ -36,7 +36,8 @@ for cin, cout, din, sd, pd in LAYERS:
     ws = _hip.conv3d_pack(w, False, split=True); wsd = _hip.conv3d_pack(w, True, split=True)
     t_fs = timeit(lambda: _hip.conv3d_forward(x, ws, b, cout, sd, pd, split=True))
     t_ds = timeit(lambda: _hip.conv3d_dgrad(dz, wsd, din, cin, sd, pd, split=True))
-    print('   bf16x3: fwd %.2f ms (%.1f TF eff)  dgrad %.2f ms (%.1f TF eff)' % (t_fs, flop / t_fs / 1e9, t_ds, flop / t_ds / 1e9))
+    t_ws = timeit(lambda: _hip.conv3d_wgrad(x, dz, sd, pd, split=True))
+    print('   bf16x3: fwd %.2f ms (%.1f TF eff)  dgrad %.2f ms (%.1f TF eff)  wgrad %.2f ms (%.1f TF eff)' % (t_fs, flop / t_fs / 1e9, t_ds, flop / t_ds / 1e9, t_ws, flop / t_ws / 1e9))
     tot += t_f + t_d + t_w
     print('conv %3d->%2d D%2d: fwd %.2f ms (%.1f TF)  dgrad %.2f ms (%.1f TF)  wgrad %.2f ms (%.1f TF)' % (
         cin, cout, din, t_f, flop / t_f / 1e9, t_d, flop / t_d / 1e9, t_w, flop / t_w / 1e9))
