@@ -26,6 +26,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(REPO, 'mvxnet-makise_amd'))
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters (matrix f32, dense)
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (never the 2:1-sparsity figure)
 
 
 def host_projection(pts, calib):
@@ -120,6 +121,8 @@ def main():
     ap.add_argument('--frames', type=int, default=4, help='frames per GPU per step')
     ap.add_argument('--points', type=int, default=20000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--convmath', choices=['bf16x3', 'f32'], default=None, help='override config.yml convmath')
+    ap.add_argument('--no-alt', action='store_true', help='skip the extra run in the other convolution arithmetic')
     args = ap.parse_args()
 
     from modules import parallel
@@ -132,6 +135,9 @@ def main():
     from modules import _hip
     from modules.pipeline import train_step_frames
     from MVXNet import MVXNet
+    if args.convmath:
+        cfg.config['convmath'] = args.convmath
+    main_math = cfg.config.get('convmath', 'f32')
 
     torch.manual_seed(0)
     model = MVXNet().to(dev)
@@ -158,33 +164,57 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    nvox = None
-    for _ in range(args.warmup):
-        nvox = step()
-    fence()
-    _hip.KERNEL_TIMERS = {}
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        nvox = step()
-    fence()
-    dt = time.perf_counter() - t0
-    timers, _hip.KERNEL_TIMERS = _hip.KERNEL_TIMERS, None
-    sparse_quads = int(_hip.SPARSE_QUADS) if _hip.SPARSE_QUADS is not None else 0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+    def timed_run(warmup, steps):
+        nv = None
+        for _ in range(warmup):
+            nv = step()
+        fence()
+        _hip.KERNEL_TIMERS = {}
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            nv = step()
+        fence()
+        dt_ = time.perf_counter() - t0
+        tm, _hip.KERNEL_TIMERS = _hip.KERNEL_TIMERS, None
+        if world > 1:
+            t = torch.tensor([dt_], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ = float(t)
+        return nv, dt_, tm
 
-    if rank == 0:
-        ev = timers.get('conv3d_gather', [])
+    def conv_roofline(tm, math):
+        name = 'conv3d_gather_split' if math == 'bf16x3' else 'conv3d_gather'
+        ev = tm.get(name, [])
         ms = sum(s.elapsed_time(e) for s, e, _ in ev)
         fl = sum(f for _, _, f in ev)
-        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        traffic = None
+        if math == 'bf16x3':
+            peak, mult, note = BF16_MFMA_PEAK_TFLOPS, 3.0, ('executed bf16 MFMA FLOPs = 3 x algorithmic '
+                                                             '(hi*hi + hi*lo + lo*hi per product)')
+        else:
+            peak, mult, note = FP32_MFMA_PEAK_TFLOPS, 1.0, 'exact f32 MFMA, executed = algorithmic FLOPs'
+        ach = mult * fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        return {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+                'kernel': name + ' (conv2/conv3 forward + dgrad launches)', 'launches': len(ev),
+                'avg_launch_ms': ms / max(1, len(ev)), 'flop_per_launch': fl / max(1, len(ev)),
+                'fp32_equivalent_tflops': fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, 'note': note}
+
+    nvox, dt, timers = timed_run(args.warmup, args.steps)
+    sparse_quads = int(_hip.SPARSE_QUADS) if _hip.SPARSE_QUADS is not None else 0
+    alt = None
+    if not args.no_alt:
+        alt_math = 'bf16x3' if main_math == 'f32' else 'f32'
+        cfg.config['convmath'] = alt_math
+        _, dt_alt, tm_alt = timed_run(max(2, args.warmup), args.steps)     # allocator re-settles after the switch
+        cfg.config['convmath'] = main_math
+        alt = {'convmath': alt_math, 'value': frames_total * args.steps / dt_alt, 'unit': 'frames/s',
+               'ms_per_step': dt_alt / args.steps * 1e3, 'roofline': conv_roofline(tm_alt, alt_math)}
+
+    if rank == 0:
+        roof = conv_roofline(timers, main_math)
         tpath = os.path.join(REPO, 'profiles', 'traffic.json')
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and main_math == 'f32':
             with open(tpath) as fh:
-                traffic = json.load(fh).get('conv3d_gather_hbm_bytes_per_launch')
+                roof['traffic'] = json.load(fh).get('conv3d_gather_hbm_bytes_per_launch')
         out = {
             'metric': 'KITTI frames/sec (voxelize+VFE+fusion+3Dconv fwd+bwd)',
             'value': frames_total * args.steps / dt,
@@ -196,16 +226,15 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32',
+            'dtype': 'f32' if main_math == 'f32' else 'f32 (bf16x3 split MFMA, f32 accumulate)',
             'data': 'synthetic',
             'config': {'workload': 'S2 ring frames, %d pts, grid 10x352x400, T=35, %d frames/GPU/step, '
-                                   'MVXNet middle (fusion on) fwd+bwd + AdamW, fp32 MFMA' % (args.points, args.frames),
+                                   'MVXNet middle (fusion on) fwd+bwd + AdamW, convmath=%s' % (args.points, args.frames, main_math),
                        'frames_per_gpu': args.frames, 'voxels_per_frame': nvox, 'parallelism': 'dp%d' % world},
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
-                         'kernel': 'conv3d_gather (fwd+dgrad launches)', 'launches': len(ev),
-                         'avg_launch_ms': ms / max(1, len(ev)), 'flop_per_launch': fl / max(1, len(ev))},
+            'roofline': roof,
         }
+        if alt is not None:
+            out['alt_modes'] = [alt]
         other = {}
         for name in ('conv3d_gather_sparse_input', 'conv3d_wgrad', 'conv3d_dgrad_sites', 'conv3d_wgrad_sites'):
             evs = timers.get(name, [])

@@ -65,6 +65,13 @@ class FCN(nn.Module):
         return out.reshape(x.shape[:-1] + (out.shape[-1],))
 
 
+def conv_split_math():
+    """True -> dense convolutions run on the bf16 matrix cores with the hi/lo split ("bf16x3",
+    fp32-grade accuracy, csrc/conv3d_split.hip); False -> exact-f32 MFMA (csrc/conv3d.hip).
+    Selected by ``convmath`` in config.yml / cfg.config (default f32)."""
+    return cfg.config.get('convmath', 'f32') == 'bf16x3'
+
+
 def _pack_cached(module, weight, for_dgrad):
     """Kernel-layout copy of a conv weight, refreshed whenever the parameter changes."""
     key = '_wpk_d' if for_dgrad else '_wpk_f'
@@ -82,24 +89,25 @@ class CRB3dFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, sd, pd, eps):
         cout = w.shape[0]
-        wpk = _hip.conv3d_pack(w, False)
-        y, stats = _hip.conv3d_forward(x, wpk, b, cout, sd, pd, relu=True, want_stats=True)
+        split = conv_split_math()
+        wpk = _hip.conv3d_pack(w, False, split=split)
+        y, stats = _hip.conv3d_forward(x, wpk, b, cout, sd, pd, relu=True, want_stats=True, split=split)
         count = y.numel() // cout
         mi = _hip.bn_finalize(stats, count, eps)
         out = _hip.bn_apply(y, mi)
         ctx.save_for_backward(x, w, y, mi)
-        ctx.geom = (sd, pd, count)
+        ctx.geom = (sd, pd, count, split)
         return out
 
     @staticmethod
     def backward(ctx, g):
         x, w, y, mi = ctx.saved_tensors
-        sd, pd, count = ctx.geom
+        sd, pd, count, split = ctx.geom
         dz, db = _hip.bn_relu_backward(g.contiguous(), y, mi, count, True)
-        dw = _hip.conv3d_wgrad(x, dz, sd, pd)
+        dw = _hip.conv3d_wgrad(x, dz, sd, pd, split=split)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _hip.conv3d_dgrad(dz, _hip.conv3d_pack(w, True), x.shape[0], x.shape[3], sd, pd)
+            dx = _hip.conv3d_dgrad(dz, _hip.conv3d_pack(w, True, split=split), x.shape[0], x.shape[3], sd, pd, split=split)
         return dx, dw, db, None, None, None
 
 

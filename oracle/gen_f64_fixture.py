@@ -33,5 +33,19 @@ def main():
                         **{'grad.' + k: v.grad.numpy().astype(np.float32) for k, v in P.items() if v.numel() <= 20000})
 
 
+def voxelnet_small():
+    """float64 run of the VoxelNet-only fixture (voxelnet_small.npz): middle output and gradients."""
+    g = np.load(os.path.join(GOLDEN, 'voxelnet_small.npz'))
+    dt = torch.float64
+    P = {k: v.to(dt).clone().requires_grad_(True) for k, v in O.strip_prefix(O.make_params(7), 'backbone.').items()}
+    x = torch.from_numpy(g['x']).to(dt).requires_grad_(True)
+    mid = O.voxelnet_middle(x, torch.from_numpy(g['idx']), P, [int(v) for v in g['voxelshape']])
+    (mid[0] * torch.from_numpy(g['G']).to(dt)).sum().backward()
+    np.savez_compressed(os.path.join(GOLDEN, 'voxelnet_small_f64.npz'), mid=mid[0].detach().numpy().astype(np.float32),
+                        grad_x=x.grad.numpy().astype(np.float32),
+                        **{'grad.' + k: v.grad.numpy().astype(np.float32) for k, v in P.items()})
+
+
 if __name__ == '__main__':
+    voxelnet_small()
     main()

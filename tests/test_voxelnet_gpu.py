@@ -20,13 +20,17 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
 
 
-@pytest.fixture()
-def small_cfg(golden):
+@pytest.fixture(params=['bf16x3', 'f32'])
+def small_cfg(golden, request):
+    """Small fixture grid; every test using it runs with both convolution arithmetics."""
     import modules.config as cfg
     old = list(cfg.config['voxelshape'])
+    old_math = cfg.config.get('convmath', 'f32')
     cfg.config['voxelshape'] = [int(v) for v in golden('voxelnet_small')['voxelshape']]
+    cfg.config['convmath'] = request.param
     yield cfg
     cfg.config['voxelshape'] = old
+    cfg.config['convmath'] = old_math
 
 
 def load_backbone(net, with_rpn=False, golden=None):
@@ -70,11 +74,25 @@ def test_voxelnet_forward_and_gradients_match_reference(golden, small_cfg):
     assert mid.shape == (1,) + g['mid'].shape
     assert rel_err(mid[0].detach().cpu(), g['mid']) < 1e-3
     (mid[0] * torch.from_numpy(g['G']).to(DEV)).sum().backward()
+    # Gradients: measured against the float64 oracle, with the reference's own fp32 distance from it as
+    # the yardstick (this tiny grid makes them ill-conditioned: BatchNorm over <= 1,920 sites).  The
+    # exact-f32 MFMA mode must stay within 3x the reference's fp32 noise (measured: ~1e-6, i.e. closer to
+    # float64 than the reference itself); the bf16x3 mode carries 16 mantissa bits per operand and this
+    # fixture amplifies rounding ~500-7000x (the reference's own 6e-8 becomes 3e-5..2e-4), so its
+    # gradients are only required to stay within 0.15 here (forward maps: 1e-4, test below).
+    g64 = golden('voxelnet_small_f64')
+    extra = 1e-3 if small_cfg.config['convmath'] == 'f32' else 0.15
+    worst = 0.0
     for k, p in net.named_parameters():
         if k.startswith('rpn'):
             continue
-        assert rel_err(p.grad.cpu(), g['grad.' + k]) < 5e-3, k
-    assert rel_err(x.grad[0].cpu(), g['grad_x']) < 5e-3
+        e_ref = rel_err(g['grad.' + k], g64['grad.' + k])
+        e_hip = rel_err(p.grad.cpu(), g64['grad.' + k])
+        worst = max(worst, e_hip)
+        assert e_hip < 3 * e_ref + extra, (k, e_hip, e_ref)
+    e_ref = rel_err(g['grad_x'], g64['grad_x'])
+    assert rel_err(x.grad[0].cpu(), g64['grad_x']) < 3 * e_ref + extra
+    print('convmath=%s worst gradient error vs f64: %.2e' % (small_cfg.config['convmath'], worst))
     with torch.no_grad():
         score, reg = net(x, idx)
     # RPN (next scope row, MIOpen): 16 BatchNorms over <= 96 samples each on this tiny grid are
@@ -117,10 +135,13 @@ def test_sparse_and_dense_first_layer_paths_agree(golden, small_cfg):
         mid = net.middle(x, idx)
         (mid[0] * G).sum().backward()
         res[mode] = (mid.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    # in bf16x3 mode the dense path runs conv1 on the split kernels while the sparse paths stay f32, so
+    # the comparison only bounds the arithmetic difference there (see the gradient note above)
+    f32 = small_cfg.config['convmath'] == 'f32'
     for mode in ('gemm', 'skip'):
-        assert rel_err(res[mode][0], res['dense'][0]) < 2e-6
+        assert rel_err(res[mode][0], res['dense'][0]) < (2e-6 if f32 else 2e-4)
         for k in res[mode][1]:
-            assert rel_err(res[mode][1][k], res['dense'][1][k]) < 2e-4, (mode, k)
+            assert rel_err(res[mode][1][k], res['dense'][1][k]) < (2e-4 if f32 else 0.15), (mode, k)
 
 
 def test_compact_vfe_equals_dense_vfe():
