@@ -31,7 +31,7 @@ class MVXNet(nn.Module):
         imfeatures = self.head(imgs, voxels, calibs, imsize)
         return torch.concat([voxels[..., :7], imfeatures], dim=-1)
 
-    def middle(self, voxels, imgs, idx, calibs, imsize, compact=True):
+    def middle(self, voxels, imgs, idx, calibs, imsize, compact=True, prepared=None, status_sink=None):
         """Hot path up to the RPN input.  ``compact=True`` evaluates the fusion MLP and the VFE stack on
         real rows + one padded row per voxel instead of all N*T rows -- identical results because
         inside MVXNet all padded rows of a voxel are identical; ``compact=False`` runs the
@@ -39,7 +39,7 @@ class MVXNet(nn.Module):
         if not compact:
             return self.backbone.middle(self.point_features(voxels, imgs, calibs, imsize), idx)
         from modules.voxelnet.Pipe import CompactInputFunction
-        imfeat, cr, vox2d = self.head.forward_compact(imgs, voxels, calibs, imsize)
+        imfeat, cr, vox2d = self.head.forward_compact(imgs, voxels, calibs, imsize, prepared, status_sink)
         rows = CompactInputFunction.apply(imfeat, vox2d, cr)
         return self.backbone.middle(rows, idx, compact_rows=cr)
 

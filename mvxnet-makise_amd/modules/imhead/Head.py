@@ -18,10 +18,20 @@ class ImageHead(nn.Module):
             p.requires_grad = False
         self.fusion = ImageFeatureFusion()
 
-    def forward_compact(self, x, voxels, calibs, imsize):
+    @staticmethod
+    def compact_map(voxels):
+        """Enqueue the dense-row -> compact-row map of one frame; returns device tensors only (no host
+        sync), so several frames can be prepared before a single read-back of their n_real."""
+        v = voxels.squeeze(0) if voxels.dim() == 4 else voxels[0]
+        n, t, c = v.shape
+        return _hip.row_compact_map(v.view(n * t, c))
+
+    def forward_compact(self, x, voxels, calibs, imsize, prepared=None, status_sink=None):
         """Fusion branch on compact rows: returns (imfeat (n_real+1, 16), CompactRows).  Row n_real is
         the shared padded row.  ``voxels`` (1,N,T,9) is zeroed in place on padded rows like the
-        reference (imhead/Pipe.py:54-59)."""
+        reference (imhead/Pipe.py:54-59).  ``prepared`` = (row_map, rows_sel, n_real:int) from
+        ``compact_map`` avoids the host sync here; ``status_sink`` (a list) collects the device status
+        word instead of checking it immediately (the reference's assert, imhead/Pipe.py:71)."""
         feats = self.extractor(x)
         v = voxels.squeeze(0) if voxels.dim() == 4 else voxels[0]
         hw = imsize.tolist() if torch.is_tensor(imsize) else list(imsize)
@@ -30,8 +40,11 @@ class ImageHead(nn.Module):
         n, t, c = v.shape
         rows = n * t
         vox2d = v.view(rows, c)
-        row_map, rows_sel, n_real = _hip.row_compact_map(vox2d)
-        nr = int(n_real)                                   # one host sync, where the reference asserts
+        if prepared is None:
+            row_map, rows_sel, n_real = _hip.row_compact_map(vox2d)
+            nr = int(n_real)                               # one host sync, where the reference asserts
+        else:
+            row_map, rows_sel, nr = prepared
         levels = _channels_last_levels(feats, 0)
         width = levels[0].shape[2] * len(levels)
         compact = torch.empty((nr + 1, width), dtype=torch.float32, device=v.device)
@@ -40,7 +53,9 @@ class ImageHead(nn.Module):
         row_w = torch.ones((nr + 1,), dtype=torch.float32, device=v.device)
         row_w[nr] = float(rows - nr)
         y = self.fusion.forward_rows(compact, row_w, rows)
-        if int(status) & 1:
+        if status_sink is not None:
+            status_sink.append(status)
+        elif int(status) & 1:
             raise AssertionError('projected point outside the feature map')
         return y, _hip.CompactRows(row_map, rows_sel, nr, n, t), vox2d
 

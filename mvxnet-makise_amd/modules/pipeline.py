@@ -36,14 +36,28 @@ def voxelize_batch(batch, T=None):
     return frames, res.status
 
 
+def prepare_frames(batch, head):
+    """Voxelize the batch and build every frame's compact-row map with TWO host reads per step (voxel
+    counts, then real-row counts) instead of one per frame, so the host can enqueue a whole step
+    ahead of the GPU."""
+    frames, status = voxelize_batch(batch)
+    maps = [head.compact_map(v) for v, _ in frames]
+    n_real = torch.cat([m[2] for m in maps]).tolist()
+    prepared = [(m[0], m[1], int(n)) for m, n in zip(maps, n_real)]
+    return frames, prepared, status
+
+
 def train_step_frames(model, batch, grad_mid, imsize):
     """Forward + backward of every frame of the batch through ``model.middle``; gradients
     accumulate in the parameters.  ``grad_mid`` is dL/d(middle output) (1,128,H,W), standing for
-    the RPN + loss that follow the hot path.  Returns the number of voxels per frame."""
-    frames, status = voxelize_batch(batch)
+    the RPN + loss that follow the hot path.  Returns (voxels per frame, list of device status words
+    to be checked by the caller once per step)."""
+    frames, prepared, status = prepare_frames(batch, model.head)
+    statuses = [status]
     nvox = []
     for f, (voxels, idx) in enumerate(frames):
-        mid = model.middle(voxels, batch.fpn_levels[f], idx, [None], imsize)
+        mid = model.middle(voxels, batch.fpn_levels[f], idx, [None], imsize, prepared=prepared[f],
+                           status_sink=statuses)
         mid.backward(grad_mid)
         nvox.append(voxels.shape[1])
-    return nvox, status
+    return nvox, statuses
