@@ -711,9 +711,13 @@ extern "C" int mvx_conv3d_dgrad(const float *dz, const float *wpk_dgrad, float *
     return MVX_OK;
 }
 
-static int wgrad_strips(int h, int w) {
+static int wgrad_strips(int h, int w, int cin) {
+    // Two 9-wave workgroups fit a CU (LDS), so 512 run at once; all have the same length, so the grid
+    // should fill exactly one round: strips x (3 depth taps x cin/32 chunks) <= 512.
     const int ntiles = (int)(mvx_cdiv(w, TW) * mvx_cdiv(h, TH));
-    int per = (ntiles + 127) / 128;      // about 128 strips per (kd, chunk)
+    int strips = 512 / (3 * (cin / BK));
+    if (strips < 1) strips = 1;
+    int per = (ntiles + strips - 1) / strips;
     if (per < 1) per = 1;
     return per;
 }
@@ -721,7 +725,7 @@ static int wgrad_strips(int h, int w) {
 extern "C" size_t mvx_conv3d_wgrad_workspace_bytes(int32_t h, int32_t w, int32_t cin, int32_t cout) {
     if (h <= 0 || w <= 0 || cin <= 0 || cout != BN) return 0;
     const int ntiles = (int)(mvx_cdiv(w, TW) * mvx_cdiv(h, TH));
-    const int per = wgrad_strips(h, w);
+    const int per = wgrad_strips(h, w, cin);
     const int nstrips = (ntiles + per - 1) / per;
     return (size_t)nstrips * 27 * cin * BN * sizeof(float);
 }
@@ -734,7 +738,7 @@ extern "C" int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int
     if (rc) return rc;
     if (cout != BN) return MVX_ESIZE;
     const int ntiles = (int)(mvx_cdiv(w, TW) * mvx_cdiv(h, TH));
-    const int per = wgrad_strips(h, w);
+    const int per = wgrad_strips(h, w, cin);
     const int nstrips = (ntiles + per - 1) / per;
     MVX_CHECK_ARG(workspace_bytes >= (size_t)nstrips * 27 * cin * BN * sizeof(float));
     Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};

@@ -426,7 +426,9 @@ extern "C" int mvx_conv3d_wgrad_split(const float *in, const float *dz, float *d
     if (cout != BN) return MVX_ESIZE;
     // same strip decomposition (and workspace size) as mvx_conv3d_wgrad
     const int ntiles = (int)(mvx_cdiv(w, TW) * mvx_cdiv(h, TH));
-    int per = (ntiles + 127) / 128;
+    int strips = 512 / (3 * (cin / BK));             // one full round of 2 workgroups per CU (see conv3d.hip)
+    if (strips < 1) strips = 1;
+    int per = (ntiles + strips - 1) / strips;
     if (per < 1) per = 1;
     const int nstrips = (ntiles + per - 1) / per;
     MVX_CHECK_ARG(workspace_bytes >= (size_t)nstrips * 27 * cin * BN * sizeof(float));
