@@ -183,11 +183,16 @@ int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int32_t din, i
  *   y f32 [rows][ldy] (n columns written) = [ReLU](x w^T + bias)
  *   stats (optional, replicated f64 [R][2][n]): per-column (sum, sum of squares) of y weighted by row_w
  *   row_w (optional) f32 [rows]: multiplicity of each row in the reference's dense tensor
+ *   splitk_workspace (optional, mvx_linear_splitk_workspace_bytes): lets a skinny product without
+ *   epilogue (no bias/ReLU/stats, ldy == n, few output blocks, long k) be split along k into slabs
+ *   that are summed in a fixed order -- fills the chip when rows x n alone cannot.
  * mvx_linear_wgrad: dw f32 [n][k] = dz^T x  (dz f32 [rows][lddz]).
  */
+size_t mvx_linear_splitk_workspace_bytes(int64_t rows, int32_t n);
 int mvx_linear_forward(const float *x, int32_t ldx, const float *w, int32_t ldw, int32_t w_transposed,
                        const float *bias, float *y, int32_t ldy, double *stats, const float *row_w,
-                       int64_t rows, int32_t k, int32_t n, int32_t relu, void *stream);
+                       int64_t rows, int32_t k, int32_t n, int32_t relu, void *splitk_workspace,
+                       size_t splitk_workspace_bytes, void *stream);
 size_t mvx_linear_wgrad_workspace_bytes(int64_t rows, int32_t k, int32_t n);
 int mvx_linear_wgrad(const float *x, int32_t ldx, const float *dz, int32_t lddz, float *dw, int64_t rows,
                      int32_t k, int32_t n, void *workspace, size_t workspace_bytes, void *stream);

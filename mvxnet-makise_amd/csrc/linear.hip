@@ -29,7 +29,7 @@ template <bool WT, int NT, bool VEC>
 __global__ __launch_bounds__(256) void linear_fwd(const float *__restrict__ x, int ldx, const float *__restrict__ w,
                                                   int ldw, const float *__restrict__ bias, float *__restrict__ y,
                                                   int ldy, double *__restrict__ stats, const float *__restrict__ row_w,
-                                                  long long R, int K, int N, int relu) {
+                                                  long long R, int K, int N, int relu, int k_per_split) {
     constexpr int BNL = 32 * NT;
     constexpr int XV = BM * BK / 4 / 256;          // float4 per thread for the x tile (4)
     constexpr int WV = BNL * BK / 4 / 256;         // float4 per thread for the w tile (NT)
@@ -111,12 +111,15 @@ __global__ __launch_bounds__(256) void linear_fwd(const float *__restrict__ x, i
         }
     };
 
-    load_tiles(0);
-    for (int k0 = 0; k0 < K; k0 += BK) {
+    // split-K: blockIdx.z owns k in [kbeg, kend) and writes its partial product to slab z of y
+    const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
+    y += (size_t)blockIdx.z * (size_t)R * ldy;
+    load_tiles(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();
         store_tiles(k0);
         __syncthreads();
-        if (k0 + BK < K) load_tiles(k0 + BK);
+        if (k0 + BK < kend) load_tiles(k0 + BK);
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
             const float4 av = *(const float4 *)(s_x + a_base + 8 * q);
@@ -275,9 +278,14 @@ inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
 
+extern "C" size_t mvx_linear_splitk_workspace_bytes(int64_t rows, int32_t n) {
+    return rows > 0 && n > 0 ? (size_t)16 * rows * n * sizeof(float) : 0;
+}
+
 extern "C" int mvx_linear_forward(const float *x, int32_t ldx, const float *w, int32_t ldw, int32_t w_transposed,
                                   const float *bias, float *y, int32_t ldy, double *stats, const float *row_w,
-                                  int64_t rows, int32_t k, int32_t n, int32_t relu, void *stream) {
+                                  int64_t rows, int32_t k, int32_t n, int32_t relu, void *splitk_workspace,
+                                  size_t splitk_workspace_bytes, void *stream) {
     MVX_CHECK_ARG(x && w && y && rows >= 0 && k > 0 && n > 0 && ldx >= k && ldy >= n);
     MVX_CHECK_ARG(ldw >= (w_transposed ? n : k));
     hipStream_t st = (hipStream_t)stream;
@@ -290,10 +298,29 @@ extern "C" int mvx_linear_forward(const float *x, int32_t ldx, const float *w, i
     const bool vec = aligned16(x) && aligned16(w) && ldx % 4 == 0 && ldw % 4 == 0 && k % 4 == 0 &&
                      (!w_transposed || n % 4 == 0);
     const bool wide = n > 64;
-    const dim3 grid(mvx_cdiv(rows, BM), mvx_cdiv(n, wide ? 128 : 64));
+    // Skinny problems (few row/column blocks, long K) without an epilogue are split along K into
+    // slabs that a second kernel sums in a fixed order (deterministic); needs a workspace.
+    int splits = 1;
+    const long long blocks = (long long)mvx_cdiv(rows, BM) * mvx_cdiv(n, wide ? 128 : 64);
+    if (splitk_workspace && !bias && !stats && !relu && ldy == n && blocks < 128 && k >= 8 * BK) {
+        splits = (int)(256 / blocks);
+        if (splits > k / (2 * BK)) splits = k / (2 * BK);
+        if (splits > 16) splits = 16;
+        if (splits < 1) splits = 1;
+    }
+    int k_per_split = ((mvx_cdiv(k, splits) + BK - 1) / BK) * BK;
+    splits = (int)mvx_cdiv(k, k_per_split);
+    float *ydst = y;
+    int ld_dst = ldy;
+    if (splits > 1) {
+        MVX_CHECK_ARG(splitk_workspace_bytes >= (size_t)splits * rows * n * sizeof(float));
+        ydst = (float *)splitk_workspace;
+        ld_dst = n;
+    }
+    const dim3 grid(mvx_cdiv(rows, BM), mvx_cdiv(n, wide ? 128 : 64), splits);
 #define MVX_LAUNCH_LIN(WT, NT, VEC)                                                                               \
-    hipLaunchKernelGGL((linear_fwd<WT, NT, VEC>), grid, dim3(256), 0, st, x, ldx, w, ldw, bias, y, ldy, stats, row_w, \
-                       (long long)rows, k, n, relu)
+    hipLaunchKernelGGL((linear_fwd<WT, NT, VEC>), grid, dim3(256), 0, st, x, ldx, w, ldw, bias, ydst, ld_dst, stats, \
+                       row_w, (long long)rows, k, n, relu, k_per_split)
     if (w_transposed) {
         if (wide) { if (vec) MVX_LAUNCH_LIN(true, 4, true); else MVX_LAUNCH_LIN(true, 4, false); }
         else      { if (vec) MVX_LAUNCH_LIN(true, 2, true); else MVX_LAUNCH_LIN(true, 2, false); }
@@ -303,6 +330,16 @@ extern "C" int mvx_linear_forward(const float *x, int32_t ldx, const float *w, i
     }
 #undef MVX_LAUNCH_LIN
     MVX_LAUNCH_CHECK();
+    if (splits > 1) {
+        if (ldy == n) {
+            const size_t total = (size_t)rows * n;
+            hipLaunchKernelGGL(slab_reduce, dim3(mvx_cdiv(total, 256) > 2048 ? 2048 : mvx_cdiv(total, 256)), dim3(256), 0, st,
+                               (const float *)splitk_workspace, y, total, splits);
+        } else {
+            return MVX_EINVAL;   // split-K needs a dense destination
+        }
+        MVX_LAUNCH_CHECK();
+    }
     return MVX_OK;
 }
 

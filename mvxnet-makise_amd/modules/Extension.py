@@ -46,7 +46,8 @@ PROTOTYPES = {
     'mvx_bn_apply': (_i32, [_p, _p, _p, _i64, _i32, _p]),
     'mvx_bn_backward_scratch_bytes': (_sz, [_i32]),
     'mvx_bn_relu_backward': (_i32, [_p, _p, _p, _f64, _p, _p, _p, _p, _i64, _i32, _p]),
-    'mvx_linear_forward': (_i32, [_p, _i32, _p, _i32, _i32, _p, _p, _i32, _p, _p, _i64, _i32, _i32, _i32, _p]),
+    'mvx_linear_splitk_workspace_bytes': (_sz, [_i64, _i32]),
+    'mvx_linear_forward': (_i32, [_p, _i32, _p, _i32, _i32, _p, _p, _i32, _p, _p, _i64, _i32, _i32, _i32, _p, _sz, _p]),
     'mvx_linear_wgrad_workspace_bytes': (_sz, [_i64, _i32, _i32]),
     'mvx_linear_wgrad': (_i32, [_p, _i32, _p, _i32, _p, _i64, _i32, _i32, _p, _sz, _p]),
     'mvx_vfe_bn_max_concat': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p]),

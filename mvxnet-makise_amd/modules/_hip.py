@@ -310,9 +310,12 @@ def linear_forward(x, w, bias, relu=True, want_stats=True, w_transposed=False, r
     if out is None:
         out = torch.empty((R, N), dtype=torch.float32, device=x.device)
     stats = torch.empty((STATS_REPLICAS, 2, N), dtype=torch.float64, device=x.device) if want_stats else None
+    ws = None
+    if bias is None and not relu and not want_stats and K >= 256 and R * N <= (1 << 22):
+        ws = workspace(X.lib.mvx_linear_splitk_workspace_bytes(R, N), x.device, 'splitk')
     X.check(X.lib.mvx_linear_forward(_vptr(x), _ld(x), _vptr(w), _ld(w), int(w_transposed), X.ptr(bias),
                                      _vptr(out), _ld(out), X.ptr(stats), X.ptr(row_w), R, K, N, int(relu),
-                                     X.stream()), 'mvx_linear_forward')
+                                     X.ptr(ws), ws.numel() if ws is not None else 0, X.stream()), 'mvx_linear_forward')
     return out, stats
 
 

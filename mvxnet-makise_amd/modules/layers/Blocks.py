@@ -72,25 +72,38 @@ def conv_split_math():
     return cfg.config.get('convmath', 'f32') == 'bf16x3'
 
 
-def _pack_cached(module, weight, for_dgrad):
-    """Kernel-layout copy of a conv weight, refreshed whenever the parameter changes."""
-    key = '_wpk_d' if for_dgrad else '_wpk_f'
-    tag = (weight._version, weight.data_ptr())
-    cached = getattr(module, key, None)
-    if cached is None or cached[0] != tag:
-        cached = (tag, _hip.conv3d_pack(weight.detach(), for_dgrad))
-        object.__setattr__(module, key, cached)
-    return cached[1]
+class PackedWeights:
+    """Kernel-layout copies of a module's conv weight, refreshed when the parameter changes (in-place
+    optimizer update -> ``_version``; ``.to()`` / reload -> ``data_ptr``).  The frames of a step share
+    one packing.  Owned by the module, so the parameter outlives every cached copy."""
+
+    def __init__(self, get_weight):
+        self._get = get_weight
+        self._cache = {}
+
+    def __call__(self, for_dgrad, split):
+        w = self._get()
+        tag = (w._version, w.data_ptr())
+        hit = self._cache.get((for_dgrad, split))
+        if hit is None or hit[0] != tag:
+            hit = (tag, _hip.conv3d_pack(w.detach(), for_dgrad, split=split))
+            self._cache[(for_dgrad, split)] = hit
+        return hit[1]
+
+
+def _pack(packer, w, for_dgrad, split):
+    return packer(for_dgrad, split) if packer is not None else _hip.conv3d_pack(w, for_dgrad, split=split)
 
 
 class CRB3dFunction(torch.autograd.Function):
     """channels-last (D,H,W,Cin) -> BN(ReLU(conv3d)) (Dout,H,W,Cout), one frame."""
 
     @staticmethod
-    def forward(ctx, x, w, b, sd, pd, eps):
+    def forward(ctx, x, w, b, sd, pd, eps, packer=None):
         cout = w.shape[0]
         split = conv_split_math()
-        wpk = _hip.conv3d_pack(w, False, split=split)
+        wpk = _pack(packer, w, False, split)
+        ctx.packer = packer
         y, stats = _hip.conv3d_forward(x, wpk, b, cout, sd, pd, relu=True, want_stats=True, split=split)
         count = y.numel() // cout
         mi = _hip.bn_finalize(stats, count, eps)
@@ -107,8 +120,8 @@ class CRB3dFunction(torch.autograd.Function):
         dw = _hip.conv3d_wgrad(x, dz, sd, pd, split=split)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _hip.conv3d_dgrad(dz, _hip.conv3d_pack(w, True, split=split), x.shape[0], x.shape[3], sd, pd, split=split)
-        return dx, dw, db, None, None, None
+            dx = _hip.conv3d_dgrad(dz, _pack(ctx.packer, w, True, split), x.shape[0], x.shape[3], sd, pd, split=split)
+        return dx, dw, db, None, None, None, None
 
 
 class SparseInputCRB3dFunction(torch.autograd.Function):
@@ -201,6 +214,7 @@ class CRB3d(nn.Module):
         if k3 != (3, 3, 3) or s3[1:] != (1, 1) or p3[1:] != (1, 1) or s3[0] not in (1, 2) or p3[0] not in (0, 1):
             raise NotImplementedError('CRB3d HIP kernel: kernel 3, stride (s,1,1), padding (p,1,1) only')
         self._sd, self._pd = s3[0], p3[0]
+        object.__setattr__(self, '_packer', PackedWeights(lambda: self.conv.weight))
         self.voxel_gemm = True          # forward_voxels: voxel-GEMM factorisation (else zero-skipping dense kernels)
 
     def forward_voxels(self, feat, coords, dhw):
@@ -214,7 +228,7 @@ class CRB3d(nn.Module):
             raise NotImplementedError('batch size 1 only (reference VoxelNet.py:19)')
         # squeeze, not x[0]: the backward of a select allocates zeros and copies the whole gradient
         xc = x.squeeze(0).permute(1, 2, 3, 0).contiguous()  # no-op when already channels-last
-        out = CRB3dFunction.apply(xc, self.conv.weight, self.conv.bias, self._sd, self._pd, cfg.eps)
+        out = CRB3dFunction.apply(xc, self.conv.weight, self.conv.bias, self._sd, self._pd, cfg.eps, self._packer)
         return out.permute(3, 0, 1, 2).unsqueeze(0)
 
 
