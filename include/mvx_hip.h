@@ -29,6 +29,13 @@ extern "C" {
  * mvx_bn_finalize sums the replicas. */
 #define MVX_STATS_REPLICAS 32
 
+/* Bits of the `flags` arguments.  (Entry points that used to take `relu` take `flags`; bit 0 keeps
+ * the old meaning.) */
+#define MVX_FLAG_RELU 1        /* apply ReLU in the epilogue */
+#define MVX_FLAG_PREZEROED 2   /* the stats / scratch accumulators passed in are already zero: skip the memset
+                                  (lets a caller clear all accumulators of a frame with ONE fill) */
+#define MVX_FLAG_ACCUMULATE 4  /* add the gradient to the destination instead of overwriting it */
+
 #define MVX_OK 0
 #define MVX_EINVAL (-1)   /* bad argument (null pointer, size, unsupported combination) */
 #define MVX_ESIZE (-2)    /* a size exceeds what the kernel supports */
@@ -126,7 +133,7 @@ int mvx_bn_apply(const float *y, const float *mean_inv, float *out, int64_t rows
 size_t mvx_bn_backward_scratch_bytes(int32_t channels);
 int mvx_bn_relu_backward(const float *dyhat, const float *y, const float *mean_inv, double count,
                          float *dz, float *dbias, double *scratch, const float *row_w, int64_t rows,
-                         int32_t channels, void *stream);
+                         int32_t channels, int32_t flags, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense 3x3x3 convolution on the matrix cores (fp32 MFMA), one frame, channels-last
@@ -158,7 +165,7 @@ int mvx_conv3d_pack_weights(const float *w, float *wpk, int32_t cout, int32_t ci
 void mvx_conv3d_tile_shape(int32_t *tile_h, int32_t *tile_w);
 int mvx_conv3d_forward(const float *in, const float *wpk, const float *bias, float *out, double *stats,
                        int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
-                       int32_t stride_d, int32_t pad_d, int32_t relu, const int32_t *occupancy,
+                       int32_t stride_d, int32_t pad_d, int32_t flags, const int32_t *occupancy,
                        const uint32_t *site_bits, uint64_t *exec_quads, void *stream);
 int mvx_conv3d_dgrad(const float *dz, const float *wpk_dgrad, float *dx, int32_t din, int32_t dout,
                      int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
@@ -173,7 +180,7 @@ int mvx_conv3d_wgrad_sites(const float *feat, const int64_t *coords, const float
                            size_t workspace_bytes, void *stream);
 size_t mvx_conv3d_wgrad_workspace_bytes(int32_t h, int32_t w, int32_t cin, int32_t cout);
 int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
-                     int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
+                     int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, int32_t flags,
                      void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -191,11 +198,11 @@ int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int32_t din, i
 size_t mvx_linear_splitk_workspace_bytes(int64_t rows, int32_t n);
 int mvx_linear_forward(const float *x, int32_t ldx, const float *w, int32_t ldw, int32_t w_transposed,
                        const float *bias, float *y, int32_t ldy, double *stats, const float *row_w,
-                       int64_t rows, int32_t k, int32_t n, int32_t relu, void *splitk_workspace,
+                       int64_t rows, int32_t k, int32_t n, int32_t flags, void *splitk_workspace,
                        size_t splitk_workspace_bytes, void *stream);
 size_t mvx_linear_wgrad_workspace_bytes(int64_t rows, int32_t k, int32_t n);
 int mvx_linear_wgrad(const float *x, int32_t ldx, const float *dz, int32_t lddz, float *dw, int64_t rows,
-                     int32_t k, int32_t n, void *workspace, size_t workspace_bytes, void *stream);
+                     int32_t k, int32_t n, int32_t flags, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * VFE glue on [n_voxels][t][channels] rows.  Replaces modules/voxelnet/Pipe.py:14-18
@@ -315,7 +322,7 @@ int mvx_index_grid(const int64_t *coords, int32_t n_voxels, int32_t d, int32_t h
                    int32_t *grid, int32_t *status, void *stream);
 int mvx_sparse_conv_output(const float *p, const int32_t *index_grid, const float *bias, float *out,
                            double *stats, int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cout,
-                           int32_t stride_d, int32_t pad_d, int32_t relu, void *stream);
+                           int32_t stride_d, int32_t pad_d, int32_t flags, void *stream);
 int mvx_sparse_conv_gather_dz(const float *dz, const int64_t *coords, int32_t n_voxels, float *g_rows,
                               int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cout,
                               int32_t stride_d, int32_t pad_d, void *stream);
@@ -331,12 +338,12 @@ int mvx_conv3d_pack_weights_split(const float *w, void *wsplit, int32_t cout, in
                                   void *stream);
 int mvx_conv3d_forward_split(const float *in, const void *wsplit, const float *bias, float *out, double *stats,
                              int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
-                             int32_t stride_d, int32_t pad_d, int32_t relu, void *stream);
+                             int32_t stride_d, int32_t pad_d, int32_t flags, void *stream);
 int mvx_conv3d_dgrad_split(const float *dz, const void *wsplit_dgrad, float *dx, int32_t din, int32_t dout,
                            int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
                            void *stream);
 int mvx_conv3d_wgrad_split(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
-                           int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
+                           int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, int32_t flags,
                            void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus

@@ -184,12 +184,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dy
 }
 
 // dbias[c] = sum over replicas of scratch[rep][2][c]
-__global__ void dbias_finish(const double *__restrict__ scratch, float *__restrict__ b, int C) {
+__global__ void dbias_finish(const double *__restrict__ scratch, float *__restrict__ b, int C, int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= C) return;
     double t = 0.0;
     for (int rp = 0; rp < REP; ++rp) t += scratch[((size_t)rp * 3 + 2) * C + i];
-    b[i] = (float)t;
+    b[i] = accumulate ? b[i] + (float)t : (float)t;
 }
 
 inline unsigned row_grid(size_t rows, int C) {
@@ -237,12 +237,14 @@ extern "C" size_t mvx_bn_backward_scratch_bytes(int32_t channels) {
 
 extern "C" int mvx_bn_relu_backward(const float *dyhat, const float *y, const float *mean_inv, double count,
                                     float *dz, float *dbias, double *scratch, const float *row_w, int64_t rows,
-                                    int32_t channels, void *stream) {
+                                    int32_t channels, int32_t flags, void *stream) {
     MVX_CHECK_ARG(dyhat && y && mean_inv && dz && scratch && rows >= 0 && channels > 0 && channels % 4 == 0);
     MVX_CHECK_ARG(count > 0);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * REP * 3 * channels, st);
-    if (e != hipSuccess) return (int)e;
+    if (!(flags & MVX_FLAG_PREZEROED)) {
+        hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * REP * 3 * channels, st);
+        if (e != hipSuccess) return (int)e;
+    }
     if (rows > 0) {
         const unsigned grid = row_grid(rows, channels);
         hipLaunchKernelGGL(bn_bwd_reduce, dim3(grid), dim3(256), 0, st, dyhat, y, mean_inv, scratch, (size_t)rows, channels);
@@ -253,7 +255,7 @@ extern "C" int mvx_bn_relu_backward(const float *dyhat, const float *y, const fl
     }
     if (dbias) {
         hipLaunchKernelGGL(dbias_finish, dim3(mvx_cdiv(channels, 128)), dim3(128), 0, st, (const double *)scratch, dbias,
-                           channels);
+                           channels, flags & MVX_FLAG_ACCUMULATE);
         MVX_LAUNCH_CHECK();
     }
     return MVX_OK;

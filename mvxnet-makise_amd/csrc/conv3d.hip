@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_sites(const float *__restric
 }
 
 // dW[co][ci][kd][kh][kw] = sum_strips slab[strip][kd][tap][ci][co]
-__global__ void wgrad_reduce(const float *__restrict__ slabs, float *__restrict__ dw, int nstrips, int Ci) {
+__global__ void wgrad_reduce(const float *__restrict__ slabs, float *__restrict__ dw, int nstrips, int Ci, int accumulate) {
     const size_t per = (size_t)27 * Ci * BN;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < per; e += (size_t)gridDim.x * blockDim.x) {
         float s = 0.f;
@@ -636,7 +636,8 @@ __global__ void wgrad_reduce(const float *__restrict__ slabs, float *__restrict_
         const int ci = (int)(r % Ci); r /= Ci;
         const int tap = (int)(r % 9);
         const int kd = (int)(r / 9);
-        dw[((((size_t)co * Ci + ci) * 3 + kd) * 3 + tap / 3) * 3 + tap % 3] = s;
+        float *dst = dw + ((((size_t)co * Ci + ci) * 3 + kd) * 3 + tap / 3) * 3 + tap % 3;
+        *dst = accumulate ? *dst + s : s;
     }
 }
 
@@ -673,14 +674,15 @@ extern "C" void mvx_conv3d_tile_shape(int32_t *tile_h, int32_t *tile_w) {
 extern "C" int mvx_conv3d_forward(const float *in, const float *wpk, const float *bias, float *out,
                                   double *stats, int32_t din, int32_t dout, int32_t h, int32_t w,
                                   int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
-                                  int32_t relu, const int32_t *occupancy, const uint32_t *site_bits,
+                                  int32_t flags, const int32_t *occupancy, const uint32_t *site_bits,
                                   uint64_t *exec_quads, void *stream) {
     MVX_CHECK_ARG(in && wpk && out);
     int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
     if (rc) return rc;
     MVX_CHECK_ARG(dout == (din + 2 * pad_d - 3) / stride_d + 1);
     hipStream_t st = (hipStream_t)stream;
-    if (stats) {
+    const int relu = flags & MVX_FLAG_RELU;
+    if (stats && !(flags & MVX_FLAG_PREZEROED)) {
         hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * MVX_REP * 2 * cout, st);
         if (e != hipSuccess) return (int)e;
     }
@@ -732,7 +734,7 @@ extern "C" size_t mvx_conv3d_wgrad_workspace_bytes(int32_t h, int32_t w, int32_t
 
 extern "C" int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int32_t din, int32_t dout,
                                 int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d,
-                                int32_t pad_d, void *workspace, size_t workspace_bytes, void *stream) {
+                                int32_t pad_d, int32_t flags, void *workspace, size_t workspace_bytes, void *stream) {
     MVX_CHECK_ARG(in && dz && dw && workspace);
     int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
     if (rc) return rc;
@@ -748,7 +750,7 @@ extern "C" int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int
     MVX_LAUNCH_CHECK();
     const size_t per_slab = (size_t)27 * cin * BN;
     hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)workspace, dw,
-                       nstrips, cin);
+                       nstrips, cin, flags & MVX_FLAG_ACCUMULATE);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -803,7 +805,7 @@ extern "C" int mvx_conv3d_wgrad_sites(const float *feat, const int64_t *coords, 
     MVX_LAUNCH_CHECK();
     const size_t per_slab = (size_t)27 * cin * BN;
     hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)workspace, dw,
-                       nstrips, cin);
+                       nstrips, cin, 0);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

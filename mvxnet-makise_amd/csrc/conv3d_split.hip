@@ -350,7 +350,7 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_split(const float *__
     }
 }
 
-__global__ void wgrad_reduce_split(const float *__restrict__ slabs, float *__restrict__ dw, int nstrips, int Ci) {
+__global__ void wgrad_reduce_split(const float *__restrict__ slabs, float *__restrict__ dw, int nstrips, int Ci, int accumulate) {
     const size_t per = (size_t)27 * Ci * BN;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < per; e += (size_t)gridDim.x * blockDim.x) {
         float s = 0.f;
@@ -360,7 +360,8 @@ __global__ void wgrad_reduce_split(const float *__restrict__ slabs, float *__res
         const int ci = (int)(r % Ci); r /= Ci;
         const int tap = (int)(r % 9);
         const int kd = (int)(r / 9);
-        dw[((((size_t)co * Ci + ci) * 3 + kd) * 3 + tap / 3) * 3 + tap % 3] = s;
+        float *dst = dw + ((((size_t)co * Ci + ci) * 3 + kd) * 3 + tap / 3) * 3 + tap % 3;
+        *dst = accumulate ? *dst + s : s;
     }
 }
 
@@ -386,13 +387,14 @@ extern "C" int mvx_conv3d_pack_weights_split(const float *w, void *wsplit, int32
 
 extern "C" int mvx_conv3d_forward_split(const float *in, const void *wsplit, const float *bias, float *out, double *stats,
                                         int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
-                                        int32_t stride_d, int32_t pad_d, int32_t relu, void *stream) {
+                                        int32_t stride_d, int32_t pad_d, int32_t flags, void *stream) {
     MVX_CHECK_ARG(in && wsplit && out);
+    const int relu = flags & MVX_FLAG_RELU;
     int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
     if (rc) return rc;
     MVX_CHECK_ARG(dout == (din + 2 * pad_d - 3) / stride_d + 1);
     hipStream_t st = (hipStream_t)stream;
-    if (stats) {
+    if (stats && !(flags & MVX_FLAG_PREZEROED)) {
         hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * MVX_REP * 2 * cout, st);
         if (e != hipSuccess) return (int)e;
     }
@@ -419,7 +421,7 @@ extern "C" int mvx_conv3d_dgrad_split(const float *dz, const void *wsplit_dgrad,
 
 extern "C" int mvx_conv3d_wgrad_split(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
                                       int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
-                                      void *workspace, size_t workspace_bytes, void *stream) {
+                                      int32_t flags, void *workspace, size_t workspace_bytes, void *stream) {
     MVX_CHECK_ARG(in && dz && dw && workspace);
     int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
     if (rc) return rc;
@@ -439,7 +441,7 @@ extern "C" int mvx_conv3d_wgrad_split(const float *in, const float *dz, float *d
     MVX_LAUNCH_CHECK();
     const size_t per_slab = (size_t)27 * cin * BN;
     hipLaunchKernelGGL(wgrad_reduce_split, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)workspace, dw,
-                       nstrips, cin);
+                       nstrips, cin, flags & MVX_FLAG_ACCUMULATE);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

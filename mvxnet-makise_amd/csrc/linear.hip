@@ -256,11 +256,11 @@ __global__ __launch_bounds__(256) void linear_wgrad(const float *__restrict__ x,
     }
 }
 
-__global__ void slab_reduce(const float *__restrict__ slabs, float *__restrict__ out, size_t per, int nslabs) {
+__global__ void slab_reduce(const float *__restrict__ slabs, float *__restrict__ out, size_t per, int nslabs, int accumulate) {
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < per; e += (size_t)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int k = 0; k < nslabs; ++k) s += slabs[(size_t)k * per + e];
-        out[e] = s;
+        out[e] = accumulate ? out[e] + s : s;
     }
 }
 
@@ -284,12 +284,13 @@ extern "C" size_t mvx_linear_splitk_workspace_bytes(int64_t rows, int32_t n) {
 
 extern "C" int mvx_linear_forward(const float *x, int32_t ldx, const float *w, int32_t ldw, int32_t w_transposed,
                                   const float *bias, float *y, int32_t ldy, double *stats, const float *row_w,
-                                  int64_t rows, int32_t k, int32_t n, int32_t relu, void *splitk_workspace,
+                                  int64_t rows, int32_t k, int32_t n, int32_t flags, void *splitk_workspace,
                                   size_t splitk_workspace_bytes, void *stream) {
+    const int relu = flags & MVX_FLAG_RELU;
     MVX_CHECK_ARG(x && w && y && rows >= 0 && k > 0 && n > 0 && ldx >= k && ldy >= n);
     MVX_CHECK_ARG(ldw >= (w_transposed ? n : k));
     hipStream_t st = (hipStream_t)stream;
-    if (stats) {
+    if (stats && !(flags & MVX_FLAG_PREZEROED)) {
         hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * MVX_REP * 2 * n, st);
         if (e != hipSuccess) return (int)e;
     }
@@ -334,7 +335,7 @@ extern "C" int mvx_linear_forward(const float *x, int32_t ldx, const float *w, i
         if (ldy == n) {
             const size_t total = (size_t)rows * n;
             hipLaunchKernelGGL(slab_reduce, dim3(mvx_cdiv(total, 256) > 2048 ? 2048 : mvx_cdiv(total, 256)), dim3(256), 0, st,
-                               (const float *)splitk_workspace, y, total, splits);
+                               (const float *)splitk_workspace, y, total, splits, 0);
         } else {
             return MVX_EINVAL;   // split-K needs a dense destination
         }
@@ -351,11 +352,12 @@ extern "C" size_t mvx_linear_wgrad_workspace_bytes(int64_t rows, int32_t k, int3
 }
 
 extern "C" int mvx_linear_wgrad(const float *x, int32_t ldx, const float *dz, int32_t lddz, float *dw,
-                                int64_t rows, int32_t k, int32_t n, void *workspace, size_t workspace_bytes,
-                                void *stream) {
+                                int64_t rows, int32_t k, int32_t n, int32_t flags, void *workspace,
+                                size_t workspace_bytes, void *stream) {
     MVX_CHECK_ARG(x && dz && dw && workspace && rows >= 0 && k > 0 && n > 0 && ldx >= k && lddz >= n);
     hipStream_t st = (hipStream_t)stream;
     if (rows == 0) {
+        if (flags & MVX_FLAG_ACCUMULATE) return MVX_OK;
         hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)n * k, st);
         return e == hipSuccess ? MVX_OK : (int)e;
     }
@@ -373,7 +375,7 @@ extern "C" int mvx_linear_wgrad(const float *x, int32_t ldx, const float *dz, in
     MVX_LAUNCH_CHECK();
     const size_t total = (size_t)n * k;
     hipLaunchKernelGGL(slab_reduce, dim3(mvx_cdiv(total, 256) > 1024 ? 1024 : mvx_cdiv(total, 256)), dim3(256), 0, st,
-                       (const float *)workspace, dw, total, (int)strips);
+                       (const float *)workspace, dw, total, (int)strips, flags & MVX_FLAG_ACCUMULATE);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

@@ -183,11 +183,12 @@ static int sgeom_ok(int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cou
 
 extern "C" int mvx_sparse_conv_output(const float *p, const int32_t *index_grid, const float *bias, float *out,
                                       double *stats, int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cout,
-                                      int32_t stride_d, int32_t pad_d, int32_t relu, void *stream) {
+                                      int32_t stride_d, int32_t pad_d, int32_t flags, void *stream) {
+    const int relu = flags & MVX_FLAG_RELU;
     MVX_CHECK_ARG(index_grid && out && sgeom_ok(din, dout, h, w, cout, stride_d, pad_d));
     MVX_CHECK_ARG(cout / 4 * OTW <= 256 && 256 % (cout / 4) == 0);
     hipStream_t st = (hipStream_t)stream;
-    if (stats) {
+    if (stats && !(flags & MVX_FLAG_PREZEROED)) {
         hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * MVX_REP * 2 * cout, st);
         if (e != hipSuccess) return (int)e;
     }

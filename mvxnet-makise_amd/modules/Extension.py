@@ -45,11 +45,11 @@ PROTOTYPES = {
     'mvx_bn_finalize': (_i32, [_p, _f64, _f64, _p, _i32, _p]),
     'mvx_bn_apply': (_i32, [_p, _p, _p, _i64, _i32, _p]),
     'mvx_bn_backward_scratch_bytes': (_sz, [_i32]),
-    'mvx_bn_relu_backward': (_i32, [_p, _p, _p, _f64, _p, _p, _p, _p, _i64, _i32, _p]),
+    'mvx_bn_relu_backward': (_i32, [_p, _p, _p, _f64, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     'mvx_linear_splitk_workspace_bytes': (_sz, [_i64, _i32]),
     'mvx_linear_forward': (_i32, [_p, _i32, _p, _i32, _i32, _p, _p, _i32, _p, _p, _i64, _i32, _i32, _i32, _p, _sz, _p]),
     'mvx_linear_wgrad_workspace_bytes': (_sz, [_i64, _i32, _i32]),
-    'mvx_linear_wgrad': (_i32, [_p, _i32, _p, _i32, _p, _i64, _i32, _i32, _p, _sz, _p]),
+    'mvx_linear_wgrad': (_i32, [_p, _i32, _p, _i32, _p, _i64, _i32, _i32, _i32, _p, _sz, _p]),
     'mvx_vfe_bn_max_concat': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p]),
     'mvx_vfe_max_concat_backward': (_i32, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p]),
     'mvx_bn_segment_max': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p]),
@@ -69,13 +69,13 @@ PROTOTYPES = {
     'mvx_conv3d_pack_weights_split': (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     'mvx_conv3d_forward_split': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_conv3d_dgrad_split': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
-    'mvx_conv3d_wgrad_split': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _sz, _p]),
+    'mvx_conv3d_wgrad_split': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _sz, _p]),
     'mvx_conv3d_dgrad_sites': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_conv3d_wgrad_sites_workspace_bytes': (_sz, [_i32, _i32, _i32]),
     'mvx_conv3d_wgrad_sites': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _sz, _p]),
     'mvx_conv3d_dgrad': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_conv3d_wgrad_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32]),
-    'mvx_conv3d_wgrad': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _sz, _p]),
+    'mvx_conv3d_wgrad': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _sz, _p]),
 }
 
 

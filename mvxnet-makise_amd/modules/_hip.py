@@ -9,6 +9,61 @@ VoxelizeResult = collections.namedtuple('VoxelizeResult', 'voxels coords counts 
 
 _ws_cache = {}
 STATS_REPLICAS = 32      # MVX_STATS_REPLICAS of include/mvx_hip.h
+FLAG_RELU, FLAG_PREZEROED, FLAG_ACCUMULATE = 1, 2, 4      # MVX_FLAG_* of include/mvx_hip.h
+
+# When True, the backward of the hot-path layers adds weight / bias gradients straight into the existing
+# ``.grad`` buffers inside the reduction kernels (and returns None to autograd), instead of producing a
+# temporary that autograd adds afterwards.  Set by the training pipeline (modules/pipeline.py).
+GRAD_SINK = False
+
+
+class ZeroArena:
+    """One f64 buffer cleared with ONE fill per frame, from which every BatchNorm accumulator of the
+    frame is carved (the C entry points then skip their own memsets: MVX_FLAG_PREZEROED)."""
+
+    def __init__(self, device, doubles=1 << 19):
+        self.buf = torch.empty((doubles,), dtype=torch.float64, device=device)
+        self.off = doubles                 # exhausted until begin()
+
+    def begin(self):
+        self.buf.zero_()
+        self.off = 0
+
+    def take(self, n):
+        n_al = (n + 31) & ~31
+        if self.off + n_al > self.buf.numel():
+            return None
+        view = self.buf[self.off:self.off + n]
+        self.off += n_al
+        return view
+
+
+ARENA = None
+
+
+def arena_begin(device):
+    """Start a frame: clear the accumulator arena (creates it on first use)."""
+    global ARENA
+    if ARENA is None or ARENA.buf.device != device:
+        ARENA = ZeroArena(device)
+    ARENA.begin()
+
+
+def arena_end():
+    if ARENA is not None:
+        ARENA.off = ARENA.buf.numel()
+
+
+def _acc_f64(shape, device):
+    """(accumulator tensor, flag): carved from the frame arena (pre-zeroed) or freshly allocated."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    if ARENA is not None and ARENA.buf.device == device:
+        v = ARENA.take(n)
+        if v is not None:
+            return v.view(shape), FLAG_PREZEROED
+    return torch.empty(shape, dtype=torch.float64, device=device), 0
 
 # Optional live kernel timing (bench.py): name -> list of (start_event, end_event, algorithmic_flops).
 # Events are recorded on the current stream, the stream every kernel of this library is launched on.
@@ -170,17 +225,22 @@ def bn_apply(y, mi, out=None):
     return out
 
 
-def bn_relu_backward(dyhat, y, mi, count, want_dbias=True, dz=None, row_w=None):
+def bn_relu_backward(dyhat, y, mi, count, want_dbias=True, dz=None, row_w=None, dbias_out=None):
+    """dbias_out: existing gradient buffer to ADD the bias gradient to (returns None for dbias then)."""
     C = mi.shape[1]
     rows = y.numel() // C
     if dz is None:
         dz = torch.empty_like(y)
-    dbias = torch.empty((C,), dtype=torch.float32, device=y.device) if want_dbias else None
-    scratch = torch.empty((X.lib.mvx_bn_backward_scratch_bytes(C) // 8,), dtype=torch.float64, device=y.device)
+    flags = 0
+    if dbias_out is not None:
+        dbias, flags = dbias_out, FLAG_ACCUMULATE
+    else:
+        dbias = torch.empty((C,), dtype=torch.float32, device=y.device) if want_dbias else None
+    scratch, fz = _acc_f64((X.lib.mvx_bn_backward_scratch_bytes(C) // 8,), y.device)
     X.check(X.lib.mvx_bn_relu_backward(X.ptr(dyhat), X.ptr(y), X.ptr(mi), float(count), X.ptr(dz),
-                                       X.ptr(dbias), X.ptr(scratch), X.ptr(row_w), rows, C, X.stream()),
+                                       X.ptr(dbias), X.ptr(scratch), X.ptr(row_w), rows, C, flags | fz, X.stream()),
             'mvx_bn_relu_backward')
-    return dz, dbias
+    return dz, (None if dbias_out is not None else dbias)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -210,12 +270,13 @@ def conv3d_forward(x, wpk, bias, cout, sd, pd, relu=True, want_stats=True, occup
     din, H, W, cin = x.shape
     dout = conv_out_depth(din, sd, pd)
     out = torch.empty((dout, H, W, cout), dtype=torch.float32, device=x.device)
-    stats = torch.empty((STATS_REPLICAS, 2, cout), dtype=torch.float64, device=x.device) if want_stats else None
+    stats, fz = _acc_f64((STATS_REPLICAS, 2, cout), x.device) if want_stats else (None, 0)
+    flags = (FLAG_RELU if relu else 0) | fz
     if split:
         assert occupancy is None
         with _Timed('conv3d_gather_split', conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None else 0):
             X.check(X.lib.mvx_conv3d_forward_split(X.ptr(x), X.ptr(wpk), X.ptr(bias), X.ptr(out), X.ptr(stats), din, dout,
-                                                   H, W, cin, cout, sd, pd, int(relu), X.stream()),
+                                                   H, W, cin, cout, sd, pd, flags, X.stream()),
                     'mvx_conv3d_forward_split')
         return out, stats
     counter = None
@@ -228,7 +289,7 @@ def conv3d_forward(x, wpk, bias, cout, sd, pd, relu=True, want_stats=True, occup
     flops = conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None and occupancy is None else 0
     with _Timed(name, flops):
         X.check(X.lib.mvx_conv3d_forward(X.ptr(x), X.ptr(wpk), X.ptr(bias), X.ptr(out), X.ptr(stats),
-                                         din, dout, H, W, cin, cout, sd, pd, int(relu), X.ptr(occ_t), X.ptr(bits_t),
+                                         din, dout, H, W, cin, cout, sd, pd, flags, X.ptr(occ_t), X.ptr(bits_t),
                                          X.ptr(counter), X.stream()), 'mvx_conv3d_forward')
     return out, stats
 
@@ -268,21 +329,21 @@ def conv3d_dgrad(dz, wpk_d, din, cin, sd, pd, split=False):
     return dx
 
 
-def conv3d_wgrad(x, dz, sd, pd, split=False):
+def conv3d_wgrad(x, dz, sd, pd, split=False, accumulate_into=None):
+    """accumulate_into: existing (cout,cin,3,3,3) gradient buffer to ADD to (returns None then)."""
     din, H, W, cin = x.shape
     dout, _, _, cout = dz.shape
-    dw = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device=x.device)
+    if accumulate_into is not None:
+        dw, flags = accumulate_into, FLAG_ACCUMULATE
+    else:
+        dw, flags = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device=x.device), 0
     nbytes = X.lib.mvx_conv3d_wgrad_workspace_bytes(H, W, cin, cout)
     ws = workspace(nbytes, x.device, 'wgrad')
-    if split:
-        with _Timed('conv3d_wgrad_split', conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None else 0):
-            X.check(X.lib.mvx_conv3d_wgrad_split(X.ptr(x), X.ptr(dz), X.ptr(dw), din, dout, H, W, cin, cout, sd, pd,
-                                                 X.ptr(ws), ws.numel(), X.stream()), 'mvx_conv3d_wgrad_split')
-        return dw
-    with _Timed('conv3d_wgrad', conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None else 0):
-        X.check(X.lib.mvx_conv3d_wgrad(X.ptr(x), X.ptr(dz), X.ptr(dw), din, dout, H, W, cin, cout, sd, pd,
-                                       X.ptr(ws), ws.numel(), X.stream()), 'mvx_conv3d_wgrad')
-    return dw
+    fn, name = (X.lib.mvx_conv3d_wgrad_split, 'conv3d_wgrad_split') if split else (X.lib.mvx_conv3d_wgrad, 'conv3d_wgrad')
+    with _Timed(name, conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None else 0):
+        X.check(fn(X.ptr(x), X.ptr(dz), X.ptr(dw), din, dout, H, W, cin, cout, sd, pd, flags, X.ptr(ws), ws.numel(),
+                   X.stream()), 'mvx_' + name)
+    return None if accumulate_into is not None else dw
 
 
 # ---------------------------------------------------------------------------------------------
@@ -309,25 +370,31 @@ def linear_forward(x, w, bias, relu=True, want_stats=True, w_transposed=False, r
     N = w.shape[1] if w_transposed else w.shape[0]
     if out is None:
         out = torch.empty((R, N), dtype=torch.float32, device=x.device)
-    stats = torch.empty((STATS_REPLICAS, 2, N), dtype=torch.float64, device=x.device) if want_stats else None
+    stats, fz = _acc_f64((STATS_REPLICAS, 2, N), x.device) if want_stats else (None, 0)
     ws = None
     if bias is None and not relu and not want_stats and K >= 256 and R * N <= (1 << 22):
         ws = workspace(X.lib.mvx_linear_splitk_workspace_bytes(R, N), x.device, 'splitk')
     X.check(X.lib.mvx_linear_forward(_vptr(x), _ld(x), _vptr(w), _ld(w), int(w_transposed), X.ptr(bias),
-                                     _vptr(out), _ld(out), X.ptr(stats), X.ptr(row_w), R, K, N, int(relu),
+                                     _vptr(out), _ld(out), X.ptr(stats), X.ptr(row_w), R, K, N,
+                                     (FLAG_RELU if relu else 0) | fz,
                                      X.ptr(ws), ws.numel() if ws is not None else 0, X.stream()), 'mvx_linear_forward')
     return out, stats
 
 
-def linear_wgrad(x, dz):
+def linear_wgrad(x, dz, accumulate_into=None):
+    """dW (N,K) = dz^T x; accumulate_into: existing contiguous (N,K)-sized gradient buffer to ADD to."""
     R, K = x.shape
     N = dz.shape[1]
-    dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
+    if accumulate_into is not None:
+        assert accumulate_into.is_contiguous() and accumulate_into.numel() == N * K
+        dw, flags = accumulate_into, FLAG_ACCUMULATE
+    else:
+        dw, flags = torch.empty((N, K), dtype=torch.float32, device=x.device), 0
     nbytes = X.lib.mvx_linear_wgrad_workspace_bytes(R, K, N)
     ws = workspace(nbytes, x.device, 'lwgrad')
-    X.check(X.lib.mvx_linear_wgrad(_vptr(x), _ld(x), _vptr(dz), _ld(dz), X.ptr(dw), R, K, N, X.ptr(ws),
+    X.check(X.lib.mvx_linear_wgrad(_vptr(x), _ld(x), _vptr(dz), _ld(dz), X.ptr(dw), R, K, N, flags, X.ptr(ws),
                                    ws.numel(), X.stream()), 'mvx_linear_wgrad')
-    return dw
+    return None if accumulate_into is not None else dw
 
 
 # ---------------------------------------------------------------------------------------------
@@ -529,10 +596,11 @@ def sparse_conv_output(P, idx_grid, dhw, bias, cout, sd, pd, relu=True, want_sta
     din, H, W = dhw
     dout = conv_out_depth(din, sd, pd)
     out = torch.empty((dout, H, W, cout), dtype=torch.float32, device=P.device)
-    stats = torch.empty((STATS_REPLICAS, 2, cout), dtype=torch.float64, device=P.device) if want_stats else None
+    stats, fz = _acc_f64((STATS_REPLICAS, 2, cout), P.device) if want_stats else (None, 0)
     with _Timed('sparse_conv_output', 0):
         X.check(X.lib.mvx_sparse_conv_output(X.ptr(P), X.ptr(idx_grid), X.ptr(bias), X.ptr(out), X.ptr(stats), din, dout,
-                                             H, W, cout, sd, pd, int(relu), X.stream()), 'mvx_sparse_conv_output')
+                                             H, W, cout, sd, pd, (FLAG_RELU if relu else 0) | fz, X.stream()),
+                'mvx_sparse_conv_output')
     return out, stats
 
 
@@ -543,3 +611,10 @@ def sparse_conv_gather_dz(dz, coords, din, sd, pd):
     X.check(X.lib.mvx_sparse_conv_gather_dz(X.ptr(dz), X.ptr(coords), V, X.ptr(G), din, dout, H, W, cout, sd, pd,
                                             X.stream()), 'mvx_sparse_conv_gather_dz')
     return G
+
+
+def sink_of(param):
+    """The parameter's existing gradient buffer if direct accumulation is enabled, else None."""
+    if GRAD_SINK and param is not None and param.grad is not None and param.grad.is_contiguous():
+        return param.grad
+    return None

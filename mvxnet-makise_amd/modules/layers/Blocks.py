@@ -32,14 +32,17 @@ class FCNFunction(torch.autograd.Function):
         out = _hip.bn_apply(y, mi)
         ctx.save_for_backward(x, w, y, mi, row_w)
         ctx.count = count
+        ctx.params = (w, b)
         return out
 
     @staticmethod
     def backward(ctx, g):
         x, w, y, mi, row_w = ctx.saved_tensors
         w2 = w.reshape(w.shape[0], -1)
-        dz, db = _hip.bn_relu_backward(g.contiguous(), y, mi, ctx.count, True, row_w=row_w)
-        dw = _hip.linear_wgrad(x, dz).reshape(w.shape)
+        sw, sb = _hip.sink_of(ctx.params[0]), _hip.sink_of(ctx.params[1])
+        dz, db = _hip.bn_relu_backward(g.contiguous(), y, mi, ctx.count, True, row_w=row_w, dbias_out=sb)
+        dw = _hip.linear_wgrad(x, dz, accumulate_into=sw)
+        dw = dw.reshape(w.shape) if dw is not None else None
         dx = None
         if ctx.needs_input_grad[0]:
             dx, _ = _hip.linear_forward(dz, w2, None, relu=False, want_stats=False, w_transposed=True)
@@ -110,14 +113,15 @@ class CRB3dFunction(torch.autograd.Function):
         out = _hip.bn_apply(y, mi)
         ctx.save_for_backward(x, w, y, mi)
         ctx.geom = (sd, pd, count, split)
+        ctx.params = (w, b)
         return out
 
     @staticmethod
     def backward(ctx, g):
         x, w, y, mi = ctx.saved_tensors
         sd, pd, count, split = ctx.geom
-        dz, db = _hip.bn_relu_backward(g.contiguous(), y, mi, count, True)
-        dw = _hip.conv3d_wgrad(x, dz, sd, pd, split=split)
+        dz, db = _hip.bn_relu_backward(g.contiguous(), y, mi, count, True, dbias_out=_hip.sink_of(ctx.params[1]))
+        dw = _hip.conv3d_wgrad(x, dz, sd, pd, split=split, accumulate_into=_hip.sink_of(ctx.params[0]))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _hip.conv3d_dgrad(dz, _pack(ctx.packer, w, True, split), x.shape[0], x.shape[3], sd, pd, split=split)
@@ -178,6 +182,7 @@ class VoxelGemmCRB3dFunction(torch.autograd.Function):
         out = _hip.bn_apply(y, mi)
         ctx.save_for_backward(feat, coords, w_all, y, mi)
         ctx.geom = (dhw[0], sd, pd, count, tuple(w.shape))
+        ctx.params = (w, b)
         return out
 
     @staticmethod
@@ -185,7 +190,7 @@ class VoxelGemmCRB3dFunction(torch.autograd.Function):
         feat, coords, w_all, y, mi = ctx.saved_tensors
         din, sd, pd, count, wshape = ctx.geom
         cout, cin = wshape[0], wshape[1]
-        dz, db = _hip.bn_relu_backward(g.contiguous(), y, mi, count, True)
+        dz, db = _hip.bn_relu_backward(g.contiguous(), y, mi, count, True, dbias_out=_hip.sink_of(ctx.params[1]))
         G = _hip.sparse_conv_gather_dz(dz, coords, din, sd, pd)
         dw_all = _hip.linear_wgrad(feat, G)                                   # (27*cout, cin)
         dw = dw_all.reshape(3, 3, 3, cout, cin).permute(3, 4, 0, 1, 2).contiguous()

@@ -55,9 +55,18 @@ def train_step_frames(model, batch, grad_mid, imsize):
     frames, prepared, status = prepare_frames(batch, model.head)
     statuses = [status]
     nvox = []
-    for f, (voxels, idx) in enumerate(frames):
-        mid = model.middle(voxels, batch.fpn_levels[f], idx, [None], imsize, prepared=prepared[f],
-                           status_sink=statuses)
-        mid.backward(grad_mid)
-        nvox.append(voxels.shape[1])
+    # gradients are accumulated over the frames of the step anyway: let the reduction kernels add them
+    # straight into the (pre-existing) .grad buffers, and clear all BatchNorm accumulators of a frame
+    # with one fill
+    old_sink, _hip.GRAD_SINK = _hip.GRAD_SINK, True
+    try:
+        for f, (voxels, idx) in enumerate(frames):
+            _hip.arena_begin(voxels.device)
+            mid = model.middle(voxels, batch.fpn_levels[f], idx, [None], imsize, prepared=prepared[f],
+                               status_sink=statuses)
+            mid.backward(grad_mid)
+            nvox.append(voxels.shape[1])
+    finally:
+        _hip.GRAD_SINK = old_sink
+        _hip.arena_end()
     return nvox, statuses

@@ -24,6 +24,7 @@ class VFEFunction(torch.autograd.Function):
         out, am = _hip.vfe_bn_max_concat(y, mi, V, T, cr)
         ctx.save_for_backward(x, w, y, mi, am)
         ctx.vt = (V, T, cr)
+        ctx.params = (w, b)
         return out
 
     @staticmethod
@@ -31,8 +32,9 @@ class VFEFunction(torch.autograd.Function):
         x, w, y, mi, am = ctx.saved_tensors
         V, T, cr = ctx.vt
         dyh = _hip.vfe_max_concat_backward(g.contiguous(), am, V, T, cr)
-        dz, db = _hip.bn_relu_backward(dyh, y, mi, V * T, True, dz=dyh, row_w=cr.row_w if cr is not None else None)
-        dw = _hip.linear_wgrad(x, dz)
+        dz, db = _hip.bn_relu_backward(dyh, y, mi, V * T, True, dz=dyh, row_w=cr.row_w if cr is not None else None,
+                                       dbias_out=_hip.sink_of(ctx.params[1]))
+        dw = _hip.linear_wgrad(x, dz, accumulate_into=_hip.sink_of(ctx.params[0]))
         dx = None
         if ctx.needs_input_grad[0]:
             dx, _ = _hip.linear_forward(dz, w, None, relu=False, want_stats=False, w_transposed=True)
@@ -50,6 +52,7 @@ class FCNMaxFunction(torch.autograd.Function):
         out, am = _hip.bn_segment_max(y, mi, V, T, cr)
         ctx.save_for_backward(x, w, y, mi, am)
         ctx.vt = (V, T, cr)
+        ctx.params = (w, b)
         return out
 
     @staticmethod
@@ -57,8 +60,9 @@ class FCNMaxFunction(torch.autograd.Function):
         x, w, y, mi, am = ctx.saved_tensors
         V, T, cr = ctx.vt
         dyh = _hip.segment_max_backward(g.contiguous(), am, V, T, cr)
-        dz, db = _hip.bn_relu_backward(dyh, y, mi, V * T, True, dz=dyh, row_w=cr.row_w if cr is not None else None)
-        dw = _hip.linear_wgrad(x, dz)
+        dz, db = _hip.bn_relu_backward(dyh, y, mi, V * T, True, dz=dyh, row_w=cr.row_w if cr is not None else None,
+                                       dbias_out=_hip.sink_of(ctx.params[1]))
+        dw = _hip.linear_wgrad(x, dz, accumulate_into=_hip.sink_of(ctx.params[0]))
         dx = None
         if ctx.needs_input_grad[0]:
             dx, _ = _hip.linear_forward(dz, w, None, relu=False, want_stats=False, w_transposed=True)

@@ -203,3 +203,46 @@ def test_reindex_layout_and_state_dict_keys(small_cfg):
     assert r.shape == (1, 128, 10, 16, 24)
     assert torch.equal(r[0, :, 3, 1, 2], x[0]) and torch.equal(r[0, :, 9, 15, 23], x[2])
     assert float(r.abs().sum()) == pytest.approx(float(x.abs().sum()), rel=1e-5)
+
+
+def test_pipeline_gradient_sink_and_arena_match_plain_autograd(golden):
+    """modules.pipeline.train_step_frames (direct accumulation into .grad, one accumulator fill per
+    frame) gives the same gradients as plain autograd on the same frames."""
+    import modules.config as cfg
+    from MVXNet import MVXNet
+    from modules import parallel
+    from modules.pipeline import FrameBatch, train_step_frames, voxelize_batch
+    g = golden('mvxnet_small')
+    old, old_r = list(cfg.config['voxelshape']), list(cfg.config['velorange'])
+    cfg.config['voxelshape'] = [int(v) for v in g['voxelshape']]
+    cfg.config['velorange'] = [0.0, -2.4, -3.0, 3.2, 2.4, 1.0]
+    cfg.config['voxelsize'] = [0.2, 0.2, 0.4]
+    try:
+        torch.manual_seed(3)
+        model = MVXNet().to(DEV)
+        gp = golden('group_small')
+        pts = torch.from_numpy(gp['pcd'].copy())
+        pts[:, 4] = torch.rand(pts.shape[0]) * 369
+        pts[:, 5] = torch.rand(pts.shape[0]) * 1223
+        B = 2
+        batch = FrameBatch(torch.stack([pts, pts.flip(0)]).to(DEV).contiguous(),
+                           torch.stack([torch.from_numpy(gp['perm'])] * B).to(DEV).contiguous(),
+                           torch.full((B,), pts.shape[0], dtype=torch.int32, device=DEV),
+                           [[torch.from_numpy(g[k])[None].to(DEV) for k in ('f0', 'f1', 'f2')]] * B)
+        G = torch.from_numpy(g['G'])[None].to(DEV)
+        imsize = [370.0, 1224.0]
+        hot = [p for k, p in model.named_parameters() if p.requires_grad and '.rpn.' not in k]
+        bucket = parallel.GradBucket(hot)
+        bucket.zero()
+        train_step_frames(model, batch, G, imsize)
+        got = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None and '.rpn.' not in k}
+        bucket.zero()
+        frames, _ = voxelize_batch(batch)
+        for f, (vox, idx) in enumerate(frames):
+            model.middle(vox, batch.fpn_levels[f], idx, [None], imsize).backward(G)
+        for k, p in model.named_parameters():
+            if k in got:
+                assert rel_err(got[k], p.grad) < 1e-5, k
+    finally:
+        cfg.config['voxelshape'], cfg.config['velorange'] = old, old_r
+        cfg.config['voxelsize'] = [(old_r[k + 3] - old_r[k]) / old[k] for k in range(3)]
