@@ -625,6 +625,117 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_sites(const float *__restric
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// weight gradient, SIMD-balanced form (used when Cin % 64 == 0).  Nine one-tap waves do not divide
+// over the CU's four SIMDs (3+2+2+2), so the 9-wave kernel above idles a quarter of the matrix
+// pipes.  Here a workgroup has FOUR waves, (m, n) in 2 x 2 over a 64(c) x 64(n) block of dW, and
+// every wave walks all nine in-plane taps itself: 9 accumulator tiles (144 VGPRs), nine tap-shifted
+// A reads + one B read per MFMA step, two workgroups (8 waves, 2 per SIMD) per CU.
+// ------------------------------------------------------------------------------------------
+constexpr int W4_THREADS = 256;
+constexpr int W4_C = 64;               // input channels per workgroup
+
+__global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restrict__ in,
+                                                            const float *__restrict__ dz,
+                                                            float *__restrict__ slabs, Geom g,
+                                                            int tiles_per_strip) {
+    __shared__ __attribute__((aligned(16))) float s_x[HH * HW * W4_C];
+    __shared__ __attribute__((aligned(16))) float s_z[TH * TW * ZP];
+    const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
+    const int ntiles = tiles_x * tiles_y;
+    const int strip = blockIdx.x;
+    const int nchunks = g.Cin / W4_C;
+    const int kd = blockIdx.y / nchunks, cc = blockIdx.y % nchunks;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int t_beg = strip * tiles_per_strip;
+    const int t_end = min(ntiles, t_beg + tiles_per_strip);
+    constexpr int NX = (HH * HW * 16 + W4_THREADS - 1) / W4_THREADS;    // float4 per thread, halo (64 ch)
+    constexpr int NZ = TH * TW * 16 / W4_THREADS;                       // float4 per thread, dz
+    float4 xr[NX], zr[NZ];
+    auto load_step = [&](int d, int t) {
+        const int ds = d * g.sd - g.pd + kd;
+        const int tx0 = (t % tiles_x) * TW, ty0 = (t / tiles_x) * TH;
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int c = tid + W4_THREADS * u;
+            xr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < HH * HW * 16) {
+                const int r = c >> 4, part = c & 15;
+                const int gy = ty0 - 1 + r / HW, gx = tx0 - 1 + r % HW;
+                if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W)
+                    xr[u] = *(const float4 *)(in + (((size_t)ds * g.H + gy) * g.W + gx) * g.Cin + cc * W4_C + part * 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NZ; ++u) {
+            const int c = tid + W4_THREADS * u;
+            const int r = c >> 4, part = c & 15;
+            const int gy = ty0 + (r >> 4), gx = tx0 + (r & 15);
+            zr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy < g.H && gx < g.W)
+                zr[u] = *(const float4 *)(dz + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout + part * 4);
+        }
+    };
+    auto next_valid = [&](int d) {
+        while (d < g.Dout) {
+            const int ds = d * g.sd - g.pd + kd;
+            if (ds >= 0 && ds < g.Din) break;
+            ++d;
+        }
+        return d;
+    };
+    int d = next_valid(0), t = t_beg;
+    const bool any = d < g.Dout && t_beg < t_end;
+    if (any) load_step(d, t);
+    while (any && d < g.Dout) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int c = tid + W4_THREADS * u;
+            if (c < HH * HW * 16) *(float4 *)(s_x + (c >> 4) * W4_C + (c & 15) * 4) = xr[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NZ; ++u) {
+            const int c = tid + W4_THREADS * u;
+            *(float4 *)(s_z + (c >> 4) * ZP + (c & 15) * 4) = zr[u];
+        }
+        __syncthreads();
+        int nt = t + 1, nd = d;
+        if (nt >= t_end) { nt = t_beg; nd = next_valid(d + 1); }
+        if (nd < g.Dout) load_step(nd, nt);
+#pragma unroll 2
+        for (int kk = 0; kk < TH * TW / 2; ++kk) {
+            const int s = 2 * kk + lh;
+            const float b = s_z[s * ZP + wn * 32 + li];
+            const float *xa = s_x + ((s >> 4) * HW + (s & 15)) * W4_C + wm * 32 + li;
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9)
+                acc[t9] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[((t9 / 3) * HW + (t9 % 3)) * W4_C], b, acc[t9], 0, 0, 0);
+        }
+        t = nt; d = nd;
+    }
+    // slab[strip][kd][tap][c (Cin)][n (64)]
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9) {
+        float *o = slabs + ((((size_t)strip * 3 + kd) * 9 + t9) * g.Cin + cc * W4_C + wm * 32) * BN + wn * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            o[(size_t)row * BN + li] = acc[t9][r];
+        }
+    }
+}
+
 // dW[co][ci][kd][kh][kw] = sum_strips slab[strip][kd][tap][ci][co]
 __global__ void wgrad_reduce(const float *__restrict__ slabs, float *__restrict__ dw, int nstrips, int Ci, int accumulate) {
     const size_t per = (size_t)27 * Ci * BN;
@@ -714,10 +825,11 @@ extern "C" int mvx_conv3d_dgrad(const float *dz, const float *wpk_dgrad, float *
 }
 
 static int wgrad_strips(int h, int w, int cin) {
-    // Two 9-wave workgroups fit a CU (LDS), so 512 run at once; all have the same length, so the grid
-    // should fill exactly one round: strips x (3 depth taps x cin/32 chunks) <= 512.
+    // Two workgroups fit a CU (LDS), so 512 run at once; all have the same length, so the grid
+    // should fill exactly one round: strips x (3 depth taps x channel chunks) <= 512.
     const int ntiles = (int)(mvx_cdiv(w, TW) * mvx_cdiv(h, TH));
-    int strips = 512 / (3 * (cin / BK));
+    const int chunks = (cin % W4_C == 0) ? cin / W4_C : cin / BK;
+    int strips = 512 / (3 * chunks);
     if (strips < 1) strips = 1;
     int per = (ntiles + strips - 1) / strips;
     if (per < 1) per = 1;
@@ -745,8 +857,12 @@ extern "C" int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int
     MVX_CHECK_ARG(workspace_bytes >= (size_t)nstrips * 27 * cin * BN * sizeof(float));
     Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv3d_wgrad, dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz,
-                       (float *)workspace, g, per);
+    if (cin % W4_C == 0)
+        hipLaunchKernelGGL(conv3d_wgrad4, dim3(nstrips, 3 * (cin / W4_C)), dim3(W4_THREADS), 0, st, in, dz,
+                           (float *)workspace, g, per);
+    else
+        hipLaunchKernelGGL(conv3d_wgrad, dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz,
+                           (float *)workspace, g, per);
     MVX_LAUNCH_CHECK();
     const size_t per_slab = (size_t)27 * cin * BN;
     hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)workspace, dw,
