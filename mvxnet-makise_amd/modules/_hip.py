@@ -17,6 +17,63 @@ FLAG_RELU, FLAG_PREZEROED, FLAG_ACCUMULATE = 1, 2, 4      # MVX_FLAG_* of includ
 GRAD_SINK = False
 
 
+# When True (and gradients go straight into .grad, see GRAD_SINK), weight-gradient kernels are enqueued
+# on a second HIP stream: their results are only needed at the optimizer step, so they overlap with the
+# rest of the backward pass (their MFMA work fills the CUs while BatchNorm / gather kernels wait on HBM).
+ASYNC_WGRAD = False
+_SIDE = {}
+
+
+def side_stream(device):
+    st = _SIDE.get(device.index)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _SIDE[device.index] = st
+    return st
+
+
+def join_side_stream(device=None):
+    """Make the current stream wait for every weight-gradient kernel enqueued on the side stream."""
+    for idx, st in _SIDE.items():
+        if device is None or device.index == idx:
+            torch.cuda.current_stream(st.device).wait_stream(st)
+
+
+class _SideStream:
+    """Run the enclosed launches on the side stream, ordered after everything already enqueued on the
+    current stream; the tensors they read are kept alive for the side stream (record_stream)."""
+
+    def __init__(self, *tensors):
+        self.tensors = [t for t in tensors if t is not None]
+
+    def __enter__(self):
+        dev = self.tensors[0].device
+        self.side = side_stream(dev)
+        self.side.wait_stream(torch.cuda.current_stream(dev))
+        for t in self.tensors:
+            t.record_stream(self.side)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc)
+
+
+class _Inline:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _wgrad_scope(accumulate_into, *tensors):
+    if ASYNC_WGRAD and accumulate_into is not None:
+        return _SideStream(*tensors)
+    return _Inline()
+
+
 class ZeroArena:
     """One f64 buffer cleared with ONE fill per frame, from which every BatchNorm accumulator of the
     frame is carved (the C entry points then skip their own memsets: MVX_FLAG_PREZEROED)."""
@@ -338,11 +395,12 @@ def conv3d_wgrad(x, dz, sd, pd, split=False, accumulate_into=None):
     else:
         dw, flags = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device=x.device), 0
     nbytes = X.lib.mvx_conv3d_wgrad_workspace_bytes(H, W, cin, cout)
-    ws = workspace(nbytes, x.device, 'wgrad')
     fn, name = (X.lib.mvx_conv3d_wgrad_split, 'conv3d_wgrad_split') if split else (X.lib.mvx_conv3d_wgrad, 'conv3d_wgrad')
-    with _Timed(name, conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None else 0):
-        X.check(fn(X.ptr(x), X.ptr(dz), X.ptr(dw), din, dout, H, W, cin, cout, sd, pd, flags, X.ptr(ws), ws.numel(),
-                   X.stream()), 'mvx_' + name)
+    with _wgrad_scope(accumulate_into, x, dz) as scope:
+        ws = workspace(nbytes, x.device, 'wgrad_side' if isinstance(scope, _SideStream) else 'wgrad')
+        with _Timed(name, conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None else 0):
+            X.check(fn(X.ptr(x), X.ptr(dz), X.ptr(dw), din, dout, H, W, cin, cout, sd, pd, flags, X.ptr(ws), ws.numel(),
+                       X.stream()), 'mvx_' + name)
     return None if accumulate_into is not None else dw
 
 
@@ -391,9 +449,10 @@ def linear_wgrad(x, dz, accumulate_into=None):
     else:
         dw, flags = torch.empty((N, K), dtype=torch.float32, device=x.device), 0
     nbytes = X.lib.mvx_linear_wgrad_workspace_bytes(R, K, N)
-    ws = workspace(nbytes, x.device, 'lwgrad')
-    X.check(X.lib.mvx_linear_wgrad(_vptr(x), _ld(x), _vptr(dz), _ld(dz), X.ptr(dw), R, K, N, flags, X.ptr(ws),
-                                   ws.numel(), X.stream()), 'mvx_linear_wgrad')
+    with _wgrad_scope(accumulate_into, x, dz) as scope:
+        ws = workspace(nbytes, x.device, 'lwgrad_side' if isinstance(scope, _SideStream) else 'lwgrad')
+        X.check(X.lib.mvx_linear_wgrad(_vptr(x), _ld(x), _vptr(dz), _ld(dz), X.ptr(dw), R, K, N, flags, X.ptr(ws),
+                                       ws.numel(), X.stream()), 'mvx_linear_wgrad')
     return None if accumulate_into is not None else dw
 
 

@@ -11,6 +11,9 @@ import modules.config as cfg
 from modules import _hip
 
 
+ASYNC_WGRAD = True      # weight-gradient kernels on a second stream (see modules/_hip.py)
+
+
 class FrameBatch:
     """B frames resident in HBM with a fixed point capacity per frame."""
 
@@ -59,6 +62,7 @@ def train_step_frames(model, batch, grad_mid, imsize):
     # straight into the (pre-existing) .grad buffers, and clear all BatchNorm accumulators of a frame
     # with one fill
     old_sink, _hip.GRAD_SINK = _hip.GRAD_SINK, True
+    old_async, _hip.ASYNC_WGRAD = _hip.ASYNC_WGRAD, ASYNC_WGRAD
     try:
         for f, (voxels, idx) in enumerate(frames):
             _hip.arena_begin(voxels.device)
@@ -68,5 +72,7 @@ def train_step_frames(model, batch, grad_mid, imsize):
             nvox.append(voxels.shape[1])
     finally:
         _hip.GRAD_SINK = old_sink
+        _hip.ASYNC_WGRAD = old_async
         _hip.arena_end()
+        _hip.join_side_stream()          # the gradients are complete for whoever comes next on this stream
     return nvox, statuses
