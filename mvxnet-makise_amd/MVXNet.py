@@ -25,6 +25,16 @@ class MVXNet(nn.Module):
         self.backbone = VoxelNet()
         self.backbone.apply(initWeights)
 
+    def prepack(self):
+        """Pack the dense-conv weights on the CURRENT stream for the arithmetic in use, so frames that
+        run on other streams find them ready (modules/pipeline.py)."""
+        from modules.layers.Blocks import CRB3d, conv_split_math
+        split = conv_split_math()
+        for m in self.backbone.cml.modules():
+            if isinstance(m, CRB3d):
+                m._packer(False, split)
+                m._packer(True, split)
+
     def point_features(self, voxels, imgs, calibs, imsize):
         """(1,N,T,9) -> (1,N,T,23): 7 geometric channels + 16 fused image channels
         (MVXNet.py:25-26).  Padded rows of ``voxels`` are zeroed in place by the head."""

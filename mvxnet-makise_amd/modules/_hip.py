@@ -95,20 +95,30 @@ class ZeroArena:
         return view
 
 
-ARENA = None
+_ARENAS = {}          # one arena per (device, stream): frames in flight on different streams never share one
+_ARENA_ON = False
+
+
+def _arena_key(device):
+    return (device.index, torch.cuda.current_stream(device).cuda_stream)
 
 
 def arena_begin(device):
-    """Start a frame: clear the accumulator arena (creates it on first use)."""
-    global ARENA
-    if ARENA is None or ARENA.buf.device != device:
-        ARENA = ZeroArena(device)
-    ARENA.begin()
+    """Start a frame on the current stream: clear its accumulator arena (created on first use)."""
+    global _ARENA_ON
+    key = _arena_key(device)
+    if key not in _ARENAS:
+        with torch.cuda.device(device):
+            _ARENAS[key] = ZeroArena(device)
+    _ARENAS[key].begin()
+    _ARENA_ON = True
 
 
 def arena_end():
-    if ARENA is not None:
-        ARENA.off = ARENA.buf.numel()
+    global _ARENA_ON
+    _ARENA_ON = False
+    for a in _ARENAS.values():
+        a.off = a.buf.numel()
 
 
 def _acc_f64(shape, device):
@@ -116,10 +126,12 @@ def _acc_f64(shape, device):
     n = 1
     for d in shape:
         n *= int(d)
-    if ARENA is not None and ARENA.buf.device == device:
-        v = ARENA.take(n)
-        if v is not None:
-            return v.view(shape), FLAG_PREZEROED
+    if _ARENA_ON:
+        a = _ARENAS.get(_arena_key(device))
+        if a is not None:
+            v = a.take(n)
+            if v is not None:
+                return v.view(shape), FLAG_PREZEROED
     return torch.empty(shape, dtype=torch.float64, device=device), 0
 
 # Optional live kernel timing (bench.py): name -> list of (start_event, end_event, algorithmic_flops).
@@ -163,7 +175,7 @@ def conv_flops(d_out_planes, d_src_planes, H, W, cin, cout, sd, pd, dgrad=False)
 
 def workspace(nbytes, dev, tag):
     """Grow-only scratch buffer per (device, tag); stream-ordered reuse on the current stream."""
-    key = (dev.index, tag)
+    key = (dev.index, tag, torch.cuda.current_stream(dev).cuda_stream)    # one buffer per (tag, stream): no cross-stream reuse
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
@@ -673,7 +685,31 @@ def sparse_conv_gather_dz(dz, coords, din, sd, pd):
 
 
 def sink_of(param):
-    """The parameter's existing gradient buffer if direct accumulation is enabled, else None."""
+    """The parameter's existing gradient buffer if direct accumulation is enabled, else None.  Used for
+    WEIGHT gradients, whose kernels run on the side stream when ASYNC_WGRAD is on."""
     if GRAD_SINK and param is not None and param.grad is not None and param.grad.is_contiguous():
         return param.grad
+    return None
+
+
+def bias_sink_of(param):
+    """Bias gradients are finished on the stream of the backward pass; with ASYNC_WGRAD every write to a
+    .grad buffer must go through the one side stream (frames may be in flight on several streams), so
+    then the bias gradient is produced as a temporary and added by ``accumulate_grad``."""
+    return None if ASYNC_WGRAD else sink_of(param)
+
+
+def accumulate_grad(param, g):
+    """Add ``g`` into ``param.grad`` without autograd when sinks are on (side stream if ASYNC_WGRAD);
+    returns what the autograd node should return for this parameter (None, or g itself)."""
+    if g is None:
+        return None
+    tgt = sink_of(param)
+    if tgt is None:
+        return g
+    if ASYNC_WGRAD:
+        with _SideStream(g):
+            tgt.add_(g.view_as(tgt))
+    else:
+        tgt.add_(g.view_as(tgt))
     return None

@@ -39,8 +39,9 @@ class FCNFunction(torch.autograd.Function):
     def backward(ctx, g):
         x, w, y, mi, row_w = ctx.saved_tensors
         w2 = w.reshape(w.shape[0], -1)
-        sw, sb = _hip.sink_of(ctx.params[0]), _hip.sink_of(ctx.params[1])
+        sw, sb = _hip.sink_of(ctx.params[0]), _hip.bias_sink_of(ctx.params[1])
         dz, db = _hip.bn_relu_backward(g.contiguous(), y, mi, ctx.count, True, row_w=row_w, dbias_out=sb)
+        db = _hip.accumulate_grad(ctx.params[1], db)
         dw = _hip.linear_wgrad(x, dz, accumulate_into=sw)
         dw = dw.reshape(w.shape) if dw is not None else None
         dx = None
@@ -120,7 +121,8 @@ class CRB3dFunction(torch.autograd.Function):
     def backward(ctx, g):
         x, w, y, mi = ctx.saved_tensors
         sd, pd, count, split = ctx.geom
-        dz, db = _hip.bn_relu_backward(g.contiguous(), y, mi, count, True, dbias_out=_hip.sink_of(ctx.params[1]))
+        dz, db = _hip.bn_relu_backward(g.contiguous(), y, mi, count, True, dbias_out=_hip.bias_sink_of(ctx.params[1]))
+        db = _hip.accumulate_grad(ctx.params[1], db)
         dw = _hip.conv3d_wgrad(x, dz, sd, pd, split=split, accumulate_into=_hip.sink_of(ctx.params[0]))
         dx = None
         if ctx.needs_input_grad[0]:
@@ -190,10 +192,11 @@ class VoxelGemmCRB3dFunction(torch.autograd.Function):
         feat, coords, w_all, y, mi = ctx.saved_tensors
         din, sd, pd, count, wshape = ctx.geom
         cout, cin = wshape[0], wshape[1]
-        dz, db = _hip.bn_relu_backward(g.contiguous(), y, mi, count, True, dbias_out=_hip.sink_of(ctx.params[1]))
+        dz, db = _hip.bn_relu_backward(g.contiguous(), y, mi, count, True, dbias_out=_hip.bias_sink_of(ctx.params[1]))
+        db = _hip.accumulate_grad(ctx.params[1], db)
         G = _hip.sparse_conv_gather_dz(dz, coords, din, sd, pd)
         dw_all = _hip.linear_wgrad(feat, G)                                   # (27*cout, cin)
-        dw = dw_all.reshape(3, 3, 3, cout, cin).permute(3, 4, 0, 1, 2).contiguous()
+        dw = _hip.accumulate_grad(ctx.params[0], dw_all.reshape(3, 3, 3, cout, cin).permute(3, 4, 0, 1, 2))
         dfeat = None
         if ctx.needs_input_grad[0]:
             dfeat, _ = _hip.linear_forward(G, w_all, None, relu=False, want_stats=False, w_transposed=True)

@@ -12,6 +12,16 @@ from modules import _hip
 
 
 ASYNC_WGRAD = True      # weight-gradient kernels on a second stream (see modules/_hip.py)
+LANES = 2               # frames in flight: frame f runs on lane stream f % LANES (needs ASYNC_WGRAD for the
+                        # single-writer gradient accumulation); 1 = all frames on the caller's stream
+_LANE_STREAMS = {}
+
+
+def lane_streams(device, n):
+    key = device.index
+    if key not in _LANE_STREAMS or len(_LANE_STREAMS[key]) < n:
+        _LANE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return _LANE_STREAMS[key][:n]
 
 
 class FrameBatch:
@@ -63,16 +73,27 @@ def train_step_frames(model, batch, grad_mid, imsize):
     # with one fill
     old_sink, _hip.GRAD_SINK = _hip.GRAD_SINK, True
     old_async, _hip.ASYNC_WGRAD = _hip.ASYNC_WGRAD, ASYNC_WGRAD
+    dev = batch.points6.device
+    main = torch.cuda.current_stream(dev)
+    lanes = lane_streams(dev, LANES) if (LANES > 1 and ASYNC_WGRAD) else [main]
     try:
+        if len(lanes) > 1:
+            model.prepack()
+            for st in lanes:
+                st.wait_stream(main)             # voxelization, maps, packed weights, zeroed gradients
         for f, (voxels, idx) in enumerate(frames):
-            _hip.arena_begin(voxels.device)
-            mid = model.middle(voxels, batch.fpn_levels[f], idx, [None], imsize, prepared=prepared[f],
-                               status_sink=statuses)
-            mid.backward(grad_mid)
+            with torch.cuda.stream(lanes[f % len(lanes)]):
+                _hip.arena_begin(dev)
+                mid = model.middle(voxels, batch.fpn_levels[f], idx, [None], imsize, prepared=prepared[f],
+                                   status_sink=statuses)
+                mid.backward(grad_mid)
             nvox.append(voxels.shape[1])
     finally:
         _hip.GRAD_SINK = old_sink
         _hip.ASYNC_WGRAD = old_async
         _hip.arena_end()
+        for st in lanes:
+            if st is not main:
+                main.wait_stream(st)
         _hip.join_side_stream()          # the gradients are complete for whoever comes next on this stream
     return nvox, statuses

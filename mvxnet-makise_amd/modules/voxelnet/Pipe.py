@@ -33,7 +33,8 @@ class VFEFunction(torch.autograd.Function):
         V, T, cr = ctx.vt
         dyh = _hip.vfe_max_concat_backward(g.contiguous(), am, V, T, cr)
         dz, db = _hip.bn_relu_backward(dyh, y, mi, V * T, True, dz=dyh, row_w=cr.row_w if cr is not None else None,
-                                       dbias_out=_hip.sink_of(ctx.params[1]))
+                                       dbias_out=_hip.bias_sink_of(ctx.params[1]))
+        db = _hip.accumulate_grad(ctx.params[1], db)
         dw = _hip.linear_wgrad(x, dz, accumulate_into=_hip.sink_of(ctx.params[0]))
         dx = None
         if ctx.needs_input_grad[0]:
@@ -61,7 +62,8 @@ class FCNMaxFunction(torch.autograd.Function):
         V, T, cr = ctx.vt
         dyh = _hip.segment_max_backward(g.contiguous(), am, V, T, cr)
         dz, db = _hip.bn_relu_backward(dyh, y, mi, V * T, True, dz=dyh, row_w=cr.row_w if cr is not None else None,
-                                       dbias_out=_hip.sink_of(ctx.params[1]))
+                                       dbias_out=_hip.bias_sink_of(ctx.params[1]))
+        db = _hip.accumulate_grad(ctx.params[1], db)
         dw = _hip.linear_wgrad(x, dz, accumulate_into=_hip.sink_of(ctx.params[0]))
         dx = None
         if ctx.needs_input_grad[0]:
