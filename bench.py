@@ -120,6 +120,39 @@ def cpu_baseline(points_per_frame, n_frames=3):
                       % (n_frames, points_per_frame, nv, dt)}
 
 
+def isolated_conv_roofline(dev, math):
+    """The dominant kernel's launches (conv2/conv3 forward + dgrad) on an otherwise idle GPU: inside the
+    step they share the CUs with the side-stream weight-gradient kernels and the other lane's frame, so
+    the live figure above includes that sharing; this one prices the kernel alone."""
+    from modules import _hip
+    import modules.config as cfg
+    H, W = cfg.voxelshape[0], cfg.voxelshape[1]
+    split = math == 'bf16x3'
+    tot_ms, tot_fl = 0.0, 0.0
+    for cin, cout, din, sd, pd in ((64, 64, 5, 1, 0), (64, 64, 3, 2, 1)):
+        dout = _hip.conv_out_depth(din, sd, pd)
+        x = torch.randn((din, H, W, cin), device=dev)
+        w = torch.randn((cout, cin, 3, 3, 3), device=dev) * 0.04
+        b = torch.zeros(cout, device=dev)
+        dz = torch.randn((dout, H, W, cout), device=dev)
+        wf, wd = _hip.conv3d_pack(w, False, split=split), _hip.conv3d_pack(w, True, split=split)
+        for fn, fl in ((lambda: _hip.conv3d_forward(x, wf, b, cout, sd, pd, split=split), _hip.conv_flops(dout, din, H, W, cin, cout, sd, pd)),
+                       (lambda: _hip.conv3d_dgrad(dz, wd, din, cin, sd, pd, split=split), _hip.conv_flops(din, dout, H, W, cout, cin, sd, pd, True))):
+            fn()
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(5):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+            tot_ms += s.elapsed_time(e) / 5
+            tot_fl += fl
+    mult, peak = (3.0, BF16_MFMA_PEAK_TFLOPS) if split else (1.0, FP32_MFMA_PEAK_TFLOPS)
+    ach = mult * tot_fl / (tot_ms * 1e-3) / 1e12
+    return {'achieved': ach, 'frac': ach / peak, 'avg_launch_ms': tot_ms / 4}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -232,6 +265,7 @@ def main():
 
     if rank == 0:
         roof = conv_roofline(timers, main_math)
+        roof['isolated'] = isolated_conv_roofline(dev, main_math)
         tpath = os.path.join(REPO, 'profiles', 'traffic.json')
         if os.path.exists(tpath) and main_math == 'f32':
             with open(tpath) as fh:

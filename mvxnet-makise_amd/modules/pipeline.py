@@ -12,7 +12,8 @@ from modules import _hip
 
 
 ASYNC_WGRAD = True      # weight-gradient kernels on a second stream (see modules/_hip.py)
-LANES = 2               # frames in flight: frame f runs on lane stream f % LANES (needs ASYNC_WGRAD for the
+import os as _os
+LANES = int(_os.environ.get('MVX_LANES', '2'))   # frames in flight: frame f runs on lane stream f % LANES (needs ASYNC_WGRAD for the
                         # single-writer gradient accumulation); 1 = all frames on the caller's stream
 _LANE_STREAMS = {}
 
