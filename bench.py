@@ -166,9 +166,9 @@ def main():
     args = ap.parse_args()
 
     from modules import parallel
-    rank, world, local = parallel.init_from_env()
+    rank, world, local = parallel.init_from_env(os.environ.get('MVX_DIST_BACKEND'))
     assert world == args.gpus or world == 1, 'launch with torchrun --nproc-per-node = --gpus'
-    dev = torch.device('cuda', local)
+    dev = torch.device('cuda', local % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
 
     import modules.config as cfg

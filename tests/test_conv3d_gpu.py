@@ -176,3 +176,27 @@ def test_conv3d_bf16x3_split_accuracy(cin, cout, din, H, W, sd, pd):
         F.conv3d(x[None].double(), wg, None, (sd, 1, 1), (pd, 1, 1)).backward(dz[None].double())
         dw = _hip.conv3d_wgrad(xc, to_cl(dz).to(DEV), sd, pd, split=True)
         assert rel_err(dw.cpu(), wg.grad) < 2e-5
+
+
+@pytest.mark.parametrize('split', [False, True])
+def test_conv3d_full_size_adjoint_identities(split):
+    """BASELINE-size grid (conv2 geometry, 5x352x400x64): the three passes must be mutually adjoint,
+    <dz, conv(x)> = <dgrad(dz), x> = <wgrad(x, dz), w> -- a size-independent check that needs no CPU
+    reference.  Inner products in float64 on the GPU."""
+    from modules import _hip
+    g = torch.Generator().manual_seed(9)
+    H, W, cin, cout, din, sd, pd = 352, 400, 64, 64, 5, 1, 0
+    dout = _hip.conv_out_depth(din, sd, pd)
+    x = torch.randn((din, H, W, cin), generator=g).to(DEV)
+    dz = torch.randn((dout, H, W, cout), generator=g).to(DEV)
+    w = (torch.randn((cout, cin, 3, 3, 3), generator=g) / np.sqrt(27 * cin)).to(DEV)
+    y, _ = _hip.conv3d_forward(x, _hip.conv3d_pack(w, False, split=split), None, cout, sd, pd, relu=False,
+                               want_stats=False, split=split)
+    dx = _hip.conv3d_dgrad(dz, _hip.conv3d_pack(w, True, split=split), din, cin, sd, pd, split=split)
+    dw = _hip.conv3d_wgrad(x, dz, sd, pd, split=split)
+    a = float((dz.double() * y.double()).sum())
+    b = float((dx.double() * x.double()).sum())
+    c = float((dw.double() * w.double()).sum())
+    scale = float(dz.double().norm() * y.double().norm())
+    tol = 2e-5 if split else 2e-6
+    assert abs(a - b) / scale < tol and abs(a - c) / scale < tol, (a, b, c, scale)
