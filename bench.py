@@ -303,6 +303,15 @@ def main():
                                'executed_tflops': tfl / (tms * 1e-3) / 1e12 if tms > 0 else 0.0,
                                'executed_gflop_per_launch': tfl / len(evs) / 1e9}
         out['other_kernels'] = other
+        stages = {}
+        for name, evs in timers.items():
+            if name.startswith('hbm:') and evs:
+                tms = sum(s.elapsed_time(e) for s, e, _ in evs)
+                tb = sum(b for _, _, b in evs)
+                stages[name[4:]] = {'launches': len(evs), 'avg_ms': tms / len(evs),
+                                    'algorithmic_GBps': tb / (tms * 1e-3) / 1e9 if tms > 0 else 0.0,
+                                    'frac_of_8TBps': tb / (tms * 1e-3) / 8e12 if tms > 0 else 0.0}
+        out['hbm_stages'] = stages
         if world == 1 and not args.no_cpu_baseline:
             del model, batch
             torch.cuda.empty_cache()

@@ -28,6 +28,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TH = 8, TW = 16;          // output patch of a workgroup
 constexpr int HH = TH + 2, HW = TW + 2; // halo
@@ -108,17 +109,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather(const float *__restrict_
     const int b_base0 = li * PITCH + 4 * lh;
     const int b_base1 = (32 + li) * PITCH + 4 * lh;
 
-    float4 wreg[2];
+    f32x4 wreg[2];
     auto load_w = [&](int kd, int tap, int cc) {
         const float *tile = wpk + ((((size_t)kd * 9 + tap) * nchunks + cc) * g.Cout + (size_t)nb * BN) * BK;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) wreg[u] = *(const float4 *)(tile + (size_t)(tid + 256 * u) * 4);
+        for (int u = 0; u < 2; ++u) wreg[u] = *(const f32x4 *)(tile + (size_t)(tid + 256 * u) * 4);
     };
     auto store_w = [&]() {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int c = tid + 256 * u;
-            *(float4 *)(s_w + (c >> 3) * PITCH + (c & 7) * 4) = wreg[u];
+            *(f32x4 *)(s_w + (c >> 3) * PITCH + (c & 7) * 4) = wreg[u];
         }
     };
 
@@ -193,6 +194,202 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather(const float *__restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;          // A-row of this accumulator register
+        const int gy = ty0 + 2 * wv + (row >> 4), gx = tx0 + (row & 15);
+        float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
+        if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+        if (gy < g.H && gx < g.W) {
+            float *o = out + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout;
+            o[n0] = v0;
+            o[n1] = v1;
+            s1a += v0; s2a += v0 * v0;
+            s1b += v1; s2b += v1 * v1;
+        }
+    }
+    if (stats) {
+        s1a += __shfl_xor(s1a, 32, 64); s2a += __shfl_xor(s2a, 32, 64);
+        s1b += __shfl_xor(s1b, 32, 64); s2b += __shfl_xor(s2b, 32, 64);
+        __syncthreads();
+        if (lh == 0) {
+            s_red[wv][li] = s1a; s_red[wv][32 + li] = s1b;
+            s_red[wv][BN + li] = s2a; s_red[wv][BN + 32 + li] = s2b;
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const double t = (double)s_red[0][tid] + (double)s_red[1][tid] + (double)s_red[2][tid] + (double)s_red[3][tid];
+            const int which = tid / BN, c = tid % BN;
+            const unsigned rep = (blockIdx.x + blockIdx.y * gridDim.x) % MVX_REP;
+            atomicAdd(stats + ((size_t)rep * 2 + which) * g.Cout + nb * BN + c, t);
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// gather convolution, software-pipelined form (dense source: forward of conv2/conv3 and every dgrad)
+//
+// Same tiling, operand layout and accumulation order as conv3d_gather, so results are bit-identical.
+// The difference is what the memory system sees: co-resident workgroups start together and share the
+// MFMA pipe, which keeps them in lock step, so a halo fetch issued at the top of a (depth tap, chunk)
+// stage is exposed in BOTH of them at once.  Here the halo of stage s+1 is fetched into registers
+// right after stage s starts computing, and the weights go to LDS a tap ROW (3 taps) at a time, with
+// the next row in flight under 96 MFMAs: 6 barriers per stage instead of 19, no exposed global latency.
+// Load order matters (vector-memory returns are in order): the weight row needed next is always issued
+// BEFORE the long-latency halo fetch, so waiting for it does not wait for the halo.
+// ------------------------------------------------------------------------------------------
+constexpr int WROW = BN * PITCH;           // one tap's weight tile in LDS
+// Halo row stride: a multiple of 64 floats, so that the two patch rows a wave reads (lanes 0-15 / 16-31)
+// start on the same 16-byte slot of the 256-byte bank row.  ds_read_b128 is served in the lane groups
+// {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): with site pitch 36 floats (9 slots, odd) the slots of one
+// row are a permutation of 0..15, and equal row phases make every group hit 16 distinct slots.
+constexpr int HROW = ((HW * PITCH + 63) / 64) * 64;
+
+// Launch geometry: (tiles, output planes, 64-channel blocks).  An XCD-contiguous remap of the (tile, plane)
+// space was measured and was not faster (forward equal, stride-2 dgrad slower), so the plain grid stays.
+inline dim3 gather_grid(const Geom &g) { return dim3(mvx_cdiv(g.W, TW) * mvx_cdiv(g.H, TH), g.Dout, g.Cout / BN); }
+
+__global__ __launch_bounds__(256, 2) void conv3d_gather_pf(const float *__restrict__ in,
+                                                           const float *__restrict__ wpk,
+                                                           const float *__restrict__ bias,
+                                                           float *__restrict__ out, double *__restrict__ stats,
+                                                           Geom g, int relu) {
+    __shared__ __attribute__((aligned(16))) float s_halo[HH * HROW];
+    __shared__ __attribute__((aligned(16))) float s_w[3 * WROW];
+    __shared__ float s_red[4][2 * BN];
+
+    const int tiles_x = (g.W + TW - 1) / TW;
+    const int tx0 = (blockIdx.x % tiles_x) * TW, ty0 = (blockIdx.x / tiles_x) * TH;
+    const int d = blockIdx.y, nb = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int nchunks = g.Cin / BK;
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+    const int my_ty = 2 * wv + (li >> 4), my_tx = li & 15;
+    const int a_base = my_ty * HROW + my_tx * PITCH + 4 * lh;
+    const int b_base0 = li * PITCH + 4 * lh;
+    const int b_base1 = (32 + li) * PITCH + 4 * lh;
+
+    // valid depth taps of this output plane (block-uniform), packed as (kd, source plane) pairs
+    int kd_l[3] = {0, 0, 0}, ds_l[3] = {0, 0, 0}, nk = 0;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+        const int ds = src_depth(g, d, kd);
+        if (ds >= 0) {
+            if (nk == 0) { kd_l[0] = kd; ds_l[0] = ds; }
+            else if (nk == 1) { kd_l[1] = kd; ds_l[1] = ds; }
+            else { kd_l[2] = kd; ds_l[2] = ds; }
+            ++nk;
+        }
+    }
+    const int nstages = nk * nchunks;
+    auto stage_kd = [&](int st, int &kd, int &ds, int &cc) __attribute__((always_inline)) {
+        const int i = st / nchunks;
+        cc = st - i * nchunks;
+        kd = i == 0 ? kd_l[0] : (i == 1 ? kd_l[1] : kd_l[2]);
+        ds = i == 0 ? ds_l[0] : (i == 1 ? ds_l[1] : ds_l[2]);
+    };
+
+    // per-thread halo slots: site r = c >> 3, 16-byte part c & 7, c = tid + 256 u
+    int h_off[6];               // global float offset inside a (plane, chunk) image, or -1 (outside -> zeros)
+    int h_lds[6];               // LDS float offset of the slot, or -1 (no slot: 1440 slots over 1536 threads x u)
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        const int c = tid + 256 * u;
+        h_off[u] = -1;
+        h_lds[u] = -1;
+        if (c < HH * HW * 8) {
+            const int r = c >> 3, part = c & 7;
+            const int ry = r / HW, rx = r - ry * HW;
+            const int gy = ty0 - 1 + ry, gx = tx0 - 1 + rx;
+            h_lds[u] = ry * HROW + rx * PITCH + part * 4;
+            if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) h_off[u] = (gy * g.W + gx) * g.Cin + part * 4;
+        }
+    }
+    f32x4 hreg[6], wreg[6];     // native vectors: HIP's float4 struct copies become memcpy and pin the arrays in scratch
+    auto load_halo = [&](int st) __attribute__((always_inline)) {
+        int kd, ds, cc;
+        stage_kd(st, kd, ds, cc);
+        const float *img = in + (size_t)ds * g.H * g.W * g.Cin + cc * BK;
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+            hreg[u] = h_off[u] >= 0 ? *(const f32x4 *)(img + h_off[u]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto store_halo = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+            if (h_lds[u] >= 0) *(f32x4 *)(s_halo + h_lds[u]) = hreg[u];
+    };
+    auto load_wrow = [&](int st, int row) __attribute__((always_inline)) {
+        int kd, ds, cc;
+        stage_kd(st, kd, ds, cc);
+        const float *row0 = wpk + ((((size_t)kd * 9 + row * 3) * nchunks + cc) * g.Cout + (size_t)nb * BN) * BK + (size_t)tid * 4;
+        const size_t tap_stride = (size_t)nchunks * g.Cout * BK;
+#pragma unroll
+        for (int v = 0; v < 6; ++v) wreg[v] = *(const f32x4 *)(row0 + (v >> 1) * tap_stride + (v & 1) * 1024);
+    };
+    auto store_wrow = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int v = 0; v < 6; ++v) {
+            const int c = tid + 256 * (v & 1);
+            *(f32x4 *)(s_w + (v >> 1) * WROW + (c >> 3) * PITCH + (c & 7) * 4) = wreg[v];
+        }
+    };
+    auto compute_row = [&](int row) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int a_off = a_base + row * HROW + t * PITCH;
+#pragma unroll
+            for (int q = 0; q < BK / 8; ++q) {
+                const float4 av = *(const float4 *)(s_halo + a_off + 8 * q);
+                const float4 b0 = *(const float4 *)(s_w + t * WROW + b_base0 + 8 * q);
+                const float4 b1 = *(const float4 *)(s_w + t * WROW + b_base1 + 8 * q);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b1.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b1.w, acc1, 0, 0, 0);
+            }
+        }
+    };
+
+    // Prefetches are unconditional (the last stage re-fetches its own operands and drops them): a
+    // conditionally written register array would be demoted to scratch memory.
+    load_wrow(0, 0);
+    load_halo(0);
+    for (int st = 0; st < nstages; ++st) {
+        const int nxt = st + 1 < nstages ? st + 1 : st;
+        __syncthreads();                           // previous stage's LDS reads are done
+        store_halo();
+        store_wrow();                              // tap row 0
+        __syncthreads();
+        load_wrow(st, 1);                          // next weight row first ...
+        load_halo(nxt);                            // ... then the long-latency halo of the next stage
+        compute_row(0);
+        __syncthreads();
+        store_wrow();                              // tap row 1 (waits for its 6 loads only)
+        __syncthreads();
+        load_wrow(st, 2);
+        compute_row(1);
+        __syncthreads();
+        store_wrow();                              // tap row 2
+        __syncthreads();
+        load_wrow(nxt, 0);
+        compute_row(2);
+    }
+
+    // ---- epilogue: bias, ReLU, store, BatchNorm statistics (identical to conv3d_gather)
+    const int n0 = nb * BN + li, n1 = n0 + 32;
+    const float bias0 = bias ? bias[n0] : 0.f, bias1 = bias ? bias[n1] : 0.f;
+    float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int gy = ty0 + 2 * wv + (row >> 4), gx = tx0 + (row & 15);
         float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
         if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
@@ -802,9 +999,11 @@ extern "C" int mvx_conv3d_forward(const float *in, const float *wpk, const float
     if (occupancy && site_bits)
         hipLaunchKernelGGL(conv3d_fwd_sparse_in, grid, dim3(256), 0, st, in, wpk, bias, out, stats, g, relu, occupancy,
                            (const unsigned *)site_bits, (int)mvx_cdiv(w, 32), (unsigned long long *)exec_quads);
-    else
+    else if (occupancy)
         hipLaunchKernelGGL(conv3d_gather, grid, dim3(256), 0, st, in, wpk, bias, out, stats, g, relu, occupancy,
                            (unsigned long long *)exec_quads);
+    else
+        hipLaunchKernelGGL(conv3d_gather_pf, gather_grid(g), dim3(256), 0, st, in, wpk, bias, out, stats, g, relu);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -818,8 +1017,8 @@ extern "C" int mvx_conv3d_dgrad(const float *dz, const float *wpk_dgrad, float *
     if (rc) return rc;
     Geom g{dout, din, h, w, cout, cin, stride_d, pad_d, 1};
     const dim3 grid(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), din, cin / BN);
-    hipLaunchKernelGGL(conv3d_gather, grid, dim3(256), 0, (hipStream_t)stream, dz, wpk_dgrad, (const float *)nullptr,
-                       dx, (double *)nullptr, g, 0, (const int *)nullptr, (unsigned long long *)nullptr);
+    hipLaunchKernelGGL(conv3d_gather_pf, gather_grid(g), dim3(256), 0, (hipStream_t)stream, dz, wpk_dgrad,
+                       (const float *)nullptr, dx, (double *)nullptr, g, 0);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

@@ -157,6 +157,11 @@ class _Timed:
         return False
 
 
+def _timed_bytes(name, nbytes):
+    """Timer for an HBM-bound stage: the third tuple field carries ALGORITHMIC bytes (negative marks bytes)."""
+    return _Timed('hbm:' + name, float(nbytes) if KERNEL_TIMERS is not None else 0)
+
+
 def conv_flops(d_out_planes, d_src_planes, H, W, cin, cout, sd, pd, dgrad=False):
     """Executed multiply-add FLOPs of one gather launch: depth taps that fall outside the source
     volume are skipped by the kernel and are NOT counted (in-plane zero padding is computed and
@@ -199,12 +204,14 @@ def voxelize(pcd, perm, n_points, lo, size, T, out_channels, cap_voxels=None, ex
     status = torch.zeros((1,), dtype=torch.int32, device=dev)
     nbytes = X.lib.mvx_voxelize_workspace_bytes(F, cap)
     ws = workspace(nbytes, dev, 'voxelize')
-    rc = X.lib.mvx_voxelize(X.ptr(pcd), X.ptr(perm), X.ptr(n_points), X.ptr(ext_idx), F, cap, ncol,
-                            float(lo[0]), float(lo[1]), float(lo[2]),
-                            float(size[0]), float(size[1]), float(size[2]),
-                            int(T), int(out_channels), cap_voxels,
-                            X.ptr(voxels), X.ptr(coords), X.ptr(counts), X.ptr(n_vox), X.ptr(status),
-                            X.ptr(ws), ws.numel(), X.stream())
+    # algorithmic bytes: points + permutation read; the voxel payload is priced at ~V = P/4 voxels per frame
+    with _timed_bytes('voxelize', F * cap * (ncol * 4 + 4) + F * (cap // 4) * (T * out_channels * 4 + 36)):
+        rc = X.lib.mvx_voxelize(X.ptr(pcd), X.ptr(perm), X.ptr(n_points), X.ptr(ext_idx), F, cap, ncol,
+                                float(lo[0]), float(lo[1]), float(lo[2]),
+                                float(size[0]), float(size[1]), float(size[2]),
+                                int(T), int(out_channels), cap_voxels,
+                                X.ptr(voxels), X.ptr(coords), X.ptr(counts), X.ptr(n_vox), X.ptr(status),
+                                X.ptr(ws), ws.numel(), X.stream())
     X.check(rc, 'mvx_voxelize')
     return VoxelizeResult(voxels, coords, counts, n_vox, status)
 
@@ -255,7 +262,8 @@ def cl_to_bev(cl):
     """channels-last (D,H,W,C) -> (C*D,H,W) contiguous, channel = c*D + d."""
     D, H, W, C = cl.shape
     bev = torch.empty((C * D, H, W), dtype=torch.float32, device=cl.device)
-    X.check(X.lib.mvx_cl_to_bev(X.ptr(cl), X.ptr(bev), D, H, W, C, 0, X.stream()), 'mvx_cl_to_bev')
+    with _timed_bytes('cl_bev_transpose', 2 * cl.numel() * 4):
+        X.check(X.lib.mvx_cl_to_bev(X.ptr(cl), X.ptr(bev), D, H, W, C, 0, X.stream()), 'mvx_cl_to_bev')
     return bev
 
 
@@ -290,7 +298,8 @@ def bn_apply(y, mi, out=None):
     rows = y.numel() // C
     if out is None:
         out = torch.empty_like(y)
-    X.check(X.lib.mvx_bn_apply(X.ptr(y), X.ptr(mi), X.ptr(out), rows, C, X.stream()), 'mvx_bn_apply')
+    with _timed_bytes('bn_apply', 2 * y.numel() * 4):
+        X.check(X.lib.mvx_bn_apply(X.ptr(y), X.ptr(mi), X.ptr(out), rows, C, X.stream()), 'mvx_bn_apply')
     return out
 
 
@@ -306,9 +315,10 @@ def bn_relu_backward(dyhat, y, mi, count, want_dbias=True, dz=None, row_w=None, 
     else:
         dbias = torch.empty((C,), dtype=torch.float32, device=y.device) if want_dbias else None
     scratch, fz = _acc_f64((X.lib.mvx_bn_backward_scratch_bytes(C) // 8,), y.device)
-    X.check(X.lib.mvx_bn_relu_backward(X.ptr(dyhat), X.ptr(y), X.ptr(mi), float(count), X.ptr(dz),
-                                       X.ptr(dbias), X.ptr(scratch), X.ptr(row_w), rows, C, flags | fz, X.stream()),
-            'mvx_bn_relu_backward')
+    with _timed_bytes('bn_relu_backward', 5 * y.numel() * 4):      # reduce reads 2 tensors, apply reads 2 + writes 1
+        X.check(X.lib.mvx_bn_relu_backward(X.ptr(dyhat), X.ptr(y), X.ptr(mi), float(count), X.ptr(dz),
+                                           X.ptr(dbias), X.ptr(scratch), X.ptr(row_w), rows, C, flags | fz, X.stream()),
+                'mvx_bn_relu_backward')
     return dz, (None if dbias_out is not None else dbias)
 
 
@@ -583,9 +593,12 @@ def feature_sample(vox2d, feats_cl, imsize_hw, eps, out, row_map=None):
     status = torch.zeros((1,), dtype=torch.int32, device=vox2d.device)
     for f in feats_cl:
         assert f.is_contiguous() and f.dtype == torch.float32 and f.shape[2] == C
-    X.check(X.lib.mvx_feature_sample(X.ptr(vox2d), vc, R, X.ptr(row_map), ptrs, hw, L, C,
-                                     float(imsize_hw[0]), float(imsize_hw[1]), float(eps), X.ptr(out),
-                                     X.ptr(status), X.stream()), 'mvx_feature_sample')
+    # algorithmic bytes: 4 taps x L levels x C floats gathered + L*C floats written per sampled row, + the voxel rows
+    nrows = out.shape[0]
+    with _timed_bytes('feature_sample', nrows * L * C * 4 * 5 + R * vc * 4):
+        X.check(X.lib.mvx_feature_sample(X.ptr(vox2d), vc, R, X.ptr(row_map), ptrs, hw, L, C,
+                                         float(imsize_hw[0]), float(imsize_hw[1]), float(eps), X.ptr(out),
+                                         X.ptr(status), X.stream()), 'mvx_feature_sample')
     return status
 
 
@@ -668,7 +681,7 @@ def sparse_conv_output(P, idx_grid, dhw, bias, cout, sd, pd, relu=True, want_sta
     dout = conv_out_depth(din, sd, pd)
     out = torch.empty((dout, H, W, cout), dtype=torch.float32, device=P.device)
     stats, fz = _acc_f64((STATS_REPLICAS, 2, cout), P.device) if want_stats else (None, 0)
-    with _Timed('sparse_conv_output', 0):
+    with _timed_bytes('sparse_conv_output', out.numel() * 4 + din * H * W * 4):     # dense output written + index grid read
         X.check(X.lib.mvx_sparse_conv_output(X.ptr(P), X.ptr(idx_grid), X.ptr(bias), X.ptr(out), X.ptr(stats), din, dout,
                                              H, W, cout, sd, pd, (FLAG_RELU if relu else 0) | fz, X.stream()),
                 'mvx_sparse_conv_output')

@@ -11,8 +11,8 @@ import modules.config as cfg
 from modules import _hip
 
 
-ASYNC_WGRAD = True      # weight-gradient kernels on a second stream (see modules/_hip.py)
 import os as _os
+ASYNC_WGRAD = _os.environ.get('MVX_ASYNC_WGRAD', '1') != '0'    # weight-gradient kernels on a second stream (see modules/_hip.py)
 LANES = int(_os.environ.get('MVX_LANES', '2'))   # frames in flight: frame f runs on lane stream f % LANES (needs ASYNC_WGRAD for the
                         # single-writer gradient accumulation); 1 = all frames on the caller's stream
 _LANE_STREAMS = {}
