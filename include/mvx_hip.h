@@ -184,6 +184,48 @@ int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int32_t din, i
                      void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Background rewrite of the CML stack (csrc/activity.hip).  The grid VoxelNet.reindex fills
+ * (modules/voxelnet/VoxelNet.py:16-22) is zero outside the voxel sites and every CML block is
+ * Conv3d -> ReLU -> BatchNorm without affine (modules/voxelnet/Pipe.py:31-43, modules/layers/Blocks.py:20-29),
+ * so a site without a voxel in its receptive field holds one per-(plane, channel) constant after each
+ * layer.  These entry points describe that background and let forward and wgrad skip it -- exact
+ * rewrites of the dense arithmetic, no approximation:
+ *
+ *   mvx_activity_dilate   dst_mask u8 [dout][h][w] = 1 where the 3x3x3 receptive field holds an active source
+ *                         site (src: i32 index grid [din][h][w], -1 = empty, or u8 mask), or, with mark_border,
+ *                         where the in-plane window leaves the image (zero padding is not the background);
+ *                         dst_halo_flags (optional) i32 [dout][tiles]: the (8+2)x(16+2) halo of the tile holds
+ *                         an active site of that plane (tiles as mvx_conv3d_tile_shape)
+ *   mvx_conv3d_background bg_pre f32 [dout][cout] = conv of the constant input c_in f32 [din][cin] at an interior
+ *                         site (valid depth taps of each plane only); w in torch layout
+ *   mvx_bn_background     y_bg = [ReLU](bg_pre + bias), c_out = (y_bg - mean) * inv: the normalised background
+ *                         of the layer output, bit-equal to what mvx_bn_apply writes at background sites
+ *   mvx_conv3d_forward_bg mvx_conv3d_forward on a source with background: tiles whose halo flags are clear
+ *                         (and, with border_active, that do not touch the image border) are filled with the
+ *                         constant; background SITES (out_mask == 0) inside computed tiles get it too.
+ *                         exec_stages (optional) u64 [1] += executed (depth tap, 32-channel) stages of 4.7 MFLOP
+ *   mvx_conv3d_wgrad_bg   dw = sum (in - c_in) (x) dz over the tiles with a set halo flag + c_in (x) (border-corrected
+ *                         plane sums of dz), equal to mvx_conv3d_wgrad
+ */
+int mvx_activity_dilate(const void *src, int32_t src_is_index, int32_t din, int32_t dout, int32_t h, int32_t w,
+                        int32_t stride_d, int32_t pad_d, int32_t mark_border, uint8_t *dst_mask,
+                        int32_t *dst_halo_flags, void *stream);
+int mvx_conv3d_background(const float *w, const float *c_in, int32_t din, int32_t dout, int32_t cin, int32_t cout,
+                          int32_t stride_d, int32_t pad_d, float *bg_pre, void *stream);
+int mvx_bn_background(const float *bg_pre, const float *bias, const float *mean_inv, int32_t planes, int32_t channels,
+                      int32_t flags, float *y_bg, float *c_out, void *stream);
+int mvx_conv3d_forward_bg(const float *in, const float *wpk, const float *bias, float *out, double *stats,
+                          int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                          int32_t stride_d, int32_t pad_d, int32_t flags, const int32_t *in_halo_flags,
+                          const uint8_t *out_mask, const float *bg_pre, int32_t border_active,
+                          uint64_t *exec_stages, void *stream);
+size_t mvx_conv3d_wgrad_bg_workspace_bytes(int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout);
+int mvx_conv3d_wgrad_bg(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
+                        int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, int32_t flags,
+                        const int32_t *in_halo_flags, const float *c_in, void *workspace, size_t workspace_bytes,
+                        void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Row-wise fully connected layer on the matrix cores (fp32 MFMA).  Replaces the nn.Linear /
  * 1x1 nn.Conv2d GEMMs of FCN and CRB2d (modules/layers/Blocks.py:9,14,35,39) and their autograd.
  *   x f32 [rows][ldx] (k columns used), w f32 [n][ldw] (or [k][ldw] when w_transposed),

@@ -251,7 +251,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_pf(const float *__restri
                                                            const float *__restrict__ wpk,
                                                            const float *__restrict__ bias,
                                                            float *__restrict__ out, double *__restrict__ stats,
-                                                           Geom g, int relu) {
+                                                           Geom g, int relu, const int *__restrict__ in_hflag,
+                                                           const unsigned char *__restrict__ out_mask,
+                                                           const float *__restrict__ bg_pre, int border_active,
+                                                           unsigned long long *__restrict__ exec_stages) {
     __shared__ __attribute__((aligned(16))) float s_halo[HH * HROW];
     __shared__ __attribute__((aligned(16))) float s_w[3 * WROW];
     __shared__ float s_red[4][2 * BN];
@@ -285,6 +288,20 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_pf(const float *__restri
         }
     }
     const int nstages = nk * nchunks;
+
+    // Background tiles (see activity.hip): no non-background source site in the halo of any depth tap and the
+    // window never leaves the image -> every output site of the tile is the per-plane constant.
+    bool active = true;
+    if (in_hflag) {
+        const int ntiles = gridDim.x;
+        int any = border_active && (tx0 == 0 || ty0 == 0 || tx0 + TW >= g.W || ty0 + TH >= g.H);
+        any |= nk > 0 ? in_hflag[(size_t)ds_l[0] * ntiles + blockIdx.x] : 0;
+        any |= nk > 1 ? in_hflag[(size_t)ds_l[1] * ntiles + blockIdx.x] : 0;
+        any |= nk > 2 ? in_hflag[(size_t)ds_l[2] * ntiles + blockIdx.x] : 0;
+        active = any != 0;
+    }
+    if (exec_stages && active && threadIdx.x == 0) atomicAdd(exec_stages, (unsigned long long)nstages);
+    if (active) {
     auto stage_kd = [&](int st, int &kd, int &ds, int &cc) __attribute__((always_inline)) {
         const int i = st / nchunks;
         cc = st - i * nchunks;
@@ -382,10 +399,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_pf(const float *__restri
         load_wrow(nxt, 0);
         compute_row(2);
     }
+    }   // active
 
     // ---- epilogue: bias, ReLU, store, BatchNorm statistics (identical to conv3d_gather)
     const int n0 = nb * BN + li, n1 = n0 + 32;
     const float bias0 = bias ? bias[n0] : 0.f, bias1 = bias ? bias[n1] : 0.f;
+    // background value of this plane: the same fp32 operations as a computed site, on the constant
+    float bgv0 = (bg_pre ? bg_pre[(size_t)d * g.Cout + n0] : 0.f) + bias0, bgv1 = (bg_pre ? bg_pre[(size_t)d * g.Cout + n1] : 0.f) + bias1;
+    if (relu) { bgv0 = fmaxf(bgv0, 0.f); bgv1 = fmaxf(bgv1, 0.f); }
     float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -393,6 +414,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_pf(const float *__restri
         const int gy = ty0 + 2 * wv + (row >> 4), gx = tx0 + (row & 15);
         float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
         if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+        if (out_mask && gy < g.H && gx < g.W) {
+            // a background SITE holds the constant bit for bit, also inside a computed tile
+            if (!active || !out_mask[((size_t)d * g.H + gy) * g.W + gx]) { v0 = bgv0; v1 = bgv1; }
+        }
         if (gy < g.H && gx < g.W) {
             float *o = out + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout;
             o[n0] = v0;
@@ -836,12 +861,13 @@ constexpr int W4_C = 64;               // input channels per workgroup
 __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restrict__ in,
                                                             const float *__restrict__ dz,
                                                             float *__restrict__ slabs, Geom g,
-                                                            int tiles_per_strip) {
+                                                            int tiles_per_strip, const int *__restrict__ in_hflag,
+                                                            const float *__restrict__ c_in) {
     __shared__ __attribute__((aligned(16))) float s_x[HH * HW * W4_C];
     __shared__ __attribute__((aligned(16))) float s_z[TH * TW * ZP];
     const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
     const int ntiles = tiles_x * tiles_y;
-    const int strip = blockIdx.x;
+    const int strip = blockIdx.x, nstrips = gridDim.x;
     const int nchunks = g.Cin / W4_C;
     const int kd = blockIdx.y / nchunks, cc = blockIdx.y % nchunks;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -854,62 +880,88 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    const int t_beg = strip * tiles_per_strip;
-    const int t_end = min(ntiles, t_beg + tiles_per_strip);
+    // Steps of this workgroup: (output plane d with a valid source plane for kd) x (tiles of the strip).
+    // Dense: the strip is a contiguous tile range.  With a background description (in_hflag, c_in) the
+    // tiles are dealt round-robin to the strips (active tiles cluster, contiguous strips would be unbalanced)
+    // and steps whose source halo holds only background sites are skipped: there x - c is exactly zero.
+    int dlo = 0, dhi = -1;                           // valid output planes form a contiguous range
+    for (int d = 0; d < g.Dout; ++d) {
+        const int ds = d * g.sd - g.pd + kd;
+        if (ds >= 0 && ds < g.Din) { if (dhi < 0) dlo = d; dhi = d; }
+    }
+    const int nd = dhi >= dlo ? dhi - dlo + 1 : 0;
+    const int per = tiles_per_strip;
+    const int nsteps = nd * per;
+    auto step_tile = [&](int i) { const int k = i % per; return in_hflag ? strip + k * nstrips : strip * per + k; };
+    auto step_plane = [&](int i) { return dlo + i / per; };
+
     constexpr int NX = (HH * HW * 16 + W4_THREADS - 1) / W4_THREADS;    // float4 per thread, halo (64 ch)
     constexpr int NZ = TH * TW * 16 / W4_THREADS;                       // float4 per thread, dz
-    float4 xr[NX], zr[NZ];
-    auto load_step = [&](int d, int t) {
+    f32x4 xr[NX], zr[NZ];
+    auto load_step = [&](int i) __attribute__((always_inline)) {
+        const int d = step_plane(i), t = step_tile(i);
         const int ds = d * g.sd - g.pd + kd;
         const int tx0 = (t % tiles_x) * TW, ty0 = (t / tiles_x) * TH;
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
             const int c = tid + W4_THREADS * u;
-            xr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (c < HH * HW * 16) {
                 const int r = c >> 4, part = c & 15;
                 const int gy = ty0 - 1 + r / HW, gx = tx0 - 1 + r % HW;
-                if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W)
-                    xr[u] = *(const float4 *)(in + (((size_t)ds * g.H + gy) * g.W + gx) * g.Cin + cc * W4_C + part * 4);
+                if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) {
+                    v = *(const f32x4 *)(in + (((size_t)ds * g.H + gy) * g.W + gx) * g.Cin + cc * W4_C + part * 4);
+                    if (c_in) v -= *(const f32x4 *)(c_in + (size_t)ds * g.Cin + cc * W4_C + part * 4);
+                }
             }
+            xr[u] = v;
         }
 #pragma unroll
         for (int u = 0; u < NZ; ++u) {
             const int c = tid + W4_THREADS * u;
             const int r = c >> 4, part = c & 15;
             const int gy = ty0 + (r >> 4), gx = tx0 + (r & 15);
-            zr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (gy < g.H && gx < g.W)
-                zr[u] = *(const float4 *)(dz + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout + part * 4);
+                v = *(const f32x4 *)(dz + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout + part * 4);
+            zr[u] = v;
         }
     };
-    auto next_valid = [&](int d) {
-        while (d < g.Dout) {
-            const int ds = d * g.sd - g.pd + kd;
-            if (ds >= 0 && ds < g.Din) break;
-            ++d;
+    // next live step at or after i (all lanes evaluate 64 candidate steps at a time: block-uniform result)
+    auto next_live = [&](int i) {
+        while (i < nsteps) {
+            const int cand = i + lane;
+            bool on = false;
+            if (cand < nsteps) {
+                const int t = step_tile(cand);
+                if (t < ntiles) {
+                    const int ds = step_plane(cand) * g.sd - g.pd + kd;
+                    on = !in_hflag || in_hflag[(size_t)ds * ntiles + t] != 0;
+                }
+            }
+            const unsigned long long m = __ballot(on);
+            if (m) return i + (int)__builtin_ctzll(m);
+            i += 64;
         }
-        return d;
+        return nsteps;
     };
-    int d = next_valid(0), t = t_beg;
-    const bool any = d < g.Dout && t_beg < t_end;
-    if (any) load_step(d, t);
-    while (any && d < g.Dout) {
+    int cur = next_live(0);
+    if (cur < nsteps) load_step(cur);
+    while (cur < nsteps) {
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
             const int c = tid + W4_THREADS * u;
-            if (c < HH * HW * 16) *(float4 *)(s_x + (c >> 4) * W4_C + (c & 15) * 4) = xr[u];
+            if (c < HH * HW * 16) *(f32x4 *)(s_x + (c >> 4) * W4_C + (c & 15) * 4) = xr[u];
         }
 #pragma unroll
         for (int u = 0; u < NZ; ++u) {
             const int c = tid + W4_THREADS * u;
-            *(float4 *)(s_z + (c >> 4) * ZP + (c & 15) * 4) = zr[u];
+            *(f32x4 *)(s_z + (c >> 4) * ZP + (c & 15) * 4) = zr[u];
         }
         __syncthreads();
-        int nt = t + 1, nd = d;
-        if (nt >= t_end) { nt = t_beg; nd = next_valid(d + 1); }
-        if (nd < g.Dout) load_step(nd, nt);
+        const int nxt = next_live(cur + 1);
+        load_step(nxt < nsteps ? nxt : cur);          // unconditional (see conv3d_gather_pf): the last one is dropped
 #pragma unroll 2
         for (int kk = 0; kk < TH * TW / 2; ++kk) {
             const int s = 2 * kk + lh;
@@ -919,7 +971,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restr
             for (int t9 = 0; t9 < 9; ++t9)
                 acc[t9] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[((t9 / 3) * HW + (t9 % 3)) * W4_C], b, acc[t9], 0, 0, 0);
         }
-        t = nt; d = nd;
+        cur = nxt;
     }
     // slab[strip][kd][tap][c (Cin)][n (64)]
 #pragma unroll
@@ -930,6 +982,83 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restr
             const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
             o[(size_t)row * BN + li] = acc[t9][r];
         }
+    }
+}
+
+// ---- closed-form part of the background rewrite of wgrad ------------------------------------------
+// R[rep][d][kind][n]: per-plane sums of dz over  0 all sites, 1 row 0, 2 row H-1, 3 column 0, 4 column W-1,
+// 5..8 the corners (0,0) (0,W-1) (H-1,0) (H-1,W-1).  One workgroup per (row, plane).
+constexpr int RK = 9;
+__global__ __launch_bounds__(256) void plane_region_sums(const float *__restrict__ dz, int D, int H, int W, int C,
+                                                         double *__restrict__ R) {
+    __shared__ float red[256][4];
+    const int y = blockIdx.x, d = blockIdx.y;
+    const int c4n = C >> 2, ct = threadIdx.x % c4n, st = threadIdx.x / c4n, spb = 256 / c4n;
+    const float *row = dz + ((size_t)d * H + y) * W * C;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int x = st; x < W; x += spb) {
+        const float4 v = *(const float4 *)(row + (size_t)x * C + ct * 4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    red[threadIdx.x][0] = s.x; red[threadIdx.x][1] = s.y; red[threadIdx.x][2] = s.z; red[threadIdx.x][3] = s.w;
+    __syncthreads();
+    if (st == 0) {
+        const unsigned rep = (unsigned)y % MVX_REP;
+        double *Rp = R + ((size_t)rep * D + d) * RK * C;
+        const float4 first = *(const float4 *)(row + ct * 4), last = *(const float4 *)(row + (size_t)(W - 1) * C + ct * 4);
+        const float f[4] = {first.x, first.y, first.z, first.w}, l[4] = {last.x, last.y, last.z, last.w};
+        for (int j = 0; j < 4; ++j) {
+            double t = 0.0;
+            for (int q = 0; q < spb; ++q) t += (double)red[q * c4n + ct][j];
+            const int n = ct * 4 + j;
+            atomicAdd(Rp + 0 * C + n, t);
+            if (y == 0) atomicAdd(Rp + 1 * C + n, t);
+            if (y == H - 1) atomicAdd(Rp + 2 * C + n, t);
+            atomicAdd(Rp + 3 * C + n, (double)f[j]);
+            atomicAdd(Rp + 4 * C + n, (double)l[j]);
+            if (y == 0) { atomicAdd(Rp + 5 * C + n, (double)f[j]); atomicAdd(Rp + 6 * C + n, (double)l[j]); }
+            if (y == H - 1) { atomicAdd(Rp + 7 * C + n, (double)f[j]); atomicAdd(Rp + 8 * C + n, (double)l[j]); }
+        }
+    }
+}
+
+// T[d][a][b][n] = sum of dz[d][y][x][n] over the sites whose tap (a,b) source (y+a-1, x+b-1) lies inside the image
+__global__ void region_tap_sums(const double *__restrict__ R, int D, int C, float *__restrict__ T) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= D * 9 * C) return;
+    const int n = e % C, tap = (e / C) % 9, d = e / (9 * C);
+    const int a = tap / 3, b = tap % 3;
+    double k[RK];
+    for (int q = 0; q < RK; ++q) {
+        double t = 0.0;
+        for (int rep = 0; rep < MVX_REP; ++rep) t += R[(((size_t)rep * D + d) * RK + q) * C + n];
+        k[q] = t;
+    }
+    double t = k[0];
+    if (a == 0) t -= k[1];
+    if (a == 2) t -= k[2];
+    if (b == 0) t -= k[3];
+    if (b == 2) t -= k[4];
+    if (a == 0 && b == 0) t += k[5];
+    if (a == 0 && b == 2) t += k[6];
+    if (a == 2 && b == 0) t += k[7];
+    if (a == 2 && b == 2) t += k[8];
+    T[e] = (float)t;
+}
+
+// dW[co][ci][kd][a][b] += sum over output planes d with a valid source plane of c_in[src(d,kd)][ci] * T[d][a][b][co]
+__global__ void wgrad_rank1(const float *__restrict__ T, const float *__restrict__ c_in, float *__restrict__ dw, Geom g) {
+    const size_t total = (size_t)27 * g.Cin * g.Cout;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(e % 9), kd = (int)((e / 9) % 3);
+        const int ci = (int)((e / 27) % g.Cin), co = (int)(e / ((size_t)27 * g.Cin));
+        float s = 0.f;
+        for (int d = 0; d < g.Dout; ++d) {
+            const int ds = d * g.sd - g.pd + kd;
+            if (ds < 0 || ds >= g.Din) continue;
+            s += c_in[(size_t)ds * g.Cin + ci] * T[((size_t)d * 9 + tap) * g.Cout + co];
+        }
+        dw[e] += s;
     }
 }
 
@@ -1003,7 +1132,31 @@ extern "C" int mvx_conv3d_forward(const float *in, const float *wpk, const float
         hipLaunchKernelGGL(conv3d_gather, grid, dim3(256), 0, st, in, wpk, bias, out, stats, g, relu, occupancy,
                            (unsigned long long *)exec_quads);
     else
-        hipLaunchKernelGGL(conv3d_gather_pf, gather_grid(g), dim3(256), 0, st, in, wpk, bias, out, stats, g, relu);
+        hipLaunchKernelGGL(conv3d_gather_pf, gather_grid(g), dim3(256), 0, st, in, wpk, bias, out, stats, g, relu,
+                           (const int *)nullptr, (const unsigned char *)nullptr, (const float *)nullptr, 0,
+                           (unsigned long long *)nullptr);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+extern "C" int mvx_conv3d_forward_bg(const float *in, const float *wpk, const float *bias, float *out, double *stats,
+                                     int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                                     int32_t stride_d, int32_t pad_d, int32_t flags, const int32_t *in_halo_flags,
+                                     const uint8_t *out_mask, const float *bg_pre, int32_t border_active,
+                                     uint64_t *exec_stages, void *stream) {
+    MVX_CHECK_ARG(in && wpk && out && in_halo_flags && out_mask && bg_pre);
+    int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
+    if (rc) return rc;
+    MVX_CHECK_ARG(dout == (din + 2 * pad_d - 3) / stride_d + 1);
+    hipStream_t st = (hipStream_t)stream;
+    if (stats && !(flags & MVX_FLAG_PREZEROED)) {
+        hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * MVX_REP * 2 * cout, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
+    hipLaunchKernelGGL(conv3d_gather_pf, gather_grid(g), dim3(256), 0, st, in, wpk, bias, out, stats, g,
+                       flags & MVX_FLAG_RELU, in_halo_flags, out_mask, bg_pre, border_active,
+                       (unsigned long long *)exec_stages);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -1018,7 +1171,8 @@ extern "C" int mvx_conv3d_dgrad(const float *dz, const float *wpk_dgrad, float *
     Geom g{dout, din, h, w, cout, cin, stride_d, pad_d, 1};
     const dim3 grid(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), din, cin / BN);
     hipLaunchKernelGGL(conv3d_gather_pf, gather_grid(g), dim3(256), 0, (hipStream_t)stream, dz, wpk_dgrad,
-                       (const float *)nullptr, dx, (double *)nullptr, g, 0);
+                       (const float *)nullptr, dx, (double *)nullptr, g, 0, (const int *)nullptr,
+                       (const unsigned char *)nullptr, (const float *)nullptr, 0, (unsigned long long *)nullptr);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -1058,7 +1212,7 @@ extern "C" int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int
     hipStream_t st = (hipStream_t)stream;
     if (cin % W4_C == 0)
         hipLaunchKernelGGL(conv3d_wgrad4, dim3(nstrips, 3 * (cin / W4_C)), dim3(W4_THREADS), 0, st, in, dz,
-                           (float *)workspace, g, per);
+                           (float *)workspace, g, per, (const int *)nullptr, (const float *)nullptr);
     else
         hipLaunchKernelGGL(conv3d_wgrad, dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz,
                            (float *)workspace, g, per);
@@ -1081,6 +1235,55 @@ extern "C" int mvx_conv3d_dgrad_sites(const float *dz, const float *wpk_dgrad, c
     Geom g{dout, din, h, w, cout, cin, stride_d, pad_d, 1};
     hipLaunchKernelGGL(conv3d_dgrad_sites, dim3(mvx_cdiv(n_voxels, 128), cin / BN), dim3(256), 0, (hipStream_t)stream, dz,
                        wpk_dgrad, (const long long *)coords, dfeat, n_voxels, g);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+// workspace of mvx_conv3d_wgrad_bg: [slabs][R f64 replicas][T]
+static size_t wgrad_bg_slab_bytes(int h, int w, int cin) {
+    const int ntiles = (int)(mvx_cdiv(w, TW) * mvx_cdiv(h, TH));
+    const int per = wgrad_strips(h, w, cin);
+    const int nstrips = (ntiles + per - 1) / per;
+    return (size_t)nstrips * 27 * cin * BN * sizeof(float);
+}
+
+extern "C" size_t mvx_conv3d_wgrad_bg_workspace_bytes(int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout) {
+    if (dout <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout != BN || cin % W4_C) return 0;
+    return wgrad_bg_slab_bytes(h, w, cin) + sizeof(double) * MVX_REP * dout * RK * cout + sizeof(float) * dout * 9 * cout;
+}
+
+extern "C" int mvx_conv3d_wgrad_bg(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
+                                   int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, int32_t flags,
+                                   const int32_t *in_halo_flags, const float *c_in, void *workspace,
+                                   size_t workspace_bytes, void *stream) {
+    MVX_CHECK_ARG(in && dz && dw && workspace && in_halo_flags && c_in);
+    int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
+    if (rc) return rc;
+    if (cout != BN || cin % W4_C) return MVX_ESIZE;
+    MVX_CHECK_ARG(workspace_bytes >= mvx_conv3d_wgrad_bg_workspace_bytes(dout, h, w, cin, cout));
+    const int ntiles = (int)(mvx_cdiv(w, TW) * mvx_cdiv(h, TH));
+    const int per = wgrad_strips(h, w, cin);
+    const int nstrips = (ntiles + per - 1) / per;
+    Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
+    hipStream_t st = (hipStream_t)stream;
+    float *slabs = (float *)workspace;
+    double *R = (double *)((char *)workspace + wgrad_bg_slab_bytes(h, w, cin));
+    float *T = (float *)(R + (size_t)MVX_REP * dout * RK * cout);
+    hipError_t e = hipMemsetAsync(R, 0, sizeof(double) * MVX_REP * dout * RK * cout, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(plane_region_sums, dim3(h, dout), dim3(256), 0, st, dz, dout, h, w, cout, R);
+    MVX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(region_tap_sums, dim3(mvx_cdiv((long long)dout * 9 * cout, 256)), dim3(256), 0, st, (const double *)R,
+                       dout, cout, T);
+    MVX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(conv3d_wgrad4, dim3(nstrips, 3 * (cin / W4_C)), dim3(W4_THREADS), 0, st, in, dz, slabs, g, per,
+                       in_halo_flags, c_in);
+    MVX_LAUNCH_CHECK();
+    const size_t per_slab = (size_t)27 * cin * BN;
+    hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)slabs, dw, nstrips, cin,
+                       flags & MVX_FLAG_ACCUMULATE);
+    MVX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wgrad_rank1, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)T, c_in, dw, g);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

@@ -76,6 +76,13 @@ PROTOTYPES = {
     'mvx_conv3d_dgrad': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_conv3d_wgrad_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32]),
     'mvx_conv3d_wgrad': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _sz, _p]),
+    'mvx_activity_dilate': (_i32, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p]),
+    'mvx_conv3d_background': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
+    'mvx_bn_background': (_i32, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _p]),
+    'mvx_conv3d_forward_bg': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p,
+                                     _i32, _p, _p]),
+    'mvx_conv3d_wgrad_bg_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    'mvx_conv3d_wgrad_bg': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _sz, _p]),
 }
 
 
@@ -119,8 +126,17 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_cur_device = torch._C._cuda_getDevice
+
+
+def raw_stream(index=None):
+    """Current HIP stream handle of a device as an int (no torch.cuda.Stream object is built)."""
+    return _raw_stream(_cur_device() if index is None else index)
+
+
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(raw_stream())
 
 
 def device():

@@ -100,7 +100,7 @@ _ARENA_ON = False
 
 
 def _arena_key(device):
-    return (device.index, torch.cuda.current_stream(device).cuda_stream)
+    return (device.index, X.raw_stream(device.index))
 
 
 def arena_begin(device):
@@ -180,7 +180,7 @@ def conv_flops(d_out_planes, d_src_planes, H, W, cin, cout, sd, pd, dgrad=False)
 
 def workspace(nbytes, dev, tag):
     """Grow-only scratch buffer per (device, tag); stream-ordered reuse on the current stream."""
-    key = (dev.index, tag, torch.cuda.current_stream(dev).cuda_stream)    # one buffer per (tag, stream): no cross-stream reuse
+    key = (dev.index, tag, X.raw_stream(dev.index))    # one buffer per (tag, stream): no cross-stream reuse
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
@@ -423,6 +423,88 @@ def conv3d_wgrad(x, dz, sd, pd, split=False, accumulate_into=None):
         with _Timed(name, conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None else 0):
             X.check(fn(X.ptr(x), X.ptr(dz), X.ptr(dw), din, dout, H, W, cin, cout, sd, pd, flags, X.ptr(ws), ws.numel(),
                        X.stream()), 'mvx_' + name)
+    return None if accumulate_into is not None else dw
+
+
+# ---------------------------------------------------------------------------------------------
+# background rewrite of the CML stack (csrc/activity.hip)
+# ---------------------------------------------------------------------------------------------
+class Background:
+    """What a CML activation looks like away from the voxels: per (plane, channel) constant ``c`` f32 (D,C),
+    site mask u8 (D,H,W) of the sites that do NOT hold it, per-tile halo flags i32 (D,tiles)."""
+    __slots__ = ('c', 'mask', 'hflag')
+
+    def __init__(self, c, mask, hflag):
+        self.c, self.mask, self.hflag = c, mask, hflag
+
+
+EXEC_STAGES = None       # device u64 counter of executed gather stages while KERNEL_TIMERS is on (bench roofline)
+STAGE_FLOP = 2.0 * 9 * 128 * 32 * 64
+
+
+def n_tiles(H, W):
+    return ((H + 7) // 8) * ((W + 15) // 16)
+
+
+def activity_dilate(src, src_is_index, din, H, W, sd, pd, mark_border):
+    """(mask u8 (dout,H,W), halo flags i32 (dout,tiles)) of a layer output from its input's activity."""
+    dout = conv_out_depth(din, sd, pd)
+    mask = torch.empty((dout, H, W), dtype=torch.uint8, device=src.device)
+    hflag = torch.empty((dout, n_tiles(H, W)), dtype=torch.int32, device=src.device)
+    X.check(X.lib.mvx_activity_dilate(X.ptr(src), 1 if src_is_index else 0, din, dout, H, W, sd, pd,
+                                      1 if mark_border else 0, X.ptr(mask), X.ptr(hflag), X.stream()), 'mvx_activity_dilate')
+    return mask, hflag
+
+
+def conv3d_background(w, c_in, din, sd, pd):
+    cout, cin = w.shape[0], w.shape[1]
+    dout = conv_out_depth(din, sd, pd)
+    bg_pre = torch.empty((dout, cout), dtype=torch.float32, device=w.device)
+    X.check(X.lib.mvx_conv3d_background(X.ptr(w.contiguous()), X.ptr(c_in), din, dout, cin, cout, sd, pd, X.ptr(bg_pre),
+                                        X.stream()), 'mvx_conv3d_background')
+    return bg_pre
+
+
+def bn_background(bg_pre, bias, mi, planes, channels, relu=True):
+    c_out = torch.empty((planes, channels), dtype=torch.float32, device=mi.device)
+    X.check(X.lib.mvx_bn_background(X.ptr(bg_pre), X.ptr(bias), X.ptr(mi), planes, channels, FLAG_RELU if relu else 0,
+                                    None, X.ptr(c_out), X.stream()), 'mvx_bn_background')
+    return c_out
+
+
+def conv3d_forward_bg(x, wpk, bias, cout, sd, pd, bg_in, out_mask, bg_pre, relu=True, want_stats=True):
+    global EXEC_STAGES
+    din, H, W, cin = x.shape
+    dout = conv_out_depth(din, sd, pd)
+    out = torch.empty((dout, H, W, cout), dtype=torch.float32, device=x.device)
+    stats, fz = _acc_f64((STATS_REPLICAS, 2, cout), x.device) if want_stats else (None, 0)
+    flags = (FLAG_RELU if relu else 0) | fz
+    counter = None
+    if KERNEL_TIMERS is not None:
+        if EXEC_STAGES is None:
+            EXEC_STAGES = torch.zeros((1,), dtype=torch.int64, device=x.device)
+        counter = EXEC_STAGES
+    with _Timed('conv3d_gather_bg', 0):
+        X.check(X.lib.mvx_conv3d_forward_bg(X.ptr(x), X.ptr(wpk), X.ptr(bias), X.ptr(out), X.ptr(stats), din, dout, H, W,
+                                            cin, cout, sd, pd, flags, X.ptr(bg_in.hflag), X.ptr(out_mask), X.ptr(bg_pre),
+                                            1, X.ptr(counter), X.stream()), 'mvx_conv3d_forward_bg')
+    return out, stats
+
+
+def conv3d_wgrad_bg(x, dz, sd, pd, bg_in, accumulate_into=None):
+    din, H, W, cin = x.shape
+    dout, _, _, cout = dz.shape
+    if accumulate_into is not None:
+        dw, flags = accumulate_into, FLAG_ACCUMULATE
+    else:
+        dw, flags = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device=x.device), 0
+    nbytes = X.lib.mvx_conv3d_wgrad_bg_workspace_bytes(dout, H, W, cin, cout)
+    with _wgrad_scope(accumulate_into, x, dz) as scope:
+        ws = workspace(nbytes, x.device, 'wgrad_bg_side' if isinstance(scope, _SideStream) else 'wgrad_bg')
+        with _Timed('conv3d_wgrad_bg', 0):
+            X.check(X.lib.mvx_conv3d_wgrad_bg(X.ptr(x), X.ptr(dz), X.ptr(dw), din, dout, H, W, cin, cout, sd, pd, flags,
+                                              X.ptr(bg_in.hflag), X.ptr(bg_in.c), X.ptr(ws), ws.numel(), X.stream()),
+                    'mvx_conv3d_wgrad_bg')
     return None if accumulate_into is not None else dw
 
 

@@ -99,22 +99,42 @@ def _pack(packer, w, for_dgrad, split):
     return packer(for_dgrad, split) if packer is not None else _hip.conv3d_pack(w, for_dgrad, split=split)
 
 
+def conv_background_on():
+    """config.yml ``convbackground``: skip the voxel-free background of the CML activations (exact rewrite, csrc/activity.hip)."""
+    return bool(cfg.config.get('convbackground', True))
+
+
 class CRB3dFunction(torch.autograd.Function):
-    """channels-last (D,H,W,Cin) -> BN(ReLU(conv3d)) (Dout,H,W,Cout), one frame."""
+    """channels-last (D,H,W,Cin) -> BN(ReLU(conv3d)) (Dout,H,W,Cout), one frame.
+
+    ``bg_in`` (a _hip.Background of x, or None) switches the background rewrite on: forward fills voxel-free
+    tiles with the per-plane constant, wgrad sums over the other tiles and adds the constant's share in
+    closed form; ``aux['bg']`` receives the Background of the result for the next block."""
 
     @staticmethod
-    def forward(ctx, x, w, b, sd, pd, eps, packer=None):
+    def forward(ctx, x, w, b, sd, pd, eps, packer=None, bg_in=None, aux=None):
         cout = w.shape[0]
         split = conv_split_math()
         wpk = _pack(packer, w, False, split)
         ctx.packer = packer
-        y, stats = _hip.conv3d_forward(x, wpk, b, cout, sd, pd, relu=True, want_stats=True, split=split)
+        if split:
+            bg_in = None                     # the bf16x3 kernels have no background form yet
+        if bg_in is not None:
+            din, H, W, _ = x.shape
+            bg_pre = _hip.conv3d_background(w, bg_in.c, din, sd, pd)
+            out_mask, out_hflag = _hip.activity_dilate(bg_in.mask, False, din, H, W, sd, pd, mark_border=True)
+            y, stats = _hip.conv3d_forward_bg(x, wpk, b, cout, sd, pd, bg_in, out_mask, bg_pre)
+        else:
+            y, stats = _hip.conv3d_forward(x, wpk, b, cout, sd, pd, relu=True, want_stats=True, split=split)
         count = y.numel() // cout
         mi = _hip.bn_finalize(stats, count, eps)
         out = _hip.bn_apply(y, mi)
+        if bg_in is not None and aux is not None:
+            aux['bg'] = _hip.Background(_hip.bn_background(bg_pre, b, mi, y.shape[0], cout), out_mask, out_hflag)
         ctx.save_for_backward(x, w, y, mi)
         ctx.geom = (sd, pd, count, split)
         ctx.params = (w, b)
+        ctx.bg_in = bg_in
         return out
 
     @staticmethod
@@ -123,11 +143,14 @@ class CRB3dFunction(torch.autograd.Function):
         sd, pd, count, split = ctx.geom
         dz, db = _hip.bn_relu_backward(g.contiguous(), y, mi, count, True, dbias_out=_hip.bias_sink_of(ctx.params[1]))
         db = _hip.accumulate_grad(ctx.params[1], db)
-        dw = _hip.conv3d_wgrad(x, dz, sd, pd, split=split, accumulate_into=_hip.sink_of(ctx.params[0]))
+        if ctx.bg_in is not None:
+            dw = _hip.conv3d_wgrad_bg(x, dz, sd, pd, ctx.bg_in, accumulate_into=_hip.sink_of(ctx.params[0]))
+        else:
+            dw = _hip.conv3d_wgrad(x, dz, sd, pd, split=split, accumulate_into=_hip.sink_of(ctx.params[0]))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _hip.conv3d_dgrad(dz, _pack(ctx.packer, w, True, split), x.shape[0], x.shape[3], sd, pd, split=split)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 class SparseInputCRB3dFunction(torch.autograd.Function):
@@ -172,7 +195,7 @@ class VoxelGemmCRB3dFunction(torch.autograd.Function):
     fp32 summation order."""
 
     @staticmethod
-    def forward(ctx, feat, coords, w, b, dhw, sd, pd, eps):
+    def forward(ctx, feat, coords, w, b, dhw, sd, pd, eps, aux=None):
         cout, cin = w.shape[0], w.shape[1]
         feat = feat.contiguous()
         w_all = w.permute(2, 3, 4, 0, 1).reshape(27 * cout, cin).contiguous()
@@ -182,6 +205,10 @@ class VoxelGemmCRB3dFunction(torch.autograd.Function):
         count = y.numel() // cout
         mi = _hip.bn_finalize(stats, count, eps)
         out = _hip.bn_apply(y, mi)
+        if aux is not None:
+            # voxel-free sites hold ReLU(bias) exactly, also at the image border (zero grid, zero padding)
+            mask, hflag = _hip.activity_dilate(idx_grid, True, dhw[0], dhw[1], dhw[2], sd, pd, mark_border=False)
+            aux['bg'] = _hip.Background(_hip.bn_background(None, b, mi, y.shape[0], cout), mask, hflag)
         ctx.save_for_backward(feat, coords, w_all, y, mi)
         ctx.geom = (dhw[0], sd, pd, count, tuple(w.shape))
         ctx.params = (w, b)
@@ -200,7 +227,7 @@ class VoxelGemmCRB3dFunction(torch.autograd.Function):
         dfeat = None
         if ctx.needs_input_grad[0]:
             dfeat, _ = _hip.linear_forward(G, w_all, None, relu=False, want_stats=False, w_transposed=True)
-        return dfeat, None, dw, db, None, None, None, None
+        return dfeat, None, dw, db, None, None, None, None, None
 
 
 def _triple(v):
@@ -227,17 +254,31 @@ class CRB3d(nn.Module):
 
     def forward_voxels(self, feat, coords, dhw):
         """Fused reindex + this block on sparse voxel rows (exact, see SparseInputCRB3dFunction)."""
-        fn = VoxelGemmCRB3dFunction if self.voxel_gemm else SparseInputCRB3dFunction
-        out = fn.apply(feat, coords, self.conv.weight, self.conv.bias, tuple(dhw), self._sd, self._pd, cfg.eps)
-        return out.permute(3, 0, 1, 2).unsqueeze(0)
+        if self.voxel_gemm:
+            aux = {} if conv_background_on() else None
+            out = VoxelGemmCRB3dFunction.apply(feat, coords, self.conv.weight, self.conv.bias, tuple(dhw), self._sd,
+                                               self._pd, cfg.eps, aux)
+        else:
+            aux = None
+            out = SparseInputCRB3dFunction.apply(feat, coords, self.conv.weight, self.conv.bias, tuple(dhw), self._sd,
+                                                 self._pd, cfg.eps)
+        res = out.permute(3, 0, 1, 2).unsqueeze(0)
+        if aux:
+            res._mvx_background = aux['bg']      # read by the next CRB3d (plain attribute: the module API is unchanged)
+        return res
 
     def forward(self, x):
         if x.shape[0] != 1:
             raise NotImplementedError('batch size 1 only (reference VoxelNet.py:19)')
         # squeeze, not x[0]: the backward of a select allocates zeros and copies the whole gradient
         xc = x.squeeze(0).permute(1, 2, 3, 0).contiguous()  # no-op when already channels-last
-        out = CRB3dFunction.apply(xc, self.conv.weight, self.conv.bias, self._sd, self._pd, cfg.eps, self._packer)
-        return out.permute(3, 0, 1, 2).unsqueeze(0)
+        bg_in = getattr(x, '_mvx_background', None) if conv_background_on() else None
+        aux = {} if bg_in is not None else None
+        out = CRB3dFunction.apply(xc, self.conv.weight, self.conv.bias, self._sd, self._pd, cfg.eps, self._packer, bg_in, aux)
+        res = out.permute(3, 0, 1, 2).unsqueeze(0)
+        if aux and 'bg' in aux:
+            res._mvx_background = aux['bg']
+        return res
 
 
 class _TorchBN2d(nn.Module):

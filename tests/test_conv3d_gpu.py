@@ -200,3 +200,66 @@ def test_conv3d_full_size_adjoint_identities(split):
     scale = float(dz.double().norm() * y.double().norm())
     tol = 2e-5 if split else 2e-6
     assert abs(a - b) / scale < tol and abs(a - c) / scale < tol, (a, b, c, scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(5, 40, 48, 1, 0), (3, 37, 53, 2, 1), (10, 24, 35, 2, 1)])
+def test_background_rewrite_equals_dense(shape):
+    """conv3d_forward_bg / conv3d_wgrad_bg (constant fill of voxel-free tiles, closed-form constant term)
+    against the dense kernels on an input that IS a background plus a few active sites -- including
+    sizes that are no multiple of the 8x16 tile and depth padding."""
+    from modules import _hip
+    din, H, W, sd, pd = shape
+    cin = cout = 64
+    dev = torch.device('cuda')
+    g = torch.Generator(device='cpu').manual_seed(5)
+    dout = _hip.conv_out_depth(din, sd, pd)
+    # source activity: a few sites, with the per-plane constant everywhere else
+    act = torch.zeros((din, H, W), dtype=torch.uint8)
+    for _ in range(6):
+        act[int(torch.randint(0, din, (1,), generator=g)), int(torch.randint(0, H, (1,), generator=g)),
+            int(torch.randint(0, W, (1,), generator=g))] = 1
+    act[0, 0, 0] = 1                                   # a corner site
+    c_in = torch.randn((din, cin), generator=g)
+    x = c_in[:, None, None, :].expand(din, H, W, cin).clone()
+    noise = torch.randn((din, H, W, cin), generator=g)
+    x = torch.where(act[..., None].bool(), noise, x).contiguous().to(dev)
+    w = (torch.randn((cout, cin, 3, 3, 3), generator=g) * 0.05).to(dev)
+    b = torch.randn((cout,), generator=g).to(dev)
+    act_d, c_d = act.to(dev), c_in.to(dev)
+    # halo flags of the source tensor itself: dilate an "index grid" stand-in through an identity? no --
+    # build them with the library: flags of a mask are produced for the DST of a dilation, so compute the
+    # source flags from the mask directly here (test-side restatement)
+    th, tw = 8, 16
+    ty, tx = (H + th - 1) // th, (W + tw - 1) // tw
+    hflag = torch.zeros((din, ty * tx), dtype=torch.int32)
+    for d in range(din):
+        for t in range(ty * tx):
+            y0, x0 = (t // tx) * th - 1, (t % tx) * tw - 1
+            sub = act[d, max(y0, 0):min(y0 + th + 2, H), max(x0, 0):min(x0 + tw + 2, W)]
+            hflag[d, t] = int(sub.any())
+    bg_in = _hip.Background(c_d, act_d, hflag.to(dev))
+    out_mask, out_hflag = _hip.activity_dilate(act_d, False, din, H, W, sd, pd, mark_border=True)
+    # the library's halo flags of the OUTPUT follow the same definition as the test-side ones of the input
+    om = out_mask.cpu()
+    for d in range(dout):
+        for t in range(ty * tx):
+            y0, x0 = (t // tx) * th - 1, (t % tx) * tw - 1
+            assert int(out_hflag[d, t]) == int(om[d, max(y0, 0):min(y0 + th + 2, H), max(x0, 0):min(x0 + tw + 2, W)].any())
+    wpk = _hip.conv3d_pack(w, False)
+    bg_pre = _hip.conv3d_background(w, c_d, din, sd, pd)
+    y_bg, st_bg = _hip.conv3d_forward_bg(x, wpk, b, cout, sd, pd, bg_in, out_mask, bg_pre)
+    y_dn, st_dn = _hip.conv3d_forward(x, wpk, b, cout, sd, pd)
+    scale = float(y_dn.abs().max())
+    assert float((y_bg - y_dn).abs().max()) < 2e-5 * scale
+    assert torch.allclose(st_bg.sum(0), st_dn.sum(0), rtol=1e-5, atol=1e-5 * float(st_dn.sum(0).abs().max()))
+    # background sites are bit-equal to one another (what the wgrad skip relies on)
+    bgsites = (out_mask == 0)
+    for d in range(dout):
+        rows = y_bg[d][bgsites[d]]
+        if rows.shape[0] > 1:
+            assert bool((rows == rows[0]).all())
+    dz = torch.randn((dout, H, W, cout), generator=g).to(dev)
+    dw_bg = _hip.conv3d_wgrad_bg(x, dz, sd, pd, bg_in)
+    dw_dn = _hip.conv3d_wgrad(x, dz, sd, pd)
+    assert float((dw_bg - dw_dn).abs().max()) < 2e-5 * float(dw_dn.abs().max())

@@ -20,17 +20,20 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
 
 
-@pytest.fixture(params=['bf16x3', 'f32'])
+@pytest.fixture(params=['bf16x3', 'f32', 'f32-dense'])
 def small_cfg(golden, request):
-    """Small fixture grid; every test using it runs with both convolution arithmetics."""
+    """Small fixture grid; every test using it runs with both convolution arithmetics, the f32 one with and
+    without the background rewrite (convbackground)."""
     import modules.config as cfg
     old = list(cfg.config['voxelshape'])
-    old_math = cfg.config.get('convmath', 'f32')
+    old_math, old_bg = cfg.config.get('convmath', 'f32'), cfg.config.get('convbackground', True)
     cfg.config['voxelshape'] = [int(v) for v in golden('voxelnet_small')['voxelshape']]
-    cfg.config['convmath'] = request.param
+    cfg.config['convmath'] = request.param.split('-')[0]
+    cfg.config['convbackground'] = not request.param.endswith('dense')
     yield cfg
     cfg.config['voxelshape'] = old
     cfg.config['convmath'] = old_math
+    cfg.config['convbackground'] = old_bg
 
 
 def load_backbone(net, with_rpn=False, golden=None):
