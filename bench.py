@@ -208,6 +208,7 @@ def main():
         torch.cuda.synchronize()
 
     host_ms = []
+    exec_stages = []        # per timed_run: executed gather stages counted by the background-aware forward kernel
 
     def timed_run(warmup, steps):
         nv = None
@@ -226,13 +227,14 @@ def main():
         dt_ = time.perf_counter() - t0
         host_ms.append(host_dt / steps * 1e3)
         tm, _hip.KERNEL_TIMERS = _hip.KERNEL_TIMERS, None
+        exec_stages.append(int(_hip.EXEC_STAGES.item()) if _hip.EXEC_STAGES is not None else 0)
         if world > 1:
             t = torch.tensor([dt_], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_ = float(t)
         return nv, dt_, tm
 
-    def conv_roofline(tm, math):
+    def conv_roofline(tm, math, run=0):
         name = 'conv3d_gather_split' if math == 'bf16x3' else 'conv3d_gather_pf'
         ev = tm.get('conv3d_gather_split' if math == 'bf16x3' else 'conv3d_gather', [])
         ms = sum(s.elapsed_time(e) for s, e, _ in ev)
@@ -241,7 +243,7 @@ def main():
         if bg:
             # forward launches with the background rewrite: EXECUTED FLOPs from the kernel's own stage counter
             ms += sum(s.elapsed_time(e) for s, e, _ in bg)
-            fl += float(_hip.EXEC_STAGES.item()) * _hip.STAGE_FLOP
+            fl += float(exec_stages[run]) * _hip.STAGE_FLOP
             ev = ev + bg
         if math == 'bf16x3':
             peak, mult, note = BF16_MFMA_PEAK_TFLOPS, 3.0, ('executed bf16 MFMA FLOPs = 3 x algorithmic '
@@ -271,7 +273,7 @@ def main():
         cfg.config['convmath'] = main_math
         alt = {'convmath': alt_math, 'value': frames_total * args.steps / dt_alt, 'unit': 'frames/s',
                'ms_per_step': dt_alt / args.steps * 1e3, 'host_enqueue_ms_per_step': host_ms[-1],
-               'roofline': conv_roofline(tm_alt, alt_math)}
+               'roofline': conv_roofline(tm_alt, alt_math, run=1)}
 
     if rank == 0:
         roof = conv_roofline(timers, main_math)
@@ -302,16 +304,17 @@ def main():
         if alt is not None:
             out['alt_modes'] = [alt]
         other = {}
-        for name in ('conv3d_gather_sparse_input', 'conv3d_wgrad', 'conv3d_dgrad_sites', 'conv3d_wgrad_sites'):
+        for name in ('conv3d_gather_sparse_input', 'conv3d_wgrad', 'conv3d_wgrad_bg', 'conv3d_dgrad_sites', 'conv3d_wgrad_sites'):
             evs = timers.get(name, [])
             if evs:
                 tms = sum(s.elapsed_time(e) for s, e, _ in evs)
                 tfl = sum(f for _, _, f in evs)
                 if name == 'conv3d_gather_sparse_input':
                     tfl = sparse_quads * 8 * 4096.0          # executed MFMAs only (exact-zero blocks skipped)
-                other[name] = {'launches': len(evs), 'avg_launch_ms': tms / len(evs),
-                               'executed_tflops': tfl / (tms * 1e-3) / 1e12 if tms > 0 else 0.0,
-                               'executed_gflop_per_launch': tfl / len(evs) / 1e9}
+                other[name] = {'launches': len(evs), 'avg_launch_ms': tms / len(evs)}
+                if tfl > 0:
+                    other[name].update({'executed_tflops': tfl / (tms * 1e-3) / 1e12 if tms > 0 else 0.0,
+                                        'executed_gflop_per_launch': tfl / len(evs) / 1e9})
         out['other_kernels'] = other
         stages = {}
         for name, evs in timers.items():

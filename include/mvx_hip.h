@@ -204,12 +204,21 @@ int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int32_t din, i
  *                         (and, with border_active, that do not touch the image border) are filled with the
  *                         constant; background SITES (out_mask == 0) inside computed tiles get it too.
  *                         exec_stages (optional) u64 [1] += executed (depth tap, 32-channel) stages of 4.7 MFLOP
- *   mvx_conv3d_wgrad_bg   dw = sum (in - c_in) (x) dz over the tiles with a set halo flag + c_in (x) (border-corrected
- *                         plane sums of dz), equal to mvx_conv3d_wgrad
+ *   mvx_plane_tap_sums    tap_sums f32 [planes][9][channels]: for each in-plane tap (a,b) the sum of dz over the sites
+ *                         whose tap source (y+a-1, x+b-1) lies inside the image (f64 accumulation)
+ *   mvx_conv3d_wgrad_bg   dw = sum (in - c_in) (x) dz over the tiles with a set halo flag + c_in (x) tap_sums, equal to
+ *                         mvx_conv3d_wgrad
+ *   mvx_conv3d_input_grad_sums  plane_grad_sums f32 [din][cin] = per input plane, the sum over all its sites of the
+ *                         input gradient (what mvx_conv3d_dgrad would write), from tap_sums in closed form
+ *   mvx_conv3d_dgrad_tiles      mvx_conv3d_dgrad for the output tiles with dx_tile_flags i32 [din][tiles] set; the
+ *                         other tiles of dx are left untouched
+ *   mvx_bn_relu_backward_tiles  mvx_bn_relu_backward of a layer whose output is the background (y_bg, c_bg per plane)
+ *                         outside the flagged tiles and whose incoming gradient dyhat is only valid ON them:
+ *                         the batch sums take the rest from plane_grad_sums; dz is written on the flagged tiles only
  */
 int mvx_activity_dilate(const void *src, int32_t src_is_index, int32_t din, int32_t dout, int32_t h, int32_t w,
                         int32_t stride_d, int32_t pad_d, int32_t mark_border, uint8_t *dst_mask,
-                        int32_t *dst_halo_flags, void *stream);
+                        int32_t *dst_halo_flags, int32_t *dst_tile_flags, void *stream);
 int mvx_conv3d_background(const float *w, const float *c_in, int32_t din, int32_t dout, int32_t cin, int32_t cout,
                           int32_t stride_d, int32_t pad_d, float *bg_pre, void *stream);
 int mvx_bn_background(const float *bg_pre, const float *bias, const float *mean_inv, int32_t planes, int32_t channels,
@@ -222,8 +231,21 @@ int mvx_conv3d_forward_bg(const float *in, const float *wpk, const float *bias, 
 size_t mvx_conv3d_wgrad_bg_workspace_bytes(int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout);
 int mvx_conv3d_wgrad_bg(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
                         int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, int32_t flags,
-                        const int32_t *in_halo_flags, const float *c_in, void *workspace, size_t workspace_bytes,
-                        void *stream);
+                        const int32_t *in_halo_flags, const float *c_in, const float *tap_sums, void *workspace,
+                        size_t workspace_bytes, void *stream);
+size_t mvx_plane_tap_sums_workspace_bytes(int32_t planes, int32_t channels);
+int mvx_plane_tap_sums(const float *dz, int32_t planes, int32_t h, int32_t w, int32_t channels, float *tap_sums,
+                       void *workspace, size_t workspace_bytes, void *stream);
+int mvx_conv3d_input_grad_sums(const float *w, const float *tap_sums, int32_t din, int32_t dout, int32_t cin,
+                               int32_t cout, int32_t stride_d, int32_t pad_d, float *plane_grad_sums, void *stream);
+int mvx_conv3d_dgrad_tiles(const float *dz, const float *wpk_dgrad, float *dx, int32_t din, int32_t dout, int32_t h,
+                           int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
+                           const int32_t *dx_tile_flags, void *stream);
+size_t mvx_bn_relu_backward_tiles_workspace_bytes(int32_t planes, int32_t h, int32_t w, int32_t channels);
+int mvx_bn_relu_backward_tiles(const float *dyhat, const float *y, const float *mean_inv, const float *c_bg,
+                               const float *y_bg, const float *plane_grad_sums, const int32_t *tile_flags,
+                               int32_t planes, int32_t h, int32_t w, int32_t channels, float *dz, float *dbias,
+                               int32_t flags, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Row-wise fully connected layer on the matrix cores (fp32 MFMA).  Replaces the nn.Linear /

@@ -45,38 +45,44 @@ __global__ void activity_sites(const void *__restrict__ src, int src_is_index, i
 }
 
 // flags[d][tile] = 1 iff the (TH+2) x (TW+2) halo of the tile holds an active site of plane d
+// tile_flags[d][tile] = 1 iff the tile itself (no halo) holds one
 __global__ __launch_bounds__(256) void activity_halo_flags(const unsigned char *__restrict__ mask, int D, int H, int W,
-                                                           int *__restrict__ flags) {
+                                                           int *__restrict__ flags, int *__restrict__ tile_flags) {
     const int tiles_x = (W + ATW - 1) / ATW;
     const int tx0 = (blockIdx.x % tiles_x) * ATW - 1, ty0 = (blockIdx.x / tiles_x) * ATH - 1;
     const int d = blockIdx.y;
-    int on = 0;
+    int on = 0, inner = 0;
     if (threadIdx.x < (ATH + 2) * (ATW + 2)) {
-        const int y = ty0 + threadIdx.x / (ATW + 2), x = tx0 + threadIdx.x % (ATW + 2);
+        const int hy = threadIdx.x / (ATW + 2), hx = threadIdx.x % (ATW + 2);
+        const int y = ty0 + hy, x = tx0 + hx;
         if (y >= 0 && y < H && x >= 0 && x < W) on = mask[((size_t)d * H + y) * W + x];
+        inner = on && hy >= 1 && hy <= ATH && hx >= 1 && hx <= ATW;
     }
     on = __syncthreads_or(on);
-    if (threadIdx.x == 0) flags[(size_t)d * gridDim.x + blockIdx.x] = on ? 1 : 0;
+    inner = __syncthreads_or(inner);
+    if (threadIdx.x == 0) {
+        if (flags) flags[(size_t)d * gridDim.x + blockIdx.x] = on ? 1 : 0;
+        if (tile_flags) tile_flags[(size_t)d * gridDim.x + blockIdx.x] = inner ? 1 : 0;
+    }
 }
 
 // bg_pre[d][n] = sum over the valid depth taps of plane d and all in-plane taps / channels of
 //                W[n][c][kd][a][b] * c_in[src(d,kd)][c]            (f64 accumulation, rounded once)
-__global__ void conv_background(const float *__restrict__ w, const float *__restrict__ c_in, int Din, int Dout, int Cin,
-                                int Cout, int sd, int pd, float *__restrict__ bg_pre) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x, d = blockIdx.y;
-    if (n >= Cout) return;
+__global__ __launch_bounds__(64) void conv_background(const float *__restrict__ w, const float *__restrict__ c_in, int Din,
+                                                      int Dout, int Cin, int Cout, int sd, int pd,
+                                                      float *__restrict__ bg_pre) {
+    const int n = blockIdx.x, d = blockIdx.y;        // one wave per (output channel, plane); lanes over (c, tap)
     double s = 0.0;
     for (int kd = 0; kd < 3; ++kd) {
         const int ds = d * sd - pd + kd;
         if (ds < 0 || ds >= Din) continue;
-        for (int c = 0; c < Cin; ++c) {
-            const float *wp = w + (((size_t)n * Cin + c) * 3 + kd) * 9;
-            double t = 0.0;
-            for (int k = 0; k < 9; ++k) t += (double)wp[k];
-            s += t * (double)c_in[(size_t)ds * Cin + c];
+        for (int e = threadIdx.x; e < Cin * 9; e += 64) {
+            const int c = e / 9, k = e - c * 9;
+            s += (double)w[(((size_t)n * Cin + c) * 3 + kd) * 9 + k] * (double)c_in[(size_t)ds * Cin + c];
         }
     }
-    bg_pre[(size_t)d * Cout + n] = (float)s;
+    s = wave_sum_f64(s);
+    if (threadIdx.x == 0) bg_pre[(size_t)d * Cout + n] = (float)s;
 }
 
 // y_bg = [ReLU](bg_pre + bias) and c_out = (y_bg - mean) * inv, with exactly the fp32 operations of the
@@ -92,11 +98,189 @@ __global__ void bn_background(const float *__restrict__ bg_pre, const float *__r
     c_out[e] = (v - mi[c]) * mi[C + c];
 }
 
+// ---- BatchNorm + ReLU backward restricted to the active tiles of a layer output -----------------------
+// Outside the active tiles every site holds the background (y = y_bg[d], yhat = c[d]); its share of the
+// batch sums follows from A[d][c] = sum over plane d of the incoming gradient (closed form, see
+// mvx_conv3d_input_grad_sums) minus what the active tiles hold.  The gradient itself is only produced on
+// the active tiles: nothing downstream reads it elsewhere (mvx_sparse_conv_gather_dz reads next to voxels).
+constexpr int BREP = 8;
+
+// tile_list[j] = d * ntiles + tile of the active tiles (ascending); n_act; n_inact[d] = sites of plane d in inactive tiles
+__global__ __launch_bounds__(1024) void bnb_tile_list(const int *__restrict__ tile_flags, int D, int H, int W, int ntiles,
+                                                      int *__restrict__ list, int *__restrict__ n_act,
+                                                      int *__restrict__ n_inact) {
+    __shared__ int smem[17];
+    __shared__ int s_inact[16];
+    const int tiles_x = (W + ATW - 1) / ATW;
+    if (threadIdx.x < 16) s_inact[threadIdx.x] = 0;
+    __syncthreads();
+    const int total = D * ntiles;
+    int base = 0;
+    for (int e0 = 0; e0 < total; e0 += 1024) {
+        const int e = e0 + threadIdx.x;
+        int on = 0;
+        if (e < total) {
+            on = tile_flags[e] != 0;
+            if (!on) {
+                const int d = e / ntiles, t = e - d * ntiles;
+                const int ty0 = (t / tiles_x) * ATH, tx0 = (t % tiles_x) * ATW;
+                atomicAdd(&s_inact[d], min(ATH, H - ty0) * min(ATW, W - tx0));
+            }
+        }
+        int tot;
+        const int pos = block_excl_scan_i32(on, smem, &tot);
+        if (on) list[base + pos] = e;
+        base += tot;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *n_act = base;
+    if (threadIdx.x < D) n_inact[threadIdx.x] = s_inact[threadIdx.x];
+}
+
+// One workgroup per listed tile; thread = (site column group, channel quad).  mode 0: sums[rep][0][d][c] += dyh,
+// sums[rep][1][0][c] += dyh * (yhat - c_bg[d]).  mode 1: dz = (y > 0) * inv * (dyh - a - yhat * b), sums[rep][2][0][c] += dz.
+__global__ __launch_bounds__(256) void bnb_tiles(const float *__restrict__ dyh, const float *__restrict__ y,
+                                                 const float *__restrict__ mi, const float *__restrict__ c_bg,
+                                                 const float *__restrict__ ab, const int *__restrict__ list,
+                                                 const int *__restrict__ n_act, int D, int H, int W, int C, int ntiles,
+                                                 int mode, float *__restrict__ dz, double *__restrict__ sums) {
+    __shared__ float red[2][256][4];
+    const int tiles_x = (W + ATW - 1) / ATW;
+    const int c4n = C >> 2, ct = threadIdx.x % c4n, st = threadIdx.x / c4n, spb = 256 / c4n;
+    const int nact = *n_act;
+    for (int j = blockIdx.x; j < nact; j += gridDim.x) {
+        const int e = list[j], d = e / ntiles, t = e - d * ntiles;
+        const int ty0 = (t / tiles_x) * ATH, tx0 = (t % tiles_x) * ATW;
+        const float4 m = *(const float4 *)(mi + ct * 4), iv = *(const float4 *)(mi + C + ct * 4);
+        const float4 cb = *(const float4 *)(c_bg + (size_t)d * C + ct * 4);
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (mode == 1) { a = *(const float4 *)(ab + ct * 4); b = *(const float4 *)(ab + C + ct * 4); }
+        float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+        for (int sidx = st; sidx < ATH * ATW; sidx += spb) {
+            const int gy = ty0 + sidx / ATW, gx = tx0 + sidx % ATW;
+            if (gy >= H || gx >= W) continue;
+            const size_t off = (((size_t)d * H + gy) * W + gx) * C + ct * 4;
+            const float4 g = *(const float4 *)(dyh + off), v = *(const float4 *)(y + off);
+            const float4 yh = make_float4((v.x - m.x) * iv.x, (v.y - m.y) * iv.y, (v.z - m.z) * iv.z, (v.w - m.w) * iv.w);
+            if (mode == 0) {
+                s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+                s2.x += g.x * (yh.x - cb.x); s2.y += g.y * (yh.y - cb.y); s2.z += g.z * (yh.z - cb.z); s2.w += g.w * (yh.w - cb.w);
+            } else {
+                float4 o;
+                o.x = v.x > 0.f ? iv.x * (g.x - (a.x + yh.x * b.x)) : 0.f;
+                o.y = v.y > 0.f ? iv.y * (g.y - (a.y + yh.y * b.y)) : 0.f;
+                o.z = v.z > 0.f ? iv.z * (g.z - (a.z + yh.z * b.z)) : 0.f;
+                o.w = v.w > 0.f ? iv.w * (g.w - (a.w + yh.w * b.w)) : 0.f;
+                *(float4 *)(dz + off) = o;
+                s1.x += o.x; s1.y += o.y; s1.z += o.z; s1.w += o.w;
+            }
+        }
+        __syncthreads();
+        red[0][threadIdx.x][0] = s1.x; red[0][threadIdx.x][1] = s1.y; red[0][threadIdx.x][2] = s1.z; red[0][threadIdx.x][3] = s1.w;
+        red[1][threadIdx.x][0] = s2.x; red[1][threadIdx.x][1] = s2.y; red[1][threadIdx.x][2] = s2.z; red[1][threadIdx.x][3] = s2.w;
+        __syncthreads();
+        if (st == 0) {
+            const unsigned rep = (unsigned)j % BREP;
+            double *base = sums + (size_t)rep * (D + 2) * C;        // layout per replica: [D planes of P1][Q1][Z1]
+            for (int q4 = 0; q4 < 4; ++q4) {
+                double t1 = 0.0, t2 = 0.0;
+                for (int q = 0; q < spb; ++q) { t1 += (double)red[0][q * c4n + ct][q4]; t2 += (double)red[1][q * c4n + ct][q4]; }
+                const int n = ct * 4 + q4;
+                if (mode == 0) {
+                    atomicAdd(base + (size_t)d * C + n, t1);
+                    atomicAdd(base + (size_t)D * C + n, t2);
+                } else {
+                    atomicAdd(base + (size_t)(D + 1) * C + n, t1);
+                }
+            }
+        }
+    }
+}
+
+// a = sum_d A[d] / N ; b = (Q1 + sum_d c[d] A[d]) / N
+__global__ void bnb_finalize_ab(const double *__restrict__ sums, const float *__restrict__ A, const float *__restrict__ c_bg,
+                                int D, int C, double count, float *__restrict__ ab) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= C) return;
+    double q1 = 0.0;
+    for (int rep = 0; rep < BREP; ++rep) q1 += sums[((size_t)rep * (D + 2) + D) * C + n];
+    double sa = 0.0, sca = 0.0;
+    for (int d = 0; d < D; ++d) {
+        const double Ad = (double)A[(size_t)d * C + n];
+        sa += Ad;
+        sca += (double)c_bg[(size_t)d * C + n] * Ad;
+    }
+    ab[n] = (float)(sa / count);
+    ab[C + n] = (float)((q1 + sca) / count);
+}
+
+// dbias = Z1 + sum_d [y_bg[d] > 0] inv ((A[d] - P1[d]) - n_inact[d] (a + c[d] b))
+__global__ void bnb_dbias(const double *__restrict__ sums, const float *__restrict__ A, const float *__restrict__ c_bg,
+                          const float *__restrict__ y_bg, const float *__restrict__ mi, const float *__restrict__ ab,
+                          const int *__restrict__ n_inact, int D, int C, float *__restrict__ dbias, int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= C) return;
+    double z1 = 0.0;
+    for (int rep = 0; rep < BREP; ++rep) z1 += sums[((size_t)rep * (D + 2) + D + 1) * C + n];
+    const double inv = (double)mi[C + n], a = (double)ab[n], b = (double)ab[C + n];
+    double t = z1;
+    for (int d = 0; d < D; ++d) {
+        if (!(y_bg[(size_t)d * C + n] > 0.f)) continue;
+        double p1 = 0.0;
+        for (int rep = 0; rep < BREP; ++rep) p1 += sums[((size_t)rep * (D + 2) + d) * C + n];
+        t += inv * (((double)A[(size_t)d * C + n] - p1) - (double)n_inact[d] * (a + (double)c_bg[(size_t)d * C + n] * b));
+    }
+    dbias[n] = accumulate ? dbias[n] + (float)t : (float)t;
+}
+
 }  // namespace
+
+extern "C" size_t mvx_bn_relu_backward_tiles_workspace_bytes(int32_t planes, int32_t h, int32_t w, int32_t channels) {
+    if (planes <= 0 || planes > 16 || h <= 0 || w <= 0 || channels <= 0) return 0;
+    const size_t ntiles = (size_t)mvx_cdiv(w, ATW) * mvx_cdiv(h, ATH);
+    return sizeof(double) * BREP * (planes + 2) * channels + sizeof(float) * 2 * channels + sizeof(int) * (planes * ntiles + 32);
+}
+
+extern "C" int mvx_bn_relu_backward_tiles(const float *dyhat, const float *y, const float *mean_inv, const float *c_bg,
+                                          const float *y_bg, const float *plane_grad_sums, const int32_t *tile_flags,
+                                          int32_t planes, int32_t h, int32_t w, int32_t channels, float *dz, float *dbias,
+                                          int32_t flags, void *workspace, size_t workspace_bytes, void *stream) {
+    MVX_CHECK_ARG(dyhat && y && mean_inv && c_bg && y_bg && plane_grad_sums && tile_flags && dz && workspace);
+    MVX_CHECK_ARG(planes > 0 && planes <= 16 && h > 0 && w > 0 && channels > 0 && channels % 4 == 0 && 256 % (channels / 4) == 0);
+    MVX_CHECK_ARG(workspace_bytes >= mvx_bn_relu_backward_tiles_workspace_bytes(planes, h, w, channels));
+    hipStream_t st = (hipStream_t)stream;
+    const int ntiles = (int)(mvx_cdiv(w, ATW) * mvx_cdiv(h, ATH));
+    double *sums = (double *)workspace;
+    float *ab = (float *)(sums + (size_t)BREP * (planes + 2) * channels);
+    int *list = (int *)(ab + 2 * channels);
+    int *n_act = list + (size_t)planes * ntiles, *n_inact = n_act + 1;
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * BREP * (planes + 2) * channels, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(bnb_tile_list, dim3(1), dim3(1024), 0, st, tile_flags, planes, h, w, ntiles, list, n_act, n_inact);
+    MVX_LAUNCH_CHECK();
+    const double count = (double)planes * h * w;
+    const unsigned grid = (unsigned)(planes * ntiles > 2048 ? 2048 : planes * ntiles);
+    hipLaunchKernelGGL(bnb_tiles, dim3(grid), dim3(256), 0, st, dyhat, y, mean_inv, c_bg, (const float *)ab, (const int *)list,
+                       (const int *)n_act, planes, h, w, channels, ntiles, 0, dz, sums);
+    MVX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bnb_finalize_ab, dim3(mvx_cdiv(channels, 64)), dim3(64), 0, st, (const double *)sums, plane_grad_sums,
+                       c_bg, planes, channels, count, ab);
+    MVX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bnb_tiles, dim3(grid), dim3(256), 0, st, dyhat, y, mean_inv, c_bg, (const float *)ab, (const int *)list,
+                       (const int *)n_act, planes, h, w, channels, ntiles, 1, dz, sums);
+    MVX_LAUNCH_CHECK();
+    if (dbias) {
+        hipLaunchKernelGGL(bnb_dbias, dim3(mvx_cdiv(channels, 64)), dim3(64), 0, st, (const double *)sums, plane_grad_sums, c_bg,
+                           y_bg, mean_inv, (const float *)ab, (const int *)n_inact, planes, channels, dbias,
+                           flags & MVX_FLAG_ACCUMULATE);
+        MVX_LAUNCH_CHECK();
+    }
+    return MVX_OK;
+}
 
 extern "C" int mvx_activity_dilate(const void *src, int32_t src_is_index, int32_t din, int32_t dout, int32_t h, int32_t w,
                                    int32_t stride_d, int32_t pad_d, int32_t mark_border, uint8_t *dst_mask,
-                                   int32_t *dst_halo_flags, void *stream) {
+                                   int32_t *dst_halo_flags, int32_t *dst_tile_flags, void *stream) {
     MVX_CHECK_ARG(src && dst_mask && din > 0 && dout > 0 && h > 0 && w > 0);
     MVX_CHECK_ARG(stride_d >= 1 && stride_d <= 2 && pad_d >= 0 && pad_d <= 1);
     MVX_CHECK_ARG(dout == (din + 2 * pad_d - 3) / stride_d + 1);
@@ -105,9 +289,9 @@ extern "C" int mvx_activity_dilate(const void *src, int32_t src_is_index, int32_
     hipLaunchKernelGGL(activity_sites, dim3(mvx_cdiv(n, 256) > 4096 ? 4096 : mvx_cdiv(n, 256)), dim3(256), 0, st, src,
                        src_is_index, din, dout, h, w, stride_d, pad_d, mark_border, dst_mask);
     MVX_LAUNCH_CHECK();
-    if (dst_halo_flags) {
+    if (dst_halo_flags || dst_tile_flags) {
         hipLaunchKernelGGL(activity_halo_flags, dim3(mvx_cdiv(w, ATW) * mvx_cdiv(h, ATH), dout), dim3(256), 0, st,
-                           (const unsigned char *)dst_mask, dout, h, w, dst_halo_flags);
+                           (const unsigned char *)dst_mask, dout, h, w, dst_halo_flags, dst_tile_flags);
         MVX_LAUNCH_CHECK();
     }
     return MVX_OK;
@@ -116,8 +300,8 @@ extern "C" int mvx_activity_dilate(const void *src, int32_t src_is_index, int32_
 extern "C" int mvx_conv3d_background(const float *w, const float *c_in, int32_t din, int32_t dout, int32_t cin,
                                      int32_t cout, int32_t stride_d, int32_t pad_d, float *bg_pre, void *stream) {
     MVX_CHECK_ARG(w && c_in && bg_pre && din > 0 && dout > 0 && cin > 0 && cout > 0);
-    hipLaunchKernelGGL(conv_background, dim3(mvx_cdiv(cout, 64), dout), dim3(64), 0, (hipStream_t)stream, w, c_in, din, dout,
-                       cin, cout, stride_d, pad_d, bg_pre);
+    hipLaunchKernelGGL(conv_background, dim3(cout, dout), dim3(64), 0, (hipStream_t)stream, w, c_in, din, dout, cin, cout,
+                       stride_d, pad_d, bg_pre);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

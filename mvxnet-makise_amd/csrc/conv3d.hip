@@ -254,7 +254,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_pf(const float *__restri
                                                            Geom g, int relu, const int *__restrict__ in_hflag,
                                                            const unsigned char *__restrict__ out_mask,
                                                            const float *__restrict__ bg_pre, int border_active,
-                                                           unsigned long long *__restrict__ exec_stages) {
+                                                           unsigned long long *__restrict__ exec_stages,
+                                                           const int *__restrict__ only_tiles) {
     __shared__ __attribute__((aligned(16))) float s_halo[HH * HROW];
     __shared__ __attribute__((aligned(16))) float s_w[3 * WROW];
     __shared__ float s_red[4][2 * BN];
@@ -265,6 +266,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_pf(const float *__restri
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int nchunks = g.Cin / BK;
+    // restricted launch: only the flagged output tiles are produced, the others are left untouched
+    if (only_tiles && !only_tiles[(size_t)d * gridDim.x + blockIdx.x]) return;
 
     f32x16 acc0, acc1;
 #pragma unroll
@@ -861,7 +864,8 @@ constexpr int W4_C = 64;               // input channels per workgroup
 __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restrict__ in,
                                                             const float *__restrict__ dz,
                                                             float *__restrict__ slabs, Geom g,
-                                                            int tiles_per_strip, const int *__restrict__ in_hflag,
+                                                            int tiles_per_strip, const int *__restrict__ step_list,
+                                                            const int *__restrict__ step_count,
                                                             const float *__restrict__ c_in) {
     __shared__ __attribute__((aligned(16))) float s_x[HH * HW * W4_C];
     __shared__ __attribute__((aligned(16))) float s_z[TH * TW * ZP];
@@ -880,10 +884,10 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    // Steps of this workgroup: (output plane d with a valid source plane for kd) x (tiles of the strip).
-    // Dense: the strip is a contiguous tile range.  With a background description (in_hflag, c_in) the
-    // tiles are dealt round-robin to the strips (active tiles cluster, contiguous strips would be unbalanced)
-    // and steps whose source halo holds only background sites are skipped: there x - c is exactly zero.
+    // Steps of this workgroup: (output plane d with a valid source plane for kd) x (tile).
+    // Dense: the strip's contiguous tile range for every valid plane.  With a background description the
+    // steps whose source halo holds a non-background site were compacted into step_list[kd][] (everywhere
+    // else x - c is exactly zero) and are dealt round-robin to the strips: balanced and deterministic.
     int dlo = 0, dhi = -1;                           // valid output planes form a contiguous range
     for (int d = 0; d < g.Dout; ++d) {
         const int ds = d * g.sd - g.pd + kd;
@@ -891,15 +895,21 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restr
     }
     const int nd = dhi >= dlo ? dhi - dlo + 1 : 0;
     const int per = tiles_per_strip;
-    const int nsteps = nd * per;
-    auto step_tile = [&](int i) { const int k = i % per; return in_hflag ? strip + k * nstrips : strip * per + k; };
-    auto step_plane = [&](int i) { return dlo + i / per; };
+    const int *my_list = step_list ? step_list + (size_t)kd * g.Dout * ntiles : nullptr;
+    const int nlist = step_list ? step_count[kd] : 0;
+    const int nsteps = step_list ? (nlist > strip ? (nlist - strip + nstrips - 1) / nstrips : 0) : nd * per;
+    // step i -> (plane, tile); dense steps past the last tile are dead (ragged last strip)
+    auto step_of = [&](int i, int &d, int &t) {
+        if (my_list) { const int e = my_list[strip + i * nstrips]; d = e / ntiles; t = e - d * ntiles; }
+        else { d = dlo + i / per; t = strip * per + i % per; }
+    };
 
     constexpr int NX = (HH * HW * 16 + W4_THREADS - 1) / W4_THREADS;    // float4 per thread, halo (64 ch)
     constexpr int NZ = TH * TW * 16 / W4_THREADS;                       // float4 per thread, dz
     f32x4 xr[NX], zr[NZ];
     auto load_step = [&](int i) __attribute__((always_inline)) {
-        const int d = step_plane(i), t = step_tile(i);
+        int d, t;
+        step_of(i, d, t);
         const int ds = d * g.sd - g.pd + kd;
         const int tx0 = (t % tiles_x) * TW, ty0 = (t / tiles_x) * TH;
 #pragma unroll
@@ -927,23 +937,10 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restr
             zr[u] = v;
         }
     };
-    // next live step at or after i (all lanes evaluate 64 candidate steps at a time: block-uniform result)
     auto next_live = [&](int i) {
-        while (i < nsteps) {
-            const int cand = i + lane;
-            bool on = false;
-            if (cand < nsteps) {
-                const int t = step_tile(cand);
-                if (t < ntiles) {
-                    const int ds = step_plane(cand) * g.sd - g.pd + kd;
-                    on = !in_hflag || in_hflag[(size_t)ds * ntiles + t] != 0;
-                }
-            }
-            const unsigned long long m = __ballot(on);
-            if (m) return i + (int)__builtin_ctzll(m);
-            i += 64;
-        }
-        return nsteps;
+        if (my_list) return i < nsteps ? i : nsteps;
+        while (i < nsteps && strip * per + i % per >= ntiles) ++i;      // ragged last strip
+        return i < nsteps ? i : nsteps;
     };
     int cur = next_live(0);
     if (cur < nsteps) load_step(cur);
@@ -985,10 +982,36 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restr
     }
 }
 
+// step_list[kd][j] = d * ntiles + tile for the (plane, tile) steps of depth tap kd whose source halo holds a
+// non-background site, in ascending (d, tile) order; step_count[kd] = how many.  One workgroup.
+__global__ __launch_bounds__(1024) void wgrad_step_list(const int *__restrict__ in_hflag, Geom g, int ntiles,
+                                                        int *__restrict__ step_list, int *__restrict__ step_count) {
+    __shared__ int smem[17];
+    const int total = g.Dout * ntiles;
+    for (int kd = 0; kd < 3; ++kd) {
+        int base = 0;
+        for (int e0 = 0; e0 < total; e0 += 1024) {
+            const int e = e0 + threadIdx.x;
+            int on = 0;
+            if (e < total) {
+                const int d = e / ntiles, t = e - d * ntiles;
+                const int ds = d * g.sd - g.pd + kd;
+                on = (ds >= 0 && ds < g.Din) ? (in_hflag[(size_t)ds * ntiles + t] != 0) : 0;
+            }
+            int tot;
+            const int pos = block_excl_scan_i32(on, smem, &tot);
+            if (on) step_list[(size_t)kd * total + base + pos] = e;
+            base += tot;
+        }
+        if (threadIdx.x == 0) step_count[kd] = base;
+    }
+}
+
 // ---- closed-form part of the background rewrite of wgrad ------------------------------------------
 // R[rep][d][kind][n]: per-plane sums of dz over  0 all sites, 1 row 0, 2 row H-1, 3 column 0, 4 column W-1,
 // 5..8 the corners (0,0) (0,W-1) (H-1,0) (H-1,W-1).  One workgroup per (row, plane).
 constexpr int RK = 9;
+constexpr int RREP = 8;     // replicas of the region sums (spreads the same-address f64 atomics of 1,200 workgroups)
 __global__ __launch_bounds__(256) void plane_region_sums(const float *__restrict__ dz, int D, int H, int W, int C,
                                                          double *__restrict__ R) {
     __shared__ float red[256][4];
@@ -1003,7 +1026,7 @@ __global__ __launch_bounds__(256) void plane_region_sums(const float *__restrict
     red[threadIdx.x][0] = s.x; red[threadIdx.x][1] = s.y; red[threadIdx.x][2] = s.z; red[threadIdx.x][3] = s.w;
     __syncthreads();
     if (st == 0) {
-        const unsigned rep = (unsigned)y % MVX_REP;
+        const unsigned rep = (unsigned)y % RREP;
         double *Rp = R + ((size_t)rep * D + d) * RK * C;
         const float4 first = *(const float4 *)(row + ct * 4), last = *(const float4 *)(row + (size_t)(W - 1) * C + ct * 4);
         const float f[4] = {first.x, first.y, first.z, first.w}, l[4] = {last.x, last.y, last.z, last.w};
@@ -1031,7 +1054,7 @@ __global__ void region_tap_sums(const double *__restrict__ R, int D, int C, floa
     double k[RK];
     for (int q = 0; q < RK; ++q) {
         double t = 0.0;
-        for (int rep = 0; rep < MVX_REP; ++rep) t += R[(((size_t)rep * D + d) * RK + q) * C + n];
+        for (int rep = 0; rep < RREP; ++rep) t += R[(((size_t)rep * D + d) * RK + q) * C + n];
         k[q] = t;
     }
     double t = k[0];
@@ -1076,6 +1099,26 @@ __global__ void wgrad_reduce(const float *__restrict__ slabs, float *__restrict_
         float *dst = dw + ((((size_t)co * Ci + ci) * 3 + kd) * 3 + tap / 3) * 3 + tap % 3;
         *dst = accumulate ? *dst + s : s;
     }
+}
+
+// A[d][c] = sum over the sites of INPUT plane d of the input gradient dx[.][c], from the tap sums T of dz:
+// A[d][c] = sum over kd with an output plane d' reading plane d through it, a, b, n of W[n][c][kd][a][b] T[d'][a][b][n]
+__global__ __launch_bounds__(64) void input_grad_sums(const float *__restrict__ w, const float *__restrict__ T, Geom g,
+                                                      float *__restrict__ A) {
+    const int c = blockIdx.x, d = blockIdx.y;        // one wave per (input channel, input plane)
+    double s = 0.0;
+    for (int kd = 0; kd < 3; ++kd) {
+        const int t = d + g.pd - kd;
+        if (t < 0 || t % g.sd) continue;
+        const int dp = t / g.sd;
+        if (dp >= g.Dout) continue;
+        for (int e = threadIdx.x; e < g.Cout * 9; e += 64) {
+            const int n = e / 9, k = e - n * 9;
+            s += (double)w[(((size_t)n * g.Cin + c) * 3 + kd) * 9 + k] * (double)T[((size_t)dp * 9 + k) * g.Cout + n];
+        }
+    }
+    s = wave_sum_f64(s);
+    if (threadIdx.x == 0) A[(size_t)d * g.Cin + c] = (float)s;
 }
 
 }  // namespace
@@ -1134,7 +1177,7 @@ extern "C" int mvx_conv3d_forward(const float *in, const float *wpk, const float
     else
         hipLaunchKernelGGL(conv3d_gather_pf, gather_grid(g), dim3(256), 0, st, in, wpk, bias, out, stats, g, relu,
                            (const int *)nullptr, (const unsigned char *)nullptr, (const float *)nullptr, 0,
-                           (unsigned long long *)nullptr);
+                           (unsigned long long *)nullptr, (const int *)nullptr);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -1156,7 +1199,22 @@ extern "C" int mvx_conv3d_forward_bg(const float *in, const float *wpk, const fl
     Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
     hipLaunchKernelGGL(conv3d_gather_pf, gather_grid(g), dim3(256), 0, st, in, wpk, bias, out, stats, g,
                        flags & MVX_FLAG_RELU, in_halo_flags, out_mask, bg_pre, border_active,
-                       (unsigned long long *)exec_stages);
+                       (unsigned long long *)exec_stages, (const int *)nullptr);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+static int launch_dgrad(const float *dz, const float *wpk_dgrad, float *dx, int32_t din, int32_t dout, int32_t h,
+                        int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, const int32_t *only_tiles,
+                        void *stream) {
+    MVX_CHECK_ARG(dz && wpk_dgrad && dx);
+    // gather view: source = dz (dout planes, cout channels), result = dx (din planes, cin channels)
+    int rc = check_geom(din, dout, h, w, cout, cin, stride_d, pad_d);
+    if (rc) return rc;
+    Geom g{dout, din, h, w, cout, cin, stride_d, pad_d, 1};
+    hipLaunchKernelGGL(conv3d_gather_pf, gather_grid(g), dim3(256), 0, (hipStream_t)stream, dz, wpk_dgrad,
+                       (const float *)nullptr, dx, (double *)nullptr, g, 0, (const int *)nullptr,
+                       (const unsigned char *)nullptr, (const float *)nullptr, 0, (unsigned long long *)nullptr, only_tiles);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -1164,17 +1222,14 @@ extern "C" int mvx_conv3d_forward_bg(const float *in, const float *wpk, const fl
 extern "C" int mvx_conv3d_dgrad(const float *dz, const float *wpk_dgrad, float *dx, int32_t din,
                                 int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
                                 int32_t stride_d, int32_t pad_d, void *stream) {
-    MVX_CHECK_ARG(dz && wpk_dgrad && dx);
-    // gather view: source = dz (dout planes, cout channels), result = dx (din planes, cin channels)
-    int rc = check_geom(din, dout, h, w, cout, cin, stride_d, pad_d);
-    if (rc) return rc;
-    Geom g{dout, din, h, w, cout, cin, stride_d, pad_d, 1};
-    const dim3 grid(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), din, cin / BN);
-    hipLaunchKernelGGL(conv3d_gather_pf, gather_grid(g), dim3(256), 0, (hipStream_t)stream, dz, wpk_dgrad,
-                       (const float *)nullptr, dx, (double *)nullptr, g, 0, (const int *)nullptr,
-                       (const unsigned char *)nullptr, (const float *)nullptr, 0, (unsigned long long *)nullptr);
-    MVX_LAUNCH_CHECK();
-    return MVX_OK;
+    return launch_dgrad(dz, wpk_dgrad, dx, din, dout, h, w, cin, cout, stride_d, pad_d, nullptr, stream);
+}
+
+extern "C" int mvx_conv3d_dgrad_tiles(const float *dz, const float *wpk_dgrad, float *dx, int32_t din, int32_t dout,
+                                      int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
+                                      const int32_t *dx_tile_flags, void *stream) {
+    MVX_CHECK_ARG(dx_tile_flags);
+    return launch_dgrad(dz, wpk_dgrad, dx, din, dout, h, w, cin, cout, stride_d, pad_d, dx_tile_flags, stream);
 }
 
 static int wgrad_strips(int h, int w, int cin) {
@@ -1212,7 +1267,7 @@ extern "C" int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int
     hipStream_t st = (hipStream_t)stream;
     if (cin % W4_C == 0)
         hipLaunchKernelGGL(conv3d_wgrad4, dim3(nstrips, 3 * (cin / W4_C)), dim3(W4_THREADS), 0, st, in, dz,
-                           (float *)workspace, g, per, (const int *)nullptr, (const float *)nullptr);
+                           (float *)workspace, g, per, (const int *)nullptr, (const int *)nullptr, (const float *)nullptr);
     else
         hipLaunchKernelGGL(conv3d_wgrad, dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz,
                            (float *)workspace, g, per);
@@ -1239,51 +1294,78 @@ extern "C" int mvx_conv3d_dgrad_sites(const float *dz, const float *wpk_dgrad, c
     return MVX_OK;
 }
 
-// workspace of mvx_conv3d_wgrad_bg: [slabs][R f64 replicas][T]
-static size_t wgrad_bg_slab_bytes(int h, int w, int cin) {
-    const int ntiles = (int)(mvx_cdiv(w, TW) * mvx_cdiv(h, TH));
-    const int per = wgrad_strips(h, w, cin);
-    const int nstrips = (ntiles + per - 1) / per;
-    return (size_t)nstrips * 27 * cin * BN * sizeof(float);
+// mvx_conv3d_wgrad_bg: one workgroup per CU (the kernel's 9 accumulator tiles leave room for one wave per SIMD),
+// strips x 3 depth taps x channel chunks = 255..256 workgroups, steps dealt round-robin from the compacted lists.
+// workspace: [slabs][R f64 replicas][T][step lists][step counts]
+static int wgrad_bg_strips(int cin) {
+    const int s = 256 / (3 * (cin / W4_C));
+    return s < 1 ? 1 : s;
+}
+static size_t wgrad_bg_slab_bytes(int cin) { return (size_t)wgrad_bg_strips(cin) * 27 * cin * BN * sizeof(float); }
+
+extern "C" size_t mvx_plane_tap_sums_workspace_bytes(int32_t planes, int32_t channels) {
+    return planes > 0 && channels > 0 ? sizeof(double) * RREP * planes * RK * channels : 0;
+}
+
+extern "C" int mvx_plane_tap_sums(const float *dz, int32_t planes, int32_t h, int32_t w, int32_t channels, float *tap_sums,
+                                  void *workspace, size_t workspace_bytes, void *stream) {
+    MVX_CHECK_ARG(dz && tap_sums && workspace && planes > 0 && h > 0 && w > 0 && channels > 0);
+    MVX_CHECK_ARG(channels % 4 == 0 && 256 % (channels / 4) == 0);
+    MVX_CHECK_ARG(workspace_bytes >= mvx_plane_tap_sums_workspace_bytes(planes, channels));
+    hipStream_t st = (hipStream_t)stream;
+    double *R = (double *)workspace;
+    hipError_t e = hipMemsetAsync(R, 0, sizeof(double) * RREP * planes * RK * channels, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(plane_region_sums, dim3(h, planes), dim3(256), 0, st, dz, planes, h, w, channels, R);
+    MVX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(region_tap_sums, dim3(mvx_cdiv((long long)planes * 9 * channels, 64)), dim3(64), 0, st,
+                       (const double *)R, planes, channels, tap_sums);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+extern "C" int mvx_conv3d_input_grad_sums(const float *w, const float *tap_sums, int32_t din, int32_t dout, int32_t cin,
+                                          int32_t cout, int32_t stride_d, int32_t pad_d, float *plane_grad_sums,
+                                          void *stream) {
+    MVX_CHECK_ARG(w && tap_sums && plane_grad_sums && din > 0 && dout > 0 && cin > 0 && cout > 0);
+    Geom g{din, dout, 0, 0, cin, cout, stride_d, pad_d, 0};
+    hipLaunchKernelGGL(input_grad_sums, dim3(cin, din), dim3(64), 0, (hipStream_t)stream, w, tap_sums, g, plane_grad_sums);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
 }
 
 extern "C" size_t mvx_conv3d_wgrad_bg_workspace_bytes(int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout) {
     if (dout <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout != BN || cin % W4_C) return 0;
-    return wgrad_bg_slab_bytes(h, w, cin) + sizeof(double) * MVX_REP * dout * RK * cout + sizeof(float) * dout * 9 * cout;
+    const size_t ntiles = (size_t)mvx_cdiv(w, TW) * mvx_cdiv(h, TH);
+    return wgrad_bg_slab_bytes(cin) + sizeof(int) * (3 * dout * ntiles + 4);
 }
 
 extern "C" int mvx_conv3d_wgrad_bg(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
                                    int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, int32_t flags,
-                                   const int32_t *in_halo_flags, const float *c_in, void *workspace,
-                                   size_t workspace_bytes, void *stream) {
-    MVX_CHECK_ARG(in && dz && dw && workspace && in_halo_flags && c_in);
+                                   const int32_t *in_halo_flags, const float *c_in, const float *tap_sums,
+                                   void *workspace, size_t workspace_bytes, void *stream) {
+    MVX_CHECK_ARG(in && dz && dw && workspace && in_halo_flags && c_in && tap_sums);
     int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
     if (rc) return rc;
     if (cout != BN || cin % W4_C) return MVX_ESIZE;
     MVX_CHECK_ARG(workspace_bytes >= mvx_conv3d_wgrad_bg_workspace_bytes(dout, h, w, cin, cout));
     const int ntiles = (int)(mvx_cdiv(w, TW) * mvx_cdiv(h, TH));
-    const int per = wgrad_strips(h, w, cin);
-    const int nstrips = (ntiles + per - 1) / per;
+    const int nstrips = wgrad_bg_strips(cin);
     Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
     hipStream_t st = (hipStream_t)stream;
     float *slabs = (float *)workspace;
-    double *R = (double *)((char *)workspace + wgrad_bg_slab_bytes(h, w, cin));
-    float *T = (float *)(R + (size_t)MVX_REP * dout * RK * cout);
-    hipError_t e = hipMemsetAsync(R, 0, sizeof(double) * MVX_REP * dout * RK * cout, st);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(plane_region_sums, dim3(h, dout), dim3(256), 0, st, dz, dout, h, w, cout, R);
+    int *list = (int *)((char *)workspace + wgrad_bg_slab_bytes(cin));
+    int *count = list + (size_t)3 * dout * ntiles;
+    hipLaunchKernelGGL(wgrad_step_list, dim3(1), dim3(1024), 0, st, in_halo_flags, g, ntiles, list, count);
     MVX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(region_tap_sums, dim3(mvx_cdiv((long long)dout * 9 * cout, 256)), dim3(256), 0, st, (const double *)R,
-                       dout, cout, T);
-    MVX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(conv3d_wgrad4, dim3(nstrips, 3 * (cin / W4_C)), dim3(W4_THREADS), 0, st, in, dz, slabs, g, per,
-                       in_halo_flags, c_in);
+    hipLaunchKernelGGL(conv3d_wgrad4, dim3(nstrips, 3 * (cin / W4_C)), dim3(W4_THREADS), 0, st, in, dz, slabs, g, 0,
+                       (const int *)list, (const int *)count, c_in);
     MVX_LAUNCH_CHECK();
     const size_t per_slab = (size_t)27 * cin * BN;
     hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)slabs, dw, nstrips, cin,
                        flags & MVX_FLAG_ACCUMULATE);
     MVX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad_rank1, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)T, c_in, dw, g);
+    hipLaunchKernelGGL(wgrad_rank1, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, tap_sums, c_in, dw, g);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

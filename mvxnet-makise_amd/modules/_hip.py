@@ -430,12 +430,15 @@ def conv3d_wgrad(x, dz, sd, pd, split=False, accumulate_into=None):
 # background rewrite of the CML stack (csrc/activity.hip)
 # ---------------------------------------------------------------------------------------------
 class Background:
-    """What a CML activation looks like away from the voxels: per (plane, channel) constant ``c`` f32 (D,C),
-    site mask u8 (D,H,W) of the sites that do NOT hold it, per-tile halo flags i32 (D,tiles)."""
-    __slots__ = ('c', 'mask', 'hflag')
+    """What a CML activation looks like away from the voxels: per (plane, channel) constant ``c`` f32 (D,C)
+    (``y_bg``: its value before the BatchNorm), site mask u8 (D,H,W) of the sites that do NOT hold it, per-tile
+    flags i32 (D,tiles): ``hflag`` = the tile's halo holds such a site, ``tflag`` = the tile itself does.
+    ``back``: dict the CONSUMER's backward fills for the producer's backward ('plane_grad_sums'), or None when
+    the producer cannot use it (then the consumer computes a dense input gradient)."""
+    __slots__ = ('c', 'y_bg', 'mask', 'hflag', 'tflag', 'back')
 
-    def __init__(self, c, mask, hflag):
-        self.c, self.mask, self.hflag = c, mask, hflag
+    def __init__(self, c, mask, hflag, tflag=None, y_bg=None, back=None):
+        self.c, self.mask, self.hflag, self.tflag, self.y_bg, self.back = c, mask, hflag, tflag, y_bg, back
 
 
 EXEC_STAGES = None       # device u64 counter of executed gather stages while KERNEL_TIMERS is on (bench roofline)
@@ -446,14 +449,16 @@ def n_tiles(H, W):
     return ((H + 7) // 8) * ((W + 15) // 16)
 
 
-def activity_dilate(src, src_is_index, din, H, W, sd, pd, mark_border):
-    """(mask u8 (dout,H,W), halo flags i32 (dout,tiles)) of a layer output from its input's activity."""
+def activity_dilate(src, src_is_index, din, H, W, sd, pd, mark_border, want_tile_flags=False):
+    """(mask u8 (dout,H,W), halo flags i32 (dout,tiles)[, tile flags]) of a layer output from its input's activity."""
     dout = conv_out_depth(din, sd, pd)
     mask = torch.empty((dout, H, W), dtype=torch.uint8, device=src.device)
     hflag = torch.empty((dout, n_tiles(H, W)), dtype=torch.int32, device=src.device)
+    tflag = torch.empty_like(hflag) if want_tile_flags else None
     X.check(X.lib.mvx_activity_dilate(X.ptr(src), 1 if src_is_index else 0, din, dout, H, W, sd, pd,
-                                      1 if mark_border else 0, X.ptr(mask), X.ptr(hflag), X.stream()), 'mvx_activity_dilate')
-    return mask, hflag
+                                      1 if mark_border else 0, X.ptr(mask), X.ptr(hflag), X.ptr(tflag), X.stream()),
+            'mvx_activity_dilate')
+    return (mask, hflag, tflag) if want_tile_flags else (mask, hflag)
 
 
 def conv3d_background(w, c_in, din, sd, pd):
@@ -465,11 +470,56 @@ def conv3d_background(w, c_in, din, sd, pd):
     return bg_pre
 
 
-def bn_background(bg_pre, bias, mi, planes, channels, relu=True):
+def bn_background(bg_pre, bias, mi, planes, channels, relu=True, want_y=False):
     c_out = torch.empty((planes, channels), dtype=torch.float32, device=mi.device)
+    y_bg = torch.empty_like(c_out) if want_y else None
     X.check(X.lib.mvx_bn_background(X.ptr(bg_pre), X.ptr(bias), X.ptr(mi), planes, channels, FLAG_RELU if relu else 0,
-                                    None, X.ptr(c_out), X.stream()), 'mvx_bn_background')
-    return c_out
+                                    X.ptr(y_bg), X.ptr(c_out), X.stream()), 'mvx_bn_background')
+    return (c_out, y_bg) if want_y else c_out
+
+
+def plane_tap_sums(dz):
+    """f32 (planes, 9, C): border-corrected per-tap sums of dz over each plane (mvx_plane_tap_sums)."""
+    D, H, W, C = dz.shape
+    T = torch.empty((D, 9, C), dtype=torch.float32, device=dz.device)
+    ws = workspace(X.lib.mvx_plane_tap_sums_workspace_bytes(D, C), dz.device, 'tap_sums')
+    X.check(X.lib.mvx_plane_tap_sums(X.ptr(dz), D, H, W, C, X.ptr(T), X.ptr(ws), ws.numel(), X.stream()), 'mvx_plane_tap_sums')
+    return T
+
+
+def conv3d_input_grad_sums(w, T, din, sd, pd):
+    cout, cin = w.shape[0], w.shape[1]
+    A = torch.empty((din, cin), dtype=torch.float32, device=w.device)
+    X.check(X.lib.mvx_conv3d_input_grad_sums(X.ptr(w.contiguous()), X.ptr(T), din, T.shape[0], cin, cout, sd, pd, X.ptr(A),
+                                             X.stream()), 'mvx_conv3d_input_grad_sums')
+    return A
+
+
+def conv3d_dgrad_tiles(dz, wpk_d, din, cin, sd, pd, tflag):
+    """Input gradient on the flagged tiles only; the rest of the returned tensor is NOT initialised."""
+    dout, H, W, cout = dz.shape
+    dx = torch.empty((din, H, W, cin), dtype=torch.float32, device=dz.device)
+    with _Timed('conv3d_gather_tiles', 0):
+        X.check(X.lib.mvx_conv3d_dgrad_tiles(X.ptr(dz), X.ptr(wpk_d), X.ptr(dx), din, dout, H, W, cin, cout, sd, pd,
+                                             X.ptr(tflag), X.stream()), 'mvx_conv3d_dgrad_tiles')
+    return dx
+
+
+def bn_relu_backward_tiles(dyhat, y, mi, bg, plane_grad_sums, dbias_out=None):
+    """BatchNorm+ReLU backward of a layer output with Background ``bg``; dyhat valid on bg.tflag tiles only.
+    Returns (dz valid on those tiles only, dbias)."""
+    D, H, W, C = y.shape
+    dz = torch.empty_like(y)
+    if dbias_out is not None:
+        db, flags = dbias_out, FLAG_ACCUMULATE
+    else:
+        db, flags = torch.empty((C,), dtype=torch.float32, device=y.device), 0
+    ws = workspace(X.lib.mvx_bn_relu_backward_tiles_workspace_bytes(D, H, W, C), y.device, 'bn_tiles')
+    with _timed_bytes('bn_relu_backward_tiles', 0):
+        X.check(X.lib.mvx_bn_relu_backward_tiles(X.ptr(dyhat), X.ptr(y), X.ptr(mi), X.ptr(bg.c), X.ptr(bg.y_bg),
+                                                 X.ptr(plane_grad_sums), X.ptr(bg.tflag), D, H, W, C, X.ptr(dz), X.ptr(db),
+                                                 flags, X.ptr(ws), ws.numel(), X.stream()), 'mvx_bn_relu_backward_tiles')
+    return dz, (None if dbias_out is not None else db)
 
 
 def conv3d_forward_bg(x, wpk, bias, cout, sd, pd, bg_in, out_mask, bg_pre, relu=True, want_stats=True):
@@ -491,7 +541,7 @@ def conv3d_forward_bg(x, wpk, bias, cout, sd, pd, bg_in, out_mask, bg_pre, relu=
     return out, stats
 
 
-def conv3d_wgrad_bg(x, dz, sd, pd, bg_in, accumulate_into=None):
+def conv3d_wgrad_bg(x, dz, sd, pd, bg_in, tap_sums=None, accumulate_into=None):
     din, H, W, cin = x.shape
     dout, _, _, cout = dz.shape
     if accumulate_into is not None:
@@ -499,11 +549,14 @@ def conv3d_wgrad_bg(x, dz, sd, pd, bg_in, accumulate_into=None):
     else:
         dw, flags = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device=x.device), 0
     nbytes = X.lib.mvx_conv3d_wgrad_bg_workspace_bytes(dout, H, W, cin, cout)
+    if tap_sums is None:
+        tap_sums = plane_tap_sums(dz)
     with _wgrad_scope(accumulate_into, x, dz) as scope:
         ws = workspace(nbytes, x.device, 'wgrad_bg_side' if isinstance(scope, _SideStream) else 'wgrad_bg')
         with _Timed('conv3d_wgrad_bg', 0):
             X.check(X.lib.mvx_conv3d_wgrad_bg(X.ptr(x), X.ptr(dz), X.ptr(dw), din, dout, H, W, cin, cout, sd, pd, flags,
-                                              X.ptr(bg_in.hflag), X.ptr(bg_in.c), X.ptr(ws), ws.numel(), X.stream()),
+                                              X.ptr(bg_in.hflag), X.ptr(bg_in.c), X.ptr(tap_sums), X.ptr(ws), ws.numel(),
+                                              X.stream()),
                     'mvx_conv3d_wgrad_bg')
     return None if accumulate_into is not None else dw
 

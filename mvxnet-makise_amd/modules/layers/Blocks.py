@@ -143,13 +143,22 @@ class CRB3dFunction(torch.autograd.Function):
         sd, pd, count, split = ctx.geom
         dz, db = _hip.bn_relu_backward(g.contiguous(), y, mi, count, True, dbias_out=_hip.bias_sink_of(ctx.params[1]))
         db = _hip.accumulate_grad(ctx.params[1], db)
-        if ctx.bg_in is not None:
-            dw = _hip.conv3d_wgrad_bg(x, dz, sd, pd, ctx.bg_in, accumulate_into=_hip.sink_of(ctx.params[0]))
+        bg_in = ctx.bg_in
+        tap_sums = None
+        if bg_in is not None:
+            tap_sums = _hip.plane_tap_sums(dz)
+            dw = _hip.conv3d_wgrad_bg(x, dz, sd, pd, bg_in, tap_sums, accumulate_into=_hip.sink_of(ctx.params[0]))
         else:
             dw = _hip.conv3d_wgrad(x, dz, sd, pd, split=split, accumulate_into=_hip.sink_of(ctx.params[0]))
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _hip.conv3d_dgrad(dz, _pack(ctx.packer, w, True, split), x.shape[0], x.shape[3], sd, pd, split=split)
+            wpd = _pack(ctx.packer, w, True, split)
+            if bg_in is not None and bg_in.back is not None and bg_in.tflag is not None:
+                # the producer only needs the gradient next to its voxels plus per-plane sums (closed form)
+                dx = _hip.conv3d_dgrad_tiles(dz, wpd, x.shape[0], x.shape[3], sd, pd, bg_in.tflag)
+                bg_in.back['plane_grad_sums'] = _hip.conv3d_input_grad_sums(w, tap_sums, x.shape[0], sd, pd)
+            else:
+                dx = _hip.conv3d_dgrad(dz, wpd, x.shape[0], x.shape[3], sd, pd, split=split)
         return dx, dw, db, None, None, None, None, None, None
 
 
@@ -207,8 +216,11 @@ class VoxelGemmCRB3dFunction(torch.autograd.Function):
         out = _hip.bn_apply(y, mi)
         if aux is not None:
             # voxel-free sites hold ReLU(bias) exactly, also at the image border (zero grid, zero padding)
-            mask, hflag = _hip.activity_dilate(idx_grid, True, dhw[0], dhw[1], dhw[2], sd, pd, mark_border=False)
-            aux['bg'] = _hip.Background(_hip.bn_background(None, b, mi, y.shape[0], cout), mask, hflag)
+            mask, hflag, tflag = _hip.activity_dilate(idx_grid, True, dhw[0], dhw[1], dhw[2], sd, pd, mark_border=False,
+                                                      want_tile_flags=True)
+            c1, y1 = _hip.bn_background(None, b, mi, y.shape[0], cout, want_y=True)
+            aux['bg'] = _hip.Background(c1, mask, hflag, tflag=tflag, y_bg=y1, back={})
+        ctx.bg = aux['bg'] if aux is not None else None
         ctx.save_for_backward(feat, coords, w_all, y, mi)
         ctx.geom = (dhw[0], sd, pd, count, tuple(w.shape))
         ctx.params = (w, b)
@@ -219,7 +231,13 @@ class VoxelGemmCRB3dFunction(torch.autograd.Function):
         feat, coords, w_all, y, mi = ctx.saved_tensors
         din, sd, pd, count, wshape = ctx.geom
         cout, cin = wshape[0], wshape[1]
-        dz, db = _hip.bn_relu_backward(g.contiguous(), y, mi, count, True, dbias_out=_hip.bias_sink_of(ctx.params[1]))
+        bg = ctx.bg
+        if bg is not None and bg.back and 'plane_grad_sums' in bg.back:
+            # g is only valid next to the voxels (conv3d_dgrad_tiles); dz is only read there (gather below)
+            dz, db = _hip.bn_relu_backward_tiles(g.contiguous(), y, mi, bg, bg.back.pop('plane_grad_sums'),
+                                                 dbias_out=_hip.bias_sink_of(ctx.params[1]))
+        else:
+            dz, db = _hip.bn_relu_backward(g.contiguous(), y, mi, count, True, dbias_out=_hip.bias_sink_of(ctx.params[1]))
         db = _hip.accumulate_grad(ctx.params[1], db)
         G = _hip.sparse_conv_gather_dz(dz, coords, din, sd, pd)
         dw_all = _hip.linear_wgrad(feat, G)                                   # (27*cout, cin)
