@@ -281,7 +281,7 @@ def main():
         tpath = os.path.join(REPO, 'profiles', 'traffic.json')
         if os.path.exists(tpath) and main_math == 'f32':
             with open(tpath) as fh:
-                roof['traffic'] = json.load(fh).get('conv3d_gather_hbm_bytes_per_launch')
+                roof['traffic'] = json.load(fh).get('conv3d_gather_pf_hbm_bytes_per_launch')
         out = {
             'metric': 'KITTI frames/sec (voxelize+VFE+fusion+3Dconv fwd+bwd)',
             'value': frames_total * args.steps / dt,

@@ -983,12 +983,13 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restr
 }
 
 // step_list[kd][j] = d * ntiles + tile for the (plane, tile) steps of depth tap kd whose source halo holds a
-// non-background site, in ascending (d, tile) order; step_count[kd] = how many.  One workgroup.
+// non-background site, in ascending (d, tile) order; step_count[kd] = how many.  One workgroup per kd.
 __global__ __launch_bounds__(1024) void wgrad_step_list(const int *__restrict__ in_hflag, Geom g, int ntiles,
                                                         int *__restrict__ step_list, int *__restrict__ step_count) {
     __shared__ int smem[17];
     const int total = g.Dout * ntiles;
-    for (int kd = 0; kd < 3; ++kd) {
+    {
+        const int kd = blockIdx.x;                 // one workgroup per depth tap
         int base = 0;
         for (int e0 = 0; e0 < total; e0 += 1024) {
             const int e = e0 + threadIdx.x;
@@ -1356,7 +1357,7 @@ extern "C" int mvx_conv3d_wgrad_bg(const float *in, const float *dz, float *dw, 
     float *slabs = (float *)workspace;
     int *list = (int *)((char *)workspace + wgrad_bg_slab_bytes(cin));
     int *count = list + (size_t)3 * dout * ntiles;
-    hipLaunchKernelGGL(wgrad_step_list, dim3(1), dim3(1024), 0, st, in_halo_flags, g, ntiles, list, count);
+    hipLaunchKernelGGL(wgrad_step_list, dim3(3), dim3(1024), 0, st, in_halo_flags, g, ntiles, list, count);
     MVX_LAUNCH_CHECK();
     hipLaunchKernelGGL(conv3d_wgrad4, dim3(nstrips, 3 * (cin / W4_C)), dim3(W4_THREADS), 0, st, in, dz, slabs, g, 0,
                        (const int *)list, (const int *)count, c_in);

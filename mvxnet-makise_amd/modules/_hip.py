@@ -840,11 +840,81 @@ def sink_of(param):
     return None
 
 
+class _BiasStage:
+    """Per-lane staging copy of the flat gradient bucket for BIAS gradients.  With ASYNC_WGRAD every write to a
+    .grad buffer must go through the one side stream (frames are in flight on several streams), but bias
+    gradients are finished on the frame's own stream: they are accumulated here (single writer: the lane) and
+    added to the bucket ONCE per frame on the side stream.  Two buffers alternate, so that clearing one for
+    frame f+2 only waits for the flush of frame f."""
+
+    def __init__(self, flat):
+        self.flat = flat
+        self.bufs = [torch.zeros_like(flat), torch.zeros_like(flat)]
+        self.events = [None, None]
+        self.turn = 0
+        self.base = flat.data_ptr()
+
+    def begin(self):
+        self.turn ^= 1
+        ev = self.events[self.turn]
+        if ev is not None:
+            torch.cuda.current_stream(self.flat.device).wait_event(ev)
+        self.bufs[self.turn].zero_()
+
+    def view_for(self, grad):
+        off = (grad.data_ptr() - self.base) // 4
+        n = grad.numel()
+        if off < 0 or off + n > self.flat.numel():
+            return None
+        return self.bufs[self.turn][off:off + n]
+
+    def flush(self):
+        buf = self.bufs[self.turn]
+        with _SideStream(buf) as sc:
+            self.flat.add_(buf)
+            ev = torch.cuda.Event()
+            ev.record(sc.side)
+        self.events[self.turn] = ev
+
+
+_BIAS_STAGES = {}        # (device, raw lane stream) -> _BiasStage
+_BIAS_STAGE_ON = False
+
+
+def bias_stage_begin(device, flat_grad):
+    """Start a frame on the current stream with bias gradients staged (see _BiasStage)."""
+    global _BIAS_STAGE_ON
+    key = _arena_key(device)
+    st = _BIAS_STAGES.get(key)
+    if st is None or st.flat is not flat_grad:
+        st = _BiasStage(flat_grad)
+        _BIAS_STAGES[key] = st
+    st.begin()
+    _BIAS_STAGE_ON = True
+
+
+def bias_stage_flush(device):
+    st = _BIAS_STAGES.get(_arena_key(device))
+    if st is not None:
+        st.flush()
+
+
+def bias_stage_end():
+    global _BIAS_STAGE_ON
+    _BIAS_STAGE_ON = False
+
+
 def bias_sink_of(param):
-    """Bias gradients are finished on the stream of the backward pass; with ASYNC_WGRAD every write to a
-    .grad buffer must go through the one side stream (frames may be in flight on several streams), so
-    then the bias gradient is produced as a temporary and added by ``accumulate_grad``."""
-    return None if ASYNC_WGRAD else sink_of(param)
+    """Bias gradients are finished on the stream of the backward pass.  Without ASYNC_WGRAD they go straight
+    into .grad; with it, into the lane's staging copy when the pipeline opened one (bias_stage_begin), else they
+    are produced as a temporary and added by ``accumulate_grad`` on the side stream."""
+    if not ASYNC_WGRAD:
+        return sink_of(param)
+    if _BIAS_STAGE_ON and GRAD_SINK and param is not None and param.grad is not None:
+        st = _BIAS_STAGES.get(_arena_key(param.device))
+        if st is not None:
+            return st.view_for(param.grad)
+    return None
 
 
 def accumulate_grad(param, g):

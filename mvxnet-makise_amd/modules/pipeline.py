@@ -9,12 +9,14 @@ import torch
 
 import modules.config as cfg
 from modules import _hip
+from modules import tape
 
 
 import os as _os
 ASYNC_WGRAD = _os.environ.get('MVX_ASYNC_WGRAD', '1') != '0'    # weight-gradient kernels on a second stream (see modules/_hip.py)
 LANES = int(_os.environ.get('MVX_LANES', '2'))   # frames in flight: frame f runs on lane stream f % LANES (needs ASYNC_WGRAD for the
                         # single-writer gradient accumulation); 1 = all frames on the caller's stream
+TAPE = _os.environ.get('MVX_TAPE', '1') != '0'     # frames run through modules/tape.py (no autograd engine); 0 = autograd
 _LANE_STREAMS = {}
 
 
@@ -82,17 +84,28 @@ def train_step_frames(model, batch, grad_mid, imsize):
             model.prepack()
             for st in lanes:
                 st.wait_stream(main)             # voxelization, maps, packed weights, zeroed gradients
+        # flat gradient bucket (modules/parallel.py GradBucket) -> per-lane staging of the bias gradients
+        some = next((p for p in model.parameters() if p.requires_grad and p.grad is not None), None)
+        flat = some.grad._base if (some is not None and ASYNC_WGRAD) else None
         for f, (voxels, idx) in enumerate(frames):
             with torch.cuda.stream(lanes[f % len(lanes)]):
                 _hip.arena_begin(dev)
-                mid = model.middle(voxels, batch.fpn_levels[f], idx, [None], imsize, prepared=prepared[f],
-                                   status_sink=statuses)
-                mid.backward(grad_mid)
+                if flat is not None:
+                    _hip.bias_stage_begin(dev, flat)
+                if TAPE:
+                    tape.middle_train(model, voxels, batch.fpn_levels[f], idx, imsize, prepared[f], statuses, grad_mid)
+                else:
+                    mid = model.middle(voxels, batch.fpn_levels[f], idx, [None], imsize, prepared=prepared[f],
+                                       status_sink=statuses)
+                    mid.backward(grad_mid)
+                if flat is not None:
+                    _hip.bias_stage_flush(dev)
             nvox.append(voxels.shape[1])
     finally:
         _hip.GRAD_SINK = old_sink
         _hip.ASYNC_WGRAD = old_async
         _hip.arena_end()
+        _hip.bias_stage_end()
         for st in lanes:
             if st is not main:
                 main.wait_stream(st)

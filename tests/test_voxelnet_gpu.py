@@ -208,10 +208,14 @@ def test_reindex_layout_and_state_dict_keys(small_cfg):
     assert float(r.abs().sum()) == pytest.approx(float(x.abs().sum()), rel=1e-5)
 
 
-def test_pipeline_gradient_sink_and_arena_match_plain_autograd(golden):
+@pytest.mark.parametrize('use_tape', [True, False])
+def test_pipeline_gradient_sink_and_arena_match_plain_autograd(golden, use_tape):
     """modules.pipeline.train_step_frames (direct accumulation into .grad, one accumulator fill per
-    frame) gives the same gradients as plain autograd on the same frames."""
+    frame; with use_tape the straight-line executor of modules/tape.py instead of the autograd engine)
+    gives the same gradients as plain autograd on the same frames."""
     import modules.config as cfg
+    import modules.pipeline as pipeline_mod
+    old_tape, pipeline_mod.TAPE = pipeline_mod.TAPE, use_tape
     from MVXNet import MVXNet
     from modules import parallel
     from modules.pipeline import FrameBatch, train_step_frames, voxelize_batch
@@ -247,5 +251,6 @@ def test_pipeline_gradient_sink_and_arena_match_plain_autograd(golden):
             if k in got:
                 assert rel_err(got[k], p.grad) < 1e-5, k
     finally:
+        pipeline_mod.TAPE = old_tape
         cfg.config['voxelshape'], cfg.config['velorange'] = old, old_r
         cfg.config['voxelsize'] = [(old_r[k + 3] - old_r[k]) / old[k] for k in range(3)]
