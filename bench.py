@@ -275,8 +275,28 @@ def main():
                'ms_per_step': dt_alt / args.steps * 1e3, 'host_enqueue_ms_per_step': host_ms[-1],
                'roofline': conv_roofline(tm_alt, alt_math, run=1)}
 
+    unshared = None
+    if world == 1:
+        # The same steps with every kernel alone on the GPU (one lane, weight gradients on the main stream): what the
+        # dominant kernel does when it does not share the CUs with the other lane's frame and the side-stream wgrads.
+        import modules.pipeline as pl
+        old = (pl.LANES, pl.ASYNC_WGRAD)
+        pl.LANES, pl.ASYNC_WGRAD = 1, False
+        try:
+            _, dt_u, tm_u = timed_run(1, 2)
+        finally:
+            pl.LANES, pl.ASYNC_WGRAD = old
+        r = conv_roofline(tm_u, main_math, run=len(exec_stages) - 1)
+        unshared = {'achieved': r['achieved'], 'frac': r['frac'], 'avg_launch_ms': r['avg_launch_ms'],
+                    'frames_per_s': frames_total * 2 / dt_u,
+                    'note': 'same step, MVX_LANES=1 and weight gradients on the main stream: no kernel shares the GPU'}
+
     if rank == 0:
         roof = conv_roofline(timers, main_math)
+        roof['note'] += ('; measured while the other lane and the side-stream weight-gradient kernels share the CUs '
+                         '(see unshared / isolated)')
+        if unshared is not None:
+            roof['unshared'] = unshared
         roof['isolated'] = isolated_conv_roofline(dev, main_math)
         tpath = os.path.join(REPO, 'profiles', 'traffic.json')
         if os.path.exists(tpath) and main_math == 'f32':

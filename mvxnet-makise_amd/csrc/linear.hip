@@ -256,12 +256,37 @@ __global__ __launch_bounds__(256) void linear_wgrad(const float *__restrict__ x,
     }
 }
 
-__global__ void slab_reduce(const float *__restrict__ slabs, float *__restrict__ out, size_t per, int nslabs, int accumulate) {
+// out[e] = sum over slabs, in a FIXED order: lane l of a 16-lane group adds slabs l, l+16, ... sequentially, the 16
+// partials are combined by a butterfly (same tree every run).  Sixteen loads in flight per element instead of a
+// dependent chain of `nslabs` loads: these reductions are small (<= 100 k elements) and were pure latency.
+__global__ __launch_bounds__(256) void slab_reduce(const float *__restrict__ slabs, float *__restrict__ out, size_t per, int nslabs,
+                                                   int accumulate) {
+    const int sub = threadIdx.x & 15;
+    for (size_t e = blockIdx.x * (size_t)16 + (threadIdx.x >> 4); e < per; e += (size_t)gridDim.x * 16) {
+        float s = 0.f;
+        for (int k = sub; k < nslabs; k += 16) s += slabs[(size_t)k * per + e];
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) s += __shfl_xor(s, d, 16);
+        if (sub == 0) out[e] = accumulate ? out[e] + s : s;
+    }
+}
+
+// large outputs (split-K of a tall product): one thread per element, coalesced, few slabs
+__global__ void slab_reduce_wide(const float *__restrict__ slabs, float *__restrict__ out, size_t per, int nslabs, int accumulate) {
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < per; e += (size_t)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int k = 0; k < nslabs; ++k) s += slabs[(size_t)k * per + e];
         out[e] = accumulate ? out[e] + s : s;
     }
+}
+
+inline void launch_slab_reduce(const float *slabs, float *out, size_t total, int nslabs, int accumulate, hipStream_t st) {
+    if (total > (1u << 18))
+        hipLaunchKernelGGL(slab_reduce_wide, dim3(mvx_cdiv(total, 256) > 2048 ? 2048 : mvx_cdiv(total, 256)), dim3(256), 0, st,
+                           slabs, out, total, nslabs, accumulate);
+    else
+        hipLaunchKernelGGL(slab_reduce, dim3(mvx_cdiv(total, 16) > 8192 ? 8192 : mvx_cdiv(total, 16)), dim3(256), 0, st, slabs,
+                           out, total, nslabs, accumulate);
 }
 
 inline long long strip_rows(long long R, int N, int K) {
@@ -334,8 +359,7 @@ extern "C" int mvx_linear_forward(const float *x, int32_t ldx, const float *w, i
     if (splits > 1) {
         if (ldy == n) {
             const size_t total = (size_t)rows * n;
-            hipLaunchKernelGGL(slab_reduce, dim3(mvx_cdiv(total, 256) > 2048 ? 2048 : mvx_cdiv(total, 256)), dim3(256), 0, st,
-                               (const float *)splitk_workspace, y, total, splits, 0);
+            launch_slab_reduce((const float *)splitk_workspace, y, total, splits, 0, st);
         } else {
             return MVX_EINVAL;   // split-K needs a dense destination
         }
@@ -374,8 +398,7 @@ extern "C" int mvx_linear_wgrad(const float *x, int32_t ldx, const float *dz, in
                            (long long)rows, k, n, per);
     MVX_LAUNCH_CHECK();
     const size_t total = (size_t)n * k;
-    hipLaunchKernelGGL(slab_reduce, dim3(mvx_cdiv(total, 256) > 1024 ? 1024 : mvx_cdiv(total, 256)), dim3(256), 0, st,
-                       (const float *)workspace, dw, total, (int)strips, flags & MVX_FLAG_ACCUMULATE);
+    launch_slab_reduce((const float *)workspace, dw, total, (int)strips, flags & MVX_FLAG_ACCUMULATE, st);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
