@@ -66,9 +66,15 @@ __global__ __launch_bounds__(256) void linear_fwd(const float *__restrict__ x, i
                     wr[u] = (n0 + n < N && k0 + part * 4 < K) ? *(const float4 *)(w + (long long)(n0 + n) * ldw + k0 + part * 4)
                                                               : make_float4(0.f, 0.f, 0.f, 0.f);
                 } else {
-                    const int k = c / (BNL / 4), n4 = c % (BNL / 4);
-                    wr[u] = (k0 + k < K && n0 + n4 * 4 < N) ? *(const float4 *)(w + (long long)(k0 + k) * ldw + n0 + n4 * 4)
-                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                    // transposed weight: lanes run along n (coalesced 4-byte loads), a thread collects 4 consecutive
+                    // k of its column so that the LDS image [n][k] is written with one 16-byte store (a float4 load
+                    // along n would have to be scattered into 4 rows: 16-way bank conflicts)
+                    const int n = c % BNL, kg = c / BNL;
+                    float kk[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        kk[j] = (k0 + kg * 4 + j < K && n0 + n < N) ? w[(long long)(k0 + kg * 4 + j) * ldw + n0 + n] : 0.f;
+                    wr[u] = make_float4(kk[0], kk[1], kk[2], kk[3]);
                 }
             }
         }
@@ -86,11 +92,8 @@ __global__ __launch_bounds__(256) void linear_fwd(const float *__restrict__ x, i
                 if (!WT) {
                     *(float4 *)(s_w + (c >> 3) * PITCH + (c & 7) * 4) = wr[u];
                 } else {
-                    const int k = c / (BNL / 4), n4 = c % (BNL / 4);
-                    s_w[(n4 * 4 + 0) * PITCH + k] = wr[u].x;
-                    s_w[(n4 * 4 + 1) * PITCH + k] = wr[u].y;
-                    s_w[(n4 * 4 + 2) * PITCH + k] = wr[u].z;
-                    s_w[(n4 * 4 + 3) * PITCH + k] = wr[u].w;
+                    const int n = c % BNL, kg = c / BNL;
+                    *(float4 *)(s_w + n * PITCH + kg * 4) = wr[u];
                 }
             }
         } else {
