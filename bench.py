@@ -191,9 +191,22 @@ def main():
     imsize = [float(v) for v in cfg.imsize]            # host list: no device read-back inside the step
     frames_total = args.frames * world
 
+    from modules import pipeline as pl_mod
+    pending = [None]
+    pipelined = os.environ.get('MVX_PIPELINE_INPUT', '0') != '0'      # measured: 218 vs 249 frames/s -> off
+
     def step():
+        # input pipelining: this step consumes the batch prepared during the previous one and starts the next
+        # (same resident synthetic batch every step; every step still voxelizes once, inside the timed region)
+        ready = None
+        if pipelined:
+            if pending[0] is not None:
+                ready = pl_mod.prepare_end(pending[0], model.head)
+            pending[0] = pl_mod.prepare_begin(batch)
         bucket.zero()
-        nv, statuses = train_step_frames(model, batch, grad_mid, imsize)
+        nv, statuses = train_step_frames(model, batch, grad_mid, imsize, ready=ready)
+        if pipelined:
+            pl_mod.prepare_mid(pending[0], model.head)
         bucket.all_reduce_mean(frames_total)
         opt.step()
         pending_status.extend(statuses)

@@ -63,12 +63,97 @@ def prepare_frames(batch, head):
     return frames, prepared, status
 
 
-def train_step_frames(model, batch, grad_mid, imsize):
+# ---- input pipelining: the voxelization of step k+1 runs on its own stream while step k computes --------------
+# Output sizes are data dependent (voxel counts, real-row counts), so a step needs two host reads.  Done on the
+# main stream they drain the whole queue twice per step; done one step ahead on a dedicated stream they only
+# wait for a few small kernels that finished long ago.  A data loader handing over the next batch plays the same
+# role in training (the reference prepares its batches on CPU workers, train.py:31-44).
+_PREP_STREAMS = {}
+
+
+def _prep_stream(device):
+    if device.index not in _PREP_STREAMS:
+        _PREP_STREAMS[device.index] = torch.cuda.Stream(device=device)
+    return _PREP_STREAMS[device.index]
+
+
+_PINNED = {}
+
+
+def _pinned(tag, like, turn):
+    """Reused page-locked host buffers (allocating one per step costs more than the step's syncs did)."""
+    key = (tag, tuple(like.shape), like.dtype, turn)
+    buf = _PINNED.get(key)
+    if buf is None:
+        buf = torch.empty(like.shape, dtype=like.dtype, pin_memory=True)
+        _PINNED[key] = buf
+    return buf
+
+
+_TURN = [0]
+
+
+class PendingPrepare:
+    __slots__ = ('batch', 'res', 'counts_host', 'ev_a', 'frames', 'maps', 'nreal_host', 'ev_b', 'turn')
+
+
+def prepare_begin(batch, T=None):
+    """Phase A (enqueue only): batched voxelization of ``batch`` on the preparation stream + async read of the counts."""
+    T = cfg.samplenum if T is None else T
+    dev = batch.points6.device
+    prep = _prep_stream(dev)
+    prep.wait_stream(torch.cuda.current_stream(dev))     # memory handed back by earlier steps is free by then
+    h = PendingPrepare()
+    h.batch = batch
+    _TURN[0] ^= 1
+    h.turn = _TURN[0]
+    with torch.cuda.stream(prep):
+        h.res = _hip.voxelize(batch.points6, batch.perms, batch.n_points, cfg.velorange[0:3], cfg.voxelsize, T, 9)
+        h.counts_host = _pinned('counts', h.res.n_voxels, h.turn)
+        h.counts_host.copy_(h.res.n_voxels, non_blocking=True)
+        h.ev_a = torch.cuda.Event()
+        h.ev_a.record(prep)
+    h.frames = None
+    return h
+
+
+def prepare_mid(h, head):
+    """Phase B (enqueue only; waits for phase A's counts, which are long there): compact-row maps of every frame."""
+    h.ev_a.synchronize()
+    counts = h.counts_host.tolist()
+    dev = h.batch.points6.device
+    prep = _prep_stream(dev)
+    with torch.cuda.stream(prep):
+        h.frames = [(h.res.voxels[f, :v].unsqueeze(0), h.res.coords[f, :v]) for f, v in enumerate(counts)]
+        h.maps = [head.compact_map(v) for v, _ in h.frames]
+        nreal = torch.cat([m[2] for m in h.maps])
+        h.nreal_host = _pinned('nreal', nreal, h.turn)
+        h.nreal_host.copy_(nreal, non_blocking=True)
+        h.ev_b = torch.cuda.Event()
+        h.ev_b.record(prep)
+
+
+def prepare_end(h, head):
+    """Host side of a finished preparation: (frames, prepared, status, event the consumers must wait for)."""
+    if h.frames is None:
+        prepare_mid(h, head)
+    h.ev_b.synchronize()
+    n_real = h.nreal_host.tolist()
+    prepared = [(m[0], m[1], int(n)) for m, n in zip(h.maps, n_real)]
+    return h.frames, prepared, h.res.status, h.ev_b
+
+
+def train_step_frames(model, batch, grad_mid, imsize, ready=None):
     """Forward + backward of every frame of the batch through ``model.middle``; gradients
     accumulate in the parameters.  ``grad_mid`` is dL/d(middle output) (1,128,H,W), standing for
-    the RPN + loss that follow the hot path.  Returns (voxels per frame, list of device status words
-    to be checked by the caller once per step)."""
-    frames, prepared, status = prepare_frames(batch, model.head)
+    the RPN + loss that follow the hot path.  ``ready``: result of ``prepare_end`` for this batch (input
+    pipelining); None prepares it here.  Returns (voxels per frame, list of device status words to be
+    checked by the caller once per step)."""
+    if ready is None:
+        frames, prepared, status = prepare_frames(batch, model.head)
+        ev_ready = None
+    else:
+        frames, prepared, status, ev_ready = ready
     statuses = [status]
     nvox = []
     # gradients are accumulated over the frames of the step anyway: let the reduction kernels add them
@@ -79,6 +164,8 @@ def train_step_frames(model, batch, grad_mid, imsize):
     dev = batch.points6.device
     main = torch.cuda.current_stream(dev)
     lanes = lane_streams(dev, LANES) if (LANES > 1 and ASYNC_WGRAD) else [main]
+    if ev_ready is not None:
+        main.wait_event(ev_ready)
     try:
         if len(lanes) > 1:
             model.prepack()

@@ -241,7 +241,13 @@ def test_pipeline_gradient_sink_and_arena_match_plain_autograd(golden, use_tape)
         hot = [p for k, p in model.named_parameters() if p.requires_grad and '.rpn.' not in k]
         bucket = parallel.GradBucket(hot)
         bucket.zero()
-        train_step_frames(model, batch, G, imsize)
+        if use_tape:
+            # with the batch prepared ahead on the preparation stream (input pipelining)
+            h = pipeline_mod.prepare_begin(batch)
+            pipeline_mod.prepare_mid(h, model.head)
+            train_step_frames(model, batch, G, imsize, ready=pipeline_mod.prepare_end(h, model.head))
+        else:
+            train_step_frames(model, batch, G, imsize)
         got = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None and '.rpn.' not in k}
         bucket.zero()
         frames, _ = voxelize_batch(batch)

@@ -24,9 +24,21 @@ grad_mid = torch.randn((1, 128, cfg.voxelshape[0], cfg.voxelshape[1]), device=de
 imsize = [float(v) for v in cfg.imsize]
 
 
+from modules import pipeline as pl_mod
+pending = [None]
+PIPE = os.environ.get('MVX_PIPELINE_INPUT', '0') != '0'
+
+
 def step():
+    ready = None
+    if PIPE:
+        if pending[0] is not None:
+            ready = pl_mod.prepare_end(pending[0], model.head)
+        pending[0] = pl_mod.prepare_begin(batch)
     bucket.zero()
-    train_step_frames(model, batch, grad_mid, imsize)
+    train_step_frames(model, batch, grad_mid, imsize, ready=ready)
+    if PIPE:
+        pl_mod.prepare_mid(pending[0], model.head)
     bucket.all_reduce_mean(4)
     opt.step()
 
