@@ -23,6 +23,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BM = 128, BK = 32, PITCH = BK + 4;
 
 template <bool WT, int NT, bool VEC>
@@ -37,8 +38,9 @@ __global__ __launch_bounds__(256) void linear_fwd(const float *__restrict__ x, i
     __shared__ __attribute__((aligned(16))) float s_w[BNL * PITCH];
     __shared__ float s_red[4][2 * BNL];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const long long r0 = (long long)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BNL;
+    // column block fastest: the workgroups that share an x tile run together and read it from HBM once
+    const long long r0 = (long long)blockIdx.y * BM;
+    const int n0 = blockIdx.x * BNL;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -48,52 +50,69 @@ __global__ __launch_bounds__(256) void linear_fwd(const float *__restrict__ x, i
     const int a_base = (wv * 32 + li) * PITCH + 4 * lh;
     const int b_base = li * PITCH + 4 * lh;
 
-    float4 xr[XV], wr[WV];
-    auto load_tiles = [&](int k0) {
+    // Prefetch registers.  Loads are UNCONDITIONAL from a clamped (always valid) address: rows >= R and columns
+    // >= N only feed outputs that the epilogue drops, so whatever is loaded there is harmless; only the K tail
+    // (k >= K inside the last chunk) must be zero, and that is done when the LAST chunk is written to LDS.
+    // (A conditional load merged with a zero made the compiler wait for the load right where it was issued --
+    // s_waitcnt vmcnt(0) inside the prefetch -- exposing the global latency once per chunk.)
+    f32x4 xr[XV], wr[WV];
+    auto load_tiles = [&](int k0) __attribute__((always_inline)) {
         if (VEC) {
 #pragma unroll
             for (int u = 0; u < XV; ++u) {
                 const int c = tid + 256 * u, r = c >> 3, part = c & 7;
                 const long long gr = r0 + r;
-                xr[u] = (gr < R && k0 + part * 4 < K) ? *(const float4 *)(x + gr * ldx + k0 + part * 4)
-                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+                const bool ok = gr < R && k0 + part * 4 < K;
+                xr[u] = *(const f32x4 *)(ok ? x + gr * ldx + k0 + part * 4 : x);
             }
 #pragma unroll
             for (int u = 0; u < WV; ++u) {
                 const int c = tid + 256 * u;
                 if (!WT) {
                     const int n = c >> 3, part = c & 7;
-                    wr[u] = (n0 + n < N && k0 + part * 4 < K) ? *(const float4 *)(w + (long long)(n0 + n) * ldw + k0 + part * 4)
-                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const bool ok = n0 + n < N && k0 + part * 4 < K;
+                    wr[u] = *(const f32x4 *)(ok ? w + (long long)(n0 + n) * ldw + k0 + part * 4 : w);
                 } else {
                     // transposed weight: lanes run along n (coalesced 4-byte loads), a thread collects 4 consecutive
                     // k of its column so that the LDS image [n][k] is written with one 16-byte store (a float4 load
                     // along n would have to be scattered into 4 rows: 16-way bank conflicts)
                     const int n = c % BNL, kg = c / BNL;
-                    float kk[4];
+                    f32x4 kk;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        kk[j] = (k0 + kg * 4 + j < K && n0 + n < N) ? w[(long long)(k0 + kg * 4 + j) * ldw + n0 + n] : 0.f;
-                    wr[u] = make_float4(kk[0], kk[1], kk[2], kk[3]);
+                    for (int j = 0; j < 4; ++j) {
+                        const bool ok = k0 + kg * 4 + j < K && n0 + n < N;
+                        kk[j] = *(ok ? w + (long long)(k0 + kg * 4 + j) * ldw + n0 + n : w);
+                    }
+                    wr[u] = kk;
                 }
             }
         }
     };
-    auto store_tiles = [&](int k0) {
+    auto store_tiles = [&](int k0) __attribute__((always_inline)) {
         if (VEC) {
+            const bool tail = k0 + BK > K;            // block-uniform: only the last chunk can hold k >= K
 #pragma unroll
             for (int u = 0; u < XV; ++u) {
                 const int c = tid + 256 * u;
-                *(float4 *)(s_x + (c >> 3) * PITCH + (c & 7) * 4) = xr[u];
+                f32x4 v = xr[u];
+                if (tail && k0 + (c & 7) * 4 >= K) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                *(f32x4 *)(s_x + (c >> 3) * PITCH + (c & 7) * 4) = v;
             }
 #pragma unroll
             for (int u = 0; u < WV; ++u) {
                 const int c = tid + 256 * u;
+                f32x4 v = wr[u];
                 if (!WT) {
-                    *(float4 *)(s_w + (c >> 3) * PITCH + (c & 7) * 4) = wr[u];
+                    if (tail && k0 + (c & 7) * 4 >= K) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    *(f32x4 *)(s_w + (c >> 3) * PITCH + (c & 7) * 4) = v;
                 } else {
                     const int n = c % BNL, kg = c / BNL;
-                    *(float4 *)(s_w + n * PITCH + kg * 4) = wr[u];
+                    if (tail) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (k0 + kg * 4 + j >= K) v[j] = 0.f;
+                    }
+                    *(f32x4 *)(s_w + n * PITCH + kg * 4) = v;
                 }
             }
         } else {
@@ -169,7 +188,7 @@ __global__ __launch_bounds__(256) void linear_fwd(const float *__restrict__ x, i
             const int which = e / BNL, c = e % BNL;
             if (n0 + c < N) {
                 const double t = (double)s_red[0][e] + (double)s_red[1][e] + (double)s_red[2][e] + (double)s_red[3][e];
-                atomicAdd(stats + ((size_t)(blockIdx.x % MVX_REP) * 2 + which) * N + n0 + c, t);
+                atomicAdd(stats + ((size_t)(blockIdx.y % MVX_REP) * 2 + which) * N + n0 + c, t);
             }
         }
     }
@@ -346,7 +365,7 @@ extern "C" int mvx_linear_forward(const float *x, int32_t ldx, const float *w, i
         ydst = (float *)splitk_workspace;
         ld_dst = n;
     }
-    const dim3 grid(mvx_cdiv(rows, BM), mvx_cdiv(n, wide ? 128 : 64), splits);
+    const dim3 grid(mvx_cdiv(n, wide ? 128 : 64), mvx_cdiv(rows, BM), splits);
 #define MVX_LAUNCH_LIN(WT, NT, VEC)                                                                               \
     hipLaunchKernelGGL((linear_fwd<WT, NT, VEC>), grid, dim3(256), 0, st, x, ldx, w, ldw, bias, ydst, ld_dst, stats, \
                        row_w, (long long)rows, k, n, relu, k_per_split)
