@@ -321,19 +321,26 @@ int mvx_vfe_compact_input_backward(const float *grad_out, int32_t feat_channels,
  *            compact row; the caller keeps one shared zero row for all padded rows
  *   status   bit0 = a sample index left the (zero-padded) map: the reference's assert, Pipe.py:71
  * mvx_row_compact_map: row_map[r] = rank of real row r among real rows, -1 for padded rows;
- *            rows_sel (optional) i32 [rows]: inverse list; n_real i32 [1] on the device.
+ *            rows_sel (optional) i32 [rows]: inverse list; n_real i32 [1] on the device.  Padding rows
+ *            (x == y == z == 0) get their channels 3.. zeroed IN PLACE here (Pipe.py:54-59), so that
+ * mvx_feature_sample_rows, the compact sampler, only visits the n_real real rows (dense row rows_sel[j]
+ *            -> out row j); same arithmetic and status as mvx_feature_sample.
  * mvx_expand_rows / _backward: compact [n][C] <-> dense [rows][C]; every padded row reads the
  *            shared row `pad_row`, whose gradient is the sum over the padded rows (C <= 256;
  *            scratch f64 [C]).
  */
 size_t mvx_row_compact_workspace_bytes(int64_t rows);
-int mvx_row_compact_map(const float *voxels, int32_t vox_channels, int64_t rows, int32_t *row_map,
+int mvx_row_compact_map(float *voxels, int32_t vox_channels, int64_t rows, int32_t *row_map,
                         int32_t *rows_sel, int32_t *n_real, void *workspace, size_t workspace_bytes,
                         void *stream);
 int mvx_feature_sample(float *voxels, int32_t vox_channels, int64_t rows, const int32_t *row_map,
                        const float *const *feats_host, const int32_t *feat_hw_host, int32_t n_levels,
                        int32_t channels, float imsize_h, float imsize_w, float eps, float *out,
                        int32_t *status, void *stream);
+int mvx_feature_sample_rows(const float *voxels, int32_t vox_channels, const int32_t *rows_sel, int32_t n_real,
+                            const float *const *feats_host, const int32_t *feat_hw_host, int32_t n_levels,
+                            int32_t channels, float imsize_h, float imsize_w, float eps, float *out,
+                            int32_t *status, void *stream);
 int mvx_expand_rows(const float *compact, const int32_t *row_map, int32_t pad_row, float *out,
                     int64_t rows, int32_t channels, void *stream);
 int mvx_expand_rows_backward(const float *grad_out, const int32_t *row_map, int32_t pad_row,

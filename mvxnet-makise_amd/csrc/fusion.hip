@@ -53,9 +53,9 @@ __global__ __launch_bounds__(1024) void map_scan(int *__restrict__ bcount, int n
     if (threadIdx.x == 0) *n_real = base;
 }
 
-__global__ __launch_bounds__(256) void map_write(const float *__restrict__ vox, int vc, long long R,
+__global__ __launch_bounds__(256) void map_write(float *__restrict__ vox, int vc, long long R,
                                                  const int *__restrict__ boff, int *__restrict__ row_map,
-                                                 int *__restrict__ rows_sel) {
+                                                 int *__restrict__ rows_sel, int zero_padding) {
     __shared__ int s[4];
     const long long r = blockIdx.x * 256ll + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -69,6 +69,10 @@ __global__ __launch_bounds__(256) void map_write(const float *__restrict__ vox, 
     if (r < R) {
         row_map[r] = flag ? off : -1;
         if (flag && rows_sel) rows_sel[off] = (int)r;
+        // padding rows: the reference zeroes all their channels in place (Pipe.py:54-59); done here, where every
+        // row is visited anyway, so that the compact sampler only has to touch the real rows
+        if (!flag && zero_padding)
+            for (int c = 3; c < vc; ++c) vox[r * vc + c] = 0.f;
     }
 }
 
@@ -127,6 +131,46 @@ __global__ __launch_bounds__(256) void feature_sample(float *__restrict__ vox, i
     }
 }
 
+// Compact form: one wave per (REAL row j, level); rows_sel[j] is the dense row, the output row is j.  The padding
+// rows are not visited at all (88 % of the dense rows on a lidar frame); same arithmetic as feature_sample.
+__global__ __launch_bounds__(256) void feature_sample_rows(const float *__restrict__ vox, int vc, const int *__restrict__ rows_sel,
+                                                           int n_real, Levels L, int C, float im_h, float im_w, float eps,
+                                                           float *__restrict__ out, int *__restrict__ status) {
+    const long long wave = (blockIdx.x * 256ll + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const long long j = wave / L.n;
+    const int lv = (int)(wave % L.n);
+    if (j >= n_real) return;
+    const float *v = vox + (size_t)rows_sel[j] * vc;
+    const int ldo = L.n * C;
+    const int H = L.h[lv], W = L.w[lv];
+    const float qy = v[vc - 2] / (im_h / (float)H) - eps;
+    const float qx = v[vc - 1] / (im_w / (float)W) - eps;
+    const long long iy = (long long)qy, ix = (long long)qx;
+    const float fy = qy - (float)iy, fx = qx - (float)ix;
+    if (iy < 0 || ix < 0 || iy + 1 > H || ix + 1 > W) {
+        if (lane == 0) atomicOr(status, 1);
+        for (int c = lane * 4; c < C; c += 256) *(float4 *)(out + j * ldo + lv * C + c) = make_float4(0, 0, 0, 0);
+        return;
+    }
+    const float *F = L.feat[lv];
+    const bool y0 = iy < H, y1 = iy + 1 < H, x0 = ix < W, x1 = ix + 1 < W;
+    const float xi = fy, yi = fx;
+    const float xi_ = 1.f - xi, yi_ = 1.f - yi;
+    for (int c = lane * 4; c < C; c += 256) {
+        const float4 z = make_float4(0, 0, 0, 0);
+        const float4 f00 = (y0 && x0) ? *(const float4 *)(F + ((size_t)iy * W + ix) * C + c) : z;
+        const float4 f10 = (y1 && x0) ? *(const float4 *)(F + ((size_t)(iy + 1) * W + ix) * C + c) : z;
+        const float4 f01 = (y0 && x1) ? *(const float4 *)(F + ((size_t)iy * W + ix + 1) * C + c) : z;
+        const float4 f11 = (y1 && x1) ? *(const float4 *)(F + ((size_t)(iy + 1) * W + ix + 1) * C + c) : z;
+        float4 o;
+#define MVX_TAP(m) o.m = (((f00.m * xi) * yi + (f10.m * xi_) * yi) + (f01.m * xi) * yi_) + (f11.m * xi_) * yi_;
+        MVX_TAP(x) MVX_TAP(y) MVX_TAP(z) MVX_TAP(w)
+#undef MVX_TAP
+        *(float4 *)(out + j * ldo + lv * C + c) = o;
+    }
+}
+
 // ---- compact rows -> dense rows and back ----------------------------------------------------------
 __global__ void expand_rows(const float *__restrict__ compact, const int *__restrict__ row_map, int pad_row,
                             float *__restrict__ out, long long R, int C) {
@@ -174,7 +218,7 @@ extern "C" size_t mvx_row_compact_workspace_bytes(int64_t rows) {
     return (size_t)(mvx_cdiv(rows > 0 ? rows : 1, 256) + 1) * sizeof(int32_t);
 }
 
-extern "C" int mvx_row_compact_map(const float *voxels, int32_t vox_channels, int64_t rows, int32_t *row_map,
+extern "C" int mvx_row_compact_map(float *voxels, int32_t vox_channels, int64_t rows, int32_t *row_map,
                                    int32_t *rows_sel, int32_t *n_real, void *workspace, size_t workspace_bytes,
                                    void *stream) {
     MVX_CHECK_ARG(voxels && row_map && n_real && workspace && vox_channels >= 3 && rows >= 0);
@@ -191,7 +235,7 @@ extern "C" int mvx_row_compact_map(const float *voxels, int32_t vox_channels, in
     hipLaunchKernelGGL(map_scan, dim3(1), dim3(1024), 0, st, bc, (int)nb, n_real);
     MVX_LAUNCH_CHECK();
     hipLaunchKernelGGL(map_write, dim3(nb), dim3(256), 0, st, voxels, vox_channels, (long long)rows, (const int *)bc,
-                       row_map, rows_sel);
+                       row_map, rows_sel, 1);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -215,6 +259,29 @@ extern "C" int mvx_feature_sample(float *voxels, int32_t vox_channels, int64_t r
     const long long waves = (long long)rows * n_levels;
     hipLaunchKernelGGL(feature_sample, dim3(mvx_cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, voxels, vox_channels,
                        (long long)rows, row_map, L, channels, imsize_h, imsize_w, eps, out, status);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+extern "C" int mvx_feature_sample_rows(const float *voxels, int32_t vox_channels, const int32_t *rows_sel, int32_t n_real,
+                                       const float *const *feats_host, const int32_t *feat_hw_host, int32_t n_levels,
+                                       int32_t channels, float imsize_h, float imsize_w, float eps, float *out,
+                                       int32_t *status, void *stream) {
+    MVX_CHECK_ARG(voxels && rows_sel && feats_host && feat_hw_host && out && status && n_real >= 0);
+    MVX_CHECK_ARG(vox_channels >= 5 && vox_channels <= 64 && n_levels >= 1 && n_levels <= MAX_LEVELS);
+    MVX_CHECK_ARG(channels > 0 && channels % 4 == 0);
+    if (n_real == 0) return MVX_OK;
+    Levels L;
+    L.n = n_levels;
+    for (int k = 0; k < MAX_LEVELS; ++k) {
+        L.feat[k] = k < n_levels ? feats_host[k] : nullptr;
+        L.h[k] = k < n_levels ? feat_hw_host[2 * k] : 0;
+        L.w[k] = k < n_levels ? feat_hw_host[2 * k + 1] : 0;
+        if (k < n_levels) MVX_CHECK_ARG(L.feat[k] && L.h[k] > 0 && L.w[k] > 0);
+    }
+    const long long waves = (long long)n_real * n_levels;
+    hipLaunchKernelGGL(feature_sample_rows, dim3(mvx_cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, voxels, vox_channels,
+                       rows_sel, n_real, L, channels, imsize_h, imsize_w, eps, out, status);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

@@ -60,6 +60,7 @@ PROTOTYPES = {
     'mvx_row_compact_workspace_bytes': (_sz, [_i64]),
     'mvx_row_compact_map': (_i32, [_p, _i32, _i64, _p, _p, _p, _p, _sz, _p]),
     'mvx_feature_sample': (_i32, [_p, _i32, _i64, _p, _p, _p, _i32, _i32, _f32, _f32, _f32, _p, _p, _p]),
+    'mvx_feature_sample_rows': (_i32, [_p, _i32, _p, _i32, _p, _p, _i32, _i32, _f32, _f32, _f32, _p, _p, _p]),
     'mvx_expand_rows': (_i32, [_p, _p, _i32, _p, _i64, _i32, _p]),
     'mvx_expand_rows_backward': (_i32, [_p, _p, _i32, _p, _p, _i64, _i32, _p]),
     'mvx_conv3d_packed_weight_bytes': (_sz, [_i32, _i32]),

@@ -717,8 +717,9 @@ def row_compact_map(vox2d):
     return row_map, rows_sel, n_real
 
 
-def feature_sample(vox2d, feats_cl, imsize_hw, eps, out, row_map=None):
-    """vox2d (R, vc) modified in place; feats_cl: list of channels-last (H, W, C) maps."""
+def feature_sample(vox2d, feats_cl, imsize_hw, eps, out, row_map=None, rows_sel=None, n_real=None):
+    """vox2d (R, vc) modified in place; feats_cl: list of channels-last (H, W, C) maps.  With ``rows_sel`` and
+    ``n_real`` (from row_compact_map, which already zeroed the padding rows) only the real rows are visited."""
     import ctypes
     R, vc = vox2d.shape
     L = len(feats_cl)
@@ -730,6 +731,12 @@ def feature_sample(vox2d, feats_cl, imsize_hw, eps, out, row_map=None):
         assert f.is_contiguous() and f.dtype == torch.float32 and f.shape[2] == C
     # algorithmic bytes: 4 taps x L levels x C floats gathered + L*C floats written per sampled row, + the voxel rows
     nrows = out.shape[0]
+    if rows_sel is not None and n_real is not None:
+        with _timed_bytes('feature_sample', nrows * L * C * 4 * 5 + int(n_real) * vc * 4):
+            X.check(X.lib.mvx_feature_sample_rows(X.ptr(vox2d), vc, X.ptr(rows_sel), int(n_real), ptrs, hw, L, C,
+                                                  float(imsize_hw[0]), float(imsize_hw[1]), float(eps), X.ptr(out),
+                                                  X.ptr(status), X.stream()), 'mvx_feature_sample_rows')
+        return status
     with _timed_bytes('feature_sample', nrows * L * C * 4 * 5 + R * vc * 4):
         X.check(X.lib.mvx_feature_sample(X.ptr(vox2d), vc, R, X.ptr(row_map), ptrs, hw, L, C,
                                          float(imsize_hw[0]), float(imsize_hw[1]), float(eps), X.ptr(out),

@@ -49,7 +49,7 @@ class ImageHead(nn.Module):
         width = levels[0].shape[2] * len(levels)
         compact = torch.empty((nr + 1, width), dtype=torch.float32, device=v.device)
         compact[nr].zero_()                                # the shared padded row (Pipe.py:80)
-        status = _hip.feature_sample(vox2d, levels, (float(hw[0]), float(hw[1])), cfg.eps, compact, row_map)
+        status = _hip.feature_sample(vox2d, levels, (float(hw[0]), float(hw[1])), cfg.eps, compact, row_map, rows_sel=rows_sel, n_real=nr)
         row_w = torch.ones((nr + 1,), dtype=torch.float32, device=v.device)
         row_w[nr] = float(rows - nr)
         y = self.fusion.forward_rows(compact, row_w, rows)

@@ -52,7 +52,7 @@ def middle_forward(model, voxels, fpn_levels, idx, imsize, prepared, status_sink
     width = levels[0].shape[2] * len(levels)
     compact = torch.empty((nr + 1, width), dtype=torch.float32, device=v.device)
     compact[nr].zero_()
-    status = _hip.feature_sample(vox2d, levels, (float(imsize[0]), float(imsize[1])), cfg.eps, compact, row_map)
+    status = _hip.feature_sample(vox2d, levels, (float(imsize[0]), float(imsize[1])), cfg.eps, compact, row_map, rows_sel=rows_sel, n_real=nr)
     status_sink.append(status)
     row_w = torch.ones((nr + 1,), dtype=torch.float32, device=v.device)
     row_w[nr] = float(rows - nr)
