@@ -193,6 +193,7 @@ def main():
 
     from modules import pipeline as pl_mod
     pending = [None]
+    step_events = []
     pipelined = os.environ.get('MVX_PIPELINE_INPUT', '0') != '0'      # measured: 218 vs 249 frames/s -> off
 
     def step():
@@ -200,6 +201,10 @@ def main():
         # (same resident synthetic batch every step; every step still voxelizes once, inside the timed region)
         ready = None
         if pipelined:
+            # bounded run-ahead: never more than one step of launches in flight (a full HIP queue blocks the host
+            # inside launches for milliseconds at a time)
+            if len(step_events) >= 2:
+                step_events.pop(0).synchronize()
             if pending[0] is not None:
                 ready = pl_mod.prepare_end(pending[0], model.head)
             pending[0] = pl_mod.prepare_begin(batch)
@@ -210,6 +215,10 @@ def main():
         bucket.all_reduce_mean(frames_total)
         opt.step()
         pending_status.extend(statuses)
+        if pipelined:
+            ev = torch.cuda.Event()
+            ev.record()
+            step_events.append(ev)
         return nv
 
     pending_status = []
