@@ -260,3 +260,60 @@ def test_pipeline_gradient_sink_and_arena_match_plain_autograd(golden, use_tape)
         pipeline_mod.TAPE = old_tape
         cfg.config['voxelshape'], cfg.config['velorange'] = old, old_r
         cfg.config['voxelsize'] = [(old_r[k + 3] - old_r[k]) / old[k] for k in range(3)]
+
+
+def test_full_size_background_rewrite_equals_dense_cml():
+    """The CML stack at the full 10x352x400 grid with `convbackground` on and off: same BEV map, same gradients
+    for every CML parameter and for the voxel rows -- on a voxel set that includes image corners, border
+    rows/columns and the first/last depth plane (where the zero padding, not the background, is seen)."""
+    import modules.config as cfg
+    from modules.voxelnet import VoxelNet
+    gen = torch.Generator().manual_seed(21)
+    D, H, W = cfg.voxelshape[2], cfg.voxelshape[0], cfg.voxelshape[1]
+    V = 3000
+    ix = torch.randint(0, H, (V,), generator=gen)
+    iy = torch.randint(0, W, (V,), generator=gen)
+    iz = torch.randint(0, D, (V,), generator=gen)
+    # clusters (like lidar returns) + explicit border / corner voxels
+    ix[:2000] = (ix[:2000] % 60) + 100
+    iy[:2000] = (iy[:2000] % 80) + 40
+    special = [(0, 0, 0), (0, W - 1, D - 1), (H - 1, 0, 0), (H - 1, W - 1, D - 1), (0, 200, 3), (H - 1, 17, 9), (123, 0, 5),
+               (77, W - 1, 0)]
+    for k, (a, b, c) in enumerate(special):
+        ix[2000 + k], iy[2000 + k], iz[2000 + k] = a, b, c
+    key = (iz * H + ix) * W + iy
+    keep = torch.zeros(V, dtype=torch.bool)
+    seen = set()
+    for v in range(V):
+        kk = int(key[v])
+        if kk not in seen:
+            seen.add(kk)
+            keep[v] = True
+    ix, iy, iz = ix[keep], iy[keep], iz[keep]
+    V = int(keep.sum())
+    idx = torch.stack([torch.zeros(V, dtype=torch.long), ix, iy, iz], 1).to(DEV)
+    feat0 = torch.randn(V, 128, generator=gen).to(DEV)
+    G = (torch.randn(1, 128, H, W, generator=gen) * 1e-2).to(DEV)
+    torch.manual_seed(5)
+    net = VoxelNet().to(DEV)
+    old = cfg.config.get('convbackground', True)
+    res = {}
+    try:
+        for mode in (True, False):
+            cfg.config['convbackground'] = mode
+            net.zero_grad()
+            feat = feat0.clone().requires_grad_(True)
+            x = net.cml.conv1.forward_voxels(feat, idx, (D, H, W))
+            x = net.cml.conv3(net.cml.conv2(x))
+            from modules.voxelnet.VoxelNet import BEVFunction
+            mid = BEVFunction.apply(x)
+            (mid * G).sum().backward()
+            res[mode] = (mid.detach().clone(), feat.grad.clone(),
+                         {k: p.grad.clone() for k, p in net.cml.named_parameters() if p.grad is not None})
+    finally:
+        cfg.config['convbackground'] = old
+    assert rel_err(res[True][0], res[False][0]) < 1e-5
+    assert rel_err(res[True][1], res[False][1]) < 2e-4
+    for k in res[False][2]:
+        tol = 5e-3 if k.endswith('bias') else 5e-4        # bias gradients in front of a BatchNorm are pure cancellation
+        assert rel_err(res[True][2][k], res[False][2][k]) < tol, (k, rel_err(res[True][2][k], res[False][2][k]))
