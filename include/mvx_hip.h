@@ -205,7 +205,11 @@ int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int32_t din, i
  *                         constant; background SITES (out_mask == 0) inside computed tiles get it too.
  *                         exec_stages (optional) u64 [1] += executed (depth tap, 32-channel) stages of 4.7 MFLOP
  *   mvx_plane_tap_sums    tap_sums f32 [planes][9][channels]: for each in-plane tap (a,b) the sum of dz over the sites
- *                         whose tap source (y+a-1, x+b-1) lies inside the image (f64 accumulation)
+ *                         whose tap source (y+a-1, x+b-1) lies inside the image (f64 accumulation).  With tile_flags
+ *                         + inactive_sums f32 [planes][channels] (both or neither): dz is only defined on the flagged
+ *                         tiles (which must include every border tile); the rest of each plane contributes inactive_sums
+ *   mvx_tile_dilate_flags out[d][t] = self[d][t] | any 3x3 tile neighbour flagged in an input plane tied to d by a depth
+ *                         tap: the tiles of a layer's output gradient that a restricted backward of its consumer reads
  *   mvx_conv3d_wgrad_bg   dw = sum (in - c_in) (x) dz over the tiles with a set halo flag + c_in (x) tap_sums, equal to
  *                         mvx_conv3d_wgrad
  *   mvx_conv3d_input_grad_sums  plane_grad_sums f32 [din][cin] = per input plane, the sum over all its sites of the
@@ -214,7 +218,8 @@ int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int32_t din, i
  *                         other tiles of dx are left untouched
  *   mvx_bn_relu_backward_tiles  mvx_bn_relu_backward of a layer whose output is the background (y_bg, c_bg per plane)
  *                         outside the flagged tiles and whose incoming gradient dyhat is only valid ON them:
- *                         the batch sums take the rest from plane_grad_sums; dz is written on the flagged tiles only
+ *                         the batch sums take the rest from plane_grad_sums; dz is written on the flagged tiles only;
+ *                         dz_inactive_sums (optional) f32 [planes][channels] = sum of dz over the other tiles (closed form)
  */
 int mvx_activity_dilate(const void *src, int32_t src_is_index, int32_t din, int32_t dout, int32_t h, int32_t w,
                         int32_t stride_d, int32_t pad_d, int32_t mark_border, uint8_t *dst_mask,
@@ -234,8 +239,11 @@ int mvx_conv3d_wgrad_bg(const float *in, const float *dz, float *dw, int32_t din
                         const int32_t *in_halo_flags, const float *c_in, const float *tap_sums, void *workspace,
                         size_t workspace_bytes, void *stream);
 size_t mvx_plane_tap_sums_workspace_bytes(int32_t planes, int32_t channels);
-int mvx_plane_tap_sums(const float *dz, int32_t planes, int32_t h, int32_t w, int32_t channels, float *tap_sums,
-                       void *workspace, size_t workspace_bytes, void *stream);
+int mvx_plane_tap_sums(const float *dz, int32_t planes, int32_t h, int32_t w, int32_t channels,
+                       const int32_t *tile_flags, const float *inactive_sums, float *tap_sums, void *workspace,
+                       size_t workspace_bytes, void *stream);
+int mvx_tile_dilate_flags(const int32_t *in_tile_flags, const int32_t *self_tile_flags, int32_t din, int32_t dout,
+                          int32_t h, int32_t w, int32_t stride_d, int32_t pad_d, int32_t *out_tile_flags, void *stream);
 int mvx_conv3d_input_grad_sums(const float *w, const float *tap_sums, int32_t din, int32_t dout, int32_t cin,
                                int32_t cout, int32_t stride_d, int32_t pad_d, float *plane_grad_sums, void *stream);
 int mvx_conv3d_dgrad_tiles(const float *dz, const float *wpk_dgrad, float *dx, int32_t din, int32_t dout, int32_t h,
@@ -245,7 +253,8 @@ size_t mvx_bn_relu_backward_tiles_workspace_bytes(int32_t planes, int32_t h, int
 int mvx_bn_relu_backward_tiles(const float *dyhat, const float *y, const float *mean_inv, const float *c_bg,
                                const float *y_bg, const float *plane_grad_sums, const int32_t *tile_flags,
                                int32_t planes, int32_t h, int32_t w, int32_t channels, float *dz, float *dbias,
-                               int32_t flags, void *workspace, size_t workspace_bytes, void *stream);
+                               float *dz_inactive_sums, int32_t flags, void *workspace, size_t workspace_bytes,
+                               void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Row-wise fully connected layer on the matrix cores (fp32 MFMA).  Replaces the nn.Linear /

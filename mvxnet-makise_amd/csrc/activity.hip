@@ -66,6 +66,28 @@ __global__ __launch_bounds__(256) void activity_halo_flags(const unsigned char *
     }
 }
 
+// out[d][t] = self[d][t] | any 3x3 tile neighbour flagged in a plane of `in` that is tied to plane d by a depth tap:
+// the tiles of this layer's OUTPUT GRADIENT that the consumers of its restricted backward read (the halo of a
+// flagged input tile reaches into all 8 neighbours).  in: flags of the conv INPUT [Din], self/out: [Dout].
+__global__ void tile_dilate_flags(const int *__restrict__ in, const int *__restrict__ self, int Din, int Dout, int tiles_y,
+                                  int tiles_x, int sd, int pd, int *__restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nt = tiles_y * tiles_x;
+    if (e >= Dout * nt) return;
+    const int d = e / nt, t = e - d * nt, ty = t / tiles_x, tx = t - ty * tiles_x;
+    int on = self ? self[e] : 0;
+    for (int kd = 0; kd < 3 && !on; ++kd) {
+        const int ds = d * sd - pd + kd;
+        if (ds < 0 || ds >= Din) continue;
+        for (int a = -1; a <= 1 && !on; ++a)
+            for (int b = -1; b <= 1; ++b) {
+                const int yy = ty + a, xx = tx + b;
+                if (yy >= 0 && yy < tiles_y && xx >= 0 && xx < tiles_x) on |= in[(size_t)ds * nt + yy * tiles_x + xx];
+            }
+    }
+    out[e] = on ? 1 : 0;
+}
+
 // bg_pre[d][n] = sum over the valid depth taps of plane d and all in-plane taps / channels of
 //                W[n][c][kd][a][b] * c_in[src(d,kd)][c]            (f64 accumulation, rounded once)
 __global__ __launch_bounds__(64) void conv_background(const float *__restrict__ w, const float *__restrict__ c_in, int Din,
@@ -217,7 +239,8 @@ __global__ void bnb_finalize_ab(const double *__restrict__ sums, const float *__
 // dbias = Z1 + sum_d [y_bg[d] > 0] inv ((A[d] - P1[d]) - n_inact[d] (a + c[d] b))
 __global__ void bnb_dbias(const double *__restrict__ sums, const float *__restrict__ A, const float *__restrict__ c_bg,
                           const float *__restrict__ y_bg, const float *__restrict__ mi, const float *__restrict__ ab,
-                          const int *__restrict__ n_inact, int D, int C, float *__restrict__ dbias, int accumulate) {
+                          const int *__restrict__ n_inact, int D, int C, float *__restrict__ dbias, int accumulate,
+                          float *__restrict__ dz_inactive_sums) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= C) return;
     double z1 = 0.0;
@@ -225,12 +248,16 @@ __global__ void bnb_dbias(const double *__restrict__ sums, const float *__restri
     const double inv = (double)mi[C + n], a = (double)ab[n], b = (double)ab[C + n];
     double t = z1;
     for (int d = 0; d < D; ++d) {
-        if (!(y_bg[(size_t)d * C + n] > 0.f)) continue;
-        double p1 = 0.0;
-        for (int rep = 0; rep < BREP; ++rep) p1 += sums[((size_t)rep * (D + 2) + d) * C + n];
-        t += inv * (((double)A[(size_t)d * C + n] - p1) - (double)n_inact[d] * (a + (double)c_bg[(size_t)d * C + n] * b));
+        double s = 0.0;                              // sum of dz over the inactive tiles of plane d
+        if (y_bg[(size_t)d * C + n] > 0.f) {
+            double p1 = 0.0;
+            for (int rep = 0; rep < BREP; ++rep) p1 += sums[((size_t)rep * (D + 2) + d) * C + n];
+            s = inv * (((double)A[(size_t)d * C + n] - p1) - (double)n_inact[d] * (a + (double)c_bg[(size_t)d * C + n] * b));
+        }
+        if (dz_inactive_sums) dz_inactive_sums[(size_t)d * C + n] = (float)s;
+        t += s;
     }
-    dbias[n] = accumulate ? dbias[n] + (float)t : (float)t;
+    if (dbias) dbias[n] = accumulate ? dbias[n] + (float)t : (float)t;
 }
 
 }  // namespace
@@ -244,7 +271,8 @@ extern "C" size_t mvx_bn_relu_backward_tiles_workspace_bytes(int32_t planes, int
 extern "C" int mvx_bn_relu_backward_tiles(const float *dyhat, const float *y, const float *mean_inv, const float *c_bg,
                                           const float *y_bg, const float *plane_grad_sums, const int32_t *tile_flags,
                                           int32_t planes, int32_t h, int32_t w, int32_t channels, float *dz, float *dbias,
-                                          int32_t flags, void *workspace, size_t workspace_bytes, void *stream) {
+                                          float *dz_inactive_sums, int32_t flags, void *workspace,
+                                          size_t workspace_bytes, void *stream) {
     MVX_CHECK_ARG(dyhat && y && mean_inv && c_bg && y_bg && plane_grad_sums && tile_flags && dz && workspace);
     MVX_CHECK_ARG(planes > 0 && planes <= 16 && h > 0 && w > 0 && channels > 0 && channels % 4 == 0 && 256 % (channels / 4) == 0);
     MVX_CHECK_ARG(workspace_bytes >= mvx_bn_relu_backward_tiles_workspace_bytes(planes, h, w, channels));
@@ -269,10 +297,10 @@ extern "C" int mvx_bn_relu_backward_tiles(const float *dyhat, const float *y, co
     hipLaunchKernelGGL(bnb_tiles, dim3(grid), dim3(256), 0, st, dyhat, y, mean_inv, c_bg, (const float *)ab, (const int *)list,
                        (const int *)n_act, planes, h, w, channels, ntiles, 1, dz, sums);
     MVX_LAUNCH_CHECK();
-    if (dbias) {
+    if (dbias || dz_inactive_sums) {
         hipLaunchKernelGGL(bnb_dbias, dim3(mvx_cdiv(channels, 64)), dim3(64), 0, st, (const double *)sums, plane_grad_sums, c_bg,
                            y_bg, mean_inv, (const float *)ab, (const int *)n_inact, planes, channels, dbias,
-                           flags & MVX_FLAG_ACCUMULATE);
+                           flags & MVX_FLAG_ACCUMULATE, dz_inactive_sums);
         MVX_LAUNCH_CHECK();
     }
     return MVX_OK;
@@ -294,6 +322,17 @@ extern "C" int mvx_activity_dilate(const void *src, int32_t src_is_index, int32_
                            (const unsigned char *)dst_mask, dout, h, w, dst_halo_flags, dst_tile_flags);
         MVX_LAUNCH_CHECK();
     }
+    return MVX_OK;
+}
+
+extern "C" int mvx_tile_dilate_flags(const int32_t *in_tile_flags, const int32_t *self_tile_flags, int32_t din, int32_t dout,
+                                     int32_t h, int32_t w, int32_t stride_d, int32_t pad_d, int32_t *out_tile_flags,
+                                     void *stream) {
+    MVX_CHECK_ARG(in_tile_flags && out_tile_flags && din > 0 && dout > 0 && h > 0 && w > 0);
+    const int ty = (int)mvx_cdiv(h, ATH), tx = (int)mvx_cdiv(w, ATW);
+    hipLaunchKernelGGL(tile_dilate_flags, dim3(mvx_cdiv((long long)dout * ty * tx, 256)), dim3(256), 0, (hipStream_t)stream,
+                       in_tile_flags, self_tile_flags, din, dout, ty, tx, stride_d, pad_d, out_tile_flags);
+    MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
 

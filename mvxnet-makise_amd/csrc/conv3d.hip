@@ -1046,8 +1046,52 @@ __global__ __launch_bounds__(256) void plane_region_sums(const float *__restrict
     }
 }
 
+// The same sums over the flagged tiles only (dz is not defined elsewhere): one workgroup per tile, thread = (site
+// column group, channel quad); interior tiles only feed kind 0.
+__global__ __launch_bounds__(256) void plane_region_sums_tiles(const float *__restrict__ dz, const int *__restrict__ tile_flags,
+                                                               int D, int H, int W, int C, double *__restrict__ R) {
+    __shared__ float red[256][4];
+    const int tiles_x = (W + TW - 1) / TW;
+    const int t = blockIdx.x, d = blockIdx.y;
+    if (!tile_flags[(size_t)d * gridDim.x + t]) return;
+    const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW;
+    const int c4n = C >> 2, ct = threadIdx.x % c4n, st = threadIdx.x / c4n, spb = 256 / c4n;
+    const unsigned rep = (unsigned)t % RREP;
+    double *Rp = R + ((size_t)rep * D + d) * RK * C;
+    // kind k of a site (y, x): 0 always; 1 y==0; 2 y==H-1; 3 x==0; 4 x==W-1; 5..8 corners
+    for (int kind = 0; kind < RK; ++kind) {
+        const bool need = kind == 0 || (kind == 1 && ty0 == 0) || (kind == 2 && ty0 + TH >= H) || (kind == 3 && tx0 == 0) ||
+                          (kind == 4 && tx0 + TW >= W) || (kind == 5 && ty0 == 0 && tx0 == 0) ||
+                          (kind == 6 && ty0 == 0 && tx0 + TW >= W) || (kind == 7 && ty0 + TH >= H && tx0 == 0) ||
+                          (kind == 8 && ty0 + TH >= H && tx0 + TW >= W);
+        if (!need) continue;                          // block-uniform
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sidx = st; sidx < TH * TW; sidx += spb) {
+            const int gy = ty0 + sidx / TW, gx = tx0 + sidx % TW;
+            if (gy >= H || gx >= W) continue;
+            const bool top = gy == 0, bot = gy == H - 1, lef = gx == 0, rig = gx == W - 1;
+            const bool in = kind == 0 || (kind == 1 && top) || (kind == 2 && bot) || (kind == 3 && lef) || (kind == 4 && rig) ||
+                            (kind == 5 && top && lef) || (kind == 6 && top && rig) || (kind == 7 && bot && lef) ||
+                            (kind == 8 && bot && rig);
+            if (!in) continue;
+            const float4 v = *(const float4 *)(dz + (((size_t)d * H + gy) * W + gx) * C + ct * 4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        __syncthreads();
+        red[threadIdx.x][0] = s.x; red[threadIdx.x][1] = s.y; red[threadIdx.x][2] = s.z; red[threadIdx.x][3] = s.w;
+        __syncthreads();
+        if (st == 0)
+            for (int j = 0; j < 4; ++j) {
+                double tt = 0.0;
+                for (int q = 0; q < spb; ++q) tt += (double)red[q * c4n + ct][j];
+                atomicAdd(Rp + (size_t)kind * C + ct * 4 + j, tt);
+            }
+    }
+}
+
 // T[d][a][b][n] = sum of dz[d][y][x][n] over the sites whose tap (a,b) source (y+a-1, x+b-1) lies inside the image
-__global__ void region_tap_sums(const double *__restrict__ R, int D, int C, float *__restrict__ T) {
+__global__ void region_tap_sums(const double *__restrict__ R, const float *__restrict__ extra_total, int D, int C,
+                                float *__restrict__ T) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= D * 9 * C) return;
     const int n = e % C, tap = (e / C) % 9, d = e / (9 * C);
@@ -1058,6 +1102,7 @@ __global__ void region_tap_sums(const double *__restrict__ R, int D, int C, floa
         for (int rep = 0; rep < RREP; ++rep) t += R[(((size_t)rep * D + d) * RK + q) * C + n];
         k[q] = t;
     }
+    if (extra_total) k[0] += (double)extra_total[(size_t)d * C + n];      // closed-form share of the unvisited tiles
     double t = k[0];
     if (a == 0) t -= k[1];
     if (a == 2) t -= k[2];
@@ -1308,19 +1353,25 @@ extern "C" size_t mvx_plane_tap_sums_workspace_bytes(int32_t planes, int32_t cha
     return planes > 0 && channels > 0 ? sizeof(double) * RREP * planes * RK * channels : 0;
 }
 
-extern "C" int mvx_plane_tap_sums(const float *dz, int32_t planes, int32_t h, int32_t w, int32_t channels, float *tap_sums,
+extern "C" int mvx_plane_tap_sums(const float *dz, int32_t planes, int32_t h, int32_t w, int32_t channels,
+                                  const int32_t *tile_flags, const float *inactive_sums, float *tap_sums,
                                   void *workspace, size_t workspace_bytes, void *stream) {
     MVX_CHECK_ARG(dz && tap_sums && workspace && planes > 0 && h > 0 && w > 0 && channels > 0);
     MVX_CHECK_ARG(channels % 4 == 0 && 256 % (channels / 4) == 0);
+    MVX_CHECK_ARG((tile_flags == nullptr) == (inactive_sums == nullptr));
     MVX_CHECK_ARG(workspace_bytes >= mvx_plane_tap_sums_workspace_bytes(planes, channels));
     hipStream_t st = (hipStream_t)stream;
     double *R = (double *)workspace;
     hipError_t e = hipMemsetAsync(R, 0, sizeof(double) * RREP * planes * RK * channels, st);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(plane_region_sums, dim3(h, planes), dim3(256), 0, st, dz, planes, h, w, channels, R);
+    if (tile_flags)
+        hipLaunchKernelGGL(plane_region_sums_tiles, dim3(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), planes), dim3(256), 0, st, dz,
+                           tile_flags, planes, h, w, channels, R);
+    else
+        hipLaunchKernelGGL(plane_region_sums, dim3(h, planes), dim3(256), 0, st, dz, planes, h, w, channels, R);
     MVX_LAUNCH_CHECK();
     hipLaunchKernelGGL(region_tap_sums, dim3(mvx_cdiv((long long)planes * 9 * channels, 64)), dim3(64), 0, st,
-                       (const double *)R, planes, channels, tap_sums);
+                       (const double *)R, inactive_sums, planes, channels, tap_sums);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

@@ -435,10 +435,12 @@ class Background:
     flags i32 (D,tiles): ``hflag`` = the tile's halo holds such a site, ``tflag`` = the tile itself does.
     ``back``: dict the CONSUMER's backward fills for the producer's backward ('plane_grad_sums'), or None when
     the producer cannot use it (then the consumer computes a dense input gradient)."""
-    __slots__ = ('c', 'y_bg', 'mask', 'hflag', 'tflag', 'back')
+    __slots__ = ('c', 'y_bg', 'mask', 'hflag', 'tflag', 'bflag', 'back')
 
-    def __init__(self, c, mask, hflag, tflag=None, y_bg=None, back=None):
+    def __init__(self, c, mask, hflag, tflag=None, y_bg=None, back=None, bflag=None):
         self.c, self.mask, self.hflag, self.tflag, self.y_bg, self.back = c, mask, hflag, tflag, y_bg, back
+        # tiles on which this tensor's GRADIENT is produced/consumed by the restricted backward (defaults to tflag)
+        self.bflag = bflag if bflag is not None else tflag
 
 
 EXEC_STAGES = None       # device u64 counter of executed gather stages while KERNEL_TIMERS is on (bench roofline)
@@ -478,13 +480,23 @@ def bn_background(bg_pre, bias, mi, planes, channels, relu=True, want_y=False):
     return (c_out, y_bg) if want_y else c_out
 
 
-def plane_tap_sums(dz):
-    """f32 (planes, 9, C): border-corrected per-tap sums of dz over each plane (mvx_plane_tap_sums)."""
+def plane_tap_sums(dz, tile_flags=None, inactive_sums=None):
+    """f32 (planes, 9, C): border-corrected per-tap sums of dz over each plane (mvx_plane_tap_sums); with
+    ``tile_flags`` dz is only read on the flagged tiles and ``inactive_sums`` (planes, C) stands for the rest."""
     D, H, W, C = dz.shape
     T = torch.empty((D, 9, C), dtype=torch.float32, device=dz.device)
     ws = workspace(X.lib.mvx_plane_tap_sums_workspace_bytes(D, C), dz.device, 'tap_sums')
-    X.check(X.lib.mvx_plane_tap_sums(X.ptr(dz), D, H, W, C, X.ptr(T), X.ptr(ws), ws.numel(), X.stream()), 'mvx_plane_tap_sums')
+    X.check(X.lib.mvx_plane_tap_sums(X.ptr(dz), D, H, W, C, X.ptr(tile_flags), X.ptr(inactive_sums), X.ptr(T), X.ptr(ws),
+                                     ws.numel(), X.stream()), 'mvx_plane_tap_sums')
     return T
+
+
+def tile_dilate_flags(in_tflag, self_tflag, din, H, W, sd, pd):
+    dout = conv_out_depth(din, sd, pd)
+    out = torch.empty((dout, n_tiles(H, W)), dtype=torch.int32, device=in_tflag.device)
+    X.check(X.lib.mvx_tile_dilate_flags(X.ptr(in_tflag), X.ptr(self_tflag), din, dout, H, W, sd, pd, X.ptr(out), X.stream()),
+            'mvx_tile_dilate_flags')
+    return out
 
 
 def conv3d_input_grad_sums(w, T, din, sd, pd):
@@ -505,9 +517,9 @@ def conv3d_dgrad_tiles(dz, wpk_d, din, cin, sd, pd, tflag):
     return dx
 
 
-def bn_relu_backward_tiles(dyhat, y, mi, bg, plane_grad_sums, dbias_out=None):
-    """BatchNorm+ReLU backward of a layer output with Background ``bg``; dyhat valid on bg.tflag tiles only.
-    Returns (dz valid on those tiles only, dbias)."""
+def bn_relu_backward_tiles(dyhat, y, mi, bg, plane_grad_sums, dbias_out=None, want_inactive_sums=False):
+    """BatchNorm+ReLU backward of a layer output with Background ``bg``; dyhat valid on bg.bflag tiles only.
+    Returns (dz valid on those tiles only, dbias[, sums of dz over the other tiles (planes, C)])."""
     D, H, W, C = y.shape
     dz = torch.empty_like(y)
     if dbias_out is not None:
@@ -515,11 +527,14 @@ def bn_relu_backward_tiles(dyhat, y, mi, bg, plane_grad_sums, dbias_out=None):
     else:
         db, flags = torch.empty((C,), dtype=torch.float32, device=y.device), 0
     ws = workspace(X.lib.mvx_bn_relu_backward_tiles_workspace_bytes(D, H, W, C), y.device, 'bn_tiles')
+    inact = torch.empty((D, C), dtype=torch.float32, device=y.device) if want_inactive_sums else None
     with _timed_bytes('bn_relu_backward_tiles', 0):
         X.check(X.lib.mvx_bn_relu_backward_tiles(X.ptr(dyhat), X.ptr(y), X.ptr(mi), X.ptr(bg.c), X.ptr(bg.y_bg),
-                                                 X.ptr(plane_grad_sums), X.ptr(bg.tflag), D, H, W, C, X.ptr(dz), X.ptr(db),
-                                                 flags, X.ptr(ws), ws.numel(), X.stream()), 'mvx_bn_relu_backward_tiles')
-    return dz, (None if dbias_out is not None else db)
+                                                 X.ptr(plane_grad_sums), X.ptr(bg.bflag), D, H, W, C, X.ptr(dz), X.ptr(db),
+                                                 X.ptr(inact), flags, X.ptr(ws), ws.numel(), X.stream()),
+                'mvx_bn_relu_backward_tiles')
+    db = None if dbias_out is not None else db
+    return (dz, db, inact) if want_inactive_sums else (dz, db)
 
 
 def conv3d_forward_bg(x, wpk, bias, cout, sd, pd, bg_in, out_mask, bg_pre, relu=True, want_stats=True):

@@ -99,6 +99,9 @@ def _pack(packer, w, for_dgrad, split):
     return packer(for_dgrad, split) if packer is not None else _hip.conv3d_pack(w, for_dgrad, split=split)
 
 
+RESTRICT_LAYER2 = True      # also restrict the backward of a layer whose input is itself restricted (conv2 in CML)
+
+
 def conv_background_on():
     """config.yml ``convbackground``: skip the voxel-free background of the CML activations (exact rewrite, csrc/activity.hip)."""
     return bool(cfg.config.get('convbackground', True))
@@ -122,15 +125,24 @@ class CRB3dFunction(torch.autograd.Function):
         if bg_in is not None:
             din, H, W, _ = x.shape
             bg_pre = _hip.conv3d_background(w, bg_in.c, din, sd, pd)
-            out_mask, out_hflag = _hip.activity_dilate(bg_in.mask, False, din, H, W, sd, pd, mark_border=True)
+            out_mask, out_hflag, out_tflag = _hip.activity_dilate(bg_in.mask, False, din, H, W, sd, pd, mark_border=True,
+                                                                  want_tile_flags=True)
             y, stats = _hip.conv3d_forward_bg(x, wpk, b, cout, sd, pd, bg_in, out_mask, bg_pre)
         else:
             y, stats = _hip.conv3d_forward(x, wpk, b, cout, sd, pd, relu=True, want_stats=True, split=split)
         count = y.numel() // cout
         mi = _hip.bn_finalize(stats, count, eps)
         out = _hip.bn_apply(y, mi)
+        ctx.bg_out = None
         if bg_in is not None and aux is not None:
-            aux['bg'] = _hip.Background(_hip.bn_background(bg_pre, b, mi, y.shape[0], cout), out_mask, out_hflag)
+            c_out, y_out = _hip.bn_background(bg_pre, b, mi, y.shape[0], cout, want_y=True)
+            restricted = RESTRICT_LAYER2 and bg_in.back is not None and bg_in.tflag is not None
+            # tiles of THIS layer's output gradient that its own restricted backward touches: the halos of the input
+            # tiles its dgrad is restricted to (and of its wgrad steps), plus every tile holding a non-background site
+            bflag = _hip.tile_dilate_flags(bg_in.tflag, out_tflag, x.shape[0], x.shape[1], x.shape[2], sd, pd) if restricted else None
+            aux['bg'] = _hip.Background(c_out, out_mask, out_hflag, tflag=out_tflag, y_bg=y_out,
+                                        back={} if restricted else None, bflag=bflag)
+            ctx.bg_out = aux['bg']
         ctx.save_for_backward(x, w, y, mi)
         ctx.geom = (sd, pd, count, split)
         ctx.params = (w, b)
@@ -141,21 +153,28 @@ class CRB3dFunction(torch.autograd.Function):
     def backward(ctx, g):
         x, w, y, mi = ctx.saved_tensors
         sd, pd, count, split = ctx.geom
-        dz, db = _hip.bn_relu_backward(g.contiguous(), y, mi, count, True, dbias_out=_hip.bias_sink_of(ctx.params[1]))
-        db = _hip.accumulate_grad(ctx.params[1], db)
-        bg_in = ctx.bg_in
+        bg_in, bg_out = ctx.bg_in, ctx.bg_out
         tap_sums = None
-        if bg_in is not None:
+        if bg_out is not None and bg_out.back and 'plane_grad_sums' in bg_out.back:
+            # the consumer produced g on bg_out.bflag tiles only and left the per-plane sums of the rest (closed form)
+            dz, db, inact = _hip.bn_relu_backward_tiles(g.contiguous(), y, mi, bg_out, bg_out.back.pop('plane_grad_sums'),
+                                                        dbias_out=_hip.bias_sink_of(ctx.params[1]), want_inactive_sums=True)
+            tap_sums = _hip.plane_tap_sums(dz, bg_out.bflag, inact)
+        else:
+            dz, db = _hip.bn_relu_backward(g.contiguous(), y, mi, count, True, dbias_out=_hip.bias_sink_of(ctx.params[1]))
+        db = _hip.accumulate_grad(ctx.params[1], db)
+        if bg_in is not None and tap_sums is None:
             tap_sums = _hip.plane_tap_sums(dz)
+        if bg_in is not None:
             dw = _hip.conv3d_wgrad_bg(x, dz, sd, pd, bg_in, tap_sums, accumulate_into=_hip.sink_of(ctx.params[0]))
         else:
             dw = _hip.conv3d_wgrad(x, dz, sd, pd, split=split, accumulate_into=_hip.sink_of(ctx.params[0]))
         dx = None
         if ctx.needs_input_grad[0]:
             wpd = _pack(ctx.packer, w, True, split)
-            if bg_in is not None and bg_in.back is not None and bg_in.tflag is not None:
-                # the producer only needs the gradient next to its voxels plus per-plane sums (closed form)
-                dx = _hip.conv3d_dgrad_tiles(dz, wpd, x.shape[0], x.shape[3], sd, pd, bg_in.tflag)
+            if bg_in is not None and bg_in.back is not None and bg_in.bflag is not None:
+                # the producer only needs the gradient on its bflag tiles plus per-plane sums (closed form)
+                dx = _hip.conv3d_dgrad_tiles(dz, wpd, x.shape[0], x.shape[3], sd, pd, bg_in.bflag)
                 bg_in.back['plane_grad_sums'] = _hip.conv3d_input_grad_sums(w, tap_sums, x.shape[0], sd, pd)
             else:
                 dx = _hip.conv3d_dgrad(dz, wpd, x.shape[0], x.shape[3], sd, pd, split=split)

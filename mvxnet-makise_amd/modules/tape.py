@@ -74,7 +74,7 @@ def middle_forward(model, voxels, fpn_levels, idx, imsize, prepared, status_sink
               c1._pd, cfg.eps, aux)
     bg = aux['bg'] if aux else None
     for m in (c2, c3):
-        aux = {} if bg is not None else None
+        aux = {} if (bg is not None and m is not c3) else None      # nobody reads the background of the last layer
         x = _call(tape, CRB3dFunction, True, x, m.conv.weight, m.conv.bias, m._sd, m._pd, cfg.eps, m._packer, bg, aux)
         bg = aux.get('bg') if aux else None
     return _hip.cl_to_bev(x)[None], tape
