@@ -232,7 +232,8 @@ int mvx_conv3d_forward_bg(const float *in, const float *wpk, const float *bias, 
                           int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
                           int32_t stride_d, int32_t pad_d, int32_t flags, const int32_t *in_halo_flags,
                           const uint8_t *out_mask, const float *bg_pre, int32_t border_active,
-                          uint64_t *exec_stages, void *stream);
+                          uint64_t *exec_stages, uint32_t *done_counter, double count, double eps, float *mean_inv,
+                          void *stream);
 size_t mvx_conv3d_wgrad_bg_workspace_bytes(int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout);
 int mvx_conv3d_wgrad_bg(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
                         int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, int32_t flags,
@@ -267,8 +268,15 @@ int mvx_bn_relu_backward_tiles(const float *dyhat, const float *y, const float *
  *   epilogue (no bias/ReLU/stats, ldy == n, few output blocks, long k) be split along k into slabs
  *   that are summed in a fixed order -- fills the chip when rows x n alone cannot.
  * mvx_linear_wgrad: dw f32 [n][k] = dz^T x  (dz f32 [rows][lddz]).
+ * mvx_linear_forward_bn (and the done_counter / count / eps / mean_inv arguments of mvx_conv3d_forward_bg): the
+ *   workgroup that finishes last turns the statistics into mean_inv f32 [2][n] (= mvx_bn_finalize) inside the same
+ *   launch; done_counter u32 [1] must be zero (cleared here unless MVX_FLAG_PREZEROED).
  */
 size_t mvx_linear_splitk_workspace_bytes(int64_t rows, int32_t n);
+int mvx_linear_forward_bn(const float *x, int32_t ldx, const float *w, int32_t ldw, int32_t w_transposed,
+                          const float *bias, float *y, int32_t ldy, double *stats, const float *row_w, int64_t rows,
+                          int32_t k, int32_t n, int32_t flags, uint32_t *done_counter, double count, double eps,
+                          float *mean_inv, void *stream);
 int mvx_linear_forward(const float *x, int32_t ldx, const float *w, int32_t ldw, int32_t w_transposed,
                        const float *bias, float *y, int32_t ldy, double *stats, const float *row_w,
                        int64_t rows, int32_t k, int32_t n, int32_t flags, void *splitk_workspace,

@@ -51,6 +51,42 @@ __device__ __forceinline__ int block_excl_scan_i32(int v, int *smem, int *total)
     return res;
 }
 
+// ---- BatchNorm finalisation by the last workgroup of the producing kernel ----------------------------
+// Every workgroup calls this after its statistics atomics (all threads, block-uniform arguments).  The workgroup that
+// arrives last turns the replicated sums into mean and 1/sqrt(var + eps), which saves the separate mvx_bn_finalize
+// launch.  Only device-scope ATOMICS carry the protocol (sums, counter, and the final reads), all served by the same
+// coherence point, so no agent-scope fence is needed: such a fence writes the XCD's L2 back (the output tile each
+// workgroup has just stored) and cost 13 % of the step when it was tried.  A workgroup's atomics are complete
+// (vmcnt == 0, workgroup-scope release) before its thread 0 bumps the counter.  `s_flag` is one int of LDS.
+__device__ __forceinline__ void bn_finalize_by_last_block(unsigned *done_counter, unsigned total_blocks,
+                                                          double *stats, int C, double count, double eps,
+                                                          float *mean_inv, int *s_flag) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned prev = atomicAdd(done_counter, 1u);
+        *s_flag = (prev == total_blocks - 1u);
+    }
+    __syncthreads();
+    if (!*s_flag) return;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double v1[MVX_REP], v2[MVX_REP];
+#pragma unroll
+        for (int rp = 0; rp < MVX_REP; ++rp) {            // 64 independent device-scope reads in flight
+            v1[rp] = __hip_atomic_load(stats + ((size_t)rp * 2) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v2[rp] = __hip_atomic_load(stats + ((size_t)rp * 2 + 1) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int rp = 0; rp < MVX_REP; ++rp) { s1 += v1[rp]; s2 += v2[rp]; }
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mean_inv[c] = (float)mean;
+        mean_inv[C + c] = (float)(1.0 / sqrt(var + eps));
+    }
+}
+
 __device__ __forceinline__ float wave_sum_f32(float v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);

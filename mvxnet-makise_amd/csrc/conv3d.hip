@@ -255,7 +255,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_pf(const float *__restri
                                                            const unsigned char *__restrict__ out_mask,
                                                            const float *__restrict__ bg_pre, int border_active,
                                                            unsigned long long *__restrict__ exec_stages,
-                                                           const int *__restrict__ only_tiles) {
+                                                           const int *__restrict__ only_tiles,
+                                                           unsigned *__restrict__ done_counter, double fin_count,
+                                                           double fin_eps, float *__restrict__ fin_mean_inv) {
     __shared__ __attribute__((aligned(16))) float s_halo[HH * HROW];
     __shared__ __attribute__((aligned(16))) float s_w[3 * WROW];
     __shared__ float s_red[4][2 * BN];
@@ -443,6 +445,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_pf(const float *__restri
             const int which = tid / BN, c = tid % BN;
             const unsigned rep = (blockIdx.x + blockIdx.y * gridDim.x) % MVX_REP;
             atomicAdd(stats + ((size_t)rep * 2 + which) * g.Cout + nb * BN + c, t);
+        }
+        if (done_counter) {
+            __shared__ int s_last;
+            bn_finalize_by_last_block(done_counter, gridDim.x * gridDim.y * gridDim.z, stats, g.Cout, fin_count, fin_eps,
+                                      fin_mean_inv, &s_last);
         }
     }
 }
@@ -1223,7 +1230,7 @@ extern "C" int mvx_conv3d_forward(const float *in, const float *wpk, const float
     else
         hipLaunchKernelGGL(conv3d_gather_pf, gather_grid(g), dim3(256), 0, st, in, wpk, bias, out, stats, g, relu,
                            (const int *)nullptr, (const unsigned char *)nullptr, (const float *)nullptr, 0,
-                           (unsigned long long *)nullptr, (const int *)nullptr);
+                           (unsigned long long *)nullptr, (const int *)nullptr, (unsigned *)nullptr, 0.0, 0.0, (float *)nullptr);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -1232,7 +1239,8 @@ extern "C" int mvx_conv3d_forward_bg(const float *in, const float *wpk, const fl
                                      int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
                                      int32_t stride_d, int32_t pad_d, int32_t flags, const int32_t *in_halo_flags,
                                      const uint8_t *out_mask, const float *bg_pre, int32_t border_active,
-                                     uint64_t *exec_stages, void *stream) {
+                                     uint64_t *exec_stages, uint32_t *done_counter, double count, double eps,
+                                     float *mean_inv, void *stream) {
     MVX_CHECK_ARG(in && wpk && out && in_halo_flags && out_mask && bg_pre);
     int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
     if (rc) return rc;
@@ -1242,10 +1250,17 @@ extern "C" int mvx_conv3d_forward_bg(const float *in, const float *wpk, const fl
         hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * MVX_REP * 2 * cout, st);
         if (e != hipSuccess) return (int)e;
     }
+    if (done_counter) {
+        MVX_CHECK_ARG(stats && mean_inv && count > 0);
+        if (!(flags & MVX_FLAG_PREZEROED)) {
+            hipError_t e = hipMemsetAsync(done_counter, 0, sizeof(uint32_t), st);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
     Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
     hipLaunchKernelGGL(conv3d_gather_pf, gather_grid(g), dim3(256), 0, st, in, wpk, bias, out, stats, g,
                        flags & MVX_FLAG_RELU, in_halo_flags, out_mask, bg_pre, border_active,
-                       (unsigned long long *)exec_stages, (const int *)nullptr);
+                       (unsigned long long *)exec_stages, (const int *)nullptr, (unsigned *)done_counter, count, eps, mean_inv);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -1260,7 +1275,8 @@ static int launch_dgrad(const float *dz, const float *wpk_dgrad, float *dx, int3
     Geom g{dout, din, h, w, cout, cin, stride_d, pad_d, 1};
     hipLaunchKernelGGL(conv3d_gather_pf, gather_grid(g), dim3(256), 0, (hipStream_t)stream, dz, wpk_dgrad,
                        (const float *)nullptr, dx, (double *)nullptr, g, 0, (const int *)nullptr,
-                       (const unsigned char *)nullptr, (const float *)nullptr, 0, (unsigned long long *)nullptr, only_tiles);
+                       (const unsigned char *)nullptr, (const float *)nullptr, 0, (unsigned long long *)nullptr, only_tiles,
+                       (unsigned *)nullptr, 0.0, 0.0, (float *)nullptr);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

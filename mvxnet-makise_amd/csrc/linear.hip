@@ -30,7 +30,9 @@ template <bool WT, int NT, bool VEC>
 __global__ __launch_bounds__(256) void linear_fwd(const float *__restrict__ x, int ldx, const float *__restrict__ w,
                                                   int ldw, const float *__restrict__ bias, float *__restrict__ y,
                                                   int ldy, double *__restrict__ stats, const float *__restrict__ row_w,
-                                                  long long R, int K, int N, int relu, int k_per_split) {
+                                                  long long R, int K, int N, int relu, int k_per_split,
+                                                  unsigned *__restrict__ done_counter, double fin_count, double fin_eps,
+                                                  float *__restrict__ fin_mean_inv) {
     constexpr int BNL = 32 * NT;
     constexpr int XV = BM * BK / 4 / 256;          // float4 per thread for the x tile (4)
     constexpr int WV = BNL * BK / 4 / 256;         // float4 per thread for the w tile (NT)
@@ -191,6 +193,10 @@ __global__ __launch_bounds__(256) void linear_fwd(const float *__restrict__ x, i
                 atomicAdd(stats + ((size_t)(blockIdx.y % MVX_REP) * 2 + which) * N + n0 + c, t);
             }
         }
+        if (done_counter) {
+            __shared__ int s_last;
+            bn_finalize_by_last_block(done_counter, gridDim.x * gridDim.y, stats, N, fin_count, fin_eps, fin_mean_inv, &s_last);
+        }
     }
 }
 
@@ -329,10 +335,11 @@ extern "C" size_t mvx_linear_splitk_workspace_bytes(int64_t rows, int32_t n) {
     return rows > 0 && n > 0 ? (size_t)16 * rows * n * sizeof(float) : 0;
 }
 
-extern "C" int mvx_linear_forward(const float *x, int32_t ldx, const float *w, int32_t ldw, int32_t w_transposed,
-                                  const float *bias, float *y, int32_t ldy, double *stats, const float *row_w,
-                                  int64_t rows, int32_t k, int32_t n, int32_t flags, void *splitk_workspace,
-                                  size_t splitk_workspace_bytes, void *stream) {
+static int linear_forward_impl(const float *x, int32_t ldx, const float *w, int32_t ldw, int32_t w_transposed,
+                               const float *bias, float *y, int32_t ldy, double *stats, const float *row_w,
+                               int64_t rows, int32_t k, int32_t n, int32_t flags, void *splitk_workspace,
+                               size_t splitk_workspace_bytes, unsigned *fin_counter, double fin_count, double fin_eps,
+                               float *fin_mean_inv, void *stream) {
     const int relu = flags & MVX_FLAG_RELU;
     MVX_CHECK_ARG(x && w && y && rows >= 0 && k > 0 && n > 0 && ldx >= k && ldy >= n);
     MVX_CHECK_ARG(ldw >= (w_transposed ? n : k));
@@ -368,7 +375,7 @@ extern "C" int mvx_linear_forward(const float *x, int32_t ldx, const float *w, i
     const dim3 grid(mvx_cdiv(n, wide ? 128 : 64), mvx_cdiv(rows, BM), splits);
 #define MVX_LAUNCH_LIN(WT, NT, VEC)                                                                               \
     hipLaunchKernelGGL((linear_fwd<WT, NT, VEC>), grid, dim3(256), 0, st, x, ldx, w, ldw, bias, ydst, ld_dst, stats, \
-                       row_w, (long long)rows, k, n, relu, k_per_split)
+                       row_w, (long long)rows, k, n, relu, k_per_split, fin_counter, fin_count, fin_eps, fin_mean_inv)
     if (w_transposed) {
         if (wide) { if (vec) MVX_LAUNCH_LIN(true, 4, true); else MVX_LAUNCH_LIN(true, 4, false); }
         else      { if (vec) MVX_LAUNCH_LIN(true, 2, true); else MVX_LAUNCH_LIN(true, 2, false); }
@@ -388,6 +395,27 @@ extern "C" int mvx_linear_forward(const float *x, int32_t ldx, const float *w, i
         MVX_LAUNCH_CHECK();
     }
     return MVX_OK;
+}
+
+extern "C" int mvx_linear_forward(const float *x, int32_t ldx, const float *w, int32_t ldw, int32_t w_transposed,
+                                  const float *bias, float *y, int32_t ldy, double *stats, const float *row_w,
+                                  int64_t rows, int32_t k, int32_t n, int32_t flags, void *splitk_workspace,
+                                  size_t splitk_workspace_bytes, void *stream) {
+    return linear_forward_impl(x, ldx, w, ldw, w_transposed, bias, y, ldy, stats, row_w, rows, k, n, flags, splitk_workspace,
+                               splitk_workspace_bytes, nullptr, 0.0, 0.0, nullptr, stream);
+}
+
+extern "C" int mvx_linear_forward_bn(const float *x, int32_t ldx, const float *w, int32_t ldw, int32_t w_transposed,
+                                     const float *bias, float *y, int32_t ldy, double *stats, const float *row_w,
+                                     int64_t rows, int32_t k, int32_t n, int32_t flags, uint32_t *done_counter,
+                                     double count, double eps, float *mean_inv, void *stream) {
+    MVX_CHECK_ARG(stats && done_counter && mean_inv && count > 0 && rows > 0);
+    if (!(flags & MVX_FLAG_PREZEROED)) {
+        hipError_t e = hipMemsetAsync(done_counter, 0, sizeof(uint32_t), (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    return linear_forward_impl(x, ldx, w, ldw, w_transposed, bias, y, ldy, stats, row_w, rows, k, n, flags, nullptr, 0,
+                               done_counter, count, eps, mean_inv, stream);
 }
 
 extern "C" size_t mvx_linear_wgrad_workspace_bytes(int64_t rows, int32_t k, int32_t n) {

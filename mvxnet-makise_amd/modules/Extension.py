@@ -81,7 +81,8 @@ PROTOTYPES = {
     'mvx_conv3d_background': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     'mvx_bn_background': (_i32, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _p]),
     'mvx_conv3d_forward_bg': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p,
-                                     _i32, _p, _p]),
+                                     _i32, _p, _p, _f64, _f64, _p, _p]),
+    'mvx_linear_forward_bn': (_i32, [_p, _i32, _p, _i32, _i32, _p, _p, _i32, _p, _p, _i64, _i32, _i32, _i32, _p, _f64, _f64, _p, _p]),
     'mvx_conv3d_wgrad_bg_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32, _i32]),
     'mvx_conv3d_wgrad_bg': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
     'mvx_plane_tap_sums_workspace_bytes': (_sz, [_i32, _i32]),

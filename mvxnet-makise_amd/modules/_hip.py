@@ -537,7 +537,8 @@ def bn_relu_backward_tiles(dyhat, y, mi, bg, plane_grad_sums, dbias_out=None, wa
     return (dz, db, inact) if want_inactive_sums else (dz, db)
 
 
-def conv3d_forward_bg(x, wpk, bias, cout, sd, pd, bg_in, out_mask, bg_pre, relu=True, want_stats=True):
+def conv3d_forward_bg(x, wpk, bias, cout, sd, pd, bg_in, out_mask, bg_pre, relu=True, want_stats=True, finalize_eps=None):
+    """finalize_eps: also form the BatchNorm mean / inverse std in the kernel (returns (y, mean_inv) then)."""
     global EXEC_STAGES
     din, H, W, cin = x.shape
     dout = conv_out_depth(din, sd, pd)
@@ -549,11 +550,18 @@ def conv3d_forward_bg(x, wpk, bias, cout, sd, pd, bg_in, out_mask, bg_pre, relu=
         if EXEC_STAGES is None:
             EXEC_STAGES = torch.zeros((1,), dtype=torch.int64, device=x.device)
         counter = EXEC_STAGES
+    fin, mi, npos = None, None, float(dout * H * W)
+    if finalize_eps is not None and want_stats:
+        fin = _fin_slot(x.device, fz)
+        if fin is None:
+            fin = torch.zeros((1,), dtype=torch.float64, device=x.device)
+        mi = torch.empty((2, cout), dtype=torch.float32, device=x.device)
     with _Timed('conv3d_gather_bg', 0):
         X.check(X.lib.mvx_conv3d_forward_bg(X.ptr(x), X.ptr(wpk), X.ptr(bias), X.ptr(out), X.ptr(stats), din, dout, H, W,
                                             cin, cout, sd, pd, flags, X.ptr(bg_in.hflag), X.ptr(out_mask), X.ptr(bg_pre),
-                                            1, X.ptr(counter), X.stream()), 'mvx_conv3d_forward_bg')
-    return out, stats
+                                            1, X.ptr(counter), X.ptr(fin), npos, float(finalize_eps or 0.0), X.ptr(mi),
+                                            X.stream()), 'mvx_conv3d_forward_bg')
+    return (out, mi) if mi is not None else (out, stats)
 
 
 def conv3d_wgrad_bg(x, dz, sd, pd, bg_in, tap_sums=None, accumulate_into=None):
@@ -594,13 +602,36 @@ def _vptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def linear_forward(x, w, bias, relu=True, want_stats=True, w_transposed=False, row_w=None, out=None):
-    """x (R,K) view, w (N,K) [or (K,N) if w_transposed] -> y (R,N), stats f64 (2,N) or None."""
+def _fin_slot(device, zeroed):
+    """u32 counter for the in-kernel BatchNorm finalisation: from the frame arena when the statistics came from it
+    (pre-zeroed), else a fresh buffer the C entry clears."""
+    if zeroed:
+        a = _ARENAS.get(_arena_key(device))
+        v = a.take(1) if a is not None else None
+        if v is not None:
+            return v
+    return None
+
+
+def linear_forward(x, w, bias, relu=True, want_stats=True, w_transposed=False, row_w=None, out=None, finalize=None):
+    """x (R,K) view, w (N,K) [or (K,N) if w_transposed] -> y (R,N), stats f64 (2,N) or None.
+    ``finalize=(count, eps)``: the BatchNorm mean / inverse std are formed by the kernel's last workgroup
+    (mvx_linear_forward_bn); returns (y, mean_inv) then."""
     R, K = x.shape
     N = w.shape[1] if w_transposed else w.shape[0]
     if out is None:
         out = torch.empty((R, N), dtype=torch.float32, device=x.device)
     stats, fz = _acc_f64((STATS_REPLICAS, 2, N), x.device) if want_stats else (None, 0)
+    if finalize is not None and want_stats and R > 0:
+        counter = _fin_slot(x.device, fz)
+        if counter is None:
+            counter = torch.zeros((1,), dtype=torch.float64, device=x.device)
+        mi = torch.empty((2, N), dtype=torch.float32, device=x.device)
+        X.check(X.lib.mvx_linear_forward_bn(_vptr(x), _ld(x), _vptr(w), _ld(w), int(w_transposed), X.ptr(bias),
+                                            _vptr(out), _ld(out), X.ptr(stats), X.ptr(row_w), R, K, N,
+                                            (FLAG_RELU if relu else 0) | fz, X.ptr(counter), float(finalize[0]),
+                                            float(finalize[1]), X.ptr(mi), X.stream()), 'mvx_linear_forward_bn')
+        return out, mi
     ws = None
     if bias is None and not relu and not want_stats and K >= 256 and R * N <= (1 << 22):
         ws = workspace(X.lib.mvx_linear_splitk_workspace_bytes(R, N), x.device, 'splitk')
@@ -608,6 +639,8 @@ def linear_forward(x, w, bias, relu=True, want_stats=True, w_transposed=False, r
                                      _vptr(out), _ld(out), X.ptr(stats), X.ptr(row_w), R, K, N,
                                      (FLAG_RELU if relu else 0) | fz,
                                      X.ptr(ws), ws.numel() if ws is not None else 0, X.stream()), 'mvx_linear_forward')
+    if finalize is not None and want_stats:      # empty input: no launch happened, finalise the (zero) sums separately
+        return out, bn_finalize(stats, finalize[0], finalize[1])
     return out, stats
 
 

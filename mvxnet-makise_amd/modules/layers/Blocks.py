@@ -27,8 +27,7 @@ class FCNFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, eps, row_w, count):
         w2 = w.reshape(w.shape[0], -1)
-        y, stats = _hip.linear_forward(x, w2, b, relu=True, want_stats=True, row_w=row_w)
-        mi = _hip.bn_finalize(stats, count, eps)
+        y, mi = _hip.linear_forward(x, w2, b, relu=True, want_stats=True, row_w=row_w, finalize=(count, eps))
         out = _hip.bn_apply(y, mi)
         ctx.save_for_backward(x, w, y, mi, row_w)
         ctx.count = count
@@ -127,11 +126,12 @@ class CRB3dFunction(torch.autograd.Function):
             bg_pre = _hip.conv3d_background(w, bg_in.c, din, sd, pd)
             out_mask, out_hflag, out_tflag = _hip.activity_dilate(bg_in.mask, False, din, H, W, sd, pd, mark_border=True,
                                                                   want_tile_flags=True)
-            y, stats = _hip.conv3d_forward_bg(x, wpk, b, cout, sd, pd, bg_in, out_mask, bg_pre)
+            y, mi = _hip.conv3d_forward_bg(x, wpk, b, cout, sd, pd, bg_in, out_mask, bg_pre, finalize_eps=eps)
+            count = y.numel() // cout
         else:
             y, stats = _hip.conv3d_forward(x, wpk, b, cout, sd, pd, relu=True, want_stats=True, split=split)
-        count = y.numel() // cout
-        mi = _hip.bn_finalize(stats, count, eps)
+            count = y.numel() // cout
+            mi = _hip.bn_finalize(stats, count, eps)
         out = _hip.bn_apply(y, mi)
         ctx.bg_out = None
         if bg_in is not None and aux is not None:

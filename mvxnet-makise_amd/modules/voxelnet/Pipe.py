@@ -19,8 +19,7 @@ class VFEFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, V, T, eps, cr):
         row_w = cr.row_w if cr is not None else None
-        y, stats = _hip.linear_forward(x, w, b, relu=True, want_stats=True, row_w=row_w)
-        mi = _hip.bn_finalize(stats, V * T, eps)
+        y, mi = _hip.linear_forward(x, w, b, relu=True, want_stats=True, row_w=row_w, finalize=(V * T, eps))
         out, am = _hip.vfe_bn_max_concat(y, mi, V, T, cr)
         ctx.save_for_backward(x, w, y, mi, am)
         ctx.vt = (V, T, cr)
@@ -48,8 +47,7 @@ class FCNMaxFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, V, T, eps, cr):
         row_w = cr.row_w if cr is not None else None
-        y, stats = _hip.linear_forward(x, w, b, relu=True, want_stats=True, row_w=row_w)
-        mi = _hip.bn_finalize(stats, V * T, eps)
+        y, mi = _hip.linear_forward(x, w, b, relu=True, want_stats=True, row_w=row_w, finalize=(V * T, eps))
         out, am = _hip.bn_segment_max(y, mi, V, T, cr)
         ctx.save_for_backward(x, w, y, mi, am)
         ctx.vt = (V, T, cr)
