@@ -35,6 +35,7 @@ extern "C" {
 #define MVX_FLAG_PREZEROED 2   /* the stats / scratch accumulators passed in are already zero: skip the memset
                                   (lets a caller clear all accumulators of a frame with ONE fill) */
 #define MVX_FLAG_ACCUMULATE 4  /* add the gradient to the destination instead of overwriting it */
+#define MVX_FLAG_CONV2D 8      /* mvx_conv3d_wgrad: dw is a 2-D kernel gradient [cout][cin][3][3] (din = dout = 1, pad_d = 1) */
 
 #define MVX_OK 0
 #define MVX_EINVAL (-1)   /* bad argument (null pointer, size, unsupported combination) */
@@ -142,7 +143,10 @@ int mvx_bn_relu_backward(const float *dyhat, const float *y, const float *mean_i
  * stride (stride_d,1,1), padding (pad_d,1,1); cin % 32 == 0, cout % 64 == 0.
  *
  *   mvx_conv3d_pack_weights  torch layout W[cout][cin][3][3][3] -> kernel layout
- *                            (for_dgrad = 0: forward operand, 1: transposed/flipped operand)
+ *                            (for_dgrad bit 0 = 0: forward operand, 1: transposed/flipped operand; bit 1 set: the source
+ *                            is a 2-D kernel W[cout][cin][3][3] = the middle depth slice -- with din = dout = 1 and
+ *                            pad_d = 1 the same kernels then evaluate nn.Conv2d 3x3, stride 1, padding 1: the RPN
+ *                            blocks of modules/voxelnet/Pipe.py:45-75, next scope row)
  *   mvx_conv3d_forward       out = [ReLU](conv(in) + bias); stats (optional, replicated f64 [R][2][cout]) =
  *                            per-channel (sum, sum of squares) of `out` for the BatchNorm that
  *                            follows (Blocks.py:28-29)
@@ -157,7 +161,8 @@ int mvx_bn_relu_backward(const float *dyhat, const float *y, const float *mean_i
  *   mvx_conv3d_dgrad_sites   dfeat [n_voxels][cin] = rows of dx at the voxel sites only (what
  *                            reindex's backward reads); coords i64 [n_voxels][4] = (b, ix, iy, iz)
  *   mvx_conv3d_wgrad_sites   dw from the n_voxels non-zero input rows feat [n_voxels][cin] only
- *   mvx_conv3d_wgrad         dw in torch layout [cout][cin][3][3][3]; cout == 64
+ *   mvx_conv3d_wgrad         dw in torch layout [cout][cin][3][3][3] ([cout][cin][3][3] with MVX_FLAG_CONV2D);
+ *                            cout % 64 == 0 when cin % 64 == 0, else cout == 64
  */
 size_t mvx_conv3d_packed_weight_bytes(int32_t cout, int32_t cin);
 int mvx_conv3d_pack_weights(const float *w, float *wpk, int32_t cout, int32_t cin, int32_t for_dgrad,

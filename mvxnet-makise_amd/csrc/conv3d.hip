@@ -59,7 +59,7 @@ __device__ __forceinline__ int src_depth(const Geom &g, int d, int kd) {
 //   forward: n = co, k = ci, (a,b) = (kh,kw)
 //   dgrad  : n = ci, k = co, (a,b) = (2-kh, 2-kw)
 // ------------------------------------------------------------------------------------------
-__global__ void pack_weights(const float *__restrict__ w, float *__restrict__ wpk, int Co, int Ci, int dgrad) {
+__global__ void pack_weights(const float *__restrict__ w, float *__restrict__ wpk, int Co, int Ci, int dgrad, int src2d) {
     const int K = dgrad ? Co : Ci, N = dgrad ? Ci : Co;
     const int nch = K / BK;
     const long long total = 27ll * K * N;
@@ -75,7 +75,10 @@ __global__ void pack_weights(const float *__restrict__ w, float *__restrict__ wp
         const int kk = ch * BK + k;
         const int co = dgrad ? kk : n, ci = dgrad ? n : kk;
         const int kh = dgrad ? 2 - a : a, kw = dgrad ? 2 - b : b;
-        wpk[e] = w[((((long long)co * Ci + ci) * 3 + kd) * 3 + kh) * 3 + kw];
+        // src2d: the source is a 2-D kernel W[co][ci][3][3] standing for the middle depth slice (depth taps 0 and 2
+        // are zero and, with din = dout = 1 and pad_d = 1, never executed)
+        if (src2d) wpk[e] = kd == 1 ? w[(((long long)co * Ci + ci) * 3 + kh) * 3 + kw] : 0.f;
+        else wpk[e] = w[((((long long)co * Ci + ci) * 3 + kd) * 3 + kh) * 3 + kw];
     }
 }
 
@@ -884,6 +887,9 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restr
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wv >> 1, wn = wv & 1;
+    const int nb = blockIdx.z;                       // 64-channel block of dz / dW (Cout = 64 * gridDim.z)
+    dz += (size_t)nb * BN;
+    slabs += (size_t)nb * gridDim.x * 27 * g.Cin * BN;
 
     f32x16 acc[9];
 #pragma unroll
@@ -1139,8 +1145,11 @@ __global__ void wgrad_rank1(const float *__restrict__ T, const float *__restrict
 }
 
 // dW[co][ci][kd][kh][kw] = sum_strips slab[strip][kd][tap][ci][co]
-__global__ void wgrad_reduce(const float *__restrict__ slabs, float *__restrict__ dw, int nstrips, int Ci, int accumulate) {
+__global__ void wgrad_reduce(const float *__restrict__ slabs, float *__restrict__ dw, int nstrips, int Ci, int accumulate,
+                             int dst2d) {
     const size_t per = (size_t)27 * Ci * BN;
+    slabs += (size_t)blockIdx.y * nstrips * per;     // 64-channel block of the output channels
+    dw += (size_t)blockIdx.y * (dst2d ? per / 3 : per);
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < per; e += (size_t)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int k = 0; k < nstrips; ++k) s += slabs[(size_t)k * per + e];
@@ -1149,7 +1158,9 @@ __global__ void wgrad_reduce(const float *__restrict__ slabs, float *__restrict_
         const int ci = (int)(r % Ci); r /= Ci;
         const int tap = (int)(r % 9);
         const int kd = (int)(r / 9);
-        float *dst = dw + ((((size_t)co * Ci + ci) * 3 + kd) * 3 + tap / 3) * 3 + tap % 3;
+        if (dst2d && kd != 1) continue;             // 2-D kernel gradient: the middle depth slice only
+        float *dst = dst2d ? dw + (((size_t)co * Ci + ci) * 3 + tap / 3) * 3 + tap % 3
+                           : dw + ((((size_t)co * Ci + ci) * 3 + kd) * 3 + tap / 3) * 3 + tap % 3;
         *dst = accumulate ? *dst + s : s;
     }
 }
@@ -1183,10 +1194,10 @@ extern "C" size_t mvx_conv3d_packed_weight_bytes(int32_t cout, int32_t cin) {
 extern "C" int mvx_conv3d_pack_weights(const float *w, float *wpk, int32_t cout, int32_t cin,
                                        int32_t for_dgrad, void *stream) {
     MVX_CHECK_ARG(w && wpk && cout > 0 && cin > 0);
-    MVX_CHECK_ARG((for_dgrad ? cout : cin) % BK == 0);
+    MVX_CHECK_ARG(((for_dgrad & 1) ? cout : cin) % BK == 0);
     const long long total = 27ll * cout * cin;
     hipLaunchKernelGGL(pack_weights, dim3(mvx_cdiv(total, 256) > 2048 ? 2048 : mvx_cdiv(total, 256)), dim3(256), 0,
-                       (hipStream_t)stream, w, wpk, cout, cin, for_dgrad);
+                       (hipStream_t)stream, w, wpk, cout, cin, for_dgrad & 1, (for_dgrad >> 1) & 1);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -1307,11 +1318,11 @@ static int wgrad_strips(int h, int w, int cin) {
 }
 
 extern "C" size_t mvx_conv3d_wgrad_workspace_bytes(int32_t h, int32_t w, int32_t cin, int32_t cout) {
-    if (h <= 0 || w <= 0 || cin <= 0 || cout != BN) return 0;
+    if (h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || cout % BN) return 0;
     const int ntiles = (int)(mvx_cdiv(w, TW) * mvx_cdiv(h, TH));
     const int per = wgrad_strips(h, w, cin);
     const int nstrips = (ntiles + per - 1) / per;
-    return (size_t)nstrips * 27 * cin * BN * sizeof(float);
+    return (size_t)(cout / BN) * nstrips * 27 * cin * BN * sizeof(float);
 }
 
 extern "C" int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int32_t din, int32_t dout,
@@ -1320,23 +1331,24 @@ extern "C" int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int
     MVX_CHECK_ARG(in && dz && dw && workspace);
     int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
     if (rc) return rc;
-    if (cout != BN) return MVX_ESIZE;
+    const int nblk = cout / BN;                     // the 4-wave kernel takes any multiple of 64 output channels
+    if (cout != BN && cin % W4_C) return MVX_ESIZE;
     const int ntiles = (int)(mvx_cdiv(w, TW) * mvx_cdiv(h, TH));
     const int per = wgrad_strips(h, w, cin);
     const int nstrips = (ntiles + per - 1) / per;
-    MVX_CHECK_ARG(workspace_bytes >= (size_t)nstrips * 27 * cin * BN * sizeof(float));
+    MVX_CHECK_ARG(workspace_bytes >= (size_t)nblk * nstrips * 27 * cin * BN * sizeof(float));
     Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
     hipStream_t st = (hipStream_t)stream;
     if (cin % W4_C == 0)
-        hipLaunchKernelGGL(conv3d_wgrad4, dim3(nstrips, 3 * (cin / W4_C)), dim3(W4_THREADS), 0, st, in, dz,
+        hipLaunchKernelGGL(conv3d_wgrad4, dim3(nstrips, 3 * (cin / W4_C), nblk), dim3(W4_THREADS), 0, st, in, dz,
                            (float *)workspace, g, per, (const int *)nullptr, (const int *)nullptr, (const float *)nullptr);
     else
         hipLaunchKernelGGL(conv3d_wgrad, dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz,
                            (float *)workspace, g, per);
     MVX_LAUNCH_CHECK();
     const size_t per_slab = (size_t)27 * cin * BN;
-    hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)workspace, dw,
-                       nstrips, cin, flags & MVX_FLAG_ACCUMULATE);
+    hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256), nblk), dim3(256), 0, st, (const float *)workspace, dw,
+                       nstrips, cin, flags & MVX_FLAG_ACCUMULATE, (flags & MVX_FLAG_CONV2D) ? 1 : 0);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -1431,7 +1443,7 @@ extern "C" int mvx_conv3d_wgrad_bg(const float *in, const float *dz, float *dw, 
     MVX_LAUNCH_CHECK();
     const size_t per_slab = (size_t)27 * cin * BN;
     hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)slabs, dw, nstrips, cin,
-                       flags & MVX_FLAG_ACCUMULATE);
+                       flags & MVX_FLAG_ACCUMULATE, 0);
     MVX_LAUNCH_CHECK();
     hipLaunchKernelGGL(wgrad_rank1, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, tap_sums, c_in, dw, g);
     MVX_LAUNCH_CHECK();
@@ -1473,7 +1485,7 @@ extern "C" int mvx_conv3d_wgrad_sites(const float *feat, const int64_t *coords, 
     MVX_LAUNCH_CHECK();
     const size_t per_slab = (size_t)27 * cin * BN;
     hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)workspace, dw,
-                       nstrips, cin, 0);
+                       nstrips, cin, 0, 0);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

@@ -9,7 +9,7 @@ VoxelizeResult = collections.namedtuple('VoxelizeResult', 'voxels coords counts 
 
 _ws_cache = {}
 STATS_REPLICAS = 32      # MVX_STATS_REPLICAS of include/mvx_hip.h
-FLAG_RELU, FLAG_PREZEROED, FLAG_ACCUMULATE = 1, 2, 4      # MVX_FLAG_* of include/mvx_hip.h
+FLAG_RELU, FLAG_PREZEROED, FLAG_ACCUMULATE, FLAG_CONV2D = 1, 2, 4, 8      # MVX_FLAG_* of include/mvx_hip.h
 
 # When True, the backward of the hot-path layers adds weight / bias gradients straight into the existing
 # ``.grad`` buffers inside the reduction kernels (and returns None to autograd), instead of producing a
@@ -326,12 +326,17 @@ def bn_relu_backward(dyhat, y, mi, count, want_dbias=True, dz=None, row_w=None, 
 # dense 3x3x3 convolution (channels-last, one frame)
 # ---------------------------------------------------------------------------------------------
 def conv3d_pack(weight, for_dgrad, split=False):
-    """Kernel-layout weights; split=True: pre-split (hi, lo) bf16 pairs for the bf16x3 kernels."""
+    """Kernel-layout weights; split=True: pre-split (hi, lo) bf16 pairs for the bf16x3 kernels.  A 2-D kernel
+    (cout,cin,3,3) is packed as the middle depth slice of a 3-D one (exact-f32 kernels only): nn.Conv2d 3x3 / stride 1 /
+    padding 1 then runs on the conv3d kernels with a depth-1 tensor and pad_d = 1."""
     cout, cin = weight.shape[0], weight.shape[1]
-    assert tuple(weight.shape[2:]) == (3, 3, 3)
+    two_d = tuple(weight.shape[2:]) == (3, 3)
+    assert two_d or tuple(weight.shape[2:]) == (3, 3, 3)
+    assert not (two_d and split)
     wpk = torch.empty((27 * cout * cin,), dtype=torch.float32, device=weight.device)
     fn = X.lib.mvx_conv3d_pack_weights_split if split else X.lib.mvx_conv3d_pack_weights
-    X.check(fn(X.ptr(weight.contiguous()), X.ptr(wpk), cout, cin, int(for_dgrad), X.stream()), 'mvx_conv3d_pack_weights')
+    X.check(fn(X.ptr(weight.contiguous()), X.ptr(wpk), cout, cin, int(for_dgrad) | (2 if two_d else 0), X.stream()),
+            'mvx_conv3d_pack_weights')
     return wpk
 
 
@@ -408,14 +413,19 @@ def conv3d_dgrad(dz, wpk_d, din, cin, sd, pd, split=False):
     return dx
 
 
-def conv3d_wgrad(x, dz, sd, pd, split=False, accumulate_into=None):
-    """accumulate_into: existing (cout,cin,3,3,3) gradient buffer to ADD to (returns None then)."""
+def conv3d_wgrad(x, dz, sd, pd, split=False, accumulate_into=None, two_d=False):
+    """accumulate_into: existing (cout,cin,3,3,3) gradient buffer to ADD to (returns None then).
+    two_d: the gradient of a 2-D kernel (cout,cin,3,3) (depth-1 tensors, pad_d = 1)."""
     din, H, W, cin = x.shape
     dout, _, _, cout = dz.shape
     if accumulate_into is not None:
         dw, flags = accumulate_into, FLAG_ACCUMULATE
     else:
-        dw, flags = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device=x.device), 0
+        shape = (cout, cin, 3, 3) if two_d else (cout, cin, 3, 3, 3)
+        dw, flags = torch.empty(shape, dtype=torch.float32, device=x.device), 0
+    if two_d:
+        assert not split and din == 1 and dout == 1 and pd == 1
+        flags |= FLAG_CONV2D
     nbytes = X.lib.mvx_conv3d_wgrad_workspace_bytes(H, W, cin, cout)
     fn, name = (X.lib.mvx_conv3d_wgrad_split, 'conv3d_wgrad_split') if split else (X.lib.mvx_conv3d_wgrad, 'conv3d_wgrad')
     with _wgrad_scope(accumulate_into, x, dz) as scope:

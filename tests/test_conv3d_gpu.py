@@ -263,3 +263,30 @@ def test_background_rewrite_equals_dense(shape):
     dw_bg = _hip.conv3d_wgrad_bg(x, dz, sd, pd, bg_in)
     dw_dn = _hip.conv3d_wgrad(x, dz, sd, pd)
     assert float((dw_bg - dw_dn).abs().max()) < 2e-5 * float(dw_dn.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cin,cout,H,W', [(128, 128, 50, 44), (128, 256, 25, 22), (256, 256, 19, 35)])
+def test_conv2d_3x3_on_the_conv3d_kernels(cin, cout, H, W):
+    """nn.Conv2d 3x3 / stride 1 / padding 1 (the RPN blocks) as a depth-1 conv3d with pad_d = 1: forward, input
+    gradient and 2-D weight gradient against torch (CPU, float64 accumulate)."""
+    from modules import _hip
+    import torch.nn.functional as F
+    dev = torch.device('cuda')
+    g = torch.Generator(device='cpu').manual_seed(9)
+    x = torch.randn((H, W, cin), generator=g)
+    w = torch.randn((cout, cin, 3, 3), generator=g) * 0.05
+    b = torch.randn((cout,), generator=g)
+    dz = torch.randn((H, W, cout), generator=g)
+    xd, wd, bd, dzd = x.to(dev), w.to(dev), b.to(dev), dz.to(dev)
+    y, _ = _hip.conv3d_forward(xd.unsqueeze(0), _hip.conv3d_pack(wd, False), bd, cout, 1, 1, relu=False, want_stats=False)
+    dx = _hip.conv3d_dgrad(dzd.unsqueeze(0), _hip.conv3d_pack(wd, True), 1, cin, 1, 1)
+    dw = _hip.conv3d_wgrad(xd.unsqueeze(0), dzd.unsqueeze(0), 1, 1, two_d=True)
+    assert dw.shape == (cout, cin, 3, 3)
+    xr = x.double().permute(2, 0, 1)[None].requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, b.double(), padding=1)
+    yr.backward(dz.double().permute(2, 0, 1)[None])
+    assert rel_err(y[0].cpu(), yr[0].permute(1, 2, 0).detach()) < 1e-5
+    assert rel_err(dx[0].cpu(), xr.grad[0].permute(1, 2, 0)) < 1e-5
+    assert rel_err(dw.cpu(), wr.grad) < 1e-5
