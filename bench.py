@@ -200,20 +200,28 @@ def main():
         # input pipelining: this step consumes the batch prepared during the previous one and starts the next
         # (same resident synthetic batch every step; every step still voxelizes once, inside the timed region)
         ready = None
+        tt = [time.perf_counter()]
         if pipelined:
             # bounded run-ahead: never more than one step of launches in flight (a full HIP queue blocks the host
             # inside launches for milliseconds at a time)
             if len(step_events) >= 2:
-                step_events.pop(0).synchronize()
+                pl_mod._spin(step_events.pop(0))
             if pending[0] is not None:
                 ready = pl_mod.prepare_end(pending[0], model.head)
+                tt.append(time.perf_counter())
             pending[0] = pl_mod.prepare_begin(batch)
+        tt.append(time.perf_counter())
         bucket.zero()
         nv, statuses = train_step_frames(model, batch, grad_mid, imsize, ready=ready)
+        tt.append(time.perf_counter())
         if pipelined:
             pl_mod.prepare_mid(pending[0], model.head)
+        tt.append(time.perf_counter())
         bucket.all_reduce_mean(frames_total)
         opt.step()
+        tt.append(time.perf_counter())
+        if os.environ.get('MVX_DEBUG_TIMES'):
+            sys.stderr.write('step phases ms: ' + ' '.join('%.2f' % ((b - a) * 1e3) for a, b in zip(tt, tt[1:])) + '\n')
         pending_status.extend(statuses)
         if pipelined:
             ev = torch.cuda.Event()

@@ -93,6 +93,13 @@ def _pinned(tag, like, turn):
 _TURN = [0]
 
 
+def _spin(ev):
+    """Wait for an event by polling: hipEventSynchronize parks the thread and wakes it late (measured: it alone made
+    the pipelined step 2.5 ms slower than the unpipelined one)."""
+    while not ev.query():
+        pass
+
+
 class PendingPrepare:
     __slots__ = ('batch', 'res', 'counts_host', 'ev_a', 'frames', 'maps', 'nreal_host', 'ev_b', 'turn')
 
@@ -119,7 +126,7 @@ def prepare_begin(batch, T=None):
 
 def prepare_mid(h, head):
     """Phase B (enqueue only; waits for phase A's counts, which are long there): compact-row maps of every frame."""
-    h.ev_a.synchronize()
+    _spin(h.ev_a)
     counts = h.counts_host.tolist()
     dev = h.batch.points6.device
     prep = _prep_stream(dev)
@@ -137,7 +144,7 @@ def prepare_end(h, head):
     """Host side of a finished preparation: (frames, prepared, status, event the consumers must wait for)."""
     if h.frames is None:
         prepare_mid(h, head)
-    h.ev_b.synchronize()
+    _spin(h.ev_b)
     n_real = h.nreal_host.tolist()
     prepared = [(m[0], m[1], int(n)) for m, n in zip(h.maps, n_real)]
     return h.frames, prepared, h.res.status, h.ev_b
