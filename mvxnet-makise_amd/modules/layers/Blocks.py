@@ -99,6 +99,11 @@ def _pack(packer, w, for_dgrad, split):
 
 
 RESTRICT_LAYER2 = True      # also restrict the backward of a layer whose input is itself restricted (conv2 in CML)
+# The restricted backward hands the producer an input gradient that is only valid on part of the grid (plus closed-form
+# sums): correct only if the producer's output has NO other consumer.  modules/tape.py knows the chain and switches it
+# on; through the nn.Module / autograd interface it stays off (dense input gradients), so a model that reuses a CML
+# activation elsewhere still gets correct gradients.
+RESTRICTED_BACKWARD = False
 
 
 def conv_background_on():
@@ -136,7 +141,7 @@ class CRB3dFunction(torch.autograd.Function):
         ctx.bg_out = None
         if bg_in is not None and aux is not None:
             c_out, y_out = _hip.bn_background(bg_pre, b, mi, y.shape[0], cout, want_y=True)
-            restricted = RESTRICT_LAYER2 and bg_in.back is not None and bg_in.tflag is not None
+            restricted = RESTRICTED_BACKWARD and RESTRICT_LAYER2 and bg_in.back is not None and bg_in.tflag is not None
             # tiles of THIS layer's output gradient that its own restricted backward touches: the halos of the input
             # tiles its dgrad is restricted to (and of its wgrad steps), plus every tile holding a non-background site
             bflag = _hip.tile_dilate_flags(bg_in.tflag, out_tflag, x.shape[0], x.shape[1], x.shape[2], sd, pd) if restricted else None
@@ -238,7 +243,7 @@ class VoxelGemmCRB3dFunction(torch.autograd.Function):
             mask, hflag, tflag = _hip.activity_dilate(idx_grid, True, dhw[0], dhw[1], dhw[2], sd, pd, mark_border=False,
                                                       want_tile_flags=True)
             c1, y1 = _hip.bn_background(None, b, mi, y.shape[0], cout, want_y=True)
-            aux['bg'] = _hip.Background(c1, mask, hflag, tflag=tflag, y_bg=y1, back={})
+            aux['bg'] = _hip.Background(c1, mask, hflag, tflag=tflag, y_bg=y1, back={} if RESTRICTED_BACKWARD else None)
         ctx.bg = aux['bg'] if aux is not None else None
         ctx.save_for_backward(feat, coords, w_all, y, mi)
         ctx.geom = (dhw[0], sd, pd, count, tuple(w.shape))

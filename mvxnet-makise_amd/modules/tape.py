@@ -95,8 +95,13 @@ def middle_backward(tape, grad_mid, depth):
 
 def middle_train(model, voxels, fpn_levels, idx, imsize, prepared, status_sink, grad_mid):
     """One frame: forward + backward of the hot path without autograd; returns the middle map."""
-    with torch.no_grad():
-        mid, tape = middle_forward(model, voxels, fpn_levels, idx, imsize, prepared, status_sink)
-        depth = mid.shape[1] // 64
-        middle_backward(tape, grad_mid, depth)
+    from modules.layers import Blocks
+    old, Blocks.RESTRICTED_BACKWARD = Blocks.RESTRICTED_BACKWARD, True     # the chain is known here: one consumer per node
+    try:
+        with torch.no_grad():
+            mid, tape = middle_forward(model, voxels, fpn_levels, idx, imsize, prepared, status_sink)
+            depth = mid.shape[1] // 64
+            middle_backward(tape, grad_mid, depth)
+    finally:
+        Blocks.RESTRICTED_BACKWARD = old
     return mid

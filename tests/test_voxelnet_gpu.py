@@ -297,6 +297,8 @@ def test_full_size_background_rewrite_equals_dense_cml():
     torch.manual_seed(5)
     net = VoxelNet().to(DEV)
     old = cfg.config.get('convbackground', True)
+    from modules.layers import Blocks
+    old_r, Blocks.RESTRICTED_BACKWARD = Blocks.RESTRICTED_BACKWARD, True      # a pure chain: also cover the restricted backward
     res = {}
     try:
         for mode in (True, False):
@@ -312,6 +314,7 @@ def test_full_size_background_rewrite_equals_dense_cml():
                          {k: p.grad.clone() for k, p in net.cml.named_parameters() if p.grad is not None})
     finally:
         cfg.config['convbackground'] = old
+        Blocks.RESTRICTED_BACKWARD = old_r
     assert rel_err(res[True][0], res[False][0]) < 1e-5
     assert rel_err(res[True][1], res[False][1]) < 2e-4
     for k in res[False][2]:
