@@ -270,11 +270,17 @@ def main():
         ms = sum(s.elapsed_time(e) for s, e, _ in ev)
         fl = sum(f for _, _, f in ev)
         bg = tm.get('conv3d_gather_bg', []) if math != 'bf16x3' else []
+        dense_fl = fl
         if bg:
             # forward launches with the background rewrite: EXECUTED FLOPs from the kernel's own stage counter
+            # (the timer's own figure is the dense-equivalent work of the launch)
             ms += sum(s.elapsed_time(e) for s, e, _ in bg)
             fl += float(exec_stages[run]) * _hip.STAGE_FLOP
+            dense_fl += sum(f for _, _, f in bg)
             ev = ev + bg
+        tiles = tm.get('conv3d_gather_tiles', []) if math != 'bf16x3' else []
+        ms_all = ms + sum(s.elapsed_time(e) for s, e, _ in tiles)
+        dense_all = dense_fl + sum(f for _, _, f in tiles)
         if math == 'bf16x3':
             peak, mult, note = BF16_MFMA_PEAK_TFLOPS, 3.0, ('executed bf16 MFMA FLOPs = 3 x algorithmic '
                                                              '(hi*hi + hi*lo + lo*hi per product)')
@@ -285,6 +291,8 @@ def main():
                 'kernel': name + ' (conv2/conv3 forward + dgrad launches)', 'launches': len(ev),
                 'avg_launch_ms': ms / max(1, len(ev)), 'flop_per_launch': fl / max(1, len(ev)),
                 'fp32_equivalent_tflops': fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                # what a dense evaluation of the same launches (incl. the tile-restricted dgrads) would have to sustain
+                'dense_equivalent_tflops': dense_all / (ms_all * 1e-3) / 1e12 if ms_all > 0 else 0.0,
                 'note': note + ('; forward launches skip voxel-free tiles (convbackground): FLOPs are the EXECUTED ones, '
                                 'counted by the kernel' if bg else '')}
 

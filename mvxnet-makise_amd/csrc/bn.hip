@@ -122,7 +122,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const float *__restrict__ d
 __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dyh, const float *__restrict__ y,
                                                     const float *__restrict__ mi, const double *__restrict__ sums,
                                                     double count, float *__restrict__ dz, double *__restrict__ dbias,
-                                                    const float *__restrict__ row_w, size_t rows, int C) {
+                                                    const float *__restrict__ row_w, size_t rows, int C,
+                                                    unsigned *__restrict__ done_counter, float *__restrict__ dbias_out,
+                                                    int accumulate) {
     __shared__ double red[256][4];
     const int c4 = C >> 2;
     const int rpi = max(1, 256 / c4);
@@ -181,6 +183,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dy
             __syncthreads();
         }
     }
+    if (dbias && done_counter) {
+        // the workgroup that finishes last folds the replicas into the bias gradient (no dbias_finish launch);
+        // atomics-only protocol as in bn_finalize_by_last_block (common.h)
+        __shared__ int s_last;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = (atomicAdd(done_counter, 1u) == gridDim.x - 1u);
+        __syncthreads();
+        if (s_last) {
+            for (int i = threadIdx.x; i < C; i += blockDim.x) {
+                double v[REP];
+#pragma unroll
+                for (int rp = 0; rp < REP; ++rp)
+                    v[rp] = __hip_atomic_load(dbias + (size_t)rp * 3 * C + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                double t = 0.0;
+#pragma unroll
+                for (int rp = 0; rp < REP; ++rp) t += v[rp];
+                dbias_out[i] = accumulate ? dbias_out[i] + (float)t : (float)t;
+            }
+        }
+    }
 }
 
 // dbias[c] = sum over replicas of scratch[rep][2][c]
@@ -232,7 +255,8 @@ extern "C" int mvx_row_stats(const float *y, double *stats, int64_t rows, int32_
 }
 
 extern "C" size_t mvx_bn_backward_scratch_bytes(int32_t channels) {
-    return channels > 0 ? sizeof(double) * REP * 3 * (size_t)channels : 0;
+    // replicated sums + one slot for the "last workgroup" counter of the fused bias-gradient reduction
+    return channels > 0 ? sizeof(double) * (REP * 3 * (size_t)channels + 1) : 0;
 }
 
 extern "C" int mvx_bn_relu_backward(const float *dyhat, const float *y, const float *mean_inv, double count,
@@ -242,7 +266,7 @@ extern "C" int mvx_bn_relu_backward(const float *dyhat, const float *y, const fl
     MVX_CHECK_ARG(count > 0);
     hipStream_t st = (hipStream_t)stream;
     if (!(flags & MVX_FLAG_PREZEROED)) {
-        hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * REP * 3 * channels, st);
+        hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * (REP * 3 * channels + 1), st);
         if (e != hipSuccess) return (int)e;
     }
     if (rows > 0) {
@@ -250,10 +274,10 @@ extern "C" int mvx_bn_relu_backward(const float *dyhat, const float *y, const fl
         hipLaunchKernelGGL(bn_bwd_reduce, dim3(grid), dim3(256), 0, st, dyhat, y, mean_inv, scratch, (size_t)rows, channels);
         MVX_LAUNCH_CHECK();
         hipLaunchKernelGGL(bn_bwd_apply, dim3(grid), dim3(256), 0, st, dyhat, y, mean_inv, (const double *)scratch, count,
-                           dz, dbias ? scratch + 2 * channels : (double *)nullptr, row_w, (size_t)rows, channels);
+                           dz, dbias ? scratch + 2 * channels : (double *)nullptr, row_w, (size_t)rows, channels,
+                           (unsigned *)(scratch + (size_t)REP * 3 * channels), dbias, flags & MVX_FLAG_ACCUMULATE);
         MVX_LAUNCH_CHECK();
-    }
-    if (dbias) {
+    } else if (dbias) {                             // no rows: the bias gradient is zero
         hipLaunchKernelGGL(dbias_finish, dim3(mvx_cdiv(channels, 128)), dim3(128), 0, st, (const double *)scratch, dbias,
                            channels, flags & MVX_FLAG_ACCUMULATE);
         MVX_LAUNCH_CHECK();

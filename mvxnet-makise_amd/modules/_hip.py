@@ -521,7 +521,7 @@ def conv3d_dgrad_tiles(dz, wpk_d, din, cin, sd, pd, tflag):
     """Input gradient on the flagged tiles only; the rest of the returned tensor is NOT initialised."""
     dout, H, W, cout = dz.shape
     dx = torch.empty((din, H, W, cin), dtype=torch.float32, device=dz.device)
-    with _Timed('conv3d_gather_tiles', 0):
+    with _Timed('conv3d_gather_tiles', conv_flops(din, dout, H, W, cout, cin, sd, pd, True) if KERNEL_TIMERS is not None else 0):   # dense-equivalent
         X.check(X.lib.mvx_conv3d_dgrad_tiles(X.ptr(dz), X.ptr(wpk_d), X.ptr(dx), din, dout, H, W, cin, cout, sd, pd,
                                              X.ptr(tflag), X.stream()), 'mvx_conv3d_dgrad_tiles')
     return dx
@@ -566,7 +566,7 @@ def conv3d_forward_bg(x, wpk, bias, cout, sd, pd, bg_in, out_mask, bg_pre, relu=
         if fin is None:
             fin = torch.zeros((1,), dtype=torch.float64, device=x.device)
         mi = torch.empty((2, cout), dtype=torch.float32, device=x.device)
-    with _Timed('conv3d_gather_bg', 0):
+    with _Timed('conv3d_gather_bg', conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None else 0):   # dense-equivalent
         X.check(X.lib.mvx_conv3d_forward_bg(X.ptr(x), X.ptr(wpk), X.ptr(bias), X.ptr(out), X.ptr(stats), din, dout, H, W,
                                             cin, cout, sd, pd, flags, X.ptr(bg_in.hflag), X.ptr(out_mask), X.ptr(bg_pre),
                                             1, X.ptr(counter), X.ptr(fin), npos, float(finalize_eps or 0.0), X.ptr(mi),
