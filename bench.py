@@ -194,6 +194,7 @@ def main():
     from modules import pipeline as pl_mod
     pending = [None]
     step_events = []
+    debug_sleep_ms = float(os.environ.get('MVX_DEBUG_HOST_DELAY_MS', '0'))
     pipelined = os.environ.get('MVX_PIPELINE_INPUT', '0') != '0'      # measured: 218 vs 249 frames/s -> off
 
     def step():
@@ -212,6 +213,10 @@ def main():
             pending[0] = pl_mod.prepare_begin(batch)
         tt.append(time.perf_counter())
         bucket.zero()
+        if debug_sleep_ms > 0:                       # host-slack probe: busy-wait on the host before enqueuing the frames
+            t_end = time.perf_counter() + debug_sleep_ms * 1e-3
+            while time.perf_counter() < t_end:
+                pass
         nv, statuses = train_step_frames(model, batch, grad_mid, imsize, ready=ready)
         tt.append(time.perf_counter())
         if pipelined:
