@@ -128,6 +128,11 @@ __global__ void vox_insert(const float *__restrict__ pcd, const int *__restrict_
     w.slot_of[(size_t)f * cap + s] = (int)h;
 }
 
+// One workgroup per frame.  Each thread owns a CONTIGUOUS run of stream positions (then of voxel ids), issues all its
+// dependent loads up front, scans its run locally and takes part in ONE block scan per phase -- the previous form
+// walked the stream in 1024-element rounds with a block scan (three barriers and two dependent loads) per round:
+// 25 serial rounds = 50 us per call whatever the batch size.
+constexpr int SCAN_K = 8;                 // positions per thread per pass (1024 x 8 = 8192 positions per pass)
 __global__ __launch_bounds__(1024) void vox_scan(const int *__restrict__ n_points, int cap, int cap_voxels,
                                                  VoxWs w, int *n_voxels, int *status) {
     __shared__ int smem[17];
@@ -140,20 +145,25 @@ __global__ __launch_bounds__(1024) void vox_scan(const int *__restrict__ n_point
     int *vox_slot = w.vox_slot + (size_t)f * cap;
     int *seg_off = w.seg_off + (size_t)f * (cap + 1);
     int base = 0;
-    for (int t0 = 0; t0 < n; t0 += blockDim.x) {
-        const int s = t0 + threadIdx.x;
-        int slot = -1, flag = 0;
-        if (s < n) {
-            slot = slot_of[s];
-            flag = first[slot] == s;
+    for (int t0 = 0; t0 < n; t0 += blockDim.x * SCAN_K) {
+        const int s0 = t0 + threadIdx.x * SCAN_K;
+        int slot[SCAN_K], flag[SCAN_K], mine = 0;
+#pragma unroll
+        for (int j = 0; j < SCAN_K; ++j) slot[j] = s0 + j < n ? slot_of[s0 + j] : -1;
+#pragma unroll
+        for (int j = 0; j < SCAN_K; ++j) {
+            flag[j] = slot[j] >= 0 && first[slot[j]] == s0 + j;       // "I am my voxel's first point"
+            mine += flag[j];
         }
         int tot;
-        const int ex = block_excl_scan_i32(flag, smem, &tot);
-        if (flag) {
-            const int v = base + ex;
-            slot_vid[slot] = v;
-            vox_slot[v] = slot;
-        }
+        int v = base + block_excl_scan_i32(mine, smem, &tot);
+#pragma unroll
+        for (int j = 0; j < SCAN_K; ++j)
+            if (flag[j]) {
+                slot_vid[slot[j]] = v;
+                vox_slot[v] = slot[j];
+                ++v;
+            }
         base += tot;
     }
     const int V = base;
@@ -163,12 +173,24 @@ __global__ __launch_bounds__(1024) void vox_scan(const int *__restrict__ n_point
     }
     __syncthreads();   // vox_slot[] written above is read below by other threads of this block
     int run = 0;
-    for (int t0 = 0; t0 < V; t0 += blockDim.x) {
-        const int v = t0 + threadIdx.x;
-        const int c = v < V ? scount[vox_slot[v]] : 0;
+    for (int t0 = 0; t0 < V; t0 += blockDim.x * SCAN_K) {
+        const int v0 = t0 + threadIdx.x * SCAN_K;
+        int c[SCAN_K], mine = 0;
+#pragma unroll
+        for (int j = 0; j < SCAN_K; ++j) c[j] = v0 + j < V ? vox_slot[v0 + j] : -1;
+#pragma unroll
+        for (int j = 0; j < SCAN_K; ++j) {
+            c[j] = c[j] >= 0 ? scount[c[j]] : 0;
+            mine += c[j];
+        }
         int tot;
-        const int ex = block_excl_scan_i32(c, smem, &tot);
-        if (v < V) seg_off[v] = run + ex;
+        int off = run + block_excl_scan_i32(mine, smem, &tot);
+#pragma unroll
+        for (int j = 0; j < SCAN_K; ++j)
+            if (v0 + j < V) {
+                seg_off[v0 + j] = off;
+                off += c[j];
+            }
         run += tot;
     }
     if (threadIdx.x == 0) seg_off[V] = run;
