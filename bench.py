@@ -289,6 +289,9 @@ def main():
         if math == 'bf16x3':
             peak, mult, note = BF16_MFMA_PEAK_TFLOPS, 3.0, ('executed bf16 MFMA FLOPs = 3 x algorithmic '
                                                              '(hi*hi + hi*lo + lo*hi per product)')
+            if cfg.config.get('convbackground', True):
+                note += ('; the background-aware launches are priced at their DENSE FLOPs (the bf16x3 kernels carry no '
+                         'stage counter): an upper bound on the executed rate')
         else:
             peak, mult, note = FP32_MFMA_PEAK_TFLOPS, 1.0, 'exact f32 MFMA, executed = algorithmic FLOPs'
         ach = mult * fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0

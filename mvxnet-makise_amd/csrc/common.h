@@ -20,6 +20,13 @@
 
 static inline unsigned mvx_cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
 
+// ---- internal helpers shared between translation units (NOT part of the C ABI) -----------------------
+// conv3d.hip: compacted (plane, tile) step lists of the background-aware weight gradient and its closed-form term
+int mvxi_wgrad_step_list(const int32_t *in_halo_flags, int din, int dout, int ntiles, int stride_d, int pad_d, int *list,
+                         int *count, hipStream_t st);
+int mvxi_wgrad_rank1(const float *tap_sums, const float *c_in, float *dw, int din, int dout, int cin, int cout, int stride_d,
+                     int pad_d, hipStream_t st);
+
 // ---- wave / block reductions and scans -------------------------------------------------
 __device__ __forceinline__ int wave_incl_scan_i32(int v) {
     const int lane = threadIdx.x & 63;

@@ -84,7 +84,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_split(const float *__res
                                                               const unsigned short *__restrict__ wsp,
                                                               const float *__restrict__ bias,
                                                               float *__restrict__ out, double *__restrict__ stats,
-                                                              Geom g, int relu) {
+                                                              Geom g, int relu, const int *__restrict__ in_hflag,
+                                                              const unsigned char *__restrict__ out_mask,
+                                                              const float *__restrict__ bg_pre, int border_active,
+                                                              const int *__restrict__ only_tiles) {
     __shared__ __attribute__((aligned(16))) unsigned char s_halo[HH * HW * ROWB];
     __shared__ __attribute__((aligned(16))) unsigned char s_w[3][BN * ROWB];
     __shared__ float s_red[4][2 * BN];
@@ -93,6 +96,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_split(const float *__res
     const int d = blockIdx.y, nb = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int nchunks = g.Cin / BK;
+    // background rewrite (see conv3d.hip / activity.hip): restricted launches and constant tiles
+    if (only_tiles && !only_tiles[(size_t)d * gridDim.x + blockIdx.x]) return;
+    bool active = true;
+    if (in_hflag) {
+        int any = border_active && (tx0 == 0 || ty0 == 0 || tx0 + TW >= g.W || ty0 + TH >= g.H);
+        for (int kd = 0; kd < 3; ++kd) {
+            const int ds = src_depth(g, d, kd);
+            if (ds >= 0) any |= in_hflag[(size_t)ds * gridDim.x + blockIdx.x];
+        }
+        active = any != 0;
+    }
 
     f32x16 acc0, acc1;
 #pragma unroll
@@ -123,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_split(const float *__res
         }
     };
 
-    for (int kd = 0; kd < 3; ++kd) {
+    for (int kd = 0; kd < 3 && active; ++kd) {
         const int ds = src_depth(g, d, kd);
         if (ds < 0) continue;
         for (int cc = 0; cc < nchunks; ++cc) {
@@ -175,6 +189,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_split(const float *__res
 
     const int n0 = nb * BN + li, n1 = n0 + 32;
     const float bias0 = bias ? bias[n0] : 0.f, bias1 = bias ? bias[n1] : 0.f;
+    float bgv0 = (bg_pre ? bg_pre[(size_t)d * g.Cout + n0] : 0.f) + bias0, bgv1 = (bg_pre ? bg_pre[(size_t)d * g.Cout + n1] : 0.f) + bias1;
+    if (relu) { bgv0 = fmaxf(bgv0, 0.f); bgv1 = fmaxf(bgv1, 0.f); }
     float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -182,6 +198,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_split(const float *__res
         const int gy = ty0 + 2 * wv + (row >> 4), gx = tx0 + (row & 15);
         float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
         if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+        if (out_mask && gy < g.H && gx < g.W) {
+            if (!active || !out_mask[((size_t)d * g.H + gy) * g.W + gx]) { v0 = bgv0; v1 = bgv1; }
+        }
         if (gy < g.H && gx < g.W) {
             float *o = out + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout;
             o[n0] = v0;
@@ -235,7 +254,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned short *row0, const unsi
 __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_split(const float *__restrict__ in,
                                                                  const float *__restrict__ dz,
                                                                  float *__restrict__ slabs, Geom g,
-                                                                 int tiles_per_strip) {
+                                                                 int tiles_per_strip, const int *__restrict__ step_list,
+                                                                 const int *__restrict__ step_count,
+                                                                 const float *__restrict__ c_in) {
     __shared__ __attribute__((aligned(16))) unsigned short s_xh[HH * HW][BK], s_xl[HH * HW][BK];
     __shared__ __attribute__((aligned(16))) unsigned short s_zh[2][TH * TW][32], s_zl[2][TH * TW][32];
     const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
@@ -253,12 +274,34 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_split(const float *__
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 
-    const int t_beg = strip * tiles_per_strip;
-    const int t_end = min(ntiles, t_beg + tiles_per_strip);
+    // steps: dense = (valid plane) x (tile of the strip); background-aware = entries of the compacted list of this depth
+    // tap dealt round-robin to the strips (see conv3d_wgrad4 in conv3d.hip)
+    const int nstrips = gridDim.x;
+    int dlo = 0, dhi = -1;
+    for (int dd = 0; dd < g.Dout; ++dd) {
+        const int ds = dd * g.sd - g.pd + kd;
+        if (ds >= 0 && ds < g.Din) { if (dhi < 0) dlo = dd; dhi = dd; }
+    }
+    const int nd = dhi >= dlo ? dhi - dlo + 1 : 0;
+    const int per = tiles_per_strip;
+    const int *my_list = step_list ? step_list + (size_t)kd * g.Dout * ntiles : nullptr;
+    const int nlist = step_list ? step_count[kd] : 0;
+    const int nsteps = step_list ? (nlist > strip ? (nlist - strip + nstrips - 1) / nstrips : 0) : nd * per;
+    auto step_of = [&](int i, int &d, int &t) {
+        if (my_list) { const int e = my_list[strip + i * nstrips]; d = e / ntiles; t = e - d * ntiles; }
+        else { d = dlo + i / per; t = strip * per + i % per; }
+    };
+    auto next_live = [&](int i) {
+        if (!my_list)
+            while (i < nsteps && strip * per + i % per >= ntiles) ++i;
+        return i < nsteps ? i : nsteps;
+    };
     constexpr int NX = (HH * HW * 8 + WG_THREADS - 1) / WG_THREADS;
     constexpr int NZ = (TH * TW * 16 + WG_THREADS - 1) / WG_THREADS;
     float4 xr[NX], zr[NZ];
-    auto load_step = [&](int d, int t) {
+    auto load_step = [&](int i) {
+        int d, t;
+        step_of(i, d, t);
         const int ds = d * g.sd - g.pd + kd;
         const int tx0 = (t % tiles_x) * TW, ty0 = (t / tiles_x) * TH;
 #pragma unroll
@@ -268,8 +311,14 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_split(const float *__
             if (c < HH * HW * 8) {
                 const int r = c >> 3, part = c & 7;
                 const int gy = ty0 - 1 + r / HW, gx = tx0 - 1 + r % HW;
-                if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W)
-                    xr[u] = *(const float4 *)(in + (((size_t)ds * g.H + gy) * g.W + gx) * g.Cin + cc * BK + part * 4);
+                if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) {
+                    float4 v = *(const float4 *)(in + (((size_t)ds * g.H + gy) * g.W + gx) * g.Cin + cc * BK + part * 4);
+                    if (c_in) {
+                        const float4 cb = *(const float4 *)(c_in + (size_t)ds * g.Cin + cc * BK + part * 4);
+                        v.x -= cb.x; v.y -= cb.y; v.z -= cb.z; v.w -= cb.w;
+                    }
+                    xr[u] = v;
+                }
             }
         }
 #pragma unroll
@@ -284,18 +333,9 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_split(const float *__
             }
         }
     };
-    auto next_valid = [&](int d) {
-        while (d < g.Dout) {
-            const int ds = d * g.sd - g.pd + kd;
-            if (ds >= 0 && ds < g.Din) break;
-            ++d;
-        }
-        return d;
-    };
-    int d = next_valid(0), t = t_beg;
-    const bool any = d < g.Dout && t_beg < t_end;
-    if (any) load_step(d, t);
-    while (any && d < g.Dout) {
+    int cur = next_live(0);
+    if (cur < nsteps) load_step(cur);
+    while (cur < nsteps) {
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
@@ -319,9 +359,8 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_split(const float *__
             }
         }
         __syncthreads();
-        int nt = t + 1, nd = d;
-        if (nt >= t_end) { nt = t_beg; nd = next_valid(d + 1); }
-        if (nd < g.Dout) load_step(nd, nt);
+        const int nxt = next_live(cur + 1);
+        if (nxt < nsteps) load_step(nxt);
 #pragma unroll 2
         for (int ks = 0; ks < TH; ++ks) {                 // 16 sites (one patch row) per MFMA k-step
             const int hr0 = (ks + ta) * HW + tb + kbase + q, hr1 = hr0 + 4;      // halo rows of sites kbase+q, +4
@@ -339,7 +378,7 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_split(const float *__
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0h, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1h, acc1, 0, 0, 0);
         }
-        t = nt; d = nd;
+        cur = nxt;
     }
     float *o = slabs + ((((size_t)strip * 3 + kd) * 9 + tap) * g.Cin + cc * BK) * BN;
 #pragma unroll
@@ -400,23 +439,60 @@ extern "C" int mvx_conv3d_forward_split(const float *in, const void *wsplit, con
     }
     Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
     hipLaunchKernelGGL(conv3d_gather_split, dim3(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), dout, cout / BN), dim3(256), 0, st, in,
-                       (const unsigned short *)wsplit, bias, out, stats, g, relu);
+                       (const unsigned short *)wsplit, bias, out, stats, g, relu, (const int *)nullptr,
+                       (const unsigned char *)nullptr, (const float *)nullptr, 0, (const int *)nullptr);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
 
-extern "C" int mvx_conv3d_dgrad_split(const float *dz, const void *wsplit_dgrad, float *dx, int32_t din, int32_t dout,
-                                      int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
-                                      void *stream) {
+extern "C" int mvx_conv3d_forward_bg_split(const float *in, const void *wsplit, const float *bias, float *out, double *stats,
+                                           int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                                           int32_t stride_d, int32_t pad_d, int32_t flags, const int32_t *in_halo_flags,
+                                           const uint8_t *out_mask, const float *bg_pre, int32_t border_active,
+                                           void *stream) {
+    MVX_CHECK_ARG(in && wsplit && out && in_halo_flags && out_mask && bg_pre);
+    int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
+    if (rc) return rc;
+    MVX_CHECK_ARG(dout == (din + 2 * pad_d - 3) / stride_d + 1);
+    hipStream_t st = (hipStream_t)stream;
+    if (stats && !(flags & MVX_FLAG_PREZEROED)) {
+        hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * MVX_REP * 2 * cout, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
+    hipLaunchKernelGGL(conv3d_gather_split, dim3(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), dout, cout / BN), dim3(256), 0, st, in,
+                       (const unsigned short *)wsplit, bias, out, stats, g, flags & MVX_FLAG_RELU, in_halo_flags, out_mask,
+                       bg_pre, border_active, (const int *)nullptr);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+static int launch_dgrad_split(const float *dz, const void *wsplit_dgrad, float *dx, int32_t din, int32_t dout, int32_t h,
+                              int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
+                              const int32_t *only_tiles, void *stream) {
     MVX_CHECK_ARG(dz && wsplit_dgrad && dx);
     int rc = check_geom(din, dout, h, w, cout, cin, stride_d, pad_d);
     if (rc) return rc;
     Geom g{dout, din, h, w, cout, cin, stride_d, pad_d, 1};
     hipLaunchKernelGGL(conv3d_gather_split, dim3(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), din, cin / BN), dim3(256), 0,
                        (hipStream_t)stream, dz, (const unsigned short *)wsplit_dgrad, (const float *)nullptr, dx,
-                       (double *)nullptr, g, 0);
+                       (double *)nullptr, g, 0, (const int *)nullptr, (const unsigned char *)nullptr,
+                       (const float *)nullptr, 0, only_tiles);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
+}
+
+extern "C" int mvx_conv3d_dgrad_tiles_split(const float *dz, const void *wsplit_dgrad, float *dx, int32_t din, int32_t dout,
+                                            int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d,
+                                            int32_t pad_d, const int32_t *dx_tile_flags, void *stream) {
+    MVX_CHECK_ARG(dx_tile_flags);
+    return launch_dgrad_split(dz, wsplit_dgrad, dx, din, dout, h, w, cin, cout, stride_d, pad_d, dx_tile_flags, stream);
+}
+
+extern "C" int mvx_conv3d_dgrad_split(const float *dz, const void *wsplit_dgrad, float *dx, int32_t din, int32_t dout,
+                                      int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
+                                      void *stream) {
+    return launch_dgrad_split(dz, wsplit_dgrad, dx, din, dout, h, w, cin, cout, stride_d, pad_d, nullptr, stream);
 }
 
 extern "C" int mvx_conv3d_wgrad_split(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
@@ -437,11 +513,51 @@ extern "C" int mvx_conv3d_wgrad_split(const float *in, const float *dz, float *d
     Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(conv3d_wgrad_split, dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz,
-                       (float *)workspace, g, per);
+                       (float *)workspace, g, per, (const int *)nullptr, (const int *)nullptr, (const float *)nullptr);
     MVX_LAUNCH_CHECK();
     const size_t per_slab = (size_t)27 * cin * BN;
     hipLaunchKernelGGL(wgrad_reduce_split, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)workspace, dw,
                        nstrips, cin, flags & MVX_FLAG_ACCUMULATE);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
+}
+
+// background-aware weight gradient, bf16x3: same decomposition as mvx_conv3d_wgrad_bg (conv3d.hip)
+static int wgrad_bg_split_strips(int cin) {
+    const int s = 256 / (3 * (cin / BK));
+    return s < 1 ? 1 : s;
+}
+
+extern "C" size_t mvx_conv3d_wgrad_bg_split_workspace_bytes(int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout) {
+    if (dout <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout != BN || cin % BK) return 0;
+    const size_t ntiles = (size_t)mvx_cdiv(w, TW) * mvx_cdiv(h, TH);
+    return (size_t)wgrad_bg_split_strips(cin) * 27 * cin * BN * sizeof(float) + sizeof(int) * (3 * dout * ntiles + 4);
+}
+
+extern "C" int mvx_conv3d_wgrad_bg_split(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
+                                         int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
+                                         int32_t flags, const int32_t *in_halo_flags, const float *c_in,
+                                         const float *tap_sums, void *workspace, size_t workspace_bytes, void *stream) {
+    MVX_CHECK_ARG(in && dz && dw && workspace && in_halo_flags && c_in && tap_sums);
+    int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
+    if (rc) return rc;
+    if (cout != BN) return MVX_ESIZE;
+    MVX_CHECK_ARG(workspace_bytes >= mvx_conv3d_wgrad_bg_split_workspace_bytes(dout, h, w, cin, cout));
+    const int ntiles = (int)(mvx_cdiv(w, TW) * mvx_cdiv(h, TH));
+    const int nstrips = wgrad_bg_split_strips(cin);
+    Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
+    hipStream_t st = (hipStream_t)stream;
+    float *slabs = (float *)workspace;
+    int *list = (int *)((char *)workspace + (size_t)nstrips * 27 * cin * BN * sizeof(float));
+    int *count = list + (size_t)3 * dout * ntiles;
+    rc = mvxi_wgrad_step_list(in_halo_flags, din, dout, ntiles, stride_d, pad_d, list, count, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(conv3d_wgrad_split, dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz, slabs, g, 0,
+                       (const int *)list, (const int *)count, c_in);
+    MVX_LAUNCH_CHECK();
+    const size_t per_slab = (size_t)27 * cin * BN;
+    hipLaunchKernelGGL(wgrad_reduce_split, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)slabs, dw, nstrips,
+                       cin, flags & MVX_FLAG_ACCUMULATE);
+    MVX_LAUNCH_CHECK();
+    return mvxi_wgrad_rank1(tap_sums, c_in, dw, din, dout, cin, cout, stride_d, pad_d, st);
 }

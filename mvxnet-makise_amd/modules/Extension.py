@@ -85,6 +85,11 @@ PROTOTYPES = {
     'mvx_linear_forward_bn': (_i32, [_p, _i32, _p, _i32, _i32, _p, _p, _i32, _p, _p, _i64, _i32, _i32, _i32, _p, _f64, _f64, _p, _p]),
     'mvx_conv3d_wgrad_bg_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32, _i32]),
     'mvx_conv3d_wgrad_bg': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
+    'mvx_conv3d_forward_bg_split': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p,
+                                           _i32, _p]),
+    'mvx_conv3d_dgrad_tiles_split': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
+    'mvx_conv3d_wgrad_bg_split_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    'mvx_conv3d_wgrad_bg_split': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
     'mvx_plane_tap_sums_workspace_bytes': (_sz, [_i32, _i32]),
     'mvx_plane_tap_sums': (_i32, [_p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
     'mvx_tile_dilate_flags': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),

@@ -517,10 +517,15 @@ def conv3d_input_grad_sums(w, T, din, sd, pd):
     return A
 
 
-def conv3d_dgrad_tiles(dz, wpk_d, din, cin, sd, pd, tflag):
+def conv3d_dgrad_tiles(dz, wpk_d, din, cin, sd, pd, tflag, split=False):
     """Input gradient on the flagged tiles only; the rest of the returned tensor is NOT initialised."""
     dout, H, W, cout = dz.shape
     dx = torch.empty((din, H, W, cin), dtype=torch.float32, device=dz.device)
+    if split:
+        with _Timed('conv3d_gather_split', 0):
+            X.check(X.lib.mvx_conv3d_dgrad_tiles_split(X.ptr(dz), X.ptr(wpk_d), X.ptr(dx), din, dout, H, W, cin, cout, sd, pd,
+                                                       X.ptr(tflag), X.stream()), 'mvx_conv3d_dgrad_tiles_split')
+        return dx
     with _Timed('conv3d_gather_tiles', conv_flops(din, dout, H, W, cout, cin, sd, pd, True) if KERNEL_TIMERS is not None else 0):   # dense-equivalent
         X.check(X.lib.mvx_conv3d_dgrad_tiles(X.ptr(dz), X.ptr(wpk_d), X.ptr(dx), din, dout, H, W, cin, cout, sd, pd,
                                              X.ptr(tflag), X.stream()), 'mvx_conv3d_dgrad_tiles')
@@ -547,14 +552,24 @@ def bn_relu_backward_tiles(dyhat, y, mi, bg, plane_grad_sums, dbias_out=None, wa
     return (dz, db, inact) if want_inactive_sums else (dz, db)
 
 
-def conv3d_forward_bg(x, wpk, bias, cout, sd, pd, bg_in, out_mask, bg_pre, relu=True, want_stats=True, finalize_eps=None):
-    """finalize_eps: also form the BatchNorm mean / inverse std in the kernel (returns (y, mean_inv) then)."""
+def conv3d_forward_bg(x, wpk, bias, cout, sd, pd, bg_in, out_mask, bg_pre, relu=True, want_stats=True, finalize_eps=None,
+                      split=False):
+    """finalize_eps: also form the BatchNorm mean / inverse std in the kernel (returns (y, mean_inv) then).
+    split=True: bf16x3 kernel (wpk from conv3d_pack(..., split=True)); the statistics are finalised separately."""
     global EXEC_STAGES
     din, H, W, cin = x.shape
     dout = conv_out_depth(din, sd, pd)
     out = torch.empty((dout, H, W, cout), dtype=torch.float32, device=x.device)
     stats, fz = _acc_f64((STATS_REPLICAS, 2, cout), x.device) if want_stats else (None, 0)
     flags = (FLAG_RELU if relu else 0) | fz
+    if split:
+        with _Timed('conv3d_gather_split', conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None else 0):
+            X.check(X.lib.mvx_conv3d_forward_bg_split(X.ptr(x), X.ptr(wpk), X.ptr(bias), X.ptr(out), X.ptr(stats), din, dout,
+                                                      H, W, cin, cout, sd, pd, flags, X.ptr(bg_in.hflag), X.ptr(out_mask),
+                                                      X.ptr(bg_pre), 1, X.stream()), 'mvx_conv3d_forward_bg_split')
+        if finalize_eps is not None and want_stats:
+            return out, bn_finalize(stats, float(dout * H * W), finalize_eps)
+        return out, stats
     counter = None
     if KERNEL_TIMERS is not None:
         if EXEC_STAGES is None:
@@ -574,20 +589,22 @@ def conv3d_forward_bg(x, wpk, bias, cout, sd, pd, bg_in, out_mask, bg_pre, relu=
     return (out, mi) if mi is not None else (out, stats)
 
 
-def conv3d_wgrad_bg(x, dz, sd, pd, bg_in, tap_sums=None, accumulate_into=None):
+def conv3d_wgrad_bg(x, dz, sd, pd, bg_in, tap_sums=None, accumulate_into=None, split=False):
     din, H, W, cin = x.shape
     dout, _, _, cout = dz.shape
     if accumulate_into is not None:
         dw, flags = accumulate_into, FLAG_ACCUMULATE
     else:
         dw, flags = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device=x.device), 0
-    nbytes = X.lib.mvx_conv3d_wgrad_bg_workspace_bytes(dout, H, W, cin, cout)
+    fn_bytes = X.lib.mvx_conv3d_wgrad_bg_split_workspace_bytes if split else X.lib.mvx_conv3d_wgrad_bg_workspace_bytes
+    fn = X.lib.mvx_conv3d_wgrad_bg_split if split else X.lib.mvx_conv3d_wgrad_bg
+    nbytes = fn_bytes(dout, H, W, cin, cout)
     if tap_sums is None:
         tap_sums = plane_tap_sums(dz)
     with _wgrad_scope(accumulate_into, x, dz) as scope:
         ws = workspace(nbytes, x.device, 'wgrad_bg_side' if isinstance(scope, _SideStream) else 'wgrad_bg')
         with _Timed('conv3d_wgrad_bg', 0):
-            X.check(X.lib.mvx_conv3d_wgrad_bg(X.ptr(x), X.ptr(dz), X.ptr(dw), din, dout, H, W, cin, cout, sd, pd, flags,
+            X.check(fn(X.ptr(x), X.ptr(dz), X.ptr(dw), din, dout, H, W, cin, cout, sd, pd, flags,
                                               X.ptr(bg_in.hflag), X.ptr(bg_in.c), X.ptr(tap_sums), X.ptr(ws), ws.numel(),
                                               X.stream()),
                     'mvx_conv3d_wgrad_bg')

@@ -124,14 +124,12 @@ class CRB3dFunction(torch.autograd.Function):
         split = conv_split_math()
         wpk = _pack(packer, w, False, split)
         ctx.packer = packer
-        if split:
-            bg_in = None                     # the bf16x3 kernels have no background form yet
         if bg_in is not None:
             din, H, W, _ = x.shape
             bg_pre = _hip.conv3d_background(w, bg_in.c, din, sd, pd)
             out_mask, out_hflag, out_tflag = _hip.activity_dilate(bg_in.mask, False, din, H, W, sd, pd, mark_border=True,
                                                                   want_tile_flags=True)
-            y, mi = _hip.conv3d_forward_bg(x, wpk, b, cout, sd, pd, bg_in, out_mask, bg_pre, finalize_eps=eps)
+            y, mi = _hip.conv3d_forward_bg(x, wpk, b, cout, sd, pd, bg_in, out_mask, bg_pre, finalize_eps=eps, split=split)
             count = y.numel() // cout
         else:
             y, stats = _hip.conv3d_forward(x, wpk, b, cout, sd, pd, relu=True, want_stats=True, split=split)
@@ -171,7 +169,7 @@ class CRB3dFunction(torch.autograd.Function):
         if bg_in is not None and tap_sums is None:
             tap_sums = _hip.plane_tap_sums(dz)
         if bg_in is not None:
-            dw = _hip.conv3d_wgrad_bg(x, dz, sd, pd, bg_in, tap_sums, accumulate_into=_hip.sink_of(ctx.params[0]))
+            dw = _hip.conv3d_wgrad_bg(x, dz, sd, pd, bg_in, tap_sums, accumulate_into=_hip.sink_of(ctx.params[0]), split=split)
         else:
             dw = _hip.conv3d_wgrad(x, dz, sd, pd, split=split, accumulate_into=_hip.sink_of(ctx.params[0]))
         dx = None
@@ -179,7 +177,7 @@ class CRB3dFunction(torch.autograd.Function):
             wpd = _pack(ctx.packer, w, True, split)
             if bg_in is not None and bg_in.back is not None and bg_in.bflag is not None:
                 # the producer only needs the gradient on its bflag tiles plus per-plane sums (closed form)
-                dx = _hip.conv3d_dgrad_tiles(dz, wpd, x.shape[0], x.shape[3], sd, pd, bg_in.bflag)
+                dx = _hip.conv3d_dgrad_tiles(dz, wpd, x.shape[0], x.shape[3], sd, pd, bg_in.bflag, split=split)
                 bg_in.back['plane_grad_sums'] = _hip.conv3d_input_grad_sums(w, tap_sums, x.shape[0], sd, pd)
             else:
                 dx = _hip.conv3d_dgrad(dz, wpd, x.shape[0], x.shape[3], sd, pd, split=split)

@@ -263,6 +263,15 @@ def test_background_rewrite_equals_dense(shape):
     dw_bg = _hip.conv3d_wgrad_bg(x, dz, sd, pd, bg_in)
     dw_dn = _hip.conv3d_wgrad(x, dz, sd, pd)
     assert float((dw_bg - dw_dn).abs().max()) < 2e-5 * float(dw_dn.abs().max())
+    # the bf16x3 forms of the same two entry points against their dense bf16x3 counterparts
+    wps = _hip.conv3d_pack(w, False, split=True)
+    ys_bg, _ = _hip.conv3d_forward_bg(x, wps, b, cout, sd, pd, bg_in, out_mask, bg_pre, split=True)
+    ys_dn, _ = _hip.conv3d_forward(x, wps, b, cout, sd, pd, split=True)
+    assert float((ys_bg - ys_dn).abs().max()) < 1e-4 * scale
+    dws_bg = _hip.conv3d_wgrad_bg(x, dz, sd, pd, bg_in, split=True)
+    dws_dn = _hip.conv3d_wgrad(x, dz, sd, pd, split=True)
+    assert float((dws_bg - dws_dn).abs().max()) < 1e-4 * float(dws_dn.abs().max())
+    assert float((dws_bg - dw_dn).abs().max()) < 1e-4 * float(dw_dn.abs().max())
 
 
 @pytest.mark.gpu
