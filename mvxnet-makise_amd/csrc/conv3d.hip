@@ -868,6 +868,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_sites(const float *__restric
 // every wave walks all nine in-plane taps itself: 9 accumulator tiles (144 VGPRs), nine tap-shifted
 // A reads + one B read per MFMA step, two workgroups (8 waves, 2 per SIMD) per CU.
 // ------------------------------------------------------------------------------------------
+struct Strips { int n[3]; };       // workgroups (strips) per depth tap in list mode
 constexpr int W4_THREADS = 256;
 constexpr int W4_C = 64;               // input channels per workgroup
 
@@ -876,20 +877,23 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restr
                                                             float *__restrict__ slabs, Geom g,
                                                             int tiles_per_strip, const int *__restrict__ step_list,
                                                             const int *__restrict__ step_count,
-                                                            const float *__restrict__ c_in) {
+                                                            const float *__restrict__ c_in, Strips ks) {
     __shared__ __attribute__((aligned(16))) float s_x[HH * HW * W4_C];
     __shared__ __attribute__((aligned(16))) float s_z[TH * TW * ZP];
     const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
     const int ntiles = tiles_x * tiles_y;
-    const int strip = blockIdx.x, nstrips = gridDim.x;
     const int nchunks = g.Cin / W4_C;
     const int kd = blockIdx.y / nchunks, cc = blockIdx.y % nchunks;
+    // strips of this depth tap: the list mode hands each tap a share of the workgroups proportional to its number of
+    // valid planes (conv3: 1 / 2 / 1); the dense mode uses the whole grid for every tap
+    const int strip = blockIdx.x, nstrips = step_list ? (kd == 0 ? ks.n[0] : (kd == 1 ? ks.n[1] : ks.n[2])) : (int)gridDim.x;
+    if (strip >= nstrips) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wv >> 1, wn = wv & 1;
     const int nb = blockIdx.z;                       // 64-channel block of dz / dW (Cout = 64 * gridDim.z)
     dz += (size_t)nb * BN;
-    slabs += (size_t)nb * gridDim.x * 27 * g.Cin * BN;
+    slabs += (size_t)nb * gridDim.x * 27 * g.Cin * BN;       // slab index = blockIdx.x (gridDim.x = the largest share)
 
     f32x16 acc[9];
 #pragma unroll
@@ -1146,18 +1150,20 @@ __global__ void wgrad_rank1(const float *__restrict__ T, const float *__restrict
 
 // dW[co][ci][kd][kh][kw] = sum_strips slab[strip][kd][tap][ci][co]
 __global__ void wgrad_reduce(const float *__restrict__ slabs, float *__restrict__ dw, int nstrips, int Ci, int accumulate,
-                             int dst2d) {
+                             int dst2d, Strips ks) {
     const size_t per = (size_t)27 * Ci * BN;
     slabs += (size_t)blockIdx.y * nstrips * per;     // 64-channel block of the output channels
     dw += (size_t)blockIdx.y * (dst2d ? per / 3 : per);
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < per; e += (size_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < nstrips; ++k) s += slabs[(size_t)k * per + e];
         const int co = (int)(e % BN);
         size_t r = e / BN;
         const int ci = (int)(r % Ci); r /= Ci;
         const int tap = (int)(r % 9);
         const int kd = (int)(r / 9);
+        const int nkd = kd == 0 ? ks.n[0] : (kd == 1 ? ks.n[1] : ks.n[2]);
+        const int nk = nkd < nstrips ? nkd : nstrips;                // slabs that exist for this depth tap
+        float s = 0.f;
+        for (int k = 0; k < nk; ++k) s += slabs[(size_t)k * per + e];
         if (dst2d && kd != 1) continue;             // 2-D kernel gradient: the middle depth slice only
         float *dst = dst2d ? dw + (((size_t)co * Ci + ci) * 3 + tap / 3) * 3 + tap % 3
                            : dw + ((((size_t)co * Ci + ci) * 3 + kd) * 3 + tap / 3) * 3 + tap % 3;
@@ -1341,14 +1347,16 @@ extern "C" int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int
     hipStream_t st = (hipStream_t)stream;
     if (cin % W4_C == 0)
         hipLaunchKernelGGL(conv3d_wgrad4, dim3(nstrips, 3 * (cin / W4_C), nblk), dim3(W4_THREADS), 0, st, in, dz,
-                           (float *)workspace, g, per, (const int *)nullptr, (const int *)nullptr, (const float *)nullptr);
+                           (float *)workspace, g, per, (const int *)nullptr, (const int *)nullptr, (const float *)nullptr,
+                           Strips{{nstrips, nstrips, nstrips}});
     else
         hipLaunchKernelGGL(conv3d_wgrad, dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz,
                            (float *)workspace, g, per);
     MVX_LAUNCH_CHECK();
     const size_t per_slab = (size_t)27 * cin * BN;
     hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256), nblk), dim3(256), 0, st, (const float *)workspace, dw,
-                       nstrips, cin, flags & MVX_FLAG_ACCUMULATE, (flags & MVX_FLAG_CONV2D) ? 1 : 0);
+                       nstrips, cin, flags & MVX_FLAG_ACCUMULATE, (flags & MVX_FLAG_CONV2D) ? 1 : 0,
+                       Strips{{nstrips, nstrips, nstrips}});
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -1372,7 +1380,9 @@ extern "C" int mvx_conv3d_dgrad_sites(const float *dz, const float *wpk_dgrad, c
 // strips x 3 depth taps x channel chunks = 255..256 workgroups, steps dealt round-robin from the compacted lists.
 // workspace: [slabs][R f64 replicas][T][step lists][step counts]
 static int wgrad_bg_strips(int cin) {
-    const int s = 256 / (3 * (cin / W4_C));
+    // slab capacity per depth tap: up to half of the 256 workgroups of a chunk set (the busiest tap of a stride-2
+    // layer has twice the planes of the others)
+    const int s = 128 / (cin / W4_C);
     return s < 1 ? 1 : s;
 }
 static size_t wgrad_bg_slab_bytes(int cin) { return (size_t)wgrad_bg_strips(cin) * 27 * cin * BN * sizeof(float); }
@@ -1447,20 +1457,39 @@ extern "C" int mvx_conv3d_wgrad_bg(const float *in, const float *dz, float *dw, 
     if (cout != BN || cin % W4_C) return MVX_ESIZE;
     MVX_CHECK_ARG(workspace_bytes >= mvx_conv3d_wgrad_bg_workspace_bytes(dout, h, w, cin, cout));
     const int ntiles = (int)(mvx_cdiv(w, TW) * mvx_cdiv(h, TH));
-    const int nstrips = wgrad_bg_strips(cin);
+    const int nstrips = wgrad_bg_strips(cin);       // slab capacity = the largest share a depth tap can get
     Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
     hipStream_t st = (hipStream_t)stream;
+    // workgroups per depth tap in proportion to its valid output planes (conv3: 1 / 2 / 1 of 2 planes), 256 per chunk set
+    int nd[3], ndsum = 0;
+    for (int kd = 0; kd < 3; ++kd) {
+        nd[kd] = 0;
+        for (int d = 0; d < dout; ++d) {
+            const int ds = d * stride_d - pad_d + kd;
+            nd[kd] += ds >= 0 && ds < din;
+        }
+        ndsum += nd[kd];
+    }
+    Strips ks;
+    int widest = 1;
+    for (int kd = 0; kd < 3; ++kd) {
+        int share = ndsum > 0 ? (2 * nstrips * nd[kd]) / ndsum : nstrips;      // 2 * nstrips = 256 / chunks workgroups in all
+        if (share < 1) share = 1;
+        if (share > nstrips) share = nstrips;       // never beyond the slab capacity
+        ks.n[kd] = share;
+        if (share > widest) widest = share;
+    }
     float *slabs = (float *)workspace;
     int *list = (int *)((char *)workspace + wgrad_bg_slab_bytes(cin));
     int *count = list + (size_t)3 * dout * ntiles;
     hipLaunchKernelGGL(wgrad_step_list, dim3(3), dim3(1024), 0, st, in_halo_flags, g, ntiles, list, count);
     MVX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(conv3d_wgrad4, dim3(nstrips, 3 * (cin / W4_C)), dim3(W4_THREADS), 0, st, in, dz, slabs, g, 0,
-                       (const int *)list, (const int *)count, c_in);
+    hipLaunchKernelGGL(conv3d_wgrad4, dim3(widest, 3 * (cin / W4_C)), dim3(W4_THREADS), 0, st, in, dz, slabs, g, 0,
+                       (const int *)list, (const int *)count, c_in, ks);
     MVX_LAUNCH_CHECK();
     const size_t per_slab = (size_t)27 * cin * BN;
-    hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)slabs, dw, nstrips, cin,
-                       flags & MVX_FLAG_ACCUMULATE, 0);
+    hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)slabs, dw, widest, cin,
+                       flags & MVX_FLAG_ACCUMULATE, 0, ks);
     MVX_LAUNCH_CHECK();
     hipLaunchKernelGGL(wgrad_rank1, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, tap_sums, c_in, dw, g);
     MVX_LAUNCH_CHECK();
@@ -1502,7 +1531,7 @@ extern "C" int mvx_conv3d_wgrad_sites(const float *feat, const int64_t *coords, 
     MVX_LAUNCH_CHECK();
     const size_t per_slab = (size_t)27 * cin * BN;
     hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)workspace, dw,
-                       nstrips, cin, 0, 0);
+                       nstrips, cin, 0, 0, Strips{{nstrips, nstrips, nstrips}});
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
