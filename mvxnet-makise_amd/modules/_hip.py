@@ -601,7 +601,9 @@ def conv3d_wgrad_bg(x, dz, sd, pd, bg_in, tap_sums=None, accumulate_into=None, s
     nbytes = fn_bytes(dout, H, W, cin, cout)
     if tap_sums is None:
         tap_sums = plane_tap_sums(dz)
-    with _wgrad_scope(accumulate_into, x, dz) as scope:
+    # every tensor the side-stream kernels read must be kept alive for that stream (record_stream), not only x and dz:
+    # the tap sums and the background description are temporaries of the frame's own stream
+    with _wgrad_scope(accumulate_into, x, dz, tap_sums, bg_in.c, bg_in.hflag) as scope:
         ws = workspace(nbytes, x.device, 'wgrad_bg_side' if isinstance(scope, _SideStream) else 'wgrad_bg')
         with _Timed('conv3d_wgrad_bg', 0):
             X.check(fn(X.ptr(x), X.ptr(dz), X.ptr(dw), din, dout, H, W, cin, cout, sd, pd, flags,

@@ -57,9 +57,12 @@ def prepare_frames(batch, head):
     counts, then real-row counts) instead of one per frame, so the host can enqueue a whole step
     ahead of the GPU."""
     frames, status = voxelize_batch(batch)
-    maps = [head.compact_map(v) for v, _ in frames]
-    n_real = torch.cat([m[2] for m in maps]).tolist()
-    prepared = [(m[0], m[1], int(n)) for m, n in zip(maps, n_real)]
+    # a frame without voxels (everything cropped away) takes no part in the step: the reference cannot run on one
+    # either (BatchNorm over zero rows)
+    maps = [head.compact_map(v) if v.shape[1] > 0 else None for v, _ in frames]
+    live = [m for m in maps if m is not None]
+    n_real = iter(torch.cat([m[2] for m in live]).tolist() if live else [])
+    prepared = [(m[0], m[1], int(next(n_real))) if m is not None else None for m in maps]
     return frames, prepared, status
 
 
@@ -132,8 +135,9 @@ def prepare_mid(h, head):
     prep = _prep_stream(dev)
     with torch.cuda.stream(prep):
         h.frames = [(h.res.voxels[f, :v].unsqueeze(0), h.res.coords[f, :v]) for f, v in enumerate(counts)]
-        h.maps = [head.compact_map(v) for v, _ in h.frames]
-        nreal = torch.cat([m[2] for m in h.maps])
+        h.maps = [head.compact_map(v) if v.shape[1] > 0 else None for v, _ in h.frames]
+        live = [m[2] for m in h.maps if m is not None]
+        nreal = torch.cat(live) if live else torch.zeros((0,), dtype=torch.int32, device=dev)
         h.nreal_host = _pinned('nreal', nreal, h.turn)
         h.nreal_host.copy_(nreal, non_blocking=True)
         h.ev_b = torch.cuda.Event()
@@ -145,8 +149,8 @@ def prepare_end(h, head):
     if h.frames is None:
         prepare_mid(h, head)
     _spin(h.ev_b)
-    n_real = h.nreal_host.tolist()
-    prepared = [(m[0], m[1], int(n)) for m, n in zip(h.maps, n_real)]
+    n_real = iter(h.nreal_host.tolist())
+    prepared = [(m[0], m[1], int(next(n_real))) if m is not None else None for m in h.maps]
     return h.frames, prepared, h.res.status, h.ev_b
 
 
@@ -182,6 +186,9 @@ def train_step_frames(model, batch, grad_mid, imsize, ready=None):
         some = next((p for p in model.parameters() if p.requires_grad and p.grad is not None), None)
         flat = some.grad._base if (some is not None and ASYNC_WGRAD) else None
         for f, (voxels, idx) in enumerate(frames):
+            if prepared[f] is None or prepared[f][2] == 0:      # empty frame: nothing to learn from
+                nvox.append(0)
+                continue
             with torch.cuda.stream(lanes[f % len(lanes)]):
                 _hip.arena_begin(dev)
                 if flat is not None:

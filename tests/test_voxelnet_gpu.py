@@ -360,3 +360,36 @@ def test_rpn_hip_blocks_match_miopen_blocks():
         worst = max(worst, e_hip)
         assert e_hip < 3 * e_ref + 1e-4, (k, e_hip, e_ref)
     print('RPN gradients: worst HIP-vs-f64 %.2e' % worst)
+
+
+def test_pipeline_skips_empty_frames():
+    """A frame whose points were all cropped away (0 voxels) takes no part in the step: the other frames' gradients
+    are the same as without it, and nothing raises (the reference cannot run on such a frame: BatchNorm over 0 rows)."""
+    import bench
+    import modules.config as cfg
+    from MVXNet import MVXNet
+    from modules import parallel
+    from modules.pipeline import train_step_frames
+    torch.manual_seed(4)
+    model = MVXNet().to(DEV)
+    hot = [p for k, p in model.named_parameters() if p.requires_grad and '.rpn.' not in k]
+    bucket = parallel.GradBucket(hot)
+    grad_mid = torch.randn((1, 128, cfg.voxelshape[0], cfg.voxelshape[1]), device=DEV) * 1e-3
+    imsize = [float(v) for v in cfg.imsize]
+    batch = bench.make_batch([0, 1], DEV, 6000)
+    batch.n_points[1] = 0
+    bucket.zero()
+    nv, st = train_step_frames(model, batch, grad_mid, imsize)
+    assert nv[0] > 0 and nv[1] == 0 and all(int(s) == 0 for s in st)
+    got = bucket.flat.clone()
+    one = bench.make_batch([0], DEV, 6000)
+    bucket.zero()
+    train_step_frames(model, one, grad_mid, imsize)
+    assert bool(torch.isfinite(got).all()) and rel_err(got, bucket.flat) < 1e-5
+    # ... and a repeated step reproduces them (this is what exposed a tensor the side stream read after the frame's
+    # own stream had recycled it: every operand of a side-stream kernel must be recorded for that stream)
+    again = bucket.flat.clone()
+    for _ in range(3):
+        bucket.zero()
+        train_step_frames(model, one, grad_mid, imsize)
+        assert rel_err(bucket.flat, again) < 1e-6
