@@ -49,3 +49,16 @@ worst = []
 for n, p in zip(names, hot):
     k = p.numel(); worst.append((rel(e[off:off+k], a[off:off+k]) if a[off:off+k].abs().max() > 0 else 0, n)); off += k
 print(sorted(worst, reverse=True)[:6])
+four = bench.make_batch([0, 1, 2, 3], dev, pts)
+g0 = run(four)
+worst = 0.0
+for _ in range(5):
+    worst = max(worst, rel(run(four), g0))
+print('4 frames / 2 lanes, 5 repeats: worst deviation', worst)
+print('   vs background off', rel(g0, run(four, bg=False)), ' vs one lane', rel(g0, run(four, lanes=1)))
+cfg.config['convmath'] = 'bf16x3'
+h0 = run(four)
+worst = 0.0
+for _ in range(3):
+    worst = max(worst, rel(run(four), h0))
+print('bf16x3: repeats', worst, ' vs f32', rel(h0, g0), ' vs bf16x3 background off', rel(h0, run(four, bg=False)))
