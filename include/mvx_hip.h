@@ -254,7 +254,7 @@ int mvx_conv3d_input_grad_sums(const float *w, const float *tap_sums, int32_t di
                                int32_t cout, int32_t stride_d, int32_t pad_d, float *plane_grad_sums, void *stream);
 int mvx_conv3d_dgrad_tiles(const float *dz, const float *wpk_dgrad, float *dx, int32_t din, int32_t dout, int32_t h,
                            int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
-                           const int32_t *dx_tile_flags, void *stream);
+                           const int32_t *dx_tile_flags, uint64_t *exec_stages, void *stream);
 /* bf16x3 forms of the background-aware entry points (csrc/conv3d_split.hip; weights from mvx_conv3d_pack_weights_split) */
 int mvx_conv3d_forward_bg_split(const float *in, const void *wsplit, const float *bias, float *out, double *stats,
                                 int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_pf(const float *__restri
         any |= nk > 2 ? in_hflag[(size_t)ds_l[2] * ntiles + blockIdx.x] : 0;
         active = any != 0;
     }
-    if (exec_stages && active && threadIdx.x == 0) atomicAdd(exec_stages, (unsigned long long)nstages);
+    if (exec_stages && active && threadIdx.x == 0) atomicAdd(exec_stages, (unsigned long long)nstages);   // executed work only
     if (active) {
     auto stage_kd = [&](int st, int &kd, int &ds, int &cc) __attribute__((always_inline)) {
         const int i = st / nchunks;
@@ -1284,7 +1284,7 @@ extern "C" int mvx_conv3d_forward_bg(const float *in, const float *wpk, const fl
 
 static int launch_dgrad(const float *dz, const float *wpk_dgrad, float *dx, int32_t din, int32_t dout, int32_t h,
                         int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, const int32_t *only_tiles,
-                        void *stream) {
+                        uint64_t *exec_stages, void *stream) {
     MVX_CHECK_ARG(dz && wpk_dgrad && dx);
     // gather view: source = dz (dout planes, cout channels), result = dx (din planes, cin channels)
     int rc = check_geom(din, dout, h, w, cout, cin, stride_d, pad_d);
@@ -1292,7 +1292,7 @@ static int launch_dgrad(const float *dz, const float *wpk_dgrad, float *dx, int3
     Geom g{dout, din, h, w, cout, cin, stride_d, pad_d, 1};
     hipLaunchKernelGGL(conv3d_gather_pf, gather_grid(g), dim3(256), 0, (hipStream_t)stream, dz, wpk_dgrad,
                        (const float *)nullptr, dx, (double *)nullptr, g, 0, (const int *)nullptr,
-                       (const unsigned char *)nullptr, (const float *)nullptr, 0, (unsigned long long *)nullptr, only_tiles,
+                       (const unsigned char *)nullptr, (const float *)nullptr, 0, (unsigned long long *)exec_stages, only_tiles,
                        (unsigned *)nullptr, 0.0, 0.0, (float *)nullptr);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
@@ -1301,14 +1301,14 @@ static int launch_dgrad(const float *dz, const float *wpk_dgrad, float *dx, int3
 extern "C" int mvx_conv3d_dgrad(const float *dz, const float *wpk_dgrad, float *dx, int32_t din,
                                 int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
                                 int32_t stride_d, int32_t pad_d, void *stream) {
-    return launch_dgrad(dz, wpk_dgrad, dx, din, dout, h, w, cin, cout, stride_d, pad_d, nullptr, stream);
+    return launch_dgrad(dz, wpk_dgrad, dx, din, dout, h, w, cin, cout, stride_d, pad_d, nullptr, nullptr, stream);
 }
 
 extern "C" int mvx_conv3d_dgrad_tiles(const float *dz, const float *wpk_dgrad, float *dx, int32_t din, int32_t dout,
                                       int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
-                                      const int32_t *dx_tile_flags, void *stream) {
+                                      const int32_t *dx_tile_flags, uint64_t *exec_stages, void *stream) {
     MVX_CHECK_ARG(dx_tile_flags);
-    return launch_dgrad(dz, wpk_dgrad, dx, din, dout, h, w, cin, cout, stride_d, pad_d, dx_tile_flags, stream);
+    return launch_dgrad(dz, wpk_dgrad, dx, din, dout, h, w, cin, cout, stride_d, pad_d, dx_tile_flags, exec_stages, stream);
 }
 
 static int wgrad_strips(int h, int w, int cin) {

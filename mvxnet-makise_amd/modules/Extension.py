@@ -94,7 +94,7 @@ PROTOTYPES = {
     'mvx_plane_tap_sums': (_i32, [_p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
     'mvx_tile_dilate_flags': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     'mvx_conv3d_input_grad_sums': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
-    'mvx_conv3d_dgrad_tiles': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
+    'mvx_conv3d_dgrad_tiles': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p]),
     'mvx_bn_relu_backward_tiles_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32]),
     'mvx_bn_relu_backward_tiles': (_i32, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _sz, _p]),
 }

@@ -526,9 +526,15 @@ def conv3d_dgrad_tiles(dz, wpk_d, din, cin, sd, pd, tflag, split=False):
             X.check(X.lib.mvx_conv3d_dgrad_tiles_split(X.ptr(dz), X.ptr(wpk_d), X.ptr(dx), din, dout, H, W, cin, cout, sd, pd,
                                                        X.ptr(tflag), X.stream()), 'mvx_conv3d_dgrad_tiles_split')
         return dx
+    global EXEC_STAGES
+    counter = None
+    if KERNEL_TIMERS is not None:
+        if EXEC_STAGES is None:
+            EXEC_STAGES = torch.zeros((1,), dtype=torch.int64, device=dz.device)
+        counter = EXEC_STAGES
     with _Timed('conv3d_gather_tiles', conv_flops(din, dout, H, W, cout, cin, sd, pd, True) if KERNEL_TIMERS is not None else 0):   # dense-equivalent
         X.check(X.lib.mvx_conv3d_dgrad_tiles(X.ptr(dz), X.ptr(wpk_d), X.ptr(dx), din, dout, H, W, cin, cout, sd, pd,
-                                             X.ptr(tflag), X.stream()), 'mvx_conv3d_dgrad_tiles')
+                                             X.ptr(tflag), X.ptr(counter), X.stream()), 'mvx_conv3d_dgrad_tiles')
     return dx
 
 
