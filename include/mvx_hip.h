@@ -157,6 +157,10 @@ int mvx_bn_relu_backward(const float *dyhat, const float *y, const float *mean_i
  *                            too, the wave-autonomous sparse kernel runs (no workgroup barriers,
  *                            per-wave halo, weight fragments from L2; same result).  exec_quads
  *                            (optional) u64 [1] += executed operand quads (1 quad = 8 MFMAs = 32,768 FLOP)
+ *   work_counter (optional, forward / dgrad and their _bg / _tiles forms): u32 [1] holding ZERO; the launch then uses
+ *                            the persistent form of the kernel -- two workgroups per CU pull (tile, plane, channel block)
+ *                            units from this counter until none is left: no tail round of idle CUs, constant-fill tiles do
+ *                            not unbalance the workgroups.  NULL: one workgroup per unit.
  *   mvx_conv3d_dgrad         dx [din][h][w][cin] from dz [dout][h][w][cout]
  *   mvx_conv3d_dgrad_sites   dfeat [n_voxels][cin] = rows of dx at the voxel sites only (what
  *                            reindex's backward reads); coords i64 [n_voxels][4] = (b, ix, iy, iz)
@@ -171,10 +175,10 @@ void mvx_conv3d_tile_shape(int32_t *tile_h, int32_t *tile_w);
 int mvx_conv3d_forward(const float *in, const float *wpk, const float *bias, float *out, double *stats,
                        int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
                        int32_t stride_d, int32_t pad_d, int32_t flags, const int32_t *occupancy,
-                       const uint32_t *site_bits, uint64_t *exec_quads, void *stream);
+                       const uint32_t *site_bits, uint64_t *exec_quads, uint32_t *work_counter, void *stream);
 int mvx_conv3d_dgrad(const float *dz, const float *wpk_dgrad, float *dx, int32_t din, int32_t dout,
                      int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
-                     void *stream);
+                     uint32_t *work_counter, void *stream);
 int mvx_conv3d_dgrad_sites(const float *dz, const float *wpk_dgrad, const int64_t *coords, float *dfeat,
                            int32_t n_voxels, int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin,
                            int32_t cout, int32_t stride_d, int32_t pad_d, void *stream);
@@ -238,7 +242,7 @@ int mvx_conv3d_forward_bg(const float *in, const float *wpk, const float *bias, 
                           int32_t stride_d, int32_t pad_d, int32_t flags, const int32_t *in_halo_flags,
                           const uint8_t *out_mask, const float *bg_pre, int32_t border_active,
                           uint64_t *exec_stages, uint32_t *done_counter, double count, double eps, float *mean_inv,
-                          void *stream);
+                          uint32_t *work_counter, void *stream);
 size_t mvx_conv3d_wgrad_bg_workspace_bytes(int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout);
 int mvx_conv3d_wgrad_bg(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
                         int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, int32_t flags,
@@ -254,7 +258,7 @@ int mvx_conv3d_input_grad_sums(const float *w, const float *tap_sums, int32_t di
                                int32_t cout, int32_t stride_d, int32_t pad_d, float *plane_grad_sums, void *stream);
 int mvx_conv3d_dgrad_tiles(const float *dz, const float *wpk_dgrad, float *dx, int32_t din, int32_t dout, int32_t h,
                            int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
-                           const int32_t *dx_tile_flags, uint64_t *exec_stages, void *stream);
+                           const int32_t *dx_tile_flags, uint64_t *exec_stages, uint32_t *work_counter, void *stream);
 /* bf16x3 forms of the background-aware entry points (csrc/conv3d_split.hip; weights from mvx_conv3d_pack_weights_split) */
 int mvx_conv3d_forward_bg_split(const float *in, const void *wsplit, const float *bias, float *out, double *stats,
                                 int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,

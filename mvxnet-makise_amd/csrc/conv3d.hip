@@ -250,29 +250,23 @@ constexpr int HROW = ((HW * PITCH + 63) / 64) * 64;
 // space was measured and was not faster (forward equal, stride-2 dgrad slower), so the plain grid stays.
 inline dim3 gather_grid(const Geom &g) { return dim3(mvx_cdiv(g.W, TW) * mvx_cdiv(g.H, TH), g.Dout, g.Cout / BN); }
 
-__global__ __launch_bounds__(256, 2) void conv3d_gather_pf(const float *__restrict__ in,
-                                                           const float *__restrict__ wpk,
-                                                           const float *__restrict__ bias,
-                                                           float *__restrict__ out, double *__restrict__ stats,
-                                                           Geom g, int relu, const int *__restrict__ in_hflag,
-                                                           const unsigned char *__restrict__ out_mask,
-                                                           const float *__restrict__ bg_pre, int border_active,
-                                                           unsigned long long *__restrict__ exec_stages,
-                                                           const int *__restrict__ only_tiles,
-                                                           unsigned *__restrict__ done_counter, double fin_count,
-                                                           double fin_eps, float *__restrict__ fin_mean_inv) {
-    __shared__ __attribute__((aligned(16))) float s_halo[HH * HROW];
-    __shared__ __attribute__((aligned(16))) float s_w[3 * WROW];
-    __shared__ float s_red[4][2 * BN];
-
+// One unit of work = (tile, output plane d, 64-channel block nb); `ntiles` tiles per plane.
+__device__ __forceinline__ void gather_unit(const int tile, const int d, const int nb, const int ntiles,
+                                            float *__restrict__ s_halo, float *__restrict__ s_w, float (*s_red)[2 * BN],
+                                            const float *__restrict__ in, const float *__restrict__ wpk,
+                                            const float *__restrict__ bias, float *__restrict__ out,
+                                            double *__restrict__ stats, const Geom &g, int relu,
+                                            const int *__restrict__ in_hflag, const unsigned char *__restrict__ out_mask,
+                                            const float *__restrict__ bg_pre, int border_active,
+                                            unsigned long long *__restrict__ exec_stages,
+                                            const int *__restrict__ only_tiles) {
     const int tiles_x = (g.W + TW - 1) / TW;
-    const int tx0 = (blockIdx.x % tiles_x) * TW, ty0 = (blockIdx.x / tiles_x) * TH;
-    const int d = blockIdx.y, nb = blockIdx.z;
+    const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int nchunks = g.Cin / BK;
     // restricted launch: only the flagged output tiles are produced, the others are left untouched
-    if (only_tiles && !only_tiles[(size_t)d * gridDim.x + blockIdx.x]) return;
+    if (only_tiles && !only_tiles[(size_t)d * ntiles + tile]) return;
 
     f32x16 acc0, acc1;
 #pragma unroll
@@ -301,11 +295,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_pf(const float *__restri
     // window never leaves the image -> every output site of the tile is the per-plane constant.
     bool active = true;
     if (in_hflag) {
-        const int ntiles = gridDim.x;
         int any = border_active && (tx0 == 0 || ty0 == 0 || tx0 + TW >= g.W || ty0 + TH >= g.H);
-        any |= nk > 0 ? in_hflag[(size_t)ds_l[0] * ntiles + blockIdx.x] : 0;
-        any |= nk > 1 ? in_hflag[(size_t)ds_l[1] * ntiles + blockIdx.x] : 0;
-        any |= nk > 2 ? in_hflag[(size_t)ds_l[2] * ntiles + blockIdx.x] : 0;
+        any |= nk > 0 ? in_hflag[(size_t)ds_l[0] * ntiles + tile] : 0;
+        any |= nk > 1 ? in_hflag[(size_t)ds_l[1] * ntiles + tile] : 0;
+        any |= nk > 2 ? in_hflag[(size_t)ds_l[2] * ntiles + tile] : 0;
         active = any != 0;
     }
     if (exec_stages && active && threadIdx.x == 0) atomicAdd(exec_stages, (unsigned long long)nstages);   // executed work only
@@ -446,17 +439,75 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_pf(const float *__restri
         if (tid < 2 * BN) {
             const double t = (double)s_red[0][tid] + (double)s_red[1][tid] + (double)s_red[2][tid] + (double)s_red[3][tid];
             const int which = tid / BN, c = tid % BN;
-            const unsigned rep = (blockIdx.x + blockIdx.y * gridDim.x) % MVX_REP;
+            const unsigned rep = (unsigned)(tile + d * ntiles) % MVX_REP;
             atomicAdd(stats + ((size_t)rep * 2 + which) * g.Cout + nb * BN + c, t);
-        }
-        if (done_counter) {
-            __shared__ int s_last;
-            bn_finalize_by_last_block(done_counter, gridDim.x * gridDim.y * gridDim.z, stats, g.Cout, fin_count, fin_eps,
-                                      fin_mean_inv, &s_last);
         }
     }
 }
 
+
+
+// Classic launch: one unit per workgroup, grid = (tiles, planes, channel blocks).
+__global__ __launch_bounds__(256, 2) void conv3d_gather_pf(const float *__restrict__ in,
+                                                           const float *__restrict__ wpk,
+                                                           const float *__restrict__ bias,
+                                                           float *__restrict__ out, double *__restrict__ stats,
+                                                           Geom g, int relu, const int *__restrict__ in_hflag,
+                                                           const unsigned char *__restrict__ out_mask,
+                                                           const float *__restrict__ bg_pre, int border_active,
+                                                           unsigned long long *__restrict__ exec_stages,
+                                                           const int *__restrict__ only_tiles,
+                                                           unsigned *__restrict__ done_counter, double fin_count,
+                                                           double fin_eps, float *__restrict__ fin_mean_inv) {
+    __shared__ __attribute__((aligned(16))) float s_halo[HH * HROW];
+    __shared__ __attribute__((aligned(16))) float s_w[3 * WROW];
+    __shared__ float s_red[4][2 * BN];
+    gather_unit(blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, s_halo, s_w, s_red, in, wpk, bias, out, stats, g, relu, in_hflag,
+                out_mask, bg_pre, border_active, exec_stages, only_tiles);
+    if (stats && done_counter) {
+        __shared__ int s_last;
+        bn_finalize_by_last_block(done_counter, gridDim.x * gridDim.y * gridDim.z, stats, g.Cout, fin_count, fin_eps,
+                                  fin_mean_inv, &s_last);
+    }
+}
+
+// Persistent launch: gridDim.x workgroups (two per CU) pull units from a device counter until none is left -- every
+// workgroup reaches the exit (`u >= units`), so the grid always drains.  Units are handed out in the classic order
+// (tile fastest), dynamically: no tail round with idle CUs (3,300 units over 512 slots = 6.45 rounds) and background
+// tiles, which only write a constant, do not unbalance the workgroups.
+__global__ __launch_bounds__(256, 2) void conv3d_gather_pw(const float *__restrict__ in,
+                                                           const float *__restrict__ wpk,
+                                                           const float *__restrict__ bias,
+                                                           float *__restrict__ out, double *__restrict__ stats,
+                                                           Geom g, int relu, const int *__restrict__ in_hflag,
+                                                           const unsigned char *__restrict__ out_mask,
+                                                           const float *__restrict__ bg_pre, int border_active,
+                                                           unsigned long long *__restrict__ exec_stages,
+                                                           const int *__restrict__ only_tiles,
+                                                           unsigned *__restrict__ done_counter, double fin_count,
+                                                           double fin_eps, float *__restrict__ fin_mean_inv,
+                                                           unsigned *__restrict__ work_counter, int ntiles, int nplanes,
+                                                           int nblocks) {
+    __shared__ __attribute__((aligned(16))) float s_halo[HH * HROW];
+    __shared__ __attribute__((aligned(16))) float s_w[3 * WROW];
+    __shared__ float s_red[4][2 * BN];
+    __shared__ unsigned s_unit;
+    const unsigned units = (unsigned)ntiles * nplanes * nblocks;
+    for (;;) {
+        __syncthreads();                            // everyone is done with the previous unit (LDS, s_unit)
+        if (threadIdx.x == 0) s_unit = atomicAdd(work_counter, 1u);
+        __syncthreads();
+        const unsigned u = s_unit;
+        if (u >= units) break;                      // block-uniform
+        const int tile = u % ntiles, d = (u / ntiles) % nplanes, nb = u / (ntiles * nplanes);
+        gather_unit(tile, d, nb, ntiles, s_halo, s_w, s_red, in, wpk, bias, out, stats, g, relu, in_hflag, out_mask, bg_pre,
+                    border_active, exec_stages, only_tiles);
+    }
+    if (stats && done_counter) {
+        __shared__ int s_last;
+        bn_finalize_by_last_block(done_counter, gridDim.x, stats, g.Cout, fin_count, fin_eps, fin_mean_inv, &s_last);
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // Forward of the input-sparse first layer, wave-autonomous form.
@@ -1216,6 +1267,35 @@ static int check_geom(int32_t din, int32_t dout, int32_t h, int32_t w, int32_t c
     return MVX_OK;
 }
 
+// Launch the gather kernel: persistent form when the caller supplies a zeroed work counter, classic grid otherwise.
+static int persistent_grid() {
+    static int cached = 0;
+    if (!cached) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            cus <= 0)
+            cus = 256;
+        cached = 2 * cus;                           // two workgroups per CU fit (LDS)
+    }
+    return cached;
+}
+
+static void launch_gather(hipStream_t st, const float *in, const float *wpk, const float *bias, float *out, double *stats,
+                          const Geom &g, int relu, const int *in_hflag, const unsigned char *out_mask, const float *bg_pre,
+                          int border_active, unsigned long long *exec_stages, const int *only_tiles, unsigned *done_counter,
+                          double fin_count, double fin_eps, float *fin_mean_inv, unsigned *work_counter) {
+    const dim3 grid = gather_grid(g);
+    const long long units = (long long)grid.x * grid.y * grid.z;
+    if (work_counter && units > persistent_grid()) {
+        hipLaunchKernelGGL(conv3d_gather_pw, dim3(persistent_grid()), dim3(256), 0, st, in, wpk, bias, out, stats, g, relu,
+                           in_hflag, out_mask, bg_pre, border_active, exec_stages, only_tiles, done_counter, fin_count, fin_eps,
+                           fin_mean_inv, work_counter, (int)grid.x, (int)grid.y, (int)grid.z);
+    } else {
+        hipLaunchKernelGGL(conv3d_gather_pf, grid, dim3(256), 0, st, in, wpk, bias, out, stats, g, relu, in_hflag, out_mask,
+                           bg_pre, border_active, exec_stages, only_tiles, done_counter, fin_count, fin_eps, fin_mean_inv);
+    }
+}
+
 extern "C" void mvx_conv3d_tile_shape(int32_t *tile_h, int32_t *tile_w) {
     if (tile_h) *tile_h = TH;
     if (tile_w) *tile_w = TW;
@@ -1225,7 +1305,7 @@ extern "C" int mvx_conv3d_forward(const float *in, const float *wpk, const float
                                   double *stats, int32_t din, int32_t dout, int32_t h, int32_t w,
                                   int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
                                   int32_t flags, const int32_t *occupancy, const uint32_t *site_bits,
-                                  uint64_t *exec_quads, void *stream) {
+                                  uint64_t *exec_quads, uint32_t *work_counter, void *stream) {
     MVX_CHECK_ARG(in && wpk && out);
     int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
     if (rc) return rc;
@@ -1245,9 +1325,8 @@ extern "C" int mvx_conv3d_forward(const float *in, const float *wpk, const float
         hipLaunchKernelGGL(conv3d_gather, grid, dim3(256), 0, st, in, wpk, bias, out, stats, g, relu, occupancy,
                            (unsigned long long *)exec_quads);
     else
-        hipLaunchKernelGGL(conv3d_gather_pf, gather_grid(g), dim3(256), 0, st, in, wpk, bias, out, stats, g, relu,
-                           (const int *)nullptr, (const unsigned char *)nullptr, (const float *)nullptr, 0,
-                           (unsigned long long *)nullptr, (const int *)nullptr, (unsigned *)nullptr, 0.0, 0.0, (float *)nullptr);
+        launch_gather(st, in, wpk, bias, out, stats, g, relu, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0.0, 0.0,
+                      nullptr, (unsigned *)work_counter);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -1257,7 +1336,7 @@ extern "C" int mvx_conv3d_forward_bg(const float *in, const float *wpk, const fl
                                      int32_t stride_d, int32_t pad_d, int32_t flags, const int32_t *in_halo_flags,
                                      const uint8_t *out_mask, const float *bg_pre, int32_t border_active,
                                      uint64_t *exec_stages, uint32_t *done_counter, double count, double eps,
-                                     float *mean_inv, void *stream) {
+                                     float *mean_inv, uint32_t *work_counter, void *stream) {
     MVX_CHECK_ARG(in && wpk && out && in_halo_flags && out_mask && bg_pre);
     int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
     if (rc) return rc;
@@ -1275,40 +1354,40 @@ extern "C" int mvx_conv3d_forward_bg(const float *in, const float *wpk, const fl
         }
     }
     Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
-    hipLaunchKernelGGL(conv3d_gather_pf, gather_grid(g), dim3(256), 0, st, in, wpk, bias, out, stats, g,
-                       flags & MVX_FLAG_RELU, in_halo_flags, out_mask, bg_pre, border_active,
-                       (unsigned long long *)exec_stages, (const int *)nullptr, (unsigned *)done_counter, count, eps, mean_inv);
+    launch_gather(st, in, wpk, bias, out, stats, g, flags & MVX_FLAG_RELU, in_halo_flags, out_mask, bg_pre, border_active,
+                  (unsigned long long *)exec_stages, nullptr, (unsigned *)done_counter, count, eps, mean_inv,
+                  (unsigned *)work_counter);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
 
 static int launch_dgrad(const float *dz, const float *wpk_dgrad, float *dx, int32_t din, int32_t dout, int32_t h,
                         int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, const int32_t *only_tiles,
-                        uint64_t *exec_stages, void *stream) {
+                        uint64_t *exec_stages, uint32_t *work_counter, void *stream) {
     MVX_CHECK_ARG(dz && wpk_dgrad && dx);
     // gather view: source = dz (dout planes, cout channels), result = dx (din planes, cin channels)
     int rc = check_geom(din, dout, h, w, cout, cin, stride_d, pad_d);
     if (rc) return rc;
     Geom g{dout, din, h, w, cout, cin, stride_d, pad_d, 1};
-    hipLaunchKernelGGL(conv3d_gather_pf, gather_grid(g), dim3(256), 0, (hipStream_t)stream, dz, wpk_dgrad,
-                       (const float *)nullptr, dx, (double *)nullptr, g, 0, (const int *)nullptr,
-                       (const unsigned char *)nullptr, (const float *)nullptr, 0, (unsigned long long *)exec_stages, only_tiles,
-                       (unsigned *)nullptr, 0.0, 0.0, (float *)nullptr);
+    launch_gather((hipStream_t)stream, dz, wpk_dgrad, nullptr, dx, nullptr, g, 0, nullptr, nullptr, nullptr, 0,
+                  (unsigned long long *)exec_stages, only_tiles, nullptr, 0.0, 0.0, nullptr, (unsigned *)work_counter);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
 
 extern "C" int mvx_conv3d_dgrad(const float *dz, const float *wpk_dgrad, float *dx, int32_t din,
                                 int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
-                                int32_t stride_d, int32_t pad_d, void *stream) {
-    return launch_dgrad(dz, wpk_dgrad, dx, din, dout, h, w, cin, cout, stride_d, pad_d, nullptr, nullptr, stream);
+                                int32_t stride_d, int32_t pad_d, uint32_t *work_counter, void *stream) {
+    return launch_dgrad(dz, wpk_dgrad, dx, din, dout, h, w, cin, cout, stride_d, pad_d, nullptr, nullptr, work_counter, stream);
 }
 
 extern "C" int mvx_conv3d_dgrad_tiles(const float *dz, const float *wpk_dgrad, float *dx, int32_t din, int32_t dout,
                                       int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
-                                      const int32_t *dx_tile_flags, uint64_t *exec_stages, void *stream) {
+                                      const int32_t *dx_tile_flags, uint64_t *exec_stages, uint32_t *work_counter,
+                                      void *stream) {
     MVX_CHECK_ARG(dx_tile_flags);
-    return launch_dgrad(dz, wpk_dgrad, dx, din, dout, h, w, cin, cout, stride_d, pad_d, dx_tile_flags, exec_stages, stream);
+    return launch_dgrad(dz, wpk_dgrad, dx, din, dout, h, w, cin, cout, stride_d, pad_d, dx_tile_flags, exec_stages,
+                        work_counter, stream);
 }
 
 static int wgrad_strips(int h, int w, int cin) {

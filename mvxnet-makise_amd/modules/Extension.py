@@ -66,7 +66,7 @@ PROTOTYPES = {
     'mvx_conv3d_packed_weight_bytes': (_sz, [_i32, _i32]),
     'mvx_conv3d_pack_weights': (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     'mvx_conv3d_tile_shape': (None, [_p, _p]),
-    'mvx_conv3d_forward': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
+    'mvx_conv3d_forward': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
     'mvx_conv3d_pack_weights_split': (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     'mvx_conv3d_forward_split': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_conv3d_dgrad_split': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
@@ -74,14 +74,14 @@ PROTOTYPES = {
     'mvx_conv3d_dgrad_sites': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_conv3d_wgrad_sites_workspace_bytes': (_sz, [_i32, _i32, _i32]),
     'mvx_conv3d_wgrad_sites': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _sz, _p]),
-    'mvx_conv3d_dgrad': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    'mvx_conv3d_dgrad': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     'mvx_conv3d_wgrad_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32]),
     'mvx_conv3d_wgrad': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _sz, _p]),
     'mvx_activity_dilate': (_i32, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
     'mvx_conv3d_background': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     'mvx_bn_background': (_i32, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _p]),
     'mvx_conv3d_forward_bg': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p,
-                                     _i32, _p, _p, _f64, _f64, _p, _p]),
+                                     _i32, _p, _p, _f64, _f64, _p, _p, _p]),
     'mvx_linear_forward_bn': (_i32, [_p, _i32, _p, _i32, _i32, _p, _p, _i32, _p, _p, _i64, _i32, _i32, _i32, _p, _f64, _f64, _p, _p]),
     'mvx_conv3d_wgrad_bg_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32, _i32]),
     'mvx_conv3d_wgrad_bg': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
@@ -94,7 +94,7 @@ PROTOTYPES = {
     'mvx_plane_tap_sums': (_i32, [_p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
     'mvx_tile_dilate_flags': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     'mvx_conv3d_input_grad_sums': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
-    'mvx_conv3d_dgrad_tiles': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p]),
+    'mvx_conv3d_dgrad_tiles': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
     'mvx_bn_relu_backward_tiles_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32]),
     'mvx_bn_relu_backward_tiles': (_i32, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _sz, _p]),
 }

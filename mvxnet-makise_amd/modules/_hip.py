@@ -374,7 +374,8 @@ def conv3d_forward(x, wpk, bias, cout, sd, pd, relu=True, want_stats=True, occup
     with _Timed(name, flops):
         X.check(X.lib.mvx_conv3d_forward(X.ptr(x), X.ptr(wpk), X.ptr(bias), X.ptr(out), X.ptr(stats),
                                          din, dout, H, W, cin, cout, sd, pd, flags, X.ptr(occ_t), X.ptr(bits_t),
-                                         X.ptr(counter), X.stream()), 'mvx_conv3d_forward')
+                                         X.ptr(counter), X.ptr(_work_counter(x.device) if occupancy is None else None),
+                                         X.stream()), 'mvx_conv3d_forward')
     return out, stats
 
 
@@ -409,7 +410,7 @@ def conv3d_dgrad(dz, wpk_d, din, cin, sd, pd, split=False):
         return dx
     with _Timed('conv3d_gather', conv_flops(din, dout, H, W, cout, cin, sd, pd, True) if KERNEL_TIMERS is not None else 0):
         X.check(X.lib.mvx_conv3d_dgrad(X.ptr(dz), X.ptr(wpk_d), X.ptr(dx), din, dout, H, W, cin, cout, sd, pd,
-                                       X.stream()), 'mvx_conv3d_dgrad')
+                                       X.ptr(_work_counter(dz.device)), X.stream()), 'mvx_conv3d_dgrad')
     return dx
 
 
@@ -534,7 +535,8 @@ def conv3d_dgrad_tiles(dz, wpk_d, din, cin, sd, pd, tflag, split=False):
         counter = EXEC_STAGES
     with _Timed('conv3d_gather_tiles', conv_flops(din, dout, H, W, cout, cin, sd, pd, True) if KERNEL_TIMERS is not None else 0):   # dense-equivalent
         X.check(X.lib.mvx_conv3d_dgrad_tiles(X.ptr(dz), X.ptr(wpk_d), X.ptr(dx), din, dout, H, W, cin, cout, sd, pd,
-                                             X.ptr(tflag), X.ptr(counter), X.stream()), 'mvx_conv3d_dgrad_tiles')
+                                             X.ptr(tflag), X.ptr(counter), X.ptr(_work_counter(dz.device)), X.stream()),
+                'mvx_conv3d_dgrad_tiles')
     return dx
 
 
@@ -591,7 +593,7 @@ def conv3d_forward_bg(x, wpk, bias, cout, sd, pd, bg_in, out_mask, bg_pre, relu=
         X.check(X.lib.mvx_conv3d_forward_bg(X.ptr(x), X.ptr(wpk), X.ptr(bias), X.ptr(out), X.ptr(stats), din, dout, H, W,
                                             cin, cout, sd, pd, flags, X.ptr(bg_in.hflag), X.ptr(out_mask), X.ptr(bg_pre),
                                             1, X.ptr(counter), X.ptr(fin), npos, float(finalize_eps or 0.0), X.ptr(mi),
-                                            X.stream()), 'mvx_conv3d_forward_bg')
+                                            X.ptr(_work_counter(x.device)), X.stream()), 'mvx_conv3d_forward_bg')
     return (out, mi) if mi is not None else (out, stats)
 
 
@@ -646,6 +648,16 @@ def _fin_slot(device, zeroed):
         if v is not None:
             return v
     return None
+
+
+def _work_counter(device):
+    """Zeroed u32 slot for the persistent convolution launches: from the frame arena, else a fresh zero."""
+    if _ARENA_ON:
+        a = _ARENAS.get(_arena_key(device))
+        v = a.take(1) if a is not None else None
+        if v is not None:
+            return v
+    return torch.zeros((1,), dtype=torch.float64, device=device)
 
 
 def linear_forward(x, w, bias, relu=True, want_stats=True, w_transposed=False, row_w=None, out=None, finalize=None):
