@@ -270,7 +270,7 @@ def main():
         return nv, dt_, tm
 
     def conv_roofline(tm, math, run=0):
-        name = 'conv3d_gather_split' if math == 'bf16x3' else 'conv3d_gather_pf'
+        name = 'conv3d_gather_split' if math == 'bf16x3' else 'conv3d_gather_pw'
         ev = tm.get('conv3d_gather_split' if math == 'bf16x3' else 'conv3d_gather', [])
         ms = sum(s.elapsed_time(e) for s, e, _ in ev)
         fl = sum(f for _, _, f in ev)
@@ -351,7 +351,7 @@ def main():
         tpath = os.path.join(REPO, 'profiles', 'traffic.json')
         if os.path.exists(tpath) and main_math == 'f32':
             with open(tpath) as fh:
-                roof['traffic'] = json.load(fh).get('conv3d_gather_pf_hbm_bytes_per_launch')
+                roof['traffic'] = json.load(fh).get('conv3d_gather_pw_hbm_bytes_per_launch')
         out = {
             'metric': 'KITTI frames/sec (voxelize+VFE+fusion+3Dconv fwd+bwd)',
             'value': frames_total * args.steps / dt,

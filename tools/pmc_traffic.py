@@ -44,10 +44,10 @@ def main():
         fb = sum(F[key][:n]) / n * 1024 * 2
         wb = sum(W[key][:n]) / n * 1024
         report['kernels']['%s grid=%d' % (name, grid)] = {'launches': n, 'fetch_bytes': fb, 'write_bytes': wb}
-        if name == 'conv3d_gather_pf':
+        if name in ('conv3d_gather_pw', 'conv3d_gather_pf'):      # persistent / classic launch of the same unit body
             tot_b += (fb + wb) * n
             tot_n += n
-    report['conv3d_gather_pf_hbm_bytes_per_launch'] = tot_b / max(1, tot_n)
+    report['conv3d_gather_pw_hbm_bytes_per_launch'] = tot_b / max(1, tot_n)
     with open(dst, 'w') as fh:
         json.dump(report, fh, indent=1)
     print(json.dumps(report, indent=1))
