@@ -195,11 +195,14 @@ def main():
     pending = [None]
     step_events = []
     debug_sleep_ms = float(os.environ.get('MVX_DEBUG_HOST_DELAY_MS', '0'))
-    pipelined = os.environ.get('MVX_PIPELINE_INPUT', '0') != '0'      # measured: 218 vs 249 frames/s -> off
+    pipelined = os.environ.get('MVX_PIPELINE_INPUT', '2') == '1'      # own preparation stream: measured slower
+    pipe_mid = os.environ.get('MVX_PIPELINE_INPUT', '2') == '2'       # default: next batch prepared mid-step on the main stream
+    mid_ready = [None]
 
     def step():
-        # input pipelining: this step consumes the batch prepared during the previous one and starts the next
-        # (same resident synthetic batch every step; every step still voxelizes once, inside the timed region)
+        # input double-buffering: this step consumes the batch that was voxelized during the previous one and voxelizes
+        # the next (same resident synthetic batch every step; every step still voxelizes exactly once, inside the
+        # timed region; MVX_PIPELINE_INPUT=0 voxelizes at the start of the step instead)
         ready = None
         tt = [time.perf_counter()]
         if pipelined:
@@ -217,7 +220,10 @@ def main():
             t_end = time.perf_counter() + debug_sleep_ms * 1e-3
             while time.perf_counter() < t_end:
                 pass
-        nv, statuses = train_step_frames(model, batch, grad_mid, imsize, ready=ready)
+        if pipe_mid:
+            nv, statuses, mid_ready[0] = train_step_frames(model, batch, grad_mid, imsize, ready=mid_ready[0], prepare_next=batch)
+        else:
+            nv, statuses = train_step_frames(model, batch, grad_mid, imsize, ready=ready)
         tt.append(time.perf_counter())
         if pipelined:
             pl_mod.prepare_mid(pending[0], model.head)

@@ -154,12 +154,14 @@ def prepare_end(h, head):
     return h.frames, prepared, h.res.status, h.ev_b
 
 
-def train_step_frames(model, batch, grad_mid, imsize, ready=None):
+def train_step_frames(model, batch, grad_mid, imsize, ready=None, prepare_next=None):
     """Forward + backward of every frame of the batch through ``model.middle``; gradients
     accumulate in the parameters.  ``grad_mid`` is dL/d(middle output) (1,128,H,W), standing for
     the RPN + loss that follow the hot path.  ``ready``: result of ``prepare_end`` for this batch (input
-    pipelining); None prepares it here.  Returns (voxels per frame, list of device status words to be
-    checked by the caller once per step)."""
+    pipelining); None prepares it here.  ``prepare_next``: a batch to voxelize on the caller's stream right after this
+    step's frames have been handed to the lane streams -- the caller's stream is idle then, so the two host reads only
+    wait for those few kernels; the result is returned as a third value, to be passed as ``ready`` (with event None) next
+    time.  Returns (voxels per frame, list of device status words to be checked by the caller once per step)."""
     if ready is None:
         frames, prepared, status = prepare_frames(batch, model.head)
         ev_ready = None
@@ -202,6 +204,10 @@ def train_step_frames(model, batch, grad_mid, imsize, ready=None):
                 if flat is not None:
                     _hip.bias_stage_flush(dev)
             nvox.append(voxels.shape[1])
+        next_ready = None
+        if prepare_next is not None:
+            fr, pr, stt = prepare_frames(prepare_next, model.head)
+            next_ready = (fr, pr, stt, None)
     finally:
         _hip.GRAD_SINK = old_sink
         _hip.ASYNC_WGRAD = old_async
@@ -211,4 +217,6 @@ def train_step_frames(model, batch, grad_mid, imsize, ready=None):
             if st is not main:
                 main.wait_stream(st)
         _hip.join_side_stream()          # the gradients are complete for whoever comes next on this stream
+    if prepare_next is not None:
+        return nvox, statuses, next_ready
     return nvox, statuses

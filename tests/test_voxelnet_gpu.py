@@ -393,3 +393,9 @@ def test_pipeline_skips_empty_frames():
         bucket.zero()
         train_step_frames(model, one, grad_mid, imsize)
         assert rel_err(bucket.flat, again) < 1e-6
+    # input double-buffering: the next batch is voxelized mid-step and consumed by the following call
+    ready = None
+    for _ in range(3):
+        bucket.zero()
+        _, _, ready = train_step_frames(model, one, grad_mid, imsize, ready=ready, prepare_next=one)
+        assert rel_err(bucket.flat, again) < 1e-6
