@@ -17,13 +17,14 @@ ASYNC_WGRAD = _os.environ.get('MVX_ASYNC_WGRAD', '1') != '0'    # weight-gradien
 LANES = int(_os.environ.get('MVX_LANES', '2'))   # frames in flight: frame f runs on lane stream f % LANES (needs ASYNC_WGRAD for the
                         # single-writer gradient accumulation); 1 = all frames on the caller's stream
 TAPE = _os.environ.get('MVX_TAPE', '1') != '0'     # frames run through modules/tape.py (no autograd engine); 0 = autograd
+LANE_PRIORITY = int(_os.environ.get('MVX_LANE_PRIORITY', '0'))      # -1 = above the side (weight-gradient) stream
 _LANE_STREAMS = {}
 
 
 def lane_streams(device, n):
     key = device.index
     if key not in _LANE_STREAMS or len(_LANE_STREAMS[key]) < n:
-        _LANE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+        _LANE_STREAMS[key] = [torch.cuda.Stream(device=device, priority=LANE_PRIORITY) for _ in range(n)]
     return _LANE_STREAMS[key][:n]
 
 
