@@ -1,0 +1,30 @@
+"""The benchmark script itself: it must run end to end and print ONE JSON line with the contract's fields."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    env = dict(os.environ)
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--steps', '2', '--warmup', '1', '--frames', '2',
+                          '--points', '4000', '--no-cpu-baseline'], capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline'):
+        assert k in d, k
+    assert d['unit'] == 'frames/s' and d['n_gpus'] == 1 and d['steps'] == 2 and d['value'] > 0
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in r, k
+    assert r['bound'] == 'mfma' and 0 < r['frac'] < 1 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    assert d['alt_modes'] and d['alt_modes'][0]['value'] > 0
