@@ -5,7 +5,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, 'mvxnet-makise_amd'))
 from modules import _hip
 dev = torch.device('cuda')
-R, K, N = 20000, 768, 768
+R, K, N = int(sys.argv[1]) if len(sys.argv) > 1 else 20000, 768, 768
 x = torch.randn((R, K), device=dev)
 w = torch.randn((N, K), device=dev) * 0.03
 b = torch.zeros(N, device=dev)
