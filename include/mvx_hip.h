@@ -456,6 +456,53 @@ int mvx_conv3d_wgrad_split(const float *in, const float *dz, float *dw, int32_t 
                            int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, int32_t flags,
                            void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Target assignment and loss.
+ *
+ * mvx_bbox_pairwise: cpp.bboxOverlap / cpp.bboxIntersection (cpp/voxelutil.cpp:96-136; callers
+ *   modules/augment/Augment.py:54).  boxes f32 [n][4][2] BEV corner points -> out f32 [n1][n2]: IoU (want_iou != 0)
+ *   or intersection area, with the reference's origin-fan clipping arithmetic in f32.  The reference fills r2[j]
+ *   (box index) instead of r2[k] (corner index) at :107-109 -- out of bounds beyond 5 boxes; computed here is what its
+ *   callers expect, box i against box j.
+ *
+ * mvx_classify_anchors: cpp._classifyAnchors (cpp/voxelutil.cpp:138-316; modules/Calc.py:88-96; train.py:46).
+ *   gts f32 [n_gt][4][2], anchors f32 [l][w][anchors_per_loc][4][2] (BEV corners), nls / nws i64 [n_gt] = centre cell of
+ *   every ground truth (Calc.py:91-94).  Output, in the reference's visiting order (ground truth, orientation, rows
+ *   up then down, columns right then left):
+ *     pos_idx i64 [3][cap] (x, y, z of the positives: IoU >= pos_thr), gi i64 [cap] their ground-truth ids,
+ *     neg_idx i64 [3][cap] (the NOT-negative anchors: IoU >= neg_thr, positives included), counts i32 [2] on the device.
+ *   window_radius R (1..55): the walk is replayed inside a (2R+1)^2 window of cells around the centre; R must cover
+ *   every cell with IoU >= 0.1 (half the sum of the two box diagonals / cell size).  status i32 [1] (OR-ed): 1 = the walk
+ *   reached the window edge (raise R), 2 = cap exceeded, 4 = a centre cell outside the grid (ground truth skipped;
+ *   the reference indexes out of bounds there).
+ *   One documented difference: when the reference's crossing test fails on a near-degenerate edge (|s2 - s1| <= 1e-6,
+ *   :44) its static scratch keeps a point from an EARLIER call; this library takes the edge's start point instead.
+ *
+ * mvx_voxel_loss: VoxelLoss forward + backward (modules/voxelnet/Loss.py:15-45; train.py:140,161).
+ *   score f32 (l, w, anchors_per_loc) and reg f32 (l, w, 7*anchors_per_loc) through explicit element strides (the RPN's
+ *   (1,2,L,W) / (1,14,L,W) maps are read in place); pos_idx / neg_idx / gi as above with leading dimensions pos_ld /
+ *   neg_ld; gts f32 [n][gt_ld >= 7] xyzlwhr, anchors f32 [l][w][anchors_per_loc][7].
+ *   losses f32 [2] = (clsLoss, regLoss); dscore / dreg (optional) = d(clsLoss)/dscore and d(regLoss)/dreg written through
+ *   their own strides -- dreg must be ZERO on entry (only positive anchors receive a gradient; repeated anchors add up).
+ *   n_pos = 0: regLoss = 0 (the reference returns None); n_pos = n_neg = 0 is the `pi is None` branch (Loss.py:17-19).
+ *   counts_dev (optional) i32 [2]: read n_pos / n_neg from the device instead (forward only: dscore must be NULL).
+ *   scratch f64 [4].
+ */
+int mvx_bbox_pairwise(const float *boxes1, int32_t n1, const float *boxes2, int32_t n2, int32_t want_iou, float *out,
+                      void *stream);
+size_t mvx_classify_anchors_workspace_bytes(int32_t n_gt, int32_t anchors_per_loc, int32_t window_radius);
+int mvx_classify_anchors(const float *gts, int32_t n_gt, const float *anchors, int32_t l, int32_t w,
+                         int32_t anchors_per_loc, const int64_t *nls, const int64_t *nws, float neg_thr, float pos_thr,
+                         int32_t window_radius, int64_t *pos_idx, int64_t *neg_idx, int64_t *gi, int64_t cap,
+                         int32_t *counts, int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
+int mvx_voxel_loss(const float *score, int64_t score_sl, int64_t score_sw, int64_t score_sa, const float *reg,
+                   int64_t reg_sl, int64_t reg_sw, int64_t reg_sc, const int64_t *pos_idx, int64_t pos_ld,
+                   const int64_t *neg_idx, int64_t neg_ld, const int64_t *gi, const int32_t *counts_dev, int32_t n_pos,
+                   int32_t n_neg, const float *gts, int32_t gt_ld, const float *anchors, int32_t l, int32_t w,
+                   int32_t anchors_per_loc, float a, float b, float eps, float *dscore, int64_t dscore_sl,
+                   int64_t dscore_sw, int64_t dscore_sa, float *dreg, int64_t dreg_sl, int64_t dreg_sw, int64_t dreg_sc,
+                   float *losses, double *scratch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dy
         // the workgroup that finishes last folds the replicas into the bias gradient (no dbias_finish launch);
         // atomics-only protocol as in bn_finalize_by_last_block (common.h)
         __shared__ int s_last;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        mvx_drain_vmem();
         __syncthreads();
         if (threadIdx.x == 0) s_last = (atomicAdd(done_counter, 1u) == gridDim.x - 1u);
         __syncthreads();

@@ -63,12 +63,18 @@ __device__ __forceinline__ int block_excl_scan_i32(int v, int *smem, int *total)
 // arrives last turns the replicated sums into mean and 1/sqrt(var + eps), which saves the separate mvx_bn_finalize
 // launch.  Only device-scope ATOMICS carry the protocol (sums, counter, and the final reads), all served by the same
 // coherence point, so no agent-scope fence is needed: such a fence writes the XCD's L2 back (the output tile each
-// workgroup has just stored) and cost 13 % of the step when it was tried.  A workgroup's atomics are complete
-// (vmcnt == 0, workgroup-scope release) before its thread 0 bumps the counter.  `s_flag` is one int of LDS.
+// workgroup has just stored) and cost 13 % of the step when it was tried.  What the protocol does need is that every
+// thread's statistics atomics have been PERFORMED at L2 before thread 0 bumps the counter: a workgroup-scope release
+// emits no wait on gfx950 (the round-1 binary had the non-returning global_atomic_add_f64 followed by s_barrier and the
+// counter atomic with nothing in between), so each thread drains its own vector-memory counter explicitly
+// (mvx_drain_vmem: `s_waitcnt vmcnt(0)`; non-returning atomics are vmcnt-tracked on gfx9 and acknowledged by L2 once
+// performed) before the barrier.  No cache write-back is involved.  `s_flag` is one int of LDS.
+__device__ __forceinline__ void mvx_drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ void bn_finalize_by_last_block(unsigned *done_counter, unsigned total_blocks,
                                                           double *stats, int C, double count, double eps,
                                                           float *mean_inv, int *s_flag) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    mvx_drain_vmem();
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned prev = atomicAdd(done_counter, 1u);

@@ -97,6 +97,11 @@ PROTOTYPES = {
     'mvx_conv3d_dgrad_tiles': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
     'mvx_bn_relu_backward_tiles_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32]),
     'mvx_bn_relu_backward_tiles': (_i32, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _sz, _p]),
+    'mvx_bbox_pairwise': (_i32, [_p, _i32, _p, _i32, _i32, _p, _p]),
+    'mvx_classify_anchors_workspace_bytes': (_sz, [_i32, _i32, _i32]),
+    'mvx_classify_anchors': (_i32, [_p, _i32, _p, _i32, _i32, _i32, _p, _p, _f32, _f32, _i32, _p, _p, _p, _i64, _p, _p, _p, _sz, _p]),
+    'mvx_voxel_loss': (_i32, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _p, _i32, _p,
+                              _i32, _i32, _i32, _f32, _f32, _f32, _p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _p, _p]),
 }
 
 
@@ -160,9 +165,52 @@ def device():
 
 
 class _Cpp:
-    """The reference extension's python-visible surface (cpp/voxelutil.cpp:362-368) for the
-    hot path.  Only ``_group`` is on the path; the anchor/IoU helpers are CPU label
-    preparation and stay out of scope (SURVEY.md section 2 #13)."""
+    """The reference extension's python-visible surface (cpp/voxelutil.cpp:362-368): ``_group``,
+    ``_classifyAnchors``, ``bboxOverlap``, ``bboxIntersection`` -- numpy in, numpy out like the pybind11
+    module, computed by the HIP kernels."""
+
+    @staticmethod
+    def _boxes(b, dev):
+        b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else b
+        return torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32)).to(dev)
+
+    @staticmethod
+    def bboxOverlap(bboxes1, bboxes2):
+        """IoU of every BEV box pair, (N,4,2) x (M,4,2) -> (N,M) f32 (cpp/voxelutil.cpp:96-116; see
+        include/mvx_hip.h for the reference's corner-index bug that is not reproduced)."""
+        from modules import _hip
+        dev = device()
+        return _hip.bbox_pairwise(_Cpp._boxes(bboxes1, dev), _Cpp._boxes(bboxes2, dev), True).cpu().numpy()
+
+    @staticmethod
+    def bboxIntersection(bboxes1, bboxes2):
+        """Intersection area of every BEV box pair (cpp/voxelutil.cpp:118-136)."""
+        from modules import _hip
+        dev = device()
+        return _hip.bbox_pairwise(_Cpp._boxes(bboxes1, dev), _Cpp._boxes(bboxes2, dev), False).cpu().numpy()
+
+    @staticmethod
+    def _classifyAnchors(gts, anchors, nls, nws, negThr, posThr):
+        """``((px,py,pz), (nx,ny,nz), gi)`` int64 numpy arrays, the contract of cpp/voxelutil.cpp:138-316."""
+        from modules import _hip
+        from modules import Calc
+        dev = device()
+        g = _Cpp._boxes(gts, dev)
+        a = _Cpp._boxes(anchors, dev)
+        to_i64 = lambda v: torch.as_tensor(np.asarray(v.cpu() if isinstance(v, torch.Tensor) else v, dtype=np.int64)).to(dev)
+        radius = Calc._window_radius(g.cpu(), a[:2, :2].cpu()) if g.shape[0] else 2
+        while True:
+            pos, neg, gi, counts, status = _hip.classify_anchors(g, a, to_i64(nls), to_i64(nws), negThr, posThr, radius)
+            n_pos, n_neg, st = counts.tolist() + status.tolist()
+            if st & 1 and radius < 55:
+                radius = min(55, 2 * radius)
+                continue
+            break
+        if st:
+            raise MvxHipError('_classifyAnchors: status %d (1 = window too small, 4 = centre outside the grid)' % st)
+        pos, neg, gi = pos.cpu().numpy(), neg.cpu().numpy(), gi.cpu().numpy()
+        return ((pos[0, :n_pos].copy(), pos[1, :n_pos].copy(), pos[2, :n_pos].copy()),
+                (neg[0, :n_neg].copy(), neg[1, :n_neg].copy(), neg[2, :n_neg].copy()), gi[:n_pos].copy())
 
     @staticmethod
     def _group(pcd, idx, samplesPerVoxel):

@@ -1033,3 +1033,58 @@ def accumulate_grad(param, g):
     else:
         tgt.add_(g.view_as(tgt))
     return None
+
+
+# ---------------------------------------------------------------------------------------------
+# target assignment and loss (csrc/anchors.hip, csrc/loss.hip)
+# ---------------------------------------------------------------------------------------------
+def bbox_pairwise(b1, b2, want_iou):
+    """b1 (N,4,2), b2 (M,4,2) f32 BEV corners on the GPU -> (N,M) IoU or intersection area."""
+    n, m = b1.shape[0], b2.shape[0]
+    out = torch.empty((n, m), dtype=torch.float32, device=b1.device)
+    X.check(X.lib.mvx_bbox_pairwise(X.ptr(b1), n, X.ptr(b2), m, int(want_iou), X.ptr(out), X.stream()), 'mvx_bbox_pairwise')
+    return out
+
+
+def classify_anchors(gts, anchor_bevs, nls, nws, neg_thr, pos_thr, radius, cap=None):
+    """Device tensors in, capacity-sized device tensors out: (pos_idx i64 (3,cap), neg_idx i64 (3,cap), gi i64 (cap,),
+    counts i32 (2,), status i32 (1,))."""
+    G = gts.shape[0]
+    L, W, A = anchor_bevs.shape[:3]
+    dev = anchor_bevs.device
+    wn = 2 * radius + 1
+    cap = max(1, G * A * wn * wn) if cap is None else int(cap)
+    pos = torch.empty((3, cap), dtype=torch.int64, device=dev)
+    neg = torch.empty((3, cap), dtype=torch.int64, device=dev)
+    gi = torch.empty((cap,), dtype=torch.int64, device=dev)
+    counts = torch.empty((2,), dtype=torch.int32, device=dev)
+    status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ws = workspace(X.lib.mvx_classify_anchors_workspace_bytes(G, A, radius), dev, 'anchors')
+    X.check(X.lib.mvx_classify_anchors(X.ptr(gts), G, X.ptr(anchor_bevs), L, W, A, X.ptr(nls), X.ptr(nws), float(neg_thr),
+                                       float(pos_thr), int(radius), X.ptr(pos), X.ptr(neg), X.ptr(gi), cap, X.ptr(counts),
+                                       X.ptr(status), X.ptr(ws), ws.numel(), X.stream()), 'mvx_classify_anchors')
+    return pos, neg, gi, counts, status
+
+
+def voxel_loss(score, reg, pos_idx, neg_idx, gi, n_pos, n_neg, gts, anchors, A, a, b, eps, want_grads=True):
+    """score (L,W,A) / reg (L,W,7A) f32 views with arbitrary strides; pos_idx / neg_idx i64 (3,cap) or None.
+    Returns (losses f32 (2,), dscore, dreg) -- the gradients share the inputs' memory layout."""
+    L, W = score.shape[0], score.shape[1]
+    dev = score.device
+    losses = torch.empty((2,), dtype=torch.float32, device=dev)
+    scratch = torch.empty((4,), dtype=torch.float64, device=dev)
+    dscore = torch.empty_strided(score.shape, score.stride(), dtype=torch.float32, device=dev) if want_grads else None
+    dreg = None
+    if want_grads and reg is not None:
+        dreg = torch.empty_strided(reg.shape, reg.stride(), dtype=torch.float32, device=dev)
+        dreg.zero_()
+    ss = score.stride()
+    rs = reg.stride() if reg is not None else (0, 0, 0)
+    X.check(X.lib.mvx_voxel_loss(_vptr(score), ss[0], ss[1], ss[2], _vptr(reg), rs[0], rs[1], rs[2],
+                                 X.ptr(pos_idx), pos_idx.shape[1] if pos_idx is not None else 0,
+                                 X.ptr(neg_idx), neg_idx.shape[1] if neg_idx is not None else 0, X.ptr(gi), None,
+                                 int(n_pos), int(n_neg), X.ptr(gts), gts.shape[1] if gts is not None else 7,
+                                 X.ptr(anchors), L, W, int(A), float(a), float(b), float(eps),
+                                 _vptr(dscore), ss[0], ss[1], ss[2], _vptr(dreg), rs[0], rs[1], rs[2],
+                                 X.ptr(losses), X.ptr(scratch), X.stream()), 'mvx_voxel_loss')
+    return losses, dscore, dreg

@@ -155,14 +155,15 @@ def prepare_end(h, head):
     return h.frames, prepared, h.res.status, h.ev_b
 
 
-def train_step_frames(model, batch, grad_mid, imsize, ready=None, prepare_next=None):
+def train_step_frames(model, batch, grad_mid, imsize, ready=None, prepare_next=None, keep_mid=None):
     """Forward + backward of every frame of the batch through ``model.middle``; gradients
     accumulate in the parameters.  ``grad_mid`` is dL/d(middle output) (1,128,H,W), standing for
     the RPN + loss that follow the hot path.  ``ready``: result of ``prepare_end`` for this batch (input
     pipelining); None prepares it here.  ``prepare_next``: a batch to voxelize on the caller's stream right after this
     step's frames have been handed to the lane streams -- the caller's stream is idle then, so the two host reads only
     wait for those few kernels; the result is returned as a third value, to be passed as ``ready`` (with event None) next
-    time.  Returns (voxels per frame, list of device status words to be checked by the caller once per step)."""
+    time.  ``keep_mid``: a list that receives every frame's middle map (tests).
+    Returns (voxels per frame, list of device status words to be checked by the caller once per step)."""
     if ready is None:
         frames, prepared, status = prepare_frames(batch, model.head)
         ev_ready = None
@@ -197,11 +198,14 @@ def train_step_frames(model, batch, grad_mid, imsize, ready=None, prepare_next=N
                 if flat is not None:
                     _hip.bias_stage_begin(dev, flat)
                 if TAPE:
-                    tape.middle_train(model, voxels, batch.fpn_levels[f], idx, imsize, prepared[f], statuses, grad_mid)
+                    mid = tape.middle_train(model, voxels, batch.fpn_levels[f], idx, imsize, prepared[f], statuses, grad_mid)
                 else:
                     mid = model.middle(voxels, batch.fpn_levels[f], idx, [None], imsize, prepared=prepared[f],
                                        status_sink=statuses)
                     mid.backward(grad_mid)
+                if keep_mid is not None:
+                    mid.record_stream(main)
+                    keep_mid.append(mid.detach())
                 if flat is not None:
                     _hip.bias_stage_flush(dev)
             nvox.append(voxels.shape[1])

@@ -35,6 +35,12 @@ import mvx_oracle as O  # noqa: E402
 def import_reference():
     os.chdir(REF)
     sys.argv = ['x']
+    # the oracle module pulls the synthetic-frame generator from the package's own ``modules``: drop that package from
+    # the import state so that ``modules`` below is the REFERENCE's
+    pkg = os.path.join(REPO, 'mvxnet-makise_amd')
+    sys.path[:] = [p for p in sys.path if os.path.abspath(p or '.') != pkg]
+    for name in [k for k in sys.modules if k == 'modules' or k.startswith('modules.') or k == 'MVXNet']:
+        del sys.modules[name]
     sys.path.insert(0, REF)
     nb = types.ModuleType('numba')
     nb.njit = lambda f=None, *a, **k: f if callable(f) else (lambda g: g)

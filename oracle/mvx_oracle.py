@@ -439,6 +439,141 @@ def strip_prefix(p: Dict[str, torch.Tensor], prefix: str) -> Dict[str, torch.Ten
     return {k[len(prefix):]: v for k, v in p.items() if k.startswith(prefix)}
 
 
+# ----------------------------------------------------------------------------
+# anchors, target assignment, loss
+# ----------------------------------------------------------------------------
+CARSIZE = [3.9, 1.6, 1.56]
+
+
+def create_anchors(l: int, w: int, rng=VELORANGE, size=CARSIZE) -> torch.Tensor:
+    """(l, w, 14): two 7-dof anchors (yaw 0, pi/2) per BEV cell, z = -1
+    (modules/data/Preprocessing.py:118-142)."""
+    ls, ws = (rng[3] - rng[0]) / l, (rng[4] - rng[1]) / w
+    x = torch.linspace(rng[0] + ls / 2, rng[3] - ls / 2, l)
+    y = torch.linspace(rng[1] + ws / 2, rng[4] - ws / 2, w)
+    gx, gy = torch.meshgrid(x, y, indexing='ij')
+    cols = [gx[..., None], gy[..., None], torch.full((l, w, 1), -1.0), torch.Tensor(size).tile((l, w, 1))]
+    a0 = torch.concat(cols + [torch.zeros((l, w, 1))], dim=2)
+    a1 = torch.concat(cols + [torch.full((l, w, 1), torch.pi / 2)], dim=2)
+    return torch.concat([a0, a1], dim=2)
+
+
+def bbox3d2bev(boxes: torch.Tensor) -> torch.Tensor:
+    """(..., 7) xyzlwhr -> BEV corner points (..., 4, 2) (modules/Calc.py:15-38): unit square corners
+    scaled by (l, w), multiplied from the RIGHT by [[cos, -sin], [sin, cos]], shifted by (x, y)."""
+    shape = boxes.shape[:-1]
+    b = boxes.reshape(-1, boxes.shape[-1])
+    unit = torch.Tensor([[0.5, 0.5], [-0.5, 0.5], [-0.5, -0.5], [0.5, -0.5]])
+    res = torch.tile(unit, (b.shape[0], 1, 1)) * b[:, None, [3, 4]]
+    c, s_ = torch.cos(b[:, 6]).reshape(-1, 1), torch.sin(b[:, 6]).reshape(-1, 1)
+    rot = torch.concat([c, -s_, s_, c], dim=1).reshape(-1, 2, 2)
+    res = res @ rot + b[:, None, [0, 1]]
+    return res.reshape(shape + (4, 2)) if len(shape) else res[0]
+
+
+_ORACLE_C = None
+
+
+def _oracle_c():
+    global _ORACLE_C
+    if _ORACLE_C is None:
+        import ctypes
+        _ORACLE_C = ctypes.CDLL(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), 'liboracle_c.so'))
+        _ORACLE_C.oracle_anchor_stale_reads.restype = ctypes.c_int64
+    return _ORACLE_C
+
+
+def _f32p(a):
+    import ctypes
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def bbox_pairwise(b1: np.ndarray, b2: np.ndarray, iou: bool) -> np.ndarray:
+    """IoU (``cpp.bboxOverlap``) or intersection area (``cpp.bboxIntersection``) of every BEV box pair,
+    (N,4,2) x (M,4,2) -> (N,M) f32, with the corner-index fix described in oracle/anchors_c.c
+    (cpp/voxelutil.cpp:96-136)."""
+    import ctypes
+    b1 = np.ascontiguousarray(b1, np.float32)
+    b2 = np.ascontiguousarray(b2, np.float32)
+    out = np.empty((b1.shape[0], b2.shape[0]), np.float32)
+    _oracle_c().oracle_bbox_pairwise(_f32p(b1), ctypes.c_int64(b1.shape[0]), _f32p(b2), ctypes.c_int64(b2.shape[0]),
+                                     ctypes.c_int(1 if iou else 0), _f32p(out))
+    return out
+
+
+def classify_anchors_cells(gts: np.ndarray, anchors: np.ndarray, nls: np.ndarray, nws: np.ndarray,
+                           neg_thr: float, pos_thr: float):
+    """``cpp._classifyAnchors`` (cpp/voxelutil.cpp:138-316): gts (G,4,2) f32, anchors (L,W,A,4,2) f32,
+    centre cells nls/nws i64 (G,) -> ((px,py,pz), (nx,ny,nz), gi) int64 arrays in the reference's order."""
+    import ctypes
+    gts = np.ascontiguousarray(gts, np.float32)
+    anchors = np.ascontiguousarray(anchors, np.float32)
+    nls = np.ascontiguousarray(nls, np.int64)
+    nws = np.ascontiguousarray(nws, np.int64)
+    L, W, A = anchors.shape[:3]
+    G = gts.shape[0]
+    cap = max(1, L * W * A * max(1, G))
+    cap = min(cap, 1 << 24)
+    bufs = [np.empty(cap, np.int64) for _ in range(7)]
+    counts = np.zeros(2, np.int64)
+    _oracle_c().oracle_classify_anchors(_f32p(gts), ctypes.c_int64(G), _f32p(anchors), ctypes.c_int64(L), ctypes.c_int64(W),
+                                        ctypes.c_int64(A), _f32p(nls), _f32p(nws), ctypes.c_float(neg_thr),
+                                        ctypes.c_float(pos_thr), *[_f32p(b) for b in bufs], _f32p(counts))
+    npos, nneg = int(counts[0]), int(counts[1])
+    return (tuple(b[:npos].copy() for b in bufs[0:3]), tuple(b[:nneg].copy() for b in bufs[3:6]), bufs[6][:npos].copy())
+
+
+def anchor_center_cells(gt_centers: torch.Tensor, anchors_shape, rng=VELORANGE):
+    """Centre cell of every ground truth (modules/Calc.py:91-94), torch f32 arithmetic then .long()."""
+    l = (rng[3] - rng[0]) / anchors_shape[0]
+    w = (rng[4] - rng[1]) / anchors_shape[1]
+    nls = ((gt_centers[:, 0] - rng[0] - l / 2) / l + 0.5).long()
+    nws = ((gt_centers[:, 1] - rng[1] - w / 2) / w + 0.5).long()
+    return nls, nws
+
+
+def classify_anchors(gts_bev: torch.Tensor, gt_centers: torch.Tensor, anchor_bevs: torch.Tensor, rng, neg_thr, pos_thr):
+    """modules/Calc.py:88-96."""
+    nls, nws = anchor_center_cells(gt_centers, anchor_bevs.shape, rng)
+    return classify_anchors_cells(gts_bev.numpy(), anchor_bevs.numpy(), nls.numpy(), nws.numpy(), neg_thr, pos_thr)
+
+
+def make_loss_inputs(L: int, W: int, seed: int):
+    """Deterministic RPN outputs for the loss fixtures: score (L,W,2) in (0,1), reg (L,W,14)."""
+    score = torch.sigmoid(torch.from_numpy(fast_uniform(L * W * 2, seed).reshape(L, W, 2)).float() * 3)
+    reg = torch.from_numpy(fast_uniform(L * W * 14, seed + 10).reshape(L, W, 14)).float() * 0.5
+    return score, reg
+
+
+def voxel_loss(pi, ni, gi, gts, score, reg, anchors, anchors_per_loc, a=1.5, b=1.0, eps=EPS):
+    """VoxelLoss.forward (modules/voxelnet/Loss.py:15-45).  score (L,W,A), reg (L,W,7A); pi / ni index triples,
+    gi ground-truth id per positive; returns (clsLoss, regLoss or None)."""
+    if pi is None:
+        return -torch.log(1 - score + eps).mean(), None
+    pi = tuple(torch.as_tensor(np.asarray(t)).long() for t in pi)
+    ni = tuple(torch.as_tensor(np.asarray(t)).long() for t in ni)
+    gi = torch.as_tensor(np.asarray(gi)).long()
+    pos = -torch.log(score[pi] + eps).sum()
+    neg_all = -torch.log(1 - score + eps)
+    size_sum = neg_all.shape[0] * neg_all.shape[1] * neg_all.shape[2]
+    neg = neg_all.sum() - neg_all[ni].sum()            # a cell listed twice in ni is subtracted twice, as in the reference
+    pos = pos / (pi[0].shape[0] + eps)
+    neg = neg / (size_sum - ni[0].shape[0] + eps)
+    cls = a * pos + b * neg
+    if len(pi[0]) == 0:
+        return cls, None
+    g = gts[gi]
+    an = anchors.reshape((anchors.shape[0], anchors.shape[1], anchors_per_loc, 7))[pi]
+    d = torch.sqrt(an[:, 3] ** 2 + an[:, 4] ** 2)[:, None]
+    t = torch.empty_like(g)
+    t[:, [0, 1]] = (g[:, [0, 1]] - an[:, [0, 1]]) / d
+    t[:, 2] = (g[:, 2] - an[:, 2]) / an[:, 5]
+    t[:, 3:6] = torch.log(g[:, 3:6] / an[:, 3:6])
+    t[:, 6] = g[:, 6] - an[:, 6]
+    r = reg.reshape((reg.shape[0], reg.shape[1], anchors_per_loc, 7))[pi]
+    return cls, F.smooth_l1_loss(r, t)                 # nn.SmoothL1Loss(): mean over N*7, beta = 1
+
+
 # Synthetic KITTI-shaped frames and the calibration live in the package (bench.py uses them and
 # may not import oracle/); re-exported here for the tests.
 import os as _os
