@@ -173,7 +173,8 @@ def main():
 
     import modules.config as cfg
     from modules import _hip
-    from modules.pipeline import train_step_frames
+    from modules import pipeline as _pl
+    train_step_frames = _pl.train_step_frame_set if _pl.BATCHED else _pl.train_step_frames
     from MVXNet import MVXNet
     if args.convmath:
         cfg.config['convmath'] = args.convmath

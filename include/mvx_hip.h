@@ -41,6 +41,39 @@ extern "C" {
 #define MVX_EINVAL (-1)   /* bad argument (null pointer, size, unsupported combination) */
 #define MVX_ESIZE (-2)    /* a size exceeds what the kernel supports */
 
+/* ------------------------------------------------------------------------------------------
+ * Frame sets.  The reference is batch-1 (config.yml:18, modules/voxelnet/VoxelNet.py:19): a batch of B frames is B
+ * independent forwards with PER-FRAME BatchNorm statistics and summed parameter gradients.  The
+ * `*_frames` entry points run all frames of a step through ONE launch per layer: row matrices hold the frames back to
+ * back, grids stack them along the depth axis ([n_frames * planes][h][w][c]), and every per-frame quantity (statistics,
+ * mean / inverse std, background constants, counters) gets a leading frame dimension.  Parameter gradients are summed
+ * over the frames by construction.  The descriptor lives on the HOST and is copied by value into the launches.
+ *
+ *   real_off[f] .. real_off[f+1]   compact REAL rows of frame f (points that survived the T cap), all frames back to back
+ *   vox_off[f]  .. vox_off[f+1]    voxels of frame f
+ *   t                              samples per voxel: frame f stands for (vox_off[f+1]-vox_off[f]) * t dense rows
+ * Row layouts (`row_kind`):
+ *   MVX_ROWS_SINGLE  one frame, no descriptor (what the entry points without `_frames` use)
+ *   MVX_ROWS_FUSION  [real rows of all frames][one shared padded row per frame]        (fusion MLP, imhead/Pipe.py:84-104)
+ *   MVX_ROWS_VFE     [real rows of all frames][one padded row per voxel, all frames]   (VFE stack, voxelnet/Pipe.py:5-29)
+ *   MVX_ROWS_VOXELS  [one row per voxel, all frames]
+ *   MVX_ROWS_GRID    [n_frames][rows / n_frames] equal shares (channels-last grids)
+ *   MVX_ROWS_REAL    [real rows of all frames] (the sampler's output before the shared padded rows are appended)
+ */
+#define MVX_MAX_FRAMES 16
+#define MVX_ROWS_SINGLE 0
+#define MVX_ROWS_FUSION 1
+#define MVX_ROWS_VFE 2
+#define MVX_ROWS_VOXELS 3
+#define MVX_ROWS_GRID 4
+#define MVX_ROWS_REAL 5        /* [real rows of all frames] only */
+typedef struct {
+    int32_t n_frames;
+    int32_t t;
+    int32_t real_off[MVX_MAX_FRAMES + 1];
+    int32_t vox_off[MVX_MAX_FRAMES + 1];
+} mvx_frames_t;
+
 /* ABI version; bumped whenever a signature changes. */
 int mvx_abi_version(void);
 
@@ -455,6 +488,107 @@ int mvx_conv3d_dgrad_split(const float *dz, const void *wsplit_dgrad, float *dx,
 int mvx_conv3d_wgrad_split(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
                            int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, int32_t flags,
                            void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Frame-set forms (see mvx_frames_t above): the same operations as the entry points of the same name without `_frames`,
+ * for all frames of a step in ONE launch.  Conventions:
+ *   - `frames_host` is a HOST pointer (copied by value into the launch); NULL = one frame;
+ *   - `n_frames` forms: grids hold the frames stacked along depth -- [n_frames * planes][h][w][c]; din / dout / planes
+ *     are PER FRAME; per-plane arrays (background constants, halo / tile flags, tap sums, plane gradient sums) are
+ *     indexed by the global plane frame * planes + local plane;
+ *   - per-frame results get a leading frame dimension: stats f64 [F][R][2][C], mean_inv f32 [F][2][C];
+ *   - bias / weight gradients are summed over the frames (the reference accumulates them over the frames of a step).
+ * Row forms take `row_kind` (MVX_ROWS_*).  BatchNorm populations per frame follow from the descriptor
+ * (voxels of the frame x t), or, for MVX_ROWS_GRID, rows / n_frames.
+ */
+int mvx_linear_forward_bn_frames(const float *x, int32_t ldx, const float *w, int32_t ldw, int32_t w_transposed,
+                                 const float *bias, float *y, int32_t ldy, double *stats, const float *row_w, int64_t rows,
+                                 int32_t k, int32_t n, int32_t flags, uint32_t *done_counter, double eps, float *mean_inv,
+                                 const mvx_frames_t *frames_host, int32_t row_kind, void *stream);
+int mvx_bn_finalize_frames(const double *stats, double count, double eps, float *mean_inv, int32_t channels,
+                           int32_t n_frames, void *stream);
+int mvx_bn_apply_frames(const float *y, const float *mean_inv, float *out, int64_t rows, int32_t channels,
+                        const mvx_frames_t *frames_host, int32_t row_kind, void *stream);
+size_t mvx_bn_backward_scratch_bytes_frames(int32_t channels, int32_t n_frames);
+int mvx_bn_relu_backward_frames(const float *dyhat, const float *y, const float *mean_inv, double count, float *dz,
+                                float *dbias, double *scratch, const float *row_w, int64_t rows, int32_t channels,
+                                int32_t flags, const mvx_frames_t *frames_host, int32_t row_kind, void *stream);
+int mvx_vfe_bn_max_concat_frames(const float *y, const float *mean_inv, float *out, int32_t *argmax, int32_t n_voxels,
+                                 int32_t t, int32_t channels, const int32_t *voff, const int32_t *vcnt, int32_t n_real,
+                                 const mvx_frames_t *frames_host, void *stream);
+int mvx_bn_segment_max_frames(const float *y, const float *mean_inv, float *out, int32_t *argmax, int32_t n_voxels,
+                              int32_t t, int32_t channels, const int32_t *voff, const int32_t *vcnt, int32_t n_real,
+                              const mvx_frames_t *frames_host, void *stream);
+/* fusion_row_w (optional) f32 [n_real + n_frames]: row weights of the MVX_ROWS_FUSION layout (1 for real rows, the number
+ * of padded rows of frame f for its shared padded row) */
+int mvx_voxel_row_offsets_frames(const int32_t *row_map, int32_t n_voxels, int32_t t, int32_t n_real, int32_t *voff,
+                                 int32_t *vcnt, float *row_w, float *fusion_row_w, const mvx_frames_t *frames_host,
+                                 void *stream);
+/* imfeat / dimfeat: MVX_ROWS_FUSION layout [n_real + n_frames][F]; scratch f64 [n_frames][F] */
+int mvx_vfe_compact_input_frames(const float *voxels, int32_t vox_channels, const int32_t *rows_sel, const float *imfeat,
+                                 int32_t feat_channels, int32_t n_real, int32_t n_voxels, float *out,
+                                 const mvx_frames_t *frames_host, void *stream);
+int mvx_vfe_compact_input_backward_frames(const float *grad_out, int32_t feat_channels, int32_t n_real, int32_t n_voxels,
+                                          float *dimfeat, double *scratch, const mvx_frames_t *frames_host, void *stream);
+/* voxels of all frames back to back ([vox_off[F]][t][vox_channels]); real_off i32 [n_frames + 1] on the DEVICE receives the
+ * real-row offsets of the frames (only vox_off and t of the descriptor are read) */
+int mvx_row_compact_map_frames(float *voxels, int32_t vox_channels, int64_t rows, int32_t *row_map, int32_t *rows_sel,
+                               int32_t *n_real, void *workspace, size_t workspace_bytes, const mvx_frames_t *frames_host,
+                               int32_t *real_off, void *stream);
+/* feats_host[f * n_levels + l] = level l of frame f (every frame has the same level shapes) */
+int mvx_feature_sample_rows_frames(const float *voxels, int32_t vox_channels, const int32_t *rows_sel, int32_t n_real,
+                                   const float *const *feats_host, const int32_t *feat_hw_host, int32_t n_levels,
+                                   int32_t channels, float imsize_h, float imsize_w, float eps, float *out, int32_t *status,
+                                   const mvx_frames_t *frames_host, void *stream);
+/* coords of all frames back to back; the frame of voxel v follows from vox_off (coords[:,0] is not read) */
+size_t mvx_index_grid_bytes_frames(int32_t d, int32_t h, int32_t w, int32_t n_frames);
+int mvx_index_grid_frames(const int64_t *coords, int32_t n_voxels, int32_t d, int32_t h, int32_t w, int32_t *grid,
+                          int32_t *status, const mvx_frames_t *frames_host, void *stream);
+int mvx_sparse_conv_output_frames(const float *p, const int32_t *index_grid, const float *bias, float *out, double *stats,
+                                  int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cout, int32_t stride_d,
+                                  int32_t pad_d, int32_t flags, int32_t n_frames, void *stream);
+int mvx_sparse_conv_gather_dz_frames(const float *dz, const int64_t *coords, int32_t n_voxels, float *g_rows, int32_t din,
+                                     int32_t dout, int32_t h, int32_t w, int32_t cout, int32_t stride_d, int32_t pad_d,
+                                     const mvx_frames_t *frames_host, void *stream);
+int mvx_activity_dilate_frames(const void *src, int32_t src_is_index, int32_t din, int32_t dout, int32_t h, int32_t w,
+                               int32_t stride_d, int32_t pad_d, int32_t mark_border, uint8_t *dst_mask,
+                               int32_t *dst_halo_flags, int32_t *dst_tile_flags, int32_t n_frames, void *stream);
+int mvx_tile_dilate_flags_frames(const int32_t *in_tile_flags, const int32_t *self_tile_flags, int32_t din, int32_t dout,
+                                 int32_t h, int32_t w, int32_t stride_d, int32_t pad_d, int32_t *out_tile_flags,
+                                 int32_t n_frames, void *stream);
+int mvx_conv3d_background_frames(const float *w, const float *c_in, int32_t din, int32_t dout, int32_t cin, int32_t cout,
+                                 int32_t stride_d, int32_t pad_d, float *bg_pre, int32_t n_frames, void *stream);
+int mvx_bn_background_frames(const float *bg_pre, const float *bias, const float *mean_inv, int32_t planes, int32_t channels,
+                             int32_t flags, float *y_bg, float *c_out, int32_t n_frames, void *stream);
+int mvx_conv3d_forward_bg_frames(const float *in, const float *wpk, const float *bias, float *out, double *stats,
+                                 int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                                 int32_t stride_d, int32_t pad_d, int32_t flags, const int32_t *in_halo_flags,
+                                 const uint8_t *out_mask, const float *bg_pre, int32_t border_active, uint64_t *exec_stages,
+                                 uint32_t *done_counter, double count, double eps, float *mean_inv, uint32_t *work_counter,
+                                 int32_t n_frames, void *stream);
+int mvx_conv3d_dgrad_tiles_frames(const float *dz, const float *wpk_dgrad, float *dx, int32_t din, int32_t dout, int32_t h,
+                                  int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
+                                  const int32_t *dx_tile_flags, uint64_t *exec_stages, uint32_t *work_counter,
+                                  int32_t n_frames, void *stream);
+int mvx_conv3d_input_grad_sums_frames(const float *w, const float *tap_sums, int32_t din, int32_t dout, int32_t cin,
+                                      int32_t cout, int32_t stride_d, int32_t pad_d, float *plane_grad_sums,
+                                      int32_t n_frames, void *stream);
+size_t mvx_conv3d_wgrad_bg_workspace_bytes_frames(int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                                                  int32_t n_frames);
+int mvx_conv3d_wgrad_bg_frames(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h, int32_t w,
+                               int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, int32_t flags,
+                               const int32_t *in_halo_flags, const float *c_in, const float *tap_sums, void *workspace,
+                               size_t workspace_bytes, int32_t n_frames, void *stream);
+size_t mvx_bn_relu_backward_tiles_workspace_bytes_frames(int32_t planes, int32_t h, int32_t w, int32_t channels,
+                                                         int32_t n_frames);
+int mvx_bn_relu_backward_tiles_frames(const float *dyhat, const float *y, const float *mean_inv, const float *c_bg,
+                                      const float *y_bg, const float *plane_grad_sums, const int32_t *tile_flags,
+                                      int32_t planes, int32_t h, int32_t w, int32_t channels, float *dz, float *dbias,
+                                      float *dz_inactive_sums, int32_t flags, void *workspace, size_t workspace_bytes,
+                                      int32_t n_frames, void *stream);
+/* cl f32 [n_frames * d][h][w][c]  <->  bev f32 [n_frames][c * d][h][w] */
+int mvx_cl_to_bev_frames(const float *cl, float *bev, int32_t d, int32_t h, int32_t w, int32_t channels, int32_t reverse,
+                         int32_t n_frames, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Target assignment and loss.

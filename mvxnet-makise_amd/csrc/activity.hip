@@ -21,14 +21,14 @@ constexpr int ATH = 8, ATW = 16;        // tile of the convolution kernels (conv
 // dst[d][y][x] = 1 iff any source site in the 3x3x3 receptive field is active, or (mark_border and the
 // in-plane window leaves the image).  Source: int32 index grid (voxel id, -1 = empty) or uint8 mask.
 __global__ void activity_sites(const void *__restrict__ src, int src_is_index, int Din, int Dout, int H, int W, int sd,
-                               int pd, int mark_border, unsigned char *__restrict__ dst) {
-    const size_t n = (size_t)Dout * H * W;
+                               int pd, int mark_border, unsigned char *__restrict__ dst, int n_frames) {
+    const size_t n = (size_t)n_frames * Dout * H * W;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(e % W), y = (int)((e / W) % H), d = (int)(e / ((size_t)W * H));
         int on = mark_border && (y == 0 || y == H - 1 || x == 0 || x == W - 1);
         for (int kd = 0; kd < 3 && !on; ++kd) {
-            const int ds = d * sd - pd + kd;
-            if (ds < 0 || ds >= Din) continue;
+            const int ds = mvx_src_plane(d, Din, Dout, sd, pd, kd);
+            if (ds < 0) continue;
             for (int a = -1; a <= 1 && !on; ++a) {
                 const int yy = y + a;
                 if (yy < 0 || yy >= H) continue;
@@ -70,15 +70,15 @@ __global__ __launch_bounds__(256) void activity_halo_flags(const unsigned char *
 // the tiles of this layer's OUTPUT GRADIENT that the consumers of its restricted backward read (the halo of a
 // flagged input tile reaches into all 8 neighbours).  in: flags of the conv INPUT [Din], self/out: [Dout].
 __global__ void tile_dilate_flags(const int *__restrict__ in, const int *__restrict__ self, int Din, int Dout, int tiles_y,
-                                  int tiles_x, int sd, int pd, int *__restrict__ out) {
+                                  int tiles_x, int sd, int pd, int *__restrict__ out, int n_frames) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int nt = tiles_y * tiles_x;
-    if (e >= Dout * nt) return;
+    if (e >= n_frames * Dout * nt) return;
     const int d = e / nt, t = e - d * nt, ty = t / tiles_x, tx = t - ty * tiles_x;
     int on = self ? self[e] : 0;
     for (int kd = 0; kd < 3 && !on; ++kd) {
-        const int ds = d * sd - pd + kd;
-        if (ds < 0 || ds >= Din) continue;
+        const int ds = mvx_src_plane(d, Din, Dout, sd, pd, kd);
+        if (ds < 0) continue;
         for (int a = -1; a <= 1 && !on; ++a)
             for (int b = -1; b <= 1; ++b) {
                 const int yy = ty + a, xx = tx + b;
@@ -93,11 +93,11 @@ __global__ void tile_dilate_flags(const int *__restrict__ in, const int *__restr
 __global__ __launch_bounds__(64) void conv_background(const float *__restrict__ w, const float *__restrict__ c_in, int Din,
                                                       int Dout, int Cin, int Cout, int sd, int pd,
                                                       float *__restrict__ bg_pre) {
-    const int n = blockIdx.x, d = blockIdx.y;        // one wave per (output channel, plane); lanes over (c, tap)
+    const int n = blockIdx.x, d = blockIdx.y;        // one wave per (output channel, global plane); lanes over (c, tap)
     double s = 0.0;
     for (int kd = 0; kd < 3; ++kd) {
-        const int ds = d * sd - pd + kd;
-        if (ds < 0 || ds >= Din) continue;
+        const int ds = mvx_src_plane(d, Din, Dout, sd, pd, kd);
+        if (ds < 0) continue;
         for (int e = threadIdx.x; e < Cin * 9; e += 64) {
             const int c = e / 9, k = e - c * 9;
             s += (double)w[(((size_t)n * Cin + c) * 3 + kd) * 9 + k] * (double)c_in[(size_t)ds * Cin + c];
@@ -110,10 +110,11 @@ __global__ __launch_bounds__(64) void conv_background(const float *__restrict__ 
 // y_bg = [ReLU](bg_pre + bias) and c_out = (y_bg - mean) * inv, with exactly the fp32 operations of the
 // convolution epilogue and of bn_apply, so that c_out equals the normalised tensor at background sites bit for bit.
 __global__ void bn_background(const float *__restrict__ bg_pre, const float *__restrict__ bias, const float *__restrict__ mi,
-                              int D, int C, int relu, float *__restrict__ y_bg, float *__restrict__ c_out) {
+                              int D, int C, int relu, float *__restrict__ y_bg, float *__restrict__ c_out, int n_frames) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= D * C) return;
+    if (e >= n_frames * D * C) return;
     const int c = e % C;
+    mi += (size_t)(e / (D * C)) * 2 * C;                  // the plane's frame
     float v = (bg_pre ? bg_pre[e] : 0.f) + (bias ? bias[c] : 0.f);
     if (relu) v = fmaxf(v, 0.f);
     if (y_bg) y_bg[e] = v;
@@ -128,13 +129,14 @@ __global__ void bn_background(const float *__restrict__ bg_pre, const float *__r
 constexpr int BREP = 8;
 
 // tile_list[j] = d * ntiles + tile of the active tiles (ascending); n_act; n_inact[d] = sites of plane d in inactive tiles
+constexpr int BNB_MAX_PLANES = 16 * MVX_MAX_FRAMES;
 __global__ __launch_bounds__(1024) void bnb_tile_list(const int *__restrict__ tile_flags, int D, int H, int W, int ntiles,
                                                       int *__restrict__ list, int *__restrict__ n_act,
                                                       int *__restrict__ n_inact) {
     __shared__ int smem[17];
-    __shared__ int s_inact[16];
+    __shared__ int s_inact[BNB_MAX_PLANES];            // D here = ALL planes of the launch (frames x planes per frame)
     const int tiles_x = (W + ATW - 1) / ATW;
-    if (threadIdx.x < 16) s_inact[threadIdx.x] = 0;
+    if (threadIdx.x < BNB_MAX_PLANES) s_inact[threadIdx.x] = 0;
     __syncthreads();
     const int total = D * ntiles;
     int base = 0;
@@ -165,18 +167,21 @@ __global__ __launch_bounds__(256) void bnb_tiles(const float *__restrict__ dyh, 
                                                  const float *__restrict__ mi, const float *__restrict__ c_bg,
                                                  const float *__restrict__ ab, const int *__restrict__ list,
                                                  const int *__restrict__ n_act, int D, int H, int W, int C, int ntiles,
-                                                 int mode, float *__restrict__ dz, double *__restrict__ sums) {
+                                                 int mode, float *__restrict__ dz, double *__restrict__ sums_all) {
     __shared__ float red[2][256][4];
     const int tiles_x = (W + ATW - 1) / ATW;
     const int c4n = C >> 2, ct = threadIdx.x % c4n, st = threadIdx.x / c4n, spb = 256 / c4n;
     const int nact = *n_act;
     for (int j = blockIdx.x; j < nact; j += gridDim.x) {
-        const int e = list[j], d = e / ntiles, t = e - d * ntiles;
+        // d = GLOBAL plane (frames stacked along depth, D planes each); per-frame: mean / inverse std, a / b, sums
+        const int e = list[j], d = e / ntiles, t = e - d * ntiles, frame = d / D, dl = d - frame * D;
         const int ty0 = (t / tiles_x) * ATH, tx0 = (t % tiles_x) * ATW;
-        const float4 m = *(const float4 *)(mi + ct * 4), iv = *(const float4 *)(mi + C + ct * 4);
+        const float *fmi = mi + (size_t)frame * 2 * C;
+        double *sums = sums_all + (size_t)frame * BREP * (D + 2) * C;
+        const float4 m = *(const float4 *)(fmi + ct * 4), iv = *(const float4 *)(fmi + C + ct * 4);
         const float4 cb = *(const float4 *)(c_bg + (size_t)d * C + ct * 4);
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-        if (mode == 1) { a = *(const float4 *)(ab + ct * 4); b = *(const float4 *)(ab + C + ct * 4); }
+        if (mode == 1) { a = *(const float4 *)(ab + (size_t)frame * 2 * C + ct * 4); b = *(const float4 *)(ab + (size_t)frame * 2 * C + C + ct * 4); }
         float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
         for (int sidx = st; sidx < ATH * ATW; sidx += spb) {
             const int gy = ty0 + sidx / ATW, gx = tx0 + sidx % ATW;
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(256) void bnb_tiles(const float *__restrict__ dyh, 
                 for (int q = 0; q < spb; ++q) { t1 += (double)red[0][q * c4n + ct][q4]; t2 += (double)red[1][q * c4n + ct][q4]; }
                 const int n = ct * 4 + q4;
                 if (mode == 0) {
-                    atomicAdd(base + (size_t)d * C + n, t1);
+                    atomicAdd(base + (size_t)dl * C + n, t1);
                     atomicAdd(base + (size_t)D * C + n, t2);
                 } else {
                     atomicAdd(base + (size_t)(D + 1) * C + n, t1);
@@ -224,6 +229,11 @@ __global__ void bnb_finalize_ab(const double *__restrict__ sums, const float *__
                                 int D, int C, double count, float *__restrict__ ab) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= C) return;
+    const int frame = blockIdx.y;                         // everything below is per frame
+    sums += (size_t)frame * BREP * (D + 2) * C;
+    A += (size_t)frame * D * C;
+    c_bg += (size_t)frame * D * C;
+    ab += (size_t)frame * 2 * C;
     double q1 = 0.0;
     for (int rep = 0; rep < BREP; ++rep) q1 += sums[((size_t)rep * (D + 2) + D) * C + n];
     double sa = 0.0, sca = 0.0;
@@ -240,59 +250,74 @@ __global__ void bnb_finalize_ab(const double *__restrict__ sums, const float *__
 __global__ void bnb_dbias(const double *__restrict__ sums, const float *__restrict__ A, const float *__restrict__ c_bg,
                           const float *__restrict__ y_bg, const float *__restrict__ mi, const float *__restrict__ ab,
                           const int *__restrict__ n_inact, int D, int C, float *__restrict__ dbias, int accumulate,
-                          float *__restrict__ dz_inactive_sums) {
+                          float *__restrict__ dz_inactive_sums, int n_frames) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= C) return;
-    double z1 = 0.0;
-    for (int rep = 0; rep < BREP; ++rep) z1 += sums[((size_t)rep * (D + 2) + D + 1) * C + n];
-    const double inv = (double)mi[C + n], a = (double)ab[n], b = (double)ab[C + n];
-    double t = z1;
-    for (int d = 0; d < D; ++d) {
-        double s = 0.0;                              // sum of dz over the inactive tiles of plane d
-        if (y_bg[(size_t)d * C + n] > 0.f) {
-            double p1 = 0.0;
-            for (int rep = 0; rep < BREP; ++rep) p1 += sums[((size_t)rep * (D + 2) + d) * C + n];
-            s = inv * (((double)A[(size_t)d * C + n] - p1) - (double)n_inact[d] * (a + (double)c_bg[(size_t)d * C + n] * b));
+    double t = 0.0;                                   // the bias gradient sums over the frames
+    for (int frame = 0; frame < n_frames; ++frame) {
+        const double *fs = sums + (size_t)frame * BREP * (D + 2) * C;
+        const float *fmi = mi + (size_t)frame * 2 * C, *fab = ab + (size_t)frame * 2 * C;
+        double z1 = 0.0;
+        for (int rep = 0; rep < BREP; ++rep) z1 += fs[((size_t)rep * (D + 2) + D + 1) * C + n];
+        const double inv = (double)fmi[C + n], a = (double)fab[n], b = (double)fab[C + n];
+        t += z1;
+        for (int dl = 0; dl < D; ++dl) {
+            const int d = frame * D + dl;
+            double s = 0.0;                              // sum of dz over the inactive tiles of plane d
+            if (y_bg[(size_t)d * C + n] > 0.f) {
+                double p1 = 0.0;
+                for (int rep = 0; rep < BREP; ++rep) p1 += fs[((size_t)rep * (D + 2) + dl) * C + n];
+                s = inv * (((double)A[(size_t)d * C + n] - p1) - (double)n_inact[d] * (a + (double)c_bg[(size_t)d * C + n] * b));
+            }
+            if (dz_inactive_sums) dz_inactive_sums[(size_t)d * C + n] = (float)s;
+            t += s;
         }
-        if (dz_inactive_sums) dz_inactive_sums[(size_t)d * C + n] = (float)s;
-        t += s;
     }
     if (dbias) dbias[n] = accumulate ? dbias[n] + (float)t : (float)t;
 }
 
 }  // namespace
 
-extern "C" size_t mvx_bn_relu_backward_tiles_workspace_bytes(int32_t planes, int32_t h, int32_t w, int32_t channels) {
-    if (planes <= 0 || planes > 16 || h <= 0 || w <= 0 || channels <= 0) return 0;
+extern "C" size_t mvx_bn_relu_backward_tiles_workspace_bytes_frames(int32_t planes, int32_t h, int32_t w, int32_t channels,
+                                                                   int32_t n_frames) {
+    if (planes <= 0 || planes > 16 || h <= 0 || w <= 0 || channels <= 0 || n_frames <= 0 || n_frames > MVX_MAX_FRAMES) return 0;
     const size_t ntiles = (size_t)mvx_cdiv(w, ATW) * mvx_cdiv(h, ATH);
-    return sizeof(double) * BREP * (planes + 2) * channels + sizeof(float) * 2 * channels + sizeof(int) * (planes * ntiles + 32);
+    const size_t P = (size_t)planes * n_frames;
+    return sizeof(double) * BREP * (planes + 2) * channels * n_frames + sizeof(float) * 2 * channels * n_frames +
+           sizeof(int) * (P * ntiles + 16 + P);
 }
 
-extern "C" int mvx_bn_relu_backward_tiles(const float *dyhat, const float *y, const float *mean_inv, const float *c_bg,
-                                          const float *y_bg, const float *plane_grad_sums, const int32_t *tile_flags,
-                                          int32_t planes, int32_t h, int32_t w, int32_t channels, float *dz, float *dbias,
-                                          float *dz_inactive_sums, int32_t flags, void *workspace,
-                                          size_t workspace_bytes, void *stream) {
+extern "C" size_t mvx_bn_relu_backward_tiles_workspace_bytes(int32_t planes, int32_t h, int32_t w, int32_t channels) {
+    return mvx_bn_relu_backward_tiles_workspace_bytes_frames(planes, h, w, channels, 1);
+}
+
+extern "C" int mvx_bn_relu_backward_tiles_frames(const float *dyhat, const float *y, const float *mean_inv, const float *c_bg,
+                                                 const float *y_bg, const float *plane_grad_sums, const int32_t *tile_flags,
+                                                 int32_t planes, int32_t h, int32_t w, int32_t channels, float *dz,
+                                                 float *dbias, float *dz_inactive_sums, int32_t flags, void *workspace,
+                                                 size_t workspace_bytes, int32_t n_frames, void *stream) {
     MVX_CHECK_ARG(dyhat && y && mean_inv && c_bg && y_bg && plane_grad_sums && tile_flags && dz && workspace);
     MVX_CHECK_ARG(planes > 0 && planes <= 16 && h > 0 && w > 0 && channels > 0 && channels % 4 == 0 && 256 % (channels / 4) == 0);
-    MVX_CHECK_ARG(workspace_bytes >= mvx_bn_relu_backward_tiles_workspace_bytes(planes, h, w, channels));
+    MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
+    MVX_CHECK_ARG(workspace_bytes >= mvx_bn_relu_backward_tiles_workspace_bytes_frames(planes, h, w, channels, n_frames));
     hipStream_t st = (hipStream_t)stream;
     const int ntiles = (int)(mvx_cdiv(w, ATW) * mvx_cdiv(h, ATH));
+    const int P = planes * n_frames;                   // all planes of the launch
     double *sums = (double *)workspace;
-    float *ab = (float *)(sums + (size_t)BREP * (planes + 2) * channels);
-    int *list = (int *)(ab + 2 * channels);
-    int *n_act = list + (size_t)planes * ntiles, *n_inact = n_act + 1;
-    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * BREP * (planes + 2) * channels, st);
+    float *ab = (float *)(sums + (size_t)BREP * (planes + 2) * channels * n_frames);
+    int *list = (int *)(ab + 2 * (size_t)channels * n_frames);
+    int *n_act = list + (size_t)P * ntiles, *n_inact = n_act + 16;
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * BREP * (planes + 2) * channels * n_frames, st);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(bnb_tile_list, dim3(1), dim3(1024), 0, st, tile_flags, planes, h, w, ntiles, list, n_act, n_inact);
+    hipLaunchKernelGGL(bnb_tile_list, dim3(1), dim3(1024), 0, st, tile_flags, P, h, w, ntiles, list, n_act, n_inact);
     MVX_LAUNCH_CHECK();
-    const double count = (double)planes * h * w;
-    const unsigned grid = (unsigned)(planes * ntiles > 2048 ? 2048 : planes * ntiles);
+    const double count = (double)planes * h * w;       // per frame
+    const unsigned grid = (unsigned)(P * ntiles > 2048 ? 2048 : P * ntiles);
     hipLaunchKernelGGL(bnb_tiles, dim3(grid), dim3(256), 0, st, dyhat, y, mean_inv, c_bg, (const float *)ab, (const int *)list,
                        (const int *)n_act, planes, h, w, channels, ntiles, 0, dz, sums);
     MVX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bnb_finalize_ab, dim3(mvx_cdiv(channels, 64)), dim3(64), 0, st, (const double *)sums, plane_grad_sums,
-                       c_bg, planes, channels, count, ab);
+    hipLaunchKernelGGL(bnb_finalize_ab, dim3(mvx_cdiv(channels, 64), n_frames), dim3(64), 0, st, (const double *)sums,
+                       plane_grad_sums, c_bg, planes, channels, count, ab);
     MVX_LAUNCH_CHECK();
     hipLaunchKernelGGL(bnb_tiles, dim3(grid), dim3(256), 0, st, dyhat, y, mean_inv, c_bg, (const float *)ab, (const int *)list,
                        (const int *)n_act, planes, h, w, channels, ntiles, 1, dz, sums);
@@ -300,7 +325,36 @@ extern "C" int mvx_bn_relu_backward_tiles(const float *dyhat, const float *y, co
     if (dbias || dz_inactive_sums) {
         hipLaunchKernelGGL(bnb_dbias, dim3(mvx_cdiv(channels, 64)), dim3(64), 0, st, (const double *)sums, plane_grad_sums, c_bg,
                            y_bg, mean_inv, (const float *)ab, (const int *)n_inact, planes, channels, dbias,
-                           flags & MVX_FLAG_ACCUMULATE, dz_inactive_sums);
+                           flags & MVX_FLAG_ACCUMULATE, dz_inactive_sums, n_frames);
+        MVX_LAUNCH_CHECK();
+    }
+    return MVX_OK;
+}
+
+extern "C" int mvx_bn_relu_backward_tiles(const float *dyhat, const float *y, const float *mean_inv, const float *c_bg,
+                                          const float *y_bg, const float *plane_grad_sums, const int32_t *tile_flags,
+                                          int32_t planes, int32_t h, int32_t w, int32_t channels, float *dz, float *dbias,
+                                          float *dz_inactive_sums, int32_t flags, void *workspace,
+                                          size_t workspace_bytes, void *stream) {
+    return mvx_bn_relu_backward_tiles_frames(dyhat, y, mean_inv, c_bg, y_bg, plane_grad_sums, tile_flags, planes, h, w, channels,
+                                             dz, dbias, dz_inactive_sums, flags, workspace, workspace_bytes, 1, stream);
+}
+
+extern "C" int mvx_activity_dilate_frames(const void *src, int32_t src_is_index, int32_t din, int32_t dout, int32_t h, int32_t w,
+                                          int32_t stride_d, int32_t pad_d, int32_t mark_border, uint8_t *dst_mask,
+                                          int32_t *dst_halo_flags, int32_t *dst_tile_flags, int32_t n_frames, void *stream) {
+    MVX_CHECK_ARG(src && dst_mask && din > 0 && dout > 0 && h > 0 && w > 0);
+    MVX_CHECK_ARG(stride_d >= 1 && stride_d <= 2 && pad_d >= 0 && pad_d <= 1);
+    MVX_CHECK_ARG(dout == (din + 2 * pad_d - 3) / stride_d + 1);
+    MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)n_frames * dout * h * w;
+    hipLaunchKernelGGL(activity_sites, dim3(mvx_cdiv(n, 256) > 4096 ? 4096 : mvx_cdiv(n, 256)), dim3(256), 0, st, src,
+                       src_is_index, din, dout, h, w, stride_d, pad_d, mark_border, dst_mask, n_frames);
+    MVX_LAUNCH_CHECK();
+    if (dst_halo_flags || dst_tile_flags) {
+        hipLaunchKernelGGL(activity_halo_flags, dim3(mvx_cdiv(w, ATW) * mvx_cdiv(h, ATH), dout * n_frames), dim3(256), 0, st,
+                           (const unsigned char *)dst_mask, dout * n_frames, h, w, dst_halo_flags, dst_tile_flags);
         MVX_LAUNCH_CHECK();
     }
     return MVX_OK;
@@ -309,47 +363,57 @@ extern "C" int mvx_bn_relu_backward_tiles(const float *dyhat, const float *y, co
 extern "C" int mvx_activity_dilate(const void *src, int32_t src_is_index, int32_t din, int32_t dout, int32_t h, int32_t w,
                                    int32_t stride_d, int32_t pad_d, int32_t mark_border, uint8_t *dst_mask,
                                    int32_t *dst_halo_flags, int32_t *dst_tile_flags, void *stream) {
-    MVX_CHECK_ARG(src && dst_mask && din > 0 && dout > 0 && h > 0 && w > 0);
-    MVX_CHECK_ARG(stride_d >= 1 && stride_d <= 2 && pad_d >= 0 && pad_d <= 1);
-    MVX_CHECK_ARG(dout == (din + 2 * pad_d - 3) / stride_d + 1);
-    hipStream_t st = (hipStream_t)stream;
-    const size_t n = (size_t)dout * h * w;
-    hipLaunchKernelGGL(activity_sites, dim3(mvx_cdiv(n, 256) > 4096 ? 4096 : mvx_cdiv(n, 256)), dim3(256), 0, st, src,
-                       src_is_index, din, dout, h, w, stride_d, pad_d, mark_border, dst_mask);
+    return mvx_activity_dilate_frames(src, src_is_index, din, dout, h, w, stride_d, pad_d, mark_border, dst_mask,
+                                      dst_halo_flags, dst_tile_flags, 1, stream);
+}
+
+extern "C" int mvx_tile_dilate_flags_frames(const int32_t *in_tile_flags, const int32_t *self_tile_flags, int32_t din,
+                                            int32_t dout, int32_t h, int32_t w, int32_t stride_d, int32_t pad_d,
+                                            int32_t *out_tile_flags, int32_t n_frames, void *stream) {
+    MVX_CHECK_ARG(in_tile_flags && out_tile_flags && din > 0 && dout > 0 && h > 0 && w > 0);
+    MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
+    const int ty = (int)mvx_cdiv(h, ATH), tx = (int)mvx_cdiv(w, ATW);
+    hipLaunchKernelGGL(tile_dilate_flags, dim3(mvx_cdiv((long long)n_frames * dout * ty * tx, 256)), dim3(256), 0,
+                       (hipStream_t)stream, in_tile_flags, self_tile_flags, din, dout, ty, tx, stride_d, pad_d, out_tile_flags,
+                       n_frames);
     MVX_LAUNCH_CHECK();
-    if (dst_halo_flags || dst_tile_flags) {
-        hipLaunchKernelGGL(activity_halo_flags, dim3(mvx_cdiv(w, ATW) * mvx_cdiv(h, ATH), dout), dim3(256), 0, st,
-                           (const unsigned char *)dst_mask, dout, h, w, dst_halo_flags, dst_tile_flags);
-        MVX_LAUNCH_CHECK();
-    }
     return MVX_OK;
 }
 
 extern "C" int mvx_tile_dilate_flags(const int32_t *in_tile_flags, const int32_t *self_tile_flags, int32_t din, int32_t dout,
                                      int32_t h, int32_t w, int32_t stride_d, int32_t pad_d, int32_t *out_tile_flags,
                                      void *stream) {
-    MVX_CHECK_ARG(in_tile_flags && out_tile_flags && din > 0 && dout > 0 && h > 0 && w > 0);
-    const int ty = (int)mvx_cdiv(h, ATH), tx = (int)mvx_cdiv(w, ATW);
-    hipLaunchKernelGGL(tile_dilate_flags, dim3(mvx_cdiv((long long)dout * ty * tx, 256)), dim3(256), 0, (hipStream_t)stream,
-                       in_tile_flags, self_tile_flags, din, dout, ty, tx, stride_d, pad_d, out_tile_flags);
+    return mvx_tile_dilate_flags_frames(in_tile_flags, self_tile_flags, din, dout, h, w, stride_d, pad_d, out_tile_flags, 1,
+                                        stream);
+}
+
+extern "C" int mvx_conv3d_background_frames(const float *w, const float *c_in, int32_t din, int32_t dout, int32_t cin,
+                                            int32_t cout, int32_t stride_d, int32_t pad_d, float *bg_pre, int32_t n_frames,
+                                            void *stream) {
+    MVX_CHECK_ARG(w && c_in && bg_pre && din > 0 && dout > 0 && cin > 0 && cout > 0);
+    MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
+    hipLaunchKernelGGL(conv_background, dim3(cout, dout * n_frames), dim3(64), 0, (hipStream_t)stream, w, c_in, din, dout, cin,
+                       cout, stride_d, pad_d, bg_pre);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
 
 extern "C" int mvx_conv3d_background(const float *w, const float *c_in, int32_t din, int32_t dout, int32_t cin,
                                      int32_t cout, int32_t stride_d, int32_t pad_d, float *bg_pre, void *stream) {
-    MVX_CHECK_ARG(w && c_in && bg_pre && din > 0 && dout > 0 && cin > 0 && cout > 0);
-    hipLaunchKernelGGL(conv_background, dim3(cout, dout), dim3(64), 0, (hipStream_t)stream, w, c_in, din, dout, cin, cout,
-                       stride_d, pad_d, bg_pre);
+    return mvx_conv3d_background_frames(w, c_in, din, dout, cin, cout, stride_d, pad_d, bg_pre, 1, stream);
+}
+
+extern "C" int mvx_bn_background_frames(const float *bg_pre, const float *bias, const float *mean_inv, int32_t planes,
+                                        int32_t channels, int32_t flags, float *y_bg, float *c_out, int32_t n_frames,
+                                        void *stream) {
+    MVX_CHECK_ARG(mean_inv && c_out && planes > 0 && channels > 0 && n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
+    hipLaunchKernelGGL(bn_background, dim3(mvx_cdiv((long long)n_frames * planes * channels, 256)), dim3(256), 0,
+                       (hipStream_t)stream, bg_pre, bias, mean_inv, planes, channels, flags & MVX_FLAG_RELU, y_bg, c_out, n_frames);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
 
 extern "C" int mvx_bn_background(const float *bg_pre, const float *bias, const float *mean_inv, int32_t planes,
                                  int32_t channels, int32_t flags, float *y_bg, float *c_out, void *stream) {
-    MVX_CHECK_ARG(mean_inv && c_out && planes > 0 && channels > 0);
-    hipLaunchKernelGGL(bn_background, dim3(mvx_cdiv((long long)planes * channels, 256)), dim3(256), 0, (hipStream_t)stream,
-                       bg_pre, bias, mean_inv, planes, channels, flags & MVX_FLAG_RELU, y_bg, c_out);
-    MVX_LAUNCH_CHECK();
-    return MVX_OK;
+    return mvx_bn_background_frames(bg_pre, bias, mean_inv, planes, channels, flags, y_bg, c_out, 1, stream);
 }

@@ -15,6 +15,8 @@ constexpr int REP = 32;   // replicas of the cross-block accumulators (spreads s
 __global__ void bn_finalize(const double *__restrict__ stats, double count, double eps, float *__restrict__ mi, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    stats += (size_t)blockIdx.y * MVX_REP * 2 * C;      // frame
+    mi += (size_t)blockIdx.y * 2 * C;
     double s1 = 0.0, s2 = 0.0;
     for (int rp = 0; rp < MVX_REP; ++rp) {
         s1 += stats[((size_t)rp * 2) * C + c];
@@ -28,12 +30,13 @@ __global__ void bn_finalize(const double *__restrict__ stats, double count, doub
 }
 
 __global__ void bn_apply(const float *__restrict__ y, const float *__restrict__ mi, float *__restrict__ out,
-                         size_t n4, int C) {
+                         size_t n4, int C, FrameMap fm) {
     const int c4 = C >> 2;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(e % c4) * 4;
+        const float *fmi = mi + (size_t)fm_frame_of(fm, (long long)(e / c4)) * 2 * C;
         const float4 v = ((const float4 *)y)[e];
-        const float4 m = *(const float4 *)(mi + c), s = *(const float4 *)(mi + C + c);
+        const float4 m = *(const float4 *)(fmi + c), s = *(const float4 *)(fmi + C + c);
         float4 o;
         o.x = (v.x - m.x) * s.x; o.y = (v.y - m.y) * s.y; o.z = (v.z - m.z) * s.z; o.w = (v.w - m.w) * s.w;
         ((float4 *)out)[e] = o;
@@ -72,101 +75,127 @@ __global__ __launch_bounds__(256) void row_stats(const float *__restrict__ y, do
     }
 }
 
-// backward, pass 1: sums[0][c] = sum dyh, sums[1][c] = sum dyh * yhat   (yhat = (y - mean) * inv)
+// backward, pass 1: sums[f][rep][0][c] = sum dyh, [1][c] = sum dyh * yhat   (yhat = (y - mean) * inv), per frame f.
+// A block owns a CONTIGUOUS run of rows (rows_per_block) and makes one reduction pass per row segment it meets
+// (almost always one: segments are whole frames).
 __global__ __launch_bounds__(256) void bn_bwd_reduce(const float *__restrict__ dyh, const float *__restrict__ y,
                                                      const float *__restrict__ mi, double *__restrict__ sums,
-                                                     size_t rows, int C) {
+                                                     size_t rows, int C, size_t rows_per_block, FrameMap fm) {
     __shared__ double red[2][256][4];
     const int c4 = C >> 2;
     const int rpi = max(1, 256 / c4);
     const int ct = threadIdx.x % c4, rt = threadIdx.x / c4;
-    for (int cb = 0; cb < c4; cb += 256) {
-        const int col = cb + ct;
-        float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
-        if (rt < rpi && col < c4) {
-            const float4 m = *(const float4 *)(mi + col * 4), iv = *(const float4 *)(mi + C + col * 4);
-            const size_t stride = (size_t)gridDim.x * rpi;
-            for (size_t r = blockIdx.x * (size_t)rpi + rt; r < rows; r += 4 * stride) {
-                float4 g[4], v[4];
+    const size_t blk_lo = blockIdx.x * rows_per_block;
+    const size_t blk_hi = blk_lo + rows_per_block < rows ? blk_lo + rows_per_block : rows;
+    if (blk_lo >= blk_hi) return;
+    const int s_lo = fm.F == 1 ? 0 : fm_seg_of(fm, (long long)blk_lo), s_hi = fm.F == 1 ? 0 : fm_seg_of(fm, (long long)blk_hi - 1);
+    for (int sg = s_lo; sg <= s_hi; ++sg) {
+        const int f = fm.F == 1 ? 0 : (int)fm.seg_frame[sg];
+        const size_t lo = fm.F == 1 ? blk_lo : max(blk_lo, (size_t)fm.bound[sg]);
+        const size_t hi = fm.F == 1 ? blk_hi : min(blk_hi, (size_t)fm.bound[sg + 1]);
+        const float *fmi = mi + (size_t)f * 2 * C;
+        double *fsums = sums + (size_t)f * REP * 3 * C;
+        for (int cb = 0; cb < c4; cb += 256) {
+            const int col = cb + ct;
+            float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+            if (rt < rpi && col < c4) {
+                const float4 m = *(const float4 *)(fmi + col * 4), iv = *(const float4 *)(fmi + C + col * 4);
+                const size_t stride = (size_t)rpi;
+                for (size_t r = lo + rt; r < hi; r += 4 * stride) {
+                    float4 g[4], v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {              // 8 independent 16-byte loads in flight
-                    const size_t rr = r + j * stride;
-                    const bool ok = rr < rows;
-                    g[j] = ok ? *(const float4 *)(dyh + rr * C + col * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    v[j] = ok ? *(const float4 *)(y + rr * C + col * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+                    for (int j = 0; j < 4; ++j) {              // 8 independent 16-byte loads in flight
+                        const size_t rr = r + j * stride;
+                        const bool ok = rr < hi;
+                        g[j] = ok ? *(const float4 *)(dyh + rr * C + col * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        v[j] = ok ? *(const float4 *)(y + rr * C + col * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    s1.x += g[j].x; s1.y += g[j].y; s1.z += g[j].z; s1.w += g[j].w;
-                    s2.x += g[j].x * ((v[j].x - m.x) * iv.x); s2.y += g[j].y * ((v[j].y - m.y) * iv.y);
-                    s2.z += g[j].z * ((v[j].z - m.z) * iv.z); s2.w += g[j].w * ((v[j].w - m.w) * iv.w);
+                    for (int j = 0; j < 4; ++j) {
+                        s1.x += g[j].x; s1.y += g[j].y; s1.z += g[j].z; s1.w += g[j].w;
+                        s2.x += g[j].x * ((v[j].x - m.x) * iv.x); s2.y += g[j].y * ((v[j].y - m.y) * iv.y);
+                        s2.z += g[j].z * ((v[j].z - m.z) * iv.z); s2.w += g[j].w * ((v[j].w - m.w) * iv.w);
+                    }
                 }
             }
+            red[0][threadIdx.x][0] = s1.x; red[0][threadIdx.x][1] = s1.y; red[0][threadIdx.x][2] = s1.z; red[0][threadIdx.x][3] = s1.w;
+            red[1][threadIdx.x][0] = s2.x; red[1][threadIdx.x][1] = s2.y; red[1][threadIdx.x][2] = s2.z; red[1][threadIdx.x][3] = s2.w;
+            __syncthreads();
+            if (rt == 0 && col < c4) {
+                for (int k = 0; k < 2; ++k)
+                    for (int j = 0; j < 4; ++j) {
+                        double t = 0.0;
+                        for (int r = 0; r < rpi; ++r) t += red[k][r * c4 + ct][j];
+                        atomicAdd(fsums + ((size_t)(blockIdx.x % REP) * 3 + k) * C + col * 4 + j, t);
+                    }
+            }
+            __syncthreads();
         }
-        red[0][threadIdx.x][0] = s1.x; red[0][threadIdx.x][1] = s1.y; red[0][threadIdx.x][2] = s1.z; red[0][threadIdx.x][3] = s1.w;
-        red[1][threadIdx.x][0] = s2.x; red[1][threadIdx.x][1] = s2.y; red[1][threadIdx.x][2] = s2.z; red[1][threadIdx.x][3] = s2.w;
-        __syncthreads();
-        if (rt == 0 && col < c4) {
-            for (int k = 0; k < 2; ++k)
-                for (int j = 0; j < 4; ++j) {
-                    double t = 0.0;
-                    for (int r = 0; r < rpi; ++r) t += red[k][r * c4 + ct][j];
-                    atomicAdd(sums + ((size_t)(blockIdx.x % REP) * 3 + k) * C + col * 4 + j, t);
-                }
-        }
-        __syncthreads();
     }
 }
 
-// backward, pass 2: dz = (y > 0) ? inv * (dyh - s1/N - yhat * s2/N) : 0 ; dbias[c] += sum dz
+// backward, pass 2: dz = (y > 0) ? inv * (dyh - s1/N - yhat * s2/N) : 0 ; dbias[c] += sum dz (over ALL frames)
 __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dyh, const float *__restrict__ y,
                                                     const float *__restrict__ mi, const double *__restrict__ sums,
-                                                    double count, float *__restrict__ dz, double *__restrict__ dbias,
+                                                    float *__restrict__ dz, double *__restrict__ dbias,
                                                     const float *__restrict__ row_w, size_t rows, int C,
                                                     unsigned *__restrict__ done_counter, float *__restrict__ dbias_out,
-                                                    int accumulate) {
+                                                    int accumulate, size_t rows_per_block, FrameMap fm) {
     __shared__ double red[256][4];
     const int c4 = C >> 2;
     const int rpi = max(1, 256 / c4);
     const int ct = threadIdx.x % c4, rt = threadIdx.x / c4;
+    const size_t blk_lo = blockIdx.x * rows_per_block;
+    const size_t blk_hi = blk_lo + rows_per_block < rows ? blk_lo + rows_per_block : rows;
+    const bool live = blk_lo < blk_hi;
+    const int s_lo = (fm.F == 1 || !live) ? 0 : fm_seg_of(fm, (long long)blk_lo);
+    const int s_hi = (fm.F == 1 || !live) ? 0 : fm_seg_of(fm, (long long)blk_hi - 1);
     for (int cb = 0; cb < c4; cb += 256) {
         const int col = cb + ct;
         float4 sb = make_float4(0, 0, 0, 0);
-        if (rt < rpi && col < c4) {
-            const float4 m = *(const float4 *)(mi + col * 4), iv = *(const float4 *)(mi + C + col * 4);
-            float a[4], b[4];
-            for (int j = 0; j < 4; ++j) {
-                double sa = 0.0, sbb = 0.0;
-                for (int rp = 0; rp < REP; ++rp) {
-                    sa += sums[((size_t)rp * 3 + 0) * C + col * 4 + j];
-                    sbb += sums[((size_t)rp * 3 + 1) * C + col * 4 + j];
-                }
-                a[j] = (float)(sa / count);
-                b[j] = (float)(sbb / count);
-            }
-            const size_t stride = (size_t)gridDim.x * rpi;
-            for (size_t r = blockIdx.x * (size_t)rpi + rt; r < rows; r += 4 * stride) {
-                float4 g[4], v[4];
-                float rw[4];
-#pragma unroll
+        for (int sg = s_lo; sg <= s_hi && live; ++sg) {
+            const int f = fm.F == 1 ? 0 : (int)fm.seg_frame[sg];
+            const size_t lo = fm.F == 1 ? blk_lo : max(blk_lo, (size_t)fm.bound[sg]);
+            const size_t hi = fm.F == 1 ? blk_hi : min(blk_hi, (size_t)fm.bound[sg + 1]);
+            const float *fmi = mi + (size_t)f * 2 * C;
+            const double *fsums = sums + (size_t)f * REP * 3 * C;
+            const double count = fm.count[f];
+            if (rt < rpi && col < c4) {
+                const float4 m = *(const float4 *)(fmi + col * 4), iv = *(const float4 *)(fmi + C + col * 4);
+                float a[4], b[4];
                 for (int j = 0; j < 4; ++j) {
-                    const size_t rr = r + j * stride;
-                    const bool ok = rr < rows;
-                    g[j] = ok ? *(const float4 *)(dyh + rr * C + col * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    v[j] = ok ? *(const float4 *)(y + rr * C + col * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    rw[j] = (ok && row_w) ? row_w[rr] : 1.f;   // a compact row standing for rw dense rows
+                    double sa = 0.0, sbb = 0.0;
+                    for (int rp = 0; rp < REP; ++rp) {
+                        sa += fsums[((size_t)rp * 3 + 0) * C + col * 4 + j];
+                        sbb += fsums[((size_t)rp * 3 + 1) * C + col * 4 + j];
+                    }
+                    a[j] = (float)(sa / count);
+                    b[j] = (float)(sbb / count);
                 }
+                const size_t stride = (size_t)rpi;
+                for (size_t r = lo + rt; r < hi; r += 4 * stride) {
+                    float4 g[4], v[4];
+                    float rw[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const size_t rr = r + j * stride;
-                    if (rr >= rows) break;
-                    float4 o;
-                    o.x = v[j].x > 0.f ? iv.x * (g[j].x - rw[j] * (a[0] + ((v[j].x - m.x) * iv.x) * b[0])) : 0.f;
-                    o.y = v[j].y > 0.f ? iv.y * (g[j].y - rw[j] * (a[1] + ((v[j].y - m.y) * iv.y) * b[1])) : 0.f;
-                    o.z = v[j].z > 0.f ? iv.z * (g[j].z - rw[j] * (a[2] + ((v[j].z - m.z) * iv.z) * b[2])) : 0.f;
-                    o.w = v[j].w > 0.f ? iv.w * (g[j].w - rw[j] * (a[3] + ((v[j].w - m.w) * iv.w) * b[3])) : 0.f;
-                    *(float4 *)(dz + rr * C + col * 4) = o;
-                    sb.x += o.x; sb.y += o.y; sb.z += o.z; sb.w += o.w;
+                    for (int j = 0; j < 4; ++j) {
+                        const size_t rr = r + j * stride;
+                        const bool ok = rr < hi;
+                        g[j] = ok ? *(const float4 *)(dyh + rr * C + col * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        v[j] = ok ? *(const float4 *)(y + rr * C + col * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        rw[j] = (ok && row_w) ? row_w[rr] : 1.f;   // a compact row standing for rw dense rows
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const size_t rr = r + j * stride;
+                        if (rr >= hi) break;
+                        float4 o;
+                        o.x = v[j].x > 0.f ? iv.x * (g[j].x - rw[j] * (a[0] + ((v[j].x - m.x) * iv.x) * b[0])) : 0.f;
+                        o.y = v[j].y > 0.f ? iv.y * (g[j].y - rw[j] * (a[1] + ((v[j].y - m.y) * iv.y) * b[1])) : 0.f;
+                        o.z = v[j].z > 0.f ? iv.z * (g[j].z - rw[j] * (a[2] + ((v[j].z - m.z) * iv.z) * b[2])) : 0.f;
+                        o.w = v[j].w > 0.f ? iv.w * (g[j].w - rw[j] * (a[3] + ((v[j].w - m.w) * iv.w) * b[3])) : 0.f;
+                        *(float4 *)(dz + rr * C + col * 4) = o;
+                        sb.x += o.x; sb.y += o.y; sb.z += o.z; sb.w += o.w;
+                    }
                 }
             }
         }
@@ -223,24 +252,36 @@ inline unsigned row_grid(size_t rows, int C) {
 
 }  // namespace
 
+extern "C" int mvx_bn_finalize_frames(const double *stats, double count, double eps, float *mean_inv, int32_t channels,
+                                      int32_t n_frames, void *stream) {
+    MVX_CHECK_ARG(stats && mean_inv && channels > 0 && count > 0 && n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
+    hipLaunchKernelGGL(bn_finalize, dim3(mvx_cdiv(channels, 128), n_frames), dim3(128), 0, (hipStream_t)stream, stats, count,
+                       eps, mean_inv, channels);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
 extern "C" int mvx_bn_finalize(const double *stats, double count, double eps, float *mean_inv, int32_t channels,
                                void *stream) {
-    MVX_CHECK_ARG(stats && mean_inv && channels > 0 && count > 0);
-    hipLaunchKernelGGL(bn_finalize, dim3(mvx_cdiv(channels, 128)), dim3(128), 0, (hipStream_t)stream, stats, count, eps,
-                       mean_inv, channels);
+    return mvx_bn_finalize_frames(stats, count, eps, mean_inv, channels, 1, stream);
+}
+
+extern "C" int mvx_bn_apply_frames(const float *y, const float *mean_inv, float *out, int64_t rows, int32_t channels,
+                                   const mvx_frames_t *frames_host, int32_t row_kind, void *stream) {
+    MVX_CHECK_ARG(y && mean_inv && out && rows >= 0 && channels > 0 && channels % 4 == 0);
+    if (rows == 0) return MVX_OK;
+    FrameMap fm;
+    MVX_CHECK_ARG(mvx_build_frame_map(fm, frames_host, row_kind, rows, 1.0));
+    const size_t n4 = (size_t)rows * channels / 4;
+    const unsigned grid = (unsigned)(mvx_cdiv(n4, 256) > 4096 ? 4096 : mvx_cdiv(n4, 256));
+    hipLaunchKernelGGL(bn_apply, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, mean_inv, out, n4, channels, fm);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
 
 extern "C" int mvx_bn_apply(const float *y, const float *mean_inv, float *out, int64_t rows, int32_t channels,
                             void *stream) {
-    MVX_CHECK_ARG(y && mean_inv && out && rows >= 0 && channels > 0 && channels % 4 == 0);
-    if (rows == 0) return MVX_OK;
-    const size_t n4 = (size_t)rows * channels / 4;
-    const unsigned grid = (unsigned)(mvx_cdiv(n4, 256) > 4096 ? 4096 : mvx_cdiv(n4, 256));
-    hipLaunchKernelGGL(bn_apply, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, mean_inv, out, n4, channels);
-    MVX_LAUNCH_CHECK();
-    return MVX_OK;
+    return mvx_bn_apply_frames(y, mean_inv, out, rows, channels, nullptr, MVX_ROWS_SINGLE, stream);
 }
 
 extern "C" int mvx_row_stats(const float *y, double *stats, int64_t rows, int32_t channels, void *stream) {
@@ -259,23 +300,37 @@ extern "C" size_t mvx_bn_backward_scratch_bytes(int32_t channels) {
     return channels > 0 ? sizeof(double) * (REP * 3 * (size_t)channels + 1) : 0;
 }
 
-extern "C" int mvx_bn_relu_backward(const float *dyhat, const float *y, const float *mean_inv, double count,
-                                    float *dz, float *dbias, double *scratch, const float *row_w, int64_t rows,
-                                    int32_t channels, int32_t flags, void *stream) {
+extern "C" size_t mvx_bn_backward_scratch_bytes_frames(int32_t channels, int32_t n_frames) {
+    // per frame: replicated (sum dyh, sum dyh*yhat, dbias replica slot); the bias gradient uses frame 0's third slot
+    return channels > 0 && n_frames > 0 ? sizeof(double) * (REP * 3 * (size_t)channels * n_frames + 1) : 0;
+}
+
+extern "C" int mvx_bn_relu_backward_frames(const float *dyhat, const float *y, const float *mean_inv, double count,
+                                           float *dz, float *dbias, double *scratch, const float *row_w, int64_t rows,
+                                           int32_t channels, int32_t flags, const mvx_frames_t *frames_host,
+                                           int32_t row_kind, void *stream) {
     MVX_CHECK_ARG(dyhat && y && mean_inv && dz && scratch && rows >= 0 && channels > 0 && channels % 4 == 0);
     MVX_CHECK_ARG(count > 0);
+    FrameMap fm;
+    MVX_CHECK_ARG(mvx_build_frame_map(fm, frames_host, row_kind, rows, count));
     hipStream_t st = (hipStream_t)stream;
+    const size_t slots = (size_t)REP * 3 * channels * fm.F;
     if (!(flags & MVX_FLAG_PREZEROED)) {
-        hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * (REP * 3 * channels + 1), st);
+        hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * (slots + 1), st);
         if (e != hipSuccess) return (int)e;
     }
     if (rows > 0) {
         const unsigned grid = row_grid(rows, channels);
-        hipLaunchKernelGGL(bn_bwd_reduce, dim3(grid), dim3(256), 0, st, dyhat, y, mean_inv, scratch, (size_t)rows, channels);
+        const int rpi = (256 / (channels / 4)) > 1 ? 256 / (channels / 4) : 1;
+        size_t rpb = ((size_t)rows + grid - 1) / grid;
+        rpb = (rpb + 4 * rpi - 1) / (4 * (size_t)rpi) * (4 * (size_t)rpi);       // whole (4 x rpi)-row trips
+        const unsigned blocks = (unsigned)(((size_t)rows + rpb - 1) / rpb);
+        hipLaunchKernelGGL(bn_bwd_reduce, dim3(blocks), dim3(256), 0, st, dyhat, y, mean_inv, scratch, (size_t)rows, channels,
+                           rpb, fm);
         MVX_LAUNCH_CHECK();
-        hipLaunchKernelGGL(bn_bwd_apply, dim3(grid), dim3(256), 0, st, dyhat, y, mean_inv, (const double *)scratch, count,
-                           dz, dbias ? scratch + 2 * channels : (double *)nullptr, row_w, (size_t)rows, channels,
-                           (unsigned *)(scratch + (size_t)REP * 3 * channels), dbias, flags & MVX_FLAG_ACCUMULATE);
+        hipLaunchKernelGGL(bn_bwd_apply, dim3(blocks), dim3(256), 0, st, dyhat, y, mean_inv, (const double *)scratch, dz,
+                           dbias ? scratch + 2 * channels : (double *)nullptr, row_w, (size_t)rows, channels,
+                           (unsigned *)(scratch + slots), dbias, flags & MVX_FLAG_ACCUMULATE, rpb, fm);
         MVX_LAUNCH_CHECK();
     } else if (dbias) {                             // no rows: the bias gradient is zero
         hipLaunchKernelGGL(dbias_finish, dim3(mvx_cdiv(channels, 128)), dim3(128), 0, st, (const double *)scratch, dbias,
@@ -283,4 +338,11 @@ extern "C" int mvx_bn_relu_backward(const float *dyhat, const float *y, const fl
         MVX_LAUNCH_CHECK();
     }
     return MVX_OK;
+}
+
+extern "C" int mvx_bn_relu_backward(const float *dyhat, const float *y, const float *mean_inv, double count,
+                                    float *dz, float *dbias, double *scratch, const float *row_w, int64_t rows,
+                                    int32_t channels, int32_t flags, void *stream) {
+    return mvx_bn_relu_backward_frames(dyhat, y, mean_inv, count, dz, dbias, scratch, row_w, rows, channels, flags, nullptr,
+                                       MVX_ROWS_SINGLE, stream);
 }

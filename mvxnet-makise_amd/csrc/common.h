@@ -27,6 +27,86 @@ int mvxi_wgrad_step_list(const int32_t *in_halo_flags, int din, int dout, int nt
 int mvxi_wgrad_rank1(const float *tap_sums, const float *c_in, float *dw, int din, int dout, int cin, int cout, int stride_d,
                      int pad_d, hipStream_t st);
 
+// ---- frame sets: the frames of a step processed by ONE launch -----------------------------------------
+// The reference is strictly batch-1 (config.yml:18, VoxelNet.py:19): a batch is B independent forwards with per-frame
+// BatchNorm statistics.  Every kernel that reduces over "the batch" therefore needs to know which frame a row (or a
+// depth plane) belongs to.  Row matrices hold the frames back to back as up to 2F segments (see mvx_frames_t in the
+// header); grids stack the frames along the depth axis: global plane = frame * planes_per_frame + local plane.
+#define MVX_MAX_SEGS (2 * MVX_MAX_FRAMES)
+struct FrameMap {
+    int F, nseg;
+    int bound[MVX_MAX_SEGS + 1];                // segment s = rows [bound[s], bound[s+1])
+    unsigned char seg_frame[MVX_MAX_SEGS];
+    double count[MVX_MAX_FRAMES];               // BatchNorm population of frame f (rows of the DENSE tensor it stands for)
+};
+__device__ __forceinline__ int fm_seg_of(const FrameMap &m, long long r) {
+    int s = 0;
+    for (int k = 1; k < m.nseg; ++k) s += (r >= (long long)m.bound[k]);
+    return s;
+}
+__device__ __forceinline__ int fm_frame_of(const FrameMap &m, long long r) { return m.F == 1 ? 0 : (int)m.seg_frame[fm_seg_of(m, r)]; }
+
+// Host side: segment table of a row layout.  kind: MVX_ROWS_* of the header; fr == NULL -> one frame of `rows` rows
+// with population `count`.  Returns false on an inconsistent description.
+static inline bool mvx_build_frame_map(FrameMap &m, const mvx_frames_t *fr, int kind, long long rows, double count) {
+    for (int k = 0; k <= MVX_MAX_SEGS; ++k) m.bound[k] = 0;
+    for (int k = 0; k < MVX_MAX_SEGS; ++k) m.seg_frame[k] = 0;
+    for (int k = 0; k < MVX_MAX_FRAMES; ++k) m.count[k] = 1.0;
+    if (!fr || kind == MVX_ROWS_SINGLE) {
+        m.F = 1; m.nseg = 1; m.bound[0] = 0; m.bound[1] = (int)rows; m.count[0] = count;
+        return rows < (1ll << 31);
+    }
+    const int F = fr->n_frames;
+    if (F < 1 || F > MVX_MAX_FRAMES || fr->t < 1) return false;
+    m.F = F;
+    for (int f = 0; f < F; ++f) {
+        if (fr->real_off[f + 1] < fr->real_off[f] || fr->vox_off[f + 1] < fr->vox_off[f]) return false;
+        m.count[f] = (double)(fr->vox_off[f + 1] - fr->vox_off[f]) * (double)fr->t;
+    }
+    const int R = fr->real_off[F], V = fr->vox_off[F];
+    int s = 0;
+    if (kind == MVX_ROWS_FUSION || kind == MVX_ROWS_VFE) {
+        for (int f = 0; f < F; ++f) { m.bound[s] = fr->real_off[f]; m.seg_frame[s++] = (unsigned char)f; }
+        for (int f = 0; f < F; ++f) {
+            m.bound[s] = R + (kind == MVX_ROWS_VFE ? fr->vox_off[f] : f);
+            m.seg_frame[s++] = (unsigned char)f;
+        }
+        m.bound[s] = R + (kind == MVX_ROWS_VFE ? V : F);
+    } else if (kind == MVX_ROWS_VOXELS) {
+        for (int f = 0; f < F; ++f) { m.bound[s] = fr->vox_off[f]; m.seg_frame[s++] = (unsigned char)f; }
+        m.bound[s] = V;
+    } else if (kind == MVX_ROWS_REAL) {
+        for (int f = 0; f < F; ++f) { m.bound[s] = fr->real_off[f]; m.seg_frame[s++] = (unsigned char)f; }
+        m.bound[s] = R;
+    } else if (kind == MVX_ROWS_GRID) {
+        if (rows % F) return false;
+        const long long per = rows / F;
+        if (rows >= (1ll << 31)) return false;
+        for (int f = 0; f < F; ++f) { m.bound[s] = (int)(per * f); m.seg_frame[s++] = (unsigned char)f; m.count[f] = (double)per; }
+        m.bound[s] = (int)rows;
+    } else {
+        return false;
+    }
+    m.nseg = s;
+    return (long long)m.bound[s] == rows;
+}
+
+// Frames stacked along the depth axis of a grid: source plane (global) of global output plane d for depth tap kd of a
+// convolution with per-frame depths din -> dout, or -1 when the tap falls into the padding.
+__device__ __forceinline__ int mvx_src_plane(int d, int din, int dout, int sd, int pd, int kd) {
+    const int f = d / dout, dl = d - f * dout;
+    const int s = dl * sd - pd + kd;
+    return (s >= 0 && s < din) ? f * din + s : -1;
+}
+// ... and the global OUTPUT plane that reads global input plane d through depth tap kd, or -1
+__device__ __forceinline__ int mvx_dst_plane(int d, int din, int dout, int sd, int pd, int kd) {
+    const int f = d / din, dl = d - f * din;
+    const int t = dl + pd - kd;
+    if (t < 0 || (t % sd) != 0) return -1;
+    const int o = t / sd;
+    return o < dout ? f * dout + o : -1;
+}
+
 // ---- wave / block reductions and scans -------------------------------------------------
 __device__ __forceinline__ int wave_incl_scan_i32(int v) {
     const int lane = threadIdx.x & 63;
@@ -72,7 +152,7 @@ __device__ __forceinline__ int block_excl_scan_i32(int v, int *smem, int *total)
 __device__ __forceinline__ void mvx_drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ void bn_finalize_by_last_block(unsigned *done_counter, unsigned total_blocks,
-                                                          double *stats, int C, double count, double eps,
+                                                          double *stats, int C, const FrameMap &fm, double eps,
                                                           float *mean_inv, int *s_flag) {
     mvx_drain_vmem();
     __syncthreads();
@@ -82,22 +162,37 @@ __device__ __forceinline__ void bn_finalize_by_last_block(unsigned *done_counter
     }
     __syncthreads();
     if (!*s_flag) return;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    // every frame of the launch: stats [F][REP][2][C] -> mean_inv [F][2][C]
+    for (int e = threadIdx.x; e < C * fm.F; e += blockDim.x) {
+        const int f = e / C, c = e - f * C;
+        const double *st = stats + (size_t)f * MVX_REP * 2 * C;
         double v1[MVX_REP], v2[MVX_REP];
 #pragma unroll
         for (int rp = 0; rp < MVX_REP; ++rp) {            // 64 independent device-scope reads in flight
-            v1[rp] = __hip_atomic_load(stats + ((size_t)rp * 2) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v2[rp] = __hip_atomic_load(stats + ((size_t)rp * 2 + 1) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v1[rp] = __hip_atomic_load(st + ((size_t)rp * 2) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v2[rp] = __hip_atomic_load(st + ((size_t)rp * 2 + 1) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int rp = 0; rp < MVX_REP; ++rp) { s1 += v1[rp]; s2 += v2[rp]; }
+        const double count = fm.count[f];
         const double mean = s1 / count;
         double var = s2 / count - mean * mean;
         if (var < 0.0) var = 0.0;
-        mean_inv[c] = (float)mean;
-        mean_inv[C + c] = (float)(1.0 / sqrt(var + eps));
+        mean_inv[(size_t)f * 2 * C + c] = (float)mean;
+        mean_inv[(size_t)f * 2 * C + C + c] = (float)(1.0 / sqrt(var + eps));
     }
+}
+
+// single-frame form (kernels whose launch covers one frame)
+__device__ __forceinline__ void bn_finalize_by_last_block(unsigned *done_counter, unsigned total_blocks,
+                                                          double *stats, int C, double count, double eps,
+                                                          float *mean_inv, int *s_flag, int n_frames = 1) {
+    FrameMap fm;
+    fm.F = n_frames;
+    fm.nseg = 1;
+    for (int f = 0; f < MVX_MAX_FRAMES; ++f) fm.count[f] = count;
+    bn_finalize_by_last_block(done_counter, total_blocks, stats, C, fm, eps, mean_inv, s_flag);
 }
 
 __device__ __forceinline__ float wave_sum_f32(float v) {

@@ -37,21 +37,17 @@ constexpr int PITCH = BK + 4;           // LDS row pitch in floats (bank-conflic
 constexpr int BN = 64;                  // output channels per workgroup
 
 struct Geom {
-    int Din, Dout, H, W, Cin, Cout;     // gather view: in has Cin channels, out has Cout
+    int Din, Dout, H, W, Cin, Cout;     // gather view: in has Cin channels, out has Cout; Din / Dout = planes PER FRAME
     int sd, pd;                         // depth stride / padding of the FORWARD conv
     int mode;                           // 0 forward gather, 1 dgrad gather
+    int F = 1;                          // frames stacked along the depth axis: global plane = frame * planes + local plane
 };
 
-// source depth plane of output plane d for depth tap kd; -1 if the tap falls outside
+// source depth plane (global) of GLOBAL output plane d for depth tap kd; -1 if the tap falls outside the frame's volume
 __device__ __forceinline__ int src_depth(const Geom &g, int d, int kd) {
-    if (g.mode == 0) {
-        const int s = d * g.sd - g.pd + kd;
-        return (s >= 0 && s < g.Din) ? s : -1;
-    }
-    const int t = d + g.pd - kd;
-    if (t < 0 || (t % g.sd) != 0) return -1;
-    const int s = t / g.sd;
-    return s < g.Din ? s : -1;
+    if (g.mode == 0) return mvx_src_plane(d, g.Din, g.Dout, g.sd, g.pd, kd);
+    // dgrad gather: the result (dx) has g.Dout planes per frame, the source (dz) g.Din
+    return mvx_dst_plane(d, g.Dout, g.Din, g.sd, g.pd, kd);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -248,7 +244,7 @@ constexpr int HROW = ((HW * PITCH + 63) / 64) * 64;
 
 // Launch geometry: (tiles, output planes, 64-channel blocks).  An XCD-contiguous remap of the (tile, plane)
 // space was measured and was not faster (forward equal, stride-2 dgrad slower), so the plain grid stays.
-inline dim3 gather_grid(const Geom &g) { return dim3(mvx_cdiv(g.W, TW) * mvx_cdiv(g.H, TH), g.Dout, g.Cout / BN); }
+inline dim3 gather_grid(const Geom &g) { return dim3(mvx_cdiv(g.W, TW) * mvx_cdiv(g.H, TH), g.Dout * g.F, g.Cout / BN); }
 
 // One unit of work = (tile, output plane d, 64-channel block nb); `ntiles` tiles per plane.
 __device__ __forceinline__ void gather_unit(const int tile, const int d, const int nb, const int ntiles,
@@ -440,7 +436,8 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
             const double t = (double)s_red[0][tid] + (double)s_red[1][tid] + (double)s_red[2][tid] + (double)s_red[3][tid];
             const int which = tid / BN, c = tid % BN;
             const unsigned rep = (unsigned)(tile + d * ntiles) % MVX_REP;
-            atomicAdd(stats + ((size_t)rep * 2 + which) * g.Cout + nb * BN + c, t);
+            double *fstats = stats + (size_t)(d / g.Dout) * MVX_REP * 2 * g.Cout;       // the plane's frame
+            atomicAdd(fstats + ((size_t)rep * 2 + which) * g.Cout + nb * BN + c, t);
         }
     }
 }
@@ -467,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_pf(const float *__restri
     if (stats && done_counter) {
         __shared__ int s_last;
         bn_finalize_by_last_block(done_counter, gridDim.x * gridDim.y * gridDim.z, stats, g.Cout, fin_count, fin_eps,
-                                  fin_mean_inv, &s_last);
+                                  fin_mean_inv, &s_last, g.F);
     }
 }
 
@@ -505,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_pw(const float *__restri
     }
     if (stats && done_counter) {
         __shared__ int s_last;
-        bn_finalize_by_last_block(done_counter, gridDim.x, stats, g.Cout, fin_count, fin_eps, fin_mean_inv, &s_last);
+        bn_finalize_by_last_block(done_counter, gridDim.x, stats, g.Cout, fin_count, fin_eps, fin_mean_inv, &s_last, g.F);
     }
 }
 
@@ -963,7 +960,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restr
     }
     const int nd = dhi >= dlo ? dhi - dlo + 1 : 0;
     const int per = tiles_per_strip;
-    const int *my_list = step_list ? step_list + (size_t)kd * g.Dout * ntiles : nullptr;
+    const int *my_list = step_list ? step_list + (size_t)kd * g.Dout * g.F * ntiles : nullptr;
     const int nlist = step_list ? step_count[kd] : 0;
     const int nsteps = step_list ? (nlist > strip ? (nlist - strip + nstrips - 1) / nstrips : 0) : nd * per;
     // step i -> (plane, tile); dense steps past the last tile are dead (ragged last strip)
@@ -978,7 +975,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restr
     auto load_step = [&](int i) __attribute__((always_inline)) {
         int d, t;
         step_of(i, d, t);
-        const int ds = d * g.sd - g.pd + kd;
+        const int ds = mvx_src_plane(d, g.Din, g.Dout, g.sd, g.pd, kd);      // listed / dense steps always have a valid source
         const int tx0 = (t % tiles_x) * TW, ty0 = (t / tiles_x) * TH;
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
@@ -1055,7 +1052,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restr
 __global__ __launch_bounds__(1024) void wgrad_step_list(const int *__restrict__ in_hflag, Geom g, int ntiles,
                                                         int *__restrict__ step_list, int *__restrict__ step_count) {
     __shared__ int smem[17];
-    const int total = g.Dout * ntiles;
+    const int total = g.Dout * g.F * ntiles;
     {
         const int kd = blockIdx.x;                 // one workgroup per depth tap
         int base = 0;
@@ -1064,8 +1061,8 @@ __global__ __launch_bounds__(1024) void wgrad_step_list(const int *__restrict__ 
             int on = 0;
             if (e < total) {
                 const int d = e / ntiles, t = e - d * ntiles;
-                const int ds = d * g.sd - g.pd + kd;
-                on = (ds >= 0 && ds < g.Din) ? (in_hflag[(size_t)ds * ntiles + t] != 0) : 0;
+                const int ds = mvx_src_plane(d, g.Din, g.Dout, g.sd, g.pd, kd);
+                on = ds >= 0 ? (in_hflag[(size_t)ds * ntiles + t] != 0) : 0;
             }
             int tot;
             const int pos = block_excl_scan_i32(on, smem, &tot);
@@ -1190,9 +1187,9 @@ __global__ void wgrad_rank1(const float *__restrict__ T, const float *__restrict
         const int tap = (int)(e % 9), kd = (int)((e / 9) % 3);
         const int ci = (int)((e / 27) % g.Cin), co = (int)(e / ((size_t)27 * g.Cin));
         float s = 0.f;
-        for (int d = 0; d < g.Dout; ++d) {
-            const int ds = d * g.sd - g.pd + kd;
-            if (ds < 0 || ds >= g.Din) continue;
+        for (int d = 0; d < g.Dout * g.F; ++d) {          // every frame: the constants c_in differ per frame
+            const int ds = mvx_src_plane(d, g.Din, g.Dout, g.sd, g.pd, kd);
+            if (ds < 0) continue;
             s += c_in[(size_t)ds * g.Cin + ci] * T[((size_t)d * 9 + tap) * g.Cout + co];
         }
         dw[e] += s;
@@ -1226,13 +1223,11 @@ __global__ void wgrad_reduce(const float *__restrict__ slabs, float *__restrict_
 // A[d][c] = sum over kd with an output plane d' reading plane d through it, a, b, n of W[n][c][kd][a][b] T[d'][a][b][n]
 __global__ __launch_bounds__(64) void input_grad_sums(const float *__restrict__ w, const float *__restrict__ T, Geom g,
                                                       float *__restrict__ A) {
-    const int c = blockIdx.x, d = blockIdx.y;        // one wave per (input channel, input plane)
+    const int c = blockIdx.x, d = blockIdx.y;        // one wave per (input channel, GLOBAL input plane)
     double s = 0.0;
     for (int kd = 0; kd < 3; ++kd) {
-        const int t = d + g.pd - kd;
-        if (t < 0 || t % g.sd) continue;
-        const int dp = t / g.sd;
-        if (dp >= g.Dout) continue;
+        const int dp = mvx_dst_plane(d, g.Din, g.Dout, g.sd, g.pd, kd);
+        if (dp < 0) continue;
         for (int e = threadIdx.x; e < g.Cout * 9; e += 64) {
             const int n = e / 9, k = e - n * 9;
             s += (double)w[(((size_t)n * g.Cin + c) * 3 + kd) * 9 + k] * (double)T[((size_t)dp * 9 + k) * g.Cout + n];
@@ -1331,19 +1326,20 @@ extern "C" int mvx_conv3d_forward(const float *in, const float *wpk, const float
     return MVX_OK;
 }
 
-extern "C" int mvx_conv3d_forward_bg(const float *in, const float *wpk, const float *bias, float *out, double *stats,
-                                     int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
-                                     int32_t stride_d, int32_t pad_d, int32_t flags, const int32_t *in_halo_flags,
-                                     const uint8_t *out_mask, const float *bg_pre, int32_t border_active,
-                                     uint64_t *exec_stages, uint32_t *done_counter, double count, double eps,
-                                     float *mean_inv, uint32_t *work_counter, void *stream) {
+extern "C" int mvx_conv3d_forward_bg_frames(const float *in, const float *wpk, const float *bias, float *out, double *stats,
+                                            int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                                            int32_t stride_d, int32_t pad_d, int32_t flags, const int32_t *in_halo_flags,
+                                            const uint8_t *out_mask, const float *bg_pre, int32_t border_active,
+                                            uint64_t *exec_stages, uint32_t *done_counter, double count, double eps,
+                                            float *mean_inv, uint32_t *work_counter, int32_t n_frames, void *stream) {
     MVX_CHECK_ARG(in && wpk && out && in_halo_flags && out_mask && bg_pre);
     int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
     if (rc) return rc;
     MVX_CHECK_ARG(dout == (din + 2 * pad_d - 3) / stride_d + 1);
+    MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
     hipStream_t st = (hipStream_t)stream;
     if (stats && !(flags & MVX_FLAG_PREZEROED)) {
-        hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * MVX_REP * 2 * cout, st);
+        hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * MVX_REP * 2 * cout * n_frames, st);
         if (e != hipSuccess) return (int)e;
     }
     if (done_counter) {
@@ -1353,7 +1349,7 @@ extern "C" int mvx_conv3d_forward_bg(const float *in, const float *wpk, const fl
             if (e != hipSuccess) return (int)e;
         }
     }
-    Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
+    Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0, n_frames};
     launch_gather(st, in, wpk, bias, out, stats, g, flags & MVX_FLAG_RELU, in_halo_flags, out_mask, bg_pre, border_active,
                   (unsigned long long *)exec_stages, nullptr, (unsigned *)done_counter, count, eps, mean_inv,
                   (unsigned *)work_counter);
@@ -1361,14 +1357,26 @@ extern "C" int mvx_conv3d_forward_bg(const float *in, const float *wpk, const fl
     return MVX_OK;
 }
 
+extern "C" int mvx_conv3d_forward_bg(const float *in, const float *wpk, const float *bias, float *out, double *stats,
+                                     int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                                     int32_t stride_d, int32_t pad_d, int32_t flags, const int32_t *in_halo_flags,
+                                     const uint8_t *out_mask, const float *bg_pre, int32_t border_active,
+                                     uint64_t *exec_stages, uint32_t *done_counter, double count, double eps,
+                                     float *mean_inv, uint32_t *work_counter, void *stream) {
+    return mvx_conv3d_forward_bg_frames(in, wpk, bias, out, stats, din, dout, h, w, cin, cout, stride_d, pad_d, flags,
+                                        in_halo_flags, out_mask, bg_pre, border_active, exec_stages, done_counter, count, eps,
+                                        mean_inv, work_counter, 1, stream);
+}
+
 static int launch_dgrad(const float *dz, const float *wpk_dgrad, float *dx, int32_t din, int32_t dout, int32_t h,
                         int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, const int32_t *only_tiles,
-                        uint64_t *exec_stages, uint32_t *work_counter, void *stream) {
+                        uint64_t *exec_stages, uint32_t *work_counter, void *stream, int32_t n_frames = 1) {
     MVX_CHECK_ARG(dz && wpk_dgrad && dx);
+    MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
     // gather view: source = dz (dout planes, cout channels), result = dx (din planes, cin channels)
     int rc = check_geom(din, dout, h, w, cout, cin, stride_d, pad_d);
     if (rc) return rc;
-    Geom g{dout, din, h, w, cout, cin, stride_d, pad_d, 1};
+    Geom g{dout, din, h, w, cout, cin, stride_d, pad_d, 1, n_frames};
     launch_gather((hipStream_t)stream, dz, wpk_dgrad, nullptr, dx, nullptr, g, 0, nullptr, nullptr, nullptr, 0,
                   (unsigned long long *)exec_stages, only_tiles, nullptr, 0.0, 0.0, nullptr, (unsigned *)work_counter);
     MVX_LAUNCH_CHECK();
@@ -1388,6 +1396,15 @@ extern "C" int mvx_conv3d_dgrad_tiles(const float *dz, const float *wpk_dgrad, f
     MVX_CHECK_ARG(dx_tile_flags);
     return launch_dgrad(dz, wpk_dgrad, dx, din, dout, h, w, cin, cout, stride_d, pad_d, dx_tile_flags, exec_stages,
                         work_counter, stream);
+}
+
+extern "C" int mvx_conv3d_dgrad_tiles_frames(const float *dz, const float *wpk_dgrad, float *dx, int32_t din, int32_t dout,
+                                             int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
+                                             const int32_t *dx_tile_flags, uint64_t *exec_stages, uint32_t *work_counter,
+                                             int32_t n_frames, void *stream) {
+    MVX_CHECK_ARG(dx_tile_flags);
+    return launch_dgrad(dz, wpk_dgrad, dx, din, dout, h, w, cin, cout, stride_d, pad_d, dx_tile_flags, exec_stages,
+                        work_counter, stream, n_frames);
 }
 
 static int wgrad_strips(int h, int w, int cin) {
@@ -1510,34 +1527,48 @@ extern "C" int mvx_plane_tap_sums(const float *dz, int32_t planes, int32_t h, in
     return MVX_OK;
 }
 
-extern "C" int mvx_conv3d_input_grad_sums(const float *w, const float *tap_sums, int32_t din, int32_t dout, int32_t cin,
-                                          int32_t cout, int32_t stride_d, int32_t pad_d, float *plane_grad_sums,
-                                          void *stream) {
+extern "C" int mvx_conv3d_input_grad_sums_frames(const float *w, const float *tap_sums, int32_t din, int32_t dout, int32_t cin,
+                                                 int32_t cout, int32_t stride_d, int32_t pad_d, float *plane_grad_sums,
+                                                 int32_t n_frames, void *stream) {
     MVX_CHECK_ARG(w && tap_sums && plane_grad_sums && din > 0 && dout > 0 && cin > 0 && cout > 0);
-    Geom g{din, dout, 0, 0, cin, cout, stride_d, pad_d, 0};
-    hipLaunchKernelGGL(input_grad_sums, dim3(cin, din), dim3(64), 0, (hipStream_t)stream, w, tap_sums, g, plane_grad_sums);
+    MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
+    Geom g{din, dout, 0, 0, cin, cout, stride_d, pad_d, 0, n_frames};
+    hipLaunchKernelGGL(input_grad_sums, dim3(cin, din * n_frames), dim3(64), 0, (hipStream_t)stream, w, tap_sums, g,
+                       plane_grad_sums);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
 
-extern "C" size_t mvx_conv3d_wgrad_bg_workspace_bytes(int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout) {
-    if (dout <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout != BN || cin % W4_C) return 0;
-    const size_t ntiles = (size_t)mvx_cdiv(w, TW) * mvx_cdiv(h, TH);
-    return wgrad_bg_slab_bytes(cin) + sizeof(int) * (3 * dout * ntiles + 4);
+extern "C" int mvx_conv3d_input_grad_sums(const float *w, const float *tap_sums, int32_t din, int32_t dout, int32_t cin,
+                                          int32_t cout, int32_t stride_d, int32_t pad_d, float *plane_grad_sums,
+                                          void *stream) {
+    return mvx_conv3d_input_grad_sums_frames(w, tap_sums, din, dout, cin, cout, stride_d, pad_d, plane_grad_sums, 1, stream);
 }
 
-extern "C" int mvx_conv3d_wgrad_bg(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
-                                   int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, int32_t flags,
-                                   const int32_t *in_halo_flags, const float *c_in, const float *tap_sums,
-                                   void *workspace, size_t workspace_bytes, void *stream) {
+extern "C" size_t mvx_conv3d_wgrad_bg_workspace_bytes_frames(int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                                                            int32_t n_frames) {
+    if (dout <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout != BN || cin % W4_C || n_frames <= 0) return 0;
+    const size_t ntiles = (size_t)mvx_cdiv(w, TW) * mvx_cdiv(h, TH);
+    return wgrad_bg_slab_bytes(cin) + sizeof(int) * (3 * (size_t)dout * n_frames * ntiles + 4);
+}
+
+extern "C" size_t mvx_conv3d_wgrad_bg_workspace_bytes(int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout) {
+    return mvx_conv3d_wgrad_bg_workspace_bytes_frames(dout, h, w, cin, cout, 1);
+}
+
+extern "C" int mvx_conv3d_wgrad_bg_frames(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
+                                          int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, int32_t flags,
+                                          const int32_t *in_halo_flags, const float *c_in, const float *tap_sums,
+                                          void *workspace, size_t workspace_bytes, int32_t n_frames, void *stream) {
     MVX_CHECK_ARG(in && dz && dw && workspace && in_halo_flags && c_in && tap_sums);
     int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
     if (rc) return rc;
     if (cout != BN || cin % W4_C) return MVX_ESIZE;
-    MVX_CHECK_ARG(workspace_bytes >= mvx_conv3d_wgrad_bg_workspace_bytes(dout, h, w, cin, cout));
+    MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
+    MVX_CHECK_ARG(workspace_bytes >= mvx_conv3d_wgrad_bg_workspace_bytes_frames(dout, h, w, cin, cout, n_frames));
     const int ntiles = (int)(mvx_cdiv(w, TW) * mvx_cdiv(h, TH));
     const int nstrips = wgrad_bg_strips(cin);       // slab capacity = the largest share a depth tap can get
-    Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
+    Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0, n_frames};
     hipStream_t st = (hipStream_t)stream;
     // workgroups per depth tap in proportion to its valid output planes (conv3: 1 / 2 / 1 of 2 planes), 256 per chunk set
     int nd[3], ndsum = 0;
@@ -1560,7 +1591,7 @@ extern "C" int mvx_conv3d_wgrad_bg(const float *in, const float *dz, float *dw, 
     }
     float *slabs = (float *)workspace;
     int *list = (int *)((char *)workspace + wgrad_bg_slab_bytes(cin));
-    int *count = list + (size_t)3 * dout * ntiles;
+    int *count = list + (size_t)3 * dout * n_frames * ntiles;
     hipLaunchKernelGGL(wgrad_step_list, dim3(3), dim3(1024), 0, st, in_halo_flags, g, ntiles, list, count);
     MVX_LAUNCH_CHECK();
     hipLaunchKernelGGL(conv3d_wgrad4, dim3(widest, 3 * (cin / W4_C)), dim3(W4_THREADS), 0, st, in, dz, slabs, g, 0,
@@ -1573,6 +1604,14 @@ extern "C" int mvx_conv3d_wgrad_bg(const float *in, const float *dz, float *dw, 
     hipLaunchKernelGGL(wgrad_rank1, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, tap_sums, c_in, dw, g);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
+}
+
+extern "C" int mvx_conv3d_wgrad_bg(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
+                                   int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, int32_t flags,
+                                   const int32_t *in_halo_flags, const float *c_in, const float *tap_sums,
+                                   void *workspace, size_t workspace_bytes, void *stream) {
+    return mvx_conv3d_wgrad_bg_frames(in, dz, dw, din, dout, h, w, cin, cout, stride_d, pad_d, flags, in_halo_flags, c_in,
+                                      tap_sums, workspace, workspace_bytes, 1, stream);
 }
 
 static int sites_rows_per_strip(int n_voxels) {

@@ -25,6 +25,12 @@ struct Levels {
     int h[MAX_LEVELS], w[MAX_LEVELS];
     int n;
 };
+// the same levels for every frame of a frame set (maps of frame f: feat[f * n + level]; one shape per level)
+struct FrameLevels {
+    const float *feat[MVX_MAX_FRAMES * MAX_LEVELS];
+    int h[MAX_LEVELS], w[MAX_LEVELS];
+    int n;
+};
 
 __device__ __forceinline__ bool row_is_zero(const float *v) { return v[0] == 0.f && v[1] == 0.f && v[2] == 0.f; }
 
@@ -74,6 +80,17 @@ __global__ __launch_bounds__(256) void map_write(float *__restrict__ vox, int vc
         if (!flag && zero_padding)
             for (int c = 3; c < vc; ++c) vox[r * vc + c] = 0.f;
     }
+}
+
+// real_off[f] = rank of the first real row at or after the first dense row of frame f (= real rows before frame f)
+__global__ void map_frame_offsets(const int *__restrict__ row_map, long long R, const int *__restrict__ n_real, int T,
+                                  FrameMap fm, int *__restrict__ real_off) {
+    const int f = threadIdx.x;
+    if (f > fm.F) return;
+    if (f == fm.F) { real_off[f] = *n_real; return; }
+    long long r = (long long)fm.bound[f] * T;       // fm: MVX_ROWS_VOXELS segments (first voxel of frame f)
+    while (r < R && row_map[r] < 0) ++r;
+    real_off[f] = r < R ? row_map[r] : *n_real;
 }
 
 // ---- sampling: one wave per (dense row, level) ---------------------------------------------------
@@ -134,8 +151,8 @@ __global__ __launch_bounds__(256) void feature_sample(float *__restrict__ vox, i
 // Compact form: one wave per (REAL row j, level); rows_sel[j] is the dense row, the output row is j.  The padding
 // rows are not visited at all (88 % of the dense rows on a lidar frame); same arithmetic as feature_sample.
 __global__ __launch_bounds__(256) void feature_sample_rows(const float *__restrict__ vox, int vc, const int *__restrict__ rows_sel,
-                                                           int n_real, Levels L, int C, float im_h, float im_w, float eps,
-                                                           float *__restrict__ out, int *__restrict__ status) {
+                                                           int n_real, FrameLevels L, int C, float im_h, float im_w, float eps,
+                                                           float *__restrict__ out, int *__restrict__ status, FrameMap fm) {
     const long long wave = (blockIdx.x * 256ll + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     const long long j = wave / L.n;
@@ -153,7 +170,7 @@ __global__ __launch_bounds__(256) void feature_sample_rows(const float *__restri
         for (int c = lane * 4; c < C; c += 256) *(float4 *)(out + j * ldo + lv * C + c) = make_float4(0, 0, 0, 0);
         return;
     }
-    const float *F = L.feat[lv];
+    const float *F = L.feat[fm_frame_of(fm, j) * L.n + lv];       // the maps of the row's own frame
     const bool y0 = iy < H, y1 = iy + 1 < H, x0 = ix < W, x1 = ix + 1 < W;
     const float xi = fy, yi = fx;
     const float xi_ = 1.f - xi, yi_ = 1.f - yi;
@@ -218,14 +235,21 @@ extern "C" size_t mvx_row_compact_workspace_bytes(int64_t rows) {
     return (size_t)(mvx_cdiv(rows > 0 ? rows : 1, 256) + 1) * sizeof(int32_t);
 }
 
-extern "C" int mvx_row_compact_map(float *voxels, int32_t vox_channels, int64_t rows, int32_t *row_map,
-                                   int32_t *rows_sel, int32_t *n_real, void *workspace, size_t workspace_bytes,
-                                   void *stream) {
+extern "C" int mvx_row_compact_map_frames(float *voxels, int32_t vox_channels, int64_t rows, int32_t *row_map,
+                                          int32_t *rows_sel, int32_t *n_real, void *workspace, size_t workspace_bytes,
+                                          const mvx_frames_t *frames_host, int32_t *real_off, void *stream) {
     MVX_CHECK_ARG(voxels && row_map && n_real && workspace && vox_channels >= 3 && rows >= 0);
     MVX_CHECK_ARG(workspace_bytes >= mvx_row_compact_workspace_bytes(rows));
+    MVX_CHECK_ARG((frames_host == nullptr) == (real_off == nullptr));
     hipStream_t st = (hipStream_t)stream;
+    FrameMap fm;
+    if (frames_host) {
+        MVX_CHECK_ARG(frames_host->t > 0 && rows % frames_host->t == 0);
+        MVX_CHECK_ARG(mvx_build_frame_map(fm, frames_host, MVX_ROWS_VOXELS, rows / frames_host->t, 1.0));
+    }
     if (rows == 0) {
         hipError_t e = hipMemsetAsync(n_real, 0, sizeof(int32_t), st);
+        if (e == hipSuccess && real_off) e = hipMemsetAsync(real_off, 0, sizeof(int32_t) * (frames_host->n_frames + 1), st);
         return e == hipSuccess ? MVX_OK : (int)e;
     }
     const unsigned nb = mvx_cdiv(rows, 256);
@@ -237,7 +261,19 @@ extern "C" int mvx_row_compact_map(float *voxels, int32_t vox_channels, int64_t 
     hipLaunchKernelGGL(map_write, dim3(nb), dim3(256), 0, st, voxels, vox_channels, (long long)rows, (const int *)bc,
                        row_map, rows_sel, 1);
     MVX_LAUNCH_CHECK();
+    if (real_off) {
+        hipLaunchKernelGGL(map_frame_offsets, dim3(1), dim3(64), 0, st, (const int *)row_map, (long long)rows,
+                           (const int *)n_real, frames_host->t, fm, real_off);
+        MVX_LAUNCH_CHECK();
+    }
     return MVX_OK;
+}
+
+extern "C" int mvx_row_compact_map(float *voxels, int32_t vox_channels, int64_t rows, int32_t *row_map,
+                                   int32_t *rows_sel, int32_t *n_real, void *workspace, size_t workspace_bytes,
+                                   void *stream) {
+    return mvx_row_compact_map_frames(voxels, vox_channels, rows, row_map, rows_sel, n_real, workspace, workspace_bytes,
+                                      nullptr, nullptr, stream);
 }
 
 extern "C" int mvx_feature_sample(float *voxels, int32_t vox_channels, int64_t rows, const int32_t *row_map,
@@ -263,27 +299,41 @@ extern "C" int mvx_feature_sample(float *voxels, int32_t vox_channels, int64_t r
     return MVX_OK;
 }
 
-extern "C" int mvx_feature_sample_rows(const float *voxels, int32_t vox_channels, const int32_t *rows_sel, int32_t n_real,
-                                       const float *const *feats_host, const int32_t *feat_hw_host, int32_t n_levels,
-                                       int32_t channels, float imsize_h, float imsize_w, float eps, float *out,
-                                       int32_t *status, void *stream) {
+extern "C" int mvx_feature_sample_rows_frames(const float *voxels, int32_t vox_channels, const int32_t *rows_sel,
+                                              int32_t n_real, const float *const *feats_host, const int32_t *feat_hw_host,
+                                              int32_t n_levels, int32_t channels, float imsize_h, float imsize_w, float eps,
+                                              float *out, int32_t *status, const mvx_frames_t *frames_host, void *stream) {
     MVX_CHECK_ARG(voxels && rows_sel && feats_host && feat_hw_host && out && status && n_real >= 0);
     MVX_CHECK_ARG(vox_channels >= 5 && vox_channels <= 64 && n_levels >= 1 && n_levels <= MAX_LEVELS);
     MVX_CHECK_ARG(channels > 0 && channels % 4 == 0);
     if (n_real == 0) return MVX_OK;
-    Levels L;
+    FrameMap fm;
+    MVX_CHECK_ARG(mvx_build_frame_map(fm, frames_host, frames_host ? MVX_ROWS_REAL : MVX_ROWS_SINGLE, n_real, 1.0));
+    FrameLevels L;
     L.n = n_levels;
     for (int k = 0; k < MAX_LEVELS; ++k) {
-        L.feat[k] = k < n_levels ? feats_host[k] : nullptr;
         L.h[k] = k < n_levels ? feat_hw_host[2 * k] : 0;
         L.w[k] = k < n_levels ? feat_hw_host[2 * k + 1] : 0;
-        if (k < n_levels) MVX_CHECK_ARG(L.feat[k] && L.h[k] > 0 && L.w[k] > 0);
+        if (k < n_levels) MVX_CHECK_ARG(L.h[k] > 0 && L.w[k] > 0);
+    }
+    for (int k = 0; k < MVX_MAX_FRAMES * MAX_LEVELS; ++k) L.feat[k] = nullptr;
+    for (int k = 0; k < fm.F * n_levels; ++k) {
+        L.feat[k] = feats_host[k];                 // frame-major: feats_host[f * n_levels + level]
+        MVX_CHECK_ARG(L.feat[k]);
     }
     const long long waves = (long long)n_real * n_levels;
     hipLaunchKernelGGL(feature_sample_rows, dim3(mvx_cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, voxels, vox_channels,
-                       rows_sel, n_real, L, channels, imsize_h, imsize_w, eps, out, status);
+                       rows_sel, n_real, L, channels, imsize_h, imsize_w, eps, out, status, fm);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
+}
+
+extern "C" int mvx_feature_sample_rows(const float *voxels, int32_t vox_channels, const int32_t *rows_sel, int32_t n_real,
+                                       const float *const *feats_host, const int32_t *feat_hw_host, int32_t n_levels,
+                                       int32_t channels, float imsize_h, float imsize_w, float eps, float *out,
+                                       int32_t *status, void *stream) {
+    return mvx_feature_sample_rows_frames(voxels, vox_channels, rows_sel, n_real, feats_host, feat_hw_host, n_levels, channels,
+                                          imsize_h, imsize_w, eps, out, status, nullptr, stream);
 }
 
 extern "C" int mvx_expand_rows(const float *compact, const int32_t *row_map, int32_t pad_row, float *out,

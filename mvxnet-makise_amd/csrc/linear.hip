@@ -31,8 +31,8 @@ __global__ __launch_bounds__(256) void linear_fwd(const float *__restrict__ x, i
                                                   int ldw, const float *__restrict__ bias, float *__restrict__ y,
                                                   int ldy, double *__restrict__ stats, const float *__restrict__ row_w,
                                                   long long R, int K, int N, int relu, int k_per_split,
-                                                  unsigned *__restrict__ done_counter, double fin_count, double fin_eps,
-                                                  float *__restrict__ fin_mean_inv) {
+                                                  unsigned *__restrict__ done_counter, double fin_eps,
+                                                  float *__restrict__ fin_mean_inv, FrameMap fm) {
     constexpr int BNL = 32 * NT;
     constexpr int XV = BM * BK / 4 / 256;          // float4 per thread for the x tile (4)
     constexpr int WV = BNL * BK / 4 / 256;         // float4 per thread for the w tile (NT)
@@ -158,44 +158,69 @@ __global__ __launch_bounds__(256) void linear_fwd(const float *__restrict__ x, i
         }
     }
 
-    float s1[NT], s2[NT];
+    // store, then the BatchNorm sums.  A 128-row block almost always lies inside one frame; a block that straddles a
+    // frame boundary repeats the (register-only) reduction once per frame with the other frames' rows masked out.
+    float bsv[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int c = n0 + t * 32 + li;
-        const float bs = (bias && c < N) ? bias[c] : 0.f;
-        s1[t] = 0.f; s2[t] = 0.f;
+        bsv[t] = (bias && c < N) ? bias[c] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
             const long long gr = r0 + wv * 32 + row;
-            float v = acc[t][r] + bs;
+            float v = acc[t][r] + bsv[t];
             if (relu) v = fmaxf(v, 0.f);
-            if (gr < R && c < N) {
-                y[gr * ldy + c] = v;
-                const float rw = row_w ? row_w[gr] : 1.f;
-                s1[t] += rw * v;
-                s2[t] += rw * v * v;
-            }
+            if (gr < R && c < N) y[gr * ldy + c] = v;
         }
     }
     if (stats) {
-        __syncthreads();
+        const long long r_last = (r0 + BM - 1 < R ? r0 + BM - 1 : R - 1);
+        const int f_lo = fm_frame_of(fm, r0), f_hi = fm.F == 1 ? 0 : fm_frame_of(fm, r_last);
+        const int s_lo = fm.F == 1 ? 0 : fm_seg_of(fm, r0), s_hi = fm.F == 1 ? 0 : fm_seg_of(fm, r_last);
+        // frames met by this block, in segment order (a block can cross from the real rows into the padded rows, whose
+        // frame order starts again at 0): walk the segments, one reduction per segment
+        for (int sg = s_lo; sg <= s_hi; ++sg) {
+            const int f = fm.F == 1 ? 0 : (int)fm.seg_frame[sg];
+            const long long lo = fm.F == 1 ? 0 : fm.bound[sg], hi = fm.F == 1 ? R : fm.bound[sg + 1];
+            float s1[NT], s2[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float a = s1[t] + __shfl_xor(s1[t], 32, 64), b = s2[t] + __shfl_xor(s2[t], 32, 64);
-            if (lh == 0) { s_red[wv][t * 32 + li] = a; s_red[wv][BNL + t * 32 + li] = b; }
-        }
-        __syncthreads();
-        for (int e = tid; e < 2 * BNL; e += 256) {
-            const int which = e / BNL, c = e % BNL;
-            if (n0 + c < N) {
-                const double t = (double)s_red[0][e] + (double)s_red[1][e] + (double)s_red[2][e] + (double)s_red[3][e];
-                atomicAdd(stats + ((size_t)(blockIdx.y % MVX_REP) * 2 + which) * N + n0 + c, t);
+            for (int t = 0; t < NT; ++t) {
+                const int c = n0 + t * 32 + li;
+                s1[t] = 0.f; s2[t] = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const long long gr = r0 + wv * 32 + row;
+                    float v = acc[t][r] + bsv[t];
+                    if (relu) v = fmaxf(v, 0.f);
+                    if (gr < R && c < N && gr >= lo && gr < hi) {
+                        const float rw = row_w ? row_w[gr] : 1.f;
+                        s1[t] += rw * v;
+                        s2[t] += rw * v * v;
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float a = s1[t] + __shfl_xor(s1[t], 32, 64), b = s2[t] + __shfl_xor(s2[t], 32, 64);
+                if (lh == 0) { s_red[wv][t * 32 + li] = a; s_red[wv][BNL + t * 32 + li] = b; }
+            }
+            __syncthreads();
+            double *fstats = stats + (size_t)f * MVX_REP * 2 * N;
+            for (int e = tid; e < 2 * BNL; e += 256) {
+                const int which = e / BNL, c = e % BNL;
+                if (n0 + c < N) {
+                    const double t = (double)s_red[0][e] + (double)s_red[1][e] + (double)s_red[2][e] + (double)s_red[3][e];
+                    atomicAdd(fstats + ((size_t)(blockIdx.y % MVX_REP) * 2 + which) * N + n0 + c, t);
+                }
             }
         }
+        (void)f_lo; (void)f_hi;
         if (done_counter) {
             __shared__ int s_last;
-            bn_finalize_by_last_block(done_counter, gridDim.x * gridDim.y, stats, N, fin_count, fin_eps, fin_mean_inv, &s_last);
+            bn_finalize_by_last_block(done_counter, gridDim.x * gridDim.y, stats, N, fm, fin_eps, fin_mean_inv, &s_last);
         }
     }
 }
@@ -339,13 +364,15 @@ static int linear_forward_impl(const float *x, int32_t ldx, const float *w, int3
                                const float *bias, float *y, int32_t ldy, double *stats, const float *row_w,
                                int64_t rows, int32_t k, int32_t n, int32_t flags, void *splitk_workspace,
                                size_t splitk_workspace_bytes, unsigned *fin_counter, double fin_count, double fin_eps,
-                               float *fin_mean_inv, void *stream) {
+                               float *fin_mean_inv, const mvx_frames_t *frames, int row_kind, void *stream) {
     const int relu = flags & MVX_FLAG_RELU;
     MVX_CHECK_ARG(x && w && y && rows >= 0 && k > 0 && n > 0 && ldx >= k && ldy >= n);
     MVX_CHECK_ARG(ldw >= (w_transposed ? n : k));
     hipStream_t st = (hipStream_t)stream;
+    FrameMap fm;
+    MVX_CHECK_ARG(mvx_build_frame_map(fm, frames, row_kind, rows, fin_count));
     if (stats && !(flags & MVX_FLAG_PREZEROED)) {
-        hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * MVX_REP * 2 * n, st);
+        hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * MVX_REP * 2 * n * fm.F, st);
         if (e != hipSuccess) return (int)e;
     }
     if (rows == 0) return MVX_OK;
@@ -375,7 +402,7 @@ static int linear_forward_impl(const float *x, int32_t ldx, const float *w, int3
     const dim3 grid(mvx_cdiv(n, wide ? 128 : 64), mvx_cdiv(rows, BM), splits);
 #define MVX_LAUNCH_LIN(WT, NT, VEC)                                                                               \
     hipLaunchKernelGGL((linear_fwd<WT, NT, VEC>), grid, dim3(256), 0, st, x, ldx, w, ldw, bias, ydst, ld_dst, stats, \
-                       row_w, (long long)rows, k, n, relu, k_per_split, fin_counter, fin_count, fin_eps, fin_mean_inv)
+                       row_w, (long long)rows, k, n, relu, k_per_split, fin_counter, fin_eps, fin_mean_inv, fm)
     if (w_transposed) {
         if (wide) { if (vec) MVX_LAUNCH_LIN(true, 4, true); else MVX_LAUNCH_LIN(true, 4, false); }
         else      { if (vec) MVX_LAUNCH_LIN(true, 2, true); else MVX_LAUNCH_LIN(true, 2, false); }
@@ -402,7 +429,7 @@ extern "C" int mvx_linear_forward(const float *x, int32_t ldx, const float *w, i
                                   int64_t rows, int32_t k, int32_t n, int32_t flags, void *splitk_workspace,
                                   size_t splitk_workspace_bytes, void *stream) {
     return linear_forward_impl(x, ldx, w, ldw, w_transposed, bias, y, ldy, stats, row_w, rows, k, n, flags, splitk_workspace,
-                               splitk_workspace_bytes, nullptr, 0.0, 0.0, nullptr, stream);
+                               splitk_workspace_bytes, nullptr, 1.0, 0.0, nullptr, nullptr, MVX_ROWS_SINGLE, stream);
 }
 
 extern "C" int mvx_linear_forward_bn(const float *x, int32_t ldx, const float *w, int32_t ldw, int32_t w_transposed,
@@ -415,7 +442,21 @@ extern "C" int mvx_linear_forward_bn(const float *x, int32_t ldx, const float *w
         if (e != hipSuccess) return (int)e;
     }
     return linear_forward_impl(x, ldx, w, ldw, w_transposed, bias, y, ldy, stats, row_w, rows, k, n, flags, nullptr, 0,
-                               done_counter, count, eps, mean_inv, stream);
+                               done_counter, count, eps, mean_inv, nullptr, MVX_ROWS_SINGLE, stream);
+}
+
+extern "C" int mvx_linear_forward_bn_frames(const float *x, int32_t ldx, const float *w, int32_t ldw, int32_t w_transposed,
+                                            const float *bias, float *y, int32_t ldy, double *stats, const float *row_w,
+                                            int64_t rows, int32_t k, int32_t n, int32_t flags, uint32_t *done_counter,
+                                            double eps, float *mean_inv, const mvx_frames_t *frames_host, int32_t row_kind,
+                                            void *stream) {
+    MVX_CHECK_ARG(stats && done_counter && mean_inv && rows > 0 && frames_host);
+    if (!(flags & MVX_FLAG_PREZEROED)) {
+        hipError_t e = hipMemsetAsync(done_counter, 0, sizeof(uint32_t), (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    return linear_forward_impl(x, ldx, w, ldw, w_transposed, bias, y, ldy, stats, row_w, rows, k, n, flags, nullptr, 0,
+                               done_counter, 1.0, eps, mean_inv, frames_host, row_kind, stream);
 }
 
 extern "C" size_t mvx_linear_wgrad_workspace_bytes(int64_t rows, int32_t k, int32_t n) {

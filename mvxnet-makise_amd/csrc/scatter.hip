@@ -102,7 +102,10 @@ __global__ __launch_bounds__(256) void cl_bev_transpose(const float *__restrict_
                                                         int D, int H, int W, int C, int dir) {
     __shared__ float tile[32][33];
     const int w0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-    const int dh = blockIdx.z, d = dh / H, h = dh % H;
+    // blockIdx.z runs over (frame, d, h): both tensors hold the frames back to back
+    const int fr = blockIdx.z / (D * H), dh = blockIdx.z - fr * D * H, d = dh / H, h = dh % H;
+    if (dir == 0) { src += (size_t)fr * D * H * W * C; dst += (size_t)fr * C * D * H * W; }
+    else { src += (size_t)fr * C * D * H * W; dst += (size_t)fr * D * H * W * C; }
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     if (dir == 0) {
         for (int j = ty; j < 32; j += 8) {
@@ -131,9 +134,14 @@ __global__ __launch_bounds__(256) void cl_bev_transpose(const float *__restrict_
 
 extern "C" int mvx_cl_to_bev(const float *cl, float *bev, int32_t d, int32_t h, int32_t w, int32_t channels,
                              int32_t reverse, void *stream) {
-    MVX_CHECK_ARG(cl && bev && d > 0 && h > 0 && w > 0 && channels > 0);
-    MVX_CHECK_ARG((long long)d * h <= 65535);
-    const dim3 grid(mvx_cdiv(w, 32), mvx_cdiv(channels, 32), d * h);
+    return mvx_cl_to_bev_frames(cl, bev, d, h, w, channels, reverse, 1, stream);
+}
+
+extern "C" int mvx_cl_to_bev_frames(const float *cl, float *bev, int32_t d, int32_t h, int32_t w, int32_t channels,
+                                    int32_t reverse, int32_t n_frames, void *stream) {
+    MVX_CHECK_ARG(cl && bev && d > 0 && h > 0 && w > 0 && channels > 0 && n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
+    MVX_CHECK_ARG((long long)d * h * n_frames <= 65535);
+    const dim3 grid(mvx_cdiv(w, 32), mvx_cdiv(channels, 32), d * h * n_frames);
     if (!reverse)
         hipLaunchKernelGGL(cl_bev_transpose, grid, dim3(256), 0, (hipStream_t)stream, cl, bev, d, h, w, channels, 0);
     else

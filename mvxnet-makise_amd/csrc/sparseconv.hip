@@ -20,11 +20,11 @@
 
 namespace {
 
-struct SGeom { int Din, Dout, H, W, Cout, sd, pd; };
+struct SGeom { int Din, Dout, H, W, Cout, sd, pd; };   // Din / Dout: planes PER FRAME (frames are stacked along depth)
 constexpr int OTH = 8, OTW = 16;      // coarse occupancy tiles (sites)
 
 __global__ void index_grid_fill(const long long *__restrict__ coords, int V, int D, int H, int W, int *__restrict__ grid,
-                                int *__restrict__ occ, int *__restrict__ status) {
+                                int *__restrict__ occ, int *__restrict__ status, FrameMap fm) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
     const long long ix = coords[(size_t)v * 4 + 1], iy = coords[(size_t)v * 4 + 2], iz = coords[(size_t)v * 4 + 3];
@@ -32,9 +32,10 @@ __global__ void index_grid_fill(const long long *__restrict__ coords, int V, int
         if (status) atomicOr(status, 1);
         return;
     }
-    grid[((size_t)iz * H + ix) * W + iy] = v;
+    const long long pz = (long long)fm_frame_of(fm, v) * D + iz;      // the voxel's frame owns planes [f*D, (f+1)*D)
+    grid[((size_t)pz * H + ix) * W + iy] = v;
     const int ty = (H + OTH - 1) / OTH, tx = (W + OTW - 1) / OTW;
-    atomicAdd(&occ[((size_t)iz * ty + ix / OTH) * tx + iy / OTW], 1);
+    atomicAdd(&occ[((size_t)pz * ty + ix / OTH) * tx + iy / OTW], 1);
 }
 
 // One workgroup = one 8 x 16-site occupancy tile of one output plane; a thread = 4 channels of one
@@ -51,12 +52,15 @@ __global__ __launch_bounds__(256) void sparse_conv_output(const float *__restric
     const int c4n = g.Cout >> 2;                       // threads per site (16 at Cout = 64)
     const int ct = threadIdx.x % c4n, st = threadIdx.x / c4n;       // st: site column inside the tile (0..15)
     const int tyn = (g.H + OTH - 1) / OTH, txn = (g.W + OTW - 1) / OTW;
-    const int tcx = blockIdx.x % txn, tcy = blockIdx.x / txn, d = blockIdx.y;
+    const int tcx = blockIdx.x % txn, tcy = blockIdx.x / txn, d = blockIdx.y;       // d: global output plane
+    const int frame = d / g.Dout;
+    if (stats) stats += (size_t)frame * MVX_REP * 2 * g.Cout;
+    active_sites += frame;
     const int x = tcx * OTW + st;
     int any = 0;
     for (int kd = 0; kd < 3; ++kd) {
-        const int ds = d * g.sd - g.pd + kd;
-        if (ds < 0 || ds >= g.Din) continue;
+        const int ds = mvx_src_plane(d, g.Din, g.Dout, g.sd, g.pd, kd);
+        if (ds < 0) continue;
         for (int ty = max(tcy - 1, 0); ty <= min(tcy + 1, tyn - 1); ++ty)
             for (int tx = max(tcx - 1, 0); tx <= min(tcx + 1, txn - 1); ++tx) any |= occ[((size_t)ds * tyn + ty) * txn + tx];
     }
@@ -64,9 +68,9 @@ __global__ __launch_bounds__(256) void sparse_conv_output(const float *__restric
         for (int e = threadIdx.x; e < 3 * (OTH + 2) * (OTW + 2); e += 256) {
             const int kd = e / ((OTH + 2) * (OTW + 2)), rem = e % ((OTH + 2) * (OTW + 2));
             const int hy = rem / (OTW + 2), hx = rem % (OTW + 2);
-            const int ds = d * g.sd - g.pd + kd, gy = tcy * OTH - 1 + hy, gx = tcx * OTW - 1 + hx;
+            const int ds = mvx_src_plane(d, g.Din, g.Dout, g.sd, g.pd, kd), gy = tcy * OTH - 1 + hy, gx = tcx * OTW - 1 + hx;
             int v = -1;
-            if (ds >= 0 && ds < g.Din && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) v = idx[((size_t)ds * g.H + gy) * g.W + gx];
+            if (ds >= 0 && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) v = idx[((size_t)ds * g.H + gy) * g.W + gx];
             s_idx[kd][hy][hx] = v;
         }
         __syncthreads();
@@ -124,6 +128,8 @@ __global__ void sparse_stats_fix(double *__restrict__ stats, const float *__rest
                                  long long total_sites, int C, int relu) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    stats += (size_t)blockIdx.y * MVX_REP * 2 * C;      // frame
+    active_sites += blockIdx.y;
     double v = bias ? (double)bias[c] : 0.0;
     if (relu && v < 0.0) v = 0.0;
     const double n = (double)(total_sites - (long long)*active_sites);
@@ -134,7 +140,7 @@ __global__ void sparse_stats_fix(double *__restrict__ stats, const float *__rest
 // G[v][tap*Cout + c] = dz[do][ix+1-a][iy+1-b][c] for the output site that read voxel v through tap
 // (kd,a,b): do*sd - pd + kd = iz; zero where that site does not exist.
 __global__ void sparse_conv_gather_dz(const float *__restrict__ dz, const long long *__restrict__ coords, int V,
-                                      float *__restrict__ G, SGeom g) {
+                                      float *__restrict__ G, SGeom g, FrameMap fm) {
     const int c4n = g.Cout >> 2;
     const long long total = (long long)V * 27 * c4n;
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
@@ -146,33 +152,43 @@ __global__ void sparse_conv_gather_dz(const float *__restrict__ dz, const long l
         const int t = (int)cd[3] + g.pd - kd, y = (int)cd[1] + 1 - a, x = (int)cd[2] + 1 - b;
         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t >= 0 && (t % g.sd) == 0 && t / g.sd < g.Dout && y >= 0 && y < g.H && x >= 0 && x < g.W)
-            val = *(const float4 *)(dz + (((size_t)(t / g.sd) * g.H + y) * g.W + x) * g.Cout + ct * 4);
+            val = *(const float4 *)(dz + (((size_t)(fm_frame_of(fm, v) * g.Dout + t / g.sd) * g.H + y) * g.W + x) * g.Cout + ct * 4);
         *(float4 *)(G + ((size_t)v * 27 + tap) * g.Cout + ct * 4) = val;
     }
 }
 
 }  // namespace
 
-extern "C" size_t mvx_index_grid_bytes(int32_t d, int32_t h, int32_t w) {
-    if (d <= 0 || h <= 0 || w <= 0) return 0;
-    return sizeof(int32_t) * ((size_t)d * h * w + (size_t)d * mvx_cdiv(h, OTH) * mvx_cdiv(w, OTW) + 4);
+extern "C" size_t mvx_index_grid_bytes_frames(int32_t d, int32_t h, int32_t w, int32_t n_frames) {
+    if (d <= 0 || h <= 0 || w <= 0 || n_frames <= 0) return 0;
+    return sizeof(int32_t) * ((size_t)n_frames * d * h * w + (size_t)n_frames * d * mvx_cdiv(h, OTH) * mvx_cdiv(w, OTW) + 4 + n_frames);
 }
 
-extern "C" int mvx_index_grid(const int64_t *coords, int32_t n_voxels, int32_t d, int32_t h, int32_t w,
-                              int32_t *grid, int32_t *status, void *stream) {
+extern "C" size_t mvx_index_grid_bytes(int32_t d, int32_t h, int32_t w) { return mvx_index_grid_bytes_frames(d, h, w, 1); }
+
+extern "C" int mvx_index_grid_frames(const int64_t *coords, int32_t n_voxels, int32_t d, int32_t h, int32_t w,
+                                     int32_t *grid, int32_t *status, const mvx_frames_t *frames_host, void *stream) {
     MVX_CHECK_ARG(grid && d > 0 && h > 0 && w > 0 && n_voxels >= 0);
+    FrameMap fm;
+    MVX_CHECK_ARG(mvx_build_frame_map(fm, frames_host, frames_host ? MVX_ROWS_VOXELS : MVX_ROWS_SINGLE, n_voxels, 1.0));
     hipStream_t st = (hipStream_t)stream;
-    int32_t *occ = grid + (size_t)d * h * w;             // coarse occupancy follows the site grid
-    hipError_t e = hipMemsetAsync(grid, 0xFF, sizeof(int32_t) * (size_t)d * h * w, st);   // every site = -1
+    const size_t planes = (size_t)fm.F * d;
+    int32_t *occ = grid + planes * h * w;             // coarse occupancy follows the site grid
+    hipError_t e = hipMemsetAsync(grid, 0xFF, sizeof(int32_t) * planes * h * w, st);   // every site = -1
     if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(occ, 0, sizeof(int32_t) * (size_t)d * mvx_cdiv(h, OTH) * mvx_cdiv(w, OTW), st);
+    e = hipMemsetAsync(occ, 0, sizeof(int32_t) * planes * mvx_cdiv(h, OTH) * mvx_cdiv(w, OTW), st);
     if (e != hipSuccess) return (int)e;
     if (n_voxels == 0) return MVX_OK;
     MVX_CHECK_ARG(coords);
     hipLaunchKernelGGL(index_grid_fill, dim3(mvx_cdiv(n_voxels, 256)), dim3(256), 0, st, (const long long *)coords,
-                       n_voxels, d, h, w, grid, occ, status);
+                       n_voxels, d, h, w, grid, occ, status, fm);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
+}
+
+extern "C" int mvx_index_grid(const int64_t *coords, int32_t n_voxels, int32_t d, int32_t h, int32_t w,
+                              int32_t *grid, int32_t *status, void *stream) {
+    return mvx_index_grid_frames(coords, n_voxels, d, h, w, grid, status, nullptr, stream);
 }
 
 static int sgeom_ok(int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cout, int32_t sd, int32_t pd) {
@@ -181,46 +197,64 @@ static int sgeom_ok(int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cou
     return dout == (din + 2 * pd - 3) / sd + 1;
 }
 
-extern "C" int mvx_sparse_conv_output(const float *p, const int32_t *index_grid, const float *bias, float *out,
-                                      double *stats, int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cout,
-                                      int32_t stride_d, int32_t pad_d, int32_t flags, void *stream) {
+extern "C" int mvx_sparse_conv_output_frames(const float *p, const int32_t *index_grid, const float *bias, float *out,
+                                             double *stats, int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cout,
+                                             int32_t stride_d, int32_t pad_d, int32_t flags, int32_t n_frames, void *stream) {
     const int relu = flags & MVX_FLAG_RELU;
     MVX_CHECK_ARG(index_grid && out && sgeom_ok(din, dout, h, w, cout, stride_d, pad_d));
     MVX_CHECK_ARG(cout / 4 * OTW <= 256 && 256 % (cout / 4) == 0);
+    MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
     hipStream_t st = (hipStream_t)stream;
     if (stats && !(flags & MVX_FLAG_PREZEROED)) {
-        hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * MVX_REP * 2 * cout, st);
+        hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * MVX_REP * 2 * cout * n_frames, st);
         if (e != hipSuccess) return (int)e;
     }
     SGeom g{din, dout, h, w, cout, stride_d, pad_d};
-    // the buffer of mvx_index_grid: site grid, coarse occupancy, then a scratch counter
-    int32_t *occ = (int32_t *)index_grid + (size_t)din * h * w;
-    int32_t *active = occ + (size_t)din * mvx_cdiv(h, OTH) * mvx_cdiv(w, OTW);
+    // the buffer of mvx_index_grid: site grid, coarse occupancy, then one scratch counter per frame
+    int32_t *occ = (int32_t *)index_grid + (size_t)n_frames * din * h * w;
+    int32_t *active = occ + (size_t)n_frames * din * mvx_cdiv(h, OTH) * mvx_cdiv(w, OTW);
     if (stats) {
-        hipError_t e = hipMemsetAsync(active, 0, sizeof(int32_t), st);
+        hipError_t e = hipMemsetAsync(active, 0, sizeof(int32_t) * n_frames, st);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(sparse_conv_output, dim3(mvx_cdiv(w, OTW) * mvx_cdiv(h, OTH), dout), dim3(256), 0, st, p, index_grid,
-                       (const int *)occ, bias, out, stats, g, relu, active);
+    hipLaunchKernelGGL(sparse_conv_output, dim3(mvx_cdiv(w, OTW) * mvx_cdiv(h, OTH), dout * n_frames), dim3(256), 0, st, p,
+                       index_grid, (const int *)occ, bias, out, stats, g, relu, active);
     MVX_LAUNCH_CHECK();
     if (stats) {
-        hipLaunchKernelGGL(sparse_stats_fix, dim3(mvx_cdiv(cout, 64)), dim3(64), 0, st, stats, bias, (const int *)active,
-                           (long long)dout * h * w, cout, relu);
+        hipLaunchKernelGGL(sparse_stats_fix, dim3(mvx_cdiv(cout, 64), n_frames), dim3(64), 0, st, stats, bias,
+                           (const int *)active, (long long)dout * h * w, cout, relu);
         MVX_LAUNCH_CHECK();
     }
+    return MVX_OK;
+}
+
+extern "C" int mvx_sparse_conv_output(const float *p, const int32_t *index_grid, const float *bias, float *out,
+                                      double *stats, int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cout,
+                                      int32_t stride_d, int32_t pad_d, int32_t flags, void *stream) {
+    return mvx_sparse_conv_output_frames(p, index_grid, bias, out, stats, din, dout, h, w, cout, stride_d, pad_d, flags, 1,
+                                         stream);
+}
+
+extern "C" int mvx_sparse_conv_gather_dz_frames(const float *dz, const int64_t *coords, int32_t n_voxels, float *g_rows,
+                                                int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cout,
+                                                int32_t stride_d, int32_t pad_d, const mvx_frames_t *frames_host,
+                                                void *stream) {
+    MVX_CHECK_ARG(dz && g_rows && n_voxels >= 0 && sgeom_ok(din, dout, h, w, cout, stride_d, pad_d));
+    if (n_voxels == 0) return MVX_OK;
+    MVX_CHECK_ARG(coords);
+    FrameMap fm;
+    MVX_CHECK_ARG(mvx_build_frame_map(fm, frames_host, frames_host ? MVX_ROWS_VOXELS : MVX_ROWS_SINGLE, n_voxels, 1.0));
+    SGeom g{din, dout, h, w, cout, stride_d, pad_d};
+    const long long total = (long long)n_voxels * 27 * (cout / 4);
+    hipLaunchKernelGGL(sparse_conv_gather_dz, dim3(mvx_cdiv(total, 256) > 4096 ? 4096 : mvx_cdiv(total, 256)), dim3(256),
+                       0, (hipStream_t)stream, dz, (const long long *)coords, n_voxels, g_rows, g, fm);
+    MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
 
 extern "C" int mvx_sparse_conv_gather_dz(const float *dz, const int64_t *coords, int32_t n_voxels, float *g_rows,
                                          int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cout,
                                          int32_t stride_d, int32_t pad_d, void *stream) {
-    MVX_CHECK_ARG(dz && g_rows && n_voxels >= 0 && sgeom_ok(din, dout, h, w, cout, stride_d, pad_d));
-    if (n_voxels == 0) return MVX_OK;
-    MVX_CHECK_ARG(coords);
-    SGeom g{din, dout, h, w, cout, stride_d, pad_d};
-    const long long total = (long long)n_voxels * 27 * (cout / 4);
-    hipLaunchKernelGGL(sparse_conv_gather_dz, dim3(mvx_cdiv(total, 256) > 4096 ? 4096 : mvx_cdiv(total, 256)), dim3(256),
-                       0, (hipStream_t)stream, dz, (const long long *)coords, n_voxels, g_rows, g);
-    MVX_LAUNCH_CHECK();
-    return MVX_OK;
+    return mvx_sparse_conv_gather_dz_frames(dz, coords, n_voxels, g_rows, din, dout, h, w, cout, stride_d, pad_d, nullptr,
+                                            stream);
 }

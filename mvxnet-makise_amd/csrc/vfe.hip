@@ -33,10 +33,11 @@ struct Rows {            // row addressing of one voxel
 
 __global__ __launch_bounds__(256) void vfe_bn_max_concat(const float *__restrict__ y, const float *__restrict__ mi,
                                                          float *__restrict__ out, int *__restrict__ argmax,
-                                                         int V, int C, Rows R) {
+                                                         int V, int C, Rows R, FrameMap fm) {
     const long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (e >= (long long)V * C) return;
     const int v = (int)(e / C), c = (int)(e % C);
+    mi += (size_t)fm_frame_of(fm, v) * 2 * C;             // per-frame BatchNorm (frames = voxel segments)
     const float m = mi[c], iv = mi[C + c];
     const int n = R.count(v) + (R.has_pad(v) ? 1 : 0);
     float best = -INFINITY;
@@ -70,10 +71,12 @@ __global__ __launch_bounds__(256) void vfe_max_concat_bwd(const float *__restric
 }
 
 __global__ __launch_bounds__(256) void bn_segmax(const float *__restrict__ y, const float *__restrict__ mi,
-                                                 float *__restrict__ out, int *__restrict__ argmax, int V, int C, Rows R) {
+                                                 float *__restrict__ out, int *__restrict__ argmax, int V, int C, Rows R,
+                                                 FrameMap fm) {
     const long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (e >= (long long)V * C) return;
     const int v = (int)(e / C), c = (int)(e % C);
+    mi += (size_t)fm_frame_of(fm, v) * 2 * C;
     const float m = mi[c], iv = mi[C + c];
     const int n = R.count(v) + (R.has_pad(v) ? 1 : 0);
     float best = -INFINITY;
@@ -102,8 +105,19 @@ __global__ __launch_bounds__(256) void segmax_bwd(const float *__restrict__ dfea
 // vcnt[v] = number of real rows, row_w[n_real + v] = T - vcnt[v] (weight of the padded row),
 // row_w[real rows] = 1.
 __global__ void voxel_row_offsets(const int *__restrict__ row_map, int V, int T, int n_real, int *__restrict__ voff,
-                                  int *__restrict__ vcnt, float *__restrict__ row_w) {
+                                  int *__restrict__ vcnt, float *__restrict__ row_w, float *__restrict__ fusion_row_w,
+                                  FrameMap fm) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    // fusion layout (optional): real rows weigh 1, the shared padded row of frame f stands for all padded rows of f
+    if (fusion_row_w) {
+        for (int j = v; j < n_real; j += gridDim.x * blockDim.x) fusion_row_w[j] = 1.f;
+        if (v < fm.F) {
+            int nreal_f = 0;                          // real rows of frame f = extent of its real-row segment
+            for (int sg = 0; sg < fm.nseg; ++sg)
+                if (fm.seg_frame[sg] == v && fm.bound[sg + 1] <= n_real) nreal_f += fm.bound[sg + 1] - fm.bound[sg];
+            fusion_row_w[n_real + v] = (float)(fm.count[v] - (double)nreal_f);
+        }
+    }
     if (v >= V) return;
     int first = -1, n = 0;
     for (int t = 0; t < T; ++t) {
@@ -118,21 +132,23 @@ __global__ void voxel_row_offsets(const int *__restrict__ row_map, int V, int T,
 // VFE-1 input in compact form: real row j = [voxels[r][0:7], imfeat[j][0:F]], padded row of voxel v =
 // [0 x 7, imfeat[n_real][0:F]] (imfeat's last row is the fusion output of the shared padded row).
 __global__ void vfe_compact_input(const float *__restrict__ vox, int vc, const int *__restrict__ rows_sel,
-                                  const float *__restrict__ imfeat, int F, int n_real, int V, float *__restrict__ out) {
+                                  const float *__restrict__ imfeat, int F, int n_real, int V, float *__restrict__ out,
+                                  FrameMap fm) {
     const int W = 7 + F;
     const long long total = (long long)(n_real + V) * W;
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int j = (int)(e / W), c = (int)(e % W);
         float val;
         if (j < n_real) val = c < 7 ? vox[(size_t)rows_sel[j] * vc + c] : imfeat[(size_t)j * F + c - 7];
-        else val = c < 7 ? 0.f : imfeat[(size_t)n_real * F + c - 7];
+        else val = c < 7 ? 0.f : imfeat[(size_t)(n_real + fm_frame_of(fm, j - n_real)) * F + c - 7];   // its frame's shared padded row
         out[e] = val;
     }
 }
 
 // gradient wrt imfeat: real rows copy columns 7.., the shared padded row sums them over the voxels
 __global__ __launch_bounds__(256) void vfe_compact_input_bwd(const float *__restrict__ g, int F, int n_real, int V,
-                                                             float *__restrict__ dimfeat, double *__restrict__ padsum) {
+                                                             float *__restrict__ dimfeat, double *__restrict__ padsum,
+                                                             FrameMap fm) {
     const int W = 7 + F;
     const long long total = (long long)n_real * F;
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
@@ -143,22 +159,29 @@ __global__ __launch_bounds__(256) void vfe_compact_input_bwd(const float *__rest
     __shared__ float red[256];
     const int rpi = 256 / F;
     const int ct = threadIdx.x % F, rt = threadIdx.x / F;
-    float s = 0.f;
-    if (rt < rpi)
-        for (long long v = blockIdx.x * (long long)rpi + rt; v < V; v += (long long)gridDim.x * rpi)
-            s += g[(size_t)(n_real + v) * W + 7 + ct];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    if (rt == 0) {
-        double t = 0.0;
-        for (int k = 0; k < rpi; ++k) t += (double)red[k * F + ct];
-        atomicAdd(padsum + ct, t);
+    // one pass per frame (voxel segment): the padded rows of frame f feed the shared padded row of f
+    for (int sg = 0; sg < fm.nseg; ++sg) {
+        const long long lo = fm.F == 1 ? 0 : fm.bound[sg], hi = fm.F == 1 ? V : fm.bound[sg + 1];
+        const int f = fm.F == 1 ? 0 : (int)fm.seg_frame[sg];
+        float s = 0.f;
+        if (rt < rpi)
+            for (long long v = lo + blockIdx.x * (long long)rpi + rt; v < hi; v += (long long)gridDim.x * rpi)
+                s += g[(size_t)(n_real + v) * W + 7 + ct];
+        __syncthreads();
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (rt == 0) {
+            double t = 0.0;
+            for (int k = 0; k < rpi; ++k) t += (double)red[k * F + ct];
+            atomicAdd(padsum + (size_t)f * F + ct, t);
+        }
     }
 }
 
-__global__ void vfe_compact_pad_finish(const double *__restrict__ padsum, float *__restrict__ dimfeat, int n_real, int F) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < F) dimfeat[(size_t)n_real * F + c] = (float)padsum[c];
+__global__ void vfe_compact_pad_finish(const double *__restrict__ padsum, float *__restrict__ dimfeat, int n_real, int F,
+                                       int n_frames) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < F * n_frames) dimfeat[(size_t)n_real * F + e] = (float)padsum[e];
 }
 
 }  // namespace
@@ -168,15 +191,24 @@ __global__ void vfe_compact_pad_finish(const double *__restrict__ padsum, float 
 
 #define VFE_ROWS Rows{voff, vcnt, t, n_real}
 #define VFE_ROWS_OK ((voff == nullptr) == (vcnt == nullptr))
+#define VFE_FRAMES(fm) FrameMap fm; MVX_CHECK_ARG(mvx_build_frame_map(fm, frames_host, frames_host ? MVX_ROWS_VOXELS : MVX_ROWS_SINGLE, n_voxels, 1.0))
+
+extern "C" int mvx_vfe_bn_max_concat_frames(const float *y, const float *mean_inv, float *out, int32_t *argmax,
+                                            int32_t n_voxels, int32_t t, int32_t channels, const int32_t *voff,
+                                            const int32_t *vcnt, int32_t n_real, const mvx_frames_t *frames_host,
+                                            void *stream) {
+    MVX_CHECK_ARG(y && mean_inv && out && argmax && VFE_ARGS_OK && VFE_ROWS_OK);
+    if (n_voxels == 0) return MVX_OK;
+    VFE_FRAMES(fm);
+    hipLaunchKernelGGL(vfe_bn_max_concat, VFE_GRID, y, mean_inv, out, argmax, n_voxels, channels, VFE_ROWS, fm);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
 
 extern "C" int mvx_vfe_bn_max_concat(const float *y, const float *mean_inv, float *out, int32_t *argmax,
                                      int32_t n_voxels, int32_t t, int32_t channels, const int32_t *voff,
                                      const int32_t *vcnt, int32_t n_real, void *stream) {
-    MVX_CHECK_ARG(y && mean_inv && out && argmax && VFE_ARGS_OK && VFE_ROWS_OK);
-    if (n_voxels == 0) return MVX_OK;
-    hipLaunchKernelGGL(vfe_bn_max_concat, VFE_GRID, y, mean_inv, out, argmax, n_voxels, channels, VFE_ROWS);
-    MVX_LAUNCH_CHECK();
-    return MVX_OK;
+    return mvx_vfe_bn_max_concat_frames(y, mean_inv, out, argmax, n_voxels, t, channels, voff, vcnt, n_real, nullptr, stream);
 }
 
 extern "C" int mvx_vfe_max_concat_backward(const float *grad_out, const int32_t *argmax, float *dyhat,
@@ -189,14 +221,22 @@ extern "C" int mvx_vfe_max_concat_backward(const float *grad_out, const int32_t 
     return MVX_OK;
 }
 
+extern "C" int mvx_bn_segment_max_frames(const float *y, const float *mean_inv, float *out, int32_t *argmax,
+                                         int32_t n_voxels, int32_t t, int32_t channels, const int32_t *voff,
+                                         const int32_t *vcnt, int32_t n_real, const mvx_frames_t *frames_host,
+                                         void *stream) {
+    MVX_CHECK_ARG(y && mean_inv && out && argmax && VFE_ARGS_OK && VFE_ROWS_OK);
+    if (n_voxels == 0) return MVX_OK;
+    VFE_FRAMES(fm);
+    hipLaunchKernelGGL(bn_segmax, VFE_GRID, y, mean_inv, out, argmax, n_voxels, channels, VFE_ROWS, fm);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
 extern "C" int mvx_bn_segment_max(const float *y, const float *mean_inv, float *out, int32_t *argmax,
                                   int32_t n_voxels, int32_t t, int32_t channels, const int32_t *voff,
                                   const int32_t *vcnt, int32_t n_real, void *stream) {
-    MVX_CHECK_ARG(y && mean_inv && out && argmax && VFE_ARGS_OK && VFE_ROWS_OK);
-    if (n_voxels == 0) return MVX_OK;
-    hipLaunchKernelGGL(bn_segmax, VFE_GRID, y, mean_inv, out, argmax, n_voxels, channels, VFE_ROWS);
-    MVX_LAUNCH_CHECK();
-    return MVX_OK;
+    return mvx_bn_segment_max_frames(y, mean_inv, out, argmax, n_voxels, t, channels, voff, vcnt, n_real, nullptr, stream);
 }
 
 extern "C" int mvx_segment_max_backward(const float *dfeat, const int32_t *argmax, float *dyhat, int32_t n_voxels,
@@ -209,12 +249,38 @@ extern "C" int mvx_segment_max_backward(const float *dfeat, const int32_t *argma
     return MVX_OK;
 }
 
-extern "C" int mvx_voxel_row_offsets(const int32_t *row_map, int32_t n_voxels, int32_t t, int32_t n_real,
-                                     int32_t *voff, int32_t *vcnt, float *row_w, void *stream) {
+extern "C" int mvx_voxel_row_offsets_frames(const int32_t *row_map, int32_t n_voxels, int32_t t, int32_t n_real,
+                                            int32_t *voff, int32_t *vcnt, float *row_w, float *fusion_row_w,
+                                            const mvx_frames_t *frames_host, void *stream) {
     MVX_CHECK_ARG(row_map && voff && vcnt && row_w && n_voxels >= 0 && t > 0 && n_real >= 0);
     if (n_voxels == 0) return MVX_OK;
+    FrameMap fm;
+    // the FUSION layout's segment table carries the real-row extents the shared-row weights need
+    MVX_CHECK_ARG(mvx_build_frame_map(fm, frames_host, frames_host ? MVX_ROWS_FUSION : MVX_ROWS_SINGLE,
+                                      frames_host ? (long long)n_real + frames_host->n_frames : (long long)n_real + 1,
+                                      (double)n_voxels * t));
+    MVX_CHECK_ARG(!fusion_row_w || frames_host);
     hipLaunchKernelGGL(voxel_row_offsets, dim3(mvx_cdiv(n_voxels, 256)), dim3(256), 0, (hipStream_t)stream, row_map,
-                       n_voxels, t, n_real, voff, vcnt, row_w);
+                       n_voxels, t, n_real, voff, vcnt, row_w, fusion_row_w, fm);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+extern "C" int mvx_voxel_row_offsets(const int32_t *row_map, int32_t n_voxels, int32_t t, int32_t n_real,
+                                     int32_t *voff, int32_t *vcnt, float *row_w, void *stream) {
+    return mvx_voxel_row_offsets_frames(row_map, n_voxels, t, n_real, voff, vcnt, row_w, nullptr, nullptr, stream);
+}
+
+extern "C" int mvx_vfe_compact_input_frames(const float *voxels, int32_t vox_channels, const int32_t *rows_sel,
+                                            const float *imfeat, int32_t feat_channels, int32_t n_real, int32_t n_voxels,
+                                            float *out, const mvx_frames_t *frames_host, void *stream) {
+    MVX_CHECK_ARG(voxels && rows_sel && imfeat && out && vox_channels >= 7 && feat_channels > 0);
+    MVX_CHECK_ARG(n_real >= 0 && n_voxels >= 0);
+    const long long total = (long long)(n_real + n_voxels) * (7 + feat_channels);
+    if (total == 0) return MVX_OK;
+    VFE_FRAMES(fm);
+    hipLaunchKernelGGL(vfe_compact_input, dim3(mvx_cdiv(total, 256) > 2048 ? 2048 : mvx_cdiv(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, voxels, vox_channels, rows_sel, imfeat, feat_channels, n_real, n_voxels, out, fm);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -222,28 +288,29 @@ extern "C" int mvx_voxel_row_offsets(const int32_t *row_map, int32_t n_voxels, i
 extern "C" int mvx_vfe_compact_input(const float *voxels, int32_t vox_channels, const int32_t *rows_sel,
                                      const float *imfeat, int32_t feat_channels, int32_t n_real, int32_t n_voxels,
                                      float *out, void *stream) {
-    MVX_CHECK_ARG(voxels && rows_sel && imfeat && out && vox_channels >= 7 && feat_channels > 0);
+    return mvx_vfe_compact_input_frames(voxels, vox_channels, rows_sel, imfeat, feat_channels, n_real, n_voxels, out, nullptr,
+                                        stream);
+}
+
+extern "C" int mvx_vfe_compact_input_backward_frames(const float *grad_out, int32_t feat_channels, int32_t n_real,
+                                                     int32_t n_voxels, float *dimfeat, double *scratch,
+                                                     const mvx_frames_t *frames_host, void *stream) {
+    MVX_CHECK_ARG(grad_out && dimfeat && scratch && feat_channels > 0 && feat_channels <= 256);
     MVX_CHECK_ARG(n_real >= 0 && n_voxels >= 0);
-    const long long total = (long long)(n_real + n_voxels) * (7 + feat_channels);
-    if (total == 0) return MVX_OK;
-    hipLaunchKernelGGL(vfe_compact_input, dim3(mvx_cdiv(total, 256) > 2048 ? 2048 : mvx_cdiv(total, 256)), dim3(256), 0,
-                       (hipStream_t)stream, voxels, vox_channels, rows_sel, imfeat, feat_channels, n_real, n_voxels, out);
+    VFE_FRAMES(fm);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * feat_channels * fm.F, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(vfe_compact_input_bwd, dim3(256), dim3(256), 0, st, grad_out, feat_channels, n_real, n_voxels,
+                       dimfeat, scratch, fm);
+    MVX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(vfe_compact_pad_finish, dim3(mvx_cdiv(feat_channels * fm.F, 64)), dim3(64), 0, st,
+                       (const double *)scratch, dimfeat, n_real, feat_channels, fm.F);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
 
 extern "C" int mvx_vfe_compact_input_backward(const float *grad_out, int32_t feat_channels, int32_t n_real,
                                               int32_t n_voxels, float *dimfeat, double *scratch, void *stream) {
-    MVX_CHECK_ARG(grad_out && dimfeat && scratch && feat_channels > 0 && feat_channels <= 256);
-    MVX_CHECK_ARG(n_real >= 0 && n_voxels >= 0);
-    hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * feat_channels, st);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(vfe_compact_input_bwd, dim3(256), dim3(256), 0, st, grad_out, feat_channels, n_real, n_voxels,
-                       dimfeat, scratch);
-    MVX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(vfe_compact_pad_finish, dim3(mvx_cdiv(feat_channels, 64)), dim3(64), 0, st,
-                       (const double *)scratch, dimfeat, n_real, feat_channels);
-    MVX_LAUNCH_CHECK();
-    return MVX_OK;
+    return mvx_vfe_compact_input_backward_frames(grad_out, feat_channels, n_real, n_voxels, dimfeat, scratch, nullptr, stream);
 }

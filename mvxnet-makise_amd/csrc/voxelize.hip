@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void vox_gather(const float *__restrict__ pcd,
 
 }  // namespace
 
-extern "C" int mvx_abi_version(void) { return 1; }
+extern "C" int mvx_abi_version(void) { return 2; }
 
 extern "C" size_t mvx_voxelize_workspace_bytes(int32_t n_frames, int32_t cap_points) {
     if (n_frames <= 0 || cap_points <= 0) return 0;

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MVX_HIP_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'libmvx_hip.so'))
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _p = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -97,6 +97,36 @@ PROTOTYPES = {
     'mvx_conv3d_dgrad_tiles': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
     'mvx_bn_relu_backward_tiles_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32]),
     'mvx_bn_relu_backward_tiles': (_i32, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _sz, _p]),
+    # frame-set forms (one launch for all frames of a step; include/mvx_hip.h "Frame sets")
+    'mvx_linear_forward_bn_frames': (_i32, [_p, _i32, _p, _i32, _i32, _p, _p, _i32, _p, _p, _i64, _i32, _i32, _i32, _p, _f64, _p, _p, _i32, _p]),
+    'mvx_bn_finalize_frames': (_i32, [_p, _f64, _f64, _p, _i32, _i32, _p]),
+    'mvx_bn_apply_frames': (_i32, [_p, _p, _p, _i64, _i32, _p, _i32, _p]),
+    'mvx_bn_backward_scratch_bytes_frames': (_sz, [_i32, _i32]),
+    'mvx_bn_relu_backward_frames': (_i32, [_p, _p, _p, _f64, _p, _p, _p, _p, _i64, _i32, _i32, _p, _i32, _p]),
+    'mvx_vfe_bn_max_concat_frames': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p, _p]),
+    'mvx_bn_segment_max_frames': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p, _p]),
+    'mvx_voxel_row_offsets_frames': (_i32, [_p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p]),
+    'mvx_vfe_compact_input_frames': (_i32, [_p, _i32, _p, _p, _i32, _i32, _i32, _p, _p, _p]),
+    'mvx_vfe_compact_input_backward_frames': (_i32, [_p, _i32, _i32, _i32, _p, _p, _p, _p]),
+    'mvx_row_compact_map_frames': (_i32, [_p, _i32, _i64, _p, _p, _p, _p, _sz, _p, _p, _p]),
+    'mvx_feature_sample_rows_frames': (_i32, [_p, _i32, _p, _i32, _p, _p, _i32, _i32, _f32, _f32, _f32, _p, _p, _p, _p]),
+    'mvx_index_grid_bytes_frames': (_sz, [_i32, _i32, _i32, _i32]),
+    'mvx_index_grid_frames': (_i32, [_p, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
+    'mvx_sparse_conv_output_frames': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    'mvx_sparse_conv_gather_dz_frames': (_i32, [_p, _p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
+    'mvx_activity_dilate_frames': (_i32, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p]),
+    'mvx_tile_dilate_flags_frames': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i32, _p]),
+    'mvx_conv3d_background_frames': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i32, _p]),
+    'mvx_bn_background_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p]),
+    'mvx_conv3d_forward_bg_frames': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p,
+                                            _i32, _p, _p, _f64, _f64, _p, _p, _i32, _p]),
+    'mvx_conv3d_dgrad_tiles_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p]),
+    'mvx_conv3d_input_grad_sums_frames': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i32, _p]),
+    'mvx_conv3d_wgrad_bg_workspace_bytes_frames': (_sz, [_i32, _i32, _i32, _i32, _i32, _i32]),
+    'mvx_conv3d_wgrad_bg_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _i32, _p]),
+    'mvx_bn_relu_backward_tiles_workspace_bytes_frames': (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    'mvx_bn_relu_backward_tiles_frames': (_i32, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _sz, _i32, _p]),
+    'mvx_cl_to_bev_frames': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_bbox_pairwise': (_i32, [_p, _i32, _p, _i32, _i32, _p, _p]),
     'mvx_classify_anchors_workspace_bytes': (_sz, [_i32, _i32, _i32]),
     'mvx_classify_anchors': (_i32, [_p, _i32, _p, _i32, _i32, _i32, _p, _p, _f32, _f32, _i32, _p, _p, _p, _i64, _p, _p, _p, _sz, _p]),
@@ -126,6 +156,32 @@ lib = _load()
 
 class MvxHipError(RuntimeError):
     pass
+
+
+MAX_FRAMES = 16       # MVX_MAX_FRAMES
+ROWS_SINGLE, ROWS_FUSION, ROWS_VFE, ROWS_VOXELS, ROWS_GRID, ROWS_REAL = 0, 1, 2, 3, 4, 5      # MVX_ROWS_*
+
+
+class FramesDesc(ctypes.Structure):
+    """mvx_frames_t of include/mvx_hip.h: host-side descriptor of the frames that share a launch."""
+    _fields_ = [('n_frames', ctypes.c_int32), ('t', ctypes.c_int32),
+                ('real_off', ctypes.c_int32 * (MAX_FRAMES + 1)), ('vox_off', ctypes.c_int32 * (MAX_FRAMES + 1))]
+
+    @classmethod
+    def make(cls, vox_off, real_off, t):
+        d = cls()
+        d.n_frames = len(vox_off) - 1
+        if not 1 <= d.n_frames <= MAX_FRAMES:
+            raise MvxHipError('a frame set holds 1..%d frames' % MAX_FRAMES)
+        d.t = int(t)
+        for i, v in enumerate(vox_off):
+            d.vox_off[i] = int(v)
+        for i, v in enumerate(real_off):
+            d.real_off[i] = int(v)
+        return d
+
+    def ref(self):
+        return ctypes.byref(self)
 
 
 def check(status, what):

@@ -103,13 +103,14 @@ def _arena_key(device):
     return (device.index, X.raw_stream(device.index))
 
 
-def arena_begin(device):
-    """Start a frame on the current stream: clear its accumulator arena (created on first use)."""
+def arena_begin(device, doubles=1 << 19):
+    """Start a frame (or a frame set) on the current stream: clear its accumulator arena (created on first use; grown
+    when a larger one is asked for)."""
     global _ARENA_ON
     key = _arena_key(device)
-    if key not in _ARENAS:
+    if key not in _ARENAS or _ARENAS[key].buf.numel() < doubles:
         with torch.cuda.device(device):
-            _ARENAS[key] = ZeroArena(device)
+            _ARENAS[key] = ZeroArena(device, doubles)
     _ARENAS[key].begin()
     _ARENA_ON = True
 

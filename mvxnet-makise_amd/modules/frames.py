@@ -1,0 +1,432 @@
+"""Frame sets: all frames of a step through ONE launch per layer.
+
+The reference is strictly batch-1 (config.yml:18; modules/voxelnet/VoxelNet.py:19; MVXNet.py:23-24), so a batch of
+B frames means B independent forwards with per-frame BatchNorm statistics and summed parameter gradients
+(SURVEY.md 8e).  ``modules/tape.py`` runs them one after the other (about 170 launches per frame); this module runs the
+same chain -- MVXNet.middle on compact rows: fusion sampling + fusion MLP (imhead/Pipe.py:23-104), the concat of
+MVXNet.py:26, SVFE + FCN + max (voxelnet/Pipe.py:5-29, VoxelNet.py:27-33), reindex + CML (VoxelNet.py:16-36,
+voxelnet/Pipe.py:31-43) -- ONCE for the whole frame set through the ``*_frames`` entry points of the C ABI: row
+matrices hold the frames back to back, grids stack them along the depth axis, every per-frame quantity carries a
+leading frame dimension.  Same kernels, same arithmetic per frame; parameter gradients are summed over the frames by
+the reductions themselves.
+
+Weight-gradient kernels go to the side stream (modules/_hip.py), everything else stays on the caller's stream.
+"""
+import ctypes
+
+import torch
+
+import modules.config as cfg
+from modules import _hip
+from modules import Extension as X
+from modules.layers.Blocks import conv_background_on, conv_split_math
+
+R = _hip.STATS_REPLICAS
+
+
+class FrameSet:
+    """Voxels of F frames back to back + the compact-row bookkeeping every layer needs.
+
+    voxels f32 (Vt, T, 9), coords i64 (Vt, 4); vox_off / real_off: host lists (F+1)."""
+
+    def __init__(self, voxels, coords, vox_off, T):
+        self.voxels, self.coords = voxels, coords
+        self.vox_off = [int(v) for v in vox_off]
+        self.F, self.T = len(vox_off) - 1, int(T)
+        self.Vt = self.vox_off[-1]
+        self.real_off = None
+        self.desc = None
+
+    # -- step 1 (enqueue only): dense-row -> compact-row map of all frames, real-row offsets stay on the device
+    def enqueue_map(self):
+        dev = self.voxels.device
+        rows = self.Vt * self.T
+        vox2d = self.voxels.view(rows, self.voxels.shape[-1])
+        self.vox2d = vox2d
+        self.row_map = torch.empty((rows,), dtype=torch.int32, device=dev)
+        self.rows_sel = torch.empty((rows,), dtype=torch.int32, device=dev)
+        self.n_real_dev = torch.empty((1,), dtype=torch.int32, device=dev)
+        self.real_off_dev = torch.empty((self.F + 1,), dtype=torch.int32, device=dev)
+        d0 = X.FramesDesc.make(self.vox_off, [0] * (self.F + 1), self.T)
+        ws = _hip.workspace(X.lib.mvx_row_compact_workspace_bytes(rows), dev, 'compact')
+        X.check(X.lib.mvx_row_compact_map_frames(X.ptr(vox2d), vox2d.shape[1], rows, X.ptr(self.row_map), X.ptr(self.rows_sel),
+                                                 X.ptr(self.n_real_dev), X.ptr(ws), ws.numel(), d0.ref(),
+                                                 X.ptr(self.real_off_dev), X.stream()), 'mvx_row_compact_map_frames')
+        return self.real_off_dev
+
+    # -- step 2 (after ONE host read of real_off_dev): the descriptor and the per-voxel offsets
+    def finish_map(self, real_off):
+        dev = self.voxels.device
+        self.real_off = [int(v) for v in real_off]
+        self.Rt = self.real_off[-1]
+        self.desc = X.FramesDesc.make(self.vox_off, self.real_off, self.T)
+        self.voff = torch.empty((self.Vt,), dtype=torch.int32, device=dev)
+        self.vcnt = torch.empty((self.Vt,), dtype=torch.int32, device=dev)
+        self.row_w = torch.empty((self.Rt + self.Vt,), dtype=torch.float32, device=dev)          # MVX_ROWS_VFE layout
+        self.fusion_row_w = torch.empty((self.Rt + self.F,), dtype=torch.float32, device=dev)    # MVX_ROWS_FUSION layout
+        X.check(X.lib.mvx_voxel_row_offsets_frames(X.ptr(self.row_map), self.Vt, self.T, self.Rt, X.ptr(self.voff),
+                                                   X.ptr(self.vcnt), X.ptr(self.row_w), X.ptr(self.fusion_row_w),
+                                                   self.desc.ref(), X.stream()), 'mvx_voxel_row_offsets_frames')
+        return self
+
+
+# ---------------------------------------------------------------------------------------------------------
+# thin wrappers over the frame-set entry points (allocation + pointers only)
+# ---------------------------------------------------------------------------------------------------------
+def _stats(F, C, dev):
+    buf, fz = _hip._acc_f64((F, R, 2, C), dev)
+    return buf, fz
+
+
+def linear_bn(x, w, b, fs, kind, row_w, eps):
+    """rows -> (y = ReLU(x w^T + b), mean_inv (F,2,N)) with per-frame statistics formed inside the launch."""
+    Rr, K = x.shape
+    N = w.shape[0]
+    w2 = w.reshape(N, -1)
+    y = torch.empty((Rr, N), dtype=torch.float32, device=x.device)
+    stats, fz = _stats(fs.F, N, x.device)
+    counter = _hip._fin_slot(x.device, fz)              # arena slot when the statistics came from the (pre-zeroed) arena
+    if counter is None:
+        counter = torch.zeros((1,), dtype=torch.float64, device=x.device)
+    mi = torch.empty((fs.F, 2, N), dtype=torch.float32, device=x.device)
+    X.check(X.lib.mvx_linear_forward_bn_frames(_hip._vptr(x), _hip._ld(x), _hip._vptr(w2), _hip._ld(w2), 0, X.ptr(b),
+                                               _hip._vptr(y), _hip._ld(y), X.ptr(stats), X.ptr(row_w), Rr, K, N,
+                                               _hip.FLAG_RELU | fz, X.ptr(counter), float(eps), X.ptr(mi), fs.desc.ref(),
+                                               kind, X.stream()), 'mvx_linear_forward_bn_frames')
+    return y, mi
+
+
+def bn_apply(y, mi, fs, kind):
+    C = mi.shape[-1]
+    rows = y.numel() // C
+    out = torch.empty_like(y)
+    with _hip._timed_bytes('bn_apply', 2 * y.numel() * 4):
+        X.check(X.lib.mvx_bn_apply_frames(X.ptr(y), X.ptr(mi), X.ptr(out), rows, C, fs.desc.ref(), kind, X.stream()),
+                'mvx_bn_apply_frames')
+    return out
+
+
+def bn_relu_backward(dyhat, y, mi, fs, kind, row_w, dbias_into, dz=None):
+    """dz (may alias dyhat); the bias gradient is ADDED to ``dbias_into`` (summed over the frames)."""
+    C = mi.shape[-1]
+    rows = y.numel() // C
+    if dz is None:
+        dz = torch.empty_like(y)
+    scratch, fz = _hip._acc_f64((X.lib.mvx_bn_backward_scratch_bytes_frames(C, fs.F) // 8,), y.device)
+    with _hip._timed_bytes('bn_relu_backward', 5 * y.numel() * 4):
+        X.check(X.lib.mvx_bn_relu_backward_frames(X.ptr(dyhat), X.ptr(y), X.ptr(mi), 1.0, X.ptr(dz), X.ptr(dbias_into),
+                                                  X.ptr(scratch), X.ptr(row_w), rows, C, _hip.FLAG_ACCUMULATE | fz,
+                                                  fs.desc.ref(), kind, X.stream()), 'mvx_bn_relu_backward_frames')
+    return dz
+
+
+def _grad_of(p):
+    if p.grad is None or not p.grad.is_contiguous():
+        raise X.MvxHipError('the frame-set path adds gradients into existing contiguous .grad buffers (GradBucket)')
+    return p.grad
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the chain
+# ---------------------------------------------------------------------------------------------------------
+class _Saved:
+    pass
+
+
+def middle_forward(model, fs, fpn_levels, imsize, status_sink):
+    """Forward of MVXNet.middle for the whole frame set.  ``fpn_levels``: per frame [f0, f1, f2] (1,C,H,W).
+    Returns (mid (F,128,H,W), saved state for the backward)."""
+    head, bb = model.head, model.backbone
+    dev = fs.voxels.device
+    F, T, Rt, Vt = fs.F, fs.T, fs.Rt, fs.Vt
+    S = _Saved()
+    S.fs = fs
+    eps = cfg.eps
+    # ---- fusion sampling (imhead/Pipe.py:23-82): real rows of all frames, each from its own frame's maps
+    levels = [f[0].permute(1, 2, 0).contiguous() for lv in fpn_levels for f in head.extractor(lv)]
+    L = len(levels) // F
+    C = levels[0].shape[2]
+    ptrs = (ctypes.c_void_p * (F * L))(*[t.data_ptr() for t in levels])
+    hw = (ctypes.c_int32 * (2 * L))(*[int(v) for t in levels[:L] for v in t.shape[:2]])
+    compact = torch.empty((Rt + F, L * C), dtype=torch.float32, device=dev)
+    compact[Rt:].zero_()                                   # the shared padded rows (Pipe.py:80)
+    status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    with _hip._timed_bytes('feature_sample', Rt * L * C * 4 * 5 + Rt * 9 * 4):
+        X.check(X.lib.mvx_feature_sample_rows_frames(X.ptr(fs.vox2d), fs.vox2d.shape[1], X.ptr(fs.rows_sel), Rt, ptrs, hw, L, C,
+                                                     float(imsize[0]), float(imsize[1]), float(eps), X.ptr(compact),
+                                                     X.ptr(status), fs.desc.ref(), X.stream()), 'mvx_feature_sample_rows_frames')
+    status_sink.append(status)
+    # ---- fusion MLP (imhead/Pipe.py:84-104) on [real rows | one shared padded row per frame]
+    S.fusion = []
+    x = compact
+    for w, b in head.fusion._layers():
+        y, mi = linear_bn(x, w, b, fs, X.ROWS_FUSION, fs.fusion_row_w, eps)
+        S.fusion.append((x, w, b, y, mi))
+        x = bn_apply(y, mi, fs, X.ROWS_FUSION)
+    # ---- concat with the 7 geometric channels (MVXNet.py:26): [real rows | one padded row per voxel]
+    Fc = x.shape[1]
+    rows23 = torch.empty((Rt + Vt, 7 + Fc), dtype=torch.float32, device=dev)
+    X.check(X.lib.mvx_vfe_compact_input_frames(X.ptr(fs.vox2d), fs.vox2d.shape[1], X.ptr(fs.rows_sel), X.ptr(x), Fc, Rt, Vt,
+                                               X.ptr(rows23), fs.desc.ref(), X.stream()), 'mvx_vfe_compact_input_frames')
+    S.fc = Fc
+    # ---- SVFE (voxelnet/Pipe.py:5-29) and FCN + max (VoxelNet.py:27-33)
+    S.vfe = []
+    x = rows23
+    for vfe in (bb.svfe.vfe1, bb.svfe.vfe2):
+        w, b = vfe.fcn.fc.weight, vfe.fcn.fc.bias
+        y, mi = linear_bn(x, w, b, fs, X.ROWS_VFE, fs.row_w, eps)
+        Cn = w.shape[0]
+        out = torch.empty((Rt + Vt, 2 * Cn), dtype=torch.float32, device=dev)
+        am = torch.empty((Vt, Cn), dtype=torch.int32, device=dev)
+        X.check(X.lib.mvx_vfe_bn_max_concat_frames(X.ptr(y), X.ptr(mi), X.ptr(out), X.ptr(am), Vt, T, Cn, X.ptr(fs.voff),
+                                                   X.ptr(fs.vcnt), Rt, fs.desc.ref(), X.stream()), 'mvx_vfe_bn_max_concat_frames')
+        S.vfe.append((x, w, b, y, mi, am))
+        x = out
+    w, b = bb.fcn.fc.weight, bb.fcn.fc.bias
+    y, mi = linear_bn(x, w, b, fs, X.ROWS_VFE, fs.row_w, eps)
+    feat = torch.empty((Vt, w.shape[0]), dtype=torch.float32, device=dev)
+    am = torch.empty((Vt, w.shape[0]), dtype=torch.int32, device=dev)
+    X.check(X.lib.mvx_bn_segment_max_frames(X.ptr(y), X.ptr(mi), X.ptr(feat), X.ptr(am), Vt, T, w.shape[0], X.ptr(fs.voff),
+                                            X.ptr(fs.vcnt), Rt, fs.desc.ref(), X.stream()), 'mvx_bn_segment_max_frames')
+    S.head = (x, w, b, y, mi, am)
+
+    # ---- reindex + conv1 through the voxel-GEMM factorisation (VoxelNet.py:16-22, voxelnet/Pipe.py:36)
+    D0, H, W = cfg.voxelshape[2], cfg.voxelshape[0], cfg.voxelshape[1]
+    c1, c2, c3 = bb.cml.conv1, bb.cml.conv2, bb.cml.conv3
+    w1, b1 = c1.conv.weight, c1.conv.bias
+    cout, cin = w1.shape[0], w1.shape[1]
+    w_all = w1.permute(2, 3, 4, 0, 1).reshape(27 * cout, cin).contiguous()
+    P, _ = _hip.linear_forward(feat, w_all, None, relu=False, want_stats=False)
+    idx_grid = torch.empty((X.lib.mvx_index_grid_bytes_frames(D0, H, W, F) // 4,), dtype=torch.int32, device=dev)
+    st2 = torch.zeros((1,), dtype=torch.int32, device=dev)
+    X.check(X.lib.mvx_index_grid_frames(X.ptr(fs.coords), Vt, D0, H, W, X.ptr(idx_grid), X.ptr(st2), fs.desc.ref(), X.stream()),
+            'mvx_index_grid_frames')
+    status_sink.append(st2)
+    D1 = _hip.conv_out_depth(D0, c1._sd, c1._pd)
+    y1 = torch.empty((F * D1, H, W, cout), dtype=torch.float32, device=dev)
+    stats, fz = _stats(F, cout, dev)
+    with _hip._timed_bytes('sparse_conv_output', y1.numel() * 4 + F * D0 * H * W * 4):
+        X.check(X.lib.mvx_sparse_conv_output_frames(X.ptr(P), X.ptr(idx_grid), X.ptr(b1), X.ptr(y1), X.ptr(stats), D0, D1, H, W,
+                                                    cout, c1._sd, c1._pd, _hip.FLAG_RELU | fz, F, X.stream()),
+                'mvx_sparse_conv_output_frames')
+    mi1 = torch.empty((F, 2, cout), dtype=torch.float32, device=dev)
+    X.check(X.lib.mvx_bn_finalize_frames(X.ptr(stats), float(D1 * H * W), float(eps), X.ptr(mi1), cout, F, X.stream()),
+            'mvx_bn_finalize_frames')
+    x1 = bn_apply(y1, mi1, fs, X.ROWS_GRID)
+    ntl = _hip.n_tiles(H, W)
+
+    def dilate(src, is_index, din, sd, pd, border):
+        dout = _hip.conv_out_depth(din, sd, pd)
+        mask = torch.empty((F * dout, H, W), dtype=torch.uint8, device=dev)
+        hflag = torch.empty((F * dout, ntl), dtype=torch.int32, device=dev)
+        tflag = torch.empty_like(hflag)
+        X.check(X.lib.mvx_activity_dilate_frames(X.ptr(src), 1 if is_index else 0, din, dout, H, W, sd, pd, 1 if border else 0,
+                                                 X.ptr(mask), X.ptr(hflag), X.ptr(tflag), F, X.stream()), 'mvx_activity_dilate_frames')
+        return mask, hflag, tflag
+
+    def background(bg_pre, bias, mi, planes, C_):
+        c_out = torch.empty((F * planes, C_), dtype=torch.float32, device=dev)
+        y_bg = torch.empty_like(c_out)
+        X.check(X.lib.mvx_bn_background_frames(X.ptr(bg_pre), X.ptr(bias), X.ptr(mi), planes, C_, _hip.FLAG_RELU, X.ptr(y_bg),
+                                               X.ptr(c_out), F, X.stream()), 'mvx_bn_background_frames')
+        return c_out, y_bg
+
+    mask1, hflag1, tflag1 = dilate(idx_grid, True, D0, c1._sd, c1._pd, False)
+    cc1, ybg1 = background(None, b1, mi1, D1, cout)
+    S.conv1 = dict(feat=feat, w=w1, b=b1, w_all=w_all, y=y1, mi=mi1, c=cc1, ybg=ybg1, tflag=tflag1, D0=D0, D1=D1)
+
+    # ---- conv2, conv3 on the MFMA gather kernel with the background rewrite (voxelnet/Pipe.py:37-42)
+    split = conv_split_math()
+    if split or not conv_background_on():
+        raise X.MvxHipError('the frame-set path runs the exact-f32 kernels with convbackground (the default configuration)')
+    S.convs = []
+    x_in, din, c_in, mask_in, hflag_in, tflag_in = x1, D1, cc1, mask1, hflag1, tflag1
+    bflag_in = tflag1                                     # tiles on which the gradient of x_in is produced / consumed
+    for li, m in enumerate((c2, c3)):
+        w, b = m.conv.weight, m.conv.bias
+        co, ci = w.shape[0], w.shape[1]
+        sd, pd = m._sd, m._pd
+        dout = _hip.conv_out_depth(din, sd, pd)
+        wpk = m._packer(False, False)
+        bg_pre = torch.empty((F * dout, co), dtype=torch.float32, device=dev)
+        X.check(X.lib.mvx_conv3d_background_frames(X.ptr(w), X.ptr(c_in), din, dout, ci, co, sd, pd, X.ptr(bg_pre), F, X.stream()),
+                'mvx_conv3d_background_frames')
+        mask_o, hflag_o, tflag_o = dilate(mask_in, False, din, sd, pd, True)
+        y = torch.empty((F * dout, H, W, co), dtype=torch.float32, device=dev)
+        stats, fz = _stats(F, co, dev)
+        fin = _hip._fin_slot(dev, fz)
+        if fin is None:
+            fin = torch.zeros((1,), dtype=torch.float64, device=dev)
+        mi = torch.empty((F, 2, co), dtype=torch.float32, device=dev)
+        counter = None
+        if _hip.KERNEL_TIMERS is not None:
+            if _hip.EXEC_STAGES is None:
+                _hip.EXEC_STAGES = torch.zeros((1,), dtype=torch.int64, device=dev)
+            counter = _hip.EXEC_STAGES
+        with _hip._Timed('conv3d_gather_bg', F * _hip.conv_flops(dout, din, H, W, ci, co, sd, pd) if _hip.KERNEL_TIMERS is not None else 0):
+            X.check(X.lib.mvx_conv3d_forward_bg_frames(X.ptr(x_in), X.ptr(wpk), X.ptr(b), X.ptr(y), X.ptr(stats), din, dout, H, W,
+                                                       ci, co, sd, pd, _hip.FLAG_RELU | fz, X.ptr(hflag_in), X.ptr(mask_o),
+                                                       X.ptr(bg_pre), 1, X.ptr(counter), X.ptr(fin), float(dout * H * W),
+                                                       float(eps), X.ptr(mi), X.ptr(_hip._work_counter(dev)), F, X.stream()),
+                    'mvx_conv3d_forward_bg_frames')
+        x_out = bn_apply(y, mi, fs, X.ROWS_GRID)
+        rec = dict(x=x_in, w=w, b=b, y=y, mi=mi, din=din, dout=dout, sd=sd, pd=pd, m=m, c_in=c_in, hflag_in=hflag_in,
+                   bflag_in=bflag_in)
+        if li == 0:
+            # the background of this layer's output and the tiles its own restricted backward touches
+            c_o, ybg_o = background(bg_pre, b, mi, dout, co)
+            bflag_o = torch.empty((F * dout, ntl), dtype=torch.int32, device=dev)
+            X.check(X.lib.mvx_tile_dilate_flags_frames(X.ptr(tflag_in), X.ptr(tflag_o), din, dout, H, W, sd, pd, X.ptr(bflag_o), F,
+                                                       X.stream()), 'mvx_tile_dilate_flags_frames')
+            rec.update(c_out=c_o, ybg_out=ybg_o, bflag_out=bflag_o)
+            c_in, bflag_in = c_o, bflag_o
+        S.convs.append(rec)
+        x_in, din, mask_in, hflag_in, tflag_in = x_out, dout, mask_o, hflag_o, tflag_o
+    D3 = din
+    mid = torch.empty((F, x_in.shape[-1] * D3, H, W), dtype=torch.float32, device=dev)
+    with _hip._timed_bytes('cl_bev_transpose', 2 * x_in.numel() * 4):
+        X.check(X.lib.mvx_cl_to_bev_frames(X.ptr(x_in), X.ptr(mid), D3, H, W, x_in.shape[-1], 0, F, X.stream()), 'mvx_cl_to_bev_frames')
+    S.D3, S.H, S.W, S.C3 = D3, H, W, x_in.shape[-1]
+    return mid, S
+
+
+def _wgrad_bg(rec, dz, tap_sums, F, H, W):
+    x, w = rec['x'], rec['w']
+    co, ci = w.shape[0], w.shape[1]
+    dw = _grad_of(w)
+    nbytes = X.lib.mvx_conv3d_wgrad_bg_workspace_bytes_frames(rec['dout'], H, W, ci, co, F)
+    with _hip._SideStream(x, dz, tap_sums, rec['c_in'], rec['hflag_in']):
+        ws = _hip.workspace(nbytes, x.device, 'wgrad_bg_side')
+        with _hip._Timed('conv3d_wgrad_bg', 0):
+            X.check(X.lib.mvx_conv3d_wgrad_bg_frames(X.ptr(x), X.ptr(dz), X.ptr(dw), rec['din'], rec['dout'], H, W, ci, co,
+                                                     rec['sd'], rec['pd'], _hip.FLAG_ACCUMULATE, X.ptr(rec['hflag_in']),
+                                                     X.ptr(rec['c_in']), X.ptr(tap_sums), X.ptr(ws), ws.numel(), F, X.stream()),
+                    'mvx_conv3d_wgrad_bg_frames')
+
+
+def _linear_wgrad_side(x, dz, w):
+    """dW += dz^T x over the rows of ALL frames, on the side stream."""
+    _hip.linear_wgrad(x, dz, accumulate_into=_grad_of(w).view(w.shape[0], -1))
+
+
+def middle_backward(model, S, grad_mid):
+    """Backward of the chain for the whole frame set.  ``grad_mid`` (F or 1, 128, H, W) = dL/d(mid); parameter gradients
+    are ADDED into the existing .grad buffers (summed over the frames)."""
+    fs = S.fs
+    F, T, Rt, Vt = fs.F, fs.T, fs.Rt, fs.Vt
+    H, W, D3, C3 = S.H, S.W, S.D3, S.C3
+    dev = grad_mid.device
+    gm = grad_mid.contiguous()
+    if gm.shape[0] == 1 and F > 1:
+        g1 = torch.empty((D3, H, W, C3), dtype=torch.float32, device=dev)
+        X.check(X.lib.mvx_cl_to_bev_frames(X.ptr(g1), X.ptr(gm), D3, H, W, C3, 1, 1, X.stream()), 'mvx_cl_to_bev_frames')
+        g = g1.repeat(F, 1, 1, 1)
+    else:
+        g = torch.empty((F * D3, H, W, C3), dtype=torch.float32, device=dev)
+        X.check(X.lib.mvx_cl_to_bev_frames(X.ptr(g), X.ptr(gm), D3, H, W, C3, 1, F, X.stream()), 'mvx_cl_to_bev_frames')
+    old_async, _hip.ASYNC_WGRAD = _hip.ASYNC_WGRAD, True
+
+    def tap_sums(dz, planes, Cn, tile_flags=None, inactive=None):
+        Tt = torch.empty((planes, 9, Cn), dtype=torch.float32, device=dev)
+        ws = _hip.workspace(X.lib.mvx_plane_tap_sums_workspace_bytes(planes, Cn), dev, 'tap_sums')
+        X.check(X.lib.mvx_plane_tap_sums(X.ptr(dz), planes, H, W, Cn, X.ptr(tile_flags), X.ptr(inactive), X.ptr(Tt), X.ptr(ws),
+                                         ws.numel(), X.stream()), 'mvx_plane_tap_sums')
+        return Tt
+
+    def dgrad_tiles(rec, dz, bflag):
+        w = rec['w']
+        co, ci = w.shape[0], w.shape[1]
+        dx = torch.empty((F * rec['din'], H, W, ci), dtype=torch.float32, device=dev)
+        wpd = rec['m']._packer(True, False)
+        counter = None
+        if _hip.KERNEL_TIMERS is not None:
+            if _hip.EXEC_STAGES is None:
+                _hip.EXEC_STAGES = torch.zeros((1,), dtype=torch.int64, device=dev)
+            counter = _hip.EXEC_STAGES
+        with _hip._Timed('conv3d_gather_tiles', F * _hip.conv_flops(rec['din'], rec['dout'], H, W, co, ci, rec['sd'], rec['pd'], True)
+                         if _hip.KERNEL_TIMERS is not None else 0):
+            X.check(X.lib.mvx_conv3d_dgrad_tiles_frames(X.ptr(dz), X.ptr(wpd), X.ptr(dx), rec['din'], rec['dout'], H, W, ci, co,
+                                                        rec['sd'], rec['pd'], X.ptr(bflag), X.ptr(counter),
+                                                        X.ptr(_hip._work_counter(dev)), F, X.stream()), 'mvx_conv3d_dgrad_tiles_frames')
+        return dx
+
+    def input_grad_sums(rec, Tt):
+        w = rec['w']
+        A = torch.empty((F * rec['din'], w.shape[1]), dtype=torch.float32, device=dev)
+        X.check(X.lib.mvx_conv3d_input_grad_sums_frames(X.ptr(w), X.ptr(Tt), rec['din'], rec['dout'], w.shape[1], w.shape[0],
+                                                        rec['sd'], rec['pd'], X.ptr(A), F, X.stream()), 'mvx_conv3d_input_grad_sums_frames')
+        return A
+
+    def bn_bwd_tiles(gin, y, mi, c_bg, y_bg, A, bflag, planes, Cn, bias, want_inactive):
+        dz = torch.empty_like(y)
+        ws = _hip.workspace(X.lib.mvx_bn_relu_backward_tiles_workspace_bytes_frames(planes, H, W, Cn, F), dev, 'bn_tiles')
+        inact = torch.empty((F * planes, Cn), dtype=torch.float32, device=dev) if want_inactive else None
+        with _hip._timed_bytes('bn_relu_backward_tiles', 0):
+            X.check(X.lib.mvx_bn_relu_backward_tiles_frames(X.ptr(gin), X.ptr(y), X.ptr(mi), X.ptr(c_bg), X.ptr(y_bg), X.ptr(A),
+                                                            X.ptr(bflag), planes, H, W, Cn, X.ptr(dz), X.ptr(_grad_of(bias)),
+                                                            X.ptr(inact), _hip.FLAG_ACCUMULATE, X.ptr(ws), ws.numel(), F,
+                                                            X.stream()), 'mvx_bn_relu_backward_tiles_frames')
+        return dz, inact
+
+    try:
+        # ---- conv3: dense gradient in, restricted gradient + closed-form plane sums out
+        r3, r2 = S.convs[1], S.convs[0]
+        dz3 = bn_relu_backward(g, r3['y'], r3['mi'], fs, X.ROWS_GRID, None, _grad_of(r3['b']))
+        T3 = tap_sums(dz3, F * r3['dout'], r3['w'].shape[0])
+        _wgrad_bg(r3, dz3, T3, F, H, W)
+        g2 = dgrad_tiles(r3, dz3, r3['bflag_in'])
+        A2 = input_grad_sums(r3, T3)
+        # ---- conv2
+        dz2, inact2 = bn_bwd_tiles(g2, r2['y'], r2['mi'], r2['c_out'], r2['ybg_out'], A2, r2['bflag_out'], r2['dout'],
+                                   r2['w'].shape[0], r2['b'], True)
+        T2 = tap_sums(dz2, F * r2['dout'], r2['w'].shape[0], r2['bflag_out'], inact2)
+        _wgrad_bg(r2, dz2, T2, F, H, W)
+        g1 = dgrad_tiles(r2, dz2, r2['bflag_in'])
+        A1 = input_grad_sums(r2, T2)
+        # ---- conv1 (voxel-GEMM factorisation): gradient only next to the voxels
+        c1 = S.conv1
+        w1 = c1['w']
+        cout, cin = w1.shape[0], w1.shape[1]
+        dz1, _ = bn_bwd_tiles(g1, c1['y'], c1['mi'], c1['c'], c1['ybg'], A1, c1['tflag'], c1['D1'], cout, c1['b'], False)
+        G = torch.empty((Vt, 27 * cout), dtype=torch.float32, device=dev)
+        cm = model.backbone.cml.conv1
+        X.check(X.lib.mvx_sparse_conv_gather_dz_frames(X.ptr(dz1), X.ptr(fs.coords), Vt, X.ptr(G), c1['D0'], c1['D1'], H, W, cout,
+                                                       cm._sd, cm._pd, fs.desc.ref(), X.stream()), 'mvx_sparse_conv_gather_dz_frames')
+        dw_all = _hip.linear_wgrad(c1['feat'], G)                              # (27*cout, cin), main stream (small)
+        with _hip._SideStream(dw_all):
+            _grad_of(w1).add_(dw_all.reshape(3, 3, 3, cout, cin).permute(3, 4, 0, 1, 2))
+        dfeat, _ = _hip.linear_forward(G, c1['w_all'], None, relu=False, want_stats=False, w_transposed=True)
+        # ---- FCN + max
+        x, w, b, y, mi, am = S.head
+        Cn = w.shape[0]
+        dyh = torch.empty((Rt + Vt, Cn), dtype=torch.float32, device=dev)
+        X.check(X.lib.mvx_segment_max_backward(X.ptr(dfeat), X.ptr(am), X.ptr(dyh), Vt, T, Cn, X.ptr(fs.voff), X.ptr(fs.vcnt), Rt,
+                                               X.stream()), 'mvx_segment_max_backward')
+        dz = bn_relu_backward(dyh, y, mi, fs, X.ROWS_VFE, fs.row_w, _grad_of(b), dz=dyh)
+        _linear_wgrad_side(x, dz, w)
+        gx, _ = _hip.linear_forward(dz, w, None, relu=False, want_stats=False, w_transposed=True)
+        # ---- VFE 2, VFE 1
+        for x, w, b, y, mi, am in reversed(S.vfe):
+            Cn = w.shape[0]
+            dyh = torch.empty((Rt + Vt, Cn), dtype=torch.float32, device=dev)
+            X.check(X.lib.mvx_vfe_max_concat_backward(X.ptr(gx), X.ptr(am), X.ptr(dyh), Vt, T, Cn, X.ptr(fs.voff), X.ptr(fs.vcnt),
+                                                      Rt, X.stream()), 'mvx_vfe_max_concat_backward')
+            dz = bn_relu_backward(dyh, y, mi, fs, X.ROWS_VFE, fs.row_w, _grad_of(b), dz=dyh)
+            _linear_wgrad_side(x, dz, w)
+            gx, _ = _hip.linear_forward(dz, w, None, relu=False, want_stats=False, w_transposed=True)
+        # ---- concat backward: gradient of the fused image features ([real rows | shared padded row per frame])
+        Fc = S.fc
+        gim = torch.empty((Rt + F, Fc), dtype=torch.float32, device=dev)
+        scratch = torch.empty((F * Fc,), dtype=torch.float64, device=dev)
+        X.check(X.lib.mvx_vfe_compact_input_backward_frames(X.ptr(gx), Fc, Rt, Vt, X.ptr(gim), X.ptr(scratch), fs.desc.ref(),
+                                                            X.stream()), 'mvx_vfe_compact_input_backward_frames')
+        # ---- fusion MLP, last layer first; the sampled features carry no gradient
+        gx = gim
+        for i in range(len(S.fusion) - 1, -1, -1):
+            x, w, b, y, mi = S.fusion[i]
+            dz = bn_relu_backward(gx, y, mi, fs, X.ROWS_FUSION, fs.fusion_row_w, _grad_of(b))
+            _linear_wgrad_side(x, dz, w)
+            if i > 0:
+                gx, _ = _hip.linear_forward(dz, w.reshape(w.shape[0], -1), None, relu=False, want_stats=False, w_transposed=True)
+    finally:
+        _hip.ASYNC_WGRAD = old_async

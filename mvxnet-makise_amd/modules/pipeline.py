@@ -225,3 +225,64 @@ def train_step_frames(model, batch, grad_mid, imsize, ready=None, prepare_next=N
     if prepare_next is not None:
         return nvox, statuses, next_ready
     return nvox, statuses
+
+
+# ---- frame sets: every layer ONCE for all frames of the step (modules/frames.py) --------------------------------------
+BATCHED = _os.environ.get('MVX_FRAME_SETS', '1') != '0'
+
+
+def prepare_frame_set(batch, T=None):
+    """Voxelize the batch and build the frame set (voxels of all non-empty frames back to back + compact-row maps) with TWO
+    host reads: the voxel counts, then the real-row offsets.  Returns (frame set or None, frame ids in it, voxel counts of
+    every frame of the batch, status word)."""
+    from modules import frames as fr
+    T = cfg.samplenum if T is None else T
+    res = _hip.voxelize(batch.points6, batch.perms, batch.n_points, cfg.velorange[0:3], cfg.voxelsize, T, 9)
+    counts = res.n_voxels.tolist()                  # host read 1: output sizes are data dependent
+    live = [f for f, v in enumerate(counts) if v > 0]
+    if not live:
+        return None, [], counts, res.status
+    if len(live) == 1:
+        f = live[0]
+        voxels, coords = res.voxels[f, :counts[f]], res.coords[f, :counts[f]]
+    else:
+        voxels = torch.cat([res.voxels[f, :counts[f]] for f in live])
+        coords = torch.cat([res.coords[f, :counts[f]] for f in live])
+    off = [0]
+    for f in live:
+        off.append(off[-1] + counts[f])
+    fs = fr.FrameSet(voxels, coords, off, T)
+    real_off = fs.enqueue_map().tolist()            # host read 2
+    fs.finish_map(real_off)
+    return fs, live, counts, res.status
+
+
+def train_step_frame_set(model, batch, grad_mid, imsize, ready=None, prepare_next=None, keep_mid=None):
+    """Same contract as train_step_frames, executed through modules/frames.py: ONE launch per layer for all frames of the
+    batch, weight-gradient kernels on the side stream.  ``grad_mid``: (1,128,H,W) for every frame or (B,128,H,W)."""
+    from modules import frames as fr
+    if ready is None:
+        ready = prepare_frame_set(batch)
+    fs, live, counts, status = ready
+    statuses = [status]
+    dev = batch.points6.device
+    old_sink, _hip.GRAD_SINK = _hip.GRAD_SINK, True
+    try:
+        if fs is not None:
+            model.prepack()
+            _hip.arena_begin(dev, doubles=1 << 21)
+            gm = grad_mid if grad_mid.shape[0] == 1 or len(live) == batch.n_frames else grad_mid[live]
+            with torch.no_grad():
+                mid, saved = fr.middle_forward(model, fs, [batch.fpn_levels[f] for f in live], imsize, statuses)
+                fr.middle_backward(model, saved, gm)
+            if keep_mid is not None:
+                for k in range(len(live)):
+                    keep_mid.append(mid[k:k + 1])
+        next_ready = prepare_frame_set(prepare_next) if prepare_next is not None else None
+    finally:
+        _hip.GRAD_SINK = old_sink
+        _hip.arena_end()
+        _hip.join_side_stream()
+    if prepare_next is not None:
+        return counts, statuses, next_ready
+    return counts, statuses

@@ -1,0 +1,103 @@
+"""Frame sets (modules/frames.py: every layer ONCE for all frames of a step) against the per-frame executor
+(modules/tape.py) on the same frames: middle maps and every parameter gradient."""
+import numpy as np
+import pytest
+import torch
+
+import mvx_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def rel_err(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture
+def small_cfg():
+    import modules.config as cfg
+    old, old_r = list(cfg.config['voxelshape']), list(cfg.config['velorange'])
+    cfg.config['voxelshape'] = [16, 24, 10]
+    cfg.config['velorange'] = [0.0, -2.4, -3.0, 3.2, 2.4, 1.0]
+    cfg.config['voxelsize'] = [0.2, 0.2, 0.4]
+    yield cfg
+    cfg.config['voxelshape'], cfg.config['velorange'] = old, old_r
+    cfg.config['voxelsize'] = [(old_r[k + 3] - old_r[k]) / old[k] for k in range(3)]
+
+
+def _small_batch(golden, B, with_empty=False):
+    from modules.pipeline import FrameBatch
+    g = golden('mvxnet_small')
+    gp = golden('group_small')
+    gen = torch.Generator().manual_seed(5)
+    frames, n = [], []
+    base = torch.from_numpy(gp['pcd'].copy())
+    P = base.shape[0]
+    for k in range(B):
+        pts = base.clone()
+        if k % 2:
+            pts = pts.flip(0)
+        pts[:, :3] += (torch.rand((P, 3), generator=gen) - 0.5) * 0.05 * k
+        lo = torch.tensor([0.0, -2.4, -3.0]) + 1e-3
+        hi = torch.tensor([3.2, 2.4, 1.0]) - 1e-3
+        pts[:, :3] = torch.minimum(torch.maximum(pts[:, :3], lo), hi)
+        pts[:, 4] = torch.rand(P, generator=gen) * 369
+        pts[:, 5] = torch.rand(P, generator=gen) * 1223
+        frames.append(pts)
+        n.append(P - 37 * k)                       # different live point counts per frame
+    if with_empty:
+        n[1] = 0
+    fpn = [[(torch.from_numpy(g[k]) * (1.0 + 0.1 * f))[None].to(DEV) for k in ('f0', 'f1', 'f2')] for f in range(B)]
+    perm = torch.stack([torch.from_numpy(gp['perm'])] * B)
+    batch = FrameBatch(torch.stack(frames).to(DEV).contiguous(), perm.to(DEV).contiguous(),
+                       torch.tensor(n, dtype=torch.int32, device=DEV), fpn)
+    return batch, torch.from_numpy(g['G'])[None].to(DEV)
+
+
+@pytest.mark.parametrize('B,with_empty', [(1, False), (3, False), (4, True)])
+def test_frame_set_equals_per_frame_execution(golden, small_cfg, B, with_empty):
+    from MVXNet import MVXNet
+    from modules import parallel
+    from modules.pipeline import train_step_frame_set, train_step_frames
+    torch.manual_seed(3)
+    model = MVXNet().to(DEV)
+    batch, G = _small_batch(golden, B, with_empty)
+    # the permutation must be a permutation of the LIVE points of each frame
+    for f in range(B):
+        nlive = int(batch.n_points[f])
+        batch.perms[f, :nlive] = torch.randperm(nlive, generator=torch.Generator().manual_seed(f)).to(DEV)
+    hot = [(k, p) for k, p in model.named_parameters() if p.requires_grad and '.rpn.' not in k]
+    bucket = parallel.GradBucket([p for _, p in hot])
+    imsize = [370.0, 1224.0]
+    bucket.zero()
+    mids_ref = []
+    nv_ref, st = train_step_frames(model, batch, G, imsize, keep_mid=mids_ref)
+    torch.cuda.synchronize()
+    ref = {k: p.grad.clone() for k, p in hot}
+    bucket.zero()
+    mids = []
+    nv, st2 = train_step_frame_set(model, batch, G, imsize, keep_mid=mids)
+    torch.cuda.synchronize()
+    assert int(torch.stack([s.reshape(()) for s in st2]).max()) == 0
+    assert list(nv) == list(nv_ref)
+    assert len(mids) == len(mids_ref)
+    for a, b in zip(mids, mids_ref):
+        assert rel_err(a, b) < 2e-5
+    for k, p in hot:
+        assert rel_err(p.grad, ref[k]) < 2e-4, k
+    # per-frame upstream gradients: (B,128,H,W) instead of one shared map
+    if not with_empty:
+        Gb = torch.stack([G[0] * (1.0 + 0.5 * f) for f in range(B)])
+        bucket.zero()
+        train_step_frame_set(model, batch, Gb, imsize)
+        torch.cuda.synchronize()
+        got = {k: p.grad.clone() for k, p in hot}
+        bucket.zero()
+        from modules.pipeline import FrameBatch
+        for f in range(B):
+            one = FrameBatch(batch.points6[f:f + 1], batch.perms[f:f + 1], batch.n_points[f:f + 1], [batch.fpn_levels[f]])
+            train_step_frames(model, one, Gb[f:f + 1], imsize)
+        torch.cuda.synchronize()
+        for k, p in hot:
+            assert rel_err(got[k], p.grad) < 2e-4, k
