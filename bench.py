@@ -163,7 +163,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--convmath', choices=['bf16x3', 'f32'], default=None, help='override config.yml convmath')
     ap.add_argument('--no-alt', action='store_true', help='skip the extra run in the other convolution arithmetic')
+    ap.add_argument('--timed-only', action='store_true',
+                    help='only warm-up + the timed steps (no alt / unshared / isolated / CPU passes): what profiles/ is made from')
     args = ap.parse_args()
+    if args.timed_only:
+        args.no_alt = args.no_cpu_baseline = True
 
     from modules import parallel
     rank, world, local = parallel.init_from_env(os.environ.get('MVX_DIST_BACKEND'))
@@ -254,9 +258,11 @@ def main():
 
     def timed_run(warmup, steps):
         nv = None
+        _hip.KERNEL_TIMERS = {}                           # the warm-up also fills the pool of timing events
         for _ in range(warmup):
             nv = step()
         fence()
+        _hip.recycle_timing_events(_hip.KERNEL_TIMERS)
         gc.collect()
         _hip.KERNEL_TIMERS = {}
         if _hip.EXEC_STAGES is not None:
@@ -316,6 +322,19 @@ def main():
                                 'counted by the kernel' if bg else '')}
 
     nvox, dt, timers = timed_run(args.warmup, args.steps)
+
+    def host_probe(n=3):
+        """Host time to enqueue one step when the launch queues are empty (over `n` steps from an idle GPU, no sync inside):
+        what the Python side costs.  Inside the timed region the host runs ahead of the GPU until the HIP queues are full,
+        so the time it spends there mostly measures the GPU."""
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        d = (time.perf_counter() - t0) / n * 1e3
+        fence()
+        return d
+    host_probe_ms = host_probe()
     bad = int(torch.stack([t.reshape(()) for t in pending_status]).max()) if pending_status else 0
     assert bad == 0, 'a kernel reported a data-dependent error (status %d)' % bad
     del pending_status[:]
@@ -333,7 +352,7 @@ def main():
                'roofline': conv_roofline(tm_alt, alt_math, run=1)}
 
     unshared = None
-    if world == 1:
+    if world == 1 and not args.timed_only:
         # The same steps with every kernel alone on the GPU (one lane, weight gradients on the main stream): what the
         # dominant kernel does when it does not share the CUs with the other lane's frame and the side-stream wgrads.
         import modules.pipeline as pl
@@ -354,7 +373,8 @@ def main():
                          '(see unshared / isolated)')
         if unshared is not None:
             roof['unshared'] = unshared
-        roof['isolated'] = isolated_conv_roofline(dev, main_math)
+        if not args.timed_only:
+            roof['isolated'] = isolated_conv_roofline(dev, main_math)
         tpath = os.path.join(REPO, 'profiles', 'traffic.json')
         if os.path.exists(tpath) and main_math == 'f32':
             with open(tpath) as fh:
@@ -367,7 +387,8 @@ def main():
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3,
-            'host_enqueue_ms_per_step': host_ms[0],
+            'host_enqueue_ms_per_step': host_probe_ms,
+            'host_in_timed_region_ms_per_step': host_ms[0],
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,

@@ -441,6 +441,17 @@ int mvx_crop_points(const float *pcd, const int32_t *n_in, int32_t n_frames, int
                     const double *cam_from_velo_host, const double *p2_host, double imsize_w,
                     double imsize_h, int32_t math_f32, float *out, int32_t *n_out, int32_t *src_index,
                     void *workspace, size_t workspace_bytes, void *stream);
+/* mvx_crop_project_points: the per-frame input preparation of the training loop in one compaction pass --
+ *   crop + cropToSight with the numpy-path (f64) masks of cropdata.py:30-65, then for every kept point the f32
+ *   projection of train.py:31-34 (lidar2Img on the torch path, swapped to (row, col)) appended as two columns:
+ *   out f32 [F][cap_out][ncol + 2] = [x y z r ... row col], n_out i32 [F].  cam_from_velo / p2: the f64 matrices of the
+ *   masks; proj_*: the matrices of the f32 projection (R0_rect @ Tr_velo_to_cam formed in f32, as torch does). */
+size_t mvx_crop_project_workspace_bytes(int32_t n_frames, int32_t cap_points);
+int mvx_crop_project_points(const float *pcd, const int32_t *n_in, int32_t n_frames, int32_t cap_points, int32_t ncol,
+                            const double *range6_host, const double *cam_from_velo_host, const double *p2_host,
+                            double imsize_w, double imsize_h, const double *proj_cam_from_velo_host,
+                            const double *proj_p2_host, float *out, int32_t cap_out, int32_t *n_out, void *workspace,
+                            size_t workspace_bytes, void *stream);
 int mvx_lidar2img(const float *pcd, int32_t ncol, int64_t n_points, const double *cam_from_velo_host,
                   const double *p2_host, int32_t math_f32, float *out, int32_t ld_out, int32_t col_offset,
                   int32_t swap_to_row_col, float *cam_z, void *stream);

@@ -87,9 +87,12 @@ __global__ __launch_bounds__(1024) void crop_scan(int *__restrict__ bcount, int 
     if (threadIdx.x == 0) n_out[f] = base;
 }
 
+// has_proj: the kept row is written as [its ncol columns, row, col] with the f32 projection of train.py:31-34
+// (lidar2Img on the torch path, swapped to (row, col)); out rows have ncol_out columns and frame stride cap_out.
 __global__ __launch_bounds__(256) void crop_write(const float *__restrict__ pcd, const int *__restrict__ n_in, int cap,
                                                   int ncol, CropParams c, const int *__restrict__ boff, int nblocks,
-                                                  float *__restrict__ out, int *__restrict__ src_index) {
+                                                  float *__restrict__ out, int *__restrict__ src_index, int ncol_out,
+                                                  int cap_out, int has_proj, CropParams proj) {
     __shared__ int s[4];
     const int f = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -103,10 +106,16 @@ __global__ __launch_bounds__(256) void crop_write(const float *__restrict__ pcd,
     int off = boff[(size_t)f * nblocks + blockIdx.x];
     for (int k = 0; k < wv; ++k) off += s[k];
     off += __popcll(b & ((1ull << lane) - 1ull));
-    if (flag) {
-        float *o = out + ((size_t)f * cap + off) * ncol;
+    if (flag && off < cap_out) {
+        float *o = out + ((size_t)f * cap_out + off) * ncol_out;
         for (int a = 0; a < ncol; ++a) o[a] = p[a];
-        if (src_index) src_index[(size_t)f * cap + off] = i;
+        if (has_proj) {
+            float z, u, v;
+            project<float>(proj, p[0], p[1], p[2], &z, &u, &v);
+            o[ncol] = v;                  // (row, col) = (v, u): train.py:33
+            o[ncol + 1] = u;
+        }
+        if (src_index) src_index[(size_t)f * cap_out + off] = i;
     }
 }
 
@@ -173,7 +182,36 @@ extern "C" int mvx_crop_points(const float *pcd, const int32_t *n_in, int32_t n_
     hipLaunchKernelGGL(crop_scan, dim3(n_frames), dim3(1024), 0, st, bc, nb, n_out);
     MVX_LAUNCH_CHECK();
     hipLaunchKernelGGL(crop_write, dim3(nb, n_frames), dim3(256), 0, st, pcd, n_in, cap_points, ncol, c, (const int *)bc,
-                       nb, out, src_index);
+                       nb, out, src_index, ncol, cap_points, 0, c);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+extern "C" size_t mvx_crop_project_workspace_bytes(int32_t n_frames, int32_t cap_points) {
+    return mvx_crop_workspace_bytes(n_frames, cap_points);
+}
+
+extern "C" int mvx_crop_project_points(const float *pcd, const int32_t *n_in, int32_t n_frames, int32_t cap_points,
+                                       int32_t ncol, const double *range6_host, const double *cam_from_velo_host,
+                                       const double *p2_host, double imsize_w, double imsize_h,
+                                       const double *proj_cam_from_velo_host, const double *proj_p2_host, float *out,
+                                       int32_t cap_out, int32_t *n_out, void *workspace, size_t workspace_bytes,
+                                       void *stream) {
+    MVX_CHECK_ARG(pcd && out && n_out && workspace && n_frames > 0 && cap_points > 0 && cap_out > 0 && ncol >= 3);
+    MVX_CHECK_ARG(range6_host && cam_from_velo_host && p2_host && proj_cam_from_velo_host && proj_p2_host);
+    MVX_CHECK_ARG(workspace_bytes >= mvx_crop_project_workspace_bytes(n_frames, cap_points));
+    CropParams c, pj;
+    fill_params(c, range6_host, 0, cam_from_velo_host, p2_host, imsize_w, imsize_h, 0);        // numpy-path masks (f64)
+    fill_params(pj, nullptr, 0, proj_cam_from_velo_host, proj_p2_host, 0.0, 0.0, 1);            // torch-path projection (f32)
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = (int)mvx_cdiv(cap_points, 256);
+    int *bc = (int *)workspace;
+    hipLaunchKernelGGL(crop_count, dim3(nb, n_frames), dim3(256), 0, st, pcd, n_in, cap_points, ncol, c, bc, nb);
+    MVX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(crop_scan, dim3(n_frames), dim3(1024), 0, st, bc, nb, n_out);
+    MVX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(crop_write, dim3(nb, n_frames), dim3(256), 0, st, pcd, n_in, cap_points, ncol, c, (const int *)bc,
+                       nb, out, (int *)nullptr, ncol + 2, cap_out, 1, pj);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

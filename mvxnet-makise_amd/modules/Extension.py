@@ -33,6 +33,8 @@ PROTOTYPES = {
                             _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
     'mvx_crop_workspace_bytes': (_sz, [_i32, _i32]),
     'mvx_crop_points': (_i32, [_p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _f64, _f64, _i32, _p, _p, _p, _p, _sz, _p]),
+    'mvx_crop_project_workspace_bytes': (_sz, [_i32, _i32]),
+    'mvx_crop_project_points': (_i32, [_p, _p, _i32, _i32, _i32, _p, _p, _p, _f64, _f64, _p, _p, _p, _i32, _p, _p, _sz, _p]),
     'mvx_lidar2img': (_i32, [_p, _i32, _i64, _p, _p, _i32, _p, _i32, _i32, _i32, _p, _p]),
     'mvx_scatter_voxels': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _i32, _i32, _p, _p]),
     'mvx_gather_voxels': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),

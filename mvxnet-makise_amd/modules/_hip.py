@@ -140,14 +140,29 @@ def _acc_f64(shape, device):
 KERNEL_TIMERS = None
 
 
+_EVENT_POOL = []          # timing events are recycled: creating one costs tens of microseconds of host time
+
+
+def _timing_event():
+    return _EVENT_POOL.pop() if _EVENT_POOL else torch.cuda.Event(enable_timing=True)
+
+
+def recycle_timing_events(timers):
+    """Hand the events of a finished (and read) KERNEL_TIMERS dict back to the pool."""
+    for evs in timers.values():
+        for s_, e_, _ in evs:
+            _EVENT_POOL.append(s_)
+            _EVENT_POOL.append(e_)
+
+
 class _Timed:
     def __init__(self, name, flops):
         self.name, self.flops = name, flops
 
     def __enter__(self):
         if KERNEL_TIMERS is not None:
-            self.s = torch.cuda.Event(enable_timing=True)
-            self.e = torch.cuda.Event(enable_timing=True)
+            self.s = _timing_event()
+            self.e = _timing_event()
             self.s.record()
         return self
 
@@ -887,6 +902,26 @@ def crop_points(pcd, n_in=None, range6=None, bounds_f32=False, cam_from_velo=Non
                                   float(imsize_wh[0]), float(imsize_wh[1]), int(math_f32), X.ptr(out), X.ptr(n_out),
                                   X.ptr(src), X.ptr(ws), ws.numel(), X.stream()), 'mvx_crop_points')
     return out, n_out, src
+
+
+def crop_project(pcd, n_in, range6, cam_from_velo64, p2_64, imsize_wh, cam_from_velo32, p2_32, cap_out):
+    """Raw clouds f32 (F, cap, 4) -> (points6 (F, cap_out, 6) = [x y z r row col], n_out i32 (F,)): crop + cropToSight
+    (numpy-path f64 masks) and the f32 projection of train.py:31-34 in one compaction pass."""
+    F, cap, ncol = pcd.shape
+    dev = pcd.device
+    out = torch.empty((F, cap_out, ncol + 2), dtype=torch.float32, device=dev)
+    n_out = torch.empty((F,), dtype=torch.int32, device=dev)
+    ws = workspace(X.lib.mvx_crop_project_workspace_bytes(F, cap), dev, 'crop')
+    k1, r_ptr = _host_f64(range6, 6)
+    k2, m_ptr = _host_f64(cam_from_velo64, 16)
+    k3, p_ptr = _host_f64(p2_64, 16)
+    k4, m32_ptr = _host_f64(cam_from_velo32, 16)
+    k5, p32_ptr = _host_f64(p2_32, 16)
+    with _timed_bytes('crop_project', F * cap * ncol * 4 * 2 + F * cap_out * (ncol + 2) * 4):
+        X.check(X.lib.mvx_crop_project_points(X.ptr(pcd), X.ptr(n_in), F, cap, ncol, r_ptr, m_ptr, p_ptr, float(imsize_wh[0]),
+                                              float(imsize_wh[1]), m32_ptr, p32_ptr, X.ptr(out), int(cap_out), X.ptr(n_out),
+                                              X.ptr(ws), ws.numel(), X.stream()), 'mvx_crop_project_points')
+    return out, n_out
 
 
 def lidar2img(pcd2d, cam_from_velo, p2, math_f32=True, out=None, col_offset=0, swap_rc=False, want_z=False):

@@ -70,6 +70,13 @@ class FrameSet:
         return self
 
 
+    def hand_over(self, stream):
+        """The set was built on another stream (input preparation): keep its tensors alive for ``stream`` too."""
+        for t in (self.voxels, self.coords, self.row_map, self.rows_sel, self.n_real_dev, self.real_off_dev, self.voff,
+                  self.vcnt, self.row_w, self.fusion_row_w):
+            t.record_stream(stream)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # thin wrappers over the frame-set entry points (allocation + pointers only)
 # ---------------------------------------------------------------------------------------------------------

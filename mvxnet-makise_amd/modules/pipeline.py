@@ -77,7 +77,9 @@ _PREP_STREAMS = {}
 
 def _prep_stream(device):
     if device.index not in _PREP_STREAMS:
-        _PREP_STREAMS[device.index] = torch.cuda.Stream(device=device)
+        # high priority: the few small preparation kernels should not queue behind the step's long ones (the host
+        # waits for their two results)
+        _PREP_STREAMS[device.index] = torch.cuda.Stream(device=device, priority=-1)
     return _PREP_STREAMS[device.index]
 
 
@@ -257,16 +259,32 @@ def prepare_frame_set(batch, T=None):
     return fs, live, counts, res.status
 
 
+PREP_STREAM = _os.environ.get('MVX_PREP_STREAM', '1') != '0'    # next batch prepared on its own stream (host reads return early)
+
+
 def train_step_frame_set(model, batch, grad_mid, imsize, ready=None, prepare_next=None, keep_mid=None):
     """Same contract as train_step_frames, executed through modules/frames.py: ONE launch per layer for all frames of the
-    batch, weight-gradient kernels on the side stream.  ``grad_mid``: (1,128,H,W) for every frame or (B,128,H,W)."""
+    batch, weight-gradient kernels on the side stream.  ``grad_mid``: (1,128,H,W) for every frame or (B,128,H,W).
+    ``prepare_next`` is voxelized and mapped on the preparation stream right after this step has been enqueued: its two
+    host reads only wait for those few small kernels (which share the GPU with the step), so the host stays a step ahead
+    of the GPU."""
     from modules import frames as fr
+    dev = batch.points6.device
+    main = torch.cuda.current_stream(dev)
+    ev_ready = None
     if ready is None:
         ready = prepare_frame_set(batch)
+    elif len(ready) == 5:
+        ready, ev_ready = ready[:4], ready[4]
     fs, live, counts, status = ready
+    if ev_ready is not None:
+        main.wait_event(ev_ready)
+        status.record_stream(main)
+        if fs is not None:
+            fs.hand_over(main)
     statuses = [status]
-    dev = batch.points6.device
     old_sink, _hip.GRAD_SINK = _hip.GRAD_SINK, True
+    next_ready = None
     try:
         if fs is not None:
             model.prepack()
@@ -278,7 +296,16 @@ def train_step_frame_set(model, batch, grad_mid, imsize, ready=None, prepare_nex
             if keep_mid is not None:
                 for k in range(len(live)):
                     keep_mid.append(mid[k:k + 1])
-        next_ready = prepare_frame_set(prepare_next) if prepare_next is not None else None
+        if prepare_next is not None:
+            if PREP_STREAM:
+                prep = _prep_stream(dev)
+                with torch.cuda.stream(prep):
+                    nr = prepare_frame_set(prepare_next)
+                    ev = torch.cuda.Event()
+                    ev.record(prep)
+                next_ready = nr + (ev,)
+            else:
+                next_ready = prepare_frame_set(prepare_next)
     finally:
         _hip.GRAD_SINK = old_sink
         _hip.arena_end()
