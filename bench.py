@@ -1,16 +1,21 @@
 #!/usr/bin/env python3
 """Headline benchmark: KITTI-shaped frames/s through the MVXNet hot path
-(voxelize + fusion + VFE + dense 3-D conv, forward + backward) on N MI355X GPUs.
+(crop + projection + voxelize + fusion + VFE + dense 3-D conv, forward + backward) on N MI355X GPUs.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One step = one batch of `--frames` synthetic ring frames PER GPU (weak scaling): batched GPU
-voxelizer, then per frame fusion sampling + fusion MLP + VFE stack + scatter + CML forward and
-the full backward (dL/d(middle) is a fixed resident tensor standing for RPN + loss), one flat
-gradient all-reduce over RCCL, one AdamW step.  Inputs are resident in HBM before the timed
-region.  Prints ONE JSON line on rank 0.
+One step (--mode hot, the headline) = one batch of `--frames` synthetic frames PER GPU (weak scaling):
+  raw 120,000-point clouds resident in HBM -> crop + cropToSight + lidar2Img (one compaction pass) -> batched
+  voxelizer -> ONE launch per layer for all frames (modules/frames.py): fusion sampling + fusion MLP + VFE stack +
+  reindex + CML forward and the full backward (dL/d(middle) is a fixed resident tensor standing for RPN + loss) ->
+  one flat gradient all-reduce over RCCL -> one AdamW step.
+Other modes (BASELINE.json configs): --mode vfe (config 2: voxelize + VFE stack forward/backward, 16 frames, voxel
+indices asserted bit-exact against the C oracle inside the run), --mode dropin (the nn.Module API: MVXNet.forward +
+VoxelLoss + autograd + AdamW, one frame at a time like train.py:110-164, RPN included).
+--workload S1|S2: uniform worst case (V ~ 19.9 k voxels per frame) or the KITTI-like ring model (V ~ 5 k, default).
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import gc
@@ -28,11 +33,12 @@ sys.path.insert(0, os.path.join(REPO, 'mvxnet-makise_amd'))
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters (matrix f32, dense)
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (never the 2:1-sparsity figure)
+HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+RAW_POINTS = 120000                # raw (un-cropped) clouds of ~120 k points
 
 
 def host_projection(pts, calib):
-    """lidar2Img(uncheck=True) + swap to (row, col) in f32 (train.py:31-33), host numpy: input
-    preparation outside the timed region."""
+    """lidar2Img(uncheck=True) + swap to (row, col) in f32 (train.py:31-33), host numpy (CPU baseline inputs)."""
     p = np.ones((4, pts.shape[0]), np.float32)
     p[:3] = pts[:, :3].T
     m = (calib['R0_rect'].astype(np.float32) @ calib['Tr_velo_to_cam'].astype(np.float32))
@@ -41,27 +47,31 @@ def host_projection(pts, calib):
     return uv[:, ::-1].astype(np.float32)
 
 
-def make_batch(frame_ids, dev, points_per_frame):
+def frame_points(workload, fid, P):
+    """The P points of a synthetic frame that survive crop + cropToSight, in cloud order."""
+    from modules.data import Synthetic as S
+    return S.synth_ring(fid, P) if workload == 'S2' else S.synth_uniform_in_sight(fid, P)
+
+
+def make_batch(frame_ids, dev, P, workload='S2', raw_points=RAW_POINTS):
+    """Resident inputs of one step: raw clouds (kept points interleaved with points that fail the crops), shuffle
+    permutations of the kept points, FPN maps."""
     from modules.data import Synthetic as S
     from modules.pipeline import FrameBatch
-    cap = points_per_frame
     B = len(frame_ids)
-    pts6 = np.zeros((B, cap, 6), np.float32)
-    perms = np.zeros((B, cap), np.int32)
-    n = np.zeros((B,), np.int32)
+    raw = np.zeros((B, raw_points, 4), np.float32)
+    perms = np.zeros((B, P), np.int32)
     fpn = []
     for k, fid in enumerate(frame_ids):
-        pc = S.synth_ring(fid, cap)
-        m = min(cap, pc.shape[0])
-        pts6[k, :m, :4] = pc[:m]
-        pts6[k, :m, 4:] = host_projection(pc[:m], S.KITTI_CALIB)
-        perms[k, :m] = S.synth_perm(fid, m)
-        n[k] = m
+        pc = frame_points(workload, fid, P)
+        assert pc.shape[0] == P, 'synthetic frame %d has %d points' % (fid, pc.shape[0])
+        raw[k] = S.synth_raw_around(pc, fid, raw_points)
+        perms[k] = S.synth_perm(fid, P)
         g = torch.Generator(device='cpu').manual_seed(3000 + fid)
         fpn.append([torch.randn((1, 256, h, w), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
                     for h, w in ((104, 336), (52, 168), (26, 84))])
-    return FrameBatch(torch.from_numpy(pts6).to(dev), torch.from_numpy(perms).to(dev),
-                      torch.from_numpy(n).to(dev), fpn)
+    return FrameBatch(None, torch.from_numpy(perms).to(dev), None, fpn, raw=torch.from_numpy(raw).to(dev),
+                      calib=S.KITTI_CALIB, cap_points=P)
 
 
 def host_threads():
@@ -77,30 +87,28 @@ def host_threads():
     return max(1, min(n, int(os.environ.get('MVX_CPU_THREADS', '64'))))
 
 
-def cpu_baseline(points_per_frame, n_frames=3):
-    """The CPU oracle (torch-CPU / oneDNN + the plain-C voxelizer) on a bounded sample of the same
-    workload (n_frames ring frames, forward + backward, dense as the reference computes it), all host
-    threads the cgroup allows.  A reported baseline, not the target."""
+def cpu_baseline(P, workload, budget_s=28.0):
+    """The CPU oracle (plain-C voxelizer + torch-CPU / oneDNN fusion, VFE, CML forward + backward, dense as the reference
+    computes it) on a BOUNDED sample of the same workload: per thread count one warm-up frame, then frames until the
+    time budget is used (at least 3); medians per stage.  All host threads the cgroup allows, and 8 threads (the size of
+    the build container).  A reported baseline, not the target."""
     import ctypes
     sys.path.insert(0, os.path.join(REPO, 'oracle'))
     import mvx_oracle as O
     from modules.data import Synthetic as S
-    torch.set_num_threads(host_threads())
     lib = ctypes.CDLL(os.path.join(REPO, 'oracle', 'liboracle_c.so'))
     lib.oracle_group9.restype = ctypes.c_int64
-    P = {k: v.requires_grad_(True) for k, v in O.make_params(7).items()}
     G = torch.ones((1, 128, O.VOXELSHAPE[0], O.VOXELSHAPE[1]))
     rng = np.asarray(O.VELORANGE, np.float64)
     size = np.asarray(O.voxelsize(), np.float64)
-    frames = []
-    for fid in range(n_frames):                       # input preparation is not timed (resident on the GPU side too)
-        pc = S.synth_ring(fid, points_per_frame)
+
+    def one_frame(fid, P_):
+        pc = frame_points(workload, fid, P)
         pcd = np.ascontiguousarray(np.concatenate([pc, host_projection(pc, S.KITTI_CALIB)], 1), np.float32)
-        frames.append((pcd, S.synth_perm(fid, pcd.shape[0]), [torch.from_numpy(f) for f in S.synth_fpn(fid)]))
-    nv = []
-    t0 = time.perf_counter()
-    for pcd, perm, feats in frames:
+        perm = S.synth_perm(fid, pcd.shape[0])
+        feats = [torch.from_numpy(f) for f in S.synth_fpn(fid)]
         Pn = pcd.shape[0]
+        t0 = time.perf_counter()
         voxel = np.empty((Pn, 35, 9), np.float64)
         uidx = np.empty((Pn, 3), np.float64)
         cnt = np.empty(Pn, np.int64)
@@ -110,20 +118,123 @@ def cpu_baseline(points_per_frame, n_frames=3):
                               uidx.ctypes.data_as(ctypes.c_void_p), cnt.ctypes.data_as(ctypes.c_void_p))
         vox = torch.from_numpy(voxel[:V].astype(np.float32))
         idx = torch.from_numpy(np.concatenate([np.zeros((V, 1)), uidx[:V]], 1).astype(np.int64))
-        v23 = O.mvx_point_features(vox, feats, torch.tensor([370.0, 1224.0]), P)
-        mid = O.voxelnet_middle(v23, idx, O.strip_prefix(P, 'backbone.'))
+        t1 = time.perf_counter()
+        v23 = O.mvx_point_features(vox, feats, torch.tensor([370.0, 1224.0]), P_)
+        feat = O.voxel_features(v23, O.strip_prefix(P_, 'backbone.'))
+        t2 = time.perf_counter()
+        leaf = feat.detach().requires_grad_(True)
+        mid = O.cml(O.reindex(leaf, idx), O.strip_prefix(P_, 'backbone.')).reshape(1, -1, O.VOXELSHAPE[0], O.VOXELSHAPE[1])
         mid.backward(G)
-        nv.append(int(V))
-    dt = time.perf_counter() - t0
-    return {'value': n_frames / dt, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d ring frames (%d pts, V=%s): C voxelizer + torch-CPU fusion/VFE/CML fwd+bwd, %.1f s'
-                      % (n_frames, points_per_frame, nv, dt)}
+        t3 = time.perf_counter()
+        feat.backward(leaf.grad)
+        t4 = time.perf_counter()
+        return int(V), (t1 - t0, (t2 - t1) + (t4 - t3), t3 - t2, t4 - t0)
+
+    out = {}
+    all_thr = host_threads()
+    for label, n, share in (('all', all_thr, 0.6), ('n8', min(8, all_thr), 0.4)):
+        if label == 'n8' and n == all_thr:
+            out['n8'] = out['all']
+            continue
+        torch.set_num_threads(n)
+        P_ = {k: v.requires_grad_(True) for k, v in O.make_params(7).items()}
+        one_frame(0, P_)                                # warm-up (oneDNN primitive creation, page faults)
+        t_begin, times, nv, fid = time.perf_counter(), [], [], 1
+        while len(times) < 3 or (time.perf_counter() - t_begin < budget_s * share and len(times) < 8):
+            v, t = one_frame(fid, P_)
+            times.append(t)
+            nv.append(v)
+            fid += 1
+        med = np.median(np.asarray(times), axis=0)
+        out[label] = {'threads': n, 'frames_timed': len(times), 'voxels': nv,
+                      'median_s': {'voxelize': float(med[0]), 'fusion_vfe_fwd_bwd': float(med[1]),
+                                   'scatter_cml_fwd_bwd': float(med[2]), 'frame': float(med[3])},
+                      'frames_per_s': float(1.0 / med[3])}
+    a = out['all']
+    return {'value': a['frames_per_s'], 'unit': 'frames/s', 'cores': a['threads'], 'kind': 'port',
+            'sample': '%s frames, %d pts: 1 warm-up + %d timed frames on %d threads (median %.2f s/frame: C voxelizer %.3f, '
+                      'torch-CPU fusion+VFE fwd+bwd %.2f, reindex+CML fwd+bwd %.2f); and %d timed frames on %d threads'
+                      % (workload, P, a['frames_timed'], a['threads'], a['median_s']['frame'], a['median_s']['voxelize'],
+                         a['median_s']['fusion_vfe_fwd_bwd'], a['median_s']['scatter_cml_fwd_bwd'],
+                         out['n8']['frames_timed'], out['n8']['threads']),
+            'runs': out}
+
+
+def _oracle_group(pcd6, perm):
+    import ctypes
+    sys.path.insert(0, os.path.join(REPO, 'oracle'))
+    import mvx_oracle as O
+    lib = ctypes.CDLL(os.path.join(REPO, 'oracle', 'liboracle_c.so'))
+    lib.oracle_group9.restype = ctypes.c_int64
+    rng = np.asarray(O.VELORANGE, np.float64)
+    size = np.asarray(O.voxelsize(), np.float64)
+    Pn = pcd6.shape[0]
+    voxel = np.empty((Pn, 35, 9), np.float64)
+    uidx = np.empty((Pn, 3), np.float64)
+    cnt = np.empty(Pn, np.int64)
+    V = lib.oracle_group9(pcd6.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(6), perm.ctypes.data_as(ctypes.c_void_p),
+                          ctypes.c_int64(Pn), rng.ctypes.data_as(ctypes.c_void_p), size.ctypes.data_as(ctypes.c_void_p),
+                          ctypes.c_int32(35), voxel.ctypes.data_as(ctypes.c_void_p), uidx.ctypes.data_as(ctypes.c_void_p),
+                          cnt.ctypes.data_as(ctypes.c_void_p))
+    return voxel[:V], uidx[:V]
+
+
+def voxel_index_check(batch, workload, frame_ids, P):
+    """CPU-baseline leg of --mode vfe: GPU crop + projection + voxelizer of every frame of the batch against the C oracle:
+    the cropped clouds, the voxel indices (order included) and the voxel payload must be bit-identical."""
+    import modules.config as cfg
+    from modules import _hip
+    from modules.data import Synthetic as S
+    points6, n_points = batch.prepared()
+    res = _hip.voxelize(points6, batch.perms, n_points, cfg.velorange[0:3], cfg.voxelsize, 35, 9)
+    n = n_points.tolist()
+    for k, fid in enumerate(frame_ids):
+        pc = frame_points(workload, fid, P)
+        assert n[k] == P and np.array_equal(points6[k, :P, :4].cpu().numpy(), pc), 'GPU crop differs from the generator'
+        ref6 = np.ascontiguousarray(np.concatenate([pc, host_projection(pc, S.KITTI_CALIB)], 1), np.float32)
+        got6 = points6[k, :P].cpu().numpy()
+        assert np.abs(got6[:, 4:] - ref6[:, 4:]).max() < 1e-2, 'GPU projection differs'
+        rv, ri = _oracle_group(np.ascontiguousarray(got6), S.synth_perm(fid, P))
+        V = int(res.n_voxels[k])
+        assert V == rv.shape[0], 'voxel count differs from the oracle'
+        assert np.array_equal(res.coords[k, :V, 1:].cpu().numpy(), ri.astype(np.int64)), 'voxel indices differ from the oracle'
+        assert np.array_equal(res.voxels[k, :V].cpu().numpy(), rv.astype(np.float32)), 'voxel payload differs from the oracle'
+    return 'ok, %d frames' % len(frame_ids)
+
+
+def cpu_baseline_vfe(P, workload, budget_s=20.0):
+    """CPU leg of --mode vfe: C voxelizer + torch-CPU SVFE + FCN + max forward/backward (dense (V,35,23) rows as the
+    reference computes them), all host threads."""
+    sys.path.insert(0, os.path.join(REPO, 'oracle'))
+    import mvx_oracle as O
+    from modules.data import Synthetic as S
+    n = host_threads()
+    torch.set_num_threads(n)
+    P_ = {k: v.requires_grad_(True) for k, v in O.strip_prefix(O.make_params(7), 'backbone.').items()}
+    times = []
+    t_begin = time.perf_counter()
+    fid = 0
+    while len(times) < 4 or (time.perf_counter() - t_begin < budget_s and len(times) < 17):
+        pc = frame_points(workload, fid, P)
+        pcd = np.ascontiguousarray(np.concatenate([pc, host_projection(pc, S.KITTI_CALIB)], 1), np.float32)
+        t0 = time.perf_counter()
+        rv, _ = _oracle_group(pcd, S.synth_perm(fid, P))
+        vox = torch.from_numpy(rv.astype(np.float32))
+        pad = (vox[..., :3] == 0).all(-1)
+        vox[pad] = 0
+        x = torch.cat([vox[..., :7], torch.randn(vox.shape[0], 35, 16)], dim=-1)
+        feat = O.voxel_features(x, P_)
+        feat.backward(torch.ones_like(feat) * 1e-3)
+        times.append(time.perf_counter() - t0)
+        fid += 1
+    med = float(np.median(times[1:]))
+    return {'value': 1.0 / med, 'unit': 'frames/s', 'cores': n, 'kind': 'port',
+            'sample': '%s frames, %d pts: 1 warm-up + %d timed frames, C voxelizer + torch-CPU SVFE+FCN+max fwd+bwd on dense '
+                      '(V,35,23) rows, median %.3f s/frame' % (workload, P, len(times) - 1, med)}
 
 
 def isolated_conv_roofline(dev, math):
-    """The dominant kernel's launches (conv2/conv3 forward + dgrad) on an otherwise idle GPU: inside the
-    step they share the CUs with the side-stream weight-gradient kernels and the other lane's frame, so
-    the live figure above includes that sharing; this one prices the kernel alone."""
+    """The dominant kernel's launches (conv2/conv3 forward + dgrad, dense) on an otherwise idle GPU."""
     from modules import _hip
     import modules.config as cfg
     H, W = cfg.voxelshape[0], cfg.voxelshape[1]
@@ -150,24 +261,29 @@ def isolated_conv_roofline(dev, math):
             tot_fl += fl
     mult, peak = (3.0, BF16_MFMA_PEAK_TFLOPS) if split else (1.0, FP32_MFMA_PEAK_TFLOPS)
     ach = mult * tot_fl / (tot_ms * 1e-3) / 1e12
-    return {'achieved': ach, 'frac': ach / peak, 'avg_launch_ms': tot_ms / 4}
+    return {'achieved': ach, 'frac': ach / peak, 'avg_launch_ms': tot_ms / 4,
+            'note': 'the same kernel, one frame, dense (no tile skipping), alone on the GPU'}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--frames', type=int, default=4, help='frames per GPU per step')
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--mode', choices=['hot', 'vfe', 'dropin'], default='hot')
+    ap.add_argument('--workload', choices=['S1', 'S2'], default='S2')
+    ap.add_argument('--frames', type=int, default=None, help='frames per GPU per step (default 4; 16 in --mode vfe)')
     ap.add_argument('--points', type=int, default=20000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--convmath', choices=['bf16x3', 'f32'], default=None, help='override config.yml convmath')
-    ap.add_argument('--no-alt', action='store_true', help='skip the extra run in the other convolution arithmetic')
+    ap.add_argument('--no-alt', action='store_true', help='skip the extra runs (bf16x3 arithmetic, the other workload)')
     ap.add_argument('--timed-only', action='store_true',
-                    help='only warm-up + the timed steps (no alt / unshared / isolated / CPU passes): what profiles/ is made from')
+                    help='only warm-up + the timed steps (no alt / isolated / CPU passes): what profiles/ is made from')
     args = ap.parse_args()
     if args.timed_only:
         args.no_alt = args.no_cpu_baseline = True
+    if args.frames is None:
+        args.frames = 16 if args.mode == 'vfe' else 4
 
     from modules import parallel
     rank, world, local = parallel.init_from_env(os.environ.get('MVX_DIST_BACKEND'))
@@ -177,75 +293,28 @@ def main():
 
     import modules.config as cfg
     from modules import _hip
-    from modules import pipeline as _pl
-    train_step_frames = _pl.train_step_frame_set if _pl.BATCHED else _pl.train_step_frames
+    from modules import pipeline as pl
     from MVXNet import MVXNet
     if args.convmath:
         cfg.config['convmath'] = args.convmath
     main_math = cfg.config.get('convmath', 'f32')
+    if main_math != 'f32':
+        pl.BATCHED = False                       # the frame-set executor runs the exact-f32 kernels only
 
     torch.manual_seed(0)
     model = MVXNet().to(dev)
-    hot = [p for k, p in model.named_parameters() if p.requires_grad and '.rpn.' not in k]
+    with_rpn = args.mode == 'dropin'
+    hot = [p for k, p in model.named_parameters() if p.requires_grad and (with_rpn or '.rpn.' not in k)]
     bucket = parallel.GradBucket(hot)
     opt = torch.optim.AdamW(hot, lr=1e-3, eps=cfg.eps)
     frame_ids = [rank + world * j for j in range(args.frames)]
-    batch = make_batch(frame_ids, dev, args.points)
+    batch = make_batch(frame_ids, dev, args.points, args.workload)
     g = torch.Generator(device='cpu').manual_seed(77)
     grad_mid = (torch.randn((1, 128, cfg.voxelshape[0], cfg.voxelshape[1]), generator=g) * 1e-3).to(dev)
     imsize = [float(v) for v in cfg.imsize]            # host list: no device read-back inside the step
     frames_total = args.frames * world
-
-    from modules import pipeline as pl_mod
-    pending = [None]
-    step_events = []
-    debug_sleep_ms = float(os.environ.get('MVX_DEBUG_HOST_DELAY_MS', '0'))
-    pipelined = os.environ.get('MVX_PIPELINE_INPUT', '2') == '1'      # own preparation stream: measured slower
-    pipe_mid = os.environ.get('MVX_PIPELINE_INPUT', '2') == '2'       # default: next batch prepared mid-step on the main stream
-    mid_ready = [None]
-
-    def step():
-        # input double-buffering: this step consumes the batch that was voxelized during the previous one and voxelizes
-        # the next (same resident synthetic batch every step; every step still voxelizes exactly once, inside the
-        # timed region; MVX_PIPELINE_INPUT=0 voxelizes at the start of the step instead)
-        ready = None
-        tt = [time.perf_counter()]
-        if pipelined:
-            # bounded run-ahead: never more than one step of launches in flight (a full HIP queue blocks the host
-            # inside launches for milliseconds at a time)
-            if len(step_events) >= 2:
-                pl_mod._spin(step_events.pop(0))
-            if pending[0] is not None:
-                ready = pl_mod.prepare_end(pending[0], model.head)
-                tt.append(time.perf_counter())
-            pending[0] = pl_mod.prepare_begin(batch)
-        tt.append(time.perf_counter())
-        bucket.zero()
-        if debug_sleep_ms > 0:                       # host-slack probe: busy-wait on the host before enqueuing the frames
-            t_end = time.perf_counter() + debug_sleep_ms * 1e-3
-            while time.perf_counter() < t_end:
-                pass
-        if pipe_mid:
-            nv, statuses, mid_ready[0] = train_step_frames(model, batch, grad_mid, imsize, ready=mid_ready[0], prepare_next=batch)
-        else:
-            nv, statuses = train_step_frames(model, batch, grad_mid, imsize, ready=ready)
-        tt.append(time.perf_counter())
-        if pipelined:
-            pl_mod.prepare_mid(pending[0], model.head)
-        tt.append(time.perf_counter())
-        bucket.all_reduce_mean(frames_total)
-        opt.step()
-        tt.append(time.perf_counter())
-        if os.environ.get('MVX_DEBUG_TIMES'):
-            sys.stderr.write('step phases ms: ' + ' '.join('%.2f' % ((b - a) * 1e3) for a, b in zip(tt, tt[1:])) + '\n')
-        pending_status.extend(statuses)
-        if pipelined:
-            ev = torch.cuda.Event()
-            ev.record()
-            step_events.append(ev)
-        return nv
-
     pending_status = []
+    state = {'ready': None}
 
     def fence():
         torch.cuda.synchronize()
@@ -253,14 +322,75 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    host_ms = []
-    exec_stages = []        # per timed_run: executed gather stages counted by the background-aware forward kernel
+    # ------------------------------------------------------------------------------------------------ step bodies
+    def step_hot(b=None):
+        b = batch if b is None else b
+        bucket.zero()
+        fn = pl.train_step_frame_set if pl.BATCHED else pl.train_step_frames
+        nv, statuses, state['ready'] = fn(model, b, grad_mid, imsize, ready=state['ready'], prepare_next=b)
+        bucket.all_reduce_mean(frames_total)
+        opt.step()
+        pending_status.extend(statuses)
+        return nv
 
-    def timed_run(warmup, steps):
+    vfe_state = {}
+
+    def step_vfe(b=None):
+        """BASELINE config 2: voxelize + VFE stack (SVFE + FCN + max, voxelnet/Pipe.py:5-29, VoxelNet.py:27-33) forward and
+        backward for all frames in one frame set; the 16 fused image channels and dL/d(voxel features) are resident random
+        tensors standing for the branches that are not part of this configuration."""
+        from modules import frames as fr
+        bucket.zero()
+        nv, statuses, state['ready'] = pl.train_step_rows_only(model, batch, vfe_state, ready=state['ready'], prepare_next=batch)
+        bucket.all_reduce_mean(frames_total)
+        opt.step()
+        pending_status.extend(statuses)
+        return nv
+
+    drop = {}
+
+    def step_dropin(b=None):
+        """The reference's own interface, one frame at a time (train.py:110-164): preprocessing -> MVXNet.forward ->
+        VoxelLoss -> backward -> AdamW.  nn.Module API + autograd, dense (1,N,35,23) contract, RPN on MIOpen."""
+        from modules import Calc
+        from modules.data import Preprocessing as pre
+        from modules.voxelnet import VoxelLoss
+        if not drop:
+            anchors = pre.createAnchors(cfg.voxelshape[0] // 2, cfg.voxelshape[1] // 2, cfg.velorange, cfg.carsize)
+            drop['anchors'] = anchors.to(dev)
+            drop['bevs'] = Calc.bbox3d2bev(anchors.reshape(anchors.shape[:2] + (-1, 7))).to(dev).contiguous()
+            gg = np.random.default_rng(11)
+            n = 8
+            gt = np.stack([gg.uniform(8, 60, n), gg.uniform(-30, 30, n), gg.uniform(-1.8, -0.6, n), gg.uniform(3.4, 4.4, n),
+                           gg.uniform(1.5, 1.8, n), gg.uniform(1.4, 1.7, n), gg.choice([0.0, np.pi / 2], n) + gg.normal(0, 0.05, n)], 1)
+            drop['gt'] = torch.tensor(gt, dtype=torch.float32)
+            drop['crit'] = VoxelLoss()
+            drop['imsize'] = torch.tensor(imsize, device=dev)
+        frames, st = pl.voxelize_batch(batch)
+        statuses = [st]
+        for f, (voxels, idx) in enumerate(frames):
+            opt.zero_grad(set_to_none=False)
+            gt = drop['gt']
+            pi, ni, gi = Calc.classifyAnchors(Calc.bbox3d2bev(gt), gt[:, [0, 1]], drop['bevs'], cfg.velorange, 0.45, 0.6)
+            score, reg = model(voxels, batch.fpn_levels[f], idx, [None], drop['imsize'])
+            score = score.squeeze(0).permute(1, 2, 0)
+            reg = reg.squeeze(0).permute(1, 2, 0)
+            cls_loss, reg_loss = drop['crit'](pi, ni, gi, gt.to(dev), score, reg, drop['anchors'], 2)
+            loss = cls_loss if reg_loss is None else cls_loss + reg_loss
+            loss.backward()
+            opt.step()
+        pending_status.extend(statuses)
+        return [v.shape[1] for v, _ in frames]
+
+    step = {'hot': step_hot, 'vfe': step_vfe, 'dropin': step_dropin}[args.mode]
+    host_ms, exec_stages = [], []
+
+    def timed_run(warmup, steps, fn=None):
+        fn = step if fn is None else fn
         nv = None
         _hip.KERNEL_TIMERS = {}                           # the warm-up also fills the pool of timing events
         for _ in range(warmup):
-            nv = step()
+            nv = fn()
         fence()
         _hip.recycle_timing_events(_hip.KERNEL_TIMERS)
         gc.collect()
@@ -269,8 +399,8 @@ def main():
             _hip.EXEC_STAGES.zero_()
         t0 = time.perf_counter()
         for _ in range(steps):
-            nv = step()
-        host_dt = time.perf_counter() - t0                 # host time to ENQUEUE the steps
+            nv = fn()
+        host_dt = time.perf_counter() - t0
         fence()
         dt_ = time.perf_counter() - t0
         host_ms.append(host_dt / steps * 1e3)
@@ -282,51 +412,52 @@ def main():
             dt_ = float(t)
         return nv, dt_, tm
 
-    def conv_roofline(tm, math, run=0):
-        name = 'conv3d_gather_split' if math == 'bf16x3' else 'conv3d_gather_pw'
-        ev = tm.get('conv3d_gather_split' if math == 'bf16x3' else 'conv3d_gather', [])
-        ms = sum(s.elapsed_time(e) for s, e, _ in ev)
-        fl = sum(f for _, _, f in ev)
-        bg = tm.get('conv3d_gather_bg', []) if math != 'bf16x3' else []
-        dense_fl = fl
-        if bg:
-            # forward launches with the background rewrite: EXECUTED FLOPs from the kernel's own stage counter
-            # (the timer's own figure is the dense-equivalent work of the launch)
-            ms += sum(s.elapsed_time(e) for s, e, _ in bg)
-            fl += float(exec_stages[run]) * _hip.STAGE_FLOP
-            dense_fl += sum(f for _, _, f in bg)
-            ev = ev + bg
-        tiles = tm.get('conv3d_gather_tiles', []) if math != 'bf16x3' else []
-        if tiles:
-            # tile-restricted dgrad launches of the same kernel: their executed stages are in the same counter
-            ms += sum(s.elapsed_time(e) for s, e, _ in tiles)
-            dense_fl += sum(f for _, _, f in tiles)
-            ev = ev + tiles
-        ms_all, dense_all = ms, dense_fl
-        if math == 'bf16x3':
-            peak, mult, note = BF16_MFMA_PEAK_TFLOPS, 3.0, ('executed bf16 MFMA FLOPs = 3 x algorithmic '
-                                                             '(hi*hi + hi*lo + lo*hi per product)')
-            if cfg.config.get('convbackground', True):
-                note += ('; the background-aware launches are priced at their DENSE FLOPs (the bf16x3 kernels carry no '
-                         'stage counter): an upper bound on the executed rate')
-        else:
-            peak, mult, note = FP32_MFMA_PEAK_TFLOPS, 1.0, 'exact f32 MFMA, executed = algorithmic FLOPs'
-        ach = mult * fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        return {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
-                'kernel': name + ' (every launch of the step: conv2/conv3 forward + dgrad)', 'launches': len(ev),
-                'avg_launch_ms': ms / max(1, len(ev)), 'flop_per_launch': fl / max(1, len(ev)),
-                'fp32_equivalent_tflops': fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
-                # what a dense evaluation of the same launches (incl. the tile-restricted dgrads) would have to sustain
-                'dense_equivalent_tflops': dense_all / (ms_all * 1e-3) / 1e12 if ms_all > 0 else 0.0,
-                'note': note + ('; forward launches skip voxel-free tiles (convbackground): FLOPs are the EXECUTED ones, '
-                                'counted by the kernel' if bg else '')}
+    def check_status():
+        bad = int(torch.stack([t.reshape(()) for t in pending_status]).max()) if pending_status else 0
+        assert bad == 0, 'a kernel reported a data-dependent error (status %d)' % bad
+        del pending_status[:]
 
+    def conv_roofline(tm, run):
+        """Dominant kernel conv3d_gather_pw: conv2/conv3 forward (background-aware) + tile-restricted dgrad launches.
+        achieved = EXECUTED FLOPs (the kernel's own stage counter x 4.72 MFLOP; skipped tiles are not credited) / sum of
+        the launch durations from HIP events recorded on the launch stream inside the timed region."""
+        ev = tm.get('conv3d_gather_bg', []) + tm.get('conv3d_gather_tiles', []) + tm.get('conv3d_gather', [])
+        ms = sum(s.elapsed_time(e) for s, e, _ in ev)
+        dense_fl = sum(f for _, _, f in ev)
+        fl = float(exec_stages[run]) * _hip.STAGE_FLOP + sum(f for _, _, f in tm.get('conv3d_gather', []))
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        return {'bound': 'mfma', 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS,
+                'traffic': None, 'kernel': 'conv3d_gather_pw (conv2 / conv3 forward + dgrad of all frames of the step: 4 launches per step)',
+                'launches': len(ev), 'avg_launch_ms': ms / max(1, len(ev)), 'flop_per_launch': fl / max(1, len(ev)),
+                'dense_equivalent_tflops': dense_fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                'note': 'exact f32 MFMA (v_mfma_f32_32x32x2_f32); FLOPs are the EXECUTED ones counted by the kernel (tiles that '
+                        'hold only the voxel-free background are filled with a constant and not credited); measured while the '
+                        'side-stream weight-gradient kernels share the CUs'}
+
+    def hbm_stages(tm):
+        out = {}
+        for name, evs in tm.items():
+            if name.startswith('hbm:') and evs:
+                tms = sum(s.elapsed_time(e) for s, e, _ in evs)
+                tb = sum(b for _, _, b in evs)
+                out[name[4:]] = {'launches': len(evs), 'avg_ms': tms / len(evs),
+                                 'algorithmic_GBps': tb / (tms * 1e-3) / 1e9 if tms > 0 and tb > 0 else None,
+                                 'frac_of_8TBps': tb / (tms * 1e-3) / 8e12 if tms > 0 and tb > 0 else None}
+        return out
+
+    # ------------------------------------------------------------------------------------------------ the timed run
+    vfe_check = None
+    if args.mode == 'vfe' and rank == 0 and not args.no_cpu_baseline:
+        # BASELINE config 2: the voxel indices of every frame of the run are checked bit-exact against the C oracle (part
+        # of the CPU-baseline leg: the only place the benchmark touches oracle/)
+        vfe_check = voxel_index_check(batch, args.workload, frame_ids, args.points)
     nvox, dt, timers = timed_run(args.warmup, args.steps)
+    check_status()
 
     def host_probe(n=3):
-        """Host time to enqueue one step when the launch queues are empty (over `n` steps from an idle GPU, no sync inside):
-        what the Python side costs.  Inside the timed region the host runs ahead of the GPU until the HIP queues are full,
-        so the time it spends there mostly measures the GPU."""
+        """Host time to enqueue one step when the launch queues are empty (`n` steps from an idle GPU, no sync inside): what
+        the Python side costs.  Inside the timed region the host runs ahead until the HIP queues are full, so the time it
+        spends there mostly measures the GPU."""
         fence()
         t0 = time.perf_counter()
         for _ in range(n):
@@ -335,52 +466,77 @@ def main():
         fence()
         return d
     host_probe_ms = host_probe()
-    bad = int(torch.stack([t.reshape(()) for t in pending_status]).max()) if pending_status else 0
-    assert bad == 0, 'a kernel reported a data-dependent error (status %d)' % bad
-    del pending_status[:]
-    sparse_quads = int(_hip.SPARSE_QUADS) if _hip.SPARSE_QUADS is not None else 0
-    alt = None
-    if not args.no_alt:
-        alt_math = 'bf16x3' if main_math == 'f32' else 'f32'
-        if os.environ.get('MVX_BENCH_ALT_SAME'):
-            alt_math = main_math
-        cfg.config['convmath'] = alt_math
-        _, dt_alt, tm_alt = timed_run(max(2, args.warmup), args.steps)     # allocator re-settles after the switch
-        cfg.config['convmath'] = main_math
-        alt = {'convmath': alt_math, 'value': frames_total * args.steps / dt_alt, 'unit': 'frames/s',
-               'ms_per_step': dt_alt / args.steps * 1e3, 'host_enqueue_ms_per_step': host_ms[-1],
-               'roofline': conv_roofline(tm_alt, alt_math, run=1)}
+    check_status()
 
-    unshared = None
-    if world == 1 and not args.timed_only:
-        # The same steps with every kernel alone on the GPU (one lane, weight gradients on the main stream): what the
-        # dominant kernel does when it does not share the CUs with the other lane's frame and the side-stream wgrads.
-        import modules.pipeline as pl
-        old = (pl.LANES, pl.ASYNC_WGRAD)
-        pl.LANES, pl.ASYNC_WGRAD = 1, False
-        try:
-            _, dt_u, tm_u = timed_run(1, 2)
-        finally:
-            pl.LANES, pl.ASYNC_WGRAD = old
-        r = conv_roofline(tm_u, main_math, run=len(exec_stages) - 1)
-        unshared = {'achieved': r['achieved'], 'frac': r['frac'], 'avg_launch_ms': r['avg_launch_ms'],
-                    'frames_per_s': frames_total * 2 / dt_u,
-                    'note': 'same step, MVX_LANES=1 and weight gradients on the main stream: no kernel shares the GPU'}
+    alt = []
+    if not args.no_alt and args.mode == 'hot':
+        # (1) the other workload on the same code path
+        other = 'S1' if args.workload == 'S2' else 'S2'
+        b2 = make_batch(frame_ids, dev, args.points, other)
+        state['ready'] = None
+        nv2, dt2, tm2 = timed_run(2, max(3, args.steps // 2), lambda: step_hot(b2))
+        check_status()
+        alt.append({'workload': other, 'convmath': main_math, 'value': frames_total * max(3, args.steps // 2) / dt2, 'unit': 'frames/s',
+                    'ms_per_step': dt2 / max(3, args.steps // 2) * 1e3, 'voxels_per_frame': nv2,
+                    'roofline': conv_roofline(tm2, len(exec_stages) - 1), 'hbm_stages': hbm_stages(tm2)})
+        del b2
+        state['ready'] = None
+        # (2) BASELINE config 3's arithmetic: bf16x3 split MFMA for the dense convolutions (per-frame executor)
+        if main_math == 'f32':
+            cfg.config['convmath'] = 'bf16x3'
+            old_b, pl.BATCHED = pl.BATCHED, False
+            try:
+                _, dt3, _ = timed_run(2, max(3, args.steps // 2))
+            finally:
+                cfg.config['convmath'] = 'f32'
+                pl.BATCHED = old_b
+                state['ready'] = None
+            check_status()
+            alt.append({'workload': args.workload, 'convmath': 'bf16x3', 'value': frames_total * max(3, args.steps // 2) / dt3,
+                        'unit': 'frames/s', 'ms_per_step': dt3 / max(3, args.steps // 2) * 1e3,
+                        'roofline': None,
+                        'note': 'bf16 hi/lo split MFMA (3 bf16 MFMAs per product, f32 accumulate) for conv2/conv3, frames one after the '
+                                'other (modules/tape.py); its kernels carry no executed-stage counter, so no roofline fraction is claimed'})
 
     if rank == 0:
-        roof = conv_roofline(timers, main_math)
-        roof['note'] += ('; measured while the other lane and the side-stream weight-gradient kernels share the CUs '
-                         '(see unshared / isolated)')
-        if unshared is not None:
-            roof['unshared'] = unshared
-        if not args.timed_only:
-            roof['isolated'] = isolated_conv_roofline(dev, main_math)
-        tpath = os.path.join(REPO, 'profiles', 'traffic.json')
-        if os.path.exists(tpath) and main_math == 'f32':
-            with open(tpath) as fh:
-                roof['traffic'] = json.load(fh).get('conv3d_gather_pw_hbm_bytes_per_launch')
+        dtype = 'f32' if main_math == 'f32' else 'f32 (bf16x3 split MFMA, f32 accumulate)'
+        wl = {'S2': 'S2 ring frames (64-beam model, KITTI-like occupancy)', 'S1': 'S1 uniform frames (worst-case voxel count)'}[args.workload]
+        if args.mode == 'hot':
+            workload = ('%s, %d raw pts -> %d pts after crop, grid 10x352x400, T=35, %d frames/GPU/step: crop+cropToSight+lidar2Img, '
+                        'voxelize, fusion sampling+MLP, VFE, reindex+CML fwd+bwd, all-reduce, AdamW; convmath=%s'
+                        % (wl, RAW_POINTS, args.points, args.frames, main_math))
+            roof = conv_roofline(timers, 0)
+            if not args.timed_only:
+                roof['isolated'] = isolated_conv_roofline(dev, main_math)
+            tpath = os.path.join(REPO, 'profiles', 'traffic.json')
+            if os.path.exists(tpath) and main_math == 'f32':
+                with open(tpath) as fh:
+                    tj = json.load(fh)
+                roof['traffic'] = tj.get('conv3d_gather_pw_hbm_bytes_per_launch_r02', tj.get('conv3d_gather_pw_hbm_bytes_per_launch'))
+                roof['traffic_note'] = tj.get('note_r02', 'per launch of the round-1 single-frame form; see profiles/')
+            metric = 'KITTI frames/sec (voxelize+VFE+fusion+3Dconv fwd+bwd)'
+        elif args.mode == 'vfe':
+            workload = ('%s, %d raw pts -> %d pts, T=35, %d frames/GPU/step: crop+cropToSight+lidar2Img, voxelize, VFE stack '
+                        '(SVFE + FCN + max) fwd+bwd, AdamW; voxel indices bit-exact vs the C oracle (checked in this run: %s)'
+                        % (wl, RAW_POINTS, args.points, args.frames, vfe_check))
+            ev = timers.get('hbm:voxelize', [])
+            ms = sum(s.elapsed_time(e) for s, e, _ in ev)
+            tb = sum(b for _, _, b in ev)
+            ach = tb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            roof = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS, 'traffic': None,
+                    'kernel': 'voxelizer (all its launches, %d frames per call)' % args.frames, 'launches': len(ev),
+                    'avg_launch_ms': ms / max(1, len(ev)),
+                    'note': 'algorithmic bytes = points + permutation read, voxel payload + indices written (SURVEY.md 8d)'}
+            metric = 'KITTI frames/sec (voxelize+VFE fwd+bwd)'
+        else:
+            workload = ('%s, %d pts, grid 10x352x400, T=35, %d frames/GPU/step one at a time through the nn.Module API: voxelize, '
+                        'classifyAnchors, MVXNet.forward (dense (1,N,35,23) contract, RPN on MIOpen), VoxelLoss, autograd backward, AdamW'
+                        % (wl, args.points, args.frames))
+            roof = conv_roofline(timers, 0)
+            roof['note'] += '; drop-in path: dense input gradients (no restricted backward), frames one after the other'
+            metric = 'KITTI frames/sec (MVXNet.forward + VoxelLoss + backward, nn.Module API)'
         out = {
-            'metric': 'KITTI frames/sec (voxelize+VFE+fusion+3Dconv fwd+bwd)',
+            'metric': metric,
             'value': frames_total * args.steps / dt,
             'unit': 'frames/s',
             'n_gpus': world,
@@ -392,41 +548,28 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32' if main_math == 'f32' else 'f32 (bf16x3 split MFMA, f32 accumulate)',
+            'dtype': dtype,
             'data': 'synthetic',
-            'config': {'workload': 'S2 ring frames, %d pts, grid 10x352x400, T=35, %d frames/GPU/step, '
-                                   'MVXNet middle (fusion on) fwd+bwd + AdamW, convmath=%s' % (args.points, args.frames, main_math),
-                       'frames_per_gpu': args.frames, 'voxels_per_frame': nvox, 'parallelism': 'dp%d' % world},
+            'config': {'workload': workload, 'mode': args.mode, 'frames_per_gpu': args.frames, 'voxels_per_frame': nvox,
+                       'parallelism': 'dp%d' % world, 'frame_sets': bool(pl.BATCHED and args.mode != 'dropin')},
             'roofline': roof,
+            'hbm_stages': hbm_stages(timers),
         }
-        if alt is not None:
-            out['alt_modes'] = [alt]
         other = {}
-        for name in ('conv3d_gather_sparse_input', 'conv3d_wgrad', 'conv3d_wgrad_bg', 'conv3d_dgrad_sites', 'conv3d_wgrad_sites'):
+        for name in ('conv3d_wgrad_bg',):
             evs = timers.get(name, [])
             if evs:
                 tms = sum(s.elapsed_time(e) for s, e, _ in evs)
-                tfl = sum(f for _, _, f in evs)
-                if name == 'conv3d_gather_sparse_input':
-                    tfl = sparse_quads * 8 * 4096.0          # executed MFMAs only (exact-zero blocks skipped)
                 other[name] = {'launches': len(evs), 'avg_launch_ms': tms / len(evs)}
-                if tfl > 0:
-                    other[name].update({'executed_tflops': tfl / (tms * 1e-3) / 1e12 if tms > 0 else 0.0,
-                                        'executed_gflop_per_launch': tfl / len(evs) / 1e9})
         out['other_kernels'] = other
-        stages = {}
-        for name, evs in timers.items():
-            if name.startswith('hbm:') and evs:
-                tms = sum(s.elapsed_time(e) for s, e, _ in evs)
-                tb = sum(b for _, _, b in evs)
-                stages[name[4:]] = {'launches': len(evs), 'avg_ms': tms / len(evs),
-                                    'algorithmic_GBps': tb / (tms * 1e-3) / 1e9 if tms > 0 else 0.0,
-                                    'frac_of_8TBps': tb / (tms * 1e-3) / 8e12 if tms > 0 else 0.0}
-        out['hbm_stages'] = stages
+        if alt:
+            out['alt_modes'] = alt
         if world == 1 and not args.no_cpu_baseline:
             del model, batch
             torch.cuda.empty_cache()
-            out['cpu_baseline'] = cpu_baseline(args.points)
+            out['cpu_baseline'] = (cpu_baseline_vfe if args.mode == 'vfe' else cpu_baseline)(args.points, args.workload)
+            if vfe_check is not None:
+                out['cpu_baseline']['voxel_indices_vs_oracle'] = vfe_check
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -58,6 +58,59 @@ def synth_uniform(frame_id: int, P: int = 20000, rng=VELORANGE) -> np.ndarray:
     return np.concatenate([xyz, r], axis=1)
 
 
+def synth_uniform_in_sight(frame_id: int, P: int = 20000, rng=VELORANGE, calib=None, imsize_wh=(1224, 370)) -> np.ndarray:
+    """S1 'uniform' for runs WITH image fusion: uniform in the crop range, restricted to the camera frustum (every point
+    must project into the image, modules/imhead/Pipe.py:71), P points; still about one point per voxel."""
+    calib = KITTI_CALIB if calib is None else calib
+    g = np.random.default_rng(1000 + frame_id)
+    lo = np.asarray(rng[:3], np.float32)
+    hi = np.asarray(rng[3:], np.float32)
+    parts, have = [], 0
+    while have < P:
+        xyz = (g.random((4 * P, 3)) * (hi - lo) + lo).astype(np.float32)
+        xyz = np.maximum(np.minimum(xyz, np.nextafter(hi, -np.inf, dtype=np.float32)), lo)
+        pc = np.concatenate([xyz, g.random((4 * P, 1)).astype(np.float32)], axis=1)
+        pc = _crop_to_sight(_crop(pc, rng), calib, imsize_wh)
+        parts.append(pc)
+        have += pc.shape[0]
+    return np.ascontiguousarray(np.concatenate(parts, 0)[:P])
+
+
+def synth_raw_around(kept: np.ndarray, frame_id: int, total: int = 120000, rng=VELORANGE, calib=None,
+                     imsize_wh=(1224, 370)) -> np.ndarray:
+    """A raw (un-cropped) cloud of `total` points whose crop + cropToSight is exactly `kept`, in the same order: the kept
+    points interleaved with points that fail the range crop or the frustum test (what cropdata.py / Load.py read from
+    disk before cropping)."""
+    calib = KITTI_CALIB if calib is None else calib
+    g = np.random.default_rng(4000 + frame_id)
+    need = total - kept.shape[0]
+    assert need >= 0
+    rejected, have = [], 0
+    while have < need:
+        cand = np.stack([g.uniform(-80, 80, 2 * need + 16), g.uniform(-80, 80, 2 * need + 16), g.uniform(-4, 3, 2 * need + 16),
+                         g.random(2 * need + 16)], axis=1).astype(np.float32)
+        lo, hi = np.asarray(rng[:3], np.float64), np.asarray(rng[3:], np.float64)
+        roi = cand[:, :3].astype(np.float64)
+        in_range = np.all((lo <= roi) & (roi < hi), axis=1)
+        bad = cand[~in_range]
+        inr = cand[in_range]
+        if inr.shape[0]:
+            ok = _crop_to_sight(inr, calib, imsize_wh)
+            # in-range points outside the frustum: everything in `inr` that is not in `ok` (rows are unique with probability 1)
+            keep_rows = {r.tobytes() for r in ok}
+            outside = np.array([r for r in inr if r.tobytes() not in keep_rows], np.float32).reshape(-1, 4)
+            bad = np.concatenate([bad, outside], 0)
+        rejected.append(bad)
+        have += bad.shape[0]
+    rej = np.concatenate(rejected, 0)[:need]
+    slot = np.zeros(total, bool)
+    slot[np.sort(g.choice(total, kept.shape[0], replace=False))] = True
+    out = np.empty((total, 4), np.float32)
+    out[slot] = kept[:, :4]
+    out[~slot] = rej
+    return out
+
+
 def synth_raw(frame_id: int, P: int = 120000) -> np.ndarray:
     """Raw un-cropped cloud for the crop/cropToSight config."""
     g = np.random.default_rng(1000 + frame_id)

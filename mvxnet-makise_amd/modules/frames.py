@@ -143,12 +143,23 @@ class _Saved:
 def middle_forward(model, fs, fpn_levels, imsize, status_sink):
     """Forward of MVXNet.middle for the whole frame set.  ``fpn_levels``: per frame [f0, f1, f2] (1,C,H,W).
     Returns (mid (F,128,H,W), saved state for the backward)."""
+    feat, S = rows_forward(model, fs, fpn_levels, imsize, status_sink)
+    return cml_forward(model, fs, feat, S, status_sink), S
+
+
+def rows_forward(model, fs, fpn_levels, imsize, status_sink, imfeat=None):
+    """The row part of the chain: fusion sampling + fusion MLP -> concat -> SVFE -> FCN + max: voxel features
+    (Vt,128) of all frames.  ``imfeat`` (Rt+F, 16), if given, stands for the fusion branch's output (VFE-only runs)."""
     head, bb = model.head, model.backbone
     dev = fs.voxels.device
     F, T, Rt, Vt = fs.F, fs.T, fs.Rt, fs.Vt
     S = _Saved()
     S.fs = fs
     eps = cfg.eps
+    S.fusion = []
+    if imfeat is not None:
+        x = imfeat
+        return _vfe_forward(bb, fs, x, S, eps)
     # ---- fusion sampling (imhead/Pipe.py:23-82): real rows of all frames, each from its own frame's maps
     levels = [f[0].permute(1, 2, 0).contiguous() for lv in fpn_levels for f in head.extractor(lv)]
     L = len(levels) // F
@@ -164,12 +175,17 @@ def middle_forward(model, fs, fpn_levels, imsize, status_sink):
                                                      X.ptr(status), fs.desc.ref(), X.stream()), 'mvx_feature_sample_rows_frames')
     status_sink.append(status)
     # ---- fusion MLP (imhead/Pipe.py:84-104) on [real rows | one shared padded row per frame]
-    S.fusion = []
     x = compact
     for w, b in head.fusion._layers():
         y, mi = linear_bn(x, w, b, fs, X.ROWS_FUSION, fs.fusion_row_w, eps)
         S.fusion.append((x, w, b, y, mi))
         x = bn_apply(y, mi, fs, X.ROWS_FUSION)
+    return _vfe_forward(bb, fs, x, S, eps)
+
+
+def _vfe_forward(bb, fs, x, S, eps):
+    dev = fs.voxels.device
+    F, T, Rt, Vt = fs.F, fs.T, fs.Rt, fs.Vt
     # ---- concat with the 7 geometric channels (MVXNet.py:26): [real rows | one padded row per voxel]
     Fc = x.shape[1]
     rows23 = torch.empty((Rt + Vt, 7 + Fc), dtype=torch.float32, device=dev)
@@ -196,7 +212,15 @@ def middle_forward(model, fs, fpn_levels, imsize, status_sink):
     X.check(X.lib.mvx_bn_segment_max_frames(X.ptr(y), X.ptr(mi), X.ptr(feat), X.ptr(am), Vt, T, w.shape[0], X.ptr(fs.voff),
                                             X.ptr(fs.vcnt), Rt, fs.desc.ref(), X.stream()), 'mvx_bn_segment_max_frames')
     S.head = (x, w, b, y, mi, am)
+    return feat, S
 
+
+def cml_forward(model, fs, feat, S, status_sink):
+    """reindex + CML + the BEV reshape (VoxelNet.py:16-36) for the whole frame set: (Vt,128) -> (F,128,H,W)."""
+    bb = model.backbone
+    dev = fs.voxels.device
+    F, T, Rt, Vt = fs.F, fs.T, fs.Rt, fs.Vt
+    eps = cfg.eps
     # ---- reindex + conv1 through the voxel-GEMM factorisation (VoxelNet.py:16-22, voxelnet/Pipe.py:36)
     D0, H, W = cfg.voxelshape[2], cfg.voxelshape[0], cfg.voxelshape[1]
     c1, c2, c3 = bb.cml.conv1, bb.cml.conv2, bb.cml.conv3
@@ -294,7 +318,7 @@ def middle_forward(model, fs, fpn_levels, imsize, status_sink):
     with _hip._timed_bytes('cl_bev_transpose', 2 * x_in.numel() * 4):
         X.check(X.lib.mvx_cl_to_bev_frames(X.ptr(x_in), X.ptr(mid), D3, H, W, x_in.shape[-1], 0, F, X.stream()), 'mvx_cl_to_bev_frames')
     S.D3, S.H, S.W, S.C3 = D3, H, W, x_in.shape[-1]
-    return mid, S
+    return mid
 
 
 def _wgrad_bg(rec, dz, tap_sums, F, H, W):
@@ -319,6 +343,15 @@ def _linear_wgrad_side(x, dz, w):
 def middle_backward(model, S, grad_mid):
     """Backward of the chain for the whole frame set.  ``grad_mid`` (F or 1, 128, H, W) = dL/d(mid); parameter gradients
     are ADDED into the existing .grad buffers (summed over the frames)."""
+    old_async, _hip.ASYNC_WGRAD = _hip.ASYNC_WGRAD, True
+    try:
+        rows_backward(model, S, cml_backward(model, S, grad_mid))
+    finally:
+        _hip.ASYNC_WGRAD = old_async
+
+
+def cml_backward(model, S, grad_mid):
+    """Backward of cml_forward: returns dL/d(voxel features) (Vt,128)."""
     fs = S.fs
     F, T, Rt, Vt = fs.F, fs.T, fs.Rt, fs.Vt
     H, W, D3, C3 = S.H, S.W, S.D3, S.C3
@@ -331,7 +364,6 @@ def middle_backward(model, S, grad_mid):
     else:
         g = torch.empty((F * D3, H, W, C3), dtype=torch.float32, device=dev)
         X.check(X.lib.mvx_cl_to_bev_frames(X.ptr(g), X.ptr(gm), D3, H, W, C3, 1, F, X.stream()), 'mvx_cl_to_bev_frames')
-    old_async, _hip.ASYNC_WGRAD = _hip.ASYNC_WGRAD, True
 
     def tap_sums(dz, planes, Cn, tile_flags=None, inactive=None):
         Tt = torch.empty((planes, 9, Cn), dtype=torch.float32, device=dev)
@@ -375,65 +407,70 @@ def middle_backward(model, S, grad_mid):
                                                             X.stream()), 'mvx_bn_relu_backward_tiles_frames')
         return dz, inact
 
-    try:
-        # ---- conv3: dense gradient in, restricted gradient + closed-form plane sums out
-        r3, r2 = S.convs[1], S.convs[0]
-        dz3 = bn_relu_backward(g, r3['y'], r3['mi'], fs, X.ROWS_GRID, None, _grad_of(r3['b']))
-        T3 = tap_sums(dz3, F * r3['dout'], r3['w'].shape[0])
-        _wgrad_bg(r3, dz3, T3, F, H, W)
-        g2 = dgrad_tiles(r3, dz3, r3['bflag_in'])
-        A2 = input_grad_sums(r3, T3)
-        # ---- conv2
-        dz2, inact2 = bn_bwd_tiles(g2, r2['y'], r2['mi'], r2['c_out'], r2['ybg_out'], A2, r2['bflag_out'], r2['dout'],
-                                   r2['w'].shape[0], r2['b'], True)
-        T2 = tap_sums(dz2, F * r2['dout'], r2['w'].shape[0], r2['bflag_out'], inact2)
-        _wgrad_bg(r2, dz2, T2, F, H, W)
-        g1 = dgrad_tiles(r2, dz2, r2['bflag_in'])
-        A1 = input_grad_sums(r2, T2)
-        # ---- conv1 (voxel-GEMM factorisation): gradient only next to the voxels
-        c1 = S.conv1
-        w1 = c1['w']
-        cout, cin = w1.shape[0], w1.shape[1]
-        dz1, _ = bn_bwd_tiles(g1, c1['y'], c1['mi'], c1['c'], c1['ybg'], A1, c1['tflag'], c1['D1'], cout, c1['b'], False)
-        G = torch.empty((Vt, 27 * cout), dtype=torch.float32, device=dev)
-        cm = model.backbone.cml.conv1
-        X.check(X.lib.mvx_sparse_conv_gather_dz_frames(X.ptr(dz1), X.ptr(fs.coords), Vt, X.ptr(G), c1['D0'], c1['D1'], H, W, cout,
-                                                       cm._sd, cm._pd, fs.desc.ref(), X.stream()), 'mvx_sparse_conv_gather_dz_frames')
-        dw_all = _hip.linear_wgrad(c1['feat'], G)                              # (27*cout, cin), main stream (small)
-        with _hip._SideStream(dw_all):
-            _grad_of(w1).add_(dw_all.reshape(3, 3, 3, cout, cin).permute(3, 4, 0, 1, 2))
-        dfeat, _ = _hip.linear_forward(G, c1['w_all'], None, relu=False, want_stats=False, w_transposed=True)
-        # ---- FCN + max
-        x, w, b, y, mi, am = S.head
+    # ---- conv3: dense gradient in, restricted gradient + closed-form plane sums out
+    r3, r2 = S.convs[1], S.convs[0]
+    dz3 = bn_relu_backward(g, r3['y'], r3['mi'], fs, X.ROWS_GRID, None, _grad_of(r3['b']))
+    T3 = tap_sums(dz3, F * r3['dout'], r3['w'].shape[0])
+    _wgrad_bg(r3, dz3, T3, F, H, W)
+    g2 = dgrad_tiles(r3, dz3, r3['bflag_in'])
+    A2 = input_grad_sums(r3, T3)
+    # ---- conv2
+    dz2, inact2 = bn_bwd_tiles(g2, r2['y'], r2['mi'], r2['c_out'], r2['ybg_out'], A2, r2['bflag_out'], r2['dout'],
+                               r2['w'].shape[0], r2['b'], True)
+    T2 = tap_sums(dz2, F * r2['dout'], r2['w'].shape[0], r2['bflag_out'], inact2)
+    _wgrad_bg(r2, dz2, T2, F, H, W)
+    g1 = dgrad_tiles(r2, dz2, r2['bflag_in'])
+    A1 = input_grad_sums(r2, T2)
+    # ---- conv1 (voxel-GEMM factorisation): gradient only next to the voxels
+    c1 = S.conv1
+    w1 = c1['w']
+    cout, cin = w1.shape[0], w1.shape[1]
+    dz1, _ = bn_bwd_tiles(g1, c1['y'], c1['mi'], c1['c'], c1['ybg'], A1, c1['tflag'], c1['D1'], cout, c1['b'], False)
+    G = torch.empty((Vt, 27 * cout), dtype=torch.float32, device=dev)
+    cm = model.backbone.cml.conv1
+    X.check(X.lib.mvx_sparse_conv_gather_dz_frames(X.ptr(dz1), X.ptr(fs.coords), Vt, X.ptr(G), c1['D0'], c1['D1'], H, W, cout,
+                                                   cm._sd, cm._pd, fs.desc.ref(), X.stream()), 'mvx_sparse_conv_gather_dz_frames')
+    dw_all = _hip.linear_wgrad(c1['feat'], G)                              # (27*cout, cin), main stream (small)
+    with _hip._SideStream(dw_all):
+        _grad_of(w1).add_(dw_all.reshape(3, 3, 3, cout, cin).permute(3, 4, 0, 1, 2))
+    dfeat, _ = _hip.linear_forward(G, c1['w_all'], None, relu=False, want_stats=False, w_transposed=True)
+    return dfeat
+
+
+def rows_backward(model, S, dfeat):
+    """Backward of rows_forward from dL/d(voxel features) (Vt,128); needs _hip.ASYNC_WGRAD set by the caller."""
+    fs = S.fs
+    F, T, Rt, Vt = fs.F, fs.T, fs.Rt, fs.Vt
+    dev = dfeat.device
+    # ---- FCN + max
+    x, w, b, y, mi, am = S.head
+    Cn = w.shape[0]
+    dyh = torch.empty((Rt + Vt, Cn), dtype=torch.float32, device=dev)
+    X.check(X.lib.mvx_segment_max_backward(X.ptr(dfeat), X.ptr(am), X.ptr(dyh), Vt, T, Cn, X.ptr(fs.voff), X.ptr(fs.vcnt), Rt,
+                                           X.stream()), 'mvx_segment_max_backward')
+    dz = bn_relu_backward(dyh, y, mi, fs, X.ROWS_VFE, fs.row_w, _grad_of(b), dz=dyh)
+    _linear_wgrad_side(x, dz, w)
+    gx, _ = _hip.linear_forward(dz, w, None, relu=False, want_stats=False, w_transposed=True)
+    # ---- VFE 2, VFE 1
+    for x, w, b, y, mi, am in reversed(S.vfe):
         Cn = w.shape[0]
         dyh = torch.empty((Rt + Vt, Cn), dtype=torch.float32, device=dev)
-        X.check(X.lib.mvx_segment_max_backward(X.ptr(dfeat), X.ptr(am), X.ptr(dyh), Vt, T, Cn, X.ptr(fs.voff), X.ptr(fs.vcnt), Rt,
-                                               X.stream()), 'mvx_segment_max_backward')
+        X.check(X.lib.mvx_vfe_max_concat_backward(X.ptr(gx), X.ptr(am), X.ptr(dyh), Vt, T, Cn, X.ptr(fs.voff), X.ptr(fs.vcnt),
+                                                  Rt, X.stream()), 'mvx_vfe_max_concat_backward')
         dz = bn_relu_backward(dyh, y, mi, fs, X.ROWS_VFE, fs.row_w, _grad_of(b), dz=dyh)
         _linear_wgrad_side(x, dz, w)
         gx, _ = _hip.linear_forward(dz, w, None, relu=False, want_stats=False, w_transposed=True)
-        # ---- VFE 2, VFE 1
-        for x, w, b, y, mi, am in reversed(S.vfe):
-            Cn = w.shape[0]
-            dyh = torch.empty((Rt + Vt, Cn), dtype=torch.float32, device=dev)
-            X.check(X.lib.mvx_vfe_max_concat_backward(X.ptr(gx), X.ptr(am), X.ptr(dyh), Vt, T, Cn, X.ptr(fs.voff), X.ptr(fs.vcnt),
-                                                      Rt, X.stream()), 'mvx_vfe_max_concat_backward')
-            dz = bn_relu_backward(dyh, y, mi, fs, X.ROWS_VFE, fs.row_w, _grad_of(b), dz=dyh)
-            _linear_wgrad_side(x, dz, w)
-            gx, _ = _hip.linear_forward(dz, w, None, relu=False, want_stats=False, w_transposed=True)
-        # ---- concat backward: gradient of the fused image features ([real rows | shared padded row per frame])
-        Fc = S.fc
-        gim = torch.empty((Rt + F, Fc), dtype=torch.float32, device=dev)
-        scratch = torch.empty((F * Fc,), dtype=torch.float64, device=dev)
-        X.check(X.lib.mvx_vfe_compact_input_backward_frames(X.ptr(gx), Fc, Rt, Vt, X.ptr(gim), X.ptr(scratch), fs.desc.ref(),
-                                                            X.stream()), 'mvx_vfe_compact_input_backward_frames')
-        # ---- fusion MLP, last layer first; the sampled features carry no gradient
-        gx = gim
-        for i in range(len(S.fusion) - 1, -1, -1):
-            x, w, b, y, mi = S.fusion[i]
-            dz = bn_relu_backward(gx, y, mi, fs, X.ROWS_FUSION, fs.fusion_row_w, _grad_of(b))
-            _linear_wgrad_side(x, dz, w)
-            if i > 0:
-                gx, _ = _hip.linear_forward(dz, w.reshape(w.shape[0], -1), None, relu=False, want_stats=False, w_transposed=True)
-    finally:
-        _hip.ASYNC_WGRAD = old_async
+    # ---- concat backward: gradient of the fused image features ([real rows | shared padded row per frame])
+    Fc = S.fc
+    gim = torch.empty((Rt + F, Fc), dtype=torch.float32, device=dev)
+    scratch = torch.empty((F * Fc,), dtype=torch.float64, device=dev)
+    X.check(X.lib.mvx_vfe_compact_input_backward_frames(X.ptr(gx), Fc, Rt, Vt, X.ptr(gim), X.ptr(scratch), fs.desc.ref(),
+                                                        X.stream()), 'mvx_vfe_compact_input_backward_frames')
+    # ---- fusion MLP, last layer first; the sampled features carry no gradient
+    gx = gim
+    for i in range(len(S.fusion) - 1, -1, -1):
+        x, w, b, y, mi = S.fusion[i]
+        dz = bn_relu_backward(gx, y, mi, fs, X.ROWS_FUSION, fs.fusion_row_w, _grad_of(b))
+        _linear_wgrad_side(x, dz, w)
+        if i > 0:
+            gx, _ = _hip.linear_forward(dz, w.reshape(w.shape[0], -1), None, relu=False, want_stats=False, w_transposed=True)

@@ -29,23 +29,47 @@ def lane_streams(device, n):
 
 
 class FrameBatch:
-    """B frames resident in HBM with a fixed point capacity per frame."""
+    """B frames resident in HBM with a fixed point capacity per frame.  Either the prepared clouds ``points6`` /
+    ``n_points`` or the RAW clouds ``raw`` (B, capRaw, 4) + ``calib`` (dict of 4x4 matrices, modules/data/Load.py:24-41): the
+    pipeline then runs crop + cropToSight + lidar2Img on the GPU first (cropdata.py:30-65, train.py:31-34)."""
 
-    def __init__(self, points6, perms, n_points, fpn_levels):
+    def __init__(self, points6, perms, n_points, fpn_levels, raw=None, calib=None, cap_points=None, n_raw=None):
         self.points6 = points6          # f32 (B, capP, 6)  x y z r row col
         self.perms = perms              # i32 (B, capP)
         self.n_points = n_points        # i32 (B,)
         self.fpn_levels = fpn_levels    # list over frames of [f0, f1, f2], each (1, C, H, W)
+        self.raw, self.n_raw, self.calib = raw, n_raw, calib
+        self.cap_points = cap_points if cap_points is not None else (points6.shape[1] if points6 is not None else None)
+        self._mats = None
 
     @property
     def n_frames(self):
-        return self.points6.shape[0]
+        return self.points6.shape[0] if self.points6 is not None else self.raw.shape[0]
+
+    @property
+    def device(self):
+        return self.points6.device if self.points6 is not None else self.raw.device
+
+    def prepared(self):
+        """(points6, n_points): as given, or cropped + projected from the raw clouds on the current stream."""
+        if self.raw is None:
+            return self.points6, self.n_points
+        if self._mats is None:
+            import numpy as np
+            c = self.calib
+            r0, tr, p2 = (np.asarray(c[k], dtype=np.float64) for k in ('R0_rect', 'Tr_velo_to_cam', 'P2'))
+            m32 = (torch.as_tensor(r0).float() @ torch.as_tensor(tr).float()).double().numpy()      # torch-path product (f32)
+            self._mats = (r0 @ tr, p2, m32, torch.as_tensor(p2).float().double().numpy())
+        m64, p64, m32, p32 = self._mats
+        imsize_wh = (float(cfg.imsize[1]), float(cfg.imsize[0]))
+        return _hip.crop_project(self.raw, self.n_raw, cfg.velorange, m64, p64, imsize_wh, m32, p32, self.cap_points)
 
 
 def voxelize_batch(batch, T=None):
     """One batched voxelizer call for all frames; a single host read of the voxel counts."""
     T = cfg.samplenum if T is None else T
-    res = _hip.voxelize(batch.points6, batch.perms, batch.n_points, cfg.velorange[0:3], cfg.voxelsize, T, 9)
+    points6, n_points = batch.prepared()
+    res = _hip.voxelize(points6, batch.perms, n_points, cfg.velorange[0:3], cfg.voxelsize, T, 9)
     counts = res.n_voxels.tolist()      # host sync: output sizes are data dependent
     frames = []
     for f, v in enumerate(counts):
@@ -178,7 +202,7 @@ def train_step_frames(model, batch, grad_mid, imsize, ready=None, prepare_next=N
     # with one fill
     old_sink, _hip.GRAD_SINK = _hip.GRAD_SINK, True
     old_async, _hip.ASYNC_WGRAD = _hip.ASYNC_WGRAD, ASYNC_WGRAD
-    dev = batch.points6.device
+    dev = batch.device
     main = torch.cuda.current_stream(dev)
     lanes = lane_streams(dev, LANES) if (LANES > 1 and ASYNC_WGRAD) else [main]
     if ev_ready is not None:
@@ -239,7 +263,8 @@ def prepare_frame_set(batch, T=None):
     every frame of the batch, status word)."""
     from modules import frames as fr
     T = cfg.samplenum if T is None else T
-    res = _hip.voxelize(batch.points6, batch.perms, batch.n_points, cfg.velorange[0:3], cfg.voxelsize, T, 9)
+    points6, n_points = batch.prepared()
+    res = _hip.voxelize(points6, batch.perms, n_points, cfg.velorange[0:3], cfg.voxelsize, T, 9)
     counts = res.n_voxels.tolist()                  # host read 1: output sizes are data dependent
     live = [f for f, v in enumerate(counts) if v > 0]
     if not live:
@@ -269,7 +294,7 @@ def train_step_frame_set(model, batch, grad_mid, imsize, ready=None, prepare_nex
     host reads only wait for those few small kernels (which share the GPU with the step), so the host stays a step ahead
     of the GPU."""
     from modules import frames as fr
-    dev = batch.points6.device
+    dev = batch.device
     main = torch.cuda.current_stream(dev)
     ev_ready = None
     if ready is None:
@@ -313,3 +338,56 @@ def train_step_frame_set(model, batch, grad_mid, imsize, ready=None, prepare_nex
     if prepare_next is not None:
         return counts, statuses, next_ready
     return counts, statuses
+
+
+def train_step_rows_only(model, batch, state, ready=None, prepare_next=None):
+    """BASELINE.json config 2 ("VFE-only"): crop + projection, voxelizer, then the VFE stack -- SVFE + FCN + max
+    (voxelnet/Pipe.py:5-29, VoxelNet.py:27-33) -- forward and backward for all frames as one frame set.  The 16 fused image
+    channels of every row and dL/d(voxel features) are resident random tensors (``state`` caches them) standing for the
+    fusion branch and for everything behind the VFE, which this configuration does not run."""
+    from modules import frames as fr
+    dev = batch.device
+    main = torch.cuda.current_stream(dev)
+    ev_ready = None
+    if ready is None:
+        ready = prepare_frame_set(batch)
+    elif len(ready) == 5:
+        ready, ev_ready = ready[:4], ready[4]
+    fs, live, counts, status = ready
+    if ev_ready is not None:
+        main.wait_event(ev_ready)
+        status.record_stream(main)
+        if fs is not None:
+            fs.hand_over(main)
+    old_sink, _hip.GRAD_SINK = _hip.GRAD_SINK, True
+    old_async, _hip.ASYNC_WGRAD = _hip.ASYNC_WGRAD, True
+    next_ready = None
+    try:
+        if fs is not None:
+            cap_rows = batch.n_frames * (batch.cap_points + 1)
+            if 'imfeat' not in state or state['imfeat'].shape[0] < cap_rows:
+                g = torch.Generator(device='cpu').manual_seed(5)
+                state['imfeat'] = torch.randn((cap_rows, 16), generator=g).to(dev)
+                state['dfeat'] = (torch.randn((batch.n_frames * batch.cap_points, 128), generator=g) * 1e-3).to(dev)
+            _hip.arena_begin(dev, doubles=1 << 21)
+            with torch.no_grad():
+                feat, saved = fr.rows_forward(model, fs, None, None, [], imfeat=state['imfeat'][:fs.Rt + fs.F])
+                fr.rows_backward(model, saved, state['dfeat'][:fs.Vt])
+        if prepare_next is not None:
+            if PREP_STREAM:
+                prep = _prep_stream(dev)
+                with torch.cuda.stream(prep):
+                    nr = prepare_frame_set(prepare_next)
+                    ev = torch.cuda.Event()
+                    ev.record(prep)
+                next_ready = nr + (ev,)
+            else:
+                next_ready = prepare_frame_set(prepare_next)
+    finally:
+        _hip.GRAD_SINK = old_sink
+        _hip.ASYNC_WGRAD = old_async
+        _hip.arena_end()
+        _hip.join_side_stream()
+    if prepare_next is not None:
+        return counts, [status], next_ready
+    return counts, [status]

@@ -27,4 +27,16 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
         assert k in r, k
     assert r['bound'] == 'mfma' and 0 < r['frac'] < 1 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
-    assert d['alt_modes'] and d['alt_modes'][0]['value'] > 0
+    assert d['alt_modes'] and all(a['value'] > 0 for a in d['alt_modes'])
+    assert {a['workload'] for a in d['alt_modes']} == {'S1', 'S2'}
+    assert d['config']['frame_sets'] and 'crop_project' in d['hbm_stages']
+
+
+@pytest.mark.gpu
+def test_bench_vfe_mode_checks_voxel_indices_against_the_oracle():
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--mode', 'vfe', '--steps', '2', '--warmup', '1', '--frames',
+                          '3', '--points', '4000'], capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith('{')][0])
+    assert d['roofline']['bound'] == 'hbm' and d['value'] > 0
+    assert d['cpu_baseline']['voxel_indices_vs_oracle'].startswith('ok') and d['cpu_baseline']['value'] > 0
