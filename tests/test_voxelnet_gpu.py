@@ -362,14 +362,16 @@ def test_rpn_hip_blocks_match_miopen_blocks():
     print('RPN gradients: worst HIP-vs-f64 %.2e' % worst)
 
 
-def test_pipeline_skips_empty_frames():
+@pytest.mark.parametrize('executor', ['train_step_frames', 'train_step_frame_set'])
+def test_pipeline_skips_empty_frames(executor):
     """A frame whose points were all cropped away (0 voxels) takes no part in the step: the other frames' gradients
     are the same as without it, and nothing raises (the reference cannot run on such a frame: BatchNorm over 0 rows)."""
     import bench
     import modules.config as cfg
     from MVXNet import MVXNet
     from modules import parallel
-    from modules.pipeline import train_step_frames
+    import modules.pipeline as pipeline_mod
+    train_step_frames = getattr(pipeline_mod, executor)
     torch.manual_seed(4)
     model = MVXNet().to(DEV)
     hot = [p for k, p in model.named_parameters() if p.requires_grad and '.rpn.' not in k]
@@ -377,7 +379,7 @@ def test_pipeline_skips_empty_frames():
     grad_mid = torch.randn((1, 128, cfg.voxelshape[0], cfg.voxelshape[1]), device=DEV) * 1e-3
     imsize = [float(v) for v in cfg.imsize]
     batch = bench.make_batch([0, 1], DEV, 6000)
-    batch.n_points[1] = 0
+    batch.n_raw = torch.tensor([batch.raw.shape[1], 0], dtype=torch.int32, device=DEV)      # frame 1: every point cropped away
     bucket.zero()
     nv, st = train_step_frames(model, batch, grad_mid, imsize)
     assert nv[0] > 0 and nv[1] == 0 and all(int(s) == 0 for s in st)
@@ -386,6 +388,7 @@ def test_pipeline_skips_empty_frames():
     bucket.zero()
     train_step_frames(model, one, grad_mid, imsize)
     assert bool(torch.isfinite(got).all()) and rel_err(got, bucket.flat) < 1e-5
+    torch.cuda.synchronize()
     # ... and a repeated step reproduces them (this is what exposed a tensor the side stream read after the frame's
     # own stream had recycled it: every operand of a side-stream kernel must be recorded for that stream)
     again = bucket.flat.clone()
