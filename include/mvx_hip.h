@@ -107,6 +107,13 @@ int mvx_abi_version(void);
  *   status     i32 [1]                     OR-ed flags: bit0 = an index fell outside the
  *                                          21-bit key range, bit1 = cap_voxels exceeded
  * cap_voxels >= cap_points always suffices.
+ *
+ * mvx_voxelize_frames: the same with the batch layout as an option.  concat = 0: as above.  concat != 0: the voxels of
+ *   all frames are written BACK TO BACK in frame order -- voxels [cap_voxels][T][C], coords [cap_voxels][4] with
+ *   coords[:,0] = frame index (the batch column of train.py:119), counts [cap_voxels]; cap_voxels is then the TOTAL
+ *   capacity (n_frames * cap_points always suffices).  vox_off (optional) i32 [n_frames + 1] on the device = voxel
+ *   offsets of the frames (vox_off[n_frames] = total).  n_frames <= 255.
+ * Three launches (insert, one look-back scan over all frames, gather) and two memsets per call.
  */
 size_t mvx_voxelize_workspace_bytes(int32_t n_frames, int32_t cap_points);
 
@@ -117,6 +124,13 @@ int mvx_voxelize(const float *pcd, const int32_t *perm, const int32_t *n_points,
                  int32_t T, int32_t out_channels, int32_t cap_voxels,
                  float *voxels, int64_t *coords, int32_t *counts, int32_t *n_voxels,
                  int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
+int mvx_voxelize_frames(const float *pcd, const int32_t *perm, const int32_t *n_points,
+                        const int32_t *ext_idx, int32_t n_frames, int32_t cap_points, int32_t ncol,
+                        double lo_x, double lo_y, double lo_z,
+                        double size_x, double size_y, double size_z,
+                        int32_t T, int32_t out_channels, int32_t cap_voxels, int32_t concat,
+                        float *voxels, int64_t *coords, int32_t *counts, int32_t *n_voxels, int32_t *vox_off,
+                        int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sparse voxel rows <-> dense grid.  Replaces VoxelNet.reindex (modules/voxelnet/VoxelNet.py:16-22,

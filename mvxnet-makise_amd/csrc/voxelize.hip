@@ -1,22 +1,24 @@
 // Point-cloud voxelizer for gfx950.
 //
 // Replaces the reference's sequential hash-map grouping (cpp/voxelutil.cpp:325-360 and the
-// Python loop of modules/data/Preprocessing.py:94-116) with five stream-ordered launches that
+// Python loop of modules/data/Preprocessing.py:94-116) with THREE stream-ordered launches (+ two memsets) that
 // reproduce its ORDER semantics exactly:
 //   voxel order  = order of first appearance in the (shuffled) point stream,
 //   kept points  = the first T stream positions that fall in the voxel, in stream order,
 //   index math   = (int32)(((double)xyz - low) / size) in f64 with true division,
 //   centroid     = sequential f64 (or f32, 7-channel mode) sum in stream order / count.
 //
-//   K0 init     : hash table reset
-//   K1 insert   : one thread per stream position -> open-addressing insert keyed by the packed
-//                 (ix,iy,iz); atomicMin records the first stream position of each key
-//   K2 scan     : one 1024-thread workgroup per frame: first-appearance flags -> voxel ids,
-//                 then per-voxel point counts -> segment offsets (CSR)
-//   K3 append   : every stream position joins its voxel's segment (unordered)
-//   K4 gather   : one wave per voxel: selects the T smallest stream positions of the segment in
-//                 order (wave-wide rank counting), stages the point group in LDS, reduces the
-//                 centroid, and writes the [T][C] block with coalesced stores.
+//   K1 insert : one thread per stream position -> open-addressing insert keyed by the packed (ix,iy,iz); atomicMin
+//               records the first stream position of each key; the position also joins the key's 64-entry bucket
+//               (arrival order, i.e. unordered)
+//   K2 scan   : "I am my voxel's first point" flags -> voxel ids in first-appearance order: ONE decoupled-look-back scan
+//               over the positions of ALL frames (work-item ticket per block, packed flag|value words, no fences), so a
+//               frame's voxels follow the previous frame's; per-frame voxel offsets fall out of it
+//   K3 gather : one wave per voxel: sorts the bucket (<= 64 members: wave-wide rank counting over the actual member
+//               count) or, for the few voxels with more members, walks the frame's stream in order until T members are
+//               found; stages the point group in LDS, reduces the centroid, writes the [T][C] block with coalesced stores.
+// Outputs either with a fixed stride per frame ([F][cap_voxels]...) or back to back over all frames (concat: the batch
+// layout of the frame-set path, coords[:,0] = frame index = the batch column of train.py:119).
 #include "common.h"
 
 namespace {
@@ -24,18 +26,23 @@ namespace {
 constexpr unsigned long long KEY_EMPTY = ~0ull;
 constexpr int KEY_BIAS = 1 << 20;
 
+constexpr int BK = 64;                  // bucket entries per key
+
 struct VoxWs {
-    unsigned long long *keys;  // [F][slots]
-    int *first;                // [F][slots] smallest stream position of the key
-    int *scount;               // [F][slots] points with this key
-    int *slot_vid;             // [F][slots] voxel id of the key
-    int *slot_of;              // [F][cap]   slot of stream position s
-    int *vox_slot;             // [F][cap]   slot of voxel v
-    int *seg_off;              // [F][cap+1] CSR offsets of voxel segments
-    int *cursor;               // [F][cap]
-    int *members;              // [F][cap]   stream positions grouped by voxel
-    int slots;
+    unsigned long long *keys;  // [F][slots]        (memset 0xFF = KEY_EMPTY)
+    unsigned *first;           // [F][slots]        smallest stream position of the key (memset 0xFF)
+    int *scount;               // [F][slots]        points with this key            (memset 0 from here ...)
+    unsigned *ticket;          // [4]               work-item counter of the scan
+    unsigned long long *bstate;// [nblk]            look-back words: flag << 62 | value   (... to here)
+    int *frame_base;           // [F+1]             id of the first voxel of frame f (written by the scan)
+    int *slot_of;              // [F][cap]          slot of stream position s
+    int *vox_slot;             // [F*cap]           slot of (global) voxel v
+    int *bucket;               // [F][slots][BK]    stream positions of the key, arrival order
+    int slots, nblk;
+    size_t ff_bytes, zero_bytes;   // extents of the two memsets (from keys / from scount)
 };
+
+constexpr int SCAN_POS = 1024;          // stream positions per scan workgroup (256 threads x 4)
 
 __host__ inline int table_slots(int cap_points) {
     int s = 64;
@@ -48,32 +55,24 @@ __host__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 __host__ VoxWs carve(void *ws, int F, int cap, size_t *total) {
     VoxWs w;
     w.slots = table_slots(cap);
+    w.nblk = (int)(((long long)F * cap + SCAN_POS - 1) / SCAN_POS);
     size_t off = 0;
     char *base = (char *)ws;
     auto take = [&](size_t bytes) { char *p = base ? base + off : nullptr; off += align256(bytes); return p; };
     w.keys = (unsigned long long *)take((size_t)F * w.slots * 8);
-    w.first = (int *)take((size_t)F * w.slots * 4);
+    w.first = (unsigned *)take((size_t)F * w.slots * 4);
+    w.ff_bytes = off;
+    const size_t z0 = off;
     w.scount = (int *)take((size_t)F * w.slots * 4);
-    w.slot_vid = (int *)take((size_t)F * w.slots * 4);
+    w.ticket = (unsigned *)take(16);
+    w.bstate = (unsigned long long *)take((size_t)w.nblk * 8);
+    w.zero_bytes = off - z0;
+    w.frame_base = (int *)take((size_t)(F + 1) * 4);
     w.slot_of = (int *)take((size_t)F * cap * 4);
     w.vox_slot = (int *)take((size_t)F * cap * 4);
-    w.seg_off = (int *)take((size_t)F * (cap + 1) * 4);
-    w.cursor = (int *)take((size_t)F * cap * 4);
-    w.members = (int *)take((size_t)F * cap * 4);
+    w.bucket = (int *)take((size_t)F * w.slots * BK * 4);
     *total = off;
     return w;
-}
-
-__global__ void vox_init(VoxWs w, int cap) {
-    const int f = blockIdx.y;
-    const int stride = gridDim.x * blockDim.x;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < w.slots; i += stride) {
-        w.keys[(size_t)f * w.slots + i] = KEY_EMPTY;
-        w.first[(size_t)f * w.slots + i] = 0x7fffffff;
-        w.scount[(size_t)f * w.slots + i] = 0;
-    }
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += stride)
-        w.cursor[(size_t)f * cap + i] = 0;
 }
 
 __device__ __forceinline__ unsigned hash_key(unsigned long long k) {
@@ -123,129 +122,151 @@ __global__ void vox_insert(const float *__restrict__ pcd, const int *__restrict_
         }
         h = (h + 1) & mask;
     }
-    atomicMin(&w.first[(size_t)f * w.slots + h], s);
-    atomicAdd(&w.scount[(size_t)f * w.slots + h], 1);
+    const size_t slot = (size_t)f * w.slots + h;
+    atomicMin(&w.first[slot], (unsigned)s);
+    const int t = atomicAdd(&w.scount[slot], 1);
+    if (t < BK) w.bucket[slot * BK + t] = s;
     w.slot_of[(size_t)f * cap + s] = (int)h;
 }
 
-// One workgroup per frame.  Each thread owns a CONTIGUOUS run of stream positions (then of voxel ids), issues all its
-// dependent loads up front, scans its run locally and takes part in ONE block scan per phase -- the previous form
-// walked the stream in 1024-element rounds with a block scan (three barriers and two dependent loads) per round:
-// 25 serial rounds = 50 us per call whatever the batch size.
-constexpr int SCAN_K = 8;                 // positions per thread per pass (1024 x 8 = 8192 positions per pass)
-__global__ __launch_bounds__(1024) void vox_scan(const int *__restrict__ n_points, int cap, int cap_voxels,
-                                                 VoxWs w, int *n_voxels, int *status) {
+// Decoupled look-back scan of the first-point flags over the positions of all frames ([F][cap], positions past a
+// frame's live count are dead).  A workgroup takes the next 1024 positions from a ticket counter, so a workgroup only
+// ever waits for workgroups that started before it (no deadlock whatever the dispatch order).  Look-back words pack
+// (flag, value) into one 64-bit atomic: 1 = aggregate of this block, 2 = inclusive prefix up to and including it.
+__global__ __launch_bounds__(256) void vox_scan(const int *__restrict__ n_points, int cap, int F, VoxWs w) {
     __shared__ int smem[17];
-    const int f = blockIdx.x;
-    const int n = min(n_points[f], cap);
-    const int *first = w.first + (size_t)f * w.slots;
-    const int *scount = w.scount + (size_t)f * w.slots;
-    const int *slot_of = w.slot_of + (size_t)f * cap;
-    int *slot_vid = w.slot_vid + (size_t)f * w.slots;
-    int *vox_slot = w.vox_slot + (size_t)f * cap;
-    int *seg_off = w.seg_off + (size_t)f * (cap + 1);
-    int base = 0;
-    for (int t0 = 0; t0 < n; t0 += blockDim.x * SCAN_K) {
-        const int s0 = t0 + threadIdx.x * SCAN_K;
-        int slot[SCAN_K], flag[SCAN_K], mine = 0;
+    __shared__ unsigned s_ticket;
+    __shared__ int s_prefix;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(w.ticket, 1u);
+    __syncthreads();
+    const int b = (int)s_ticket;
+    const long long total_pos = (long long)F * cap;
+    const long long g0 = (long long)b * SCAN_POS + threadIdx.x * 4;
+    int slot[4], flag[4], fr[4], mine = 0;
 #pragma unroll
-        for (int j = 0; j < SCAN_K; ++j) slot[j] = s0 + j < n ? slot_of[s0 + j] : -1;
-#pragma unroll
-        for (int j = 0; j < SCAN_K; ++j) {
-            flag[j] = slot[j] >= 0 && first[slot[j]] == s0 + j;       // "I am my voxel's first point"
-            mine += flag[j];
-        }
-        int tot;
-        int v = base + block_excl_scan_i32(mine, smem, &tot);
-#pragma unroll
-        for (int j = 0; j < SCAN_K; ++j)
-            if (flag[j]) {
-                slot_vid[slot[j]] = v;
-                vox_slot[v] = slot[j];
-                ++v;
+    for (int j = 0; j < 4; ++j) {
+        const long long g = g0 + j;
+        slot[j] = -1; flag[j] = 0; fr[j] = 0;
+        if (g < total_pos) {
+            const int f = (int)(g / cap), s = (int)(g - (long long)f * cap);
+            fr[j] = f;
+            if (s < min(n_points[f], cap)) {
+                slot[j] = w.slot_of[g];
+                flag[j] = w.first[(size_t)f * w.slots + slot[j]] == (unsigned)s;       // "I am my voxel's first point"
             }
-        base += tot;
+        }
+        mine += flag[j];
     }
-    const int V = base;
+    int tot;
+    const int my_off = block_excl_scan_i32(mine, smem, &tot);
     if (threadIdx.x == 0) {
-        n_voxels[f] = V;
-        if (V > cap_voxels) atomicOr(status, 2);
+        const unsigned long long word = ((b == 0 ? 2ull : 1ull) << 62) | (unsigned long long)(unsigned)tot;
+        __hip_atomic_store(w.bstate + b, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();   // vox_slot[] written above is read below by other threads of this block
-    int run = 0;
-    for (int t0 = 0; t0 < V; t0 += blockDim.x * SCAN_K) {
-        const int v0 = t0 + threadIdx.x * SCAN_K;
-        int c[SCAN_K], mine = 0;
-#pragma unroll
-        for (int j = 0; j < SCAN_K; ++j) c[j] = v0 + j < V ? vox_slot[v0 + j] : -1;
-#pragma unroll
-        for (int j = 0; j < SCAN_K; ++j) {
-            c[j] = c[j] >= 0 ? scount[c[j]] : 0;
-            mine += c[j];
-        }
-        int tot;
-        int off = run + block_excl_scan_i32(mine, smem, &tot);
-#pragma unroll
-        for (int j = 0; j < SCAN_K; ++j)
-            if (v0 + j < V) {
-                seg_off[v0 + j] = off;
-                off += c[j];
+    if (threadIdx.x < 64) {            // wave 0 looks back over the predecessors, 64 at a time
+        int prefix = 0;
+        int k = b - 1;
+        while (k >= 0) {
+            const int idx = k - (int)threadIdx.x;
+            unsigned long long word = 2ull << 62;           // lanes before block 0: an (empty) inclusive prefix
+            if (idx >= 0) {
+                do {
+                    word = __hip_atomic_load(w.bstate + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } while ((word >> 62) == 0);
             }
-        run += tot;
+            const unsigned long long incl = __ballot((word >> 62) == 2ull);
+            const int stop = __ffsll((long long)incl) - 1;                   // nearest predecessor with an inclusive prefix
+            const int val = (int)(unsigned)(word & 0xffffffffull);
+            int part = ((int)threadIdx.x <= stop || stop < 0) ? val : 0;
+            if (idx < 0) part = 0;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+            prefix += part;
+            if (stop >= 0) break;
+            k -= 64;
+        }
+        if (threadIdx.x == 0) {
+            s_prefix = prefix;
+            if (b > 0)
+                __hip_atomic_store(w.bstate + b, (2ull << 62) | (unsigned long long)(unsigned)(prefix + tot), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    if (threadIdx.x == 0) seg_off[V] = run;
+    __syncthreads();
+    int v = s_prefix + my_off;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long g = g0 + j;
+        if (g < total_pos && g - (long long)fr[j] * cap == 0) w.frame_base[fr[j]] = v;     // first position of a frame
+        if (flag[j]) w.vox_slot[v++] = slot[j];
+    }
+    if (g0 <= total_pos - 1 && total_pos - 1 < g0 + 4) w.frame_base[F] = v;               // the thread that owns the last position
 }
 
-__global__ void vox_append(const int *__restrict__ n_points, int cap, VoxWs w) {
-    const int f = blockIdx.y;
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = min(n_points[f], cap);
-    if (s >= n) return;
-    const int v = w.slot_vid[(size_t)f * w.slots + w.slot_of[(size_t)f * cap + s]];
-    const int pos = atomicAdd(&w.cursor[(size_t)f * cap + v], 1);
-    w.members[(size_t)f * cap + w.seg_off[(size_t)f * (cap + 1) + v] + pos] = s;
-}
-
-// One wave per voxel.  LDS per wave: 64 candidate slots + the staged point group.
+// One wave per (global) voxel.  LDS per wave: 64 sorted member slots + the staged point group.
 template <int C>
 __global__ __launch_bounds__(256) void vox_gather(const float *__restrict__ pcd, const int *__restrict__ perm,
-                                                  int cap, int ncol, int T, int cap_voxels, VoxWs w,
-                                                  const int *__restrict__ n_voxels,
-                                                  float *__restrict__ voxels, long long *__restrict__ coords,
-                                                  int *__restrict__ counts) {
+                                                  const int *__restrict__ n_points, int cap, int ncol, int T, int F,
+                                                  int cap_voxels, int concat, VoxWs w, float *__restrict__ voxels,
+                                                  long long *__restrict__ coords, int *__restrict__ counts,
+                                                  int *__restrict__ n_voxels, int *__restrict__ vox_off,
+                                                  int *__restrict__ status) {
     __shared__ int s_best[4][64];
     __shared__ float s_pts[4][64][6];
-    const int f = blockIdx.y;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int v = blockIdx.x * 4 + wid;
-    const int V = min(n_voxels[f], cap_voxels);
-    if (v >= V) return;   // whole wave leaves together: no block-wide barrier below
-    const int *seg_off = w.seg_off + (size_t)f * (cap + 1);
-    const int *members = w.members + (size_t)f * cap;
-    const int beg = seg_off[v], n = seg_off[v + 1] - beg;
-
-    // ---- the (up to) 64 smallest stream positions of the segment, sorted: lane r holds rank r
-    int best = 0x7fffffff;
-    for (int c0 = 0; c0 < n; c0 += 64) {
-        const int cand = (c0 + lane < n) ? members[beg + c0 + lane] : 0x7fffffff;
-        int rb = 0, rc = 0;   // ranks of `best` and `cand` inside best U cand (positions are unique)
-        for (int j = 0; j < 64; ++j) {
-            const int bj = __shfl(best, j, 64), cj = __shfl(cand, j, 64);
-            rb += (bj < best) + (cj < best);
-            rc += (bj < cand) + (cj < cand);
+    if (blockIdx.x == 0 && threadIdx.x <= F) {          // per-frame counts / offsets for the caller
+        const int f = threadIdx.x;
+        if (vox_off) vox_off[f] = w.frame_base[f];
+        if (f < F) {
+            const int nv = w.frame_base[f + 1] - w.frame_base[f];
+            n_voxels[f] = nv;
+            if (!concat && nv > cap_voxels) atomicOr(status, 2);
         }
-        // sentinels tie with each other; give them distinct ranks past every real value
-        if (best == 0x7fffffff) rb = 128 + lane;
-        if (cand == 0x7fffffff) rc = 192 + lane;
+        if (f == F && concat && w.frame_base[F] > cap_voxels) atomicOr(status, 2);
+    }
+    const int Vtot = w.frame_base[F];
+    if (v >= Vtot) return;   // whole wave leaves together: no block-wide barrier below
+    int f = 0;
+    while (f + 1 < F && v >= w.frame_base[f + 1]) ++f;
+    const int vl = v - w.frame_base[f];
+    const long long dst = concat ? (long long)v : (long long)f * cap_voxels + vl;
+    if (concat ? v >= cap_voxels : vl >= cap_voxels) return;
+    const int h = w.vox_slot[v];
+    const size_t slot = (size_t)f * w.slots + h;
+    const int n = w.scount[slot];
+
+    // ---- the (up to) T smallest stream positions of the voxel, sorted: lane r holds rank r
+    int best = 0x7fffffff;
+    if (n <= BK) {
+        const int cand = lane < n ? w.bucket[slot * BK + lane] : 0x7fffffff;
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += __shfl(cand, j, 64) < cand;       // positions are unique
         __builtin_amdgcn_wave_barrier();
         s_best[wid][lane] = 0x7fffffff;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (rb < 64) s_best[wid][rb] = best;
-        if (rc < 64) s_best[wid][rc] = cand;
+        if (lane < n) s_best[wid][rank] = cand;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         best = s_best[wid][lane];
+    } else {
+        // crowded voxel: the bucket holds an arbitrary subset -- walk the frame's stream in order, the first T matches
+        // are the answer (already sorted)
+        const int npts = min(n_points[f], cap);
+        const int *so = w.slot_of + (size_t)f * cap;
+        int found = 0;
+        for (int s0 = 0; s0 < npts && found < T; s0 += 64) {
+            const int s = s0 + lane;
+            const bool match = s < npts && so[s] == h;
+            const unsigned long long bal = __ballot(match);
+            const int pos = found + __popcll(bal & ((1ull << lane) - 1ull));
+            if (match && pos < 64) s_best[wid][pos] = s;
+            found += __popcll(bal);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        best = lane < min(found, 64) ? s_best[wid][lane] : 0x7fffffff;
     }
     const int kept = min(n, T);
 
@@ -287,7 +308,7 @@ __global__ __launch_bounds__(256) void vox_gather(const float *__restrict__ pcd,
 
     // ---- coalesced write of the [T][C] block; padded rows carry -centroid in cols 3:6
     //      (Preprocessing.py:115)
-    float *out = voxels + ((size_t)f * cap_voxels + v) * (size_t)T * C;
+    float *out = voxels + (size_t)dst * (size_t)T * C;
     for (int e = lane; e < T * C; e += 64) {
         const int t = e / C, c = e - t * C;
         const bool real = t < kept;
@@ -304,13 +325,13 @@ __global__ __launch_bounds__(256) void vox_gather(const float *__restrict__ pcd,
         out[e] = val;
     }
     if (lane == 0) {
-        const unsigned long long key = w.keys[(size_t)f * w.slots + w.vox_slot[(size_t)f * cap + v]];
-        long long *cd = coords + ((size_t)f * cap_voxels + v) * 4;
-        cd[0] = 0;
+        const unsigned long long key = w.keys[slot];
+        long long *cd = coords + (size_t)dst * 4;
+        cd[0] = concat ? f : 0;                       // batch column (train.py:119): the frame inside a concatenated batch
         cd[1] = (long long)(int)(key & 0x1fffff) - KEY_BIAS;
         cd[2] = (long long)(int)((key >> 21) & 0x1fffff) - KEY_BIAS;
         cd[3] = (long long)(int)((key >> 42) & 0x1fffff) - KEY_BIAS;
-        counts[(size_t)f * cap_voxels + v] = kept;
+        counts[dst] = kept;
     }
 }
 
@@ -325,6 +346,47 @@ extern "C" size_t mvx_voxelize_workspace_bytes(int32_t n_frames, int32_t cap_poi
     return total;
 }
 
+extern "C" int mvx_voxelize_frames(const float *pcd, const int32_t *perm, const int32_t *n_points,
+                                   const int32_t *ext_idx, int32_t n_frames, int32_t cap_points, int32_t ncol,
+                                   double lo_x, double lo_y, double lo_z,
+                                   double size_x, double size_y, double size_z,
+                                   int32_t T, int32_t out_channels, int32_t cap_voxels, int32_t concat,
+                                   float *voxels, int64_t *coords, int32_t *counts, int32_t *n_voxels, int32_t *vox_off,
+                                   int32_t *status, void *workspace, size_t workspace_bytes, void *stream) {
+    MVX_CHECK_ARG(pcd && n_points && voxels && coords && counts && n_voxels && status && workspace);
+    MVX_CHECK_ARG(n_frames > 0 && n_frames <= 255 && cap_points > 0 && cap_voxels > 0 && ncol >= 4);
+    MVX_CHECK_ARG(T > 0 && T <= 64);
+    MVX_CHECK_ARG(out_channels == 7 || out_channels == 9);
+    MVX_CHECK_ARG(size_x > 0 && size_y > 0 && size_z > 0);
+    if ((long long)cap_points > (1ll << 28) || (long long)cap_points * n_frames >= (1ll << 31)) return MVX_ESIZE;
+    size_t need = 0;
+    VoxWs w = carve(workspace, n_frames, cap_points, &need);
+    MVX_CHECK_ARG(workspace_bytes >= need);
+    hipStream_t st = (hipStream_t)stream;
+
+    hipError_t e = hipMemsetAsync(w.keys, 0xFF, w.ff_bytes, st);             // empty keys, first = UINT_MAX
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(w.scount, 0, w.zero_bytes, st);                         // counts, scan ticket, look-back words
+    if (e != hipSuccess) return (int)e;
+    const unsigned gb = mvx_cdiv(cap_points, 256);
+    hipLaunchKernelGGL(vox_insert, dim3(gb, n_frames), dim3(256), 0, st, pcd, perm, n_points, ext_idx, cap_points, ncol,
+                       lo_x, lo_y, lo_z, size_x, size_y, size_z, w, status);
+    MVX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(vox_scan, dim3(w.nblk), dim3(256), 0, st, n_points, cap_points, n_frames, w);
+    MVX_LAUNCH_CHECK();
+    const long long vmax = concat ? (cap_voxels < (long long)cap_points * n_frames ? cap_voxels : (long long)cap_points * n_frames)
+                                  : (long long)cap_points * n_frames;
+    const dim3 gg(mvx_cdiv(vmax, 4));
+    if (out_channels == 9)
+        hipLaunchKernelGGL(vox_gather<9>, gg, dim3(256), 0, st, pcd, perm, n_points, cap_points, ncol, T, n_frames, cap_voxels,
+                           concat, w, voxels, (long long *)coords, counts, n_voxels, vox_off, status);
+    else
+        hipLaunchKernelGGL(vox_gather<7>, gg, dim3(256), 0, st, pcd, perm, n_points, cap_points, ncol, T, n_frames, cap_voxels,
+                           concat, w, voxels, (long long *)coords, counts, n_voxels, vox_off, status);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
 extern "C" int mvx_voxelize(const float *pcd, const int32_t *perm, const int32_t *n_points,
                             const int32_t *ext_idx, int32_t n_frames, int32_t cap_points, int32_t ncol,
                             double lo_x, double lo_y, double lo_z,
@@ -332,35 +394,7 @@ extern "C" int mvx_voxelize(const float *pcd, const int32_t *perm, const int32_t
                             int32_t T, int32_t out_channels, int32_t cap_voxels,
                             float *voxels, int64_t *coords, int32_t *counts, int32_t *n_voxels,
                             int32_t *status, void *workspace, size_t workspace_bytes, void *stream) {
-    MVX_CHECK_ARG(pcd && n_points && voxels && coords && counts && n_voxels && status && workspace);
-    MVX_CHECK_ARG(n_frames > 0 && cap_points > 0 && cap_voxels > 0 && ncol >= 4);
-    MVX_CHECK_ARG(T > 0 && T <= 64);
-    MVX_CHECK_ARG(out_channels == 7 || out_channels == 9);
-    MVX_CHECK_ARG(size_x > 0 && size_y > 0 && size_z > 0);
-    if ((long long)cap_points > (1ll << 28)) return MVX_ESIZE;
-    size_t need = 0;
-    VoxWs w = carve(workspace, n_frames, cap_points, &need);
-    MVX_CHECK_ARG(workspace_bytes >= need);
-    hipStream_t st = (hipStream_t)stream;
-
-    const unsigned gb = mvx_cdiv(cap_points, 256);
-    hipLaunchKernelGGL(vox_init, dim3(mvx_cdiv(w.slots, 256), n_frames), dim3(256), 0, st, w, cap_points);
-    MVX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(vox_insert, dim3(gb, n_frames), dim3(256), 0, st, pcd, perm, n_points, ext_idx, cap_points, ncol,
-                       lo_x, lo_y, lo_z, size_x, size_y, size_z, w, status);
-    MVX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(vox_scan, dim3(n_frames), dim3(1024), 0, st, n_points, cap_points, cap_voxels, w,
-                       n_voxels, status);
-    MVX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(vox_append, dim3(gb, n_frames), dim3(256), 0, st, n_points, cap_points, w);
-    MVX_LAUNCH_CHECK();
-    const dim3 gg(mvx_cdiv(cap_voxels < cap_points ? cap_voxels : cap_points, 4), n_frames);
-    if (out_channels == 9)
-        hipLaunchKernelGGL(vox_gather<9>, gg, dim3(256), 0, st, pcd, perm, cap_points, ncol, T, cap_voxels, w,
-                           n_voxels, voxels, (long long *)coords, counts);
-    else
-        hipLaunchKernelGGL(vox_gather<7>, gg, dim3(256), 0, st, pcd, perm, cap_points, ncol, T, cap_voxels, w,
-                           n_voxels, voxels, (long long *)coords, counts);
-    MVX_LAUNCH_CHECK();
-    return MVX_OK;
+    return mvx_voxelize_frames(pcd, perm, n_points, ext_idx, n_frames, cap_points, ncol, lo_x, lo_y, lo_z, size_x, size_y,
+                               size_z, T, out_channels, cap_voxels, 0, voxels, coords, counts, n_voxels, nullptr, status,
+                               workspace, workspace_bytes, stream);
 }

@@ -31,6 +31,8 @@ PROTOTYPES = {
     'mvx_voxelize_workspace_bytes': (_sz, [_i32, _i32]),
     'mvx_voxelize': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _f64, _f64, _f64, _f64, _f64, _f64,
                             _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    'mvx_voxelize_frames': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _f64, _f64, _f64, _f64, _f64, _f64,
+                                   _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     'mvx_crop_workspace_bytes': (_sz, [_i32, _i32]),
     'mvx_crop_points': (_i32, [_p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _f64, _f64, _i32, _p, _p, _p, _p, _sz, _p]),
     'mvx_crop_project_workspace_bytes': (_sz, [_i32, _i32]),

@@ -232,6 +232,31 @@ def voxelize(pcd, perm, n_points, lo, size, T, out_channels, cap_voxels=None, ex
     return VoxelizeResult(voxels, coords, counts, n_vox, status)
 
 
+def voxelize_concat(pcd, perm, n_points, lo, size, T, out_channels):
+    """The batch layout: voxels of all frames back to back.  Returns (voxels (F*cap,T,C), coords (F*cap,4) with the frame
+    index in column 0, counts, n_voxels i32 (F,), vox_off i32 (F+1,), status) -- capacity-sized, offsets on the device."""
+    assert pcd.dim() == 3 and pcd.dtype == torch.float32
+    F, cap, ncol = pcd.shape
+    dev = pcd.device
+    if n_points is None:
+        n_points = torch.full((F,), cap, dtype=torch.int32, device=dev)
+    total = F * cap
+    voxels = torch.empty((total, T, out_channels), dtype=torch.float32, device=dev)
+    coords = torch.empty((total, 4), dtype=torch.int64, device=dev)
+    counts = torch.empty((total,), dtype=torch.int32, device=dev)
+    n_vox = torch.empty((F,), dtype=torch.int32, device=dev)
+    vox_off = torch.empty((F + 1,), dtype=torch.int32, device=dev)
+    status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ws = workspace(X.lib.mvx_voxelize_workspace_bytes(F, cap), dev, 'voxelize')
+    with _timed_bytes('voxelize', F * cap * (ncol * 4 + 4) + F * (cap // 4) * (T * out_channels * 4 + 36)):
+        rc = X.lib.mvx_voxelize_frames(X.ptr(pcd), X.ptr(perm), X.ptr(n_points), None, F, cap, ncol,
+                                       float(lo[0]), float(lo[1]), float(lo[2]), float(size[0]), float(size[1]), float(size[2]),
+                                       int(T), int(out_channels), total, 1, X.ptr(voxels), X.ptr(coords), X.ptr(counts),
+                                       X.ptr(n_vox), X.ptr(vox_off), X.ptr(status), X.ptr(ws), ws.numel(), X.stream())
+    X.check(rc, 'mvx_voxelize_frames')
+    return voxels, coords, counts, n_vox, vox_off, status
+
+
 # ---------------------------------------------------------------------------------------------
 # dense grid scatter / gather
 # ---------------------------------------------------------------------------------------------

@@ -85,6 +85,8 @@ def synth_raw_around(kept: np.ndarray, frame_id: int, total: int = 120000, rng=V
     g = np.random.default_rng(4000 + frame_id)
     need = total - kept.shape[0]
     assert need >= 0
+    if need == 0:
+        return np.ascontiguousarray(kept[:, :4], np.float32)
     rejected, have = [], 0
     while have < need:
         cand = np.stack([g.uniform(-80, 80, 2 * need + 16), g.uniform(-80, 80, 2 * need + 16), g.uniform(-4, 3, 2 * need + 16),

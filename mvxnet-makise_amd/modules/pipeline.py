@@ -264,24 +264,22 @@ def prepare_frame_set(batch, T=None):
     from modules import frames as fr
     T = cfg.samplenum if T is None else T
     points6, n_points = batch.prepared()
-    res = _hip.voxelize(points6, batch.perms, n_points, cfg.velorange[0:3], cfg.voxelsize, T, 9)
-    counts = res.n_voxels.tolist()                  # host read 1: output sizes are data dependent
+    # the voxelizer writes the batch layout directly: voxels of all frames back to back, frame index in coords[:,0]
+    voxels, coords, _, _, vox_off, status_v = _hip.voxelize_concat(points6, batch.perms, n_points, cfg.velorange[0:3],
+                                                                   cfg.voxelsize, T, 9)
+    offs = vox_off.tolist()                         # host read 1: output sizes are data dependent
+    counts = [offs[f + 1] - offs[f] for f in range(batch.n_frames)]
     live = [f for f, v in enumerate(counts) if v > 0]
     if not live:
-        return None, [], counts, res.status
-    if len(live) == 1:
-        f = live[0]
-        voxels, coords = res.voxels[f, :counts[f]], res.coords[f, :counts[f]]
-    else:
-        voxels = torch.cat([res.voxels[f, :counts[f]] for f in live])
-        coords = torch.cat([res.coords[f, :counts[f]] for f in live])
+        return None, [], counts, status_v
+    voxels, coords = voxels[:offs[-1]], coords[:offs[-1]]
     off = [0]
-    for f in live:
+    for f in live:                                  # empty frames occupy no rows: the live frames stay back to back
         off.append(off[-1] + counts[f])
     fs = fr.FrameSet(voxels, coords, off, T)
     real_off = fs.enqueue_map().tolist()            # host read 2
     fs.finish_map(real_off)
-    return fs, live, counts, res.status
+    return fs, live, counts, status_v
 
 
 PREP_STREAM = _os.environ.get('MVX_PREP_STREAM', '1') != '0'    # next batch prepared on its own stream (host reads return early)
