@@ -173,3 +173,46 @@ def synth_perm(frame_id: int, P: int) -> np.ndarray:
 def synth_fpn(frame_id: int, shapes=((256, 104, 336), (256, 52, 168), (256, 26, 84))):
     g = np.random.default_rng(3000 + frame_id)
     return [g.standard_normal(s, dtype=np.float32) for s in shapes]
+
+
+def write_kitti_tree(root: str, frame_ids, points: int = 20000, raw_points: int = 120000, cars: int = 6, seed: int = 0):
+    """A KITTI-format directory tree with synthetic frames, for the reader / training-loop tests (there is no dataset on
+    the GPU box): training/{velodyne, velodyne_croped, label_2, calib, image_2} and ImageSets/train.txt, in the layout
+    modules/data/Load.py:17-20 and cropdata.py:21-28 expect.  Labels hold `cars` random 'Car' boxes (camera frame, KITTI
+    column order) plus one 'Pedestrian' row that the reader must skip."""
+    import os
+    from PIL import Image
+    t = os.path.join(root, 'training')
+    for d in ('velodyne', 'velodyne_croped', 'label_2', 'calib', 'image_2'):
+        os.makedirs(os.path.join(t, d), exist_ok=True)
+    os.makedirs(os.path.join(root, 'ImageSets'), exist_ok=True)
+    names = []
+    v2c = KITTI_CALIB['Tr_velo_to_cam']
+    for fid in frame_ids:
+        name = '%06d' % fid
+        names.append(name)
+        pc = synth_ring(fid, points)
+        pc.tofile(os.path.join(t, 'velodyne_croped', name + '.bin'))
+        synth_raw_around(pc, fid, raw_points).tofile(os.path.join(t, 'velodyne', name + '.bin'))
+        g = np.random.default_rng(seed * 1000 + fid)
+        img = g.integers(0, 256, (375, 1242, 3), dtype=np.uint8)
+        Image.fromarray(img).save(os.path.join(t, 'image_2', name + '.png'))
+        with open(os.path.join(t, 'calib', name + '.txt'), 'w') as f:
+            p2 = ' '.join('%.6e' % v for v in KITTI_CALIB['P2'][:3].reshape(-1))
+            r0 = ' '.join('%.6e' % v for v in KITTI_CALIB['R0_rect'][:3, :3].reshape(-1))
+            tr = ' '.join('%.6e' % v for v in v2c[:3].reshape(-1))
+            f.write('P0: %s\nP1: %s\nP2: %s\nP3: %s\nR0_rect: %s\nTr_velo_to_cam: %s\nTr_imu_to_velo: %s\n' % (p2, p2, p2, p2, r0, tr, tr))
+        with open(os.path.join(t, 'label_2', name + '.txt'), 'w') as f:
+            for k in range(cars):
+                # a car in the lidar frame, written in the camera frame (inverse of modules/Calc.py bboxCam2Lidar)
+                x, y, z = g.uniform(8, 60), g.uniform(-20, 20), g.uniform(-1.8, -1.2)
+                l, w, h = g.uniform(3.4, 4.4), g.uniform(1.5, 1.8), g.uniform(1.4, 1.7)
+                yaw = g.choice([0.0, np.pi / 2]) + g.normal(0, 0.05)
+                cam = v2c @ np.array([x, y, z, 1.0])
+                ry = yaw + 0.5 * np.pi
+                f.write('Car 0.00 0 0.00 100.00 100.00 200.00 200.00 %.4f %.4f %.4f %.4f %.4f %.4f %.4f\n'
+                        % (h, w, l, cam[0], cam[1], cam[2], ry))
+            f.write('Pedestrian 0.00 0 0.00 10.00 10.00 20.00 20.00 1.70 0.60 0.80 1.00 1.50 10.00 0.10\n')
+    with open(os.path.join(root, 'ImageSets', 'train.txt'), 'w') as f:
+        f.write('\n'.join(names) + '\n')
+    return names

@@ -389,3 +389,88 @@ def train_step_rows_only(model, batch, state, ready=None, prepare_next=None):
     if prepare_next is not None:
         return counts, [status], next_ready
     return counts, [status]
+
+
+# ---- whole model on the fast path: frame sets up to the BEV map, RPN + VoxelLoss per frame ------------------------------
+def batch_from_dataset(group, names, device, anchorBevs, fpn_fn, cap_points):
+    """Frames of ``modules.data.Load.createDataset`` -> (FrameBatch resident on the GPU, per-frame targets).  Per frame, as
+    train.py:26-49: lidar2Img on the torch path + (row, col) swap, the shuffle permutation drawn with np.random, and
+    classifyAnchors for the 'Car' boxes; (pi, ni, gi, gt) or None when the frame has no box."""
+    import numpy as np
+    from modules import Calc
+    from modules.data.Preprocessing import _calib_products
+    B = len(group)
+    pts6 = torch.zeros((B, cap_points, 6), dtype=torch.float32, device=device)
+    perms = np.zeros((B, cap_points), np.int32)
+    n = np.zeros((B,), np.int32)
+    fpn, targets = [], []
+    for k, (velo, img, bbox2d, bbox3d, bev, calib) in enumerate(group):
+        P = velo.shape[0]
+        src = torch.from_numpy(np.ascontiguousarray(velo, dtype=np.float32)).to(device)
+        pts6[k, :P, :4] = src
+        m, p2 = _calib_products(calib, True)
+        _hip.lidar2img(src, m, p2, math_f32=True, out=pts6[k, :P], col_offset=4, swap_rc=True)
+        a = np.arange(P, dtype=np.int32)
+        np.random.shuffle(a)
+        perms[k, :P] = a
+        n[k] = P
+        fpn.append(fpn_fn(names[k], device))
+        if bev is not None and bev.shape[0] != 0:
+            pi, ni, gi = Calc.classifyAnchors(bev, bbox3d[:, [0, 1]], anchorBevs, cfg.velorange, 0.45, 0.6)
+            targets.append((pi, ni, gi, bbox3d.to(device)))
+        else:
+            targets.append(None)
+    batch = FrameBatch(pts6, torch.from_numpy(perms).to(device), torch.from_numpy(n).to(device), fpn)
+    return batch, targets
+
+
+def train_step_full(model, batch, targets, criterion, anchors, imsize):
+    """One optimizer step's worth of forward + backward of the WHOLE model for the frames of ``batch``: frame sets up to
+    the BEV map (modules/frames.py), then RPN + VoxelLoss frame by frame (batch-1 BatchNorm statistics, exactly B
+    reference forwards, train.py:131-161) under autograd, whose gradient at the BEV map feeds the frame-set backward.
+    Gradients are ADDED into the existing .grad buffers (GradBucket); returns per-frame loss values (host floats)."""
+    from modules import frames as fr
+    dev = batch.device
+    fs, live, counts, status = prepare_frame_set(batch)
+    out = {'loss': [], 'cls': [], 'reg': [], 'voxels': counts}
+    if fs is None:
+        return out
+    hw = [float(imsize[0]), float(imsize[1])]
+    old_sink, _hip.GRAD_SINK = _hip.GRAD_SINK, True
+    try:
+        model.prepack()
+        _hip.arena_begin(dev, doubles=1 << 21)
+        statuses = [status]
+        with torch.no_grad():
+            mid, saved = fr.middle_forward(model, fs, [batch.fpn_levels[f] for f in live], hw, statuses)
+        leaf = mid.detach().requires_grad_(True)
+        total = None
+        parts = []
+        for k, f in enumerate(live):
+            score, reg = model.backbone.rpn(leaf[k:k + 1])
+            score = score.squeeze(dim=0).permute(1, 2, 0)
+            reg = reg.squeeze(dim=0).permute(1, 2, 0)
+            t = targets[f]
+            if t is None:
+                cls_loss, reg_loss = criterion(None, None, None, None, score, None, anchors, 2)
+            else:
+                cls_loss, reg_loss = criterion(t[0], t[1], t[2], t[3], score, reg, anchors, 2)
+            loss = cls_loss if reg_loss is None else cls_loss + reg_loss
+            total = loss if total is None else total + loss
+            parts.append((loss, cls_loss, reg_loss))
+        total.backward()
+        with torch.no_grad():
+            fr.middle_backward(model, saved, leaf.grad)
+        bad = int(torch.stack([s.reshape(()) for s in statuses]).max())
+        if bad:
+            raise _hip.X.MvxHipError('a kernel reported a data-dependent error (status %d)' % bad)
+        for loss, c, r in parts:
+            out['loss'].append(float(loss))
+            out['cls'].append(float(c))
+            if r is not None:
+                out['reg'].append(float(r))
+    finally:
+        _hip.GRAD_SINK = old_sink
+        _hip.arena_end()
+        _hip.join_side_stream()
+    return out
