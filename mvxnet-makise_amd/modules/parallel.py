@@ -17,7 +17,9 @@ def init_from_env(backend=None):
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29500')
+        if 'MASTER_PORT' not in os.environ:
+            # a fixed default port collides as soon as two jobs share a host: the launcher (torchrun) must name it
+            raise RuntimeError('WORLD_SIZE > 1 needs MASTER_PORT (launch with torchrun / torch.distributed.run)')
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -45,8 +47,18 @@ class GradBucket:
     def zero(self):
         self.flat.zero_()
 
+    def check_views(self):
+        """Every parameter's .grad must still be its view of the flat buffer: ``zero_grad(set_to_none=True)`` or an
+        assignment to .grad detaches it silently, and the all-reduce would then exchange stale memory."""
+        base, end = self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.flat.numel()
+        for p in self.params:
+            if p.grad is None or not (base <= p.grad.data_ptr() < end):
+                raise RuntimeError('a parameter gradient is no longer a view of the GradBucket (use bucket.zero(), or '
+                                   'optimizer.zero_grad(set_to_none=False))')
+
     def all_reduce_mean(self, frames_total):
         """Sum over ranks, then divide by the global number of frames."""
+        self.check_views()
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         self.flat.mul_(1.0 / float(frames_total))

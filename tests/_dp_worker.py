@@ -1,5 +1,11 @@
-"""Worker of the world_size-2 gloo test: each rank accumulates the gradients of its own frames into
-the flat bucket, then one all-reduce must produce the mean over ALL frames on every rank."""
+"""Worker of the world_size-2 gloo tests (CPU): gradient exchange of the data-parallel step.
+
+mode toy   : two small parameters, every rank adds the gradients of its frames, one all-reduce -> mean over all frames.
+mode model : the REAL flat bucket over MVXNet's hot-path parameters (same construction as bench.py / train_like.py): every
+             rank fills the gradients of its own frames with a frame-dependent pattern, all-reduces, and compares with
+             the single-process sum over all frames computed locally; then one AdamW step must leave both ranks with
+             bit-identical parameters.  The HIP kernels are not involved (no GPU here): this covers the N > 1 path's
+             sharding, bucket layout, reduction and scaling."""
 import os
 import sys
 
@@ -8,22 +14,61 @@ import torch.distributed as dist
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, 'mvxnet-makise_amd'))
+sys.argv = sys.argv[:2]
+mode = sys.argv[1] if len(sys.argv) > 1 else 'toy'
+sys.argv = sys.argv[:1]
 from modules import parallel  # noqa: E402
 
 rank, world, _ = parallel.init_from_env('gloo')
 torch.manual_seed(0)
-params = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
-bucket = parallel.GradBucket(params)
-frames_total = 6
-mine = parallel.shard_frames(frames_total, rank, world)
-bucket.zero()
-for f in mine:                                   # "backward" of frame f: gradient = (f+1) * ones
-    loss = sum(((f + 1.0) * p).sum() for p in params)
-    loss.backward()
-assert params[0].grad.data_ptr() == bucket.flat.data_ptr(), 'gradients must stay views of the flat bucket'
-bucket.all_reduce_mean(frames_total)
-expect = sum(f + 1.0 for f in range(frames_total)) / frames_total
-assert torch.allclose(bucket.flat, torch.full_like(bucket.flat, expect)), (bucket.flat, expect)
+if mode == 'toy':
+    params = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+    bucket = parallel.GradBucket(params)
+    frames_total = 6
+    mine = parallel.shard_frames(frames_total, rank, world)
+    bucket.zero()
+    for f in mine:                                   # "backward" of frame f: gradient = (f+1) * ones
+        loss = sum(((f + 1.0) * p).sum() for p in params)
+        loss.backward()
+    assert params[0].grad.data_ptr() == bucket.flat.data_ptr(), 'gradients must stay views of the flat bucket'
+    bucket.all_reduce_mean(frames_total)
+    expect = sum(f + 1.0 for f in range(frames_total)) / frames_total
+    assert torch.allclose(bucket.flat, torch.full_like(bucket.flat, expect)), (bucket.flat, expect)
+else:
+    from MVXNet import MVXNet
+    model = MVXNet()                                 # CPU parameters: only the bucket / optimizer logic runs here
+    hot = [(k, p) for k, p in model.named_parameters() if p.requires_grad and '.rpn.' not in k]
+    bucket = parallel.GradBucket([p for _, p in hot])
+    assert bucket.flat.numel() == sum(p.numel() for _, p in hot) == 1169440
+    opt = torch.optim.AdamW([p for _, p in hot], lr=1e-3, eps=1e-6)
+    frames_total = 8                                 # 4 frames per rank, frames {i : i mod world == rank}
+
+    def frame_grad(f, p, j):
+        g = torch.Generator().manual_seed(1000 * f + j)
+        return torch.randn(p.shape, generator=g)
+
+    mine = parallel.shard_frames(frames_total, rank, world)
+    assert mine == list(range(rank, frames_total, world))
+    bucket.zero()
+    for f in mine:                                   # what the reduction kernels do: ADD into the existing .grad views
+        for j, (_, p) in enumerate(hot):
+            p.grad.add_(frame_grad(f, p, j))
+    bucket.all_reduce_mean(frames_total)
+    for j, (k, p) in enumerate(hot):
+        want = sum(frame_grad(f, p, j) for f in range(frames_total)) / frames_total
+        assert torch.allclose(p.grad, want, rtol=1e-5, atol=1e-6), k
+    opt.step()
+    flat_params = torch.cat([p.detach().reshape(-1) for _, p in hot])
+    gathered = [torch.empty_like(flat_params) for _ in range(world)]
+    dist.all_gather(gathered, flat_params)
+    assert all(torch.equal(gathered[0], g) for g in gathered), 'replicas diverged after the optimizer step'
+    # a stray zero_grad(set_to_none=True) would silently detach the parameters from the bucket: it must be caught
+    hot[0][1].grad = None
+    try:
+        bucket.all_reduce_mean(frames_total)
+        raise SystemExit('detached gradient not detected')
+    except RuntimeError:
+        pass
 dist.barrier()
 dist.destroy_process_group()
 print('DP_OK rank', rank)

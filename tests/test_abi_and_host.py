@@ -102,13 +102,23 @@ def test_synthetic_frames_are_deterministic():
     assert sorted(S.synth_perm(3, 100).tolist()) == list(range(100))
 
 
-def test_data_parallel_gradient_exchange_gloo_world2():
-    """Two CPU processes over gloo: the flat bucket all-reduce gives the mean over all frames."""
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29731')
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return str(sk.getsockname()[1])
+
+
+@pytest.mark.parametrize('mode', ['toy', 'model'])
+def test_data_parallel_gradient_exchange_gloo_world2(mode):
+    """Two CPU processes over gloo.  toy: the flat bucket all-reduce gives the mean over all frames.  model: the real
+    GradBucket over MVXNet's 1,169,440 hot-path parameters with different per-frame gradients on the two ranks equals the
+    single-process sum, and the replicas stay identical after AdamW."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=_free_port())
     worker = os.path.join(REPO, 'tests', '_dp_worker.py')
-    procs = [subprocess.Popen([sys.executable, worker], env=dict(env, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r)),
+    procs = [subprocess.Popen([sys.executable, worker, mode], env=dict(env, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
-    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert 'DP_OK' in o, o
