@@ -1,0 +1,50 @@
+"""Summary of the counter passes of tools/profile_round.sh for profiles/ (developer tool).
+
+usage: pmc_summary.py gpurun_out/prof_<tag> profiles/<tag>_pmc_summary.json
+Derived figures (gfx950, MI355X_MICROARCH.md): cycles per XCD = GRBM_GUI_ACTIVE / 8 (the counter sums the 8 XCDs);
+MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (cycles per XCD x 1024 SIMDs); executed matrix FLOPs = SQ_INSTS_VALU_MFMA_MOPS_F32 x 512;
+HBM bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950 counts a wide coalesced read at half its bytes) + WRITE_SIZE KiB x 1024 (exact for
+16-B-per-lane stores, uncalibrated for the 4-B-per-lane epilogue stores of the convolution)."""
+import collections, csv, glob, json, re, sys
+
+root, dst = sys.argv[1], sys.argv[2]
+WANT = ('conv3d_gather_pw', 'conv3d_wgrad4', 'linear_fwd', 'linear_wgrad', 'bn_apply', 'bn_bwd_apply', 'bn_bwd_reduce', 'bnb_tiles',
+        'sparse_conv_output', 'vox_gather', 'vox_insert', 'vox_scan', 'crop_write', 'feature_sample_rows')
+
+
+def short(name):
+    n = name.replace('(anonymous namespace)::', '')
+    m = re.match(r'(void )?([\w:]+(<[^(]*>)?)\(', n)
+    return m.group(2) if m else n[:40]
+
+
+def load(sub):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob('%s/%s/**/*counter_collection.csv' % (root, sub), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = short(r['Kernel_Name'])
+            if any(k.startswith(w) for w in WANT):
+                acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
+    return acc
+
+
+sq, fe, wr = load('pmc_sq'), load('pmc_fetch'), load('pmc_write')
+out = {'source': root, 'kernels': {}}
+for k in sorted(sq):
+    c = {n: sum(v) / len(v) for n, v in sq[k].items()}
+    cyc = c.get('GRBM_GUI_ACTIVE', 0) / 8.0
+    e = {'launches_in_pass': len(sq[k].get('GRBM_GUI_ACTIVE', [])), 'cycles_per_xcd': cyc,
+         'mfma_busy_frac': c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (cyc * 1024) if cyc else None,
+         'executed_matrix_gflop': c.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0) * 512 / 1e9,
+         'lds_bank_conflict_cycles': c.get('SQ_LDS_BANK_CONFLICT', 0), 'lds_active_cycles': c.get('SQ_LDS_IDX_ACTIVE', 0),
+         'wave_cycles': c.get('SQ_WAVE_CYCLES', 0)}
+    if k in fe and 'FETCH_SIZE' in fe[k]:
+        e['hbm_fetch_bytes'] = sum(fe[k]['FETCH_SIZE']) / len(fe[k]['FETCH_SIZE']) * 1024 * 2
+    if k in wr and 'WRITE_SIZE' in wr[k]:
+        e['hbm_write_bytes'] = sum(wr[k]['WRITE_SIZE']) / len(wr[k]['WRITE_SIZE']) * 1024
+    out['kernels'][k] = e
+json.dump(out, open(dst, 'w'), indent=1)
+for k, e in out['kernels'].items():
+    print('%-28s n=%-3d mfma busy %-6s  matrix GFLOP %-8.2f fetch %-9s write %-9s' % (
+        k, e['launches_in_pass'], '%.3f' % e['mfma_busy_frac'] if e['mfma_busy_frac'] is not None else '-', e['executed_matrix_gflop'],
+        '%.1f MB' % (e.get('hbm_fetch_bytes', 0) / 1e6), '%.1f MB' % (e.get('hbm_write_bytes', 0) / 1e6)))
