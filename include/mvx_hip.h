@@ -36,6 +36,7 @@ extern "C" {
                                   (lets a caller clear all accumulators of a frame with ONE fill) */
 #define MVX_FLAG_ACCUMULATE 4  /* add the gradient to the destination instead of overwriting it */
 #define MVX_FLAG_CONV2D 8      /* mvx_conv3d_wgrad: dw is a 2-D kernel gradient [cout][cin][3][3] (din = dout = 1, pad_d = 1) */
+#define MVX_FLAG_TAPS2 16      /* mvx_conv2d_*: only the 2x2 tap window {0,1}^2 carries weight (stride-2 conv on the space-to-depth image) */
 
 #define MVX_OK 0
 #define MVX_EINVAL (-1)   /* bad argument (null pointer, size, unsupported combination) */
@@ -614,6 +615,44 @@ int mvx_bn_relu_backward_tiles_frames(const float *dyhat, const float *y, const 
 /* cl f32 [n_frames * d][h][w][c]  <->  bev f32 [n_frames][c * d][h][w] */
 int mvx_cl_to_bev_frames(const float *cl, float *bev, int32_t d, int32_t h, int32_t w, int32_t channels, int32_t reverse,
                          int32_t n_frames, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Region proposal network on frame sets.  Replaces what RPN.forward and its autograd obtain from
+ * ATen / MIOpen (modules/voxelnet/Pipe.py:45-75; CRB2d / DeCRB2d of modules/layers/Blocks.py:31-51): maps are
+ * channels-last [n_frames][h][w][c] f32, BatchNorm statistics per frame.
+ *
+ *   mvx_conv2d_forward_frames  out = [ReLU](conv3x3(in) + bias), stride 1, padding 1; stats / in-kernel finalisation as
+ *                              mvx_conv3d_forward_bg_frames (count = h * w per frame).  wpk from mvx_conv3d_pack_weights with
+ *                              bit 1 of for_dgrad set (2-D source kernel).  MVX_FLAG_TAPS2: only taps {0,1}^2 carry weight:
+ *                              a stride-2 3x3 convolution (padding 1) of an image X equals this 2x2-window convolution of
+ *                              space_to_depth(X) with the weight rearranged as W2[co][(pr,pc,ci)][ta][tb] = W[co][ci][a][b],
+ *                              a -> (ta, pr): 0 -> (0,1), 1 -> (1,0), 2 -> (1,1), likewise b -> (tb, pc).
+ *   mvx_conv2d_dgrad_frames    dx from dz (flipped window {1,2}^2 under MVX_FLAG_TAPS2)
+ *   mvx_conv2d_wgrad_frames    dw f32 [cout][cin][3][3] summed over all frames; cin % 64 == 0, cout % 64 == 0
+ *   mvx_space_to_depth_frames  in [F*planes][h][w][c] -> out [F][h/2][w/2][4][planes][c], channel block p = 2*(y&1) + (x&1)
+ *                              (reverse != 0: the inverse, `in` is the space-to-depth tensor and `out` the full one)
+ *   mvx_d2s_bn_apply_frames    t [F][h][w][s*s][c] (row-GEMM output of a ConvTranspose2d with kernel = stride = s, column
+ *                              order (i, j, co)) -> out[f][y*s+i][x*s+j][col_offset + co] = (t - mean_f) * inv_f with rows of
+ *                              ld_out floats (mean_inv NULL: copy); reverse != 0: t is WRITTEN from the out slice
+ *   mvx_bn_apply_strided_frames  y [rows][c] dense -> out rows of ld_out floats at col_offset (frames = equal row shares);
+ *                              reverse != 0: y is WRITTEN from the out slice
+ *   mvx_row_stats_frames       stats f64 [F][R][2][c] of y [F][rows / F][c]
+ */
+int mvx_conv2d_forward_frames(const float *in, const float *wpk, const float *bias, float *out, double *stats, int32_t h,
+                              int32_t w, int32_t cin, int32_t cout, int32_t flags, uint32_t *done_counter, double eps,
+                              float *mean_inv, uint32_t *work_counter, int32_t n_frames, void *stream);
+int mvx_conv2d_dgrad_frames(const float *dz, const float *wpk_dgrad, float *dx, int32_t h, int32_t w, int32_t cin,
+                            int32_t cout, int32_t flags, uint32_t *work_counter, int32_t n_frames, void *stream);
+size_t mvx_conv2d_wgrad_workspace_bytes_frames(int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t n_frames);
+int mvx_conv2d_wgrad_frames(const float *in, const float *dz, float *dw, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                            int32_t flags, void *workspace, size_t workspace_bytes, int32_t n_frames, void *stream);
+int mvx_space_to_depth_frames(const float *in, float *out, int32_t n_frames, int32_t planes, int32_t h, int32_t w,
+                              int32_t channels, int32_t reverse, void *stream);
+int mvx_d2s_bn_apply_frames(float *t, const float *mean_inv, float *out, int32_t n_frames, int32_t h, int32_t w, int32_t s,
+                            int32_t channels, int32_t ld_out, int32_t col_offset, int32_t reverse, void *stream);
+int mvx_bn_apply_strided_frames(float *y, const float *mean_inv, float *out, int64_t rows, int32_t channels, int32_t ld_out,
+                                int32_t col_offset, int32_t n_frames, int32_t reverse, void *stream);
+int mvx_row_stats_frames(const float *y, double *stats, int64_t rows, int32_t channels, int32_t n_frames, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Target assignment and loss.

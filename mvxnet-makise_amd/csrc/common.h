@@ -151,9 +151,9 @@ __device__ __forceinline__ int block_excl_scan_i32(int v, int *smem, int *total)
 // performed) before the barrier.  No cache write-back is involved.  `s_flag` is one int of LDS.
 __device__ __forceinline__ void mvx_drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-__device__ __forceinline__ void bn_finalize_by_last_block(unsigned *done_counter, unsigned total_blocks,
-                                                          double *stats, int C, const FrameMap &fm, double eps,
-                                                          float *mean_inv, int *s_flag) {
+template <typename CountOf>
+__device__ __forceinline__ void bn_finalize_core(unsigned *done_counter, unsigned total_blocks, double *stats, int C, int F,
+                                                 CountOf count_of, double eps, float *mean_inv, int *s_flag) {
     mvx_drain_vmem();
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -163,7 +163,7 @@ __device__ __forceinline__ void bn_finalize_by_last_block(unsigned *done_counter
     __syncthreads();
     if (!*s_flag) return;
     // every frame of the launch: stats [F][REP][2][C] -> mean_inv [F][2][C]
-    for (int e = threadIdx.x; e < C * fm.F; e += blockDim.x) {
+    for (int e = threadIdx.x; e < C * F; e += blockDim.x) {
         const int f = e / C, c = e - f * C;
         const double *st = stats + (size_t)f * MVX_REP * 2 * C;
         double v1[MVX_REP], v2[MVX_REP];
@@ -175,7 +175,7 @@ __device__ __forceinline__ void bn_finalize_by_last_block(unsigned *done_counter
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int rp = 0; rp < MVX_REP; ++rp) { s1 += v1[rp]; s2 += v2[rp]; }
-        const double count = fm.count[f];
+        const double count = count_of(f);
         const double mean = s1 / count;
         double var = s2 / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -184,15 +184,18 @@ __device__ __forceinline__ void bn_finalize_by_last_block(unsigned *done_counter
     }
 }
 
-// single-frame form (kernels whose launch covers one frame)
+// row matrices: per-frame populations from the frame map
+__device__ __forceinline__ void bn_finalize_by_last_block(unsigned *done_counter, unsigned total_blocks,
+                                                          double *stats, int C, const FrameMap &fm, double eps,
+                                                          float *mean_inv, int *s_flag) {
+    bn_finalize_core(done_counter, total_blocks, stats, C, fm.F, [&](int f) { return fm.count[f]; }, eps, mean_inv, s_flag);
+}
+
+// grids / single frames: the same population for every frame of the launch
 __device__ __forceinline__ void bn_finalize_by_last_block(unsigned *done_counter, unsigned total_blocks,
                                                           double *stats, int C, double count, double eps,
                                                           float *mean_inv, int *s_flag, int n_frames = 1) {
-    FrameMap fm;
-    fm.F = n_frames;
-    fm.nseg = 1;
-    for (int f = 0; f < MVX_MAX_FRAMES; ++f) fm.count[f] = count;
-    bn_finalize_by_last_block(done_counter, total_blocks, stats, C, fm, eps, mean_inv, s_flag);
+    bn_finalize_core(done_counter, total_blocks, stats, C, n_frames, [=](int) { return count; }, eps, mean_inv, s_flag);
 }
 
 __device__ __forceinline__ float wave_sum_f32(float v) {

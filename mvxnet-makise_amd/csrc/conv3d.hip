@@ -41,6 +41,8 @@ struct Geom {
     int sd, pd;                         // depth stride / padding of the FORWARD conv
     int mode;                           // 0 forward gather, 1 dgrad gather
     int F = 1;                          // frames stacked along the depth axis: global plane = frame * planes + local plane
+    int tap_lo = 0, tap_hi = 3;         // in-plane taps (rows AND columns) [tap_lo, tap_hi) carry weight; the others are skipped
+                                        // (stride-2 convolutions evaluated on the space-to-depth image use a 2x2 window)
 };
 
 // source depth plane (global) of GLOBAL output plane d for depth tap kd; -1 if the tap falls outside the frame's volume
@@ -247,6 +249,10 @@ constexpr int HROW = ((HW * PITCH + 63) / 64) * 64;
 inline dim3 gather_grid(const Geom &g) { return dim3(mvx_cdiv(g.W, TW) * mvx_cdiv(g.H, TH), g.Dout * g.F, g.Cout / BN); }
 
 // One unit of work = (tile, output plane d, 64-channel block nb); `ntiles` tiles per plane.
+// TLO / THI: in-plane taps [TLO, THI) (rows and columns) carry weight -- compile-time, so that the two-row pipeline
+// of the 2 x 2 window keeps its prefetch registers in VGPRs (a run-time choice between two pipelines demoted them
+// to scratch).
+template <int TLO, int THI>
 __device__ __forceinline__ void gather_unit(const int tile, const int d, const int nb, const int ntiles,
                                             float *__restrict__ s_halo, float *__restrict__ s_w, float (*s_red)[2 * BN],
                                             const float *__restrict__ in, const float *__restrict__ wpk,
@@ -354,6 +360,7 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
     auto compute_row = [&](int row) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
+            if (t < TLO || t >= THI) continue;
             const int a_off = a_base + row * HROW + t * PITCH;
 #pragma unroll
             for (int q = 0; q < BK / 8; ++q) {
@@ -374,6 +381,7 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
 
     // Prefetches are unconditional (the last stage re-fetches its own operands and drops them): a
     // conditionally written register array would be demoted to scratch memory.
+    if (TLO == 0 && THI == 3) {
     load_wrow(0, 0);
     load_halo(0);
     for (int st = 0; st < nstages; ++st) {
@@ -395,6 +403,27 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
         __syncthreads();
         load_wrow(nxt, 0);
         compute_row(2);
+    }
+    } else {
+    // two tap rows [r0, r0 + 1] (2 x 2 window): the same pipeline with one row step less per stage
+    constexpr int r0 = TLO;
+    load_wrow(0, r0);
+    load_halo(0);
+    for (int st = 0; st < nstages; ++st) {
+        const int nxt = st + 1 < nstages ? st + 1 : st;
+        __syncthreads();
+        store_halo();
+        store_wrow();                              // tap row r0
+        __syncthreads();
+        load_wrow(st, r0 + 1);
+        load_halo(nxt);
+        compute_row(r0);
+        __syncthreads();
+        store_wrow();                              // tap row r0 + 1
+        __syncthreads();
+        load_wrow(nxt, r0);
+        compute_row(r0 + 1);
+    }
     }
     }   // active
 
@@ -445,6 +474,7 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
 
 
 // Classic launch: one unit per workgroup, grid = (tiles, planes, channel blocks).
+template <int TLO, int THI>
 __global__ __launch_bounds__(256, 2) void conv3d_gather_pf(const float *__restrict__ in,
                                                            const float *__restrict__ wpk,
                                                            const float *__restrict__ bias,
@@ -459,8 +489,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_pf(const float *__restri
     __shared__ __attribute__((aligned(16))) float s_halo[HH * HROW];
     __shared__ __attribute__((aligned(16))) float s_w[3 * WROW];
     __shared__ float s_red[4][2 * BN];
-    gather_unit(blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, s_halo, s_w, s_red, in, wpk, bias, out, stats, g, relu, in_hflag,
-                out_mask, bg_pre, border_active, exec_stages, only_tiles);
+    gather_unit<TLO, THI>(blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, s_halo, s_w, s_red, in, wpk, bias, out, stats, g, relu,
+                          in_hflag, out_mask, bg_pre, border_active, exec_stages, only_tiles);
     if (stats && done_counter) {
         __shared__ int s_last;
         bn_finalize_by_last_block(done_counter, gridDim.x * gridDim.y * gridDim.z, stats, g.Cout, fin_count, fin_eps,
@@ -472,6 +502,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_pf(const float *__restri
 // workgroup reaches the exit (`u >= units`), so the grid always drains.  Units are handed out in the classic order
 // (tile fastest), dynamically: no tail round with idle CUs (3,300 units over 512 slots = 6.45 rounds) and background
 // tiles, which only write a constant, do not unbalance the workgroups.
+template <int TLO, int THI>
 __global__ __launch_bounds__(256, 2) void conv3d_gather_pw(const float *__restrict__ in,
                                                            const float *__restrict__ wpk,
                                                            const float *__restrict__ bias,
@@ -497,8 +528,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_pw(const float *__restri
         const unsigned u = s_unit;
         if (u >= units) break;                      // block-uniform
         const int tile = u % ntiles, d = (u / ntiles) % nplanes, nb = u / (ntiles * nplanes);
-        gather_unit(tile, d, nb, ntiles, s_halo, s_w, s_red, in, wpk, bias, out, stats, g, relu, in_hflag, out_mask, bg_pre,
-                    border_active, exec_stages, only_tiles);
+        gather_unit<TLO, THI>(tile, d, nb, ntiles, s_halo, s_w, s_red, in, wpk, bias, out, stats, g, relu, in_hflag, out_mask,
+                              bg_pre, border_active, exec_stages, only_tiles);
     }
     if (stats && done_counter) {
         __shared__ int s_last;
@@ -1030,8 +1061,10 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restr
             const float b = s_z[s * ZP + wn * 32 + li];
             const float *xa = s_x + ((s >> 4) * HW + (s & 15)) * W4_C + wm * 32 + li;
 #pragma unroll
-            for (int t9 = 0; t9 < 9; ++t9)
+            for (int t9 = 0; t9 < 9; ++t9) {
+                if (t9 / 3 < g.tap_lo || t9 / 3 >= g.tap_hi || t9 % 3 < g.tap_lo || t9 % 3 >= g.tap_hi) continue;   // uniform
                 acc[t9] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[((t9 / 3) * HW + (t9 % 3)) * W4_C], b, acc[t9], 0, 0, 0);
+            }
         }
         cur = nxt;
     }
@@ -1281,14 +1314,21 @@ static void launch_gather(hipStream_t st, const float *in, const float *wpk, con
                           double fin_count, double fin_eps, float *fin_mean_inv, unsigned *work_counter) {
     const dim3 grid = gather_grid(g);
     const long long units = (long long)grid.x * grid.y * grid.z;
-    if (work_counter && units > persistent_grid()) {
-        hipLaunchKernelGGL(conv3d_gather_pw, dim3(persistent_grid()), dim3(256), 0, st, in, wpk, bias, out, stats, g, relu,
-                           in_hflag, out_mask, bg_pre, border_active, exec_stages, only_tiles, done_counter, fin_count, fin_eps,
-                           fin_mean_inv, work_counter, (int)grid.x, (int)grid.y, (int)grid.z);
-    } else {
-        hipLaunchKernelGGL(conv3d_gather_pf, grid, dim3(256), 0, st, in, wpk, bias, out, stats, g, relu, in_hflag, out_mask,
-                           bg_pre, border_active, exec_stages, only_tiles, done_counter, fin_count, fin_eps, fin_mean_inv);
-    }
+#define MVX_LAUNCH_GATHER(TLO, THI)                                                                                              \
+    do {                                                                                                                         \
+        if (work_counter && units > persistent_grid())                                                                           \
+            hipLaunchKernelGGL((conv3d_gather_pw<TLO, THI>), dim3(persistent_grid()), dim3(256), 0, st, in, wpk, bias, out, stats, g, \
+                               relu, in_hflag, out_mask, bg_pre, border_active, exec_stages, only_tiles, done_counter, fin_count,   \
+                               fin_eps, fin_mean_inv, work_counter, (int)grid.x, (int)grid.y, (int)grid.z);                        \
+        else                                                                                                                     \
+            hipLaunchKernelGGL((conv3d_gather_pf<TLO, THI>), grid, dim3(256), 0, st, in, wpk, bias, out, stats, g, relu, in_hflag,  \
+                               out_mask, bg_pre, border_active, exec_stages, only_tiles, done_counter, fin_count, fin_eps,          \
+                               fin_mean_inv);                                                                                      \
+    } while (0)
+    if (g.tap_lo == 0 && g.tap_hi == 3) MVX_LAUNCH_GATHER(0, 3);
+    else if (g.tap_lo == 0 && g.tap_hi == 2) MVX_LAUNCH_GATHER(0, 2);
+    else MVX_LAUNCH_GATHER(1, 3);
+#undef MVX_LAUNCH_GATHER
 }
 
 extern "C" void mvx_conv3d_tile_shape(int32_t *tile_h, int32_t *tile_w) {
@@ -1612,6 +1652,103 @@ extern "C" int mvx_conv3d_wgrad_bg(const float *in, const float *dz, float *dw, 
                                    void *workspace, size_t workspace_bytes, void *stream) {
     return mvx_conv3d_wgrad_bg_frames(in, dz, dw, din, dout, h, w, cin, cout, stride_d, pad_d, flags, in_halo_flags, c_in,
                                       tap_sums, workspace, workspace_bytes, 1, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// 2-D convolutions of the RPN on frame sets (modules/voxelnet/Pipe.py:45-75): 3x3, stride 1, padding 1 on
+// channels-last [F][H][W][C] maps = the gather / wgrad kernels above with one plane per frame (depth tap 1 only).
+// MVX_FLAG_TAPS2: only the 2x2 window of taps {0,1}^2 carries weight (a stride-2 3x3 convolution evaluated on the
+// space-to-depth image of its input); the dgrad of such a layer reads the flipped window {1,2}^2.
+// ------------------------------------------------------------------------------------------
+static int conv2d_geom_ok(int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t n_frames) {
+    if (h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || n_frames < 1 || n_frames > MVX_MAX_FRAMES) return MVX_EINVAL;
+    if (cin % BK || cout % BN) return MVX_ESIZE;
+    return MVX_OK;
+}
+
+extern "C" int mvx_conv2d_forward_frames(const float *in, const float *wpk, const float *bias, float *out, double *stats,
+                                         int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t flags,
+                                         uint32_t *done_counter, double eps, float *mean_inv, uint32_t *work_counter,
+                                         int32_t n_frames, void *stream) {
+    MVX_CHECK_ARG(in && wpk && out);
+    int rc = conv2d_geom_ok(h, w, cin, cout, n_frames);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (stats && !(flags & MVX_FLAG_PREZEROED)) {
+        hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * MVX_REP * 2 * cout * n_frames, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (done_counter) {
+        MVX_CHECK_ARG(stats && mean_inv);
+        if (!(flags & MVX_FLAG_PREZEROED)) {
+            hipError_t e = hipMemsetAsync(done_counter, 0, sizeof(uint32_t), st);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    Geom g{1, 1, h, w, cin, cout, 1, 1, 0, n_frames, 0, (flags & MVX_FLAG_TAPS2) ? 2 : 3};
+    launch_gather(st, in, wpk, bias, out, stats, g, flags & MVX_FLAG_RELU, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+                  (unsigned *)done_counter, (double)h * w, eps, mean_inv, (unsigned *)work_counter);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+extern "C" int mvx_conv2d_dgrad_frames(const float *dz, const float *wpk_dgrad, float *dx, int32_t h, int32_t w, int32_t cin,
+                                       int32_t cout, int32_t flags, uint32_t *work_counter, int32_t n_frames, void *stream) {
+    MVX_CHECK_ARG(dz && wpk_dgrad && dx);
+    int rc = conv2d_geom_ok(h, w, cout, cin, n_frames);          // gather view: source dz (cout channels) -> dx (cin channels)
+    if (rc) return rc;
+    Geom g{1, 1, h, w, cout, cin, 1, 1, 1, n_frames, (flags & MVX_FLAG_TAPS2) ? 1 : 0, 3};
+    launch_gather((hipStream_t)stream, dz, wpk_dgrad, nullptr, dx, nullptr, g, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+                  nullptr, 0.0, 0.0, nullptr, (unsigned *)work_counter);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+static int conv2d_wgrad_strips(int cin, int cout) {
+    int s = 512 / ((cin / W4_C) * (cout / BN));                   // about two workgroups per CU in all
+    if (s > 128) s = 128;
+    return s < 1 ? 1 : s;
+}
+
+extern "C" size_t mvx_conv2d_wgrad_workspace_bytes_frames(int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t n_frames) {
+    if (h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || cin % W4_C || cout % BN || n_frames <= 0) return 0;
+    const size_t ntiles = (size_t)mvx_cdiv(w, TW) * mvx_cdiv(h, TH);
+    const size_t slabs = (size_t)(cout / BN) * conv2d_wgrad_strips(cin, cout) * 27 * cin * BN * sizeof(float);
+    return slabs + sizeof(int) * (3 * (size_t)n_frames * ntiles + 4) + sizeof(int) * (size_t)n_frames * ntiles;
+}
+
+// dw f32 [cout][cin][3][3] (ADDED to with MVX_FLAG_ACCUMULATE) = sum over all frames and sites of in (x) dz
+extern "C" int mvx_conv2d_wgrad_frames(const float *in, const float *dz, float *dw, int32_t h, int32_t w, int32_t cin,
+                                       int32_t cout, int32_t flags, void *workspace, size_t workspace_bytes, int32_t n_frames,
+                                       void *stream) {
+    MVX_CHECK_ARG(in && dz && dw && workspace);
+    int rc = conv2d_geom_ok(h, w, cin, cout, n_frames);
+    if (rc) return rc;
+    if (cin % W4_C) return MVX_ESIZE;
+    MVX_CHECK_ARG(workspace_bytes >= mvx_conv2d_wgrad_workspace_bytes_frames(h, w, cin, cout, n_frames));
+    hipStream_t st = (hipStream_t)stream;
+    const int ntiles = (int)(mvx_cdiv(w, TW) * mvx_cdiv(h, TH));
+    const int nstrips = conv2d_wgrad_strips(cin, cout);
+    const int nblk = cout / BN;
+    Geom g{1, 1, h, w, cin, cout, 1, 1, 0, n_frames, 0, (flags & MVX_FLAG_TAPS2) ? 2 : 3};
+    float *slabs = (float *)workspace;
+    int *list = (int *)((char *)workspace + (size_t)nblk * nstrips * 27 * cin * BN * sizeof(float));
+    int *count = list + (size_t)3 * n_frames * ntiles;
+    int *ones = count + 4;                                         // "every tile is a step": any non-zero word is a set flag
+    hipError_t e = hipMemsetAsync(ones, 0x01, sizeof(int) * (size_t)n_frames * ntiles, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(wgrad_step_list, dim3(3), dim3(1024), 0, st, (const int *)ones, g, ntiles, list, count);
+    MVX_LAUNCH_CHECK();
+    Strips ks;
+    ks.n[0] = 1; ks.n[1] = nstrips; ks.n[2] = 1;                    // depth tap 1 is the only one with a source plane
+    hipLaunchKernelGGL(conv3d_wgrad4, dim3(nstrips, 3 * (cin / W4_C), nblk), dim3(W4_THREADS), 0, st, in, dz, slabs, g, 0,
+                       (const int *)list, (const int *)count, (const float *)nullptr, ks);
+    MVX_LAUNCH_CHECK();
+    const size_t per_slab = (size_t)27 * cin * BN;
+    hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256), nblk), dim3(256), 0, st, (const float *)slabs, dw, nstrips, cin,
+                       flags & MVX_FLAG_ACCUMULATE, 1, ks);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
 }
 
 static int sites_rows_per_strip(int n_voxels) {

@@ -131,6 +131,14 @@ PROTOTYPES = {
     'mvx_bn_relu_backward_tiles_workspace_bytes_frames': (_sz, [_i32, _i32, _i32, _i32, _i32]),
     'mvx_bn_relu_backward_tiles_frames': (_i32, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _sz, _i32, _p]),
     'mvx_cl_to_bev_frames': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    'mvx_conv2d_forward_frames': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _f64, _p, _p, _i32, _p]),
+    'mvx_conv2d_dgrad_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _i32, _p]),
+    'mvx_conv2d_wgrad_workspace_bytes_frames': (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    'mvx_conv2d_wgrad_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _sz, _i32, _p]),
+    'mvx_space_to_depth_frames': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    'mvx_d2s_bn_apply_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    'mvx_bn_apply_strided_frames': (_i32, [_p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p]),
+    'mvx_row_stats_frames': (_i32, [_p, _p, _i64, _i32, _i32, _p]),
     'mvx_bbox_pairwise': (_i32, [_p, _i32, _p, _i32, _i32, _p, _p]),
     'mvx_classify_anchors_workspace_bytes': (_sz, [_i32, _i32, _i32]),
     'mvx_classify_anchors': (_i32, [_p, _i32, _p, _i32, _i32, _i32, _p, _p, _f32, _f32, _i32, _p, _p, _p, _i64, _p, _p, _p, _sz, _p]),

@@ -215,8 +215,10 @@ def _vfe_forward(bb, fs, x, S, eps):
     return feat, S
 
 
-def cml_forward(model, fs, feat, S, status_sink):
-    """reindex + CML + the BEV reshape (VoxelNet.py:16-36) for the whole frame set: (Vt,128) -> (F,128,H,W)."""
+def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
+    """reindex + CML + the BEV reshape (VoxelNet.py:16-36) for the whole frame set: (Vt,128) -> (F,128,H,W).
+    The channels-last CML output [F*D3][H][W][64] stays in ``S.x3`` (what modules/rpn_frames.py reads); with
+    ``want_bev=False`` the (F,128,H,W) map is not materialised and None is returned."""
     bb = model.backbone
     dev = fs.voxels.device
     F, T, Rt, Vt = fs.F, fs.T, fs.Rt, fs.Vt
@@ -314,10 +316,13 @@ def cml_forward(model, fs, feat, S, status_sink):
         S.convs.append(rec)
         x_in, din, mask_in, hflag_in, tflag_in = x_out, dout, mask_o, hflag_o, tflag_o
     D3 = din
+    S.D3, S.H, S.W, S.C3 = D3, H, W, x_in.shape[-1]
+    S.x3 = x_in
+    if not want_bev:
+        return None
     mid = torch.empty((F, x_in.shape[-1] * D3, H, W), dtype=torch.float32, device=dev)
     with _hip._timed_bytes('cl_bev_transpose', 2 * x_in.numel() * 4):
         X.check(X.lib.mvx_cl_to_bev_frames(X.ptr(x_in), X.ptr(mid), D3, H, W, x_in.shape[-1], 0, F, X.stream()), 'mvx_cl_to_bev_frames')
-    S.D3, S.H, S.W, S.C3 = D3, H, W, x_in.shape[-1]
     return mid
 
 
@@ -350,14 +355,17 @@ def middle_backward(model, S, grad_mid):
         _hip.ASYNC_WGRAD = old_async
 
 
-def cml_backward(model, S, grad_mid):
-    """Backward of cml_forward: returns dL/d(voxel features) (Vt,128)."""
+def cml_backward(model, S, grad_mid, g_cl=None):
+    """Backward of cml_forward: returns dL/d(voxel features) (Vt,128).  ``g_cl``: the gradient already in the
+    channels-last layout of ``S.x3`` ([F*D3][H][W][64], from modules/rpn_frames.py) instead of ``grad_mid`` (F or 1,128,H,W)."""
     fs = S.fs
     F, T, Rt, Vt = fs.F, fs.T, fs.Rt, fs.Vt
     H, W, D3, C3 = S.H, S.W, S.D3, S.C3
-    dev = grad_mid.device
-    gm = grad_mid.contiguous()
-    if gm.shape[0] == 1 and F > 1:
+    dev = fs.voxels.device
+    gm = grad_mid.contiguous() if g_cl is None else None
+    if g_cl is not None:
+        g = g_cl
+    elif gm.shape[0] == 1 and F > 1:
         g1 = torch.empty((D3, H, W, C3), dtype=torch.float32, device=dev)
         X.check(X.lib.mvx_cl_to_bev_frames(X.ptr(g1), X.ptr(gm), D3, H, W, C3, 1, 1, X.stream()), 'mvx_cl_to_bev_frames')
         g = g1.repeat(F, 1, 1, 1)

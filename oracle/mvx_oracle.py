@@ -343,6 +343,47 @@ def voxelnet_middle(x, idx, p, voxelshape=VOXELSHAPE, eps=EPS):
 
 
 # ----------------------------------------------------------------------------
+# f1: RPN  (modules/voxelnet/Pipe.py:45-75; CRB2d / DeCRB2d of modules/layers/Blocks.py:31-51)
+# ----------------------------------------------------------------------------
+def crb2d(x, w, b, stride, pad, eps=EPS):
+    """Conv2d -> ReLU -> BN2d on NCHW (Blocks.py:31-40)."""
+    y = F.relu(F.conv2d(x, w, b, stride, pad))
+    return F.batch_norm(y, None, None, None, None, True, 0.0, eps)
+
+
+def decrb2d(x, w, b, stride, pad, eps=EPS):
+    """ConvTranspose2d -> ReLU -> BN2d on NCHW (Blocks.py:42-51)."""
+    y = F.relu(F.conv_transpose2d(x, w, b, stride, pad))
+    return F.batch_norm(y, None, None, None, None, True, 0.0, eps)
+
+
+def rpn(x, p, prefix='rpn.', eps=EPS):
+    """(1,128,H,W) -> (score (1,2,H/2,W/2), reg (1,14,H/2,W/2)) (Pipe.py:45-75)."""
+    def blk(x, name, n):
+        for i in range(n):
+            x = crb2d(x, p['%s%s.%d.conv.weight' % (prefix, name, i)], p['%s%s.%d.conv.bias' % (prefix, name, i)], 2 if i == 0 else 1, 1, eps)
+        return x
+    x1 = blk(x, 'blk1', 4)
+    x2 = blk(x1, 'blk2', 6)
+    x3 = blk(x2, 'blk3', 6)
+    ups = [decrb2d(x1, p[prefix + 'deconv1.deconv.weight'], p[prefix + 'deconv1.deconv.bias'], 1, 1, eps),
+           decrb2d(x2, p[prefix + 'deconv2.deconv.weight'], p[prefix + 'deconv2.deconv.bias'], 2, 0, eps),
+           decrb2d(x3, p[prefix + 'deconv3.deconv.weight'], p[prefix + 'deconv3.deconv.bias'], 4, 0, eps)]
+    up = torch.cat(ups, dim=1)
+    score = torch.sigmoid(F.conv2d(up, p[prefix + 'cls.weight'], p[prefix + 'cls.bias']))
+    return score, F.conv2d(up, p[prefix + 'reg.weight'], p[prefix + 'reg.bias'])
+
+
+def rpn_params(golden_rpn_shapes, dtype=torch.float32):
+    """The deterministic RPN tensors the reference fixtures were generated with (make_rpn_param per state-dict key)."""
+    out = {}
+    for name, shape in zip(golden_rpn_shapes['names'], golden_rpn_shapes['shapes']):
+        shape = tuple(int(v) for v in shape if v != 0)
+        out[str(name)] = make_rpn_param(str(name), shape).to(dtype)
+    return out
+
+
+# ----------------------------------------------------------------------------
 # a7: ImageFeatureFusion  (modules/imhead/Pipe.py:84-104)
 # ----------------------------------------------------------------------------
 def image_feature_fusion(x, p, prefix='', eps=EPS):

@@ -148,3 +148,12 @@ def test_mvxnet_front_matches_reference(golden):
     shape = [int(v) for v in g['voxelshape']]
     mid = O.voxelnet_middle(v23, torch.from_numpy(g['idx']), bp, shape)
     np.testing.assert_allclose(mid[0].numpy(), g['mid'], rtol=1e-3, atol=2e-3)
+
+
+def test_rpn_matches_reference(golden):
+    """oracle.rpn against the score / regression maps the reference's VoxelNet produced on the small grid."""
+    g = golden('voxelnet_small')
+    P = O.rpn_params(golden('rpn_shapes'))
+    score, reg = O.rpn(torch.from_numpy(g['mid'])[None], P)
+    assert float((score[0] - torch.from_numpy(g['score'])).abs().max()) < 2e-5
+    assert float((reg[0] - torch.from_numpy(g['reg'])).abs().max() / np.abs(g['reg']).max()) < 2e-5
