@@ -254,7 +254,7 @@ inline dim3 gather_grid(const Geom &g) { return dim3(mvx_cdiv(g.W, TW) * mvx_cdi
 // to scratch).
 template <int TLO, int THI>
 __device__ __forceinline__ void gather_unit(const int tile, const int d, const int nb, const int ntiles,
-                                            float *__restrict__ s_halo, float *__restrict__ s_w, float (*s_red)[2 * BN],
+                                            float *__restrict__ s_halo, float *__restrict__ s_w, double (*s_red)[2 * BN],
                                             const float *__restrict__ in, const float *__restrict__ wpk,
                                             const float *__restrict__ bias, float *__restrict__ out,
                                             double *__restrict__ stats, const Geom &g, int relu,
@@ -433,7 +433,9 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
     // background value of this plane: the same fp32 operations as a computed site, on the constant
     float bgv0 = (bg_pre ? bg_pre[(size_t)d * g.Cout + n0] : 0.f) + bias0, bgv1 = (bg_pre ? bg_pre[(size_t)d * g.Cout + n1] : 0.f) + bias1;
     if (relu) { bgv0 = fmaxf(bgv0, 0.f); bgv1 = fmaxf(bgv1, 0.f); }
-    float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+    // BatchNorm sums in f64 from the first addition on: var = E[y^2] - mean^2 cancels, and f32 partial sums cost
+    // mean^2 / var times their 1e-7 in the variance (the reference's torch-CPU BatchNorm accumulates in double too)
+    double s1a = 0.0, s2a = 0.0, s1b = 0.0, s2b = 0.0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -448,8 +450,8 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
             float *o = out + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout;
             o[n0] = v0;
             o[n1] = v1;
-            s1a += v0; s2a += v0 * v0;
-            s1b += v1; s2b += v1 * v1;
+            s1a += (double)v0; s2a += (double)v0 * (double)v0;
+            s1b += (double)v1; s2b += (double)v1 * (double)v1;
         }
     }
     if (stats) {
@@ -462,7 +464,7 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
         }
         __syncthreads();
         if (tid < 2 * BN) {
-            const double t = (double)s_red[0][tid] + (double)s_red[1][tid] + (double)s_red[2][tid] + (double)s_red[3][tid];
+            const double t = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
             const int which = tid / BN, c = tid % BN;
             const unsigned rep = (unsigned)(tile + d * ntiles) % MVX_REP;
             double *fstats = stats + (size_t)(d / g.Dout) * MVX_REP * 2 * g.Cout;       // the plane's frame
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_pf(const float *__restri
                                                            double fin_eps, float *__restrict__ fin_mean_inv) {
     __shared__ __attribute__((aligned(16))) float s_halo[HH * HROW];
     __shared__ __attribute__((aligned(16))) float s_w[3 * WROW];
-    __shared__ float s_red[4][2 * BN];
+    __shared__ double s_red[4][2 * BN];
     gather_unit<TLO, THI>(blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, s_halo, s_w, s_red, in, wpk, bias, out, stats, g, relu,
                           in_hflag, out_mask, bg_pre, border_active, exec_stages, only_tiles);
     if (stats && done_counter) {
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_pw(const float *__restri
                                                            int nblocks) {
     __shared__ __attribute__((aligned(16))) float s_halo[HH * HROW];
     __shared__ __attribute__((aligned(16))) float s_w[3 * WROW];
-    __shared__ float s_red[4][2 * BN];
+    __shared__ double s_red[4][2 * BN];
     __shared__ unsigned s_unit;
     const unsigned units = (unsigned)ntiles * nplanes * nblocks;
     for (;;) {

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void linear_fwd(const float *__restrict__ x, i
     constexpr int WV = BNL * BK / 4 / 256;         // float4 per thread for the w tile (NT)
     __shared__ __attribute__((aligned(16))) float s_x[BM * PITCH];
     __shared__ __attribute__((aligned(16))) float s_w[BNL * PITCH];
-    __shared__ float s_red[4][2 * BNL];
+    __shared__ double s_red[4][2 * BNL];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
     // column block fastest: the workgroups that share an x tile run together and read it from HBM once
     const long long r0 = (long long)blockIdx.y * BM;
@@ -183,11 +183,11 @@ __global__ __launch_bounds__(256) void linear_fwd(const float *__restrict__ x, i
         for (int sg = s_lo; sg <= s_hi; ++sg) {
             const int f = fm.F == 1 ? 0 : (int)fm.seg_frame[sg];
             const long long lo = fm.F == 1 ? 0 : fm.bound[sg], hi = fm.F == 1 ? R : fm.bound[sg + 1];
-            float s1[NT], s2[NT];
+            double s1[NT], s2[NT];          // f64 from the first addition on (var = E[y^2] - mean^2 cancels)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int c = n0 + t * 32 + li;
-                s1[t] = 0.f; s2[t] = 0.f;
+                s1[t] = 0.0; s2[t] = 0.0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -195,16 +195,16 @@ __global__ __launch_bounds__(256) void linear_fwd(const float *__restrict__ x, i
                     float v = acc[t][r] + bsv[t];
                     if (relu) v = fmaxf(v, 0.f);
                     if (gr < R && c < N && gr >= lo && gr < hi) {
-                        const float rw = row_w ? row_w[gr] : 1.f;
-                        s1[t] += rw * v;
-                        s2[t] += rw * v * v;
+                        const double rw = row_w ? (double)row_w[gr] : 1.0;
+                        s1[t] += rw * (double)v;
+                        s2[t] += rw * (double)v * (double)v;
                     }
                 }
             }
             __syncthreads();
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const float a = s1[t] + __shfl_xor(s1[t], 32, 64), b = s2[t] + __shfl_xor(s2[t], 32, 64);
+                const double a = s1[t] + __shfl_xor(s1[t], 32, 64), b = s2[t] + __shfl_xor(s2[t], 32, 64);
                 if (lh == 0) { s_red[wv][t * 32 + li] = a; s_red[wv][BNL + t * 32 + li] = b; }
             }
             __syncthreads();
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void linear_fwd(const float *__restrict__ x, i
             for (int e = tid; e < 2 * BNL; e += 256) {
                 const int which = e / BNL, c = e % BNL;
                 if (n0 + c < N) {
-                    const double t = (double)s_red[0][e] + (double)s_red[1][e] + (double)s_red[2][e] + (double)s_red[3][e];
+                    const double t = s_red[0][e] + s_red[1][e] + s_red[2][e] + s_red[3][e];
                     atomicAdd(fstats + ((size_t)(blockIdx.y % MVX_REP) * 2 + which) * N + n0 + c, t);
                 }
             }

@@ -102,16 +102,17 @@ __global__ __launch_bounds__(256) void row_stats_frames(const float *__restrict_
     stats += (size_t)f * MVX_REP * 2 * C;
     for (int cb = 0; cb < c4; cb += 256) {
         const int col = cb + ct;
-        float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+        double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};      // f64 throughout (var = E[y^2] - mean^2 cancels)
         if (rt < rpi && col < c4) {
             for (size_t r = blockIdx.x * (size_t)rpi + rt; r < rows_per_frame; r += (size_t)gridDim.x * rpi) {
                 const float4 v = *(const float4 *)(y + r * C + col * 4);
-                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-                s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+                const double d[4] = {(double)v.x, (double)v.y, (double)v.z, (double)v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s1[j] += d[j]; s2[j] += d[j] * d[j]; }
             }
         }
-        red[0][threadIdx.x][0] = s1.x; red[0][threadIdx.x][1] = s1.y; red[0][threadIdx.x][2] = s1.z; red[0][threadIdx.x][3] = s1.w;
-        red[1][threadIdx.x][0] = s2.x; red[1][threadIdx.x][1] = s2.y; red[1][threadIdx.x][2] = s2.z; red[1][threadIdx.x][3] = s2.w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { red[0][threadIdx.x][j] = s1[j]; red[1][threadIdx.x][j] = s2[j]; }
         __syncthreads();
         if (rt == 0 && col < c4) {
             for (int k = 0; k < 2; ++k)

@@ -248,6 +248,7 @@ def rpn_backward(rpn, S, d_heads):
     F = S['F']
     planes, H, W, Cp = S['geom']
     pk = _packs_of(rpn)
+    cap = S.get('capture')          # tests: list receiving (layer key, upstream gradient, input gradient) per conv layer
     up, w_heads, h1, w1 = S['up'], S['w_heads'], S['h1'], S['w1']
     dev = up.device
     rows = up.shape[0]
@@ -296,6 +297,7 @@ def rpn_backward(rpn, S, d_heads):
             m = rec['m']
             wt = m.conv.weight
             h, w, cin, cout = rec['h'], rec['w'], rec['cin'], rec['cout']
+            g_up_layer = g
             dz = _bn_bwd(g, rec['y'], rec['mi'], F, m.conv.bias)
             if rec['kind'] == 's1':
                 _wgrad(rec['x'], dz, F, h, w, cin, cout, 0, into=_grad_of(wt))
@@ -311,4 +313,6 @@ def rpn_backward(rpn, S, d_heads):
                 g = _d2s(gs, F, pl, 2 * h, 2 * w, Cf)
                 if pl == 1:
                     g = g.view(F, 2 * h, 2 * w, Cf)
+            if cap is not None:
+                cap.append(((rec['bi'], rec.get('li', 0)), g_up_layer.clone(), g.clone()))
     return g                                       # [F*planes][H][W][Cp]
