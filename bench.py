@@ -13,7 +13,9 @@ One step (--mode hot, the headline) = one batch of `--frames` synthetic frames P
   one flat gradient all-reduce over RCCL -> one AdamW step.
 Other modes (BASELINE.json configs): --mode vfe (config 2: voxelize + VFE stack forward/backward, 16 frames, voxel
 indices asserted bit-exact against the C oracle inside the run), --mode dropin (the nn.Module API: MVXNet.forward +
-VoxelLoss + autograd + AdamW, one frame at a time like train.py:110-164, RPN included).
+VoxelLoss + autograd + AdamW, one frame at a time like train.py:110-164, RPN on MIOpen), --mode full (the WHOLE model
+of train.py:110-164 for B frames per step on this library's kernels: classifyAnchors, frame sets through fusion / VFE /
+CML, the RPN on the same gather kernels, VoxelLoss, whole backward).
 --workload S1|S2: uniform worst case (V ~ 19.9 k voxels per frame) or the KITTI-like ring model (V ~ 5 k, default).
 Prints ONE JSON line on rank 0.
 """
@@ -270,7 +272,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--mode', choices=['hot', 'vfe', 'dropin'], default='hot')
+    ap.add_argument('--mode', choices=['hot', 'vfe', 'dropin', 'full'], default='hot')
     ap.add_argument('--workload', choices=['S1', 'S2'], default='S2')
     ap.add_argument('--frames', type=int, default=None, help='frames per GPU per step (default 4; 16 in --mode vfe)')
     ap.add_argument('--points', type=int, default=20000)
@@ -303,7 +305,7 @@ def main():
 
     torch.manual_seed(0)
     model = MVXNet().to(dev)
-    with_rpn = args.mode == 'dropin'
+    with_rpn = args.mode in ('dropin', 'full')
     hot = [p for k, p in model.named_parameters() if p.requires_grad and (with_rpn or '.rpn.' not in k)]
     bucket = parallel.GradBucket(hot)
     opt = torch.optim.AdamW(hot, lr=1e-3, eps=cfg.eps)
@@ -349,9 +351,7 @@ def main():
 
     drop = {}
 
-    def step_dropin(b=None):
-        """The reference's own interface, one frame at a time (train.py:110-164): preprocessing -> MVXNet.forward ->
-        VoxelLoss -> backward -> AdamW.  nn.Module API + autograd, dense (1,N,35,23) contract, RPN on MIOpen."""
+    def targets_setup():
         from modules import Calc
         from modules.data import Preprocessing as pre
         from modules.voxelnet import VoxelLoss
@@ -364,8 +364,17 @@ def main():
             gt = np.stack([gg.uniform(8, 60, n), gg.uniform(-30, 30, n), gg.uniform(-1.8, -0.6, n), gg.uniform(3.4, 4.4, n),
                            gg.uniform(1.5, 1.8, n), gg.uniform(1.4, 1.7, n), gg.choice([0.0, np.pi / 2], n) + gg.normal(0, 0.05, n)], 1)
             drop['gt'] = torch.tensor(gt, dtype=torch.float32)
+            drop['gt_dev'] = drop['gt'].to(dev)
+            drop['gt_bev'] = Calc.bbox3d2bev(drop['gt'])
             drop['crit'] = VoxelLoss()
             drop['imsize'] = torch.tensor(imsize, device=dev)
+        return drop
+
+    def step_dropin(b=None):
+        """The reference's own interface, one frame at a time (train.py:110-164): preprocessing -> MVXNet.forward ->
+        VoxelLoss -> backward -> AdamW.  nn.Module API + autograd, dense (1,N,35,23) contract, RPN on MIOpen."""
+        from modules import Calc
+        targets_setup()
         frames, st = pl.voxelize_batch(batch)
         statuses = [st]
         for f, (voxels, idx) in enumerate(frames):
@@ -382,7 +391,39 @@ def main():
         pending_status.extend(statuses)
         return [v.shape[1] for v, _ in frames]
 
-    step = {'hot': step_hot, 'vfe': step_vfe, 'dropin': step_dropin}[args.mode]
+    full = {}
+
+    def full_targets():
+        """train.py:44-46 for every frame of the batch: classifyAnchors on the GPU (one host read of two list lengths each)."""
+        from modules import Calc
+        d = targets_setup()
+        out = []
+        for _ in range(args.frames):
+            pi, ni, gi = Calc.classifyAnchors(d['gt_bev'], d['gt'][:, [0, 1]], d['bevs'], cfg.velorange, 0.45, 0.6)
+            out.append((pi, ni, gi, d['gt_dev']))
+        return out
+
+    def step_full(b=None):
+        """The WHOLE model on this library's kernels (train.py:110-164 for B frames): crop + projection, voxelizer,
+        classifyAnchors, fusion + VFE + CML as frame sets, RPN (modules/rpn_frames.py), VoxelLoss, everything back, one
+        all-reduce, AdamW.  The losses of a step are read one step later (the host never waits for what it just enqueued)."""
+        d = targets_setup()
+        bucket.zero()
+        if state['ready'] is None:
+            ready, targets = None, full_targets()
+        else:
+            ready, targets = state['ready']
+        out = pl.train_step_full(model, batch, targets, d['crit'], d['anchors'], imsize, ready=ready,
+                                 prepare_next=(batch, full_targets), read=False)
+        state['ready'] = out.pop('next')
+        bucket.all_reduce_mean(frames_total)
+        opt.step()
+        if full.get('pending') is not None:
+            full['last'] = pl.read_losses(full['pending'])['loss']
+        full['pending'] = out
+        return out['voxels']
+
+    step = {'hot': step_hot, 'vfe': step_vfe, 'dropin': step_dropin, 'full': step_full}[args.mode]
     host_ms, exec_stages = [], []
 
     def timed_run(warmup, steps, fn=None):
@@ -528,6 +569,14 @@ def main():
                     'avg_launch_ms': ms / max(1, len(ev)),
                     'note': 'algorithmic bytes = points + permutation read, voxel payload + indices written (SURVEY.md 8d)'}
             metric = 'KITTI frames/sec (voxelize+VFE fwd+bwd)'
+        elif args.mode == 'full':
+            workload = ('%s, %d raw pts -> %d pts after crop, grid 10x352x400, T=35, %d frames/GPU/step: crop+cropToSight+lidar2Img, '
+                        'voxelize, classifyAnchors, fusion sampling+MLP, VFE, reindex+CML, RPN (all on this library\'s kernels, frame '
+                        'sets), VoxelLoss, whole backward, all-reduce, AdamW; convmath=%s'
+                        % (wl, RAW_POINTS, args.points, args.frames, main_math))
+            roof = conv_roofline(timers, 0)
+            roof['note'] += '; CML launches only (the RPN\'s 2-D convolutions run the same gather kernel and are listed under other_kernels)'
+            metric = 'KITTI frames/sec (whole model fwd+bwd: voxelize+VFE+fusion+3Dconv+RPN+VoxelLoss)'
         else:
             workload = ('%s, %d pts, grid 10x352x400, T=35, %d frames/GPU/step one at a time through the nn.Module API: voxelize, '
                         'classifyAnchors, MVXNet.forward (dense (1,N,35,23) contract, RPN on MIOpen), VoxelLoss, autograd backward, AdamW'
@@ -556,11 +605,15 @@ def main():
             'hbm_stages': hbm_stages(timers),
         }
         other = {}
-        for name in ('conv3d_wgrad_bg',):
+        for name in ('conv3d_wgrad_bg', 'rpn_conv'):
             evs = timers.get(name, [])
             if evs:
                 tms = sum(s.elapsed_time(e) for s, e, _ in evs)
                 other[name] = {'launches': len(evs), 'avg_launch_ms': tms / len(evs)}
+                fl = sum(f for _, _, f in evs)
+                if fl > 0:
+                    other[name]['dense_tflops'] = fl / (tms * 1e-3) / 1e12
+                    other[name]['frac_of_f32_mfma_peak'] = other[name]['dense_tflops'] / FP32_MFMA_PEAK_TFLOPS
         out['other_kernels'] = other
         if alt:
             out['alt_modes'] = alt
@@ -570,6 +623,8 @@ def main():
             out['cpu_baseline'] = (cpu_baseline_vfe if args.mode == 'vfe' else cpu_baseline)(args.points, args.workload)
             if vfe_check is not None:
                 out['cpu_baseline']['voxel_indices_vs_oracle'] = vfe_check
+        if args.mode == 'full' and full.get('last'):
+            out['last_losses'] = full['last']
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -1127,25 +1127,33 @@ def classify_anchors(gts, anchor_bevs, nls, nws, neg_thr, pos_thr, radius, cap=N
     return pos, neg, gi, counts, status
 
 
-def voxel_loss(score, reg, pos_idx, neg_idx, gi, n_pos, n_neg, gts, anchors, A, a, b, eps, want_grads=True):
+def voxel_loss(score, reg, pos_idx, neg_idx, gi, n_pos, n_neg, gts, anchors, A, a, b, eps, want_grads=True,
+               dscore_out=None, dreg_out=None):
     """score (L,W,A) / reg (L,W,7A) f32 views with arbitrary strides; pos_idx / neg_idx i64 (3,cap) or None.
-    Returns (losses f32 (2,), dscore, dreg) -- the gradients share the inputs' memory layout."""
+    Returns (losses f32 (2,), dscore, dreg) -- the gradients share the inputs' memory layout, or are written into the
+    given views ``dscore_out`` / ``dreg_out`` (dreg_out ZERO on entry)."""
     L, W = score.shape[0], score.shape[1]
     dev = score.device
     losses = torch.empty((2,), dtype=torch.float32, device=dev)
     scratch = torch.empty((4,), dtype=torch.float64, device=dev)
-    dscore = torch.empty_strided(score.shape, score.stride(), dtype=torch.float32, device=dev) if want_grads else None
+    dscore = dscore_out
+    if want_grads and dscore is None:
+        dscore = torch.empty_strided(score.shape, score.stride(), dtype=torch.float32, device=dev)
     dreg = None
     if want_grads and reg is not None:
-        dreg = torch.empty_strided(reg.shape, reg.stride(), dtype=torch.float32, device=dev)
-        dreg.zero_()
+        dreg = dreg_out
+        if dreg is None:
+            dreg = torch.empty_strided(reg.shape, reg.stride(), dtype=torch.float32, device=dev)
+            dreg.zero_()
     ss = score.stride()
     rs = reg.stride() if reg is not None else (0, 0, 0)
+    ds = dscore.stride() if dscore is not None else (0, 0, 0)
+    dr = dreg.stride() if dreg is not None else (0, 0, 0)
     X.check(X.lib.mvx_voxel_loss(_vptr(score), ss[0], ss[1], ss[2], _vptr(reg), rs[0], rs[1], rs[2],
                                  X.ptr(pos_idx), pos_idx.shape[1] if pos_idx is not None else 0,
                                  X.ptr(neg_idx), neg_idx.shape[1] if neg_idx is not None else 0, X.ptr(gi), None,
                                  int(n_pos), int(n_neg), X.ptr(gts), gts.shape[1] if gts is not None else 7,
                                  X.ptr(anchors), L, W, int(A), float(a), float(b), float(eps),
-                                 _vptr(dscore), ss[0], ss[1], ss[2], _vptr(dreg), rs[0], rs[1], rs[2],
+                                 _vptr(dscore), ds[0], ds[1], ds[2], _vptr(dreg), dr[0], dr[1], dr[2],
                                  X.ptr(losses), X.ptr(scratch), X.stream()), 'mvx_voxel_loss')
     return losses, dscore, dreg

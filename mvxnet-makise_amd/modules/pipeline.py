@@ -424,53 +424,150 @@ def batch_from_dataset(group, names, device, anchorBevs, fpn_fn, cap_points):
     return batch, targets
 
 
-def train_step_full(model, batch, targets, criterion, anchors, imsize):
+RPN_HIP = _os.environ.get('MVX_RPN_HIP', '1') != '0'       # RPN on this library's kernels (modules/rpn_frames.py); 0 = torch modules
+
+
+def heads_loss(heads, F, h1, w1, targets, criterion, anchors):
+    """VoxelLoss (voxelnet/Loss.py:15-45) of every frame on the channels-last head output (F*h1*w1, 16) = [cls logits | reg]
+    and its gradient, without the autograd engine: score = sigmoid(logits) (voxelnet/Pipe.py:74), one loss call per frame
+    writing d(loss)/dscore and d(loss)/dreg straight into the gradient of the heads, then the sigmoid's derivative.
+    Returns (losses (F,2) on the device = (clsLoss, regLoss or 0), per-frame bool "has a regression loss", d_heads)."""
+    from modules.voxelnet.Loss import _index_block
+    dev = heads.device
+    v = heads.view(F, h1, w1, 16)
+    score = torch.sigmoid(v[..., :2])
+    d = torch.zeros_like(v)
+    dscore = torch.empty_like(score)
+    anc = anchors.detach().float().contiguous()
+    losses, has_reg = [], []
+    for k in range(F):
+        t = targets[k]
+        pos = neg = gi = gts = None
+        n_pos = n_neg = 0
+        if t is not None:
+            pos, n_pos = _index_block(t[0], dev)
+            neg, n_neg = _index_block(t[1], dev)
+            if n_pos > 0:
+                gi = torch.as_tensor(t[2]).long().to(dev).contiguous()
+                gts = t[3].detach().float().to(dev).contiguous()
+        regress = n_pos > 0
+        ls, _, _ = _hip.voxel_loss(score[k], v[k, :, :, 2:] if regress else None, pos, neg, gi, n_pos, n_neg, gts,
+                                   anc if regress else None, 2, float(criterion.a), float(criterion.b), float(criterion.eps),
+                                   dscore_out=dscore[k], dreg_out=d[k, :, :, 2:] if regress else None)
+        losses.append(ls)
+        has_reg.append(regress)
+    d[..., :2] = dscore * score * (1.0 - score)
+    return torch.stack(losses), has_reg, d.view(F * h1 * w1, 16)
+
+
+def train_step_full(model, batch, targets, criterion, anchors, imsize, ready=None, prepare_next=None, rpn_hip=None, read=True):
     """One optimizer step's worth of forward + backward of the WHOLE model for the frames of ``batch``: frame sets up to
-    the BEV map (modules/frames.py), then RPN + VoxelLoss frame by frame (batch-1 BatchNorm statistics, exactly B
-    reference forwards, train.py:131-161) under autograd, whose gradient at the BEV map feeds the frame-set backward.
-    Gradients are ADDED into the existing .grad buffers (GradBucket); returns per-frame loss values (host floats)."""
+    the CML output (modules/frames.py), the RPN of all frames on this library's kernels (modules/rpn_frames.py; per-frame
+    BatchNorm statistics, exactly B reference forwards, train.py:131-161), VoxelLoss per frame, and the whole way back.
+    ``targets``: per frame (pi, ni, gi, gt boxes) or None.  Gradients are ADDED into the existing .grad buffers
+    (GradBucket).  ``rpn_hip=False`` runs the RPN + loss through the torch modules under autograd instead (comparison).
+    ``prepare_next`` = (next batch, callable returning its targets): voxelized, mapped and target-assigned on the
+    preparation stream after this step has been enqueued; returned as out['next'] = (ready, targets) for the next call.
+    ``read=False`` leaves the losses on the device (out['losses_dev'] (F,2)) and skips the status read: the caller reads
+    them a step later, so the host never waits for the step it has just enqueued."""
     from modules import frames as fr
+    from modules import rpn_frames as rf
+    rpn_hip = RPN_HIP if rpn_hip is None else rpn_hip
     dev = batch.device
-    fs, live, counts, status = prepare_frame_set(batch)
-    out = {'loss': [], 'cls': [], 'reg': [], 'voxels': counts}
-    if fs is None:
-        return out
+    main = torch.cuda.current_stream(dev)
+    ev_ready = None
+    if ready is None:
+        ready = prepare_frame_set(batch)
+    elif len(ready) == 5:
+        ready, ev_ready = ready[:4], ready[4]
+    fs, live, counts, status = ready
+    if ev_ready is not None:
+        main.wait_event(ev_ready)
+        status.record_stream(main)
+        if fs is not None:
+            fs.hand_over(main)
+        for t in targets:
+            if t is not None:
+                for x in tuple(t[0]) + tuple(t[1]) + (t[2], t[3]):
+                    if isinstance(x, torch.Tensor) and x.is_cuda:
+                        x.record_stream(main)
+    out = {'loss': [], 'cls': [], 'reg': [], 'voxels': counts, 'live': live}
     hw = [float(imsize[0]), float(imsize[1])]
     old_sink, _hip.GRAD_SINK = _hip.GRAD_SINK, True
+    old_async, _hip.ASYNC_WGRAD = _hip.ASYNC_WGRAD, True
+    statuses = [status]
     try:
-        model.prepack()
-        _hip.arena_begin(dev, doubles=1 << 21)
-        statuses = [status]
-        with torch.no_grad():
-            mid, saved = fr.middle_forward(model, fs, [batch.fpn_levels[f] for f in live], hw, statuses)
-        leaf = mid.detach().requires_grad_(True)
-        total = None
-        parts = []
-        for k, f in enumerate(live):
-            score, reg = model.backbone.rpn(leaf[k:k + 1])
-            score = score.squeeze(dim=0).permute(1, 2, 0)
-            reg = reg.squeeze(dim=0).permute(1, 2, 0)
-            t = targets[f]
-            if t is None:
-                cls_loss, reg_loss = criterion(None, None, None, None, score, None, anchors, 2)
+        if fs is not None:
+            model.prepack()
+            _hip.arena_begin(dev, doubles=1 << 21)
+            F = len(live)
+            tl = [targets[f] for f in live]
+            with torch.no_grad():
+                feat, saved = fr.rows_forward(model, fs, [batch.fpn_levels[f] for f in live], hw, statuses)
+                if rpn_hip:
+                    fr.cml_forward(model, fs, feat, saved, statuses, want_bev=False)
+                    rpn = model.backbone.rpn
+                    heads, rs = rf.rpn_forward(rpn, saved.x3, F, saved.D3, saved.H, saved.W, saved.C3)
+                    losses, has_reg, d_heads = heads_loss(heads, F, rs['h1'], rs['w1'], tl, criterion, anchors)
+                    g_cl = rf.rpn_backward(rpn, rs, d_heads)
+                    fr.rows_backward(model, saved, fr.cml_backward(model, saved, None, g_cl=g_cl))
+                else:
+                    mid = fr.cml_forward(model, fs, feat, saved, statuses)
+            if not rpn_hip:
+                leaf = mid.detach().requires_grad_(True)
+                total, parts = None, []
+                for k in range(F):
+                    score, reg = model.backbone.rpn(leaf[k:k + 1])
+                    score = score.squeeze(dim=0).permute(1, 2, 0)
+                    reg = reg.squeeze(dim=0).permute(1, 2, 0)
+                    t = tl[k]
+                    if t is None:
+                        cls_loss, reg_loss = criterion(None, None, None, None, score, None, anchors, 2)
+                    else:
+                        cls_loss, reg_loss = criterion(t[0], t[1], t[2], t[3], score, reg, anchors, 2)
+                    loss = cls_loss if reg_loss is None else cls_loss + reg_loss
+                    total = loss if total is None else total + loss
+                    parts.append(torch.stack([cls_loss.detach(), reg_loss.detach() if reg_loss is not None else cls_loss.detach() * 0]))
+                total.backward()
+                has_reg = [t is not None and len(t[0][0]) > 0 for t in tl]
+                losses = torch.stack(parts)
+                with torch.no_grad():
+                    fr.rows_backward(model, saved, fr.cml_backward(model, saved, leaf.grad))
+            out['losses_dev'], out['has_reg'] = losses, has_reg
+        if prepare_next is not None:
+            nb, target_fn = prepare_next
+            if PREP_STREAM:
+                prep = _prep_stream(dev)
+                with torch.cuda.stream(prep):
+                    nr = prepare_frame_set(nb)
+                    nt = target_fn()
+                    ev = torch.cuda.Event()
+                    ev.record(prep)
+                out['next'] = (nr + (ev,), nt)
             else:
-                cls_loss, reg_loss = criterion(t[0], t[1], t[2], t[3], score, reg, anchors, 2)
-            loss = cls_loss if reg_loss is None else cls_loss + reg_loss
-            total = loss if total is None else total + loss
-            parts.append((loss, cls_loss, reg_loss))
-        total.backward()
-        with torch.no_grad():
-            fr.middle_backward(model, saved, leaf.grad)
-        bad = int(torch.stack([s.reshape(()) for s in statuses]).max())
-        if bad:
-            raise _hip.X.MvxHipError('a kernel reported a data-dependent error (status %d)' % bad)
-        for loss, c, r in parts:
-            out['loss'].append(float(loss))
-            out['cls'].append(float(c))
-            if r is not None:
-                out['reg'].append(float(r))
+                out['next'] = (prepare_frame_set(nb), target_fn())
+        out['statuses'] = statuses
+        if read and fs is not None:
+            read_losses(out)
     finally:
         _hip.GRAD_SINK = old_sink
+        _hip.ASYNC_WGRAD = old_async
         _hip.arena_end()
         _hip.join_side_stream()
+    return out
+
+
+def read_losses(out):
+    """Host side of a step enqueued with read=False: the status words and the per-frame losses (ONE device read each)."""
+    if 'losses_dev' not in out:
+        return out
+    bad = int(torch.stack([s.reshape(()) for s in out['statuses']]).max())
+    if bad:
+        raise _hip.X.MvxHipError('a kernel reported a data-dependent error (status %d)' % bad)
+    vals = out['losses_dev'].tolist()
+    for (c, r), hr in zip(vals, out['has_reg']):
+        out['cls'].append(c)
+        if hr:
+            out['reg'].append(r)
+        out['loss'].append(c + r if hr else c)
     return out

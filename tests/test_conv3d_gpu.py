@@ -139,7 +139,7 @@ def test_input_sparse_first_layer_equals_dense(golden):
     for mode in (occ, occ[0]):                             # wave-autonomous kernel / tile-skipping dense kernel
         sparse, st_s = _hip.conv3d_forward(grid, wpk, b, 64, 2, 1, occupancy=mode)
         assert torch.equal(dense, sparse)                  # only exact-zero products were dropped
-        assert torch.allclose(st_d.sum(0), st_s.sum(0), rtol=1e-12)
+        assert torch.allclose(st_d.sum(0), st_s.sum(0), rtol=1e-6)    # per-wave partial sums in f32 vs f64 block sums
     dz = torch.randn(dense.shape, generator=g).to(DEV)
     dw_d = _hip.conv3d_wgrad(grid, dz, 2, 1)
     dw_s = _hip.conv3d_wgrad_sites(feat, coords, dz, D, 2, 1)

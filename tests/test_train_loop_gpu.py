@@ -72,6 +72,68 @@ def test_train_like_runs_and_resumes(tmp_path, mode):
 
 
 @pytest.mark.gpu
+def test_whole_model_step_hip_rpn_agrees_with_the_module_rpn(tmp_path):
+    """pipeline.train_step_full with the RPN + VoxelLoss on this library's kernels (modules/rpn_frames.py, no autograd)
+    against the same step with the torch RPN modules (MIOpen) + VoxelLoss under autograd, same frames and targets, full
+    176x200 maps: losses to 1e-4, every parameter gradient to 3e-2 of its rms (both are fp32 evaluations through 17 + 9
+    ReLU + BatchNorm layers; tools/fullsize_grad_check.py has the float64 yardstick for that figure), and the deferred
+    read (read=False + read_losses) returns the same numbers."""
+    sys.path.insert(0, PKG)
+    import modules.config as cfg
+    from modules import parallel, pipeline as pl
+    from modules.Calc import bbox3d2bev
+    from modules.data import Load, Preprocessing as pre
+    from modules.voxelnet import VoxelLoss
+    from MVXNet import MVXNet
+    import train_like
+    root = _tree(tmp_path, n=2)
+    ds = Load.createDataset(['000000', '000001'], root=root)
+    dev = torch.device('cuda')
+    anchors = pre.createAnchors(cfg.voxelshape[0] // 2, cfg.voxelshape[1] // 2, cfg.velorange, cfg.carsize)
+    bevs = bbox3d2bev(anchors.reshape(anchors.shape[:2] + (-1, 7))).to(dev).contiguous()
+    anchors = anchors.to(dev)
+    torch.manual_seed(0)
+    model = MVXNet().to(dev)
+    params = [p for p in model.parameters() if p.requires_grad]
+    bucket = parallel.GradBucket(params)
+    crit = VoxelLoss()
+    np.random.seed(0)
+    batch, targets = pl.batch_from_dataset(ds, ['000000', '000001'], dev, bevs, train_like.fpn_maps_for, cap_points=3000)
+    assert any(t is not None and len(t[0][0]) > 0 for t in targets)
+    res = {}
+    for name, hip in (('hip', True), ('module', False)):
+        bucket.zero()
+        out = pl.train_step_full(model, batch, targets, crit, anchors, cfg.imsize, rpn_hip=hip)
+        torch.cuda.synchronize()
+        res[name] = (out, bucket.flat.clone())
+    a, b = res['hip'][0], res['module'][0]
+    assert len(a['loss']) == len(b['loss']) == 2 and len(a['reg']) == len(b['reg'])
+    for key in ('loss', 'cls', 'reg'):
+        np.testing.assert_allclose(a[key], b[key], rtol=1e-4, atol=1e-6)
+    ga, gb = res['hip'][1], res['module'][1]
+    off = 0
+    worst = 0.0
+    for k, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        x, y = ga[off:off + p.numel()].double(), gb[off:off + p.numel()].double()
+        off += p.numel()
+        rms = float(y.pow(2).mean().sqrt())
+        if rms == 0.0:
+            assert float(x.abs().max()) == 0.0, k
+            continue
+        e = float((x - y).abs().max()) / max(float(y.abs().max()), rms)
+        worst = max(worst, e)
+        assert e < 3e-2, (k, e)
+    print('worst parameter-gradient deviation hip vs module RPN: %.2e' % worst)
+    bucket.zero()
+    out = pl.train_step_full(model, batch, targets, crit, anchors, cfg.imsize, read=False)
+    assert out['loss'] == [] and out['losses_dev'].shape == (2, 2)
+    pl.read_losses(out)
+    np.testing.assert_allclose(out['loss'], a['loss'], rtol=1e-6)
+
+
+@pytest.mark.gpu
 def test_state_dict_round_trip_reproduces_outputs(tmp_path):
     from MVXNet import MVXNet
     torch.manual_seed(1)
