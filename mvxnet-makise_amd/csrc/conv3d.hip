@@ -943,16 +943,41 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_sites(const float *__restric
 
 
 // ------------------------------------------------------------------------------------------
-// weight gradient, SIMD-balanced form (used when Cin % 64 == 0).  Nine one-tap waves do not divide
-// over the CU's four SIMDs (3+2+2+2), so the 9-wave kernel above idles a quarter of the matrix
-// pipes.  Here a workgroup has FOUR waves, (m, n) in 2 x 2 over a 64(c) x 64(n) block of dW, and
-// every wave walks all nine in-plane taps itself: 9 accumulator tiles (144 VGPRs), nine tap-shifted
-// A reads + one B read per MFMA step, two workgroups (8 waves, 2 per SIMD) per CU.
+// weight gradient, SIMD-balanced form (used when Cin % 64 == 0).  A workgroup has EIGHT waves: (m, n) in 2 x 2 over a
+// 64(c) x 64(n) block of dW, times two tap groups -- waves 0-3 walk in-plane taps {0..4}, waves 4-7 taps {5..8} of the
+// same staged tile (2-tap / 2-tap for the 2x2 window of the stride-2 RPN layers).  Waves w and w+4 share a SIMD, so every
+// SIMD carries nine MFMAs per k step and two waves to hide each other's LDS and barrier waits: the earlier four-wave form
+// (all nine taps per wave, 144 accumulator + 80 prefetch VGPRs = 300, ONE wave per SIMD) ran at 0.46 of the matrix peak
+// in isolation.  Here: 80 accumulator + 40 prefetch VGPRs, one workgroup (2 waves per SIMD) per CU.
 // ------------------------------------------------------------------------------------------
 struct Strips { int n[3]; };       // workgroups (strips) per depth tap in list mode
-constexpr int W4_THREADS = 256;
+constexpr int W4_THREADS = 512;
 constexpr int W4_C = 64;               // input channels per workgroup
 
+// tap OWNED (written) by slot i of a tap group (-1: none); the first w4_ncomp() slots are computed, the rest stay zero
+__host__ __device__ constexpr int w4_own(bool t2, int grp, int i) {
+    return t2 ? (grp == 0 ? (i < 3 ? i : i + 2) : (i < 2 ? i + 3 : (i < 4 ? i + 5 : -1)))      // {0,1,2,5,6} / {3,4,7,8}
+              : (grp == 0 ? i : (i < 4 ? i + 5 : -1));                                         // {0,1,2,3,4} / {5,6,7,8}
+}
+__host__ __device__ constexpr int w4_ncomp(bool t2, int grp) { return t2 ? 2 : (grp == 0 ? 5 : 4); }
+
+template <bool T2, int GRP>
+__device__ __forceinline__ void wgrad4_mfma_step(const float *__restrict__ s_x, const float *__restrict__ s_z, f32x16 (&acc)[5],
+                                                 int wm, int wn, int li, int lh) {
+#pragma unroll 2
+    for (int kk = 0; kk < TH * TW / 2; ++kk) {
+        const int s = 2 * kk + lh;
+        const float b = s_z[s * ZP + wn * 32 + li];
+        const float *xa = s_x + ((s >> 4) * HW + (s & 15)) * W4_C + wm * 32 + li;
+#pragma unroll
+        for (int i = 0; i < w4_ncomp(T2, GRP); ++i) {
+            const int t9 = w4_own(T2, GRP, i);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[((t9 / 3) * HW + (t9 % 3)) * W4_C], b, acc[i], 0, 0, 0);
+        }
+    }
+}
+
+template <bool T2>
 __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restrict__ in,
                                                             const float *__restrict__ dz,
                                                             float *__restrict__ slabs, Geom g,
@@ -971,14 +996,15 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restr
     if (strip >= nstrips) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int wm = wv >> 1, wn = wv & 1;
+    const int grp = wv >> 2;                         // tap group
+    const int wm = (wv >> 1) & 1, wn = wv & 1;
     const int nb = blockIdx.z;                       // 64-channel block of dz / dW (Cout = 64 * gridDim.z)
     dz += (size_t)nb * BN;
     slabs += (size_t)nb * gridDim.x * 27 * g.Cin * BN;       // slab index = blockIdx.x (gridDim.x = the largest share)
 
-    f32x16 acc[9];
+    f32x16 acc[5];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 5; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -1057,27 +1083,20 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restr
         __syncthreads();
         const int nxt = next_live(cur + 1);
         load_step(nxt < nsteps ? nxt : cur);          // unconditional (see conv3d_gather_pf): the last one is dropped
-#pragma unroll 2
-        for (int kk = 0; kk < TH * TW / 2; ++kk) {
-            const int s = 2 * kk + lh;
-            const float b = s_z[s * ZP + wn * 32 + li];
-            const float *xa = s_x + ((s >> 4) * HW + (s & 15)) * W4_C + wm * 32 + li;
-#pragma unroll
-            for (int t9 = 0; t9 < 9; ++t9) {
-                if (t9 / 3 < g.tap_lo || t9 / 3 >= g.tap_hi || t9 % 3 < g.tap_lo || t9 % 3 >= g.tap_hi) continue;   // uniform
-                acc[t9] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[((t9 / 3) * HW + (t9 % 3)) * W4_C], b, acc[t9], 0, 0, 0);
-            }
-        }
+        if (grp == 0) wgrad4_mfma_step<T2, 0>(s_x, s_z, acc, wm, wn, li, lh);
+        else wgrad4_mfma_step<T2, 1>(s_x, s_z, acc, wm, wn, li, lh);
         cur = nxt;
     }
-    // slab[strip][kd][tap][c (Cin)][n (64)]
+    // slab[strip][kd][tap][c (Cin)][n (64)]: every tap is written by the group that owns it (zeros where nothing was computed)
 #pragma unroll
-    for (int t9 = 0; t9 < 9; ++t9) {
+    for (int i = 0; i < 5; ++i) {
+        const int t9 = grp == 0 ? w4_own(T2, 0, i) : w4_own(T2, 1, i);
+        if (t9 < 0) continue;
         float *o = slabs + ((((size_t)strip * 3 + kd) * 9 + t9) * g.Cin + cc * W4_C + wm * 32) * BN + wn * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            o[(size_t)row * BN + li] = acc[t9][r];
+            o[(size_t)row * BN + li] = acc[i][r];
         }
     }
 }
@@ -1484,7 +1503,7 @@ extern "C" int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int
     Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
     hipStream_t st = (hipStream_t)stream;
     if (cin % W4_C == 0)
-        hipLaunchKernelGGL(conv3d_wgrad4, dim3(nstrips, 3 * (cin / W4_C), nblk), dim3(W4_THREADS), 0, st, in, dz,
+        hipLaunchKernelGGL(conv3d_wgrad4<false>, dim3(nstrips, 3 * (cin / W4_C), nblk), dim3(W4_THREADS), 0, st, in, dz,
                            (float *)workspace, g, per, (const int *)nullptr, (const int *)nullptr, (const float *)nullptr,
                            Strips{{nstrips, nstrips, nstrips}});
     else
@@ -1636,7 +1655,7 @@ extern "C" int mvx_conv3d_wgrad_bg_frames(const float *in, const float *dz, floa
     int *count = list + (size_t)3 * dout * n_frames * ntiles;
     hipLaunchKernelGGL(wgrad_step_list, dim3(3), dim3(1024), 0, st, in_halo_flags, g, ntiles, list, count);
     MVX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(conv3d_wgrad4, dim3(widest, 3 * (cin / W4_C)), dim3(W4_THREADS), 0, st, in, dz, slabs, g, 0,
+    hipLaunchKernelGGL(conv3d_wgrad4<false>, dim3(widest, 3 * (cin / W4_C)), dim3(W4_THREADS), 0, st, in, dz, slabs, g, 0,
                        (const int *)list, (const int *)count, c_in, ks);
     MVX_LAUNCH_CHECK();
     const size_t per_slab = (size_t)27 * cin * BN;
@@ -1707,7 +1726,7 @@ extern "C" int mvx_conv2d_dgrad_frames(const float *dz, const float *wpk_dgrad, 
 }
 
 static int conv2d_wgrad_strips(int cin, int cout) {
-    int s = 512 / ((cin / W4_C) * (cout / BN));                   // about two workgroups per CU in all
+    int s = 256 / ((cin / W4_C) * (cout / BN));                   // one 8-wave workgroup per CU in all (slab capacity)
     if (s > 128) s = 128;
     return s < 1 ? 1 : s;
 }
@@ -1730,7 +1749,9 @@ extern "C" int mvx_conv2d_wgrad_frames(const float *in, const float *dz, float *
     MVX_CHECK_ARG(workspace_bytes >= mvx_conv2d_wgrad_workspace_bytes_frames(h, w, cin, cout, n_frames));
     hipStream_t st = (hipStream_t)stream;
     const int ntiles = (int)(mvx_cdiv(w, TW) * mvx_cdiv(h, TH));
-    const int nstrips = conv2d_wgrad_strips(cin, cout);
+    int nstrips = conv2d_wgrad_strips(cin, cout);
+    if (nstrips > (n_frames * ntiles + 3) / 4) nstrips = (n_frames * ntiles + 3) / 4;     // >= 4 tile steps per strip: the slabs
+    if (nstrips < 1) nstrips = 1;                                                       // (589 KB per strip at cin 128) stay small
     const int nblk = cout / BN;
     Geom g{1, 1, h, w, cin, cout, 1, 1, 0, n_frames, 0, (flags & MVX_FLAG_TAPS2) ? 2 : 3};
     float *slabs = (float *)workspace;
@@ -1743,8 +1764,12 @@ extern "C" int mvx_conv2d_wgrad_frames(const float *in, const float *dz, float *
     MVX_LAUNCH_CHECK();
     Strips ks;
     ks.n[0] = 1; ks.n[1] = nstrips; ks.n[2] = 1;                    // depth tap 1 is the only one with a source plane
-    hipLaunchKernelGGL(conv3d_wgrad4, dim3(nstrips, 3 * (cin / W4_C), nblk), dim3(W4_THREADS), 0, st, in, dz, slabs, g, 0,
-                       (const int *)list, (const int *)count, (const float *)nullptr, ks);
+    if (flags & MVX_FLAG_TAPS2)
+        hipLaunchKernelGGL(conv3d_wgrad4<true>, dim3(nstrips, 3 * (cin / W4_C), nblk), dim3(W4_THREADS), 0, st, in, dz, slabs, g, 0,
+                           (const int *)list, (const int *)count, (const float *)nullptr, ks);
+    else
+        hipLaunchKernelGGL(conv3d_wgrad4<false>, dim3(nstrips, 3 * (cin / W4_C), nblk), dim3(W4_THREADS), 0, st, in, dz, slabs, g, 0,
+                           (const int *)list, (const int *)count, (const float *)nullptr, ks);
     MVX_LAUNCH_CHECK();
     const size_t per_slab = (size_t)27 * cin * BN;
     hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256), nblk), dim3(256), 0, st, (const float *)slabs, dw, nstrips, cin,
