@@ -166,15 +166,22 @@ __device__ __forceinline__ void bn_finalize_core(unsigned *done_counter, unsigne
     for (int e = threadIdx.x; e < C * F; e += blockDim.x) {
         const int f = e / C, c = e - f * C;
         const double *st = stats + (size_t)f * MVX_REP * 2 * C;
-        double v1[MVX_REP], v2[MVX_REP];
-#pragma unroll
-        for (int rp = 0; rp < MVX_REP; ++rp) {            // 64 independent device-scope reads in flight
-            v1[rp] = __hip_atomic_load(st + ((size_t)rp * 2) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v2[rp] = __hip_atomic_load(st + ((size_t)rp * 2 + 1) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        // 16 independent device-scope reads in flight per round: the registers of this (one workgroup per launch) tail
+        // are allocated for every wave of the kernel -- 64 reads in flight cost the row GEMM 128 VGPRs and with them its
+        // second wave per SIMD
+        constexpr int CH = 8;
         double s1 = 0.0, s2 = 0.0;
+#pragma unroll 1
+        for (int r0 = 0; r0 < MVX_REP; r0 += CH) {
+            double v1[CH], v2[CH];
 #pragma unroll
-        for (int rp = 0; rp < MVX_REP; ++rp) { s1 += v1[rp]; s2 += v2[rp]; }
+            for (int rp = 0; rp < CH; ++rp) {
+                v1[rp] = __hip_atomic_load(st + ((size_t)(r0 + rp) * 2) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v2[rp] = __hip_atomic_load(st + ((size_t)(r0 + rp) * 2 + 1) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int rp = 0; rp < CH; ++rp) { s1 += v1[rp]; s2 += v2[rp]; }
+        }
         const double count = count_of(f);
         const double mean = s1 / count;
         double var = s2 / count - mean * mean;

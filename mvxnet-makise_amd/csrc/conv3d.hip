@@ -435,6 +435,21 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
     if (relu) { bgv0 = fmaxf(bgv0, 0.f); bgv1 = fmaxf(bgv1, 0.f); }
     // BatchNorm sums in f64 from the first addition on: var = E[y^2] - mean^2 cancels, and f32 partial sums cost
     // mean^2 / var times their 1e-7 in the variance (the reference's torch-CPU BatchNorm accumulates in double too)
+    // the 16 site-mask bytes of this lane are fetched up front, unconditionally from clamped coordinates: a load between the
+    // stores (vector-memory operations return in order) made every store pair wait for the previous one to complete
+    unsigned site_on = active ? 0xffffu : 0u;          // bit r: site r is a computed (non-background) site
+    if (out_mask && active) {
+        unsigned char mk[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int gy = min(ty0 + 2 * wv + (row >> 4), g.H - 1), gx = min(tx0 + (row & 15), g.W - 1);
+            mk[r] = out_mask[((size_t)d * g.H + gy) * g.W + gx];
+        }
+        site_on = 0u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) site_on |= (mk[r] ? 1u : 0u) << r;
+    }
     double s1a = 0.0, s2a = 0.0, s1b = 0.0, s2b = 0.0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -442,10 +457,8 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
         const int gy = ty0 + 2 * wv + (row >> 4), gx = tx0 + (row & 15);
         float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
         if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-        if (out_mask && gy < g.H && gx < g.W) {
-            // a background SITE holds the constant bit for bit, also inside a computed tile
-            if (!active || !out_mask[((size_t)d * g.H + gy) * g.W + gx]) { v0 = bgv0; v1 = bgv1; }
-        }
+        // a background SITE holds the constant bit for bit, also inside a computed tile
+        if (out_mask && !((site_on >> r) & 1u)) { v0 = bgv0; v1 = bgv1; }
         if (gy < g.H && gx < g.W) {
             float *o = out + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout;
             o[n0] = v0;

@@ -27,7 +27,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BM = 128, BK = 32, PITCH = BK + 4;
 
 template <bool WT, int NT, bool VEC>
-__global__ __launch_bounds__(256) void linear_fwd(const float *__restrict__ x, int ldx, const float *__restrict__ w,
+__global__ __launch_bounds__(256, 2) void linear_fwd(const float *__restrict__ x, int ldx, const float *__restrict__ w,
                                                   int ldw, const float *__restrict__ bias, float *__restrict__ y,
                                                   int ldy, double *__restrict__ stats, const float *__restrict__ row_w,
                                                   long long R, int K, int N, int relu, int k_per_split,
@@ -158,20 +158,46 @@ __global__ __launch_bounds__(256) void linear_fwd(const float *__restrict__ x, i
         }
     }
 
-    // store, then the BatchNorm sums.  A 128-row block almost always lies inside one frame; a block that straddles a
-    // frame boundary repeats the (register-only) reduction once per frame with the other frames' rows masked out.
+    // Epilogue.  Every load it needs (bias, row weights) is issued FIRST and unconditionally from clamped addresses, the
+    // accumulators become the outputs in place, and only then come the stores: vector-memory operations return in order
+    // (one vmcnt), so a load issued between stores -- or under a condition the waitcnt pass cannot see through -- made
+    // every store wait for all earlier ones (`s_waitcnt vmcnt(0)` in front of each of the 16 * NT stores).
     float bsv[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int c = n0 + t * 32 + li;
-        bsv[t] = (bias && c < N) ? bias[c] : 0.f;
+        bsv[t] = bias ? bias[c < N ? c : N - 1] : 0.f;
+    }
+    float rwv[16];
+    if (stats && row_w) {                      // one uniform branch around the whole batch of loads
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
             const long long gr = r0 + wv * 32 + row;
+            rwv[r] = row_w[gr < R ? gr : R - 1];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rwv[r] = 1.f;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
             float v = acc[t][r] + bsv[t];
             if (relu) v = fmaxf(v, 0.f);
-            if (gr < R && c < N) y[gr * ldy + c] = v;
+            acc[t][r] = v;
+        }
+    // store, then the BatchNorm sums.  A 128-row block almost always lies inside one frame; a block that straddles a
+    // frame boundary repeats the (register-only) reduction once per frame with the other frames' rows masked out.
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int c = n0 + t * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const long long gr = r0 + wv * 32 + row;
+            if (gr < R && c < N) y[gr * ldy + c] = acc[t][r];
         }
     }
     if (stats) {
@@ -192,10 +218,11 @@ __global__ __launch_bounds__(256) void linear_fwd(const float *__restrict__ x, i
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
                     const long long gr = r0 + wv * 32 + row;
-                    float v = acc[t][r] + bsv[t];
-                    if (relu) v = fmaxf(v, 0.f);
+                    float v = acc[t][r];
+                    asm volatile("" : "+v"(v));     // opaque per segment: keeps the 64 f64 conversions and squares from being
+                                                    // hoisted out of the segment loop (they cost 256 VGPRs = the second wave)
                     if (gr < R && c < N && gr >= lo && gr < hi) {
-                        const double rw = row_w ? (double)row_w[gr] : 1.0;
+                        const double rw = (double)rwv[r];
                         s1[t] += rw * (double)v;
                         s2[t] += rw * (double)v * (double)v;
                     }
