@@ -140,20 +140,32 @@ __global__ __launch_bounds__(1024) void bnb_tile_list(const int *__restrict__ ti
     __syncthreads();
     const int total = D * ntiles;
     int base = 0;
-    for (int e0 = 0; e0 < total; e0 += 1024) {
-        const int e = e0 + threadIdx.x;
-        int on = 0;
-        if (e < total) {
-            on = tile_flags[e] != 0;
-            if (!on) {
+    // contiguous run per thread, flags in one 64-bit word, one block scan per 65,536 entries (see wgrad_step_list)
+    for (int s0 = 0; s0 < total; s0 += 1024 * 64) {
+        const int left = total - s0;
+        const int per = left >= 1024 * 64 ? 64 : (left + 1023) / 1024;
+        const int b0 = s0 + (int)threadIdx.x * per;
+        unsigned long long bits = 0ull;
+#pragma unroll 8
+        for (int k = 0; k < per; ++k) {
+            const int e = b0 + k;
+            if (e < total) bits |= (unsigned long long)(tile_flags[e] != 0) << k;
+        }
+        for (int k = 0; k < per; ++k) {
+            const int e = b0 + k;
+            if (e < total && !((bits >> k) & 1ull)) {
                 const int d = e / ntiles, t = e - d * ntiles;
                 const int ty0 = (t / tiles_x) * ATH, tx0 = (t % tiles_x) * ATW;
                 atomicAdd(&s_inact[d], min(ATH, H - ty0) * min(ATW, W - tx0));
             }
         }
         int tot;
-        const int pos = block_excl_scan_i32(on, smem, &tot);
-        if (on) list[base + pos] = e;
+        int pos = base + block_excl_scan_i32(__popcll(bits), smem, &tot);
+        while (bits) {
+            const int k = __ffsll((long long)bits) - 1;
+            bits &= bits - 1;
+            list[pos++] = b0 + k;
+        }
         base += tot;
     }
     __syncthreads();

@@ -191,6 +191,20 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_split(const float *__res
     const float bias0 = bias ? bias[n0] : 0.f, bias1 = bias ? bias[n1] : 0.f;
     float bgv0 = (bg_pre ? bg_pre[(size_t)d * g.Cout + n0] : 0.f) + bias0, bgv1 = (bg_pre ? bg_pre[(size_t)d * g.Cout + n1] : 0.f) + bias1;
     if (relu) { bgv0 = fmaxf(bgv0, 0.f); bgv1 = fmaxf(bgv1, 0.f); }
+    // site-mask bytes fetched up front (see conv3d.hip: a load between the stores made every store pair wait)
+    unsigned site_on = active ? 0xffffu : 0u;
+    if (out_mask && active) {
+        unsigned char mk[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int gy = min(ty0 + 2 * wv + (row >> 4), g.H - 1), gx = min(tx0 + (row & 15), g.W - 1);
+            mk[r] = out_mask[((size_t)d * g.H + gy) * g.W + gx];
+        }
+        site_on = 0u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) site_on |= (mk[r] ? 1u : 0u) << r;
+    }
     float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -198,9 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_split(const float *__res
         const int gy = ty0 + 2 * wv + (row >> 4), gx = tx0 + (row & 15);
         float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
         if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-        if (out_mask && gy < g.H && gx < g.W) {
-            if (!active || !out_mask[((size_t)d * g.H + gy) * g.W + gx]) { v0 = bgv0; v1 = bgv1; }
-        }
+        if (out_mask && !((site_on >> r) & 1u)) { v0 = bgv0; v1 = bgv1; }
         if (gy < g.H && gx < g.W) {
             float *o = out + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout;
             o[n0] = v0;

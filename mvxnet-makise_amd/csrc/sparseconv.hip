@@ -84,18 +84,27 @@ __global__ __launch_bounds__(256) void sparse_conv_output(const float *__restric
         if (y >= g.H || !col_live) continue;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (any) {
+            // per depth tap: the nine voxel ids from LDS, then nine UNCONDITIONAL row loads in flight together (an absent
+            // voxel reads row 0 and is dropped afterwards), added in the fixed tap order.  A load under `if (v >= 0)` was
+            // waited for where it was issued: 27 dependent latencies per site row.
 #pragma unroll
-            for (int kd = 0; kd < 3; ++kd)
+            for (int kd = 0; kd < 3; ++kd) {
+                int v[9];
+                int some = 0;
 #pragma unroll
-                for (int a = 0; a < 3; ++a)
+                for (int j = 0; j < 9; ++j) {
+                    v[j] = s_idx[kd][r + j / 3][st + j % 3];          // -1 outside the grid / invalid depth tap
+                    some |= v[j] >= 0;
+                }
+                if (!__any(some)) continue;                            // wave-uniform
+                float4 p[9];
 #pragma unroll
-                    for (int b = 0; b < 3; ++b) {
-                        const int v = s_idx[kd][r + a][st + b];       // -1 outside the grid / invalid depth tap
-                        if (v >= 0) {
-                            const float4 p = *(const float4 *)(P + ((size_t)v * 27 + (kd * 9 + a * 3 + b)) * g.Cout + ct * 4);
-                            acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
-                        }
-                    }
+                for (int j = 0; j < 9; ++j)
+                    p[j] = *(const float4 *)(P + ((size_t)max(v[j], 0) * 27 + (kd * 9 + j)) * g.Cout + ct * 4);
+#pragma unroll
+                for (int j = 0; j < 9; ++j)
+                    if (v[j] >= 0) { acc.x += p[j].x; acc.y += p[j].y; acc.z += p[j].z; acc.w += p[j].w; }
+            }
         }
         acc.x += bs.x; acc.y += bs.y; acc.z += bs.z; acc.w += bs.w;
         if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
