@@ -21,7 +21,7 @@ def init_from_env(backend=None):
             # a fixed default port collides as soon as two jobs share a host: the launcher (torchrun) must name it
             raise RuntimeError('WORLD_SIZE > 1 needs MASTER_PORT (launch with torchrun / torch.distributed.run)')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('MVX_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -62,3 +62,16 @@ class GradBucket:
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         self.flat.mul_(1.0 / float(frames_total))
+
+
+def assert_replicas_in_sync(params):
+    """Every rank must hold bit-identical parameters after an optimizer step on the all-reduced gradient: compares a
+    (sum, sum of squares) fingerprint in float64 across ranks; raises on divergence.  No-op in a single process."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    flat = torch.cat([p.detach().reshape(-1).double() for p in params])
+    mine = torch.stack([flat.sum(), (flat * flat).sum()])
+    all_ = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(all_, mine)
+    if not all(torch.equal(all_[0], a) for a in all_):
+        raise RuntimeError('data-parallel replicas diverged: %s' % [a.tolist() for a in all_])

@@ -192,6 +192,8 @@ def train(args):
             torch.save(opt.state_dict(), os.path.join(args.checkpoints, 'epoch%d_opt.pkl' % n))
         if args.steps and steps_done >= args.steps:
             break
+    if args.mode == 'fast':
+        parallel.assert_replicas_in_sync(params)
     say('forward %.2f s, loss %.2f s, backward %.2f s' % (forwardTime, lossTime, backwardTime))
     return {'losses': losses, 'steps': steps_done, 'model': model, 'opt': opt}
 

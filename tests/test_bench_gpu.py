@@ -40,3 +40,36 @@ def test_bench_vfe_mode_checks_voxel_indices_against_the_oracle():
     d = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith('{')][0])
     assert d['roofline']['bound'] == 'hbm' and d['value'] > 0
     assert d['cpu_baseline']['voxel_indices_vs_oracle'].startswith('ok') and d['cpu_baseline']['value'] > 0
+
+
+@pytest.mark.gpu
+def test_bench_full_mode_runs_the_whole_model_and_reports_losses():
+    """--mode full (BASELINE config 3): classifyAnchors + frame sets + HIP RPN + VoxelLoss + whole backward inside the step."""
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--mode', 'full', '--steps', '3', '--warmup', '1', '--frames',
+                          '2', '--points', '4000', '--no-cpu-baseline'], capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith('{')][0])
+    assert d['config']['mode'] == 'full' and d['value'] > 0 and 'rpn_conv' in d['other_kernels']
+    assert len(d['last_losses']) == 2 and all(0 < v < 100 for v in d['last_losses'])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_the_frames_and_print_one_line():
+    """The N > 1 path of bench.py on this one-GPU box: two ranks under torch.distributed.run (gloo instead of RCCL, which
+    refuses two ranks on one device), frames {i : i mod 2 = rank}, barrier + MAX over ranks, ONE JSON line from rank 0."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MVX_DIST_BACKEND='gloo')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                          '127.0.0.1', '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2',
+                          '--warmup', '1', '--frames', '2', '--points', '4000', '--timed-only'],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['config']['parallelism'] == 'dp2' and d['value'] > 0
+    assert abs(d['value'] - 2 * 2 * d['steps'] / (d['ms_per_step'] * d['steps'] * 1e-3)) < 1e-6 * d['value']

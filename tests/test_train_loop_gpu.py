@@ -72,6 +72,29 @@ def test_train_like_runs_and_resumes(tmp_path, mode):
 
 
 @pytest.mark.gpu
+def test_train_like_two_ranks_data_parallel(tmp_path):
+    """BASELINE config 5 in small: train_like.py --mode fast under torch.distributed.run with two ranks on this one-GPU box
+    (gloo: RCCL refuses two ranks on one device), 2 frames per rank per step, one all-reduce of the flat gradient bucket
+    per step; the script itself asserts that the replicas are bit-identical after training, rank 0 writes the checkpoint."""
+    import socket
+    import subprocess
+    root = _tree(tmp_path, n=8)
+    ck = str(tmp_path / 'ck')
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, MVX_DIST_BACKEND='gloo')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                          '127.0.0.1', '--master-port', str(port), os.path.join(PKG, 'train_like.py'), root, '-n', '1', '--mode',
+                          'fast', '--frames', '2', '--points', '3000', '--checkpoints', ck],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert 'Epoch1 4/4' in out.stdout                    # each rank saw its 4 of the 8 frames, 2 steps of 2 frames
+    assert os.path.exists(os.path.join(ck, 'epoch1.pkl'))
+
+
+@pytest.mark.gpu
 def test_whole_model_step_hip_rpn_agrees_with_the_module_rpn(tmp_path):
     """pipeline.train_step_full with the RPN + VoxelLoss on this library's kernels (modules/rpn_frames.py, no autograd)
     against the same step with the torch RPN modules (MIOpen) + VoxelLoss under autograd, same frames and targets, full
