@@ -1014,27 +1014,37 @@ class _BiasStage:
         self.flat = flat
         self.bufs = [torch.zeros_like(flat), torch.zeros_like(flat)]
         self.events = [None, None]
+        self.touched = [{}, {}]            # per buffer: offset -> length of the slices handed out since its last clear
         self.turn = 0
         self.base = flat.data_ptr()
+
+    def _slices(self, t, turn):
+        return [t[o:o + n] for o, n in sorted(self.touched[turn].items())]
 
     def begin(self):
         self.turn ^= 1
         ev = self.events[self.turn]
         if ev is not None:
             torch.cuda.current_stream(self.flat.device).wait_event(ev)
-        self.bufs[self.turn].zero_()
+        # only the bias slices are ever written: clear and flush those (one multi-tensor kernel each), not the whole
+        # bucket (two full-bucket passes per frame to move a few KB)
+        if self.touched[self.turn]:
+            torch._foreach_zero_(self._slices(self.bufs[self.turn], self.turn))
+            self.touched[self.turn] = {}
 
     def view_for(self, grad):
         off = (grad.data_ptr() - self.base) // 4
         n = grad.numel()
         if off < 0 or off + n > self.flat.numel():
             return None
+        self.touched[self.turn][off] = n
         return self.bufs[self.turn][off:off + n]
 
     def flush(self):
         buf = self.bufs[self.turn]
         with _SideStream(buf) as sc:
-            self.flat.add_(buf)
+            if self.touched[self.turn]:
+                torch._foreach_add_(self._slices(self.flat, self.turn), self._slices(buf, self.turn))
             ev = torch.cuda.Event()
             ev.record(sc.side)
         self.events[self.turn] = ev
