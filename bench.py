@@ -424,7 +424,7 @@ def main():
         return out['voxels']
 
     step = {'hot': step_hot, 'vfe': step_vfe, 'dropin': step_dropin, 'full': step_full}[args.mode]
-    host_ms, exec_stages = [], []
+    host_ms, exec_stages, launches = [], [], []
 
     def timed_run(warmup, steps, fn=None):
         fn = step if fn is None else fn
@@ -438,12 +438,14 @@ def main():
         _hip.KERNEL_TIMERS = {}
         if _hip.EXEC_STAGES is not None:
             _hip.EXEC_STAGES.zero_()
+        l0 = _hip.X.lib.mvx_launch_count()
         t0 = time.perf_counter()
         for _ in range(steps):
             nv = fn()
         host_dt = time.perf_counter() - t0
         fence()
         dt_ = time.perf_counter() - t0
+        launches.append((_hip.X.lib.mvx_launch_count() - l0) / steps)
         host_ms.append(host_dt / steps * 1e3)
         tm, _hip.KERNEL_TIMERS = _hip.KERNEL_TIMERS, None
         exec_stages.append(int(_hip.EXEC_STAGES.item()) if _hip.EXEC_STAGES is not None else 0)
@@ -480,7 +482,7 @@ def main():
         for name, evs in tm.items():
             if name.startswith('hbm:') and evs:
                 tms = sum(s.elapsed_time(e) for s, e, _ in evs)
-                tb = sum(b for _, _, b in evs)
+                tb = sum(float(b) for _, _, b in evs)       # device scalars (data-dependent byte counts) are read here
                 out[name[4:]] = {'launches': len(evs), 'avg_ms': tms / len(evs),
                                  'algorithmic_GBps': tb / (tms * 1e-3) / 1e9 if tms > 0 and tb > 0 else None,
                                  'frac_of_8TBps': tb / (tms * 1e-3) / 8e12 if tms > 0 and tb > 0 else None}
@@ -594,6 +596,8 @@ def main():
             'ms_per_step': dt / args.steps * 1e3,
             'host_enqueue_ms_per_step': host_probe_ms,
             'host_in_timed_region_ms_per_step': host_ms[0],
+            'library_launches_per_step': launches[0],
+            'library_launches_per_frame': launches[0] / args.frames,
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,

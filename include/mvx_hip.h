@@ -77,6 +77,8 @@ typedef struct {
 
 /* ABI version; bumped whenever a signature changes. */
 int mvx_abi_version(void);
+/* Diagnostics: number of kernel launches the library has issued since it was loaded (fills excluded). */
+uint64_t mvx_launch_count(void);
 
 /* ------------------------------------------------------------------------------------------
  * Voxelizer.  Replaces cpp/voxelutil.cpp:325-360 (`_group`) together with the Python around

@@ -12,8 +12,10 @@
         if (!(cond)) return MVX_EINVAL; \
     } while (0)
 
+void mvxi_count_launch();       // diagnostics only: kernel launches issued by the library (mvx_launch_count)
 #define MVX_LAUNCH_CHECK()                              \
     do {                                                \
+        mvxi_count_launch();                            \
         hipError_t e__ = hipGetLastError();             \
         if (e__ != hipSuccess) return (int)e__;         \
     } while (0)

@@ -19,6 +19,7 @@
 //               found; stages the point group in LDS, reduces the centroid, writes the [T][C] block with coalesced stores.
 // Outputs either with a fixed stride per frame ([F][cap_voxels]...) or back to back over all frames (concat: the batch
 // layout of the frame-set path, coords[:,0] = frame index = the batch column of train.py:119).
+#include <atomic>
 #include "common.h"
 
 namespace {
@@ -338,6 +339,12 @@ __global__ __launch_bounds__(256) void vox_gather(const float *__restrict__ pcd,
 }  // namespace
 
 extern "C" int mvx_abi_version(void) { return 2; }
+
+// Diagnostics: kernel launches issued through the library since it was loaded (the only process-wide state it keeps;
+// hipMemsetAsync fills are not counted).  bench.py reports the difference over the timed steps.
+static std::atomic<unsigned long long> g_launches{0};
+void mvxi_count_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
+extern "C" uint64_t mvx_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
 
 extern "C" size_t mvx_voxelize_workspace_bytes(int32_t n_frames, int32_t cap_points) {
     if (n_frames <= 0 || cap_points <= 0) return 0;

@@ -175,7 +175,11 @@ class _Timed:
 
 def _timed_bytes(name, nbytes):
     """Timer for an HBM-bound stage: the third tuple field carries ALGORITHMIC bytes (negative marks bytes)."""
-    return _Timed('hbm:' + name, float(nbytes) if KERNEL_TIMERS is not None else 0)
+    if KERNEL_TIMERS is None:
+        return _Timed('hbm:' + name, 0)
+    # a device scalar (data-dependent byte count, e.g. bytes of the flagged tiles) is kept as a tensor and read by the
+    # consumer of the timers after the run: no host read inside the step
+    return _Timed('hbm:' + name, nbytes if isinstance(nbytes, torch.Tensor) else float(nbytes))
 
 
 def conv_flops(d_out_planes, d_src_planes, H, W, cin, cout, sd, pd, dgrad=False):

@@ -408,7 +408,9 @@ def cml_backward(model, S, grad_mid, g_cl=None):
         dz = torch.empty_like(y)
         ws = _hip.workspace(X.lib.mvx_bn_relu_backward_tiles_workspace_bytes_frames(planes, H, W, Cn, F), dev, 'bn_tiles')
         inact = torch.empty((F * planes, Cn), dtype=torch.float32, device=dev) if want_inactive else None
-        with _hip._timed_bytes('bn_relu_backward_tiles', 0):
+        # algorithmic bytes (timing runs only): the flagged 8x16 tiles, two passes reading dyhat and y, the second writing dz
+        nbytes = bflag.ne(0).sum() * (128 * Cn * 4 * 5) if _hip.KERNEL_TIMERS is not None else 0
+        with _hip._timed_bytes('bn_relu_backward_tiles', nbytes):
             X.check(X.lib.mvx_bn_relu_backward_tiles_frames(X.ptr(gin), X.ptr(y), X.ptr(mi), X.ptr(c_bg), X.ptr(y_bg), X.ptr(A),
                                                             X.ptr(bflag), planes, H, W, Cn, X.ptr(dz), X.ptr(_grad_of(bias)),
                                                             X.ptr(inact), _hip.FLAG_ACCUMULATE, X.ptr(ws), ws.numel(), F,
