@@ -237,7 +237,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather(const float *__restrict_
 // Load order matters (vector-memory returns are in order): the weight row needed next is always issued
 // BEFORE the long-latency halo fetch, so waiting for it does not wait for the halo.
 // ------------------------------------------------------------------------------------------
-constexpr int WROW = BN * PITCH;           // one tap's weight tile in LDS
+constexpr int WROW = BN * BK;              // one tap's weight tile in LDS: [64 cout][32 k], rows UNPADDED, the eight 16-byte
+                                           // slots of a row XOR-swizzled with (cout >> 1) & 7 -- conflict-free for the
+                                           // ds_read_b128 lane groups like the padded pitch was, and 3 KB smaller, which
+                                           // (with the statistics scratch aliased onto it) lets THREE workgroups share a CU
 // Halo row stride: a multiple of 64 floats, so that the two patch rows a wave reads (lanes 0-15 / 16-31)
 // start on the same 16-byte slot of the 256-byte bank row.  ds_read_b128 is served in the lane groups
 // {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): with site pitch 36 floats (9 slots, odd) the slots of one
@@ -276,8 +279,11 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
 
     const int my_ty = 2 * wv + (li >> 4), my_tx = li & 15;
     const int a_base = my_ty * HROW + my_tx * PITCH + 4 * lh;
-    const int b_base0 = li * PITCH + 4 * lh;
-    const int b_base1 = (32 + li) * PITCH + 4 * lh;
+    // weight rows li and 32 + li share the swizzle key; slot of k-group q: ((2q | lh) ^ key)
+    const int wkey = (li >> 1) & 7;
+    int b_off[BK / 8];
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) b_off[q] = li * BK + 4 * (((2 * q) | lh) ^ wkey);
 
     // valid depth taps of this output plane (block-uniform), packed as (kd, source plane) pairs
     int kd_l[3] = {0, 0, 0}, ds_l[3] = {0, 0, 0}, nk = 0;
@@ -354,7 +360,7 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
 #pragma unroll
         for (int v = 0; v < 6; ++v) {
             const int c = tid + 256 * (v & 1);
-            *(f32x4 *)(s_w + (v >> 1) * WROW + (c >> 3) * PITCH + (c & 7) * 4) = wreg[v];
+            *(f32x4 *)(s_w + (v >> 1) * WROW + (c >> 3) * BK + (((c & 7) ^ ((c >> 4) & 7)) * 4)) = wreg[v];
         }
     };
     auto compute_row = [&](int row) __attribute__((always_inline)) {
@@ -365,8 +371,8 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
 #pragma unroll
             for (int q = 0; q < BK / 8; ++q) {
                 const float4 av = *(const float4 *)(s_halo + a_off + 8 * q);
-                const float4 b0 = *(const float4 *)(s_w + t * WROW + b_base0 + 8 * q);
-                const float4 b1 = *(const float4 *)(s_w + t * WROW + b_base1 + 8 * q);
+                const float4 b0 = *(const float4 *)(s_w + t * WROW + b_off[q]);
+                const float4 b1 = *(const float4 *)(s_w + t * WROW + 32 * BK + b_off[q]);
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc0, 0, 0, 0);
@@ -490,7 +496,7 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
 
 // Classic launch: one unit per workgroup, grid = (tiles, planes, channel blocks).
 template <int TLO, int THI>
-__global__ __launch_bounds__(256, 2) void conv3d_gather_pf(const float *__restrict__ in,
+__global__ __launch_bounds__(256, 3) void conv3d_gather_pf(const float *__restrict__ in,
                                                            const float *__restrict__ wpk,
                                                            const float *__restrict__ bias,
                                                            float *__restrict__ out, double *__restrict__ stats,
@@ -503,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_pf(const float *__restri
                                                            double fin_eps, float *__restrict__ fin_mean_inv) {
     __shared__ __attribute__((aligned(16))) float s_halo[HH * HROW];
     __shared__ __attribute__((aligned(16))) float s_w[3 * WROW];
-    __shared__ double s_red[4][2 * BN];
+    double (*s_red)[2 * BN] = reinterpret_cast<double (*)[2 * BN]>(s_w);      // epilogue scratch: the weights are done by then
     gather_unit<TLO, THI>(blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, s_halo, s_w, s_red, in, wpk, bias, out, stats, g, relu,
                           in_hflag, out_mask, bg_pre, border_active, exec_stages, only_tiles);
     if (stats && done_counter) {
@@ -518,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_pf(const float *__restri
 // (tile fastest), dynamically: no tail round with idle CUs (3,300 units over 512 slots = 6.45 rounds) and background
 // tiles, which only write a constant, do not unbalance the workgroups.
 template <int TLO, int THI>
-__global__ __launch_bounds__(256, 2) void conv3d_gather_pw(const float *__restrict__ in,
+__global__ __launch_bounds__(256, 3) void conv3d_gather_pw(const float *__restrict__ in,
                                                            const float *__restrict__ wpk,
                                                            const float *__restrict__ bias,
                                                            float *__restrict__ out, double *__restrict__ stats,
@@ -533,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_pw(const float *__restri
                                                            int nblocks) {
     __shared__ __attribute__((aligned(16))) float s_halo[HH * HROW];
     __shared__ __attribute__((aligned(16))) float s_w[3 * WROW];
-    __shared__ double s_red[4][2 * BN];
+    double (*s_red)[2 * BN] = reinterpret_cast<double (*)[2 * BN]>(s_w);      // epilogue scratch: the weights are done by then
     __shared__ unsigned s_unit;
     const unsigned units = (unsigned)ntiles * nplanes * nblocks;
     for (;;) {
@@ -1349,7 +1355,7 @@ static int persistent_grid() {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
             cus <= 0)
             cus = 256;
-        cached = 2 * cus;                           // two workgroups per CU fit (LDS)
+        cached = 3 * cus;                           // three workgroups per CU fit (52.7 KB of LDS, 158 VGPRs each)
     }
     return cached;
 }
