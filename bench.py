@@ -76,6 +76,15 @@ def make_batch(frame_ids, dev, P, workload='S2', raw_points=RAW_POINTS):
                       calib=S.KITTI_CALIB, cap_points=P)
 
 
+def synthetic_gt():
+    """Eight 'Car' boxes (x y z l w h r, LiDAR frame) inside the range: the targets of --mode full / dropin."""
+    gg = np.random.default_rng(11)
+    n = 8
+    gt = np.stack([gg.uniform(8, 60, n), gg.uniform(-30, 30, n), gg.uniform(-1.8, -0.6, n), gg.uniform(3.4, 4.4, n),
+                   gg.uniform(1.5, 1.8, n), gg.uniform(1.4, 1.7, n), gg.choice([0.0, np.pi / 2], n) + gg.normal(0, 0.05, n)], 1)
+    return torch.tensor(gt, dtype=torch.float32)
+
+
 def host_threads():
     """Host threads this process may really use: affinity mask, then the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -89,11 +98,12 @@ def host_threads():
     return max(1, min(n, int(os.environ.get('MVX_CPU_THREADS', '64'))))
 
 
-def cpu_baseline(P, workload, budget_s=28.0):
+def cpu_baseline(P, workload, budget_s=28.0, with_rpn=False):
     """The CPU oracle (plain-C voxelizer + torch-CPU / oneDNN fusion, VFE, CML forward + backward, dense as the reference
     computes it) on a BOUNDED sample of the same workload: per thread count one warm-up frame, then frames until the
     time budget is used (at least 3); medians per stage.  All host threads the cgroup allows, and 8 threads (the size of
-    the build container).  A reported baseline, not the target."""
+    the build container).  A reported baseline, not the target.  ``with_rpn`` (--mode full): the C
+    classifyAnchors + torch-CPU RPN + VoxelLoss forward and backward in place of the fixed dL/d(BEV map)."""
     import ctypes
     sys.path.insert(0, os.path.join(REPO, 'oracle'))
     import mvx_oracle as O
@@ -103,6 +113,21 @@ def cpu_baseline(P, workload, budget_s=28.0):
     G = torch.ones((1, 128, O.VOXELSHAPE[0], O.VOXELSHAPE[1]))
     rng = np.asarray(O.VELORANGE, np.float64)
     size = np.asarray(O.voxelsize(), np.float64)
+    if with_rpn:
+        Prpn = {k: v.requires_grad_(True) for k, v in O.rpn_params(np.load(os.path.join(REPO, 'tests', 'golden', 'rpn_shapes.npz'))).items()}
+        anchors = O.create_anchors(O.VOXELSHAPE[0] // 2, O.VOXELSHAPE[1] // 2)
+        abev = O.bbox3d2bev(anchors.reshape(anchors.shape[:2] + (-1, 7)))
+        gt = synthetic_gt()
+        gbev = O.bbox3d2bev(gt)
+
+    def rpn_loss(mid):
+        """dL/d(mid) of clsLoss + regLoss through the RPN (train.py:131-161)."""
+        leaf_m = mid.detach().requires_grad_(True)
+        pi, ni, gi = O.classify_anchors(gbev, gt[:, [0, 1]], abev, O.VELORANGE, 0.45, 0.6)
+        score, reg = O.rpn(leaf_m, Prpn)
+        cls, rl = O.voxel_loss(pi, ni, gi, gt, score[0].permute(1, 2, 0), reg[0].permute(1, 2, 0), anchors, 2)
+        (cls if rl is None else cls + rl).backward()
+        return leaf_m.grad
 
     def one_frame(fid, P_):
         pc = frame_points(workload, fid, P)
@@ -126,11 +151,14 @@ def cpu_baseline(P, workload, budget_s=28.0):
         t2 = time.perf_counter()
         leaf = feat.detach().requires_grad_(True)
         mid = O.cml(O.reindex(leaf, idx), O.strip_prefix(P_, 'backbone.')).reshape(1, -1, O.VOXELSHAPE[0], O.VOXELSHAPE[1])
-        mid.backward(G)
+        tr0 = time.perf_counter()
+        g_mid = rpn_loss(mid) if with_rpn else G
+        tr1 = time.perf_counter()
+        mid.backward(g_mid)
         t3 = time.perf_counter()
         feat.backward(leaf.grad)
         t4 = time.perf_counter()
-        return int(V), (t1 - t0, (t2 - t1) + (t4 - t3), t3 - t2, t4 - t0)
+        return int(V), (t1 - t0, (t2 - t1) + (t4 - t3), (t3 - t2) - (tr1 - tr0), t4 - t0, tr1 - tr0)
 
     out = {}
     all_thr = host_threads()
@@ -150,14 +178,17 @@ def cpu_baseline(P, workload, budget_s=28.0):
         med = np.median(np.asarray(times), axis=0)
         out[label] = {'threads': n, 'frames_timed': len(times), 'voxels': nv,
                       'median_s': {'voxelize': float(med[0]), 'fusion_vfe_fwd_bwd': float(med[1]),
-                                   'scatter_cml_fwd_bwd': float(med[2]), 'frame': float(med[3])},
+                                   'scatter_cml_fwd_bwd': float(med[2]), 'frame': float(med[3]),
+                                   'anchors_rpn_loss_fwd_bwd': float(med[4])},
                       'frames_per_s': float(1.0 / med[3])}
     a = out['all']
     return {'value': a['frames_per_s'], 'unit': 'frames/s', 'cores': a['threads'], 'kind': 'port',
             'sample': '%s frames, %d pts: 1 warm-up + %d timed frames on %d threads (median %.2f s/frame: C voxelizer %.3f, '
-                      'torch-CPU fusion+VFE fwd+bwd %.2f, reindex+CML fwd+bwd %.2f); and %d timed frames on %d threads'
+                      'torch-CPU fusion+VFE fwd+bwd %.2f, reindex+CML fwd+bwd %.2f, C classifyAnchors + torch-CPU RPN + VoxelLoss '
+                      'fwd+bwd %.2f%s); and %d timed frames on %d threads'
                       % (workload, P, a['frames_timed'], a['threads'], a['median_s']['frame'], a['median_s']['voxelize'],
                          a['median_s']['fusion_vfe_fwd_bwd'], a['median_s']['scatter_cml_fwd_bwd'],
+                         a['median_s']['anchors_rpn_loss_fwd_bwd'], '' if with_rpn else ' (not part of this mode)',
                          out['n8']['frames_timed'], out['n8']['threads']),
             'runs': out}
 
@@ -359,11 +390,7 @@ def main():
             anchors = pre.createAnchors(cfg.voxelshape[0] // 2, cfg.voxelshape[1] // 2, cfg.velorange, cfg.carsize)
             drop['anchors'] = anchors.to(dev)
             drop['bevs'] = Calc.bbox3d2bev(anchors.reshape(anchors.shape[:2] + (-1, 7))).to(dev).contiguous()
-            gg = np.random.default_rng(11)
-            n = 8
-            gt = np.stack([gg.uniform(8, 60, n), gg.uniform(-30, 30, n), gg.uniform(-1.8, -0.6, n), gg.uniform(3.4, 4.4, n),
-                           gg.uniform(1.5, 1.8, n), gg.uniform(1.4, 1.7, n), gg.choice([0.0, np.pi / 2], n) + gg.normal(0, 0.05, n)], 1)
-            drop['gt'] = torch.tensor(gt, dtype=torch.float32)
+            drop['gt'] = synthetic_gt()
             drop['gt_dev'] = drop['gt'].to(dev)
             drop['gt_bev'] = Calc.bbox3d2bev(drop['gt'])
             drop['crit'] = VoxelLoss()
@@ -624,7 +651,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             del model, batch
             torch.cuda.empty_cache()
-            out['cpu_baseline'] = (cpu_baseline_vfe if args.mode == 'vfe' else cpu_baseline)(args.points, args.workload)
+            if args.mode == 'vfe':
+                out['cpu_baseline'] = cpu_baseline_vfe(args.points, args.workload)
+            else:
+                out['cpu_baseline'] = cpu_baseline(args.points, args.workload, with_rpn=args.mode == 'full')
             if vfe_check is not None:
                 out['cpu_baseline']['voxel_indices_vs_oracle'] = vfe_check
         if args.mode == 'full' and full.get('last'):
