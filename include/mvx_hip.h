@@ -200,21 +200,11 @@ int mvx_bn_relu_backward(const float *dyhat, const float *y, const float *mean_i
  *   mvx_conv3d_forward       out = [ReLU](conv(in) + bias); stats (optional, replicated f64 [R][2][cout]) =
  *                            per-channel (sum, sum of squares) of `out` for the BatchNorm that
  *                            follows (Blocks.py:28-29)
- *                            occupancy (optional, from mvx_scatter_voxels): the input is the scattered
- *                            voxel grid; depth taps whose 3x3 tile neighbourhood is empty and wave
- *                            operand fragments that are all zero are skipped -- only exact-zero
- *                            products are dropped, the result is the dense result.  With site_bits
- *                            too, the wave-autonomous sparse kernel runs (no workgroup barriers,
- *                            per-wave halo, weight fragments from L2; same result).  exec_quads
- *                            (optional) u64 [1] += executed operand quads (1 quad = 8 MFMAs = 32,768 FLOP)
  *   work_counter (optional, forward / dgrad and their _bg / _tiles forms): u32 [1] holding ZERO; the launch then uses
- *                            the persistent form of the kernel -- two workgroups per CU pull (tile, plane, channel block)
+ *                            the persistent form of the kernel -- three workgroups per CU pull (tile, plane, channel block)
  *                            units from this counter until none is left: no tail round of idle CUs, constant-fill tiles do
  *                            not unbalance the workgroups.  NULL: one workgroup per unit.
  *   mvx_conv3d_dgrad         dx [din][h][w][cin] from dz [dout][h][w][cout]
- *   mvx_conv3d_dgrad_sites   dfeat [n_voxels][cin] = rows of dx at the voxel sites only (what
- *                            reindex's backward reads); coords i64 [n_voxels][4] = (b, ix, iy, iz)
- *   mvx_conv3d_wgrad_sites   dw from the n_voxels non-zero input rows feat [n_voxels][cin] only
  *   mvx_conv3d_wgrad         dw in torch layout [cout][cin][3][3][3] ([cout][cin][3][3] with MVX_FLAG_CONV2D);
  *                            cout % 64 == 0 when cin % 64 == 0, else cout == 64
  */
@@ -224,19 +214,10 @@ int mvx_conv3d_pack_weights(const float *w, float *wpk, int32_t cout, int32_t ci
 void mvx_conv3d_tile_shape(int32_t *tile_h, int32_t *tile_w);
 int mvx_conv3d_forward(const float *in, const float *wpk, const float *bias, float *out, double *stats,
                        int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
-                       int32_t stride_d, int32_t pad_d, int32_t flags, const int32_t *occupancy,
-                       const uint32_t *site_bits, uint64_t *exec_quads, uint32_t *work_counter, void *stream);
+                       int32_t stride_d, int32_t pad_d, int32_t flags, uint32_t *work_counter, void *stream);
 int mvx_conv3d_dgrad(const float *dz, const float *wpk_dgrad, float *dx, int32_t din, int32_t dout,
                      int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
                      uint32_t *work_counter, void *stream);
-int mvx_conv3d_dgrad_sites(const float *dz, const float *wpk_dgrad, const int64_t *coords, float *dfeat,
-                           int32_t n_voxels, int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin,
-                           int32_t cout, int32_t stride_d, int32_t pad_d, void *stream);
-size_t mvx_conv3d_wgrad_sites_workspace_bytes(int32_t n_voxels, int32_t cin, int32_t cout);
-int mvx_conv3d_wgrad_sites(const float *feat, const int64_t *coords, const float *dz, float *dw,
-                           int32_t n_voxels, int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin,
-                           int32_t cout, int32_t stride_d, int32_t pad_d, void *workspace,
-                           size_t workspace_bytes, void *stream);
 size_t mvx_conv3d_wgrad_workspace_bytes(int32_t h, int32_t w, int32_t cin, int32_t cout);
 int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
                      int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, int32_t flags,

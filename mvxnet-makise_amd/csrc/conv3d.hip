@@ -81,155 +81,9 @@ __global__ void pack_weights(const float *__restrict__ w, float *__restrict__ wp
 }
 
 // ------------------------------------------------------------------------------------------
-// gather convolution (forward / dgrad)
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void conv3d_gather(const float *__restrict__ in,
-                                                        const float *__restrict__ wpk,
-                                                        const float *__restrict__ bias,
-                                                        float *__restrict__ out, double *__restrict__ stats,
-                                                        Geom g, int relu, const int *__restrict__ occ,
-                                                        unsigned long long *__restrict__ exec_quads) {
-    __shared__ __attribute__((aligned(16))) float s_halo[HH * HW * PITCH];
-    __shared__ __attribute__((aligned(16))) float s_w[BN * PITCH];
-    __shared__ float s_red[4][2 * BN];
-
-    const int tiles_x = (g.W + TW - 1) / TW;
-    const int tx0 = (blockIdx.x % tiles_x) * TW, ty0 = (blockIdx.x / tiles_x) * TH;
-    const int d = blockIdx.y, nb = blockIdx.z;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int nchunks = g.Cin / BK;
-
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-
-    // operand addresses (floats) inside the LDS images for tap (0,0), k-quad 0
-    const int my_ty = 2 * wv + (li >> 4), my_tx = li & 15;
-    const int a_base = (my_ty * HW + my_tx) * PITCH + 4 * lh;
-    const int b_base0 = li * PITCH + 4 * lh;
-    const int b_base1 = (32 + li) * PITCH + 4 * lh;
-
-    f32x4 wreg[2];
-    auto load_w = [&](int kd, int tap, int cc) {
-        const float *tile = wpk + ((((size_t)kd * 9 + tap) * nchunks + cc) * g.Cout + (size_t)nb * BN) * BK;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) wreg[u] = *(const f32x4 *)(tile + (size_t)(tid + 256 * u) * 4);
-    };
-    auto store_w = [&]() {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int c = tid + 256 * u;
-            *(f32x4 *)(s_w + (c >> 3) * PITCH + (c & 7) * 4) = wreg[u];
-        }
-    };
-
-    const int tiles_y = (g.H + TH - 1) / TH;
-    const int tcx = blockIdx.x % tiles_x, tcy = blockIdx.x / tiles_x;
-    unsigned nquads = 0;
-    for (int kd = 0; kd < 3; ++kd) {
-        const int ds = src_depth(g, d, kd);
-        if (ds < 0) continue;                      // block-uniform
-        if (occ) {
-            // Input-sparse source (the scattered voxel grid): occ[plane][tile] counts the non-zero
-            // sites of each 8x16 tile.  The halo of this patch lies inside the 3x3 tile
-            // neighbourhood; if that is empty every product of this depth tap is an exact zero.
-            int any = 0;
-            for (int yy = max(tcy - 1, 0); yy <= min(tcy + 1, tiles_y - 1); ++yy)
-                for (int xx = max(tcx - 1, 0); xx <= min(tcx + 1, tiles_x - 1); ++xx)
-                    any |= occ[((size_t)ds * tiles_y + yy) * tiles_x + xx];
-            if (!any) continue;                    // block-uniform
-        }
-        for (int cc = 0; cc < nchunks; ++cc) {
-            __syncthreads();                       // previous stage's LDS reads are done
-            // ---- stage the halo of this (depth plane, channel chunk)
-#pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                const int c = tid + 256 * u;
-                if (c < HH * HW * 8) {
-                    const int r = c >> 3, part = c & 7;
-                    const int gy = ty0 - 1 + r / HW, gx = tx0 - 1 + r % HW;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W)
-                        v = *(const float4 *)(in + (((size_t)ds * g.H + gy) * g.W + gx) * g.Cin + cc * BK + part * 4);
-                    *(float4 *)(s_halo + r * PITCH + part * 4) = v;
-                }
-            }
-            load_w(kd, 0, cc);
-            for (int tap = 0; tap < 9; ++tap) {
-                if (tap) __syncthreads();          // everyone finished reading the previous weight tile
-                store_w();
-                __syncthreads();
-                if (tap < 8) load_w(kd, tap + 1, cc);   // prefetch under the MFMAs below
-                const int a_off = a_base + ((tap / 3) * HW + (tap % 3)) * PITCH;
-#pragma unroll
-                for (int q = 0; q < BK / 8; ++q) {
-                    const float4 av = *(const float4 *)(s_halo + a_off + 8 * q);
-                    if (occ) {
-                        // wave-uniform: this wave's 32 source sites hold only zeros for these 8 channels
-                        const bool nz = av.x != 0.f || av.y != 0.f || av.z != 0.f || av.w != 0.f;
-                        if (__ballot(nz) == 0ull) continue;
-                        ++nquads;
-                    }
-                    const float4 b0 = *(const float4 *)(s_w + b_base0 + 8 * q);
-                    const float4 b1 = *(const float4 *)(s_w + b_base1 + 8 * q);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b1.z, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b1.w, acc1, 0, 0, 0);
-                }
-            }
-        }
-    }
-
-    if (exec_quads && occ && lane == 0 && nquads) atomicAdd(exec_quads, (unsigned long long)nquads);
-
-    // ---- epilogue: bias, ReLU, store, BatchNorm statistics
-    const int n0 = nb * BN + li, n1 = n0 + 32;
-    const float bias0 = bias ? bias[n0] : 0.f, bias1 = bias ? bias[n1] : 0.f;
-    float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;          // A-row of this accumulator register
-        const int gy = ty0 + 2 * wv + (row >> 4), gx = tx0 + (row & 15);
-        float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
-        if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-        if (gy < g.H && gx < g.W) {
-            float *o = out + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout;
-            o[n0] = v0;
-            o[n1] = v1;
-            s1a += v0; s2a += v0 * v0;
-            s1b += v1; s2b += v1 * v1;
-        }
-    }
-    if (stats) {
-        s1a += __shfl_xor(s1a, 32, 64); s2a += __shfl_xor(s2a, 32, 64);
-        s1b += __shfl_xor(s1b, 32, 64); s2b += __shfl_xor(s2b, 32, 64);
-        __syncthreads();
-        if (lh == 0) {
-            s_red[wv][li] = s1a; s_red[wv][32 + li] = s1b;
-            s_red[wv][BN + li] = s2a; s_red[wv][BN + 32 + li] = s2b;
-        }
-        __syncthreads();
-        if (tid < 2 * BN) {
-            const double t = (double)s_red[0][tid] + (double)s_red[1][tid] + (double)s_red[2][tid] + (double)s_red[3][tid];
-            const int which = tid / BN, c = tid % BN;
-            const unsigned rep = (blockIdx.x + blockIdx.y * gridDim.x) % MVX_REP;
-            atomicAdd(stats + ((size_t)rep * 2 + which) * g.Cout + nb * BN + c, t);
-        }
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------
-// gather convolution, software-pipelined form (dense source: forward of conv2/conv3 and every dgrad)
+// gather convolution (forward and dgrad), software-pipelined
 //
-// Same tiling, operand layout and accumulation order as conv3d_gather, so results are bit-identical.
-// The difference is what the memory system sees: co-resident workgroups start together and share the
+// Co-resident workgroups start together and share the
 // MFMA pipe, which keeps them in lock step, so a halo fetch issued at the top of a (depth tap, chunk)
 // stage is exposed in BOTH of them at once.  Here the halo of stage s+1 is fetched into registers
 // right after stage s starts computing, and the weights go to LDS a tap ROW (3 taps) at a time, with
@@ -559,163 +413,6 @@ __global__ __launch_bounds__(256, 3) void conv3d_gather_pw(const float *__restri
 }
 
 // ------------------------------------------------------------------------------------------
-// Forward of the input-sparse first layer, wave-autonomous form.
-// Same patch decomposition and accumulator layout as conv3d_gather, but the waves of a
-// workgroup never synchronise inside the K loop: each wave owns 2 rows x 16 sites, keeps a
-// private 4 x 18-site halo in LDS and fetches the weight fragments it needs straight from
-// L2.  A per-site occupancy bitmap (built by the scatter) tells a wave (i) whether its halo holds
-// any voxel for this depth tap and (ii) which of the 9 in-plane taps can see one; everything else
-// is skipped.  Only products with an exact-zero input factor are dropped: the output equals the
-// dense kernel's bit for bit.
-// ------------------------------------------------------------------------------------------
-constexpr int WHH = 4, WHS = WHH * HW;           // wave halo: 4 rows x 18 sites
-
-__global__ __launch_bounds__(256, 2) void conv3d_fwd_sparse_in(const float *__restrict__ in,
-                                                               const float *__restrict__ wpk,
-                                                               const float *__restrict__ bias,
-                                                               float *__restrict__ out, double *__restrict__ stats,
-                                                               Geom g, int relu, const int *__restrict__ occ,
-                                                               const unsigned *__restrict__ bits, int wwords,
-                                                               unsigned long long *__restrict__ exec_quads) {
-    __shared__ __attribute__((aligned(16))) float s_h[4][WHS * PITCH];
-    __shared__ float s_red[4][2 * BN];
-    const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
-    const int tcx = blockIdx.x % tiles_x, tcy = blockIdx.x / tiles_x;
-    const int tx0 = tcx * TW, ty0 = tcy * TH;
-    const int d = blockIdx.y, nb = blockIdx.z;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int nchunks = g.Cin / BK;
-    float *sh = s_h[wv];
-
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    const int a_base = ((li >> 4) * HW + (li & 15)) * PITCH + 4 * lh;     // local halo row 0 = global row ty0+2wv-1
-    unsigned nquads = 0;
-
-    for (int kd = 0; kd < 3; ++kd) {
-        const int ds = src_depth(g, d, kd);
-        if (ds < 0) continue;
-        int any = 0;
-        for (int yy = max(tcy - 1, 0); yy <= min(tcy + 1, tiles_y - 1); ++yy)
-            for (int xx = max(tcx - 1, 0); xx <= min(tcx + 1, tiles_x - 1); ++xx)
-                any |= occ[((size_t)ds * tiles_y + yy) * tiles_x + xx];
-        if (!any) continue;                                   // block-uniform, exact
-        // ---- occupancy bits of this wave's 4 x 18 halo (lanes 0..3 hold one row each)
-        unsigned rowbits = 0;
-        if (lane < WHH) {
-            const int gy = ty0 + 2 * wv - 1 + lane;
-            if (gy >= 0 && gy < g.H) {
-                const unsigned *rowp = bits + ((size_t)ds * g.H + gy) * wwords;
-                const int gx0 = tx0 - 1;                      // first halo column, may be -1
-                const int base = gx0 < 0 ? 0 : gx0;
-                const int w0 = base >> 5;
-                unsigned long long win = rowp[w0];
-                if (w0 + 1 < wwords) win |= (unsigned long long)rowp[w0 + 1] << 32;
-                win >>= (base & 31);
-                if (gx0 < 0) win <<= 1;                       // column -1 does not exist
-                rowbits = (unsigned)(win & 0x3FFFFull);
-            }
-        }
-        const unsigned rb0 = __shfl(rowbits, 0, 64), rb1 = __shfl(rowbits, 1, 64), rb2 = __shfl(rowbits, 2, 64),
-                       rb3 = __shfl(rowbits, 3, 64);
-        if ((rb0 | rb1 | rb2 | rb3) == 0u) continue;          // wave-uniform: no voxel in this wave's halo
-        unsigned tapmask = 0;
-        {
-            const unsigned pr[3] = {rb0 | rb1, rb1 | rb2, rb2 | rb3};
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b)
-                    if ((pr[a] >> b) & 0xFFFFu) tapmask |= 1u << (a * 3 + b);
-        }
-        for (int cc = 0; cc < nchunks; ++cc) {
-            // ---- stage the wave's halo chunk (72 sites x 32 channels), zero where no voxel / outside
-            for (int c = lane; c < WHS * 8; c += 64) {
-                const int r = c >> 3, part = c & 7;
-                const int hy = r / HW, hx = r % HW;
-                const int gy = ty0 + 2 * wv - 1 + hy, gx = tx0 - 1 + hx;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                const unsigned rb = hy == 0 ? rb0 : (hy == 1 ? rb1 : (hy == 2 ? rb2 : rb3));
-                if ((rb >> hx) & 1u)
-                    v = *(const float4 *)(in + (((size_t)ds * g.H + gy) * g.W + gx) * g.Cin + cc * BK + part * 4);
-                *(float4 *)(sh + r * PITCH + part * 4) = v;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            for (int tap = 0; tap < 9; ++tap) {
-                if (!((tapmask >> tap) & 1u)) continue;       // wave-uniform
-                const int a_off = a_base + ((tap / 3) * HW + (tap % 3)) * PITCH;
-                const float *wt = wpk + ((((size_t)kd * 9 + tap) * nchunks + cc) * g.Cout + (size_t)nb * BN) * BK;
-                float4 av[BK / 8], b0[BK / 8], b1[BK / 8];
-                unsigned qmask = 0;
-#pragma unroll
-                for (int q = 0; q < BK / 8; ++q) {
-                    av[q] = *(const float4 *)(sh + a_off + 8 * q);
-                    const bool nz = av[q].x != 0.f || av[q].y != 0.f || av[q].z != 0.f || av[q].w != 0.f;
-                    if (__ballot(nz) != 0ull) qmask |= 1u << q;
-                }
-                if (!qmask) continue;
-#pragma unroll
-                for (int q = 0; q < BK / 8; ++q) {            // weight fragments straight from L2
-                    b0[q] = *(const float4 *)(wt + (size_t)li * BK + 4 * lh + 8 * q);
-                    b1[q] = *(const float4 *)(wt + (size_t)(32 + li) * BK + 4 * lh + 8 * q);
-                }
-#pragma unroll
-                for (int q = 0; q < BK / 8; ++q) {
-                    if (!((qmask >> q) & 1u)) continue;
-                    ++nquads;
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].x, b0[q].x, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].x, b1[q].x, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].y, b0[q].y, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].y, b1[q].y, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].z, b0[q].z, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].z, b1[q].z, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].w, b0[q].w, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].w, b1[q].w, acc1, 0, 0, 0);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    if (exec_quads && lane == 0 && nquads) atomicAdd(exec_quads, (unsigned long long)nquads);
-
-    // ---- epilogue: identical to conv3d_gather
-    const int n0 = nb * BN + li, n1 = n0 + 32;
-    const float bias0 = bias ? bias[n0] : 0.f, bias1 = bias ? bias[n1] : 0.f;
-    float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int gy = ty0 + 2 * wv + (row >> 4), gx = tx0 + (row & 15);
-        float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
-        if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-        if (gy < g.H && gx < g.W) {
-            float *o = out + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout;
-            o[n0] = v0;
-            o[n1] = v1;
-            s1a += v0; s2a += v0 * v0;
-            s1b += v1; s2b += v1 * v1;
-        }
-    }
-    if (stats) {
-        s1a += __shfl_xor(s1a, 32, 64); s2a += __shfl_xor(s2a, 32, 64);
-        s1b += __shfl_xor(s1b, 32, 64); s2b += __shfl_xor(s2b, 32, 64);
-        if (lh == 0) {
-            s_red[wv][li] = s1a; s_red[wv][32 + li] = s1b;
-            s_red[wv][BN + li] = s2a; s_red[wv][BN + 32 + li] = s2b;
-        }
-        __syncthreads();
-        if (tid < 2 * BN) {
-            const double t = (double)s_red[0][tid] + (double)s_red[1][tid] + (double)s_red[2][tid] + (double)s_red[3][tid];
-            const int which = tid / BN, c = tid % BN;
-            const unsigned rep = (blockIdx.x + blockIdx.y * gridDim.x) % MVX_REP;
-            atomicAdd(stats + ((size_t)rep * 2 + which) * g.Cout + nb * BN + c, t);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // weight gradient
 // ------------------------------------------------------------------------------------------
 constexpr int WG_THREADS = 9 * 64;
@@ -820,143 +517,6 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad(const float *__restri
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
         o[(size_t)row * BN + li] = acc0[r];
         o[(size_t)row * BN + 32 + li] = acc1[r];
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------
-// Input-sparse first layer: gradients evaluated only where they are used.
-// The dense grid that feeds conv1 is zero except at the V scattered voxels, and its gradient is
-// only ever read back at those voxels (reindex backward).  So
-//   dgrad : dfeat[v][ci] = sum_{kd,a,b,co} dz[do(v,kd)][ix+a-1][iy+b-1][co] * wpk_d[kd][a][b][co][ci]
-//           -- the same gather as the dense kernel, on a list of sites instead of a patch;
-//   wgrad : dW[kd][a][b][ci][co] = sum_v feat[v][ci] * dz[do(v,kd)][ix+1-a][iy+1-b][co]
-//           -- only the V non-zero input rows contribute.
-// Both are exact (they drop products whose input factor is an exact zero or whose result is never read).
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void conv3d_dgrad_sites(const float *__restrict__ dz,
-                                                             const float *__restrict__ wpk,
-                                                             const long long *__restrict__ coords,
-                                                             float *__restrict__ dfeat, int V, Geom g) {
-    // gather view: g.Din = planes of dz, g.Cin = channels of dz, g.Cout = channels of dfeat
-    __shared__ __attribute__((aligned(16))) float s_a[128 * PITCH];
-    __shared__ __attribute__((aligned(16))) float s_w[BN * PITCH];
-    __shared__ int s_site[128][3];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int v0 = blockIdx.x * 128, nb = blockIdx.y;
-    const int nchunks = g.Cin / BK;
-    if (tid < 128) {
-        const int v = v0 + tid;
-        s_site[tid][0] = v < V ? (int)coords[(size_t)v * 4 + 3] : -1000;   // depth (iz)
-        s_site[tid][1] = v < V ? (int)coords[(size_t)v * 4 + 1] : -1000;   // row   (ix)
-        s_site[tid][2] = v < V ? (int)coords[(size_t)v * 4 + 2] : -1000;   // col   (iy)
-    }
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    const int a_base = (wv * 32 + li) * PITCH + 4 * lh;
-    const int b_base0 = li * PITCH + 4 * lh, b_base1 = (32 + li) * PITCH + 4 * lh;
-    for (int kd = 0; kd < 3; ++kd)
-        for (int cc = 0; cc < nchunks; ++cc)
-            for (int tap = 0; tap < 9; ++tap) {
-                __syncthreads();
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int c = tid + 256 * u, r = c >> 3, part = c & 7;
-                    const int iz = s_site[r][0], y = s_site[r][1] + tap / 3 - 1, x = s_site[r][2] + tap % 3 - 1;
-                    const int t = iz + g.pd - kd;
-                    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (t >= 0 && (t % g.sd) == 0 && t / g.sd < g.Din && y >= 0 && y < g.H && x >= 0 && x < g.W)
-                        val = *(const float4 *)(dz + (((size_t)(t / g.sd) * g.H + y) * g.W + x) * g.Cin + cc * BK + part * 4);
-                    *(float4 *)(s_a + r * PITCH + part * 4) = val;
-                }
-                const float *tile = wpk + ((((size_t)kd * 9 + tap) * nchunks + cc) * g.Cout + (size_t)nb * BN) * BK;
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int c = tid + 256 * u;
-                    *(float4 *)(s_w + (c >> 3) * PITCH + (c & 7) * 4) = *(const float4 *)(tile + (size_t)c * 4);
-                }
-                __syncthreads();
-#pragma unroll
-                for (int q = 0; q < BK / 8; ++q) {
-                    const float4 av = *(const float4 *)(s_a + a_base + 8 * q);
-                    const float4 b0 = *(const float4 *)(s_w + b_base0 + 8 * q);
-                    const float4 b1 = *(const float4 *)(s_w + b_base1 + 8 * q);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b1.z, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b1.w, acc1, 0, 0, 0);
-                }
-            }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int v = v0 + wv * 32 + row;
-        if (v < V) {
-            dfeat[(size_t)v * g.Cout + nb * BN + li] = acc0[r];
-            dfeat[(size_t)v * g.Cout + nb * BN + 32 + li] = acc1[r];
-        }
-    }
-}
-
-constexpr int SV = 64;     // voxel rows per LDS step of the sparse wgrad
-__global__ __launch_bounds__(256) void conv3d_wgrad_sites(const float *__restrict__ feat,
-                                                          const long long *__restrict__ coords,
-                                                          const float *__restrict__ dz, float *__restrict__ slabs,
-                                                          int V, int rows_per_strip, Geom g) {
-    // forward geometry: g.Cin = channels of feat (128), g.Cout = channels of dz (64)
-    __shared__ float s_x[SV * 128];
-    __shared__ float s_z[SV * BN];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int kd = blockIdx.y / 9, tap = blockIdx.y % 9, ta = tap / 3, tb = tap % 3;
-    const int vbeg = blockIdx.x * rows_per_strip, vend = min(V, vbeg + rows_per_strip);
-    const int cin = g.Cin;       // <= 128, multiple of 32
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    const bool active = wv * 32 < cin;
-    for (int v0 = vbeg; v0 < vend; v0 += SV) {
-        __syncthreads();
-        for (int c = tid; c < SV * (cin / 4); c += 256) {
-            const int r = c / (cin / 4), part = c % (cin / 4);
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (v0 + r < vend) val = *(const float4 *)(feat + (size_t)(v0 + r) * cin + part * 4);
-            *(float4 *)(s_x + r * 128 + part * 4) = val;
-        }
-        for (int c = tid; c < SV * 16; c += 256) {
-            const int r = c >> 4, part = c & 15;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (v0 + r < vend) {
-                const long long *cd = coords + (size_t)(v0 + r) * 4;
-                const int t = (int)cd[3] + g.pd - kd, y = (int)cd[1] + 1 - ta, x = (int)cd[2] + 1 - tb;
-                if (t >= 0 && (t % g.sd) == 0 && t / g.sd < g.Dout && y >= 0 && y < g.H && x >= 0 && x < g.W)
-                    val = *(const float4 *)(dz + (((size_t)(t / g.sd) * g.H + y) * g.W + x) * BN + part * 4);
-            }
-            *(float4 *)(s_z + r * BN + part * 4) = val;
-        }
-        __syncthreads();
-        if (active) {
-#pragma unroll 8
-            for (int kk = 0; kk < SV / 2; ++kk) {
-                const int row = 2 * kk + lh;
-                const float a = s_x[row * 128 + wv * 32 + li];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s_z[row * BN + li], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s_z[row * BN + 32 + li], acc1, 0, 0, 0);
-            }
-        }
-    }
-    if (active) {
-        float *o = slabs + ((((size_t)blockIdx.x * 3 + kd) * 9 + tap) * cin + wv * 32) * BN;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            o[(size_t)row * BN + li] = acc0[r];
-            o[(size_t)row * BN + 32 + li] = acc1[r];
-        }
     }
 }
 
@@ -1391,8 +951,7 @@ extern "C" void mvx_conv3d_tile_shape(int32_t *tile_h, int32_t *tile_w) {
 extern "C" int mvx_conv3d_forward(const float *in, const float *wpk, const float *bias, float *out,
                                   double *stats, int32_t din, int32_t dout, int32_t h, int32_t w,
                                   int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
-                                  int32_t flags, const int32_t *occupancy, const uint32_t *site_bits,
-                                  uint64_t *exec_quads, uint32_t *work_counter, void *stream) {
+                                  int32_t flags, uint32_t *work_counter, void *stream) {
     MVX_CHECK_ARG(in && wpk && out);
     int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
     if (rc) return rc;
@@ -1404,16 +963,8 @@ extern "C" int mvx_conv3d_forward(const float *in, const float *wpk, const float
         if (e != hipSuccess) return (int)e;
     }
     Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
-    const dim3 grid(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), dout, cout / BN);
-    if (occupancy && site_bits)
-        hipLaunchKernelGGL(conv3d_fwd_sparse_in, grid, dim3(256), 0, st, in, wpk, bias, out, stats, g, relu, occupancy,
-                           (const unsigned *)site_bits, (int)mvx_cdiv(w, 32), (unsigned long long *)exec_quads);
-    else if (occupancy)
-        hipLaunchKernelGGL(conv3d_gather, grid, dim3(256), 0, st, in, wpk, bias, out, stats, g, relu, occupancy,
-                           (unsigned long long *)exec_quads);
-    else
-        launch_gather(st, in, wpk, bias, out, stats, g, relu, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0.0, 0.0,
-                      nullptr, (unsigned *)work_counter);
+    launch_gather(st, in, wpk, bias, out, stats, g, relu, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0.0, 0.0,
+                  nullptr, (unsigned *)work_counter);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -1545,21 +1096,6 @@ extern "C" int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int
     hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256), nblk), dim3(256), 0, st, (const float *)workspace, dw,
                        nstrips, cin, flags & MVX_FLAG_ACCUMULATE, (flags & MVX_FLAG_CONV2D) ? 1 : 0,
                        Strips{{nstrips, nstrips, nstrips}});
-    MVX_LAUNCH_CHECK();
-    return MVX_OK;
-}
-
-extern "C" int mvx_conv3d_dgrad_sites(const float *dz, const float *wpk_dgrad, const int64_t *coords, float *dfeat,
-                                      int32_t n_voxels, int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin,
-                                      int32_t cout, int32_t stride_d, int32_t pad_d, void *stream) {
-    MVX_CHECK_ARG(dz && wpk_dgrad && dfeat && n_voxels >= 0);
-    int rc = check_geom(din, dout, h, w, cout, cin, stride_d, pad_d);
-    if (rc) return rc;
-    if (n_voxels == 0) return MVX_OK;
-    MVX_CHECK_ARG(coords);
-    Geom g{dout, din, h, w, cout, cin, stride_d, pad_d, 1};
-    hipLaunchKernelGGL(conv3d_dgrad_sites, dim3(mvx_cdiv(n_voxels, 128), cin / BN), dim3(256), 0, (hipStream_t)stream, dz,
-                       wpk_dgrad, (const long long *)coords, dfeat, n_voxels, g);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -1805,46 +1341,6 @@ extern "C" int mvx_conv2d_wgrad_frames(const float *in, const float *dz, float *
     const size_t per_slab = (size_t)27 * cin * BN;
     hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256), nblk), dim3(256), 0, st, (const float *)slabs, dw, nstrips, cin,
                        flags & MVX_FLAG_ACCUMULATE, 1, ks);
-    MVX_LAUNCH_CHECK();
-    return MVX_OK;
-}
-
-static int sites_rows_per_strip(int n_voxels) {
-    int rows = (n_voxels + 15) / 16;           // about 16 strips x 27 taps = 432 workgroups
-    rows = ((rows + SV - 1) / SV) * SV;
-    return rows < SV ? SV : rows;
-}
-
-extern "C" size_t mvx_conv3d_wgrad_sites_workspace_bytes(int32_t n_voxels, int32_t cin, int32_t cout) {
-    if (n_voxels <= 0 || cin <= 0 || cout != BN) return 256;
-    const int per = sites_rows_per_strip(n_voxels);
-    return (size_t)((n_voxels + per - 1) / per) * 27 * cin * BN * sizeof(float);
-}
-
-extern "C" int mvx_conv3d_wgrad_sites(const float *feat, const int64_t *coords, const float *dz, float *dw,
-                                      int32_t n_voxels, int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin,
-                                      int32_t cout, int32_t stride_d, int32_t pad_d, void *workspace,
-                                      size_t workspace_bytes, void *stream) {
-    MVX_CHECK_ARG(dz && dw && workspace && n_voxels >= 0);
-    int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
-    if (rc) return rc;
-    if (cout != BN || cin > 128) return MVX_ESIZE;
-    hipStream_t st = (hipStream_t)stream;
-    if (n_voxels == 0) {
-        hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * 27 * (size_t)cin * cout, st);
-        return e == hipSuccess ? MVX_OK : (int)e;
-    }
-    MVX_CHECK_ARG(feat && coords);
-    const int per = sites_rows_per_strip(n_voxels);
-    const int nstrips = (n_voxels + per - 1) / per;
-    MVX_CHECK_ARG(workspace_bytes >= (size_t)nstrips * 27 * cin * BN * sizeof(float));
-    Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
-    hipLaunchKernelGGL(conv3d_wgrad_sites, dim3(nstrips, 27), dim3(256), 0, st, feat, (const long long *)coords, dz,
-                       (float *)workspace, n_voxels, per, g);
-    MVX_LAUNCH_CHECK();
-    const size_t per_slab = (size_t)27 * cin * BN;
-    hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)workspace, dw,
-                       nstrips, cin, 0, 0, Strips{{nstrips, nstrips, nstrips}});
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

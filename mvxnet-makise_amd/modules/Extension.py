@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MVX_HIP_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'libmvx_hip.so'))
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _p = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -71,14 +71,11 @@ PROTOTYPES = {
     'mvx_conv3d_packed_weight_bytes': (_sz, [_i32, _i32]),
     'mvx_conv3d_pack_weights': (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     'mvx_conv3d_tile_shape': (None, [_p, _p]),
-    'mvx_conv3d_forward': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
+    'mvx_conv3d_forward': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     'mvx_conv3d_pack_weights_split': (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     'mvx_conv3d_forward_split': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_conv3d_dgrad_split': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_conv3d_wgrad_split': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _sz, _p]),
-    'mvx_conv3d_dgrad_sites': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
-    'mvx_conv3d_wgrad_sites_workspace_bytes': (_sz, [_i32, _i32, _i32]),
-    'mvx_conv3d_wgrad_sites': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _sz, _p]),
     'mvx_conv3d_dgrad': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     'mvx_conv3d_wgrad_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32]),
     'mvx_conv3d_wgrad': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _sz, _p]),

@@ -389,60 +389,24 @@ def conv_out_depth(din, sd, pd):
     return (din + 2 * pd - 3) // sd + 1
 
 
-SPARSE_QUADS = None      # u64 device counter of executed operand quads of input-sparse launches
-
-
-def conv3d_forward(x, wpk, bias, cout, sd, pd, relu=True, want_stats=True, occupancy=None, split=False):
-    """occupancy: per-tile voxel counts of the scattered input grid -> exact zero-skipping.
-    split=True: bf16x3 kernel (wpk from conv3d_pack(..., split=True))."""
-    global SPARSE_QUADS
+def conv3d_forward(x, wpk, bias, cout, sd, pd, relu=True, want_stats=True, split=False):
+    """Dense forward of one frame; split=True: bf16x3 kernel (wpk from conv3d_pack(..., split=True))."""
     din, H, W, cin = x.shape
     dout = conv_out_depth(din, sd, pd)
     out = torch.empty((dout, H, W, cout), dtype=torch.float32, device=x.device)
     stats, fz = _acc_f64((STATS_REPLICAS, 2, cout), x.device) if want_stats else (None, 0)
     flags = (FLAG_RELU if relu else 0) | fz
     if split:
-        assert occupancy is None
         with _Timed('conv3d_gather_split', conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None else 0):
             X.check(X.lib.mvx_conv3d_forward_split(X.ptr(x), X.ptr(wpk), X.ptr(bias), X.ptr(out), X.ptr(stats), din, dout,
                                                    H, W, cin, cout, sd, pd, flags, X.stream()),
                     'mvx_conv3d_forward_split')
         return out, stats
-    counter = None
-    occ_t, bits_t = occupancy if isinstance(occupancy, tuple) else (occupancy, None)
-    if occupancy is not None and KERNEL_TIMERS is not None:
-        if SPARSE_QUADS is None:
-            SPARSE_QUADS = torch.zeros((1,), dtype=torch.int64, device=x.device)
-        counter = SPARSE_QUADS
-    name = 'conv3d_gather' if occupancy is None else 'conv3d_gather_sparse_input'
-    flops = conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None and occupancy is None else 0
-    with _Timed(name, flops):
+    with _Timed('conv3d_gather', conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None else 0):
         X.check(X.lib.mvx_conv3d_forward(X.ptr(x), X.ptr(wpk), X.ptr(bias), X.ptr(out), X.ptr(stats),
-                                         din, dout, H, W, cin, cout, sd, pd, flags, X.ptr(occ_t), X.ptr(bits_t),
-                                         X.ptr(counter), X.ptr(_work_counter(x.device) if occupancy is None else None),
+                                         din, dout, H, W, cin, cout, sd, pd, flags, X.ptr(_work_counter(x.device)),
                                          X.stream()), 'mvx_conv3d_forward')
     return out, stats
-
-
-def conv3d_dgrad_sites(dz, wpk_d, coords, n_voxels, din, cin, sd, pd):
-    """Rows of the input gradient at the voxel sites only: (V, cin)."""
-    dout, H, W, cout = dz.shape
-    dfeat = torch.empty((n_voxels, cin), dtype=torch.float32, device=dz.device)
-    with _Timed('conv3d_dgrad_sites', 2.0 * n_voxels * 27 * cin * cout if KERNEL_TIMERS is not None else 0):
-        X.check(X.lib.mvx_conv3d_dgrad_sites(X.ptr(dz), X.ptr(wpk_d), X.ptr(coords), X.ptr(dfeat), n_voxels, din, dout,
-                                             H, W, cin, cout, sd, pd, X.stream()), 'mvx_conv3d_dgrad_sites')
-    return dfeat
-
-
-def conv3d_wgrad_sites(feat, coords, dz, din, sd, pd):
-    V, cin = feat.shape
-    dout, H, W, cout = dz.shape
-    dw = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device=dz.device)
-    ws = workspace(X.lib.mvx_conv3d_wgrad_sites_workspace_bytes(V, cin, cout), dz.device, 'wgrad_sites')
-    with _Timed('conv3d_wgrad_sites', 2.0 * V * 27 * cin * cout if KERNEL_TIMERS is not None else 0):
-        X.check(X.lib.mvx_conv3d_wgrad_sites(X.ptr(feat), X.ptr(coords), X.ptr(dz), X.ptr(dw), V, din, dout, H, W, cin,
-                                             cout, sd, pd, X.ptr(ws), ws.numel(), X.stream()), 'mvx_conv3d_wgrad_sites')
-    return dw
 
 
 def conv3d_dgrad(dz, wpk_d, din, cin, sd, pd, split=False):

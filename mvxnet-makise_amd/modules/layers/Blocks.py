@@ -184,42 +184,6 @@ class CRB3dFunction(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None, None
 
 
-class SparseInputCRB3dFunction(torch.autograd.Function):
-    """reindex + first CRB3d as one node: voxel rows (V,Cin) + coords -> BN(ReLU(conv3d(dense grid))).
-
-    The dense grid is zero except at the V voxel sites and its gradient is only read back there
-    (VoxelNet.reindex's backward), so: forward skips operand blocks that are exact zeros
-    (occupancy map from the scatter), dgrad is evaluated at the V sites only and wgrad sums over
-    the V non-zero input rows only.  Results equal the dense evaluation (no approximation); the
-    721 MB dense input gradient is never materialised."""
-
-    @staticmethod
-    def forward(ctx, feat, coords, w, b, dhw, sd, pd, eps):
-        cout = w.shape[0]
-        feat = feat.contiguous()
-        grid, status, occ = _hip.scatter_voxels(feat, coords, dhw, want_occupancy=True)
-        y, stats = _hip.conv3d_forward(grid, _hip.conv3d_pack(w, False), b, cout, sd, pd, relu=True, want_stats=True,
-                                       occupancy=occ)
-        count = y.numel() // cout
-        mi = _hip.bn_finalize(stats, count, eps)
-        out = _hip.bn_apply(y, mi)
-        ctx.save_for_backward(feat, coords, w, y, mi)
-        ctx.geom = (dhw[0], sd, pd, count)
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        feat, coords, w, y, mi = ctx.saved_tensors
-        din, sd, pd, count = ctx.geom
-        dz, db = _hip.bn_relu_backward(g.contiguous(), y, mi, count, True)
-        dw = _hip.conv3d_wgrad_sites(feat, coords, dz, din, sd, pd)
-        dfeat = None
-        if ctx.needs_input_grad[0]:
-            dfeat = _hip.conv3d_dgrad_sites(dz, _hip.conv3d_pack(w, True), coords, feat.shape[0], din, feat.shape[1],
-                                            sd, pd)
-        return dfeat, None, dw, db, None, None, None, None
-
-
 class VoxelGemmCRB3dFunction(torch.autograd.Function):
     """reindex + first CRB3d through the [V x 27*Cout] factorisation (csrc/sparseconv.hip): one row
     GEMM + one index-grid gather per pass, no dense input grid.  Equal to the dense evaluation up to
@@ -290,18 +254,13 @@ class CRB3d(nn.Module):
             raise NotImplementedError('CRB3d HIP kernel: kernel 3, stride (s,1,1), padding (p,1,1) only')
         self._sd, self._pd = s3[0], p3[0]
         object.__setattr__(self, '_packer', PackedWeights(lambda: self.conv.weight))
-        self.voxel_gemm = True          # forward_voxels: voxel-GEMM factorisation (else zero-skipping dense kernels)
 
     def forward_voxels(self, feat, coords, dhw):
-        """Fused reindex + this block on sparse voxel rows (exact, see SparseInputCRB3dFunction)."""
-        if self.voxel_gemm:
-            aux = {} if conv_background_on() else None
-            out = VoxelGemmCRB3dFunction.apply(feat, coords, self.conv.weight, self.conv.bias, tuple(dhw), self._sd,
-                                               self._pd, cfg.eps, aux)
-        else:
-            aux = None
-            out = SparseInputCRB3dFunction.apply(feat, coords, self.conv.weight, self.conv.bias, tuple(dhw), self._sd,
-                                                 self._pd, cfg.eps)
+        """Fused reindex + this block on sparse voxel rows: the [V x 27*Cout] factorisation (exact, see
+        VoxelGemmCRB3dFunction); the dense grid is never built."""
+        aux = {} if conv_background_on() else None
+        out = VoxelGemmCRB3dFunction.apply(feat, coords, self.conv.weight, self.conv.bias, tuple(dhw), self._sd,
+                                           self._pd, cfg.eps, aux)
         res = out.permute(3, 0, 1, 2).unsqueeze(0)
         if aux:
             res._mvx_background = aux['bg']      # read by the next CRB3d (plain attribute: the module API is unchanged)

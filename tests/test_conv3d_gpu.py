@@ -119,37 +119,6 @@ def test_cml_stack_matches_reference_fixture(golden):
         assert rel_err(x.cpu().permute(3, 0, 1, 2), ref) < 1e-4, key
 
 
-def test_input_sparse_first_layer_equals_dense(golden):
-    """Zero-skipping forward, sites-only dgrad and wgrad give the dense results (to fp32 summation
-    order) on a realistic occupancy: 0.4 % of a 10x64x80 grid."""
-    from modules import _hip
-    g = torch.Generator().manual_seed(5)
-    D, H, W, C = 10, 64, 80, 128
-    V = 200
-    flat = torch.randperm(D * H * W, generator=g)[:V]
-    iz, rem = flat // (H * W), flat % (H * W)
-    coords = torch.stack([torch.zeros(V, dtype=torch.long), rem // W, rem % W, iz], 1).to(DEV)
-    feat = torch.randn((V, C), generator=g).to(DEV)
-    w = (torch.randn((64, C, 3, 3, 3), generator=g) / np.sqrt(27 * C)).to(DEV)
-    b = (torch.randn((64,), generator=g) * 0.1).to(DEV)
-    grid, _, occ = _hip.scatter_voxels(feat, coords, (D, H, W), want_occupancy=True)
-    assert int(occ[0].sum()) == V
-    wpk = _hip.conv3d_pack(w, False)
-    dense, st_d = _hip.conv3d_forward(grid, wpk, b, 64, 2, 1)
-    for mode in (occ, occ[0]):                             # wave-autonomous kernel / tile-skipping dense kernel
-        sparse, st_s = _hip.conv3d_forward(grid, wpk, b, 64, 2, 1, occupancy=mode)
-        assert torch.equal(dense, sparse)                  # only exact-zero products were dropped
-        assert torch.allclose(st_d.sum(0), st_s.sum(0), rtol=1e-6)    # per-wave partial sums in f32 vs f64 block sums
-    dz = torch.randn(dense.shape, generator=g).to(DEV)
-    dw_d = _hip.conv3d_wgrad(grid, dz, 2, 1)
-    dw_s = _hip.conv3d_wgrad_sites(feat, coords, dz, D, 2, 1)
-    assert rel_err(dw_s.cpu(), dw_d.cpu()) < 1e-5
-    dx = _hip.conv3d_dgrad(dz, _hip.conv3d_pack(w, True), D, C, 2, 1)
-    df_d = _hip.gather_voxels(dx, coords, V)
-    df_s = _hip.conv3d_dgrad_sites(dz, _hip.conv3d_pack(w, True), coords, V, D, C, 2, 1)
-    assert rel_err(df_s.cpu(), df_d.cpu()) < 1e-5
-
-
 @pytest.mark.parametrize('cin,cout,din,H,W,sd,pd', GEOMS[:4])
 def test_conv3d_bf16x3_split_accuracy(cin, cout, din, H, W, sd, pd):
     """bf16x3 kernels against float64: fp32-grade accuracy (well inside the 1e-4 feature bar)."""
