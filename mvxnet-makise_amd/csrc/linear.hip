@@ -372,7 +372,11 @@ inline void launch_slab_reduce(const float *slabs, float *out, size_t total, int
 inline long long strip_rows(long long R, int N, int K) {
     const long long blocks = (long long)mvx_cdiv(N, 128) * mvx_cdiv(K, 128);
     long long strips = 1536 / blocks;            // enough workgroups to fill 256 CUs a few times over
-    if (strips > 96) strips = 96;                // ... without making the slab sum long
+    // ... without making the slab sum long: 96 strips for the wide layers; the narrow ones (one or two 128 x 128 blocks:
+    // the VFE / fusion tail layers, HBM bound on reading x and dz) need more workgroups than 96 to draw bandwidth, and
+    // their slabs are small (64 KB per strip and block)
+    const long long cap = blocks <= 2 ? 512 / blocks : 96;
+    if (strips > cap) strips = cap;
     if (strips < 1) strips = 1;
     long long rows = (R + strips - 1) / strips;
     if (rows < 4 * WR) rows = 4 * WR;
