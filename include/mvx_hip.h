@@ -303,6 +303,22 @@ int mvx_conv3d_wgrad_bg_split(const float *in, const float *dz, float *dw, int32
                               int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, int32_t flags,
                               const int32_t *in_halo_flags, const float *c_in, const float *tap_sums, void *workspace,
                               size_t workspace_bytes, void *stream);
+/* ... and their frame-set forms (planes of n_frames frames stacked along depth, per-frame statistics [F][R][2][cout];
+ * exec_stages (optional) u64 [1] += executed (depth tap, 32-channel chunk) stages, as in the f32 kernels) */
+int mvx_conv3d_forward_bg_split_frames(const float *in, const void *wsplit, const float *bias, float *out, double *stats,
+                                       int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                                       int32_t stride_d, int32_t pad_d, int32_t flags, const int32_t *in_halo_flags,
+                                       const uint8_t *out_mask, const float *bg_pre, int32_t border_active,
+                                       uint64_t *exec_stages, int32_t n_frames, void *stream);
+int mvx_conv3d_dgrad_tiles_split_frames(const float *dz, const void *wsplit_dgrad, float *dx, int32_t din, int32_t dout,
+                                        int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
+                                        const int32_t *dx_tile_flags, uint64_t *exec_stages, int32_t n_frames, void *stream);
+size_t mvx_conv3d_wgrad_bg_split_workspace_bytes_frames(int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                                                        int32_t n_frames);
+int mvx_conv3d_wgrad_bg_split_frames(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
+                                     int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, int32_t flags,
+                                     const int32_t *in_halo_flags, const float *c_in, const float *tap_sums,
+                                     void *workspace, size_t workspace_bytes, int32_t n_frames, void *stream);
 size_t mvx_bn_relu_backward_tiles_workspace_bytes(int32_t planes, int32_t h, int32_t w, int32_t channels);
 int mvx_bn_relu_backward_tiles(const float *dyhat, const float *y, const float *mean_inv, const float *c_bg,
                                const float *y_bg, const float *plane_grad_sums, const int32_t *tile_flags,

@@ -25,9 +25,9 @@ static inline unsigned mvx_cdiv(long long a, long long b) { return (unsigned)((a
 // ---- internal helpers shared between translation units (NOT part of the C ABI) -----------------------
 // conv3d.hip: compacted (plane, tile) step lists of the background-aware weight gradient and its closed-form term
 int mvxi_wgrad_step_list(const int32_t *in_halo_flags, int din, int dout, int ntiles, int stride_d, int pad_d, int *list,
-                         int *count, hipStream_t st);
+                         int *count, hipStream_t st, int n_frames = 1);
 int mvxi_wgrad_rank1(const float *tap_sums, const float *c_in, float *dw, int din, int dout, int cin, int cout, int stride_d,
-                     int pad_d, hipStream_t st);
+                     int pad_d, hipStream_t st, int n_frames = 1);
 
 // ---- frame sets: the frames of a step processed by ONE launch -----------------------------------------
 // The reference is strictly batch-1 (config.yml:18, VoxelNet.py:19): a batch is B independent forwards with per-frame

@@ -1112,16 +1112,16 @@ static int wgrad_bg_strips(int cin) {
 static size_t wgrad_bg_slab_bytes(int cin) { return (size_t)wgrad_bg_strips(cin) * 27 * cin * BN * sizeof(float); }
 
 int mvxi_wgrad_step_list(const int32_t *in_halo_flags, int din, int dout, int ntiles, int stride_d, int pad_d, int *list,
-                         int *count, hipStream_t st) {
-    Geom g{din, dout, 0, 0, 0, 0, stride_d, pad_d, 0};
+                         int *count, hipStream_t st, int n_frames) {
+    Geom g{din, dout, 0, 0, 0, 0, stride_d, pad_d, 0, n_frames};
     hipLaunchKernelGGL(wgrad_step_list, dim3(3), dim3(1024), 0, st, in_halo_flags, g, ntiles, list, count);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
 
 int mvxi_wgrad_rank1(const float *tap_sums, const float *c_in, float *dw, int din, int dout, int cin, int cout, int stride_d,
-                     int pad_d, hipStream_t st) {
-    Geom g{din, dout, 0, 0, cin, cout, stride_d, pad_d, 0};
+                     int pad_d, hipStream_t st, int n_frames) {
+    Geom g{din, dout, 0, 0, cin, cout, stride_d, pad_d, 0, n_frames};
     const size_t total = (size_t)27 * cin * cout;
     hipLaunchKernelGGL(wgrad_rank1, dim3(mvx_cdiv(total, 256)), dim3(256), 0, st, tap_sums, c_in, dw, g);
     MVX_LAUNCH_CHECK();

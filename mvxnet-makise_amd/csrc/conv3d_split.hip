@@ -27,17 +27,21 @@ constexpr int ROWB = 144;                         // bytes per LDS row: 64 hi + 
 
 struct Geom {
     int Din, Dout, H, W, Cin, Cout, sd, pd, mode;
+    int F = 1;                                     // frames stacked along depth: planes [F * Dout] <- [F * Din]
 };
 
+// source plane of output plane d (a GLOBAL plane index: frame * Dout + plane) for depth tap kd, or -1; planes of
+// different frames never connect (same rule as mvx_src_plane / mvx_dst_plane in common.h)
 __device__ __forceinline__ int src_depth(const Geom &g, int d, int kd) {
+    const int f = d / g.Dout, dl = d - f * g.Dout;
     if (g.mode == 0) {
-        const int s = d * g.sd - g.pd + kd;
-        return (s >= 0 && s < g.Din) ? s : -1;
+        const int s = dl * g.sd - g.pd + kd;
+        return (s >= 0 && s < g.Din) ? f * g.Din + s : -1;
     }
-    const int t = d + g.pd - kd;
+    const int t = dl + g.pd - kd;
     if (t < 0 || (t % g.sd) != 0) return -1;
     const int s = t / g.sd;
-    return s < g.Din ? s : -1;
+    return s < g.Din ? f * g.Din + s : -1;
 }
 
 __device__ __forceinline__ void split4(const float4 v, uint2 *hi, uint2 *lo) {
@@ -87,7 +91,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_split(const float *__res
                                                               Geom g, int relu, const int *__restrict__ in_hflag,
                                                               const unsigned char *__restrict__ out_mask,
                                                               const float *__restrict__ bg_pre, int border_active,
-                                                              const int *__restrict__ only_tiles) {
+                                                              const int *__restrict__ only_tiles,
+                                                              unsigned long long *__restrict__ exec_stages) {
     __shared__ __attribute__((aligned(16))) unsigned char s_halo[HH * HW * ROWB];
     __shared__ __attribute__((aligned(16))) unsigned char s_w[3][BN * ROWB];
     __shared__ float s_red[4][2 * BN];
@@ -106,6 +111,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_split(const float *__res
             if (ds >= 0) any |= in_hflag[(size_t)ds * gridDim.x + blockIdx.x];
         }
         active = any != 0;
+    }
+    if (exec_stages && active && threadIdx.x == 0) {              // executed (depth tap, 32-channel chunk) stages only
+        int nk = 0;
+        for (int kd = 0; kd < 3; ++kd) nk += src_depth(g, d, kd) >= 0;
+        atomicAdd(exec_stages, (unsigned long long)(nk * nchunks));
     }
 
     f32x16 acc0, acc1;
@@ -234,7 +244,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_split(const float *__res
             const double t = (double)s_red[0][tid] + (double)s_red[1][tid] + (double)s_red[2][tid] + (double)s_red[3][tid];
             const int which = tid / BN, c = tid % BN;
             const unsigned rep = (blockIdx.x + blockIdx.y * gridDim.x) % MVX_REP;
-            atomicAdd(stats + ((size_t)rep * 2 + which) * g.Cout + nb * BN + c, t);
+            double *fstats = stats + (size_t)(d / g.Dout) * MVX_REP * 2 * g.Cout;       // the plane's frame
+            atomicAdd(fstats + ((size_t)rep * 2 + which) * g.Cout + nb * BN + c, t);
         }
     }
 }
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_split(const float *__
     }
     const int nd = dhi >= dlo ? dhi - dlo + 1 : 0;
     const int per = tiles_per_strip;
-    const int *my_list = step_list ? step_list + (size_t)kd * g.Dout * ntiles : nullptr;
+    const int *my_list = step_list ? step_list + (size_t)kd * g.Dout * g.F * ntiles : nullptr;
     const int nlist = step_list ? step_count[kd] : 0;
     const int nsteps = step_list ? (nlist > strip ? (nlist - strip + nstrips - 1) / nstrips : 0) : nd * per;
     auto step_of = [&](int i, int &d, int &t) {
@@ -314,7 +325,7 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_split(const float *__
     auto load_step = [&](int i) {
         int d, t;
         step_of(i, d, t);
-        const int ds = d * g.sd - g.pd + kd;
+        const int ds = src_depth(g, d, kd);                       // listed / dense steps always have a valid source plane
         const int tx0 = (t % tiles_x) * TW, ty0 = (t / tiles_x) * TH;
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
@@ -452,7 +463,31 @@ extern "C" int mvx_conv3d_forward_split(const float *in, const void *wsplit, con
     Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
     hipLaunchKernelGGL(conv3d_gather_split, dim3(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), dout, cout / BN), dim3(256), 0, st, in,
                        (const unsigned short *)wsplit, bias, out, stats, g, relu, (const int *)nullptr,
-                       (const unsigned char *)nullptr, (const float *)nullptr, 0, (const int *)nullptr);
+                       (const unsigned char *)nullptr, (const float *)nullptr, 0, (const int *)nullptr,
+                       (unsigned long long *)nullptr);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+extern "C" int mvx_conv3d_forward_bg_split_frames(const float *in, const void *wsplit, const float *bias, float *out,
+                                                  double *stats, int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin,
+                                                  int32_t cout, int32_t stride_d, int32_t pad_d, int32_t flags,
+                                                  const int32_t *in_halo_flags, const uint8_t *out_mask, const float *bg_pre,
+                                                  int32_t border_active, uint64_t *exec_stages, int32_t n_frames, void *stream) {
+    MVX_CHECK_ARG(in && wsplit && out && in_halo_flags && out_mask && bg_pre);
+    MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
+    int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
+    if (rc) return rc;
+    MVX_CHECK_ARG(dout == (din + 2 * pad_d - 3) / stride_d + 1);
+    hipStream_t st = (hipStream_t)stream;
+    if (stats && !(flags & MVX_FLAG_PREZEROED)) {
+        hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * MVX_REP * 2 * cout * n_frames, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0, n_frames};
+    hipLaunchKernelGGL(conv3d_gather_split, dim3(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), dout * n_frames, cout / BN), dim3(256), 0, st,
+                       in, (const unsigned short *)wsplit, bias, out, stats, g, flags & MVX_FLAG_RELU, in_halo_flags, out_mask,
+                       bg_pre, border_active, (const int *)nullptr, (unsigned long long *)exec_stages);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -462,49 +497,46 @@ extern "C" int mvx_conv3d_forward_bg_split(const float *in, const void *wsplit, 
                                            int32_t stride_d, int32_t pad_d, int32_t flags, const int32_t *in_halo_flags,
                                            const uint8_t *out_mask, const float *bg_pre, int32_t border_active,
                                            void *stream) {
-    MVX_CHECK_ARG(in && wsplit && out && in_halo_flags && out_mask && bg_pre);
-    int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
-    if (rc) return rc;
-    MVX_CHECK_ARG(dout == (din + 2 * pad_d - 3) / stride_d + 1);
-    hipStream_t st = (hipStream_t)stream;
-    if (stats && !(flags & MVX_FLAG_PREZEROED)) {
-        hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * MVX_REP * 2 * cout, st);
-        if (e != hipSuccess) return (int)e;
-    }
-    Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
-    hipLaunchKernelGGL(conv3d_gather_split, dim3(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), dout, cout / BN), dim3(256), 0, st, in,
-                       (const unsigned short *)wsplit, bias, out, stats, g, flags & MVX_FLAG_RELU, in_halo_flags, out_mask,
-                       bg_pre, border_active, (const int *)nullptr);
-    MVX_LAUNCH_CHECK();
-    return MVX_OK;
+    return mvx_conv3d_forward_bg_split_frames(in, wsplit, bias, out, stats, din, dout, h, w, cin, cout, stride_d, pad_d, flags,
+                                              in_halo_flags, out_mask, bg_pre, border_active, nullptr, 1, stream);
 }
 
 static int launch_dgrad_split(const float *dz, const void *wsplit_dgrad, float *dx, int32_t din, int32_t dout, int32_t h,
                               int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
-                              const int32_t *only_tiles, void *stream) {
+                              const int32_t *only_tiles, uint64_t *exec_stages, int32_t n_frames, void *stream) {
     MVX_CHECK_ARG(dz && wsplit_dgrad && dx);
+    MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
     int rc = check_geom(din, dout, h, w, cout, cin, stride_d, pad_d);
     if (rc) return rc;
-    Geom g{dout, din, h, w, cout, cin, stride_d, pad_d, 1};
-    hipLaunchKernelGGL(conv3d_gather_split, dim3(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), din, cin / BN), dim3(256), 0,
+    Geom g{dout, din, h, w, cout, cin, stride_d, pad_d, 1, n_frames};
+    hipLaunchKernelGGL(conv3d_gather_split, dim3(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), din * n_frames, cin / BN), dim3(256), 0,
                        (hipStream_t)stream, dz, (const unsigned short *)wsplit_dgrad, (const float *)nullptr, dx,
                        (double *)nullptr, g, 0, (const int *)nullptr, (const unsigned char *)nullptr,
-                       (const float *)nullptr, 0, only_tiles);
+                       (const float *)nullptr, 0, only_tiles, (unsigned long long *)exec_stages);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
+}
+
+extern "C" int mvx_conv3d_dgrad_tiles_split_frames(const float *dz, const void *wsplit_dgrad, float *dx, int32_t din,
+                                                   int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                                                   int32_t stride_d, int32_t pad_d, const int32_t *dx_tile_flags,
+                                                   uint64_t *exec_stages, int32_t n_frames, void *stream) {
+    MVX_CHECK_ARG(dx_tile_flags);
+    return launch_dgrad_split(dz, wsplit_dgrad, dx, din, dout, h, w, cin, cout, stride_d, pad_d, dx_tile_flags, exec_stages,
+                              n_frames, stream);
 }
 
 extern "C" int mvx_conv3d_dgrad_tiles_split(const float *dz, const void *wsplit_dgrad, float *dx, int32_t din, int32_t dout,
                                             int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d,
                                             int32_t pad_d, const int32_t *dx_tile_flags, void *stream) {
     MVX_CHECK_ARG(dx_tile_flags);
-    return launch_dgrad_split(dz, wsplit_dgrad, dx, din, dout, h, w, cin, cout, stride_d, pad_d, dx_tile_flags, stream);
+    return launch_dgrad_split(dz, wsplit_dgrad, dx, din, dout, h, w, cin, cout, stride_d, pad_d, dx_tile_flags, nullptr, 1, stream);
 }
 
 extern "C" int mvx_conv3d_dgrad_split(const float *dz, const void *wsplit_dgrad, float *dx, int32_t din, int32_t dout,
                                       int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
                                       void *stream) {
-    return launch_dgrad_split(dz, wsplit_dgrad, dx, din, dout, h, w, cin, cout, stride_d, pad_d, nullptr, stream);
+    return launch_dgrad_split(dz, wsplit_dgrad, dx, din, dout, h, w, cin, cout, stride_d, pad_d, nullptr, nullptr, 1, stream);
 }
 
 extern "C" int mvx_conv3d_wgrad_split(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
@@ -540,29 +572,36 @@ static int wgrad_bg_split_strips(int cin) {
     return s < 1 ? 1 : s;
 }
 
-extern "C" size_t mvx_conv3d_wgrad_bg_split_workspace_bytes(int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout) {
-    if (dout <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout != BN || cin % BK) return 0;
+extern "C" size_t mvx_conv3d_wgrad_bg_split_workspace_bytes_frames(int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                                                                  int32_t n_frames) {
+    if (dout <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout != BN || cin % BK || n_frames <= 0) return 0;
     const size_t ntiles = (size_t)mvx_cdiv(w, TW) * mvx_cdiv(h, TH);
-    return (size_t)wgrad_bg_split_strips(cin) * 27 * cin * BN * sizeof(float) + sizeof(int) * (3 * dout * ntiles + 4);
+    return (size_t)wgrad_bg_split_strips(cin) * 27 * cin * BN * sizeof(float) + sizeof(int) * (3 * dout * n_frames * ntiles + 4);
 }
 
-extern "C" int mvx_conv3d_wgrad_bg_split(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
-                                         int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
-                                         int32_t flags, const int32_t *in_halo_flags, const float *c_in,
-                                         const float *tap_sums, void *workspace, size_t workspace_bytes, void *stream) {
+extern "C" size_t mvx_conv3d_wgrad_bg_split_workspace_bytes(int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout) {
+    return mvx_conv3d_wgrad_bg_split_workspace_bytes_frames(dout, h, w, cin, cout, 1);
+}
+
+extern "C" int mvx_conv3d_wgrad_bg_split_frames(const float *in, const float *dz, float *dw, int32_t din, int32_t dout,
+                                                int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d,
+                                                int32_t pad_d, int32_t flags, const int32_t *in_halo_flags, const float *c_in,
+                                                const float *tap_sums, void *workspace, size_t workspace_bytes,
+                                                int32_t n_frames, void *stream) {
     MVX_CHECK_ARG(in && dz && dw && workspace && in_halo_flags && c_in && tap_sums);
+    MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
     int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
     if (rc) return rc;
     if (cout != BN) return MVX_ESIZE;
-    MVX_CHECK_ARG(workspace_bytes >= mvx_conv3d_wgrad_bg_split_workspace_bytes(dout, h, w, cin, cout));
+    MVX_CHECK_ARG(workspace_bytes >= mvx_conv3d_wgrad_bg_split_workspace_bytes_frames(dout, h, w, cin, cout, n_frames));
     const int ntiles = (int)(mvx_cdiv(w, TW) * mvx_cdiv(h, TH));
     const int nstrips = wgrad_bg_split_strips(cin);
-    Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
+    Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0, n_frames};
     hipStream_t st = (hipStream_t)stream;
     float *slabs = (float *)workspace;
     int *list = (int *)((char *)workspace + (size_t)nstrips * 27 * cin * BN * sizeof(float));
-    int *count = list + (size_t)3 * dout * ntiles;
-    rc = mvxi_wgrad_step_list(in_halo_flags, din, dout, ntiles, stride_d, pad_d, list, count, st);
+    int *count = list + (size_t)3 * dout * n_frames * ntiles;
+    rc = mvxi_wgrad_step_list(in_halo_flags, din, dout, ntiles, stride_d, pad_d, list, count, st, n_frames);
     if (rc) return rc;
     hipLaunchKernelGGL(conv3d_wgrad_split, dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz, slabs, g, 0,
                        (const int *)list, (const int *)count, c_in);
@@ -571,5 +610,13 @@ extern "C" int mvx_conv3d_wgrad_bg_split(const float *in, const float *dz, float
     hipLaunchKernelGGL(wgrad_reduce_split, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)slabs, dw, nstrips,
                        cin, flags & MVX_FLAG_ACCUMULATE);
     MVX_LAUNCH_CHECK();
-    return mvxi_wgrad_rank1(tap_sums, c_in, dw, din, dout, cin, cout, stride_d, pad_d, st);
+    return mvxi_wgrad_rank1(tap_sums, c_in, dw, din, dout, cin, cout, stride_d, pad_d, st, n_frames);
+}
+
+extern "C" int mvx_conv3d_wgrad_bg_split(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
+                                         int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
+                                         int32_t flags, const int32_t *in_halo_flags, const float *c_in,
+                                         const float *tap_sums, void *workspace, size_t workspace_bytes, void *stream) {
+    return mvx_conv3d_wgrad_bg_split_frames(in, dz, dw, din, dout, h, w, cin, cout, stride_d, pad_d, flags, in_halo_flags, c_in,
+                                            tap_sums, workspace, workspace_bytes, 1, stream);
 }

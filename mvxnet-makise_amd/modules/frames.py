@@ -269,9 +269,10 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
     S.conv1 = dict(feat=feat, w=w1, b=b1, w_all=w_all, y=y1, mi=mi1, c=cc1, ybg=ybg1, tflag=tflag1, D0=D0, D1=D1)
 
     # ---- conv2, conv3 on the MFMA gather kernel with the background rewrite (voxelnet/Pipe.py:37-42)
-    split = conv_split_math()
-    if split or not conv_background_on():
-        raise X.MvxHipError('the frame-set path runs the exact-f32 kernels with convbackground (the default configuration)')
+    split = conv_split_math()                # convmath: bf16x3 -> the split-MFMA forms of the three conv2 / conv3 kernels
+    if not conv_background_on():
+        raise X.MvxHipError('the frame-set path needs convbackground (the default configuration)')
+    S.split = split
     S.convs = []
     x_in, din, c_in, mask_in, hflag_in, tflag_in = x1, D1, cc1, mask1, hflag1, tflag1
     bflag_in = tflag1                                     # tiles on which the gradient of x_in is produced / consumed
@@ -280,7 +281,7 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
         co, ci = w.shape[0], w.shape[1]
         sd, pd = m._sd, m._pd
         dout = _hip.conv_out_depth(din, sd, pd)
-        wpk = m._packer(False, False)
+        wpk = m._packer(False, split)
         bg_pre = torch.empty((F * dout, co), dtype=torch.float32, device=dev)
         X.check(X.lib.mvx_conv3d_background_frames(X.ptr(w), X.ptr(c_in), din, dout, ci, co, sd, pd, X.ptr(bg_pre), F, X.stream()),
                 'mvx_conv3d_background_frames')
@@ -296,7 +297,16 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
             if _hip.EXEC_STAGES is None:
                 _hip.EXEC_STAGES = torch.zeros((1,), dtype=torch.int64, device=dev)
             counter = _hip.EXEC_STAGES
-        with _hip._Timed('conv3d_gather_bg', F * _hip.conv_flops(dout, din, H, W, ci, co, sd, pd) if _hip.KERNEL_TIMERS is not None else 0):
+        if split:
+            with _hip._Timed('conv3d_gather_bg', F * _hip.conv_flops(dout, din, H, W, ci, co, sd, pd) if _hip.KERNEL_TIMERS is not None else 0):
+                X.check(X.lib.mvx_conv3d_forward_bg_split_frames(X.ptr(x_in), X.ptr(wpk), X.ptr(b), X.ptr(y), X.ptr(stats), din, dout,
+                                                                 H, W, ci, co, sd, pd, _hip.FLAG_RELU | fz, X.ptr(hflag_in),
+                                                                 X.ptr(mask_o), X.ptr(bg_pre), 1, X.ptr(counter), F, X.stream()),
+                        'mvx_conv3d_forward_bg_split_frames')
+            X.check(X.lib.mvx_bn_finalize_frames(X.ptr(stats), float(dout * H * W), float(eps), X.ptr(mi), co, F, X.stream()),
+                    'mvx_bn_finalize_frames')
+        else:
+          with _hip._Timed('conv3d_gather_bg', F * _hip.conv_flops(dout, din, H, W, ci, co, sd, pd) if _hip.KERNEL_TIMERS is not None else 0):
             X.check(X.lib.mvx_conv3d_forward_bg_frames(X.ptr(x_in), X.ptr(wpk), X.ptr(b), X.ptr(y), X.ptr(stats), din, dout, H, W,
                                                        ci, co, sd, pd, _hip.FLAG_RELU | fz, X.ptr(hflag_in), X.ptr(mask_o),
                                                        X.ptr(bg_pre), 1, X.ptr(counter), X.ptr(fin), float(dout * H * W),
@@ -304,7 +314,7 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
                     'mvx_conv3d_forward_bg_frames')
         x_out = bn_apply(y, mi, fs, X.ROWS_GRID)
         rec = dict(x=x_in, w=w, b=b, y=y, mi=mi, din=din, dout=dout, sd=sd, pd=pd, m=m, c_in=c_in, hflag_in=hflag_in,
-                   bflag_in=bflag_in)
+                   bflag_in=bflag_in, split=split)
         if li == 0:
             # the background of this layer's output and the tiles its own restricted backward touches
             c_o, ybg_o = background(bg_pre, b, mi, dout, co)
@@ -331,6 +341,16 @@ def _wgrad_bg(rec, dz, tap_sums, F, H, W):
     co, ci = w.shape[0], w.shape[1]
     dw = _grad_of(w)
     nbytes = X.lib.mvx_conv3d_wgrad_bg_workspace_bytes_frames(rec['dout'], H, W, ci, co, F)
+    if rec.get('split'):
+        nbytes = X.lib.mvx_conv3d_wgrad_bg_split_workspace_bytes_frames(rec['dout'], H, W, ci, co, F)
+        with _hip._SideStream(x, dz, tap_sums, rec['c_in'], rec['hflag_in']):
+            ws = _hip.workspace(nbytes, x.device, 'wgrad_bg_side')
+            with _hip._Timed('conv3d_wgrad_bg', 0):
+                X.check(X.lib.mvx_conv3d_wgrad_bg_split_frames(X.ptr(x), X.ptr(dz), X.ptr(dw), rec['din'], rec['dout'], H, W, ci, co,
+                                                               rec['sd'], rec['pd'], _hip.FLAG_ACCUMULATE, X.ptr(rec['hflag_in']),
+                                                               X.ptr(rec['c_in']), X.ptr(tap_sums), X.ptr(ws), ws.numel(), F,
+                                                               X.stream()), 'mvx_conv3d_wgrad_bg_split_frames')
+        return
     with _hip._SideStream(x, dz, tap_sums, rec['c_in'], rec['hflag_in']):
         ws = _hip.workspace(nbytes, x.device, 'wgrad_bg_side')
         with _hip._Timed('conv3d_wgrad_bg', 0):
@@ -384,12 +404,19 @@ def cml_backward(model, S, grad_mid, g_cl=None):
         w = rec['w']
         co, ci = w.shape[0], w.shape[1]
         dx = torch.empty((F * rec['din'], H, W, ci), dtype=torch.float32, device=dev)
-        wpd = rec['m']._packer(True, False)
+        wpd = rec['m']._packer(True, bool(rec.get('split')))
         counter = None
         if _hip.KERNEL_TIMERS is not None:
             if _hip.EXEC_STAGES is None:
                 _hip.EXEC_STAGES = torch.zeros((1,), dtype=torch.int64, device=dev)
             counter = _hip.EXEC_STAGES
+        if rec.get('split'):
+            with _hip._Timed('conv3d_gather_tiles', F * _hip.conv_flops(rec['din'], rec['dout'], H, W, co, ci, rec['sd'], rec['pd'], True)
+                             if _hip.KERNEL_TIMERS is not None else 0):
+                X.check(X.lib.mvx_conv3d_dgrad_tiles_split_frames(X.ptr(dz), X.ptr(wpd), X.ptr(dx), rec['din'], rec['dout'], H, W, ci,
+                                                                  co, rec['sd'], rec['pd'], X.ptr(bflag), X.ptr(counter), F,
+                                                                  X.stream()), 'mvx_conv3d_dgrad_tiles_split_frames')
+            return dx
         with _hip._Timed('conv3d_gather_tiles', F * _hip.conv_flops(rec['din'], rec['dout'], H, W, co, ci, rec['sd'], rec['pd'], True)
                          if _hip.KERNEL_TIMERS is not None else 0):
             X.check(X.lib.mvx_conv3d_dgrad_tiles_frames(X.ptr(dz), X.ptr(wpd), X.ptr(dx), rec['din'], rec['dout'], H, W, ci, co,

@@ -101,3 +101,46 @@ def test_frame_set_equals_per_frame_execution(golden, small_cfg, B, with_empty):
         torch.cuda.synchronize()
         for k, p in hot:
             assert rel_err(got[k], p.grad) < 2e-4, k
+
+
+def test_frame_set_bf16x3_matches_per_frame_bf16x3_and_f32(golden, small_cfg):
+    """convmath: bf16x3 on the frame-set executor (conv2 / conv3 forward, dgrad, wgrad on the split-MFMA kernels with a frame
+    dimension): the same arithmetic as the per-frame executor in that mode (maps to summation order), and the maps
+    within the split's 2e-5 of the exact-f32 frame set."""
+    from MVXNet import MVXNet
+    from modules import parallel
+    from modules.pipeline import train_step_frame_set, train_step_frames
+    torch.manual_seed(3)
+    model = MVXNet().to(DEV)
+    B = 3
+    batch, G = _small_batch(golden, B)
+    for f in range(B):
+        nlive = int(batch.n_points[f])
+        batch.perms[f, :nlive] = torch.randperm(nlive, generator=torch.Generator().manual_seed(f)).to(DEV)
+    hot = [(k, p) for k, p in model.named_parameters() if p.requires_grad and '.rpn.' not in k]
+    bucket = parallel.GradBucket([p for _, p in hot])
+    imsize = [370.0, 1224.0]
+    bucket.zero()
+    mids_f32 = []
+    train_step_frame_set(model, batch, G, imsize, keep_mid=mids_f32)
+    torch.cuda.synchronize()
+    old = small_cfg.config.get('convmath', 'f32')
+    small_cfg.config['convmath'] = 'bf16x3'
+    try:
+        bucket.zero()
+        mids_ref = []
+        train_step_frames(model, batch, G, imsize, keep_mid=mids_ref)
+        torch.cuda.synchronize()
+        ref = {k: p.grad.clone() for k, p in hot}
+        bucket.zero()
+        mids = []
+        _, st = train_step_frame_set(model, batch, G, imsize, keep_mid=mids)
+        torch.cuda.synchronize()
+    finally:
+        small_cfg.config['convmath'] = old
+    assert int(torch.stack([s.reshape(()) for s in st]).max()) == 0
+    for a, b, c in zip(mids, mids_ref, mids_f32):
+        assert rel_err(a, b) < 2e-5                      # same split arithmetic, different launch shape
+        assert rel_err(a, c) < 1e-4                      # against the exact-f32 mode
+    for k, p in hot:
+        assert rel_err(p.grad, ref[k]) < 2e-3, k
