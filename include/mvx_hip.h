@@ -201,7 +201,7 @@ int mvx_bn_relu_backward(const float *dyhat, const float *y, const float *mean_i
  *                            per-channel (sum, sum of squares) of `out` for the BatchNorm that
  *                            follows (Blocks.py:28-29)
  *   work_counter (optional, forward / dgrad and their _bg / _tiles forms): u32 [1] holding ZERO; the launch then uses
- *                            the persistent form of the kernel -- three workgroups per CU pull (tile, plane, channel block)
+ *                            the persistent form of the kernel -- two workgroups per CU pull (tile, plane, channel block)
  *                            units from this counter until none is left: no tail round of idle CUs, constant-fill tiles do
  *                            not unbalance the workgroups.  NULL: one workgroup per unit.
  *   mvx_conv3d_dgrad         dx [din][h][w][cin] from dz [dout][h][w][cout]

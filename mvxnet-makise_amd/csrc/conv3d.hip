@@ -915,7 +915,7 @@ static int persistent_grid() {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
             cus <= 0)
             cus = 256;
-        cached = 3 * cus;                           // three workgroups per CU fit (52.7 KB of LDS, 158 VGPRs each)
+        cached = 2 * cus;                           // two workgroups per CU (three would fit: 52.7 KB of LDS, 158 VGPRs each)
     }
     return cached;
 }
