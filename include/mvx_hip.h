@@ -319,6 +319,17 @@ int mvx_conv3d_wgrad_bg_split_frames(const float *in, const float *dz, float *dw
                                      int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, int32_t flags,
                                      const int32_t *in_halo_flags, const float *c_in, const float *tap_sums,
                                      void *workspace, size_t workspace_bytes, int32_t n_frames, void *stream);
+/* bf16x3 forms of the RPN's 2-D convolutions on frame sets (modules/voxelnet/Pipe.py:45-75; one plane per frame).  wsplit:
+ * the 2-D kernel placed in the middle depth slice of a [cout][cin][3][3][3] tensor, packed by
+ * mvx_conv3d_pack_weights_split; dw3 f32 [cout][cin][3][3][3] (overwritten): the 2-D gradient is its middle depth slice. */
+int mvx_conv2d_forward_split_frames(const float *in, const void *wsplit, const float *bias, float *out, double *stats,
+                                    int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t flags, int32_t n_frames,
+                                    void *stream);
+int mvx_conv2d_dgrad_split_frames(const float *dz, const void *wsplit_dgrad, float *dx, int32_t h, int32_t w, int32_t cin,
+                                  int32_t cout, int32_t n_frames, void *stream);
+size_t mvx_conv2d_wgrad_split_workspace_bytes_frames(int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t n_frames);
+int mvx_conv2d_wgrad_split_frames(const float *in, const float *dz, float *dw3, int32_t h, int32_t w, int32_t cin,
+                                  int32_t cout, void *workspace, size_t workspace_bytes, int32_t n_frames, void *stream);
 size_t mvx_bn_relu_backward_tiles_workspace_bytes(int32_t planes, int32_t h, int32_t w, int32_t channels);
 int mvx_bn_relu_backward_tiles(const float *dyhat, const float *y, const float *mean_inv, const float *c_bg,
                                const float *y_bg, const float *plane_grad_sums, const int32_t *tile_flags,

@@ -620,3 +620,80 @@ extern "C" int mvx_conv3d_wgrad_bg_split(const float *in, const float *dz, float
     return mvx_conv3d_wgrad_bg_split_frames(in, dz, dw, din, dout, h, w, cin, cout, stride_d, pad_d, flags, in_halo_flags, c_in,
                                             tap_sums, workspace, workspace_bytes, 1, stream);
 }
+
+// ------------------------------------------------------------------------------------------
+// 2-D convolutions of the RPN on frame sets, bf16x3 (modules/voxelnet/Pipe.py:45-75): the same kernels with one plane
+// per frame (din = dout = 1, pad_d = 1: only the middle depth tap exists).  Weights: the 2-D kernel placed in the middle
+// depth slice of a 3-D one and packed with mvx_conv3d_pack_weights_split.  The stride-2 layers run on the space-to-depth
+// image with their rearranged 3x3 kernel (zeros where the 2x2 window has no tap: all nine taps are executed here).
+// ------------------------------------------------------------------------------------------
+extern "C" int mvx_conv2d_forward_split_frames(const float *in, const void *wsplit, const float *bias, float *out, double *stats,
+                                               int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t flags,
+                                               int32_t n_frames, void *stream) {
+    MVX_CHECK_ARG(in && wsplit && out);
+    MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
+    int rc = check_geom(1, 1, h, w, cin, cout, 1, 1);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (stats && !(flags & MVX_FLAG_PREZEROED)) {
+        hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * MVX_REP * 2 * cout * n_frames, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    Geom g{1, 1, h, w, cin, cout, 1, 1, 0, n_frames};
+    hipLaunchKernelGGL(conv3d_gather_split, dim3(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), n_frames, cout / BN), dim3(256), 0, st, in,
+                       (const unsigned short *)wsplit, bias, out, stats, g, flags & MVX_FLAG_RELU, (const int *)nullptr,
+                       (const unsigned char *)nullptr, (const float *)nullptr, 0, (const int *)nullptr,
+                       (unsigned long long *)nullptr);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+extern "C" int mvx_conv2d_dgrad_split_frames(const float *dz, const void *wsplit_dgrad, float *dx, int32_t h, int32_t w,
+                                             int32_t cin, int32_t cout, int32_t n_frames, void *stream) {
+    return launch_dgrad_split(dz, wsplit_dgrad, dx, 1, 1, h, w, cin, cout, 1, 1, nullptr, nullptr, n_frames, stream);
+}
+
+static int conv2d_wgrad_split_strips(int cin) {
+    const int s = 256 / (cin / BK);                 // one depth tap carries work: 256 workgroups per 64-channel block of dz
+    return s < 1 ? 1 : (s > 64 ? 64 : s);
+}
+
+extern "C" size_t mvx_conv2d_wgrad_split_workspace_bytes_frames(int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t n_frames) {
+    if (h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || cin % BK || cout % BN || n_frames <= 0) return 0;
+    const size_t ntiles = (size_t)mvx_cdiv(w, TW) * mvx_cdiv(h, TH);
+    return (size_t)conv2d_wgrad_split_strips(cin) * 27 * cin * BN * sizeof(float) +
+           sizeof(int) * (3 * (size_t)n_frames * ntiles + 4) + sizeof(int) * (size_t)n_frames * ntiles;
+}
+
+// dw3 f32 [cout][cin][3][3][3]: the 2-D gradient is its middle depth slice (slices 0 and 2 come out zero)
+extern "C" int mvx_conv2d_wgrad_split_frames(const float *in, const float *dz, float *dw3, int32_t h, int32_t w, int32_t cin,
+                                             int32_t cout, void *workspace, size_t workspace_bytes, int32_t n_frames,
+                                             void *stream) {
+    MVX_CHECK_ARG(in && dz && dw3 && workspace);
+    MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
+    int rc = check_geom(1, 1, h, w, cin, cout, 1, 1);
+    if (rc) return rc;
+    MVX_CHECK_ARG(workspace_bytes >= mvx_conv2d_wgrad_split_workspace_bytes_frames(h, w, cin, cout, n_frames));
+    hipStream_t st = (hipStream_t)stream;
+    const int ntiles = (int)(mvx_cdiv(w, TW) * mvx_cdiv(h, TH));
+    const int nstrips = conv2d_wgrad_split_strips(cin);
+    float *slabs = (float *)workspace;
+    int *list = (int *)((char *)workspace + (size_t)nstrips * 27 * cin * BN * sizeof(float));
+    int *count = list + (size_t)3 * n_frames * ntiles;
+    int *ones = count + 4;                          // "every tile is a step": any non-zero word is a set flag
+    hipError_t e = hipMemsetAsync(ones, 0x01, sizeof(int) * (size_t)n_frames * ntiles, st);
+    if (e != hipSuccess) return (int)e;
+    rc = mvxi_wgrad_step_list(ones, 1, 1, ntiles, 1, 1, list, count, st, n_frames);
+    if (rc) return rc;
+    Geom g{1, 1, h, w, cin, cout, 1, 1, 0, n_frames};
+    const size_t per_slab = (size_t)27 * cin * BN;
+    for (int nb = 0; nb < cout / BN; ++nb) {        // the kernel owns 64 channels of dz per launch
+        hipLaunchKernelGGL(conv3d_wgrad_split, dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz + (size_t)nb * BN,
+                           slabs, g, 0, (const int *)list, (const int *)count, (const float *)nullptr);
+        MVX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(wgrad_reduce_split, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)slabs,
+                           dw3 + (size_t)nb * BN * cin * 27, nstrips, cin, 0);
+        MVX_LAUNCH_CHECK();
+    }
+    return MVX_OK;
+}

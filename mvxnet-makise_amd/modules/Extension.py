@@ -98,6 +98,10 @@ PROTOTYPES = {
     'mvx_conv3d_wgrad_bg_split_workspace_bytes_frames': (_sz, [_i32, _i32, _i32, _i32, _i32, _i32]),
     'mvx_conv3d_wgrad_bg_split_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _sz,
                                                 _i32, _p]),
+    'mvx_conv2d_forward_split_frames': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    'mvx_conv2d_dgrad_split_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    'mvx_conv2d_wgrad_split_workspace_bytes_frames': (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    'mvx_conv2d_wgrad_split_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _p, _sz, _i32, _p]),
     'mvx_plane_tap_sums_workspace_bytes': (_sz, [_i32, _i32]),
     'mvx_plane_tap_sums': (_i32, [_p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
     'mvx_tile_dilate_flags': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),

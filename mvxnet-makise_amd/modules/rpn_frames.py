@@ -29,6 +29,11 @@ R = _hip.STATS_REPLICAS
 TAPS2 = 16          # MVX_FLAG_TAPS2
 
 
+def _split():
+    """convmath: bf16x3 -> the 3x3 convolutions run on the split-MFMA kernels (csrc/conv3d_split.hip)."""
+    return cfg.config.get('convmath', 'f32') == 'bf16x3'
+
+
 def _grad_of(p):
     if p.grad is None or not p.grad.is_contiguous():
         raise X.MvxHipError('the frame-set path adds gradients into existing contiguous .grad buffers (GradBucket)')
@@ -84,11 +89,18 @@ class _Packs:
         self.cache = {}
 
     def get(self, key, w, make, for_dgrad):
+        split = _split()
         tag = (w._version, w.data_ptr())
-        hit = self.cache.get((key, for_dgrad))
+        hit = self.cache.get((key, for_dgrad, split))
         if hit is None or hit[0] != tag:
-            hit = (tag, _hip.conv3d_pack(make().detach(), for_dgrad))
-            self.cache[(key, for_dgrad)] = hit
+            w2 = make().detach()
+            if split:                      # bf16x3: the 2-D kernel as the middle depth slice of a 3-D one, hi/lo split pack
+                w3 = torch.zeros(w2.shape[:2] + (3, 3, 3), dtype=torch.float32, device=w2.device)
+                w3[:, :, 1] = w2
+                hit = (tag, _hip.conv3d_pack(w3, for_dgrad, split=True))
+            else:
+                hit = (tag, _hip.conv3d_pack(w2, for_dgrad))
+            self.cache[(key, for_dgrad, split)] = hit
         return hit[1]
 
 
@@ -113,6 +125,13 @@ def _conv(x, wpk, bias, F, h, w, cin, cout, flags, eps):
     if fin is None:
         fin = torch.zeros((1,), dtype=torch.float64, device=dev)
     mi = torch.empty((F, 2, cout), dtype=torch.float32, device=dev)
+    if _split():                               # all nine taps of the rearranged stride-2 kernels are executed here
+        with _hip._Timed('rpn_conv', 2.0 * F * h * w * cin * cout * 9 if _hip.KERNEL_TIMERS is not None else 0):
+            X.check(X.lib.mvx_conv2d_forward_split_frames(X.ptr(x), X.ptr(wpk), X.ptr(bias), X.ptr(y), X.ptr(stats), h, w, cin, cout,
+                                                          _hip.FLAG_RELU | fz, F, X.stream()), 'mvx_conv2d_forward_split_frames')
+        X.check(X.lib.mvx_bn_finalize_frames(X.ptr(stats), float(h * w), float(eps), X.ptr(mi), cout, F, X.stream()),
+                'mvx_bn_finalize_frames')
+        return y, mi
     nt = 4 if flags & TAPS2 else 9
     with _hip._Timed('rpn_conv', 2.0 * F * h * w * cin * cout * nt if _hip.KERNEL_TIMERS is not None else 0):
         X.check(X.lib.mvx_conv2d_forward_frames(X.ptr(x), X.ptr(wpk), X.ptr(bias), X.ptr(y), X.ptr(stats), h, w, cin, cout,
@@ -141,6 +160,11 @@ def _bn_bwd(g, y, mi, F, bias):
 
 def _dgrad(dz, wpd, F, h, w, cin, cout, flags):
     dx = torch.empty((F, h, w, cin), dtype=torch.float32, device=dz.device)
+    if _split():
+        with _hip._Timed('rpn_conv', 2.0 * F * h * w * cin * cout * 9 if _hip.KERNEL_TIMERS is not None else 0):
+            X.check(X.lib.mvx_conv2d_dgrad_split_frames(X.ptr(dz), X.ptr(wpd), X.ptr(dx), h, w, cin, cout, F, X.stream()),
+                    'mvx_conv2d_dgrad_split_frames')
+        return dx
     nt = 4 if flags & TAPS2 else 9
     with _hip._Timed('rpn_conv', 2.0 * F * h * w * cin * cout * nt if _hip.KERNEL_TIMERS is not None else 0):
         X.check(X.lib.mvx_conv2d_dgrad_frames(X.ptr(dz), X.ptr(wpd), X.ptr(dx), h, w, cin, cout, flags,
@@ -151,6 +175,17 @@ def _dgrad(dz, wpd, F, h, w, cin, cout, flags):
 def _wgrad(x, dz, F, h, w, cin, cout, flags, into=None):
     """dW (cout, cin, 3, 3) over all frames, on the side stream; ADDED into ``into`` or returned."""
     dev = x.device
+    if _split():
+        nbytes = X.lib.mvx_conv2d_wgrad_split_workspace_bytes_frames(h, w, cin, cout, F)
+        dw3 = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device=dev)
+        with _hip._SideStream(x, dz, dw3, into):
+            ws = _hip.workspace(nbytes, dev, 'rpn_wgrad_side')
+            X.check(X.lib.mvx_conv2d_wgrad_split_frames(X.ptr(x), X.ptr(dz), X.ptr(dw3), h, w, cin, cout, X.ptr(ws), ws.numel(), F,
+                                                        X.stream()), 'mvx_conv2d_wgrad_split_frames')
+            if into is not None:
+                into.add_(dw3[:, :, 1])
+                return into
+            return dw3[:, :, 1].contiguous()
     nbytes = X.lib.mvx_conv2d_wgrad_workspace_bytes_frames(h, w, cin, cout, F)
     dw = into if into is not None else torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
     with _hip._SideStream(x, dz, dw):

@@ -171,3 +171,41 @@ def test_rpn_hip_agrees_with_the_module_path_at_full_size():
         score, reg = rf.split_heads(heads, 1, S['h1'], S['w1'])
     assert float((score - s_ref).abs().max()) < 1e-4
     assert rel(reg, r_ref) < 1e-4
+
+
+def test_rpn_bf16x3_mode_stays_within_the_feature_bar(golden):
+    """convmath: bf16x3 -- the RPN's 3x3 convolutions (forward, dgrad, wgrad; stride-2 layers through their rearranged 3x3
+    kernel) on the split-MFMA kernels.  Through 17 layers the split's 2e-5 per product reaches 1.3e-4 on the head maps of
+    these small 64x96 inputs (deepest maps 8x12 sites per frame): above the 1e-4 feature bar, which is why this mode is
+    opt-in; bounded here at 3e-4, gradients at 5e-2 (ReLU-kink sensitivity of small maps)."""
+    import modules.config as cfg
+    from modules import _hip, parallel
+    from modules import rpn_frames as rf
+    P = O.rpn_params(golden('rpn_shapes'))
+    rpn = _load_rpn(P)
+    bucket = parallel.GradBucket(list(rpn.parameters()))
+    F, H, W = 2, 64, 96
+    gen = torch.Generator().manual_seed(5)
+    x_cl = _to_planes(torch.randn((F, 128, H, W), generator=gen).to(DEV))
+    d_heads = (torch.randn((F * (H // 2) * (W // 2), 16), generator=gen) * 0.1).to(DEV)
+    res = {}
+    old = cfg.config.get('convmath', 'f32')
+    try:
+        for math in ('f32', 'bf16x3'):
+            cfg.config['convmath'] = math
+            bucket.zero()
+            heads, S = rf.rpn_forward(rpn, x_cl, F, 2, H, W, 64)
+            g = rf.rpn_backward(rpn, S, d_heads)
+            _hip.join_side_stream()
+            torch.cuda.synchronize()
+            res[math] = (heads.clone(), g.clone(), bucket.flat.clone())
+    finally:
+        cfg.config['convmath'] = old
+    assert rel(res['bf16x3'][0], res['f32'][0]) < 3e-4
+    assert rel(res['bf16x3'][1], res['f32'][1]) < 5e-2          # input gradient: the ReLU-kink sensitivity of these small maps
+    a, b = res['bf16x3'][2], res['f32'][2]
+    off = 0
+    for k, p in rpn.named_parameters():
+        ga, gb = a[off:off + p.numel()], b[off:off + p.numel()]
+        off += p.numel()
+        assert rel(ga, gb) < 5e-2, k
