@@ -1,5 +1,5 @@
 // Knock-out probe of conv3d_gather_pf: the production kernel text with pieces removed by template knobs
-// (results are garbage; only the time matters).  GENERATED by tools/probes/mk_gather_probe.py.
+// (results are garbage; only the time matters).  Snapshot of the ROUND-1 kernel text (generated then by a script that tracked the kernel source; the production kernel has since gained the frame dimension, the tap-range template and the swizzled weight tile).
 //   knob 1: no barriers between tap rows   2: no weight traffic (global loads + LDS stores)
 //        4: no halo traffic                8: MFMA operands from registers (no LDS reads)
 #include <hip/hip_runtime.h>
