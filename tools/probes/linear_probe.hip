@@ -1,4 +1,4 @@
-// GENERATED by tools/probes/mk_linear_probe.py: production linear_fwd with knock-out knobs (times only).
+// Snapshot of the ROUND-1 linear_fwd kernel text with knock-out knobs (times only); generated then by a script that tracked the kernel source.
 //   knob 1: barriers only in the first chunk   2: LDS tile stores only in the first chunk   4: no global prefetch loads
 //        8: no output stores / statistics
 #include <hip/hip_runtime.h>
