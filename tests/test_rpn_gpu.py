@@ -209,3 +209,37 @@ def test_rpn_bf16x3_mode_stays_within_the_feature_bar(golden):
         ga, gb = a[off:off + p.numel()], b[off:off + p.numel()]
         off += p.numel()
         assert rel(ga, gb) < 5e-2, k
+
+
+def test_rpn_full_size_maps_match_the_float64_oracle(golden):
+    """The RPN at the benchmark's size (352x400 BEV map -> 176x200 heads, one frame inside a 2-frame set) against the oracle
+    evaluated in float64 on the CPU: score within 1e-4 absolute, regression map within 1e-4 of its maximum (north_star's
+    bar for the RPN maps), where BatchNorm is well conditioned (>= 2,200 sites per channel in the deepest maps)."""
+    from modules import rpn_frames as rf
+    P = O.rpn_params(golden('rpn_shapes'))
+    rpn = _load_rpn(P)
+    F, H, W = 2, 352, 400
+    gen = torch.Generator().manual_seed(11)
+    mids = torch.randn((F, 128, H, W), generator=gen)
+    heads, S = rf.rpn_forward(rpn, _to_planes(mids.to(DEV)), F, 2, H, W, 64)
+    got = heads.view(F, H // 2, W // 2, 16)[1].cpu().double()
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    with torch.no_grad():
+        score, reg = O.rpn(mids[1:2].double(), {k: v.double() for k, v in P.items()})
+    e_score = float((torch.sigmoid(got[..., :2]) - score[0].permute(1, 2, 0)).abs().max())
+    e_reg = rel(got[..., 2:], reg[0].permute(1, 2, 0))
+    print('full-size RPN vs float64 oracle: score %.2e (abs), reg %.2e (max-norm rel)' % (e_score, e_reg))
+    assert e_score < 1e-4 and e_reg < 1e-4
+    # the same maps in convmath: bf16x3 (opt-in): reported, and bounded at 5e-4
+    import modules.config as cfg
+    old = cfg.config.get('convmath', 'f32')
+    cfg.config['convmath'] = 'bf16x3'
+    try:
+        heads2, _ = rf.rpn_forward(rpn, _to_planes(mids.to(DEV)), F, 2, H, W, 64)
+    finally:
+        cfg.config['convmath'] = old
+    got2 = heads2.view(F, H // 2, W // 2, 16)[1].cpu().double()
+    e2_score = float((torch.sigmoid(got2[..., :2]) - score[0].permute(1, 2, 0)).abs().max())
+    e2_reg = rel(got2[..., 2:], reg[0].permute(1, 2, 0))
+    print('  bf16x3: score %.2e (abs), reg %.2e (max-norm rel)' % (e2_score, e2_reg))
+    assert e2_score < 5e-4 and e2_reg < 5e-4
