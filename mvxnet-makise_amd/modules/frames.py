@@ -201,16 +201,18 @@ def _vfe_forward(bb, fs, x, S, eps):
         Cn = w.shape[0]
         out = torch.empty((Rt + Vt, 2 * Cn), dtype=torch.float32, device=dev)
         am = torch.empty((Vt, Cn), dtype=torch.int32, device=dev)
-        X.check(X.lib.mvx_vfe_bn_max_concat_frames(X.ptr(y), X.ptr(mi), X.ptr(out), X.ptr(am), Vt, T, Cn, X.ptr(fs.voff),
-                                                   X.ptr(fs.vcnt), Rt, fs.desc.ref(), X.stream()), 'mvx_vfe_bn_max_concat_frames')
+        with _hip._timed_bytes('vfe_bn_max_concat', (Rt + Vt) * Cn * 4 * 3 + Vt * Cn * 4):      # read y, write [x | max] + argmax
+            X.check(X.lib.mvx_vfe_bn_max_concat_frames(X.ptr(y), X.ptr(mi), X.ptr(out), X.ptr(am), Vt, T, Cn, X.ptr(fs.voff),
+                                                       X.ptr(fs.vcnt), Rt, fs.desc.ref(), X.stream()), 'mvx_vfe_bn_max_concat_frames')
         S.vfe.append((x, w, b, y, mi, am))
         x = out
     w, b = bb.fcn.fc.weight, bb.fcn.fc.bias
     y, mi = linear_bn(x, w, b, fs, X.ROWS_VFE, fs.row_w, eps)
     feat = torch.empty((Vt, w.shape[0]), dtype=torch.float32, device=dev)
     am = torch.empty((Vt, w.shape[0]), dtype=torch.int32, device=dev)
-    X.check(X.lib.mvx_bn_segment_max_frames(X.ptr(y), X.ptr(mi), X.ptr(feat), X.ptr(am), Vt, T, w.shape[0], X.ptr(fs.voff),
-                                            X.ptr(fs.vcnt), Rt, fs.desc.ref(), X.stream()), 'mvx_bn_segment_max_frames')
+    with _hip._timed_bytes('vfe_bn_segment_max', (Rt + Vt) * w.shape[0] * 4 + Vt * w.shape[0] * 8):   # read y, write max + argmax
+        X.check(X.lib.mvx_bn_segment_max_frames(X.ptr(y), X.ptr(mi), X.ptr(feat), X.ptr(am), Vt, T, w.shape[0], X.ptr(fs.voff),
+                                                X.ptr(fs.vcnt), Rt, fs.desc.ref(), X.stream()), 'mvx_bn_segment_max_frames')
     S.head = (x, w, b, y, mi, am)
     return feat, S
 
@@ -492,8 +494,9 @@ def rows_backward(model, S, dfeat):
     for x, w, b, y, mi, am in reversed(S.vfe):
         Cn = w.shape[0]
         dyh = torch.empty((Rt + Vt, Cn), dtype=torch.float32, device=dev)
-        X.check(X.lib.mvx_vfe_max_concat_backward(X.ptr(gx), X.ptr(am), X.ptr(dyh), Vt, T, Cn, X.ptr(fs.voff), X.ptr(fs.vcnt),
-                                                  Rt, X.stream()), 'mvx_vfe_max_concat_backward')
+        with _hip._timed_bytes('vfe_max_concat_backward', (Rt + Vt) * Cn * 4 * 3 + Vt * Cn * 4):  # read [gx | gmax] + argmax, write dyhat
+            X.check(X.lib.mvx_vfe_max_concat_backward(X.ptr(gx), X.ptr(am), X.ptr(dyh), Vt, T, Cn, X.ptr(fs.voff), X.ptr(fs.vcnt),
+                                                      Rt, X.stream()), 'mvx_vfe_max_concat_backward')
         dz = bn_relu_backward(dyh, y, mi, fs, X.ROWS_VFE, fs.row_w, _grad_of(b), dz=dyh)
         _linear_wgrad_side(x, dz, w)
         gx, _ = _hip.linear_forward(dz, w, None, relu=False, want_stats=False, w_transposed=True)
