@@ -93,11 +93,11 @@ def test_mvxnet_without_extractor_matches_reference(golden):
         idx = torch.from_numpy(g['idx']).to(DEV)
         imsize = torch.from_numpy(g['imsize_hw']).to(DEV)
         v23 = model.point_features(vox, feats, [None], imsize)
-        assert rel_err(v23[0], g['v23']) < 2e-4
+        assert rel_err(v23[0], g['v23']) < 1e-4
         feat = model.backbone.voxel_features(v23)
-        assert rel_err(feat, g['feat']) < 5e-4
+        assert rel_err(feat, g['feat']) < 2e-4
         mid = model.backbone.middle(v23, idx)
-        assert rel_err(mid[0], g['mid']) < 2e-3
+        assert rel_err(mid[0], g['mid']) < 2e-4
         (mid[0] * torch.from_numpy(g['G']).to(DEV)).sum().backward()
         # Parameter gradients.  On this tiny grid the reference's OWN fp32 gradients sit 1-6 % away
         # from exact arithmetic (bias gradients in front of a BatchNorm are pure cancellation), so

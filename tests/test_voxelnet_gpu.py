@@ -72,10 +72,10 @@ def test_voxelnet_forward_and_gradients_match_reference(golden, small_cfg):
     x = torch.from_numpy(g['x'])[None].to(DEV).requires_grad_(True)
     idx = torch.from_numpy(g['idx']).to(DEV)
     feat = net.voxel_features(x)
-    assert rel_err(feat.detach().cpu(), g['feat']) < 2e-4
+    assert rel_err(feat.detach().cpu(), g['feat']) < 1e-4
     mid = net.middle(x, idx)
     assert mid.shape == (1,) + g['mid'].shape
-    assert rel_err(mid[0].detach().cpu(), g['mid']) < 1e-3
+    assert rel_err(mid[0].detach().cpu(), g['mid']) < 1e-4
     (mid[0] * torch.from_numpy(g['G']).to(DEV)).sum().backward()
     # Gradients: measured against the float64 oracle, with the reference's own fp32 distance from it as
     # the yardstick (this tiny grid makes them ill-conditioned: BatchNorm over <= 1,920 sites).  The
@@ -100,8 +100,8 @@ def test_voxelnet_forward_and_gradients_match_reference(golden, small_cfg):
         score, reg = net(x, idx)
     # RPN (next scope row, MIOpen): 16 BatchNorms over <= 96 samples each on this tiny grid are
     # ill-conditioned, so the maps are only checked loosely here
-    assert rel_err(score[0].cpu(), g['score']) < 2e-2
-    assert rel_err(reg[0].cpu(), g['reg']) < 2e-2
+    assert rel_err(score[0].cpu(), g['score']) < 1e-2
+    assert rel_err(reg[0].cpu(), g['reg']) < 1e-2
 
 
 def test_voxelnet_vs_f64_oracle(golden, small_cfg):
