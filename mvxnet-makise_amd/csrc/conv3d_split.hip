@@ -125,8 +125,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_split(const float *__res
     const int a_base = (my_ty * HW + my_tx) * ROWB + lh * 16;     // bytes; + part*64 + kstep*32
     const int b_base = li * ROWB + lh * 16;
 
-    // three weight tiles (one kernel row) = 3 x 8 KB = 1536 x 16 B -> 6 per thread
-    uint4 wreg[6];
+    // three weight tiles (one kernel row) = 3 x 8 KB = 1536 x 16 B -> 6 per thread.  A NATIVE vector type: an array of HIP's
+    // uint4 struct stays an alloca, and the backend "promoted" it to 24 KB of LDS (80 KB per workgroup: one workgroup per CU)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 wreg[6];
     auto load_w3 = [&](int kd, int a, int cc) {
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_split(const float *__res
             const int t = c >> 9, rem = c & 511;      // tap in row, 16-byte piece of the tile
             const unsigned char *tile = (const unsigned char *)wsp +
                 ((((size_t)kd * 9 + a * 3 + t) * nchunks + cc) * g.Cout + (size_t)nb * BN) * (2 * BK * 2);
-            wreg[u] = *(const uint4 *)(tile + (size_t)rem * 16);
+            wreg[u] = *(const u32x4 *)(tile + (size_t)rem * 16);
         }
     };
     auto store_w3 = [&]() {
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_split(const float *__res
             const int c = tid + 256 * u;
             const int t = c >> 9, rem = c & 511;
             const int n = rem >> 3, piece = rem & 7;  // 8 pieces of 16 B per 128-B row
-            *(uint4 *)(s_w[t] + n * ROWB + piece * 16) = wreg[u];
+            *(u32x4 *)(s_w[t] + n * ROWB + piece * 16) = wreg[u];
         }
     };
 
