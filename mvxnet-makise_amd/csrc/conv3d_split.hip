@@ -149,54 +149,110 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_split(const float *__res
         }
     };
 
-    for (int kd = 0; kd < 3 && active; ++kd) {
+    // Stages = (valid depth tap) x (32-channel chunk), software-pipelined like conv3d_gather_pf (conv3d.hip): the halo of
+    // stage s + 1 is fetched into registers while stage s computes (split into hi / lo when it is written to LDS), the
+    // weight rows go to LDS one kernel row at a time with the next row in flight, and the row needed next is always issued
+    // BEFORE the long-latency halo fetch (vector-memory returns are in order).
+    int kd_l[3] = {0, 0, 0}, ds_l[3] = {0, 0, 0}, nk = 0;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
         const int ds = src_depth(g, d, kd);
-        if (ds < 0) continue;
-        for (int cc = 0; cc < nchunks; ++cc) {
-            __syncthreads();
-            // ---- stage the halo, splitting f32 -> (hi, lo) bf16
+        if (ds >= 0) {
+            if (nk == 0) { kd_l[0] = kd; ds_l[0] = ds; }
+            else if (nk == 1) { kd_l[1] = kd; ds_l[1] = ds; }
+            else { kd_l[2] = kd; ds_l[2] = ds; }
+            ++nk;
+        }
+    }
+    const int nstages = active ? nk * nchunks : 0;
+    auto stage_of = [&](int st, int &kd, int &ds, int &cc) __attribute__((always_inline)) {
+        const int i = st / nchunks;
+        cc = st - i * nchunks;
+        kd = i == 0 ? kd_l[0] : (i == 1 ? kd_l[1] : kd_l[2]);
+        ds = i == 0 ? ds_l[0] : (i == 1 ? ds_l[1] : ds_l[2]);
+    };
+    int h_off[6], h_lds[6];     // per-thread halo slots: global float offset inside a (plane, chunk) image or -1; LDS byte offset or -1
 #pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                const int c = tid + 256 * u;
-                if (c < HH * HW * 8) {
-                    const int r = c >> 3, part = c & 7;
-                    const int gy = ty0 - 1 + r / HW, gx = tx0 - 1 + r % HW;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W)
-                        v = *(const float4 *)(in + (((size_t)ds * g.H + gy) * g.W + gx) * g.Cin + cc * BK + part * 4);
-                    uint2 hi, lo;
-                    split4(v, &hi, &lo);
-                    *(uint2 *)(s_halo + r * ROWB + part * 8) = hi;
-                    *(uint2 *)(s_halo + r * ROWB + 64 + part * 8) = lo;
-                }
+    for (int u = 0; u < 6; ++u) {
+        const int c = tid + 256 * u;
+        h_off[u] = -1;
+        h_lds[u] = -1;
+        if (c < HH * HW * 8) {
+            const int r = c >> 3, part = c & 7;
+            const int gy = ty0 - 1 + r / HW, gx = tx0 - 1 + r % HW;
+            h_lds[u] = r * ROWB + part * 8;
+            if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) h_off[u] = (gy * g.W + gx) * g.Cin + part * 4;
+        }
+    }
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 hreg[6];
+    auto load_halo = [&](int st) __attribute__((always_inline)) {
+        int kd, ds, cc;
+        stage_of(st, kd, ds, cc);
+        const float *img = in + (size_t)ds * g.H * g.W * g.Cin + cc * BK;
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+            hreg[u] = h_off[u] >= 0 ? *(const f32x4 *)(img + h_off[u]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto store_halo = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+            if (h_lds[u] >= 0) {
+                uint2 hi, lo;
+                split4(make_float4(hreg[u][0], hreg[u][1], hreg[u][2], hreg[u][3]), &hi, &lo);
+                *(uint2 *)(s_halo + h_lds[u]) = hi;
+                *(uint2 *)(s_halo + h_lds[u] + 64) = lo;
             }
-            load_w3(kd, 0, cc);
-            for (int a = 0; a < 3; ++a) {
-                if (a) __syncthreads();
-                store_w3();
-                __syncthreads();
-                if (a < 2) load_w3(kd, a + 1, cc);
+    };
+    auto load_wrow = [&](int st, int a) __attribute__((always_inline)) {
+        int kd, ds, cc;
+        stage_of(st, kd, ds, cc);
+        load_w3(kd, a, cc);
+    };
+    auto compute_row = [&](int a) __attribute__((always_inline)) {
 #pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    const int a_off = a_base + (a * HW + b) * ROWB;
+        for (int b = 0; b < 3; ++b) {
+            const int a_off = a_base + (a * HW + b) * ROWB;
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_halo + a_off + s * 32));
-                        const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_halo + a_off + 64 + s * 32));
-                        const bf16x8 b0h = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_w[b] + b_base + s * 32));
-                        const bf16x8 b0l = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_w[b] + b_base + 64 + s * 32));
-                        const bf16x8 b1h = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_w[b] + b_base + 32 * ROWB + s * 32));
-                        const bf16x8 b1l = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_w[b] + b_base + 32 * ROWB + 64 + s * 32));
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b0h, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b1h, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0l, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1l, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0h, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1h, acc1, 0, 0, 0);
-                    }
-                }
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_halo + a_off + s2 * 32));
+                const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_halo + a_off + 64 + s2 * 32));
+                const bf16x8 b0h = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_w[b] + b_base + s2 * 32));
+                const bf16x8 b0l = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_w[b] + b_base + 64 + s2 * 32));
+                const bf16x8 b1h = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_w[b] + b_base + 32 * ROWB + s2 * 32));
+                const bf16x8 b1l = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_w[b] + b_base + 32 * ROWB + 64 + s2 * 32));
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b0h, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b1h, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0l, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1l, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0h, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1h, acc1, 0, 0, 0);
             }
         }
+    };
+    if (nstages > 0) {
+        load_wrow(0, 0);
+        load_halo(0);
+    }
+    for (int st = 0; st < nstages; ++st) {
+        const int nxt = st + 1 < nstages ? st + 1 : st;      // unconditional prefetches: the last stage re-fetches and drops
+        __syncthreads();                                      // the previous stage's LDS reads are done
+        store_halo();
+        store_w3();                                           // kernel row 0
+        __syncthreads();
+        load_wrow(st, 1);                                     // next weight row first ...
+        load_halo(nxt);                                       // ... then the long-latency halo of the next stage
+        compute_row(0);
+        __syncthreads();
+        store_w3();                                           // kernel row 1
+        __syncthreads();
+        load_wrow(st, 2);
+        compute_row(1);
+        __syncthreads();
+        store_w3();                                           // kernel row 2
+        __syncthreads();
+        load_wrow(nxt, 0);
+        compute_row(2);
     }
 
     const int n0 = nb * BN + li, n1 = n0 + 32;

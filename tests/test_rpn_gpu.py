@@ -208,7 +208,9 @@ def test_rpn_bf16x3_mode_stays_within_the_feature_bar(golden):
     for k, p in rpn.named_parameters():
         ga, gb = a[off:off + p.numel()], b[off:off + p.numel()]
         off += p.numel()
-        assert rel(ga, gb) < 2e-1, k                            # (same loose bound as the f32 end-to-end check above)
+        # 2-norm, not max-norm: a handful of ReLU flips on the 8x12-site maps moves single weight-gradient entries by tens of
+        # per cent in either arithmetic (tools/rpn_diag.py); the gradient as a whole must agree
+        assert float((ga - gb).norm() / gb.norm().clamp_min(1e-30)) < 1e-1, k
 
 
 def test_rpn_full_size_maps_match_the_float64_oracle(golden):
