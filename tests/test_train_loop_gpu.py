@@ -189,3 +189,26 @@ def test_reference_checkpoint_keys_load_on_cpu(golden):
     ref_keys = set(str(n) for n in g['names']) | {k[len('backbone.'):] for k in O.PARAM_SHAPES if k.startswith('backbone.')}
     assert ref_keys == set(sd.keys())
     net.load_state_dict({k: torch.zeros_like(v) for k, v in sd.items()}, strict=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['numpy', 'torch'])
+def test_cropdata_like_on_8_synthetic_frames_matches_the_oracle(tmp_path, mode):
+    """BASELINE config 1 as a runnable thing: the reference's cropdata.py pass (crop + cropToSight per frame, written to
+    velodyne_croped/) on 8 synthetic KITTI frames through this package's kernels; every output file bit-identical to the
+    CPU oracle's numpy (float64) or torch (float32) path on the same raw cloud, points in their original order."""
+    sys.path.insert(0, PKG)
+    import cropdata_like
+    from modules.data import Load
+    root = str(tmp_path / 'kitti')
+    n, kept, dt = cropdata_like.main([root, mode, '--synthetic', '8', '--quiet'])
+    assert n == 8 and kept > 0
+    for i in range(8):
+        name = '%06d' % i
+        raw = np.fromfile(os.path.join(root, 'training/velodyne', name + '.bin'), dtype=np.float32).reshape(-1, 4)
+        calib = Load.readCalib(os.path.join(root, 'training/calib', name + '.txt'))
+        f32 = mode == 'torch'
+        ref = O.crop(raw, O.VELORANGE, bounds_f32=f32)
+        ref = O.crop_to_sight(ref, calib, (1224, 370), dtype=np.float32 if f32 else np.float64)
+        got = np.fromfile(os.path.join(root, 'training/velodyne_croped', name + '.bin'), dtype=np.float32).reshape(-1, 4)
+        assert got.shape == ref.shape and np.array_equal(got, ref.astype(np.float32)), name
