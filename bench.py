@@ -11,7 +11,8 @@ One step (--mode hot, the headline) = one batch of `--frames` synthetic frames P
   voxelizer -> ONE launch per layer for all frames (modules/frames.py): fusion sampling + fusion MLP + VFE stack +
   reindex + CML forward and the full backward (dL/d(middle) is a fixed resident tensor standing for RPN + loss) ->
   one flat gradient all-reduce over RCCL -> one AdamW step.
-Other modes (BASELINE.json configs): --mode vfe (config 2: voxelize + VFE stack forward/backward, 16 frames, voxel
+Other modes (BASELINE.json configs): --mode fusion (config 4: FPN feature sampling + fusion MLP + VFE, 2 frames),
+--mode vfe (config 2: voxelize + VFE stack forward/backward, 16 frames, voxel
 indices asserted bit-exact against the C oracle inside the run), --mode dropin (the nn.Module API: MVXNet.forward +
 VoxelLoss + autograd + AdamW, one frame at a time like train.py:110-164, RPN on MIOpen), --mode full (the WHOLE model
 of train.py:110-164 for B frames per step on this library's kernels: classifyAnchors, frame sets through fusion / VFE /
@@ -306,7 +307,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--mode', choices=['hot', 'vfe', 'dropin', 'full'], default='hot')
+    ap.add_argument('--mode', choices=['hot', 'vfe', 'fusion', 'dropin', 'full'], default='hot')
     ap.add_argument('--workload', choices=['S1', 'S2'], default='S2')
     ap.add_argument('--frames', type=int, default=None, help='frames per GPU per step (default 4; 16 in --mode vfe)')
     ap.add_argument('--points', type=int, default=20000)
@@ -319,7 +320,7 @@ def main():
     if args.timed_only:
         args.no_alt = args.no_cpu_baseline = True
     if args.frames is None:
-        args.frames = 16 if args.mode == 'vfe' else 4
+        args.frames = {'vfe': 16, 'fusion': 2}.get(args.mode, 4)
 
     from modules import parallel
     rank, world, local = parallel.init_from_env(os.environ.get('MVX_DIST_BACKEND'))
@@ -376,6 +377,17 @@ def main():
         from modules import frames as fr
         bucket.zero()
         nv, statuses, state['ready'] = pl.train_step_rows_only(model, batch, vfe_state, ready=state['ready'], prepare_next=batch)
+        bucket.all_reduce_mean(frames_total)
+        opt.step()
+        pending_status.extend(statuses)
+        return nv
+
+    def step_fusion(b=None):
+        """BASELINE config 4: PointFusion on -- crop + projection (KITTI calibration), voxelize, FPN feature sampling + fusion
+        MLP + VFE stack forward and backward, 2 frames per step; dL/d(voxel features) is a resident tensor."""
+        bucket.zero()
+        nv, statuses, state['ready'] = pl.train_step_rows_only(model, batch, vfe_state, ready=state['ready'], prepare_next=batch,
+                                                               with_fusion=True, imsize=imsize)
         bucket.all_reduce_mean(frames_total)
         opt.step()
         pending_status.extend(statuses)
@@ -451,7 +463,7 @@ def main():
         full['pending'] = out
         return out['voxels']
 
-    step = {'hot': step_hot, 'vfe': step_vfe, 'dropin': step_dropin, 'full': step_full}[args.mode]
+    step = {'hot': step_hot, 'vfe': step_vfe, 'fusion': step_fusion, 'dropin': step_dropin, 'full': step_full}[args.mode]
     host_ms, exec_stages, launches = [], [], []
 
     def timed_run(warmup, steps, fn=None):
@@ -589,6 +601,20 @@ def main():
                 roof['traffic'] = tj.get('conv3d_gather_pw_hbm_bytes_per_launch_r02', tj.get('conv3d_gather_pw_hbm_bytes_per_launch'))
                 roof['traffic_note'] = tj.get('note_r02', 'per launch of the round-1 single-frame form; see profiles/')
             metric = 'KITTI frames/sec (voxelize+VFE+fusion+3Dconv fwd+bwd)'
+        elif args.mode == 'fusion':
+            workload = ('%s, %d raw pts -> %d pts, T=35, %d frames/GPU/step: crop+cropToSight+lidar2Img (KITTI 2011_09_26 calibration), '
+                        'voxelize, FPN feature sampling (3 levels x 256 ch) + fusion MLP + VFE stack fwd+bwd, AdamW'
+                        % (wl, RAW_POINTS, args.points, args.frames))
+            ev = timers.get('hbm:feature_sample', [])
+            ms = sum(s.elapsed_time(e) for s, e, _ in ev)
+            tb = sum(float(b) for _, _, b in ev)
+            ach = tb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            roof = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS, 'traffic': None,
+                    'kernel': 'feature_sample_rows (bilinear FPN sampling of all frames of the step)', 'launches': len(ev),
+                    'avg_launch_ms': ms / max(1, len(ev)),
+                    'note': 'algorithmic bytes = 12 taps x 1 KiB gathered + 3 KiB written per real row (SURVEY.md 8d); the gathers hit '
+                            'L2 / MALL, so the figure can exceed what HBM alone would deliver'}
+            metric = 'KITTI frames/sec (voxelize + FPN feature sample + fusion MLP + VFE fwd+bwd)'
         elif args.mode == 'vfe':
             workload = ('%s, %d raw pts -> %d pts, T=35, %d frames/GPU/step: crop+cropToSight+lidar2Img, voxelize, VFE stack '
                         '(SVFE + FCN + max) fwd+bwd, AdamW; voxel indices bit-exact vs the C oracle (checked in this run: %s)'

@@ -338,11 +338,13 @@ def train_step_frame_set(model, batch, grad_mid, imsize, ready=None, prepare_nex
     return counts, statuses
 
 
-def train_step_rows_only(model, batch, state, ready=None, prepare_next=None):
+def train_step_rows_only(model, batch, state, ready=None, prepare_next=None, with_fusion=False, imsize=None):
     """BASELINE.json config 2 ("VFE-only"): crop + projection, voxelizer, then the VFE stack -- SVFE + FCN + max
     (voxelnet/Pipe.py:5-29, VoxelNet.py:27-33) -- forward and backward for all frames as one frame set.  The 16 fused image
     channels of every row and dL/d(voxel features) are resident random tensors (``state`` caches them) standing for the
-    fusion branch and for everything behind the VFE, which this configuration does not run."""
+    fusion branch and for everything behind the VFE, which this configuration does not run.
+    ``with_fusion`` (config 4, "PointFusion on: FPN feature sample + VFE"): the fusion branch is real -- bilinear sampling of
+    the frames' FPN maps at the projected points + the fusion MLP (imhead/Pipe.py:23-104), forward and backward."""
     from modules import frames as fr
     dev = batch.device
     main = torch.cuda.current_stream(dev)
@@ -369,7 +371,12 @@ def train_step_rows_only(model, batch, state, ready=None, prepare_next=None):
                 state['dfeat'] = (torch.randn((batch.n_frames * batch.cap_points, 128), generator=g) * 1e-3).to(dev)
             _hip.arena_begin(dev, doubles=1 << 21)
             with torch.no_grad():
-                feat, saved = fr.rows_forward(model, fs, None, None, [], imfeat=state['imfeat'][:fs.Rt + fs.F])
+                if with_fusion:
+                    statuses = [status]
+                    feat, saved = fr.rows_forward(model, fs, [batch.fpn_levels[f] for f in live], imsize, statuses)
+                    state['statuses'] = statuses
+                else:
+                    feat, saved = fr.rows_forward(model, fs, None, None, [], imfeat=state['imfeat'][:fs.Rt + fs.F])
                 fr.rows_backward(model, saved, state['dfeat'][:fs.Vt])
         if prepare_next is not None:
             if PREP_STREAM:
@@ -386,9 +393,10 @@ def train_step_rows_only(model, batch, state, ready=None, prepare_next=None):
         _hip.ASYNC_WGRAD = old_async
         _hip.arena_end()
         _hip.join_side_stream()
+    st_out = state.pop('statuses', [status])
     if prepare_next is not None:
-        return counts, [status], next_ready
-    return counts, [status]
+        return counts, st_out, next_ready
+    return counts, st_out
 
 
 # ---- whole model on the fast path: frame sets up to the BEV map, RPN + VoxelLoss per frame ------------------------------

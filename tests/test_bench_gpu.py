@@ -73,3 +73,14 @@ def test_bench_two_ranks_share_the_frames_and_print_one_line():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['config']['parallelism'] == 'dp2' and d['value'] > 0
     assert abs(d['value'] - 2 * 2 * d['steps'] / (d['ms_per_step'] * d['steps'] * 1e-3)) < 1e-6 * d['value']
+
+
+@pytest.mark.gpu
+def test_bench_fusion_mode_runs_config_4():
+    """--mode fusion (BASELINE config 4): FPN feature sampling + fusion MLP + VFE, 2 frames per step, HBM roofline of the sampler."""
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--mode', 'fusion', '--steps', '2', '--warmup', '1', '--points',
+                          '4000', '--no-cpu-baseline'], capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith('{')][0])
+    assert d['config']['mode'] == 'fusion' and d['config']['frames_per_gpu'] == 2 and d['value'] > 0
+    assert d['roofline']['bound'] == 'hbm' and d['roofline']['launches'] == 2 and 'feature_sample' in d['hbm_stages']
