@@ -178,3 +178,58 @@ def test_bench_path_matches_oracle_at_full_size():
         assert e_hip.max() < 1e-3, e_hip.max()
         assert max(gr.values()) < 3e-2, sorted(gr.items(), key=lambda t: -t[1])[:4]
     print(json.dumps(report))
+
+
+def test_whole_model_losses_match_oracle_at_full_size():
+    """The --mode full path (pipeline.train_step_full: frame sets up to the CML output, RPN and VoxelLoss on this library's
+    kernels) on one full-size S2 frame against the oracle run end to end in float64 from the voxels on: target lists
+    bit-identical to the C oracle's classifyAnchors, classification and regression loss within 1e-4 relative."""
+    import modules.config as cfg
+    import modules.pipeline as pl
+    from MVXNet import MVXNet
+    from modules import Calc, parallel
+    from modules.data import Preprocessing as pre
+    from modules.voxelnet import VoxelLoss
+    dev = torch.device('cuda')
+    batch, raw, kept, perms, fpn_cpu = _make_batch((0,), dev)
+    torch.manual_seed(0)
+    model = MVXNet().to(dev)
+    bucket = parallel.GradBucket([p for p in model.parameters() if p.requires_grad])
+    anchors = pre.createAnchors(cfg.voxelshape[0] // 2, cfg.voxelshape[1] // 2, cfg.velorange, cfg.carsize)
+    bevs = Calc.bbox3d2bev(anchors.reshape(anchors.shape[:2] + (-1, 7)))
+    gg = np.random.default_rng(11)
+    n = 8
+    gt = torch.tensor(np.stack([gg.uniform(8, 60, n), gg.uniform(-30, 30, n), gg.uniform(-1.8, -0.6, n), gg.uniform(3.4, 4.4, n),
+                                gg.uniform(1.5, 1.8, n), gg.uniform(1.4, 1.7, n),
+                                gg.choice([0.0, np.pi / 2], n) + gg.normal(0, 0.05, n)], 1), dtype=torch.float32)
+    gbev = Calc.bbox3d2bev(gt)
+    pi, ni, gi = Calc.classifyAnchors(gbev, gt[:, [0, 1]], bevs.to(dev).contiguous(), cfg.velorange, 0.45, 0.6)
+    rp, rn, rg = O.classify_anchors(O.bbox3d2bev(gt), gt[:, [0, 1]], O.bbox3d2bev(O.create_anchors(176, 200).reshape(176, 200, 2, 7)),
+                                    O.VELORANGE, 0.45, 0.6)
+    for a, b in zip(tuple(pi) + tuple(ni) + (gi,), tuple(rp) + tuple(rn) + (rg,)):
+        assert np.array_equal(a.cpu().numpy(), np.asarray(b)), 'anchor lists differ from the C oracle'
+    bucket.zero()
+    out = pl.train_step_full(model, batch, [(pi, ni, gi, gt.to(dev))], VoxelLoss(), anchors.to(dev), cfg.imsize)
+    torch.cuda.synchronize()
+    assert torch.isfinite(bucket.flat).all() and len(out['loss']) == 1 and len(out['reg']) == 1
+    # ---- the oracle, float64 from the voxels on (sampling positions in f32: see the test above)
+    points6, n_points = batch.prepared()
+    pts6 = points6.cpu().numpy()
+    rv, ri, _ = O.group(pts6[0], perms[0], O.VELORANGE, O.voxelsize(), 35)
+    V = rv.shape[0]
+    P64 = {k: v.detach().cpu().double() for k, v in model.state_dict().items()}
+    vox = torch.from_numpy(rv.astype(np.float32))
+    idx = torch.from_numpy(np.concatenate([np.zeros((V, 1), np.int64), ri.astype(np.int64)], 1))
+    with torch.no_grad():
+        imf = O.feature_mapping(vox, fpn_cpu[0], torch.tensor([370.0, 1224.0]))
+        imf64 = O.image_feature_fusion(imf.double(), P64, 'head.fusion.')
+        v23 = torch.cat([vox[..., :7].double(), imf64], dim=-1)
+        bb = O.strip_prefix(P64, 'backbone.')
+        mid = O.voxelnet_middle(v23, idx, bb)
+        score, reg = O.rpn(mid, bb)
+        cls, rl = O.voxel_loss(rp, rn, rg, gt.double(), score[0].permute(1, 2, 0), reg[0].permute(1, 2, 0),
+                               O.create_anchors(176, 200).double(), 2)
+    e_cls = abs(out['cls'][0] - float(cls)) / abs(float(cls))
+    e_reg = abs(out['reg'][0] - float(rl)) / abs(float(rl))
+    print('whole model at full size vs float64 oracle: clsLoss %.6f (rel %.1e), regLoss %.6f (rel %.1e)' % (out['cls'][0], e_cls, out['reg'][0], e_reg))
+    assert e_cls < 1e-4 and e_reg < 1e-4
