@@ -1,0 +1,46 @@
+"""How many executed (output tile, depth tap) stages of the conv2 / conv3 forward have a source halo WITHOUT an active site
+(their contribution is a per-plane constant)?  Developer diagnostic for the benchmark frames."""
+import os, sys
+import torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.argv = sys.argv[:1]
+sys.path.insert(0, os.path.join(REPO, 'mvxnet-makise_amd'))
+sys.path.insert(0, REPO)
+import bench  # noqa: E402
+import modules.config as cfg  # noqa: E402
+from modules import frames as fr, pipeline as pl, _hip  # noqa: E402
+from MVXNet import MVXNet  # noqa: E402
+dev = torch.device('cuda')
+torch.manual_seed(0)
+model = MVXNet().to(dev)
+for wl in ('S2', 'S1'):
+    batch = bench.make_batch([0, 1, 2, 3], dev, 20000, wl)
+    fs, live, counts, status = pl.prepare_frame_set(batch)
+    model.prepack()
+    _hip.arena_begin(dev, doubles=1 << 21)
+    with torch.no_grad():
+        feat, S = fr.rows_forward(model, fs, [batch.fpn_levels[f] for f in live], [370.0, 1224.0], [])
+        fr.cml_forward(model, fs, feat, S, [])
+    _hip.arena_end()
+    torch.cuda.synchronize()
+    F = fs.F
+    H, W = cfg.voxelshape[0], cfg.voxelshape[1]
+    ty, tx = (H + 7) // 8, (W + 15) // 16
+    border = torch.zeros((ty, tx), dtype=torch.bool, device=dev)
+    border[0, :] = border[-1, :] = True
+    border[:, 0] = border[:, -1] = True
+    border = border.reshape(-1)
+    for li, rec in enumerate(S.convs):
+        hf = rec['hflag_in'].view(F, rec['din'], -1) != 0
+        din, dout, sd, pd = rec['din'], rec['dout'], rec['sd'], rec['pd']
+        tot_exec = tot_inactive = tot_inactive_interior = 0
+        for d in range(dout):
+            taps = [d * sd - pd + kd for kd in range(3) if 0 <= d * sd - pd + kd < din]
+            act = torch.stack([hf[:, s] for s in taps], 0)            # [nk][F][tiles]
+            computed = act.any(0) | border[None]
+            tot_exec += int(computed.sum()) * len(taps)
+            inactive = (~act) & computed[None]
+            tot_inactive += int(inactive.sum())
+            tot_inactive_interior += int((inactive & ~border[None, None]).sum())
+        print('%s conv%d forward: executed stages (x chunks) %d, with an inactive source halo %d (%.1f %%), of those in interior tiles %d (%.1f %%)'
+              % (wl, li + 2, tot_exec, tot_inactive, 100.0 * tot_inactive / tot_exec, tot_inactive_interior, 100.0 * tot_inactive_interior / tot_exec))
