@@ -37,6 +37,9 @@ extern "C" {
 #define MVX_FLAG_ACCUMULATE 4  /* add the gradient to the destination instead of overwriting it */
 #define MVX_FLAG_CONV2D 8      /* mvx_conv3d_wgrad: dw is a 2-D kernel gradient [cout][cin][3][3] (din = dout = 1, pad_d = 1) */
 #define MVX_FLAG_TAPS2 16      /* mvx_conv2d_*: only the 2x2 tap window {0,1}^2 carries weight (stride-2 conv on the space-to-depth image) */
+#define MVX_FLAG_BG_TAPS 32    /* mvx_conv3d_forward_bg_frames: bg_pre is the buffer of mvx_conv3d_background_taps_frames ([planes][cout] totals
+                                  followed by [planes][3][cout] per-depth-tap constants); in interior tiles a depth tap whose source halo
+                                  holds no active site is then not executed, its constant is added in the epilogue (exact rewrite) */
 
 #define MVX_OK 0
 #define MVX_EINVAL (-1)   /* bad argument (null pointer, size, unsupported combination) */
@@ -264,6 +267,8 @@ int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int32_t din, i
 int mvx_activity_dilate(const void *src, int32_t src_is_index, int32_t din, int32_t dout, int32_t h, int32_t w,
                         int32_t stride_d, int32_t pad_d, int32_t mark_border, uint8_t *dst_mask,
                         int32_t *dst_halo_flags, int32_t *dst_tile_flags, void *stream);
+int mvx_conv3d_background_taps_frames(const float *w, const float *c_in, int32_t din, int32_t dout, int32_t cin, int32_t cout,
+                                      int32_t stride_d, int32_t pad_d, float *bg, int32_t n_frames, void *stream);
 int mvx_conv3d_background(const float *w, const float *c_in, int32_t din, int32_t dout, int32_t cin, int32_t cout,
                           int32_t stride_d, int32_t pad_d, float *bg_pre, void *stream);
 int mvx_bn_background(const float *bg_pre, const float *bias, const float *mean_inv, int32_t planes, int32_t channels,

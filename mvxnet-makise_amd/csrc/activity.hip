@@ -90,17 +90,25 @@ __global__ void tile_dilate_flags(const int *__restrict__ in, const int *__restr
 
 // bg_pre[d][n] = sum over the valid depth taps of plane d and all in-plane taps / channels of
 //                W[n][c][kd][a][b] * c_in[src(d,kd)][c]            (f64 accumulation, rounded once)
+// bg_tap (optional) [planes][3][Cout]: the same sum per depth tap (0 for a tap without a source plane) -- what a depth tap
+// contributes to an interior output site when every source site of its window is background.
 __global__ __launch_bounds__(64) void conv_background(const float *__restrict__ w, const float *__restrict__ c_in, int Din,
                                                       int Dout, int Cin, int Cout, int sd, int pd,
-                                                      float *__restrict__ bg_pre) {
+                                                      float *__restrict__ bg_pre, float *__restrict__ bg_tap) {
     const int n = blockIdx.x, d = blockIdx.y;        // one wave per (output channel, global plane); lanes over (c, tap)
     double s = 0.0;
     for (int kd = 0; kd < 3; ++kd) {
         const int ds = mvx_src_plane(d, Din, Dout, sd, pd, kd);
-        if (ds < 0) continue;
-        for (int e = threadIdx.x; e < Cin * 9; e += 64) {
-            const int c = e / 9, k = e - c * 9;
-            s += (double)w[(((size_t)n * Cin + c) * 3 + kd) * 9 + k] * (double)c_in[(size_t)ds * Cin + c];
+        double sk = 0.0;
+        if (ds >= 0)
+            for (int e = threadIdx.x; e < Cin * 9; e += 64) {
+                const int c = e / 9, k = e - c * 9;
+                sk += (double)w[(((size_t)n * Cin + c) * 3 + kd) * 9 + k] * (double)c_in[(size_t)ds * Cin + c];
+            }
+        s += sk;
+        if (bg_tap) {
+            sk = wave_sum_f64(sk);
+            if (threadIdx.x == 0) bg_tap[((size_t)d * 3 + kd) * Cout + n] = (float)sk;
         }
     }
     s = wave_sum_f64(s);
@@ -437,7 +445,20 @@ extern "C" int mvx_conv3d_background_frames(const float *w, const float *c_in, i
     MVX_CHECK_ARG(w && c_in && bg_pre && din > 0 && dout > 0 && cin > 0 && cout > 0);
     MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
     hipLaunchKernelGGL(conv_background, dim3(cout, dout * n_frames), dim3(64), 0, (hipStream_t)stream, w, c_in, din, dout, cin,
-                       cout, stride_d, pad_d, bg_pre);
+                       cout, stride_d, pad_d, bg_pre, (float *)nullptr);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+// bg f32 [planes][cout] totals followed by [planes][3][cout] per-depth-tap constants (planes = dout * n_frames): the buffer
+// mvx_conv3d_forward_bg_frames takes with MVX_FLAG_BG_TAPS
+extern "C" int mvx_conv3d_background_taps_frames(const float *w, const float *c_in, int32_t din, int32_t dout, int32_t cin,
+                                                 int32_t cout, int32_t stride_d, int32_t pad_d, float *bg, int32_t n_frames,
+                                                 void *stream) {
+    MVX_CHECK_ARG(w && c_in && bg && din > 0 && dout > 0 && cin > 0 && cout > 0);
+    MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
+    hipLaunchKernelGGL(conv_background, dim3(cout, dout * n_frames), dim3(64), 0, (hipStream_t)stream, w, c_in, din, dout, cin,
+                       cout, stride_d, pad_d, bg, bg + (size_t)dout * n_frames * cout);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

@@ -139,12 +139,23 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
 #pragma unroll
     for (int q = 0; q < BK / 8; ++q) b_off[q] = li * BK + 4 * (((2 * q) | lh) ^ wkey);
 
-    // valid depth taps of this output plane (block-uniform), packed as (kd, source plane) pairs
+    // valid depth taps of this output plane (block-uniform), packed as (kd, source plane) pairs.
+    // border_active bit 0: tiles on the image border always count as active (zero padding is not the background);
+    // bit 1: bg_pre is followed by per-depth-tap constants bg_tap[plane][kd][cout] -- in an INTERIOR tile a depth tap whose
+    // source halo holds no active site contributes exactly that constant (every source site is the plane's background
+    // value and the window stays inside the image), so it is not executed: `skipped` collects those taps for the epilogue.
+    const bool on_border = tx0 == 0 || ty0 == 0 || tx0 + TW >= g.W || ty0 + TH >= g.H;
+    const bool skip_taps = in_hflag && (border_active & 2) && !on_border;
     int kd_l[3] = {0, 0, 0}, ds_l[3] = {0, 0, 0}, nk = 0;
+    unsigned skipped = 0;
+    int any_flag = 0;
 #pragma unroll
     for (int kd = 0; kd < 3; ++kd) {
         const int ds = src_depth(g, d, kd);
         if (ds >= 0) {
+            const int fl = in_hflag ? in_hflag[(size_t)ds * ntiles + tile] : 1;
+            any_flag |= fl;
+            if (skip_taps && !fl) { skipped |= 1u << kd; continue; }
             if (nk == 0) { kd_l[0] = kd; ds_l[0] = ds; }
             else if (nk == 1) { kd_l[1] = kd; ds_l[1] = ds; }
             else { kd_l[2] = kd; ds_l[2] = ds; }
@@ -156,13 +167,7 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
     // Background tiles (see activity.hip): no non-background source site in the halo of any depth tap and the
     // window never leaves the image -> every output site of the tile is the per-plane constant.
     bool active = true;
-    if (in_hflag) {
-        int any = border_active && (tx0 == 0 || ty0 == 0 || tx0 + TW >= g.W || ty0 + TH >= g.H);
-        any |= nk > 0 ? in_hflag[(size_t)ds_l[0] * ntiles + tile] : 0;
-        any |= nk > 1 ? in_hflag[(size_t)ds_l[1] * ntiles + tile] : 0;
-        any |= nk > 2 ? in_hflag[(size_t)ds_l[2] * ntiles + tile] : 0;
-        active = any != 0;
-    }
+    if (in_hflag) active = (((border_active & 1) && on_border) || any_flag) != 0;
     if (exec_stages && active && threadIdx.x == 0) atomicAdd(exec_stages, (unsigned long long)nstages);   // executed work only
     if (active) {
     auto stage_kd = [&](int st, int &kd, int &ds, int &cc) __attribute__((always_inline)) {
@@ -290,6 +295,13 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
     // ---- epilogue: bias, ReLU, store, BatchNorm statistics (identical to conv3d_gather)
     const int n0 = nb * BN + li, n1 = n0 + 32;
     const float bias0 = bias ? bias[n0] : 0.f, bias1 = bias ? bias[n1] : 0.f;
+    float skip0 = 0.f, skip1 = 0.f;            // constants of the depth taps that were not executed (see the stage list)
+    if (skipped && active) {
+        const float *bg_tap = bg_pre + (size_t)g.Dout * g.F * g.Cout + (size_t)d * 3 * g.Cout;
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+            if ((skipped >> kd) & 1u) { skip0 += bg_tap[kd * g.Cout + n0]; skip1 += bg_tap[kd * g.Cout + n1]; }
+    }
     // background value of this plane: the same fp32 operations as a computed site, on the constant
     float bgv0 = (bg_pre ? bg_pre[(size_t)d * g.Cout + n0] : 0.f) + bias0, bgv1 = (bg_pre ? bg_pre[(size_t)d * g.Cout + n1] : 0.f) + bias1;
     if (relu) { bgv0 = fmaxf(bgv0, 0.f); bgv1 = fmaxf(bgv1, 0.f); }
@@ -315,7 +327,7 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int gy = ty0 + 2 * wv + (row >> 4), gx = tx0 + (row & 15);
-        float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
+        float v0 = (acc0[r] + skip0) + bias0, v1 = (acc1[r] + skip1) + bias1;
         if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
         // a background SITE holds the constant bit for bit, also inside a computed tile
         if (out_mask && !((site_on >> r) & 1u)) { v0 = bgv0; v1 = bgv1; }
@@ -993,7 +1005,8 @@ extern "C" int mvx_conv3d_forward_bg_frames(const float *in, const float *wpk, c
         }
     }
     Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0, n_frames};
-    launch_gather(st, in, wpk, bias, out, stats, g, flags & MVX_FLAG_RELU, in_halo_flags, out_mask, bg_pre, border_active,
+    launch_gather(st, in, wpk, bias, out, stats, g, flags & MVX_FLAG_RELU, in_halo_flags, out_mask, bg_pre,
+                  (border_active ? 1 : 0) | ((flags & MVX_FLAG_BG_TAPS) ? 2 : 0),
                   (unsigned long long *)exec_stages, nullptr, (unsigned *)done_counter, count, eps, mean_inv,
                   (unsigned *)work_counter);
     MVX_LAUNCH_CHECK();

@@ -10,6 +10,7 @@ VoxelizeResult = collections.namedtuple('VoxelizeResult', 'voxels coords counts 
 _ws_cache = {}
 STATS_REPLICAS = 32      # MVX_STATS_REPLICAS of include/mvx_hip.h
 FLAG_RELU, FLAG_PREZEROED, FLAG_ACCUMULATE, FLAG_CONV2D = 1, 2, 4, 8      # MVX_FLAG_* of include/mvx_hip.h
+FLAG_BG_TAPS = 32
 
 # When True, the backward of the hot-path layers adds weight / bias gradients straight into the existing
 # ``.grad`` buffers inside the reduction kernels (and returns None to autograd), instead of producing a

@@ -13,6 +13,7 @@ the reductions themselves.
 Weight-gradient kernels go to the side stream (modules/_hip.py), everything else stays on the caller's stream.
 """
 import ctypes
+import os
 
 import torch
 
@@ -83,6 +84,9 @@ class FrameSet:
 def _stats(F, C, dev):
     buf, fz = _hip._acc_f64((F, R, 2, C), dev)
     return buf, fz
+
+
+TAP_SKIP = os.environ.get('MVX_TAP_SKIP', '1') != '0'     # conv2 / conv3 forward: skip depth taps with a background-only source halo
 
 
 def linear_bn(x, w, b, fs, kind, row_w, eps):
@@ -284,9 +288,12 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
         sd, pd = m._sd, m._pd
         dout = _hip.conv_out_depth(din, sd, pd)
         wpk = m._packer(False, split)
-        bg_pre = torch.empty((F * dout, co), dtype=torch.float32, device=dev)
-        X.check(X.lib.mvx_conv3d_background_frames(X.ptr(w), X.ptr(c_in), din, dout, ci, co, sd, pd, X.ptr(bg_pre), F, X.stream()),
-                'mvx_conv3d_background_frames')
+        # background constants of this layer: [planes][co] totals, followed by the per-depth-tap ones the exact-f32 gather
+        # uses to skip the depth taps whose source halo holds no active site (TAP_SKIP)
+        bg_all = torch.empty((F * dout * 4, co), dtype=torch.float32, device=dev)
+        bg_pre = bg_all[:F * dout]
+        X.check(X.lib.mvx_conv3d_background_taps_frames(X.ptr(w), X.ptr(c_in), din, dout, ci, co, sd, pd, X.ptr(bg_all), F,
+                                                        X.stream()), 'mvx_conv3d_background_taps_frames')
         mask_o, hflag_o, tflag_o = dilate(mask_in, False, din, sd, pd, True)
         y = torch.empty((F * dout, H, W, co), dtype=torch.float32, device=dev)
         stats, fz = _stats(F, co, dev)
@@ -310,7 +317,8 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
         else:
           with _hip._Timed('conv3d_gather_bg', F * _hip.conv_flops(dout, din, H, W, ci, co, sd, pd) if _hip.KERNEL_TIMERS is not None else 0):
             X.check(X.lib.mvx_conv3d_forward_bg_frames(X.ptr(x_in), X.ptr(wpk), X.ptr(b), X.ptr(y), X.ptr(stats), din, dout, H, W,
-                                                       ci, co, sd, pd, _hip.FLAG_RELU | fz, X.ptr(hflag_in), X.ptr(mask_o),
+                                                       ci, co, sd, pd, _hip.FLAG_RELU | fz | (_hip.FLAG_BG_TAPS if TAP_SKIP else 0),
+                                                       X.ptr(hflag_in), X.ptr(mask_o),
                                                        X.ptr(bg_pre), 1, X.ptr(counter), X.ptr(fin), float(dout * H * W),
                                                        float(eps), X.ptr(mi), X.ptr(_hip._work_counter(dev)), F, X.stream()),
                     'mvx_conv3d_forward_bg_frames')
