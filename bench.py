@@ -513,9 +513,11 @@ def main():
                 'traffic': None, 'kernel': 'conv3d_gather_pw (conv2 / conv3 forward + dgrad of all frames of the step: 4 launches per step)',
                 'launches': len(ev), 'avg_launch_ms': ms / max(1, len(ev)), 'flop_per_launch': fl / max(1, len(ev)),
                 'dense_equivalent_tflops': dense_fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
-                'note': 'exact f32 MFMA (v_mfma_f32_32x32x2_f32); FLOPs are the EXECUTED ones counted by the kernel (tiles that '
-                        'hold only the voxel-free background are filled with a constant and not credited); measured while the '
-                        'side-stream weight-gradient kernels share the CUs'}
+                'note': 'exact f32 MFMA (v_mfma_f32_32x32x2_f32); FLOPs are the EXECUTED ones counted by the kernel: tiles that hold '
+                        'only the voxel-free background, depth taps whose source halo holds no voxel and idle image-border tiles are '
+                        'written from constants and not credited, while the time of filling them (about 60 % of the tiles of a launch) '
+                        'stays in the denominator; measured while the side-stream weight-gradient kernels share the CUs; `isolated` '
+                        '= the same kernel on dense launches alone'}
 
     def hbm_stages(tm):
         out = {}

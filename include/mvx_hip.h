@@ -37,9 +37,10 @@ extern "C" {
 #define MVX_FLAG_ACCUMULATE 4  /* add the gradient to the destination instead of overwriting it */
 #define MVX_FLAG_CONV2D 8      /* mvx_conv3d_wgrad: dw is a 2-D kernel gradient [cout][cin][3][3] (din = dout = 1, pad_d = 1) */
 #define MVX_FLAG_TAPS2 16      /* mvx_conv2d_*: only the 2x2 tap window {0,1}^2 carries weight (stride-2 conv on the space-to-depth image) */
-#define MVX_FLAG_BG_TAPS 32    /* mvx_conv3d_forward_bg_frames: bg_pre is the buffer of mvx_conv3d_background_taps_frames ([planes][cout] totals
-                                  followed by [planes][3][cout] per-depth-tap constants); in interior tiles a depth tap whose source halo
-                                  holds no active site is then not executed, its constant is added in the epilogue (exact rewrite) */
+#define MVX_FLAG_BG_TAPS 32    /* mvx_conv3d_forward_bg_frames: bg_pre is the buffer of mvx_conv3d_background_taps_frames ([planes][cout] totals |
+                                  [planes][3][cout] per-depth-tap constants | [planes][9][cout] image-border position classes): in interior
+                                  tiles a depth tap whose source halo holds no active site is not executed (its constant is added in the
+                                  epilogue), and a border tile without any active source is filled from the class constants (exact rewrites) */
 
 #define MVX_OK 0
 #define MVX_EINVAL (-1)   /* bad argument (null pointer, size, unsupported combination) */

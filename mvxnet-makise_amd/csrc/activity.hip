@@ -92,18 +92,35 @@ __global__ void tile_dilate_flags(const int *__restrict__ in, const int *__restr
 //                W[n][c][kd][a][b] * c_in[src(d,kd)][c]            (f64 accumulation, rounded once)
 // bg_tap (optional) [planes][3][Cout]: the same sum per depth tap (0 for a tap without a source plane) -- what a depth tap
 // contributes to an interior output site when every source site of its window is background.
+// bg_cls (optional) [planes][9][Cout]: the sum for an output site on the image border, class = 3 * ry + rx with
+// ry = 0 / 1 / 2 for the first / an inner / the last image row (rx likewise for columns): in-plane taps that fall outside the
+// image are dropped (zero padding), all source sites inside hold the background.
 __global__ __launch_bounds__(64) void conv_background(const float *__restrict__ w, const float *__restrict__ c_in, int Din,
                                                       int Dout, int Cin, int Cout, int sd, int pd,
-                                                      float *__restrict__ bg_pre, float *__restrict__ bg_tap) {
+                                                      float *__restrict__ bg_pre, float *__restrict__ bg_tap,
+                                                      float *__restrict__ bg_cls) {
     const int n = blockIdx.x, d = blockIdx.y;        // one wave per (output channel, global plane); lanes over (c, tap)
     double s = 0.0;
+    double cls[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) cls[q] = 0.0;
     for (int kd = 0; kd < 3; ++kd) {
         const int ds = mvx_src_plane(d, Din, Dout, sd, pd, kd);
         double sk = 0.0;
         if (ds >= 0)
             for (int e = threadIdx.x; e < Cin * 9; e += 64) {
-                const int c = e / 9, k = e - c * 9;
-                sk += (double)w[(((size_t)n * Cin + c) * 3 + kd) * 9 + k] * (double)c_in[(size_t)ds * Cin + c];
+                const int c = e / 9, k = e - c * 9, a = k / 3, b = k - a * 3;
+                const double t = (double)w[(((size_t)n * Cin + c) * 3 + kd) * 9 + k] * (double)c_in[(size_t)ds * Cin + c];
+                sk += t;
+                if (bg_cls) {
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) {
+                        const int ry = q / 3, rx = q - ry * 3;
+                        // tap row a reads source row gy + a - 1: outside for the first image row when a == 0, for the last when a == 2
+                        const bool inside = !(ry == 0 && a == 0) && !(ry == 2 && a == 2) && !(rx == 0 && b == 0) && !(rx == 2 && b == 2);
+                        if (inside) cls[q] += t;
+                    }
+                }
             }
         s += sk;
         if (bg_tap) {
@@ -113,6 +130,13 @@ __global__ __launch_bounds__(64) void conv_background(const float *__restrict__ 
     }
     s = wave_sum_f64(s);
     if (threadIdx.x == 0) bg_pre[(size_t)d * Cout + n] = (float)s;
+    if (bg_cls) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const double v = wave_sum_f64(cls[q]);
+            if (threadIdx.x == 0) bg_cls[((size_t)d * 9 + q) * Cout + n] = (float)v;
+        }
+    }
 }
 
 // y_bg = [ReLU](bg_pre + bias) and c_out = (y_bg - mean) * inv, with exactly the fp32 operations of the
@@ -445,20 +469,20 @@ extern "C" int mvx_conv3d_background_frames(const float *w, const float *c_in, i
     MVX_CHECK_ARG(w && c_in && bg_pre && din > 0 && dout > 0 && cin > 0 && cout > 0);
     MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
     hipLaunchKernelGGL(conv_background, dim3(cout, dout * n_frames), dim3(64), 0, (hipStream_t)stream, w, c_in, din, dout, cin,
-                       cout, stride_d, pad_d, bg_pre, (float *)nullptr);
+                       cout, stride_d, pad_d, bg_pre, (float *)nullptr, (float *)nullptr);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
 
-// bg f32 [planes][cout] totals followed by [planes][3][cout] per-depth-tap constants (planes = dout * n_frames): the buffer
-// mvx_conv3d_forward_bg_frames takes with MVX_FLAG_BG_TAPS
+// bg f32: [planes][cout] totals | [planes][3][cout] per-depth-tap constants | [planes][9][cout] image-border classes
+// (planes = dout * n_frames; 13 * planes * cout floats): the buffer mvx_conv3d_forward_bg_frames takes with MVX_FLAG_BG_TAPS
 extern "C" int mvx_conv3d_background_taps_frames(const float *w, const float *c_in, int32_t din, int32_t dout, int32_t cin,
                                                  int32_t cout, int32_t stride_d, int32_t pad_d, float *bg, int32_t n_frames,
                                                  void *stream) {
     MVX_CHECK_ARG(w && c_in && bg && din > 0 && dout > 0 && cin > 0 && cout > 0);
     MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
     hipLaunchKernelGGL(conv_background, dim3(cout, dout * n_frames), dim3(64), 0, (hipStream_t)stream, w, c_in, din, dout, cin,
-                       cout, stride_d, pad_d, bg, bg + (size_t)dout * n_frames * cout);
+                       cout, stride_d, pad_d, bg, bg + (size_t)dout * n_frames * cout, bg + (size_t)4 * dout * n_frames * cout);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

@@ -162,6 +162,11 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
             ++nk;
         }
     }
+    // ... and a BORDER tile without any active source site is not convolved either: its sites are the plane's background
+    // inside and, on the outermost ring, the background minus the taps that fall into the zero padding -- nine
+    // per-(plane, channel) constants by position class (bg_cls, after bg_tap in the buffer).
+    const bool idle_border = in_hflag && (border_active & 2) && on_border && !any_flag;
+    if (idle_border) nk = 0;
     const int nstages = nk * nchunks;
 
     // Background tiles (see activity.hip): no non-background source site in the halo of any depth tap and the
@@ -169,7 +174,7 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
     bool active = true;
     if (in_hflag) active = (((border_active & 1) && on_border) || any_flag) != 0;
     if (exec_stages && active && threadIdx.x == 0) atomicAdd(exec_stages, (unsigned long long)nstages);   // executed work only
-    if (active) {
+    if (active && nstages > 0) {
     auto stage_kd = [&](int st, int &kd, int &ds, int &cc) __attribute__((always_inline)) {
         const int i = st / nchunks;
         cc = st - i * nchunks;
@@ -295,6 +300,17 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
     // ---- epilogue: bias, ReLU, store, BatchNorm statistics (identical to conv3d_gather)
     const int n0 = nb * BN + li, n1 = n0 + 32;
     const float bias0 = bias ? bias[n0] : 0.f, bias1 = bias ? bias[n1] : 0.f;
+    if (idle_border) {                         // the accumulators are still zero: they take the position-class constants
+        const float *bg_cls = bg_pre + (size_t)4 * g.Dout * g.F * g.Cout + (size_t)d * 9 * g.Cout;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int gy = ty0 + 2 * wv + (row >> 4), gx = tx0 + (row & 15);
+            const int q = 3 * (gy == 0 ? 0 : (gy >= g.H - 1 ? 2 : 1)) + (gx == 0 ? 0 : (gx >= g.W - 1 ? 2 : 1));
+            acc0[r] = bg_cls[q * g.Cout + n0];
+            acc1[r] = bg_cls[q * g.Cout + n1];
+        }
+    }
     float skip0 = 0.f, skip1 = 0.f;            // constants of the depth taps that were not executed (see the stage list)
     if (skipped && active) {
         const float *bg_tap = bg_pre + (size_t)g.Dout * g.F * g.Cout + (size_t)d * 3 * g.Cout;

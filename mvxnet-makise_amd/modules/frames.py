@@ -290,7 +290,7 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
         wpk = m._packer(False, split)
         # background constants of this layer: [planes][co] totals, followed by the per-depth-tap ones the exact-f32 gather
         # uses to skip the depth taps whose source halo holds no active site (TAP_SKIP)
-        bg_all = torch.empty((F * dout * 4, co), dtype=torch.float32, device=dev)
+        bg_all = torch.empty((F * dout * 13, co), dtype=torch.float32, device=dev)      # totals | 3 depth taps | 9 border classes
         bg_pre = bg_all[:F * dout]
         X.check(X.lib.mvx_conv3d_background_taps_frames(X.ptr(w), X.ptr(c_in), din, dout, ci, co, sd, pd, X.ptr(bg_all), F,
                                                         X.stream()), 'mvx_conv3d_background_taps_frames')

@@ -33,7 +33,7 @@ for wl in ('S2', 'S1'):
     for li, rec in enumerate(S.convs):
         hf = rec['hflag_in'].view(F, rec['din'], -1) != 0
         din, dout, sd, pd = rec['din'], rec['dout'], rec['sd'], rec['pd']
-        tot_exec = tot_inactive = tot_inactive_interior = 0
+        tot_exec = tot_inactive = tot_inactive_interior = idle_border = 0
         for d in range(dout):
             taps = [d * sd - pd + kd for kd in range(3) if 0 <= d * sd - pd + kd < din]
             act = torch.stack([hf[:, s] for s in taps], 0)            # [nk][F][tiles]
@@ -42,5 +42,8 @@ for wl in ('S2', 'S1'):
             inactive = (~act) & computed[None]
             tot_inactive += int(inactive.sum())
             tot_inactive_interior += int((inactive & ~border[None, None]).sum())
-        print('%s conv%d forward: executed stages (x chunks) %d, with an inactive source halo %d (%.1f %%), of those in interior tiles %d (%.1f %%)'
-              % (wl, li + 2, tot_exec, tot_inactive, 100.0 * tot_inactive / tot_exec, tot_inactive_interior, 100.0 * tot_inactive_interior / tot_exec))
+            idle_border += int((border[None] & ~act.any(0)).sum()) * len(taps)      # border tiles computed without any active source
+        print('%s conv%d forward: executed stages (x chunks) %d, with an inactive source halo %d (%.1f %%), of those in interior tiles %d (%.1f %%); '
+              'stages of border tiles without any active source %d (%.1f %%)'
+              % (wl, li + 2, tot_exec, tot_inactive, 100.0 * tot_inactive / tot_exec, tot_inactive_interior, 100.0 * tot_inactive_interior / tot_exec,
+                 idle_border, 100.0 * idle_border / tot_exec))
