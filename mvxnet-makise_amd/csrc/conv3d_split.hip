@@ -103,20 +103,26 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_split(const float *__res
     const int nchunks = g.Cin / BK;
     // background rewrite (see conv3d.hip / activity.hip): restricted launches and constant tiles
     if (only_tiles && !only_tiles[(size_t)d * gridDim.x + blockIdx.x]) return;
+    // border_active bit 0: border tiles always count as active; bit 1: bg_pre carries the per-depth-tap and position-class
+    // constants (see gather_unit in conv3d.hip): interior tiles skip depth taps with a background-only source halo, border
+    // tiles without any active source are filled from the class constants
+    const bool on_border = tx0 == 0 || ty0 == 0 || tx0 + TW >= g.W || ty0 + TH >= g.H;
+    const bool skip_taps = in_hflag && (border_active & 2) && !on_border;
+    unsigned skipped = 0;
+    int any_flag = 0;
     bool active = true;
     if (in_hflag) {
-        int any = border_active && (tx0 == 0 || ty0 == 0 || tx0 + TW >= g.W || ty0 + TH >= g.H);
         for (int kd = 0; kd < 3; ++kd) {
             const int ds = src_depth(g, d, kd);
-            if (ds >= 0) any |= in_hflag[(size_t)ds * gridDim.x + blockIdx.x];
+            if (ds >= 0) {
+                const int fl = in_hflag[(size_t)ds * gridDim.x + blockIdx.x];
+                any_flag |= fl;
+                if (skip_taps && !fl) skipped |= 1u << kd;
+            }
         }
-        active = any != 0;
+        active = (((border_active & 1) && on_border) || any_flag) != 0;
     }
-    if (exec_stages && active && threadIdx.x == 0) {              // executed (depth tap, 32-channel chunk) stages only
-        int nk = 0;
-        for (int kd = 0; kd < 3; ++kd) nk += src_depth(g, d, kd) >= 0;
-        atomicAdd(exec_stages, (unsigned long long)(nk * nchunks));
-    }
+    const bool idle_border = in_hflag && (border_active & 2) && on_border && !any_flag;
 
     f32x16 acc0, acc1;
 #pragma unroll
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_split(const float *__res
 #pragma unroll
     for (int kd = 0; kd < 3; ++kd) {
         const int ds = src_depth(g, d, kd);
-        if (ds >= 0) {
+        if (ds >= 0 && !((skipped >> kd) & 1u) && !idle_border) {
             if (nk == 0) { kd_l[0] = kd; ds_l[0] = ds; }
             else if (nk == 1) { kd_l[1] = kd; ds_l[1] = ds; }
             else { kd_l[2] = kd; ds_l[2] = ds; }
@@ -165,6 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_split(const float *__res
         }
     }
     const int nstages = active ? nk * nchunks : 0;
+    if (exec_stages && nstages > 0 && threadIdx.x == 0) atomicAdd(exec_stages, (unsigned long long)nstages);    // executed stages only
     auto stage_of = [&](int st, int &kd, int &ds, int &cc) __attribute__((always_inline)) {
         const int i = st / nchunks;
         cc = st - i * nchunks;
@@ -257,6 +264,24 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_split(const float *__res
 
     const int n0 = nb * BN + li, n1 = n0 + 32;
     const float bias0 = bias ? bias[n0] : 0.f, bias1 = bias ? bias[n1] : 0.f;
+    if (idle_border) {                         // the accumulators are still zero: they take the position-class constants
+        const float *bg_cls = bg_pre + (size_t)4 * g.Dout * g.F * g.Cout + (size_t)d * 9 * g.Cout;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int gy = ty0 + 2 * wv + (row >> 4), gx = tx0 + (row & 15);
+            const int q = 3 * (gy == 0 ? 0 : (gy >= g.H - 1 ? 2 : 1)) + (gx == 0 ? 0 : (gx >= g.W - 1 ? 2 : 1));
+            acc0[r] = bg_cls[q * g.Cout + n0];
+            acc1[r] = bg_cls[q * g.Cout + n1];
+        }
+    }
+    float skip0 = 0.f, skip1 = 0.f;            // constants of the depth taps that were not executed
+    if (skipped && active) {
+        const float *bg_tap = bg_pre + (size_t)g.Dout * g.F * g.Cout + (size_t)d * 3 * g.Cout;
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+            if ((skipped >> kd) & 1u) { skip0 += bg_tap[kd * g.Cout + n0]; skip1 += bg_tap[kd * g.Cout + n1]; }
+    }
     float bgv0 = (bg_pre ? bg_pre[(size_t)d * g.Cout + n0] : 0.f) + bias0, bgv1 = (bg_pre ? bg_pre[(size_t)d * g.Cout + n1] : 0.f) + bias1;
     if (relu) { bgv0 = fmaxf(bgv0, 0.f); bgv1 = fmaxf(bgv1, 0.f); }
     // site-mask bytes fetched up front (see conv3d.hip: a load between the stores made every store pair wait)
@@ -278,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_split(const float *__res
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int gy = ty0 + 2 * wv + (row >> 4), gx = tx0 + (row & 15);
-        float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
+        float v0 = (acc0[r] + skip0) + bias0, v1 = (acc1[r] + skip1) + bias1;
         if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
         if (out_mask && !((site_on >> r) & 1u)) { v0 = bgv0; v1 = bgv1; }
         if (gy < g.H && gx < g.W) {
@@ -545,7 +570,8 @@ extern "C" int mvx_conv3d_forward_bg_split_frames(const float *in, const void *w
     Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0, n_frames};
     hipLaunchKernelGGL(conv3d_gather_split, dim3(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), dout * n_frames, cout / BN), dim3(256), 0, st,
                        in, (const unsigned short *)wsplit, bias, out, stats, g, flags & MVX_FLAG_RELU, in_halo_flags, out_mask,
-                       bg_pre, border_active, (const int *)nullptr, (unsigned long long *)exec_stages);
+                       bg_pre, (border_active ? 1 : 0) | ((flags & MVX_FLAG_BG_TAPS) ? 2 : 0), (const int *)nullptr,
+                       (unsigned long long *)exec_stages);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

@@ -309,8 +309,10 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
         if split:
             with _hip._Timed('conv3d_gather_bg', F * _hip.conv_flops(dout, din, H, W, ci, co, sd, pd) if _hip.KERNEL_TIMERS is not None else 0):
                 X.check(X.lib.mvx_conv3d_forward_bg_split_frames(X.ptr(x_in), X.ptr(wpk), X.ptr(b), X.ptr(y), X.ptr(stats), din, dout,
-                                                                 H, W, ci, co, sd, pd, _hip.FLAG_RELU | fz, X.ptr(hflag_in),
-                                                                 X.ptr(mask_o), X.ptr(bg_pre), 1, X.ptr(counter), F, X.stream()),
+                                                                 H, W, ci, co, sd, pd,
+                                                                 _hip.FLAG_RELU | fz | (_hip.FLAG_BG_TAPS if TAP_SKIP else 0),
+                                                                 X.ptr(hflag_in), X.ptr(mask_o), X.ptr(bg_pre), 1, X.ptr(counter), F,
+                                                                 X.stream()),
                         'mvx_conv3d_forward_bg_split_frames')
             X.check(X.lib.mvx_bn_finalize_frames(X.ptr(stats), float(dout * H * W), float(eps), X.ptr(mi), co, F, X.stream()),
                     'mvx_bn_finalize_frames')
