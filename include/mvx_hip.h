@@ -268,6 +268,11 @@ int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int32_t din, i
 int mvx_activity_dilate(const void *src, int32_t src_is_index, int32_t din, int32_t dout, int32_t h, int32_t w,
                         int32_t stride_d, int32_t pad_d, int32_t mark_border, uint8_t *dst_mask,
                         int32_t *dst_halo_flags, int32_t *dst_tile_flags, void *stream);
+/* BatchNorm apply of a layer output with a background: (y - mean) * inv on the tiles whose flag is set (tiles as
+ * mvx_conv3d_tile_shape, flags i32 [n_frames * planes][tiles]), the normalised background constant c_bg f32
+ * [n_frames * planes][channels] (mvx_bn_background) everywhere else, without reading y there.  Bit-identical to mvx_bn_apply. */
+int mvx_bn_apply_tiles_frames(const float *y, const float *mean_inv, const float *c_bg, const int32_t *tile_flags, float *out,
+                              int32_t planes, int32_t h, int32_t w, int32_t channels, int32_t n_frames, void *stream);
 int mvx_conv3d_background_taps_frames(const float *w, const float *c_in, int32_t din, int32_t dout, int32_t cin, int32_t cout,
                                       int32_t stride_d, int32_t pad_d, float *bg, int32_t n_frames, void *stream);
 int mvx_conv3d_background(const float *w, const float *c_in, int32_t din, int32_t dout, int32_t cin, int32_t cout,

@@ -153,6 +153,33 @@ __global__ void bn_background(const float *__restrict__ bg_pre, const float *__r
     c_out[e] = (v - mi[c]) * mi[C + c];
 }
 
+// ---- BatchNorm apply with the background: out = (y - mean) * inv on the tiles that hold a non-background site, the
+// plane's normalised background constant c_bg[plane][c] everywhere else WITHOUT reading y there (bit-identical to bn_apply:
+// c_bg is formed with the same fp32 operations, see bn_background).  One workgroup per (tile, plane).
+__global__ __launch_bounds__(256) void bn_apply_tiles(const float *__restrict__ y, const float *__restrict__ mi,
+                                                      const float *__restrict__ c_bg, const int *__restrict__ tile_flags,
+                                                      float *__restrict__ out, int D, int H, int W, int C, int ntiles) {
+    const int tiles_x = (W + ATW - 1) / ATW;
+    const int t = blockIdx.x, d = blockIdx.y, frame = d / D;
+    const int c4n = C >> 2, ct = threadIdx.x % c4n, st = threadIdx.x / c4n, spb = 256 / c4n;
+    const int ty0 = (t / tiles_x) * ATH, tx0 = (t % tiles_x) * ATW;
+    const bool on = tile_flags[(size_t)d * ntiles + t] != 0;          // block-uniform
+    const float4 cb = *(const float4 *)(c_bg + (size_t)d * C + ct * 4);
+    const float *fmi = mi + (size_t)frame * 2 * C;
+    const float4 m = *(const float4 *)(fmi + ct * 4), iv = *(const float4 *)(fmi + C + ct * 4);
+    for (int sidx = st; sidx < ATH * ATW; sidx += spb) {
+        const int gy = ty0 + sidx / ATW, gx = tx0 + sidx % ATW;
+        if (gy >= H || gx >= W) continue;
+        const size_t off = (((size_t)d * H + gy) * W + gx) * C + ct * 4;
+        float4 o = cb;
+        if (on) {
+            const float4 v = *(const float4 *)(y + off);
+            o = make_float4((v.x - m.x) * iv.x, (v.y - m.y) * iv.y, (v.z - m.z) * iv.z, (v.w - m.w) * iv.w);
+        }
+        *(float4 *)(out + off) = o;
+    }
+}
+
 // ---- BatchNorm + ReLU backward restricted to the active tiles of a layer output -----------------------
 // Outside the active tiles every site holds the background (y = y_bg[d], yhat = c[d]); its share of the
 // batch sums follows from A[d][c] = sum over plane d of the incoming gradient (closed form, see
@@ -498,6 +525,19 @@ extern "C" int mvx_bn_background_frames(const float *bg_pre, const float *bias, 
     MVX_CHECK_ARG(mean_inv && c_out && planes > 0 && channels > 0 && n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
     hipLaunchKernelGGL(bn_background, dim3(mvx_cdiv((long long)n_frames * planes * channels, 256)), dim3(256), 0,
                        (hipStream_t)stream, bg_pre, bias, mean_inv, planes, channels, flags & MVX_FLAG_RELU, y_bg, c_out, n_frames);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+extern "C" int mvx_bn_apply_tiles_frames(const float *y, const float *mean_inv, const float *c_bg, const int32_t *tile_flags,
+                                         float *out, int32_t planes, int32_t h, int32_t w, int32_t channels, int32_t n_frames,
+                                         void *stream) {
+    MVX_CHECK_ARG(y && mean_inv && c_bg && tile_flags && out && planes > 0 && h > 0 && w > 0);
+    MVX_CHECK_ARG(channels > 0 && channels % 4 == 0 && channels <= 1024 && 256 % (channels / 4) == 0);
+    MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
+    const int ntiles = (int)(mvx_cdiv(w, ATW) * mvx_cdiv(h, ATH));
+    hipLaunchKernelGGL(bn_apply_tiles, dim3(ntiles, planes * n_frames), dim3(256), 0, (hipStream_t)stream, y, mean_inv, c_bg,
+                       (const int *)tile_flags, out, planes, h, w, channels, ntiles);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

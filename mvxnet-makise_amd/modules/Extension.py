@@ -129,6 +129,7 @@ PROTOTYPES = {
     'mvx_activity_dilate_frames': (_i32, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p]),
     'mvx_tile_dilate_flags_frames': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i32, _p]),
     'mvx_conv3d_background_frames': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i32, _p]),
+    'mvx_bn_apply_tiles_frames': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_conv3d_background_taps_frames': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i32, _p]),
     'mvx_bn_background_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p]),
     'mvx_conv3d_forward_bg_frames': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p,

@@ -251,7 +251,6 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
     mi1 = torch.empty((F, 2, cout), dtype=torch.float32, device=dev)
     X.check(X.lib.mvx_bn_finalize_frames(X.ptr(stats), float(D1 * H * W), float(eps), X.ptr(mi1), cout, F, X.stream()),
             'mvx_bn_finalize_frames')
-    x1 = bn_apply(y1, mi1, fs, X.ROWS_GRID)
     ntl = _hip.n_tiles(H, W)
 
     def dilate(src, is_index, din, sd, pd, border):
@@ -270,8 +269,21 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
                                                X.ptr(c_out), F, X.stream()), 'mvx_bn_background_frames')
         return c_out, y_bg
 
+    def bn_apply_bg(y, mi, c_bg, tflag, planes):
+        """BatchNorm apply of a layer output with a background: tiles without a non-background site take the normalised
+        constant without being read (bit-identical to bn_apply)."""
+        out = torch.empty_like(y)
+        Cn = y.shape[-1]
+        # algorithmic bytes (timing runs only): flagged tiles are read and written, the others only written
+        nbytes = (tflag.ne(0).sum() + tflag.numel()) * (128 * Cn * 4) if _hip.KERNEL_TIMERS is not None else 0
+        with _hip._timed_bytes('bn_apply', nbytes):
+            X.check(X.lib.mvx_bn_apply_tiles_frames(X.ptr(y), X.ptr(mi), X.ptr(c_bg), X.ptr(tflag), X.ptr(out), planes, H, W, Cn, F,
+                                                    X.stream()), 'mvx_bn_apply_tiles_frames')
+        return out
+
     mask1, hflag1, tflag1 = dilate(idx_grid, True, D0, c1._sd, c1._pd, False)
     cc1, ybg1 = background(None, b1, mi1, D1, cout)
+    x1 = bn_apply_bg(y1, mi1, cc1, tflag1, D1)
     S.conv1 = dict(feat=feat, w=w1, b=b1, w_all=w_all, y=y1, mi=mi1, c=cc1, ybg=ybg1, tflag=tflag1, D0=D0, D1=D1)
 
     # ---- conv2, conv3 on the MFMA gather kernel with the background rewrite (voxelnet/Pipe.py:37-42)
@@ -324,12 +336,12 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
                                                        X.ptr(bg_pre), 1, X.ptr(counter), X.ptr(fin), float(dout * H * W),
                                                        float(eps), X.ptr(mi), X.ptr(_hip._work_counter(dev)), F, X.stream()),
                     'mvx_conv3d_forward_bg_frames')
-        x_out = bn_apply(y, mi, fs, X.ROWS_GRID)
+        c_o, ybg_o = background(bg_pre, b, mi, dout, co)         # the background of this layer's output
+        x_out = bn_apply_bg(y, mi, c_o, tflag_o, dout)
         rec = dict(x=x_in, w=w, b=b, y=y, mi=mi, din=din, dout=dout, sd=sd, pd=pd, m=m, c_in=c_in, hflag_in=hflag_in,
                    bflag_in=bflag_in, split=split)
         if li == 0:
-            # the background of this layer's output and the tiles its own restricted backward touches
-            c_o, ybg_o = background(bg_pre, b, mi, dout, co)
+            # the tiles this layer's own restricted backward touches
             bflag_o = torch.empty((F * dout, ntl), dtype=torch.int32, device=dev)
             X.check(X.lib.mvx_tile_dilate_flags_frames(X.ptr(tflag_in), X.ptr(tflag_o), din, dout, H, W, sd, pd, X.ptr(bflag_o), F,
                                                        X.stream()), 'mvx_tile_dilate_flags_frames')
