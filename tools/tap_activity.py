@@ -13,7 +13,7 @@ from MVXNet import MVXNet  # noqa: E402
 dev = torch.device('cuda')
 torch.manual_seed(0)
 model = MVXNet().to(dev)
-for wl in ('S2', 'S1'):
+for wl in ('S1', 'S2'):
     batch = bench.make_batch([0, 1, 2, 3], dev, 20000, wl)
     fs, live, counts, status = pl.prepare_frame_set(batch)
     model.prepack()
@@ -47,3 +47,25 @@ for wl in ('S2', 'S1'):
               'stages of border tiles without any active source %d (%.1f %%)'
               % (wl, li + 2, tot_exec, tot_inactive, 100.0 * tot_inactive / tot_exec, tot_inactive_interior, 100.0 * tot_inactive_interior / tot_exec,
                  idle_border, 100.0 * idle_border / tot_exec))
+
+# ---- weight-gradient step lists: entries per depth tap vs the share of workgroups each tap gets (by plane count)
+print('weight-gradient lists (last workload): steps per depth tap, and steps per workgroup with the plane-count shares')
+for li, rec in enumerate(S.convs):
+    hf = rec['hflag_in'].view(F, rec['din'], -1) != 0
+    din, dout, sd, pd = rec['din'], rec['dout'], rec['sd'], rec['pd']
+    counts, nd = [], []
+    for kd in range(3):
+        c = 0
+        n = 0
+        for d in range(dout):
+            s_ = d * sd - pd + kd
+            if 0 <= s_ < din:
+                c += int(hf[:, s_].sum())
+                n += 1
+        counts.append(c)
+        nd.append(n)
+    chunks = rec['w'].shape[1] // 64
+    nstrips = max(1, 128 // chunks)
+    shares = [min(nstrips, max(1, (2 * nstrips * n) // max(1, sum(nd)))) for n in nd]
+    per = [c / s_ for c, s_ in zip(counts, shares)]
+    print('  conv%d: steps %s, shares %s -> steps per workgroup %s (ideal %.1f)' % (li + 2, counts, shares, ['%.1f' % p for p in per], sum(counts) / sum(shares)))
