@@ -183,6 +183,17 @@ def _timed_bytes(name, nbytes):
     return _Timed('hbm:' + name, nbytes if isinstance(nbytes, torch.Tensor) else float(nbytes))
 
 
+def require_plain_batchnorm():
+    """The kernels normalise with (mean, 1/sqrt(var + eps)) of the batch only -- the reference's configuration
+    (config.yml:19-20: bnaffine False, bntrack False; Blocks.py:10,25).  With affine parameters or running statistics
+    switched on, bn.weight / bn.bias would enter the optimizer with permanently zero gradients and the running buffers
+    would never move, silently: refuse instead."""
+    import modules.config as cfg
+    if bool(cfg.config.get('bnaffine', False)) or bool(cfg.config.get('bntrack', False)):
+        raise X.MvxHipError('bnaffine / bntrack are not supported by the HIP BatchNorm kernels (batch statistics, no affine '
+                            'parameters, no running buffers: the reference\'s config.yml:19-20); set both to False')
+
+
 def conv_flops(d_out_planes, d_src_planes, H, W, cin, cout, sd, pd, dgrad=False):
     """Executed multiply-add FLOPs of one gather launch: depth taps that fall outside the source
     volume are skipped by the kernel and are NOT counted (in-plane zero padding is computed and

@@ -157,6 +157,7 @@ def rows_forward(model, fs, fpn_levels, imsize, status_sink, imfeat=None):
     head, bb = model.head, model.backbone
     dev = fs.voxels.device
     F, T, Rt, Vt = fs.F, fs.T, fs.Rt, fs.Vt
+    _hip.require_plain_batchnorm()
     S = _Saved()
     S.fs = fs
     eps = cfg.eps
@@ -229,6 +230,7 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
     dev = fs.voxels.device
     F, T, Rt, Vt = fs.F, fs.T, fs.Rt, fs.Vt
     eps = cfg.eps
+    _hip.require_plain_batchnorm()
     # ---- reindex + conv1 through the voxel-GEMM factorisation (VoxelNet.py:16-22, voxelnet/Pipe.py:36)
     D0, H, W = cfg.voxelshape[2], cfg.voxelshape[0], cfg.voxelshape[1]
     c1, c2, c3 = bb.cml.conv1, bb.cml.conv2, bb.cml.conv3

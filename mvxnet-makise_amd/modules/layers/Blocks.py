@@ -59,6 +59,7 @@ class FCN(nn.Module):
 
     def __init__(self, cin, cout):
         super().__init__()
+        _hip.require_plain_batchnorm()
         self.fc = nn.Linear(cin, cout)
         self.bn = nn.BatchNorm2d(cout, eps=cfg.eps, affine=cfg.bnaffine, track_running_stats=cfg.bntrack)
 
@@ -247,6 +248,7 @@ class CRB3d(nn.Module):
 
     def __init__(self, cin, cout, k, s, p):
         super().__init__()
+        _hip.require_plain_batchnorm()
         self.conv = nn.Conv3d(cin, cout, k, s, p)
         self.bn = nn.BatchNorm3d(cout, eps=cfg.eps, affine=cfg.bnaffine, track_running_stats=cfg.bntrack)
         k3, s3, p3 = _triple(k), _triple(s), _triple(p)
@@ -351,6 +353,7 @@ class CRB2d(nn.Module):
 
     def __init__(self, cin, cout, k, s, p):
         super().__init__()
+        _hip.require_plain_batchnorm()
         self.conv = nn.Conv2d(cin, cout, k, s, p)
         self.bn = nn.BatchNorm2d(cout, eps=cfg.eps, affine=cfg.bnaffine, track_running_stats=cfg.bntrack)
         self._pointwise = (k == 1 and s == 1 and p == 0)
@@ -377,6 +380,7 @@ class DeCRB2d(nn.Module):
 
     def __init__(self, cin, cout, k, s, p):
         super().__init__()
+        _hip.require_plain_batchnorm()
         self.deconv = nn.ConvTranspose2d(cin, cout, k, s, p)
         self.bn = nn.BatchNorm2d(cout, eps=cfg.eps, affine=cfg.bnaffine, track_running_stats=cfg.bntrack)
         self._hip3x3 = (k == 3 and s == 1 and p == 1 and cin % 64 == 0 and cout % 64 == 0)

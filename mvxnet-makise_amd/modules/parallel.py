@@ -31,6 +31,17 @@ def shard_frames(n_frames_total, rank, world):
     return list(range(rank, n_frames_total, world))
 
 
+def global_count(n_local, device=None):
+    """Sum of a per-rank count over all ranks (at least 1): the divisor of a step whose ranks contributed different
+    numbers of frames (a short last chunk of an epoch, frames without voxels)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dev = device if (device is not None and dist.get_backend() == 'nccl') else torch.device('cpu')
+        t = torch.tensor([float(n_local)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        n_local = int(round(float(t)))
+    return max(1, int(n_local))
+
+
 class GradBucket:
     """Flat view over the gradients of the trainable parameters that took part in the step."""
 

@@ -213,6 +213,7 @@ def rpn_forward(rpn, x_cl, F, planes, H, W, Cp):
     Returns (heads (F*H/2*W/2, 16) = [cls logits (2) | reg (14)] per BEV cell, saved state)."""
     dev = x_cl.device
     eps = cfg.eps
+    _hip.require_plain_batchnorm()
     pk = _packs_of(rpn)
     S = {'F': F, 'geom': (planes, H, W, Cp), 'blocks': []}
     x, h, w, C, pl = x_cl, H, W, Cp, planes

@@ -77,6 +77,12 @@ def cputask(data, anchorBevs, cfg):
     return voxel, idx, img, bbox3d, bev, pi, ni, gi, calib
 
 
+def fast_chunks(n_frames, frames_per_rank, world):
+    """[lo, hi) frame ranges of the global steps of one epoch in --mode fast: the same list on every rank."""
+    stride = frames_per_rank * world
+    return [(lo, min(n_frames, lo + stride)) for lo in range(0, n_frames, stride)]
+
+
 def train(args):
     import modules.config as cfg
     from modules import parallel
@@ -112,8 +118,8 @@ def train(args):
     imsize = torch.Tensor(cfg.imsize).to(device)
     os.makedirs(args.checkpoints, exist_ok=True)
     if args.lastiter > 0:
-        model.load_state_dict(torch.load(os.path.join(args.checkpoints, 'epoch%d.pkl' % args.lastiter)))
-        opt.load_state_dict(torch.load(os.path.join(args.checkpoints, 'epoch%d_opt.pkl' % args.lastiter)))
+        model.load_state_dict(torch.load(os.path.join(args.checkpoints, 'epoch%d.pkl' % args.lastiter), map_location=device))
+        opt.load_state_dict(torch.load(os.path.join(args.checkpoints, 'epoch%d_opt.pkl' % args.lastiter), map_location=device))
     bucket = parallel.GradBucket(params) if args.mode == 'fast' else None
     tv = have_torchvision()
 
@@ -121,7 +127,7 @@ def train(args):
     steps_done, losses = 0, []
     for epoch in range(args.numepochs):
         random.Random(epoch + args.lastiter).shuffle(trainDataSet)
-        mine = trainDataSet[rank::world] if args.mode == 'fast' else trainDataSet
+        mine = trainDataSet
         clsLossSum = regLossSum = 0.0
         clsCnt = regCnt = 0
         if args.mode == 'module':
@@ -166,24 +172,35 @@ def train(args):
         else:
             from modules import pipeline as pl
             B = args.frames
-            for i in range(0, len(mine) - len(mine) % B if len(mine) >= B else 0, B):
-                group = mine[i:i + B]
+            # ONE step count for every rank, derived from the global length (ranks that ran different numbers of steps would
+            # issue different collective sequences): global step g covers frames [g*B*W, (g+1)*B*W) of the shuffled epoch,
+            # rank r takes every W-th of them.  The last chunk may be short -- the reference trains on every frame
+            # (train.py:110) -- so a rank may get fewer than B frames, or none: it still takes part in the all-reduce with
+            # a zero gradient, and the divisor is the number of frames that contributed on all ranks.
+            chunks = fast_chunks(len(trainDataSet), B, world)
+            for gstep, (lo, hi) in enumerate(chunks):
+                group = trainDataSet[lo + rank:hi:world]
                 st = time.perf_counter()
-                batch, targets = pl.batch_from_dataset(group, [names[id(d)] for d in group], device, anchorBevs,
-                                                       fpn_maps_for, cap_points=max(args.points, max(d[0].shape[0] for d in group)))
                 bucket.zero()
-                out = pl.train_step_full(model, batch, targets, criterion, anchors, cfg.imsize)
+                used = 0
+                if group:
+                    batch, targets = pl.batch_from_dataset(group, [names[id(d)] for d in group], device, anchorBevs,
+                                                           fpn_maps_for, cap_points=max(args.points, max(d[0].shape[0] for d in group)))
+                    out = pl.train_step_full(model, batch, targets, criterion, anchors, cfg.imsize)
+                    used = len(out['live'])
+                    if used < len(group):
+                        say('Epoch%d step %d: %d frame(s) without a voxel skipped' % (epoch + args.lastiter + 1, gstep, len(group) - used))
+                    losses.extend(out['loss'])
+                    clsLossSum += sum(out['cls'])
+                    clsCnt += len(out['cls'])
+                    regLossSum += sum(out['reg'])
+                    regCnt += len(out['reg'])
                 forwardTime += time.perf_counter() - st
-                bucket.all_reduce_mean(B * world)
+                bucket.all_reduce_mean(parallel.global_count(used, device))
                 opt.step()
-                losses.extend(out['loss'])
-                clsLossSum += sum(out['cls'])
-                clsCnt += len(out['cls'])
-                regLossSum += sum(out['reg'])
-                regCnt += len(out['reg'])
                 steps_done += 1
                 say('Epoch%d %d/%d  average classification loss %.6f, average regression loss %.6f'
-                    % (epoch + args.lastiter + 1, i + B, len(mine), clsLossSum / max(1, clsCnt), regLossSum / max(1, regCnt)))
+                    % (epoch + args.lastiter + 1, hi, len(trainDataSet), clsLossSum / max(1, clsCnt), regLossSum / max(1, regCnt)))
                 if args.steps and steps_done >= args.steps:
                     break
         if rank == 0:

@@ -1,6 +1,9 @@
 """Worker of the world_size-2 gloo tests (CPU): gradient exchange of the data-parallel step.
 
 mode toy   : two small parameters, every rank adds the gradients of its frames, one all-reduce -> mean over all frames.
+mode chunks: train_like.py's --mode fast step schedule on an ODD frame count (7 and 9 frames, 2 per rank per step): every rank
+             runs the same number of steps, a rank without a frame in the short last chunk still joins the all-reduce, the
+             divisor is the global number of contributing frames, every frame is used exactly once.
 mode model : the REAL flat bucket over MVXNet's hot-path parameters (same construction as bench.py / train_like.py): every
              rank fills the gradients of its own frames with a frame-dependent pattern, all-reduces, and compares with
              the single-process sum over all frames computed locally; then one AdamW step must leave both ranks with
@@ -34,6 +37,30 @@ if mode == 'toy':
     bucket.all_reduce_mean(frames_total)
     expect = sum(f + 1.0 for f in range(frames_total)) / frames_total
     assert torch.allclose(bucket.flat, torch.full_like(bucket.flat, expect)), (bucket.flat, expect)
+elif mode == 'chunks':
+    import train_like
+    B = 2
+    for n_frames in (7, 9, 3):
+        params = [torch.nn.Parameter(torch.zeros(4))]
+        bucket = parallel.GradBucket(params)
+        chunks = train_like.fast_chunks(n_frames, B, world)
+        assert chunks[0][0] == 0 and chunks[-1][1] == n_frames and all(a[1] == b[0] for a, b in zip(chunks, chunks[1:]))
+        seen = []
+        for lo, hi in chunks:                        # the loop of train_like.train (--mode fast), gradients = frame id + 1
+            mine = list(range(lo + rank, hi, world))
+            bucket.zero()
+            for f in mine:
+                params[0].grad.add_(float(f + 1))
+            total = parallel.global_count(len(mine))
+            assert total == hi - lo, (total, lo, hi)
+            bucket.all_reduce_mean(total)
+            want = sum(f + 1.0 for f in range(lo, hi)) / (hi - lo)
+            assert torch.allclose(bucket.flat, torch.full_like(bucket.flat, want)), (bucket.flat, want)
+            seen.extend(mine)
+        cnt = torch.tensor([float(len(seen)), float(len(chunks))])
+        both = [torch.empty_like(cnt) for _ in range(world)]
+        dist.all_gather(both, cnt)
+        assert sum(int(b[0]) for b in both) == n_frames and len({int(b[1]) for b in both}) == 1
 else:
     from MVXNet import MVXNet
     model = MVXNet()                                 # CPU parameters: only the bucket / optimizer logic runs here

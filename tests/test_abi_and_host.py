@@ -109,7 +109,7 @@ def _free_port():
         return str(sk.getsockname()[1])
 
 
-@pytest.mark.parametrize('mode', ['toy', 'model'])
+@pytest.mark.parametrize('mode', ['toy', 'chunks', 'model'])
 def test_data_parallel_gradient_exchange_gloo_world2(mode):
     """Two CPU processes over gloo.  toy: the flat bucket all-reduce gives the mean over all frames.  model: the real
     GradBucket over MVXNet's 1,169,440 hot-path parameters with different per-frame gradients on the two ranks equals the
