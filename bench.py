@@ -50,10 +50,17 @@ def host_projection(pts, calib):
     return uv[:, ::-1].astype(np.float32)
 
 
+_FRAME_CACHE = {}
+
+
 def frame_points(workload, fid, P):
-    """The P points of a synthetic frame that survive crop + cropToSight, in cloud order."""
+    """The P points of a synthetic frame that survive crop + cropToSight, in cloud order (cached: the runs of one process
+    share their frames)."""
     from modules.data import Synthetic as S
-    return S.synth_ring(fid, P) if workload == 'S2' else S.synth_uniform_in_sight(fid, P)
+    key = (workload, fid, P)
+    if key not in _FRAME_CACHE:
+        _FRAME_CACHE[key] = S.synth_ring(fid, P) if workload == 'S2' else S.synth_uniform_in_sight(fid, P)
+    return _FRAME_CACHE[key]
 
 
 def make_batch(frame_ids, dev, P, workload='S2', raw_points=RAW_POINTS):
@@ -302,31 +309,59 @@ def isolated_conv_roofline(dev, math):
             'note': 'the same kernel, one frame, dense (no tile skipping), alone on the GPU'}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--mode', choices=['hot', 'vfe', 'fusion', 'dropin', 'full'], default='hot')
     ap.add_argument('--workload', choices=['S1', 'S2'], default='S2')
-    ap.add_argument('--frames', type=int, default=None, help='frames per GPU per step (default 4; 16 in --mode vfe)')
+    ap.add_argument('--frames', type=int, default=None, help='frames per GPU per step (default 4; 16 in --mode vfe, 2 in --mode fusion)')
     ap.add_argument('--points', type=int, default=20000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--convmath', choices=['bf16x3', 'f32'], default=None, help='override config.yml convmath')
-    ap.add_argument('--no-alt', action='store_true', help='skip the extra runs (bf16x3 arithmetic, the other workload)')
+    ap.add_argument('--no-alt', action='store_true', help='skip the extra runs (other workload, bf16x3 arithmetic, the other BASELINE configs)')
     ap.add_argument('--timed-only', action='store_true',
                     help='only warm-up + the timed steps (no alt / isolated / CPU passes): what profiles/ is made from')
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.timed_only:
         args.no_alt = args.no_cpu_baseline = True
-    if args.frames is None:
-        args.frames = {'vfe': 16, 'fusion': 2}.get(args.mode, 4)
+    return args
 
+
+def main():
+    args = parse_args()
     from modules import parallel
     rank, world, local = parallel.init_from_env(os.environ.get('MVX_DIST_BACKEND'))
     assert world == args.gpus or world == 1, 'launch with torchrun --nproc-per-node = --gpus'
     dev = torch.device('cuda', local % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
+    out = run(args, rank, world, dev)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run(args, rank, world, dev):
+    """One benchmark run in this process: the timed region of ``args.mode`` plus (unless switched off) its alternative runs and
+    the CPU baseline; returns the JSON object on rank 0 (None elsewhere).  Called again by itself for the other BASELINE
+    configs that the default run appends under ``alt_modes``."""
+    import modules.config as cfg
+    from modules import _hip
+    old_math = cfg.config.get('convmath', 'f32')
+    try:
+        return _run(args, rank, world, dev)
+    finally:
+        cfg.config['convmath'] = old_math
+        _hip.KERNEL_TIMERS = None
+
+
+def _run(args, rank, world, dev):
+    from modules import parallel
+    if args.frames is None:
+        args.frames = {'vfe': 16, 'fusion': 2}.get(args.mode, 4)
 
     import modules.config as cfg
     from modules import _hip
@@ -500,24 +535,34 @@ def main():
         assert bad == 0, 'a kernel reported a data-dependent error (status %d)' % bad
         del pending_status[:]
 
-    def conv_roofline(tm, run):
-        """Dominant kernel conv3d_gather_pw: conv2/conv3 forward (background-aware) + tile-restricted dgrad launches.
-        achieved = EXECUTED FLOPs (the kernel's own stage counter x 4.72 MFLOP; skipped tiles are not credited) / sum of
-        the launch durations from HIP events recorded on the launch stream inside the timed region."""
+    def conv_roofline(tm, run, math=None):
+        """Dominant kernel conv3d_gather_pw (exact f32) / conv3d_gather_split (bf16x3): conv2/conv3 forward (background-aware)
+        + tile-restricted dgrad launches.  achieved = EXECUTED matrix FLOPs (the kernel's own stage counter x 4.72 MFLOP;
+        skipped tiles are not credited; x 3 MFMAs per product in the bf16x3 arithmetic) / sum of the launch durations from
+        HIP events recorded on the launch stream inside the timed region, against the peak of the MFMA type that ran."""
+        math = main_math if math is None else math
         ev = tm.get('conv3d_gather_bg', []) + tm.get('conv3d_gather_tiles', []) + tm.get('conv3d_gather', [])
         ms = sum(s.elapsed_time(e) for s, e, _ in ev)
         dense_fl = sum(f for _, _, f in ev)
         fl = float(exec_stages[run]) * _hip.STAGE_FLOP + sum(f for _, _, f in tm.get('conv3d_gather', []))
-        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        return {'bound': 'mfma', 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS,
-                'traffic': None, 'kernel': 'conv3d_gather_pw (conv2 / conv3 forward + dgrad of all frames of the step: 4 launches per step)',
-                'launches': len(ev), 'avg_launch_ms': ms / max(1, len(ev)), 'flop_per_launch': fl / max(1, len(ev)),
-                'dense_equivalent_tflops': dense_fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
-                'note': 'exact f32 MFMA (v_mfma_f32_32x32x2_f32); FLOPs are the EXECUTED ones counted by the kernel: tiles that hold '
-                        'only the voxel-free background, depth taps whose source halo holds no voxel and idle image-border tiles are '
-                        'written from constants and not credited, while the time of filling them (about 60 % of the tiles of a launch) '
-                        'stays in the denominator; measured while the side-stream weight-gradient kernels share the CUs; `isolated` '
-                        '= the same kernel on dense launches alone'}
+        alg = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        r = {'bound': 'mfma', 'achieved': alg, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': alg / FP32_MFMA_PEAK_TFLOPS,
+             'traffic': None, 'kernel': 'conv3d_gather_pw (conv2 / conv3 forward + dgrad of all frames of the step: 4 launches per step)',
+             'launches': len(ev), 'avg_launch_ms': ms / max(1, len(ev)), 'flop_per_launch': fl / max(1, len(ev)),
+             'dense_equivalent_tflops': dense_fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+             'note': 'exact f32 MFMA (v_mfma_f32_32x32x2_f32); FLOPs are the EXECUTED ones counted by the kernel: tiles that hold '
+                     'only the voxel-free background, depth taps whose source halo holds no voxel and idle image-border tiles are '
+                     'written from constants and not credited, while the time of filling them (about 60 % of the tiles of a launch) '
+                     'stays in the denominator; measured while the side-stream weight-gradient kernels share the CUs; `isolated` '
+                     '= the same kernel on dense launches alone'}
+        if math == 'bf16x3':
+            # every product is three bf16 MFMAs (hi*hi + hi*lo + lo*hi): executed matrix FLOPs = 3 x the algorithmic ones
+            r.update(achieved=3.0 * alg, peak=BF16_MFMA_PEAK_TFLOPS, frac=3.0 * alg / BF16_MFMA_PEAK_TFLOPS, algorithmic_tflops=alg,
+                     flop_per_launch=3.0 * r['flop_per_launch'],
+                     kernel='conv3d_gather_split (conv2 / conv3 forward + dgrad of all frames of the step)',
+                     note='bf16 hi/lo split MFMA (v_mfma_f32_32x32x16_bf16, f32 accumulate), EXECUTED stages counted by the kernel '
+                          'x 4.72 MFLOP x 3 MFMAs per product, against the dense bf16 peak; skipped background tiles are not credited')
+        return r
 
     def hbm_stages(tm):
         out = {}
@@ -532,7 +577,7 @@ def main():
 
     # ------------------------------------------------------------------------------------------------ the timed run
     vfe_check = None
-    if args.mode == 'vfe' and rank == 0 and not args.no_cpu_baseline:
+    if args.mode == 'vfe' and rank == 0 and not args.timed_only:
         # BASELINE config 2: the voxel indices of every frame of the run are checked bit-exact against the C oracle (part
         # of the CPU-baseline leg: the only place the benchmark touches oracle/)
         vfe_check = voxel_index_check(batch, args.workload, frame_ids, args.points)
@@ -575,16 +620,33 @@ def main():
                 cfg.config['convmath'] = 'f32'
                 state['ready'] = None
             check_status()
-            r3 = conv_roofline(tm3, len(exec_stages) - 1)
-            # every product is three bf16 MFMAs (hi*hi + hi*lo + lo*hi): executed matrix FLOPs = 3 x the algorithmic ones
-            r3.update(achieved=3.0 * r3['achieved'], peak=BF16_MFMA_PEAK_TFLOPS, frac=3.0 * r3['achieved'] / BF16_MFMA_PEAK_TFLOPS,
-                      algorithmic_tflops=r3['achieved'], kernel='conv3d_gather_split (conv2 / conv3 forward + dgrad of all frames)',
-                      note='bf16 hi/lo split MFMA (v_mfma_f32_32x32x16_bf16, f32 accumulate), EXECUTED stages counted by the kernel '
-                           'x 4.72 MFLOP x 3 MFMAs per product, against the dense bf16 peak')
+            r3 = conv_roofline(tm3, len(exec_stages) - 1, 'bf16x3')
             alt.append({'workload': args.workload, 'convmath': 'bf16x3', 'value': frames_total * max(3, args.steps // 2) / dt3,
                         'unit': 'frames/s', 'ms_per_step': dt3 / max(3, args.steps // 2) * 1e3, 'roofline': r3,
                         'note': 'conv2 / conv3 forward, input and weight gradients on the bf16x3 kernels (forward maps within 1e-5 of '
                                 'the exact-f32 mode; gradients carry the split\'s 2e-5 per product), everything else unchanged'})
+
+    if not args.no_alt and args.mode == 'hot' and world == 1:
+        # (3) the other BASELINE.json configs as short runs of their own modes, so that the driver's default invocation
+        # carries a timed number and a roofline for each of them: config 2 (--mode vfe, 16 frames), config 4 (--mode fusion,
+        # 2 frames), config 3 (--mode full, 4 frames: exact f32 and "bf16 MFMA conv" = convmath bf16x3)
+        import copy
+        for cfg_no, mode, math in ((2, 'vfe', main_math), (4, 'fusion', main_math), (3, 'full', 'f32'), (3, 'full', 'bf16x3')):
+            a2 = copy.copy(args)
+            a2.mode, a2.convmath, a2.frames = mode, math, None
+            a2.steps, a2.warmup = 5, 2
+            a2.no_alt = a2.no_cpu_baseline = True
+            a2.timed_only = False
+            state['ready'] = None
+            o2 = run(a2, rank, world, dev)
+            alt.append({'baseline_config': cfg_no, 'mode': mode, 'convmath': math, 'workload': args.workload, 'metric': o2['metric'],
+                        'value': o2['value'], 'unit': o2['unit'], 'steps': o2['steps'], 'warmup': o2['warmup'],
+                        'ms_per_step': o2['ms_per_step'], 'frames_per_gpu': o2['config']['frames_per_gpu'],
+                        'host_enqueue_ms_per_step': o2['host_enqueue_ms_per_step'], 'roofline': o2['roofline'],
+                        'other_kernels': o2.get('other_kernels', {}), 'config': o2['config']['workload']})
+            gc.collect()
+            torch.cuda.empty_cache()
+        state['ready'] = None
 
     if rank == 0:
         dtype = 'f32' if main_math == 'f32' else 'f32 (bf16x3 split MFMA, f32 accumulate)'
@@ -689,12 +751,12 @@ def main():
                 out['cpu_baseline'] = cpu_baseline(args.points, args.workload, with_rpn=args.mode == 'full')
             if vfe_check is not None:
                 out['cpu_baseline']['voxel_indices_vs_oracle'] = vfe_check
+        if vfe_check is not None:
+            out['config']['voxel_indices_vs_oracle'] = vfe_check
         if args.mode == 'full' and full.get('last'):
             out['last_losses'] = full['last']
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        return out
+    return None
 
 
 if __name__ == '__main__':

@@ -70,7 +70,7 @@ class GradBucket:
     def all_reduce_mean(self, frames_total):
         """Sum over ranks, then divide by the global number of frames."""
         self.check_views()
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_initialized():             # also with one rank: the collective path is the same code at every world size
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         self.flat.mul_(1.0 / float(frames_total))
 

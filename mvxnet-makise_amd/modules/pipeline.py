@@ -468,7 +468,8 @@ def heads_loss(heads, F, h1, w1, targets, criterion, anchors):
     return torch.stack(losses), has_reg, d.view(F * h1 * w1, 16)
 
 
-def train_step_full(model, batch, targets, criterion, anchors, imsize, ready=None, prepare_next=None, rpn_hip=None, read=True):
+def train_step_full(model, batch, targets, criterion, anchors, imsize, ready=None, prepare_next=None, rpn_hip=None, read=True,
+                    keep=None):
     """One optimizer step's worth of forward + backward of the WHOLE model for the frames of ``batch``: frame sets up to
     the CML output (modules/frames.py), the RPN of all frames on this library's kernels (modules/rpn_frames.py; per-frame
     BatchNorm statistics, exactly B reference forwards, train.py:131-161), VoxelLoss per frame, and the whole way back.
@@ -477,7 +478,9 @@ def train_step_full(model, batch, targets, criterion, anchors, imsize, ready=Non
     ``prepare_next`` = (next batch, callable returning its targets): voxelized, mapped and target-assigned on the
     preparation stream after this step has been enqueued; returned as out['next'] = (ready, targets) for the next call.
     ``read=False`` leaves the losses on the device (out['losses_dev'] (F,2)) and skips the status read: the caller reads
-    them a step later, so the host never waits for the step it has just enqueued."""
+    them a step later, so the host never waits for the step it has just enqueued.
+    ``keep`` (tests): a dict that receives the step's intermediate maps -- 'x3' the normalised CML output, channels-last
+    [F*D3][H][W][C3] (BEV channel c*D3 + d, VoxelNet.py:36), 'heads' (F*h1*w1, 16) = [cls logits | reg], 'geom'."""
     from modules import frames as fr
     from modules import rpn_frames as rf
     rpn_hip = RPN_HIP if rpn_hip is None else rpn_hip
@@ -517,6 +520,8 @@ def train_step_full(model, batch, targets, criterion, anchors, imsize, ready=Non
                     rpn = model.backbone.rpn
                     heads, rs = rf.rpn_forward(rpn, saved.x3, F, saved.D3, saved.H, saved.W, saved.C3)
                     losses, has_reg, d_heads = heads_loss(heads, F, rs['h1'], rs['w1'], tl, criterion, anchors)
+                    if keep is not None:
+                        keep.update(x3=saved.x3, heads=heads, geom=(F, saved.D3, saved.H, saved.W, saved.C3, rs['h1'], rs['w1']))
                     g_cl = rf.rpn_backward(rpn, rs, d_heads)
                     fr.rows_backward(model, saved, fr.cml_backward(model, saved, None, g_cl=g_cl))
                 else:

@@ -59,6 +59,18 @@ def _make_batch(frame_ids, dev, P_pts=20000):
     return batch, raw, kept, perms, fpn_cpu
 
 
+def _smooth_gradient(C=128, H=352, W=400):
+    """dL/d(BEV map) (1,C,H,W): per channel an offset plus a product of low-frequency cosines, magnitude 1e-3."""
+    g = np.random.default_rng(123)
+    hh = np.arange(H, dtype=np.float64)[None, :, None] / H
+    ww = np.arange(W, dtype=np.float64)[None, None, :] / W
+    fa, fb = g.integers(0, 3, (C, 1, 1)), g.integers(0, 3, (C, 1, 1))
+    ph = g.uniform(0, 2 * np.pi, (2, C, 1, 1))
+    off = g.uniform(-0.5, 0.5, (C, 1, 1))
+    pat = off + np.cos(2 * np.pi * fa * hh + ph[0]) * np.cos(2 * np.pi * fb * ww + ph[1])
+    return torch.from_numpy((1e-3 * pat).astype(np.float32))[None]
+
+
 def test_bench_path_matches_oracle_at_full_size():
     import modules.config as cfg
     import modules.pipeline as pl
@@ -78,9 +90,9 @@ def test_bench_path_matches_oracle_at_full_size():
     G = torch.randn((1, 128, 352, 400), generator=g) * 1e-3
     imsize = [370.0, 1224.0]
 
-    def run(b, keep=None, fn=train_step_frame_set):
+    def run(b, keep=None, fn=train_step_frame_set, g_up=None):
         bucket.zero()
-        nv, st = fn(model, b, G.to(dev), imsize, keep_mid=keep)
+        nv, st = fn(model, b, (G if g_up is None else g_up).to(dev), imsize, keep_mid=keep)
         torch.cuda.synchronize()
         assert int(torch.stack([s_.reshape(()) for s_ in st]).max()) == 0
         return nv, {k: p.grad.detach().clone() for k, p in hot}
@@ -161,6 +173,20 @@ def test_bench_path_matches_oracle_at_full_size():
         imf64 = O.image_feature_fusion(imf.double(), P64, 'head.fusion.')
         v23_64 = torch.cat([vz[..., :7].double(), imf64], dim=-1)
         mid64 = O.voxelnet_middle(v23_64, idx, O.strip_prefix(P64, 'backbone.'))
+        # (a) a SMOOTH upstream gradient (low-frequency pattern + offset per channel): the parameter gradients are then
+        # sums of coherent terms, fp32 rounding and the odd ReLU-mask flip stay far below them, and a 1 % error in any
+        # closed-form term of the restricted backward (input_grad_sums, dz_inactive_sums, the border-region
+        # tap sums) would show: asserted at 1e-3 (max-norm relative) for EVERY parameter of the path
+        Gs = _smooth_gradient()
+        mid64.backward(Gs.double(), retain_graph=True)
+        smooth64 = {n: v.grad.clone() for n, v in P64.items() if v.grad is not None}
+        for v in P64.values():
+            v.grad = None
+        smooth_hip = run(singles[0], g_up=Gs)[1]
+        gs = {n: float((smooth_hip[n].cpu().double() - smooth64[n]).abs().max() / smooth64[n].abs().max()) for n, _ in hot}
+        report['param_grad_rel_maxnorm_vs_float64_smooth_upstream'] = gs
+        # (b) the benchmark's white-noise upstream gradient: the reported worst case (every gradient the residue of 1.4 M
+        # cancelling terms)
         mid64.backward(G.double())
         ref64 = mid64.detach().reshape(-1).numpy()
         mag64 = np.maximum(np.abs(ref64), rms)
@@ -177,6 +203,7 @@ def test_bench_path_matches_oracle_at_full_size():
         assert y['hip_rel_maxnorm'] < 1e-4
         assert e_hip.max() < 1e-3, e_hip.max()
         assert max(gr.values()) < 3e-2, sorted(gr.items(), key=lambda t: -t[1])[:4]
+        assert max(gs.values()) < 1e-3, sorted(gs.items(), key=lambda t: -t[1])[:4]
     print(json.dumps(report))
 
 
@@ -217,19 +244,38 @@ def test_whole_model_losses_match_oracle_at_full_size():
     pts6 = points6.cpu().numpy()
     rv, ri, _ = O.group(pts6[0], perms[0], O.VELORANGE, O.voxelsize(), 35)
     V = rv.shape[0]
+    trainable = [k for k, p in model.named_parameters() if p.requires_grad]
     P64 = {k: v.detach().cpu().double() for k, v in model.state_dict().items()}
+    for k in trainable:
+        P64[k].requires_grad_(True)
     vox = torch.from_numpy(rv.astype(np.float32))
     idx = torch.from_numpy(np.concatenate([np.zeros((V, 1), np.int64), ri.astype(np.int64)], 1))
     with torch.no_grad():
         imf = O.feature_mapping(vox, fpn_cpu[0], torch.tensor([370.0, 1224.0]))
-        imf64 = O.image_feature_fusion(imf.double(), P64, 'head.fusion.')
-        v23 = torch.cat([vox[..., :7].double(), imf64], dim=-1)
-        bb = O.strip_prefix(P64, 'backbone.')
-        mid = O.voxelnet_middle(v23, idx, bb)
-        score, reg = O.rpn(mid, bb)
-        cls, rl = O.voxel_loss(rp, rn, rg, gt.double(), score[0].permute(1, 2, 0), reg[0].permute(1, 2, 0),
-                               O.create_anchors(176, 200).double(), 2)
+    imf64 = O.image_feature_fusion(imf.double(), P64, 'head.fusion.')
+    v23 = torch.cat([vox[..., :7].double(), imf64], dim=-1)
+    bb = O.strip_prefix(P64, 'backbone.')
+    mid = O.voxelnet_middle(v23, idx, bb)
+    score, reg = O.rpn(mid, bb)
+    cls, rl = O.voxel_loss(rp, rn, rg, gt.double(), score[0].permute(1, 2, 0), reg[0].permute(1, 2, 0),
+                           O.create_anchors(176, 200).double(), 2)
+    # the gradient of the REAL loss (train.py:146-161: clsLoss + regLoss) through RPN, CML, VFE and fusion in float64: a
+    # structured upstream gradient, against which every parameter gradient of the HIP step is compared
+    (cls + rl).backward()
     e_cls = abs(out['cls'][0] - float(cls)) / abs(float(cls))
     e_reg = abs(out['reg'][0] - float(rl)) / abs(float(rl))
     print('whole model at full size vs float64 oracle: clsLoss %.6f (rel %.1e), regLoss %.6f (rel %.1e)' % (out['cls'][0], e_cls, out['reg'][0], e_reg))
     assert e_cls < 1e-4 and e_reg < 1e-4
+    grads = dict(zip(trainable, [p.grad.detach().cpu().double() for k, p in model.named_parameters() if p.requires_grad]))
+    ge, ge2 = {}, {}
+    for k in trainable:
+        ref = P64[k].grad
+        ge[k] = float((grads[k] - ref).abs().max() / ref.abs().max())
+        ge2[k] = float((grads[k] - ref).norm() / ref.norm())
+    worst = sorted(ge.items(), key=lambda t: -t[1])[:5]
+    print('whole-model parameter gradients vs float64 (loss-derived upstream gradient): worst max-norm %s; worst 2-norm %.2e'
+          % (worst, max(ge2.values())))
+    os.makedirs(os.path.join(REPO, 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(REPO, 'gpurun_out', 'fullsize_whole_model_grads.json'), 'w') as fh:
+        json.dump({'rel_maxnorm': ge, 'rel_2norm': ge2, 'cls_loss_rel': e_cls, 'reg_loss_rel': e_reg}, fh, indent=1)
+    assert max(ge.values()) < 1e-3, worst
