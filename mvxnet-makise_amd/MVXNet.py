@@ -53,5 +53,15 @@ class MVXNet(nn.Module):
         rows = CompactInputFunction.apply(imfeat, vox2d, cr)
         return self.backbone.middle(rows, idx, compact_rows=cr)
 
-    def forward(self, voxels, imgs, idx, calibs, imsize):
-        return self.backbone(self.point_features(voxels, imgs, calibs, imsize), idx)
+    def forward(self, voxels, imgs, idx, calibs, imsize, compact=True):
+        """(1,N,T,9) voxels, image or FPN maps, (N,4) indices -> (score (1,2,H/2,W/2), reg (1,14,H/2,W/2)) (MVXNet.py:21-27).
+        ``compact=True`` (default) evaluates the fusion MLP and the VFE stack on the real rows + one padded row per voxel
+        and the first CML layer on the voxel rows: exact for ANY input, because featureMaping zeroes every row whose
+        x = y = z = 0 in place (imhead/Pipe.py:54-59), which makes all such rows of a voxel identical from there on
+        (SURVEY Q5); ``compact=False`` is the reference's dense (1,N,T,23) formulation."""
+        if not compact:
+            return self.backbone(self.point_features(voxels, imgs, calibs, imsize), idx)
+        from modules.voxelnet.Pipe import CompactInputFunction
+        imfeat, cr, vox2d = self.head.forward_compact(imgs, voxels, calibs, imsize)
+        rows = CompactInputFunction.apply(imfeat, vox2d, cr)
+        return self.backbone(rows, idx, compact_rows=cr)

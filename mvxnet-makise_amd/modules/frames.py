@@ -87,6 +87,9 @@ def _stats(F, C, dev):
 
 
 TAP_SKIP = os.environ.get('MVX_TAP_SKIP', '1') != '0'     # conv2 / conv3 forward: skip depth taps with a background-only source halo
+# DIAGNOSTIC ONLY (tools/knockout.sh): comma-separated kernel classes that are NOT launched, to measure what each class costs
+# on the critical path of a step (step time with the class removed).  Results are garbage; bench.py marks such a run invalid.
+KNOCKOUT = frozenset(k for k in os.environ.get('MVX_KNOCKOUT', '').split(',') if k)
 
 
 def linear_bn(x, w, b, fs, kind, row_w, eps):
@@ -100,6 +103,8 @@ def linear_bn(x, w, b, fs, kind, row_w, eps):
     if counter is None:
         counter = torch.zeros((1,), dtype=torch.float64, device=x.device)
     mi = torch.empty((fs.F, 2, N), dtype=torch.float32, device=x.device)
+    if 'lin_fwd' in KNOCKOUT:
+        return y, mi
     X.check(X.lib.mvx_linear_forward_bn_frames(_hip._vptr(x), _hip._ld(x), _hip._vptr(w2), _hip._ld(w2), 0, X.ptr(b),
                                                _hip._vptr(y), _hip._ld(y), X.ptr(stats), X.ptr(row_w), Rr, K, N,
                                                _hip.FLAG_RELU | fz, X.ptr(counter), float(eps), X.ptr(mi), fs.desc.ref(),
@@ -110,6 +115,8 @@ def linear_bn(x, w, b, fs, kind, row_w, eps):
 def bn_apply(y, mi, fs, kind):
     C = mi.shape[-1]
     rows = y.numel() // C
+    if 'bn_apply_rows' in KNOCKOUT:
+        return y
     out = torch.empty_like(y)
     with _hip._timed_bytes('bn_apply', 2 * y.numel() * 4):
         X.check(X.lib.mvx_bn_apply_frames(X.ptr(y), X.ptr(mi), X.ptr(out), rows, C, fs.desc.ref(), kind, X.stream()),
@@ -123,6 +130,8 @@ def bn_relu_backward(dyhat, y, mi, fs, kind, row_w, dbias_into, dz=None):
     rows = y.numel() // C
     if dz is None:
         dz = torch.empty_like(y)
+    if ('bn_bwd_rows' if kind != X.ROWS_GRID else 'bn_bwd_grid') in KNOCKOUT:
+        return dz
     scratch, fz = _hip._acc_f64((X.lib.mvx_bn_backward_scratch_bytes_frames(C, fs.F) // 8,), y.device)
     with _hip._timed_bytes('bn_relu_backward', 5 * y.numel() * 4):
         X.check(X.lib.mvx_bn_relu_backward_frames(X.ptr(dyhat), X.ptr(y), X.ptr(mi), 1.0, X.ptr(dz), X.ptr(dbias_into),
@@ -131,7 +140,31 @@ def bn_relu_backward(dyhat, y, mi, fs, kind, row_w, dbias_into, dz=None):
     return dz
 
 
+_GRAD_TARGETS = None        # id(parameter) -> buffer the gradient is ADDED into instead of .grad (a second lane of frame sets)
+
+
+class grad_targets:
+    """``with grad_targets(mapping)``: parameter gradients of the enclosed calls are added into ``mapping[id(p)]`` instead of
+    ``p.grad`` (modules/pipeline.py: the second lane accumulates into its own flat buffer, so two lanes never write the
+    same memory concurrently).  ``None`` = the parameters' own .grad."""
+
+    def __init__(self, mapping):
+        self.mapping = mapping
+
+    def __enter__(self):
+        global _GRAD_TARGETS
+        self.old, _GRAD_TARGETS = _GRAD_TARGETS, self.mapping
+        return self
+
+    def __exit__(self, *exc):
+        global _GRAD_TARGETS
+        _GRAD_TARGETS = self.old
+        return False
+
+
 def _grad_of(p):
+    if _GRAD_TARGETS is not None:
+        return _GRAD_TARGETS[id(p)]
     if p.grad is None or not p.grad.is_contiguous():
         raise X.MvxHipError('the frame-set path adds gradients into existing contiguous .grad buffers (GradBucket)')
     return p.grad
@@ -175,6 +208,7 @@ def rows_forward(model, fs, fpn_levels, imsize, status_sink, imfeat=None):
     compact[Rt:].zero_()                                   # the shared padded rows (Pipe.py:80)
     status = torch.zeros((1,), dtype=torch.int32, device=dev)
     with _hip._timed_bytes('feature_sample', Rt * L * C * 4 * 5 + Rt * 9 * 4):
+      if 'sample' not in KNOCKOUT:
         X.check(X.lib.mvx_feature_sample_rows_frames(X.ptr(fs.vox2d), fs.vox2d.shape[1], X.ptr(fs.rows_sel), Rt, ptrs, hw, L, C,
                                                      float(imsize[0]), float(imsize[1]), float(eps), X.ptr(compact),
                                                      X.ptr(status), fs.desc.ref(), X.stream()), 'mvx_feature_sample_rows_frames')
@@ -247,6 +281,7 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
     y1 = torch.empty((F * D1, H, W, cout), dtype=torch.float32, device=dev)
     stats, fz = _stats(F, cout, dev)
     with _hip._timed_bytes('sparse_conv_output', y1.numel() * 4 + F * D0 * H * W * 4):
+      if 'sparse_out' not in KNOCKOUT:
         X.check(X.lib.mvx_sparse_conv_output_frames(X.ptr(P), X.ptr(idx_grid), X.ptr(b1), X.ptr(y1), X.ptr(stats), D0, D1, H, W,
                                                     cout, c1._sd, c1._pd, _hip.FLAG_RELU | fz, F, X.stream()),
                 'mvx_sparse_conv_output_frames')
@@ -274,6 +309,8 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
     def bn_apply_bg(y, mi, c_bg, tflag, planes):
         """BatchNorm apply of a layer output with a background: tiles without a non-background site take the normalised
         constant without being read (bit-identical to bn_apply)."""
+        if 'bn_apply_cml' in KNOCKOUT:
+            return y
         out = torch.empty_like(y)
         Cn = y.shape[-1]
         # algorithmic bytes (timing runs only): flagged tiles are read and written, the others only written
@@ -330,7 +367,7 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
                         'mvx_conv3d_forward_bg_split_frames')
             X.check(X.lib.mvx_bn_finalize_frames(X.ptr(stats), float(dout * H * W), float(eps), X.ptr(mi), co, F, X.stream()),
                     'mvx_bn_finalize_frames')
-        else:
+        elif 'gather_fwd' not in KNOCKOUT:
           with _hip._Timed('conv3d_gather_bg', F * _hip.conv_flops(dout, din, H, W, ci, co, sd, pd) if _hip.KERNEL_TIMERS is not None else 0):
             X.check(X.lib.mvx_conv3d_forward_bg_frames(X.ptr(x_in), X.ptr(wpk), X.ptr(b), X.ptr(y), X.ptr(stats), din, dout, H, W,
                                                        ci, co, sd, pd, _hip.FLAG_RELU | fz | (_hip.FLAG_BG_TAPS if TAP_SKIP else 0),
@@ -363,6 +400,8 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
 
 
 def _wgrad_bg(rec, dz, tap_sums, F, H, W):
+    if 'wgrad_bg' in KNOCKOUT:
+        return
     x, w = rec['x'], rec['w']
     co, ci = w.shape[0], w.shape[1]
     dw = _grad_of(w)
@@ -388,6 +427,8 @@ def _wgrad_bg(rec, dz, tap_sums, F, H, W):
 
 def _linear_wgrad_side(x, dz, w):
     """dW += dz^T x over the rows of ALL frames, on the side stream."""
+    if 'lin_wgrad' in KNOCKOUT:
+        return
     _hip.linear_wgrad(x, dz, accumulate_into=_grad_of(w).view(w.shape[0], -1))
 
 
@@ -399,6 +440,15 @@ def middle_backward(model, S, grad_mid):
         rows_backward(model, S, cml_backward(model, S, grad_mid))
     finally:
         _hip.ASYNC_WGRAD = old_async
+
+
+_MUTATE = {}        # TESTS ONLY (tests/test_fullsize_gpu.py): name -> factor applied to a closed-form term of the restricted
+                    # backward, to prove that the parity tests would notice a 1 % error in it.  Empty in every product run.
+
+
+def _mut(name, t):
+    f = _MUTATE.get(name)
+    return t if f is None or t is None else t * f
 
 
 def cml_backward(model, S, grad_mid, g_cl=None):
@@ -421,6 +471,8 @@ def cml_backward(model, S, grad_mid, g_cl=None):
 
     def tap_sums(dz, planes, Cn, tile_flags=None, inactive=None):
         Tt = torch.empty((planes, 9, Cn), dtype=torch.float32, device=dev)
+        if 'tap_sums' in KNOCKOUT:
+            return Tt
         ws = _hip.workspace(X.lib.mvx_plane_tap_sums_workspace_bytes(planes, Cn), dev, 'tap_sums')
         X.check(X.lib.mvx_plane_tap_sums(X.ptr(dz), planes, H, W, Cn, X.ptr(tile_flags), X.ptr(inactive), X.ptr(Tt), X.ptr(ws),
                                          ws.numel(), X.stream()), 'mvx_plane_tap_sums')
@@ -443,6 +495,8 @@ def cml_backward(model, S, grad_mid, g_cl=None):
                                                                   co, rec['sd'], rec['pd'], X.ptr(bflag), X.ptr(counter), F,
                                                                   X.stream()), 'mvx_conv3d_dgrad_tiles_split_frames')
             return dx
+        if 'gather_dgrad' in KNOCKOUT:
+            return dx
         with _hip._Timed('conv3d_gather_tiles', F * _hip.conv_flops(rec['din'], rec['dout'], H, W, co, ci, rec['sd'], rec['pd'], True)
                          if _hip.KERNEL_TIMERS is not None else 0):
             X.check(X.lib.mvx_conv3d_dgrad_tiles_frames(X.ptr(dz), X.ptr(wpd), X.ptr(dx), rec['din'], rec['dout'], H, W, ci, co,
@@ -461,6 +515,8 @@ def cml_backward(model, S, grad_mid, g_cl=None):
         dz = torch.empty_like(y)
         ws = _hip.workspace(X.lib.mvx_bn_relu_backward_tiles_workspace_bytes_frames(planes, H, W, Cn, F), dev, 'bn_tiles')
         inact = torch.empty((F * planes, Cn), dtype=torch.float32, device=dev) if want_inactive else None
+        if 'bn_bwd_tiles' in KNOCKOUT:
+            return dz, inact
         # algorithmic bytes (timing runs only): the flagged 8x16 tiles, two passes reading dyhat and y, the second writing dz
         nbytes = bflag.ne(0).sum() * (128 * Cn * 4 * 5) if _hip.KERNEL_TIMERS is not None else 0
         with _hip._timed_bytes('bn_relu_backward_tiles', nbytes):
@@ -473,17 +529,18 @@ def cml_backward(model, S, grad_mid, g_cl=None):
     # ---- conv3: dense gradient in, restricted gradient + closed-form plane sums out
     r3, r2 = S.convs[1], S.convs[0]
     dz3 = bn_relu_backward(g, r3['y'], r3['mi'], fs, X.ROWS_GRID, None, _grad_of(r3['b']))
-    T3 = tap_sums(dz3, F * r3['dout'], r3['w'].shape[0])
+    T3 = _mut('T3', tap_sums(dz3, F * r3['dout'], r3['w'].shape[0]))
     _wgrad_bg(r3, dz3, T3, F, H, W)
     g2 = dgrad_tiles(r3, dz3, r3['bflag_in'])
-    A2 = input_grad_sums(r3, T3)
+    A2 = _mut('A2', input_grad_sums(r3, T3))
     # ---- conv2
     dz2, inact2 = bn_bwd_tiles(g2, r2['y'], r2['mi'], r2['c_out'], r2['ybg_out'], A2, r2['bflag_out'], r2['dout'],
                                r2['w'].shape[0], r2['b'], True)
-    T2 = tap_sums(dz2, F * r2['dout'], r2['w'].shape[0], r2['bflag_out'], inact2)
+    inact2 = _mut('inact2', inact2)
+    T2 = _mut('T2', tap_sums(dz2, F * r2['dout'], r2['w'].shape[0], r2['bflag_out'], inact2))
     _wgrad_bg(r2, dz2, T2, F, H, W)
     g1 = dgrad_tiles(r2, dz2, r2['bflag_in'])
-    A1 = input_grad_sums(r2, T2)
+    A1 = _mut('A1', input_grad_sums(r2, T2))
     # ---- conv1 (voxel-GEMM factorisation): gradient only next to the voxels
     c1 = S.conv1
     w1 = c1['w']
@@ -500,6 +557,14 @@ def cml_backward(model, S, grad_mid, g_cl=None):
     return dfeat
 
 
+def _rows_dgrad(dz, w2):
+    """dx = dz w (rows x K): the input gradient of a row layer."""
+    if 'lin_dgrad' in KNOCKOUT:
+        return torch.empty((dz.shape[0], w2.shape[1]), dtype=torch.float32, device=dz.device)
+    gx, _ = _hip.linear_forward(dz, w2, None, relu=False, want_stats=False, w_transposed=True)
+    return gx
+
+
 def rows_backward(model, S, dfeat):
     """Backward of rows_forward from dL/d(voxel features) (Vt,128); needs _hip.ASYNC_WGRAD set by the caller."""
     fs = S.fs
@@ -513,7 +578,7 @@ def rows_backward(model, S, dfeat):
                                            X.stream()), 'mvx_segment_max_backward')
     dz = bn_relu_backward(dyh, y, mi, fs, X.ROWS_VFE, fs.row_w, _grad_of(b), dz=dyh)
     _linear_wgrad_side(x, dz, w)
-    gx, _ = _hip.linear_forward(dz, w, None, relu=False, want_stats=False, w_transposed=True)
+    gx = _rows_dgrad(dz, w)
     # ---- VFE 2, VFE 1
     for x, w, b, y, mi, am in reversed(S.vfe):
         Cn = w.shape[0]
@@ -523,7 +588,7 @@ def rows_backward(model, S, dfeat):
                                                       Rt, X.stream()), 'mvx_vfe_max_concat_backward')
         dz = bn_relu_backward(dyh, y, mi, fs, X.ROWS_VFE, fs.row_w, _grad_of(b), dz=dyh)
         _linear_wgrad_side(x, dz, w)
-        gx, _ = _hip.linear_forward(dz, w, None, relu=False, want_stats=False, w_transposed=True)
+        gx = _rows_dgrad(dz, w)
     # ---- concat backward: gradient of the fused image features ([real rows | shared padded row per frame])
     Fc = S.fc
     gim = torch.empty((Rt + F, Fc), dtype=torch.float32, device=dev)
@@ -537,4 +602,4 @@ def rows_backward(model, S, dfeat):
         dz = bn_relu_backward(gx, y, mi, fs, X.ROWS_FUSION, fs.fusion_row_w, _grad_of(b))
         _linear_wgrad_side(x, dz, w)
         if i > 0:
-            gx, _ = _hip.linear_forward(dz, w.reshape(w.shape[0], -1), None, relu=False, want_stats=False, w_transposed=True)
+            gx = _rows_dgrad(dz, w.reshape(w.shape[0], -1))

@@ -326,7 +326,7 @@ class CRB2dConvFunction(torch.autograd.Function):
 def _hip3x3_pays(x, cout):
     """The conv3d kernels work on 8x16-site tiles x 64 output channels: below one workgroup per CU (the 100x88 and
     50x44 maps of RPN blocks 2 and 3) MIOpen's Winograd kernels are faster (measured), so those stay there."""
-    if cfg.config.get('rpn_hip', False) == 'force':     # tests: every eligible block regardless of its size
+    if cfg.config.get('crb2d_hip', False) == 'force':     # tests: every eligible block regardless of its size
         return True
     h, w = x.shape[2], x.shape[3]
     return ((h + 7) // 8) * ((w + 15) // 16) * (cout // 64) >= 256
@@ -348,8 +348,9 @@ class _TorchBN2d(nn.Module):
 
 class CRB2d(nn.Module):
     """Conv2d -> ReLU -> BN2d (reference Blocks.py:31-40).  1x1 kernels (the fusion MLP,
-    imhead/Pipe.py:89,91) run on the HIP row-GEMM; 3x3 kernels belong to the RPN, which is the
-    next scope row and stays on PyTorch-ROCm/MIOpen for now."""
+    imhead/Pipe.py:89,91) run on the HIP row-GEMM.  3x3 kernels belong to the RPN, whose forward runs as one node on the HIP
+    kernels (voxelnet/Pipe.py RPNFunction); this module's own forward for them is the torch / MIOpen comparison path
+    (``rpn_hip: false``), optionally per block on the MFMA conv kernels (``crb2d_hip``)."""
 
     def __init__(self, cin, cout, k, s, p):
         super().__init__()
@@ -367,7 +368,7 @@ class CRB2d(nn.Module):
             rows = x.permute(0, 2, 3, 1)
             out = fcn_rows(_as_rows(rows), self.conv.weight, self.conv.bias)
             return out.reshape(rows.shape[:-1] + (out.shape[-1],)).permute(0, 3, 1, 2)
-        if (self._hip3x3 and x.is_cuda and x.shape[0] == 1 and cfg.config.get('rpn_hip', False) and not conv_split_math()
+        if (self._hip3x3 and x.is_cuda and x.shape[0] == 1 and cfg.config.get('crb2d_hip', False) and not conv_split_math()
                 and _hip3x3_pays(x, self.conv.out_channels)):
             xc = x.squeeze(0).permute(1, 2, 0).contiguous()       # (H,W,C): no copy for channels_last input
             out = CRB2dConvFunction.apply(xc, self.conv.weight, self.conv.bias, cfg.eps, self._packer, False)
@@ -376,7 +377,8 @@ class CRB2d(nn.Module):
 
 
 class DeCRB2d(nn.Module):
-    """ConvTranspose2d -> ReLU -> BN2d (reference Blocks.py:42-51); RPN only (next scope row)."""
+    """ConvTranspose2d -> ReLU -> BN2d (reference Blocks.py:42-51); RPN only: used by RPN.forward_torch (the comparison path),
+    the default RPN.forward reads this module's parameters and runs modules/rpn_frames.py."""
 
     def __init__(self, cin, cout, k, s, p):
         super().__init__()
@@ -386,7 +388,7 @@ class DeCRB2d(nn.Module):
         self._hip3x3 = (k == 3 and s == 1 and p == 1 and cin % 64 == 0 and cout % 64 == 0)
 
     def forward(self, x):
-        if (self._hip3x3 and x.is_cuda and x.shape[0] == 1 and cfg.config.get('rpn_hip', False) and not conv_split_math()
+        if (self._hip3x3 and x.is_cuda and x.shape[0] == 1 and cfg.config.get('crb2d_hip', False) and not conv_split_math()
                 and _hip3x3_pays(x, self.deconv.out_channels)):
             xc = x.squeeze(0).permute(1, 2, 0).contiguous()
             out = CRB2dConvFunction.apply(xc, self.deconv.weight, self.deconv.bias, cfg.eps, None, True)

@@ -283,6 +283,139 @@ def prepare_frame_set(batch, T=None):
 
 
 PREP_STREAM = _os.environ.get('MVX_PREP_STREAM', '1') != '0'    # next batch prepared on its own stream (host reads return early)
+# Frame-set lanes: the frames of a step split into this many frame sets that run on their own streams, so that the small
+# latency-bound kernels of one set (BatchNorm passes, VFE, list builders) execute beside the MFMA-bound kernels of the other.
+# Every set keeps per-frame BatchNorm statistics, so the result per frame is unchanged; lane k > 0 accumulates its parameter
+# gradients in a buffer of its own that is added to the bucket once per step (no two streams ever write one address).
+SET_LANES = int(_os.environ.get('MVX_SET_LANES', '1'))
+_LANE_FLAT = {}
+
+
+def prepare_frame_sets(batch, lanes, T=None):
+    """prepare_frame_set for ``lanes`` frame sets over contiguous groups of the batch's non-empty frames: ONE voxelizer call,
+    one compact-row map per set, the same two host reads.  Returns ([(frame set, frame ids)], live ids, counts, status)."""
+    from modules import frames as fr
+    T = cfg.samplenum if T is None else T
+    points6, n_points = batch.prepared()
+    voxels, coords, _, _, vox_off, status_v = _hip.voxelize_concat(points6, batch.perms, n_points, cfg.velorange[0:3],
+                                                                   cfg.voxelsize, T, 9)
+    offs = vox_off.tolist()                         # host read 1
+    counts = [offs[f + 1] - offs[f] for f in range(batch.n_frames)]
+    live = [f for f, v in enumerate(counts) if v > 0]
+    if not live:
+        return [], [], counts, status_v
+    lanes = max(1, min(lanes, len(live)))
+    per = (len(live) + lanes - 1) // lanes
+    sets = []
+    for k in range(0, len(live), per):
+        ids = live[k:k + per]
+        off = [0]
+        for f in ids:
+            off.append(off[-1] + counts[f])
+        # empty frames hold no voxels, so the voxels of a group of live frames are contiguous in the concatenated layout
+        a = offs[ids[0]]
+        sets.append((fr.FrameSet(voxels[a:a + off[-1]], coords[a:a + off[-1]], off, T), ids))
+    devs = [fs.enqueue_map() for fs, _ in sets]
+    for (fs, _), d in zip(sets, devs):
+        fs.finish_map(d.tolist())                   # host read 2 (the later ones return at once)
+    return sets, live, counts, status_v
+
+
+def _lane_flat(flat, k):
+    key = (flat.data_ptr(), flat.numel(), k)
+    buf = _LANE_FLAT.get(key)
+    if buf is None:
+        buf = torch.zeros_like(flat)
+        _LANE_FLAT[key] = buf
+    return buf
+
+
+def _train_step_frame_set_lanes(model, batch, grad_mid, imsize, ready, prepare_next, keep_mid):
+    """train_step_frame_set with SET_LANES > 1 (see SET_LANES)."""
+    from modules import frames as fr
+    dev = batch.device
+    main = torch.cuda.current_stream(dev)
+    ev_ready = None
+    if ready is None:
+        ready = prepare_frame_sets(batch, SET_LANES)
+    elif len(ready) == 5:
+        ready, ev_ready = ready[:4], ready[4]
+    sets, live, counts, status = ready
+    if ev_ready is not None:
+        main.wait_event(ev_ready)
+        status.record_stream(main)
+    statuses = [status]
+    old_sink, _hip.GRAD_SINK = _hip.GRAD_SINK, True
+    old_async, _hip.ASYNC_WGRAD = _hip.ASYNC_WGRAD, True
+    next_ready = None
+    streams = [main] + lane_streams(dev, max(0, len(sets) - 1))
+    try:
+        if sets:
+            model.prepack()
+            params = [p for p in model.parameters() if p.requires_grad and p.grad is not None]
+            flat = params[0].grad._base
+            if flat is None:
+                raise _hip.X.MvxHipError('frame-set lanes need the flat gradient bucket (modules/parallel.py GradBucket)')
+            lane_state = []
+            for k, (fs, ids) in enumerate(sets):
+                st = streams[k]
+                if st is not main:
+                    st.wait_stream(main)                        # packed weights, zeroed bucket, the preparation event
+                    fs.hand_over(st)
+                elif ev_ready is not None:
+                    fs.hand_over(main)
+                targets = None
+                if k > 0:
+                    lf = _lane_flat(flat, k)
+                    targets = {}
+                    for p in params:
+                        o = (p.grad.data_ptr() - flat.data_ptr()) // 4
+                        targets[id(p)] = lf[o:o + p.numel()].view_as(p)
+                gm = grad_mid if grad_mid.shape[0] == 1 else grad_mid[ids]
+                lane_state.append([st, fs, ids, targets, gm, None, None])
+            with torch.no_grad():
+                for ls in lane_state:                           # forward of every lane, then the backward of every lane
+                    st, fs, ids, targets, gm, _, _ = ls
+                    with torch.cuda.stream(st):
+                        if targets is not None:
+                            _lane_flat(flat, lane_state.index(ls)).zero_()
+                        _hip.arena_begin(dev, doubles=1 << 21)
+                        ls[5], ls[6] = fr.middle_forward(model, fs, [batch.fpn_levels[f] for f in ids], imsize, statuses)
+                for ls in lane_state:
+                    st, fs, ids, targets, gm, mid, saved = ls
+                    with torch.cuda.stream(st), fr.grad_targets(targets):
+                        if gm.device == dev and st is not main:
+                            gm.record_stream(st)
+                        fr.middle_backward(model, saved, gm)
+                    ls[6] = None
+            if keep_mid is not None:
+                for ls in lane_state:
+                    ls[5].record_stream(main)
+                    for k in range(len(ls[2])):
+                        keep_mid.append(ls[5][k:k + 1])
+        if prepare_next is not None:
+            if PREP_STREAM:
+                prep = _prep_stream(dev)
+                with torch.cuda.stream(prep):
+                    nr = prepare_frame_sets(prepare_next, SET_LANES)
+                    ev = torch.cuda.Event()
+                    ev.record(prep)
+                next_ready = nr + (ev,)
+            else:
+                next_ready = prepare_frame_sets(prepare_next, SET_LANES)
+    finally:
+        _hip.GRAD_SINK = old_sink
+        _hip.ASYNC_WGRAD = old_async
+        _hip.arena_end()
+        for st in streams[1:]:
+            main.wait_stream(st)
+        _hip.join_side_stream()
+        if sets:
+            for k in range(1, len(sets)):                       # the other lanes' gradients join the bucket (main stream)
+                flat.add_(_lane_flat(flat, k))
+    if prepare_next is not None:
+        return counts, statuses, next_ready
+    return counts, statuses
 
 
 def train_step_frame_set(model, batch, grad_mid, imsize, ready=None, prepare_next=None, keep_mid=None):
@@ -292,6 +425,8 @@ def train_step_frame_set(model, batch, grad_mid, imsize, ready=None, prepare_nex
     host reads only wait for those few small kernels (which share the GPU with the step), so the host stays a step ahead
     of the GPU."""
     from modules import frames as fr
+    if SET_LANES > 1:
+        return _train_step_frame_set_lanes(model, batch, grad_mid, imsize, ready, prepare_next, keep_mid)
     dev = batch.device
     main = torch.cuda.current_stream(dev)
     ev_ready = None
@@ -432,7 +567,7 @@ def batch_from_dataset(group, names, device, anchorBevs, fpn_fn, cap_points):
     return batch, targets
 
 
-RPN_HIP = _os.environ.get('MVX_RPN_HIP', '1') != '0'       # RPN on this library's kernels (modules/rpn_frames.py); 0 = torch modules
+RPN_HIP = _os.environ.get('MVX_RPN_HIP', '1') != '0'       # RPN frame sets on this library's kernels (modules/rpn_frames.py); 0 = torch modules (MIOpen)
 
 
 def heads_loss(heads, F, h1, w1, targets, criterion, anchors):
@@ -530,7 +665,7 @@ def train_step_full(model, batch, targets, criterion, anchors, imsize, ready=Non
                 leaf = mid.detach().requires_grad_(True)
                 total, parts = None, []
                 for k in range(F):
-                    score, reg = model.backbone.rpn(leaf[k:k + 1])
+                    score, reg = model.backbone.rpn.forward_torch(leaf[k:k + 1])
                     score = score.squeeze(dim=0).permute(1, 2, 0)
                     reg = reg.squeeze(dim=0).permute(1, 2, 0)
                     t = tl[k]

@@ -34,7 +34,30 @@ def _split():
     return cfg.config.get('convmath', 'f32') == 'bf16x3'
 
 
+_GRAD_TARGETS = None        # id(parameter) -> tensor the gradient is ADDED into instead of .grad (the autograd wrapper)
+
+
+class grad_targets:
+    """``with grad_targets({id(p): buffer})``: rpn_backward adds every parameter gradient into the given buffers instead of
+    the parameters' .grad (modules/voxelnet/Pipe.py RPNFunction hands them to the autograd engine)."""
+
+    def __init__(self, mapping):
+        self.mapping = mapping
+
+    def __enter__(self):
+        global _GRAD_TARGETS
+        self.old, _GRAD_TARGETS = _GRAD_TARGETS, self.mapping
+        return self
+
+    def __exit__(self, *exc):
+        global _GRAD_TARGETS
+        _GRAD_TARGETS = self.old
+        return False
+
+
 def _grad_of(p):
+    if _GRAD_TARGETS is not None:
+        return _GRAD_TARGETS[id(p)]
     if p.grad is None or not p.grad.is_contiguous():
         raise X.MvxHipError('the frame-set path adds gradients into existing contiguous .grad buffers (GradBucket)')
     return p.grad

@@ -130,9 +130,49 @@ class CML(nn.Module):
         return self.conv3(self.conv2(self.conv1(x)))
 
 
+class RPNFunction(torch.autograd.Function):
+    """The whole RPN as ONE autograd node on this library's kernels (modules/rpn_frames.py, a frame set of one frame):
+    channels-last planes [planes][H][W][Cp] (BEV channel c*planes + d) -> heads (H/2*W/2, 16) = [cls logits | reg].
+    Backward: rpn_frames.rpn_backward; the parameter gradients go into the existing .grad buffers when the training
+    pipeline opened them (_hip.GRAD_SINK), otherwise they are returned to the autograd engine."""
+
+    @staticmethod
+    def forward(ctx, x_cl, rpn, planes, H, W, Cp, *params):
+        from modules import rpn_frames as rf
+        heads, S = rf.rpn_forward(rpn, x_cl.contiguous(), 1, planes, H, W, Cp)
+        ctx.rpn, ctx.S, ctx.n_params = rpn, S, len(params)
+        ctx.params = params
+        return heads
+
+    @staticmethod
+    def backward(ctx, g):
+        from modules import rpn_frames as rf
+        params = ctx.params
+        direct = _hip.GRAD_SINK and all(p.grad is not None and p.grad.is_contiguous() for p in params)
+        if direct:
+            gx = rf.rpn_backward(ctx.rpn, ctx.S, g)
+            grads = (None,) * len(params)
+        else:
+            flat = torch.zeros((sum(p.numel() for p in params),), dtype=torch.float32, device=g.device)
+            views, off = [], 0
+            for p in params:
+                views.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            with rf.grad_targets({id(p): v for p, v in zip(params, views)}):
+                gx = rf.rpn_backward(ctx.rpn, ctx.S, g)
+            grads = tuple(views)
+        if not _hip.ASYNC_WGRAD:
+            _hip.join_side_stream(g.device)        # the weight gradients were produced on the side stream
+        ctx.S = None
+        return (gx if ctx.needs_input_grad[0] else None, None, None, None, None, None) + grads
+
+
 class RPN(nn.Module):
-    """Region proposal network (reference Pipe.py:45-75).  Next scope row: runs on
-    PyTorch-ROCm/MIOpen through CRB2d/DeCRB2d, same topology and state-dict keys."""
+    """Region proposal network (reference Pipe.py:45-75), same topology and state-dict keys.  On the GPU the forward and
+    backward run on this library's kernels as one autograd node (RPNFunction over modules/rpn_frames.py: the MFMA gather /
+    weight-gradient kernels for the 3x3 layers, row GEMMs for the kernel = stride deconvolutions and the heads; per-frame
+    BatchNorm statistics); ``rpn_hip: False`` in config.yml (or a CPU tensor, or batch > 1) takes the torch modules
+    (CRB2d / DeCRB2d -> MIOpen), which remain as the comparison path of the tests."""
 
     def __init__(self):
         super().__init__()
@@ -145,9 +185,26 @@ class RPN(nn.Module):
         self.cls = nn.Conv2d(768, 2, 1, 1, 0)
         self.reg = nn.Conv2d(768, 14, 1, 1, 0)
 
-    def forward(self, x):
+    def _hip_ok(self, x, H, W):
+        return bool(cfg.config.get('rpn_hip', True)) and x.is_cuda and x.dtype == torch.float32 and H % 8 == 0 and W % 8 == 0
+
+    def forward_cl(self, x_cl, planes, H, W, Cp):
+        """The RPN on the channels-last planes of the CML output [planes][H][W][Cp] (BEV channel c*planes + d, the reshape
+        of VoxelNet.py:36 folded into the first layer's weight): (score (1,2,H/2,W/2), reg (1,14,H/2,W/2))."""
+        params = [p for p in self.parameters()]
+        heads = RPNFunction.apply(x_cl, self, planes, H, W, Cp, *params)
+        v = heads.view(1, H // 2, W // 2, 16)
+        return torch.sigmoid(v[..., :2]).permute(0, 3, 1, 2), v[..., 2:].permute(0, 3, 1, 2)
+
+    def forward_torch(self, x):
         x1 = self.blk1(x)
         x2 = self.blk2(x1)
         x3 = self.blk3(x2)
         up = torch.concat([self.deconv1(x1), self.deconv2(x2), self.deconv3(x3)], dim=1)
         return torch.sigmoid(self.cls(up)), self.reg(up)
+
+    def forward(self, x):
+        if x.dim() == 4 and x.shape[0] == 1 and self._hip_ok(x, x.shape[2], x.shape[3]):
+            H, W = x.shape[2], x.shape[3]
+            return self.forward_cl(x[0].permute(1, 2, 0), 1, H, W, x.shape[1])      # one plane of C channels per site
+        return self.forward_torch(x)

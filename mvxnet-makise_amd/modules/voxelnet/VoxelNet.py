@@ -50,6 +50,7 @@ class VoxelNet(nn.Module):
         self.cml = Pipe.CML()
         self.rpn = Pipe.RPN()
         self.sparse_first_layer = True     # exact input-sparse evaluation of reindex + cml.conv1
+        self.restricted_backward = True    # tile-restricted backward inside the CML chain (exact; see middle_cl)
 
     @staticmethod
     def reindex(x, idx):
@@ -72,19 +73,40 @@ class VoxelNet(nn.Module):
         x = self.svfe.forward_compact(rows, cr)
         return Pipe.FCNMaxFunction.apply(x, self.fcn.fc.weight, self.fcn.fc.bias, cr.V, cr.T, cfg.eps, cr)
 
+    def middle_cl(self, x, idx, compact_rows=None):
+        """Everything before the BEV reshape: (1,N,T,23) [or compact rows], (N,4) -> the normalised CML output as a logical
+        (1,C,D,H,W) view of channels-last storage."""
+        from modules.layers import Blocks
+        x = self.voxel_features(x) if compact_rows is None else self.voxel_features_compact(x, compact_rows)
+        if self.sparse_first_layer:
+            # reindex + cml.conv1 fused on the sparse rows (same numbers as the dense path below).  conv1 -> conv2 -> conv3 is
+            # a chain inside this method -- no intermediate activation has another consumer -- so the restricted backward
+            # forms (gradients only on the tiles a producer reads + closed-form plane sums, DESIGN 3.9) are safe here
+            d, h, w = cfg.voxelshape[2], cfg.voxelshape[0], cfg.voxelshape[1]
+            old, Blocks.RESTRICTED_BACKWARD = Blocks.RESTRICTED_BACKWARD, (Blocks.RESTRICTED_BACKWARD or self.restricted_backward)
+            try:
+                x = self.cml.conv1.forward_voxels(x, idx.contiguous(), (d, h, w))
+                x = self.cml.conv3(self.cml.conv2(x))
+            finally:
+                Blocks.RESTRICTED_BACKWARD = old
+        else:
+            x = self.cml(self.reindex(x, idx))
+        return x
+
     def middle(self, x, idx, compact_rows=None):
         """Everything before the RPN: (1,N,T,23), (N,4) -> (1,128,H,W), channel = c*2+d.
         With ``compact_rows`` x is the compact row matrix instead of the dense tensor."""
-        x = self.voxel_features(x) if compact_rows is None else self.voxel_features_compact(x, compact_rows)
-        if self.sparse_first_layer:
-            # reindex + cml.conv1 fused on the sparse rows (same numbers as the dense path below)
-            d, h, w = cfg.voxelshape[2], cfg.voxelshape[0], cfg.voxelshape[1]
-            x = self.cml.conv1.forward_voxels(x, idx.contiguous(), (d, h, w))
-            x = self.cml.conv3(self.cml.conv2(x))
-        else:
-            x = self.cml(self.reindex(x, idx))
-        return BEVFunction.apply(x)
+        return BEVFunction.apply(self.middle_cl(x, idx, compact_rows))
 
-    def forward(self, x, idx):
-        score, reg = self.rpn(self.middle(x, idx))
+    def heads(self, x_cl5):
+        """RPN on the CML output (logical (1,C,D,H,W), channels-last storage).  On the GPU the (1,C*D,H,W) reshape of
+        VoxelNet.py:36 is folded into the first RPN layer (modules/rpn_frames.py reads the planes directly)."""
+        _, c, d, h, w = x_cl5.shape
+        if self.rpn._hip_ok(x_cl5, h, w):
+            planes = x_cl5[0].permute(1, 2, 3, 0)                  # (D,H,W,C): no copy for channels-last storage
+            return self.rpn.forward_cl(planes, d, h, w, c)
+        return self.rpn.forward_torch(BEVFunction.apply(x_cl5))
+
+    def forward(self, x, idx, compact_rows=None):
+        score, reg = self.heads(self.middle_cl(x, idx, compact_rows))
         return score, reg

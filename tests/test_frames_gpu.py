@@ -144,3 +144,46 @@ def test_frame_set_bf16x3_matches_per_frame_bf16x3_and_f32(golden, small_cfg):
         assert rel_err(a, c) < 1e-4                      # against the exact-f32 mode
     for k, p in hot:
         assert rel_err(p.grad, ref[k]) < 2e-3, k
+
+
+@pytest.mark.parametrize('B,with_empty', [(4, False), (4, True), (3, False)])
+def test_frame_set_lanes_equal_one_frame_set(golden, small_cfg, B, with_empty):
+    """MVX_SET_LANES = 2: the frames of a step as TWO frame sets on two streams (modules/pipeline.py) -- per-frame BatchNorm
+    statistics, so every frame's map is that of the single frame set; the parameter gradients (second lane accumulated in
+    its own buffer, added once) equal the single set's up to the order of the sums over the frames.  Repeated with the next
+    batch prepared on the preparation stream, as bench.py runs it."""
+    import modules.pipeline as pl
+    from MVXNet import MVXNet
+    from modules import parallel
+    torch.manual_seed(3)
+    model = MVXNet().to(DEV)
+    batch, G = _small_batch(golden, B, with_empty)
+    for f in range(B):
+        nlive = int(batch.n_points[f])
+        if nlive:
+            batch.perms[f, :nlive] = torch.randperm(nlive, generator=torch.Generator().manual_seed(f)).to(DEV)
+    hot = [(k, p) for k, p in model.named_parameters() if p.requires_grad and '.rpn.' not in k]
+    bucket = parallel.GradBucket([p for _, p in hot])
+    imsize = [370.0, 1224.0]
+    Gb = torch.stack([G[0] * (1.0 + 0.5 * f) for f in range(B)])
+    bucket.zero()
+    mids_ref = []
+    nv_ref, _ = pl.train_step_frame_set(model, batch, Gb, imsize, keep_mid=mids_ref)
+    torch.cuda.synchronize()
+    ref = bucket.flat.clone()
+    old = pl.SET_LANES
+    pl.SET_LANES = 2
+    try:
+        ready = None
+        for rep in range(2):
+            bucket.zero()
+            mids = []
+            nv, st, ready = pl.train_step_frame_set(model, batch, Gb, imsize, ready=ready, prepare_next=batch, keep_mid=mids)
+            torch.cuda.synchronize()
+            assert int(torch.stack([s.reshape(()) for s in st]).max()) == 0
+            assert list(nv) == list(nv_ref) and len(mids) == len(mids_ref)
+            for a, b in zip(mids, mids_ref):
+                assert rel_err(a, b) < 1e-6
+            assert rel_err(bucket.flat, ref) < 2e-4
+    finally:
+        pl.SET_LANES = old

@@ -71,6 +71,13 @@ def _smooth_gradient(C=128, H=352, W=400):
     return torch.from_numpy((1e-3 * pat).astype(np.float32))[None]
 
 
+def _smooth_bound(name):
+    """Bound on the max-norm relative distance of a parameter gradient from float64 under the smooth upstream gradient:
+    2.5e-3 for the CML / VFE parameters (measured <= 1.1e-3), 1.2e-2 for the fusion MLP (five BatchNorms over 176 k rows with
+    K = 768 sums in front of them: measured <= 5.9e-3)."""
+    return 1.2e-2 if name.startswith('head.fusion.') else 2.5e-3
+
+
 def test_bench_path_matches_oracle_at_full_size():
     import modules.config as cfg
     import modules.pipeline as pl
@@ -183,8 +190,24 @@ def test_bench_path_matches_oracle_at_full_size():
         for v in P64.values():
             v.grad = None
         smooth_hip = run(singles[0], g_up=Gs)[1]
-        gs = {n: float((smooth_hip[n].cpu().double() - smooth64[n]).abs().max() / smooth64[n].abs().max()) for n, _ in hot}
+
+        def dist(grads_hip):
+            return {n: float((grads_hip[n].cpu().double() - smooth64[n]).abs().max() / smooth64[n].abs().max()) for n, _ in hot}
+        gs = dist(smooth_hip)
         report['param_grad_rel_maxnorm_vs_float64_smooth_upstream'] = gs
+        # Would this comparison notice a 1 % error in a closed-form term of the restricted backward?  Each term is scaled by
+        # 1.01 in turn (modules/frames.py _MUTATE, a test hook) and the same distances are formed: the mutated run must break
+        # the bound asserted below for at least one parameter.
+        from modules import frames as fr
+        detect = {}
+        for term in ('A2', 'A1', 'inact2', 'T3', 'T2'):
+            fr._MUTATE = {term: 1.01}
+            try:
+                gm_ = dist(run(singles[0], g_up=Gs)[1])
+            finally:
+                fr._MUTATE = {}
+            detect[term] = max(gm_[n] / _smooth_bound(n) for n, _ in hot)
+        report['mutation_1pct_worst_ratio_to_bound'] = detect
         # (b) the benchmark's white-noise upstream gradient: the reported worst case (every gradient the residue of 1.4 M
         # cancelling terms)
         mid64.backward(G.double())
@@ -203,7 +226,8 @@ def test_bench_path_matches_oracle_at_full_size():
         assert y['hip_rel_maxnorm'] < 1e-4
         assert e_hip.max() < 1e-3, e_hip.max()
         assert max(gr.values()) < 3e-2, sorted(gr.items(), key=lambda t: -t[1])[:4]
-        assert max(gs.values()) < 1e-3, sorted(gs.items(), key=lambda t: -t[1])[:4]
+        assert all(v < _smooth_bound(n) for n, v in gs.items()), sorted(gs.items(), key=lambda t: -t[1])[:4]
+        assert min(detect.values()) > 1.0, detect          # every 1 % mutation is caught by the bound above
     print(json.dumps(report))
 
 

@@ -139,3 +139,38 @@ def test_mvxnet_without_extractor_matches_reference(golden):
         assert rel_err(v23[0], v23r) < 1e-4
     finally:
         cfg.config['voxelshape'] = old
+
+
+def test_mvxnet_forward_compact_equals_the_dense_formulation(golden):
+    """MVXNet.forward (MVXNet.py:21-27) -- the interface train.py calls -- runs fusion + VFE on compact rows, the first CML
+    layer on the voxel rows, the CML chain with the tile-restricted backward and the RPN as one HIP node; ``compact=False``
+    is the reference's dense (1,N,T,23) formulation through the same modules.  Score / regression maps and every parameter
+    gradient of the two must agree (the in-place zeroing of the padded voxel rows included)."""
+    import modules.config as cfg
+    from MVXNet import MVXNet
+    g = golden('mvxnet_small')
+    old = list(cfg.config['voxelshape'])
+    cfg.config['voxelshape'] = [int(v) for v in g['voxelshape']]
+    try:
+        torch.manual_seed(4)
+        model = MVXNet().to(DEV)
+        feats = [torch.from_numpy(g[k])[None].to(DEV) for k in ('f0', 'f1', 'f2')]
+        idx = torch.from_numpy(g['idx']).to(DEV)
+        imsize = torch.from_numpy(g['imsize_hw']).to(DEV)
+        res = {}
+        for compact in (True, False):
+            model.zero_grad()
+            vox = torch.from_numpy(g['voxels'].copy())[None].to(DEV)
+            score, reg = model(vox, feats, idx, [None], imsize, compact=compact)
+            assert score.shape[:2] == (1, 2) and reg.shape[:2] == (1, 14)
+            (score.square().sum() + reg.square().sum()).backward()
+            res[compact] = (score.detach().clone(), reg.detach().clone(), vox.clone(),
+                            {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+        assert torch.equal(res[True][2], res[False][2])                    # padded rows zeroed in place, both ways
+        assert rel_err(res[True][0], res[False][0]) < 1e-4 and rel_err(res[True][1], res[False][1]) < 1e-3
+        for k in res[False][3]:
+            a, b = res[True][3][k].double(), res[False][3][k].double()
+            # tiny grid: 16 BatchNorms over <= 96 sites in the RPN amplify fp32 rounding; compared in the 2-norm
+            assert float((a - b).norm() / b.norm().clamp_min(1e-30)) < 5e-2, k
+    finally:
+        cfg.config['voxelshape'] = old

@@ -166,7 +166,7 @@ def test_rpn_hip_agrees_with_the_module_path_at_full_size():
     rpn = RPN().to(DEV)
     mid = torch.randn((1, 128, 352, 400), device=DEV)
     with torch.no_grad():
-        s_ref, r_ref = rpn(mid)
+        s_ref, r_ref = rpn.forward_torch(mid)
         heads, S = rf.rpn_forward(rpn, _to_planes(mid), 1, 2, 352, 400, 64)
         score, reg = rf.split_heads(heads, 1, S['h1'], S['w1'])
     assert float((score - s_ref).abs().max()) < 1e-4
@@ -245,3 +245,49 @@ def test_rpn_full_size_maps_match_the_float64_oracle(golden):
     e2_reg = rel(got2[..., 2:], reg[0].permute(1, 2, 0))
     print('  bf16x3: score %.2e (abs), reg %.2e (max-norm rel)' % (e2_score, e2_reg))
     assert e2_score < 5e-4 and e2_reg < 5e-4
+
+
+def test_rpn_module_runs_on_the_hip_node_and_matches_float64():
+    """modules.voxelnet.Pipe.RPN.forward -- the reference's own interface (voxelnet/Pipe.py:67-75), (1,128,H,W) in, (score,
+    reg) out, under autograd -- IS the HIP path (RPNFunction over modules/rpn_frames.py, one frame, one plane of 128
+    channels), not MIOpen: outputs, input gradient and every parameter gradient against a float64 CPU evaluation of the
+    same module, next to the torch / MIOpen path (forward_torch) as the fp32 comparator."""
+    import copy
+    from modules import _hip
+    from modules.voxelnet.Pipe import RPN
+    torch.manual_seed(12)
+    rpn = RPN().to(DEV)
+    x0 = torch.randn((1, 128, 96, 80), device=DEV)
+    res = {}
+    launches = {}
+    for mode in ('hip', 'torch'):
+        rpn.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        l0 = _hip.X.lib.mvx_launch_count()
+        s, r = rpn(x) if mode == 'hip' else rpn.forward_torch(x)
+        (s.square().sum() + r.square().sum()).backward()
+        torch.cuda.synchronize()
+        launches[mode] = _hip.X.lib.mvx_launch_count() - l0
+        res[mode] = (s.detach().cpu(), r.detach().cpu(), x.grad.cpu(), {k: p.grad.cpu() for k, p in rpn.named_parameters()})
+    assert launches['hip'] > 100 and launches['torch'] == 0, launches      # the module's forward runs this library's kernels
+    ref = copy.deepcopy(rpn).cpu().double()
+    ref.zero_grad()
+    x = x0.cpu().double().requires_grad_(True)
+    s, r = ref(x)
+    (s.square().sum() + r.square().sum()).backward()
+    f64 = (s.detach(), r.detach(), x.grad, {k: p.grad for k, p in ref.named_parameters()})
+    assert float((res['hip'][0] - f64[0]).abs().max()) < 1e-4 and rel(res['hip'][1], f64[1]) < 1e-4
+    assert rel(res['hip'][2], f64[2]) < 3 * rel(res['torch'][2], f64[2]) + 1e-4
+    worst = 0.0
+    for k in f64[3]:
+        e_hip, e_ref = rel(res['hip'][3][k], f64[3][k]), rel(res['torch'][3][k], f64[3][k])
+        worst = max(worst, e_hip)
+        assert e_hip < 3 * e_ref + 1e-4, (k, e_hip, e_ref)
+    print('RPN module on the HIP node vs float64: worst parameter-gradient error %.2e' % worst)
+    # gradients accumulate like any autograd node: a second backward doubles them
+    x = x0.clone().requires_grad_(True)
+    s, r = rpn(x)
+    (s.square().sum() + r.square().sum()).backward()
+    torch.cuda.synchronize()
+    k0 = 'blk1.0.conv.weight'
+    assert rel(dict(rpn.named_parameters())[k0].grad.cpu(), 2 * res['hip'][3][k0]) < 1e-5

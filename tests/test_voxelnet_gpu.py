@@ -323,7 +323,7 @@ def test_full_size_background_rewrite_equals_dense_cml():
 
 def test_rpn_hip_blocks_match_miopen_blocks():
     """RPN with its 3x3 / stride-1 blocks (13 CRB2d + deconv1) on the HIP conv kernels against the same module on
-    stock PyTorch-ROCm (config `rpn_hip`).  Maps agree directly; gradients run through 16 BatchNorms over few
+    stock PyTorch-ROCm (config `crb2d_hip`; RPN.forward_torch = the per-module path, not the fused RPNFunction).  Maps agree directly; gradients run through 16 BatchNorms over few
     samples on this small input, so both fp32 implementations are measured against a float64 CPU evaluation of
     the same module and the HIP path may be at most 3x further from it than the stock one."""
     import copy
@@ -333,13 +333,13 @@ def test_rpn_hip_blocks_match_miopen_blocks():
     rpn = RPN().to(DEV)
     x0 = torch.randn((1, 128, 96, 80), device=DEV)
     res = {}
-    old = cfg.config.get('rpn_hip', False)
+    old = cfg.config.get('crb2d_hip', False)
     try:
         for mode in (True, False):
-            cfg.config['rpn_hip'] = 'force' if mode else False
+            cfg.config['crb2d_hip'] = 'force' if mode else False
             rpn.zero_grad()
             x = x0.clone().requires_grad_(True)
-            s, r = rpn(x)
+            s, r = rpn.forward_torch(x)
             (s.square().sum() + r.square().sum()).backward()
             res[mode] = (s.detach().cpu(), r.detach().cpu(), x.grad.cpu(), {k: p.grad.cpu() for k, p in rpn.named_parameters()})
         ref = copy.deepcopy(rpn).cpu().double()
@@ -349,7 +349,7 @@ def test_rpn_hip_blocks_match_miopen_blocks():
         (s.square().sum() + r.square().sum()).backward()
         res['f64'] = (s.detach(), r.detach(), x.grad, {k: p.grad for k, p in ref.named_parameters()})
     finally:
-        cfg.config['rpn_hip'] = old
+        cfg.config['crb2d_hip'] = old
     assert rel_err(res[True][0], res[False][0]) < 1e-3 and rel_err(res[True][1], res[False][1]) < 1e-3
     assert rel_err(res[True][0], res['f64'][0]) < 3 * rel_err(res[False][0], res['f64'][0]) + 1e-5
     assert rel_err(res[True][2], res['f64'][2]) < 3 * rel_err(res[False][2], res['f64'][2]) + 1e-4
