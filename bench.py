@@ -470,14 +470,12 @@ def _run(args, rank, world, dev):
     full = {}
 
     def full_targets():
-        """train.py:44-46 for every frame of the batch: classifyAnchors on the GPU (one host read of two list lengths each)."""
+        """train.py:44-46 for every frame of the batch: classifyAnchors on the GPU, all frames in one kernel pass and one host
+        read of the list lengths (Calc.classifyAnchorsFrames)."""
         from modules import Calc
         d = targets_setup()
-        out = []
-        for _ in range(args.frames):
-            pi, ni, gi = Calc.classifyAnchors(d['gt_bev'], d['gt'][:, [0, 1]], d['bevs'], cfg.velorange, 0.45, 0.6)
-            out.append((pi, ni, gi, d['gt_dev']))
-        return out
+        res = Calc.classifyAnchorsFrames([(d['gt_bev'], d['gt'][:, [0, 1]])] * args.frames, d['bevs'], cfg.velorange, 0.45, 0.6)
+        return [(pi, ni, gi, d['gt_dev']) for pi, ni, gi in res]
 
     def step_full(b=None):
         """The WHOLE model on this library's kernels (train.py:110-164 for B frames): crop + projection, voxelizer,

@@ -696,6 +696,10 @@ int mvx_row_stats_frames(const float *y, double *stats, int64_t rows, int32_t ch
  *   the reference indexes out of bounds there).
  *   One documented difference: when the reference's crossing test fails on a near-degenerate edge (|s2 - s1| <= 1e-6,
  *   :44) its static scratch keeps a point from an EARLIER call; this library takes the edge's start point instead.
+ * mvx_classify_anchors_frames: the same for the frames of a step in ONE walk launch (train.py:46 once per frame): gts / nls /
+ *   nws hold the ground truths of all frames back to back, gt_off_host i32 [n_frames + 1] (HOST memory, read during the
+ *   call) their offsets; frame f's lists go to pos_idx[f][3][cap], neg_idx[f][3][cap], gi[f][cap] (ground-truth ids local
+ *   to the frame) and counts[f][2]; status is OR-ed over the frames.  workspace: the _workspace_bytes of the TOTAL count.
  *
  * mvx_voxel_loss: VoxelLoss forward + backward (modules/voxelnet/Loss.py:15-45; train.py:140,161).
  *   score f32 (l, w, anchors_per_loc) and reg f32 (l, w, 7*anchors_per_loc) through explicit element strides (the RPN's
@@ -714,6 +718,11 @@ int mvx_classify_anchors(const float *gts, int32_t n_gt, const float *anchors, i
                          int32_t anchors_per_loc, const int64_t *nls, const int64_t *nws, float neg_thr, float pos_thr,
                          int32_t window_radius, int64_t *pos_idx, int64_t *neg_idx, int64_t *gi, int64_t cap,
                          int32_t *counts, int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
+int mvx_classify_anchors_frames(const float *gts, const int32_t *gt_off_host, int32_t n_frames, const float *anchors, int32_t l,
+                                int32_t w, int32_t anchors_per_loc, const int64_t *nls, const int64_t *nws, float neg_thr,
+                                float pos_thr, int32_t window_radius, int64_t *pos_idx, int64_t *neg_idx, int64_t *gi,
+                                int64_t cap, int32_t *counts, int32_t *status, void *workspace, size_t workspace_bytes,
+                                void *stream);
 int mvx_voxel_loss(const float *score, int64_t score_sl, int64_t score_sw, int64_t score_sa, const float *reg,
                    int64_t reg_sl, int64_t reg_sw, int64_t reg_sc, const int64_t *pos_idx, int64_t pos_ld,
                    const int64_t *neg_idx, int64_t neg_ld, const int64_t *gi, const int32_t *counts_dev, int32_t n_pos,

@@ -225,23 +225,33 @@ __global__ __launch_bounds__(256) void anchor_window_walk(const float *__restric
     if (overflow) atomicOr(status, 1);
 }
 
-// Single workgroup: concatenates the per-pair lists in pair order into the i64 index triples of the reference.
+// One workgroup per FRAME: concatenates the per-pair lists of the frame's ground truths in pair order into the i64 index
+// triples of the reference.  ``goff`` = ground-truth offsets of the frames (a single frame: {0, n_gt}); frame f writes
+// pos_idx[f][3][cap], neg_idx[f][3][cap], gi[f][cap] (ground-truth ids LOCAL to the frame) and counts[f][2].
+struct GtOffsets { int off[MVX_MAX_FRAMES + 1]; };
+
 __global__ void anchor_concat(const int *__restrict__ pair_counts, const int *__restrict__ pos_list,
-                              const int *__restrict__ neg_list, int n_pairs, int A, int W, int cap_pair,
+                              const int *__restrict__ neg_list, GtOffsets goff, int A, int W, int cap_pair,
                               long long *__restrict__ pos_idx, long long *__restrict__ neg_idx, long long *__restrict__ gi,
                               long long cap, int *__restrict__ counts, int *__restrict__ status) {
     __shared__ int s_scan[17];
     __shared__ int s_base[2];
+    const int f = blockIdx.x;
+    const int g_lo = goff.off[f], pair_lo = g_lo * A, pair_hi = goff.off[f + 1] * A;
+    pos_idx += (size_t)f * 3 * cap;
+    neg_idx += (size_t)f * 3 * cap;
+    gi += (size_t)f * cap;
+    counts += 2 * f;
     if (threadIdx.x == 0) { s_base[0] = 0; s_base[1] = 0; }
     __syncthreads();
-    for (int p0 = 0; p0 < n_pairs; p0 += blockDim.x) {
+    for (int p0 = pair_lo; p0 < pair_hi; p0 += blockDim.x) {
         const int p = p0 + threadIdx.x;
-        const int cp = p < n_pairs ? pair_counts[2 * p] : 0, cn = p < n_pairs ? pair_counts[2 * p + 1] : 0;
+        const int cp = p < pair_hi ? pair_counts[2 * p] : 0, cn = p < pair_hi ? pair_counts[2 * p + 1] : 0;
         int tot_p, tot_n;
         const int op = block_excl_scan_i32(cp, s_scan, &tot_p) + s_base[0];
         const int on = block_excl_scan_i32(cn, s_scan, &tot_n) + s_base[1];
-        if (p < n_pairs) {
-            const long long g = p / A, z = p % A;
+        if (p < pair_hi) {
+            const long long g = p / A - g_lo, z = p % A;
             for (int k = 0; k < cp; ++k) {
                 const long long o = op + k;
                 if (o >= cap) { atomicOr(status, 2); break; }
@@ -290,18 +300,24 @@ extern "C" size_t mvx_classify_anchors_workspace_bytes(int32_t n_gt, int32_t anc
     return pairs * (2 + 2 * wn * wn) * sizeof(int32_t) + 256;
 }
 
-extern "C" int mvx_classify_anchors(const float *gts, int32_t n_gt, const float *anchors, int32_t l, int32_t w,
-                                    int32_t anchors_per_loc, const int64_t *nls, const int64_t *nws, float neg_thr,
-                                    float pos_thr, int32_t window_radius, int64_t *pos_idx, int64_t *neg_idx, int64_t *gi,
-                                    int64_t cap, int32_t *counts, int32_t *status, void *workspace, size_t workspace_bytes,
-                                    void *stream) {
-    MVX_CHECK_ARG(n_gt >= 0 && l > 0 && w > 0 && anchors_per_loc > 0 && window_radius >= 1 && window_radius <= 55);
+extern "C" int mvx_classify_anchors_frames(const float *gts, const int32_t *gt_off_host, int32_t n_frames, const float *anchors,
+                                           int32_t l, int32_t w, int32_t anchors_per_loc, const int64_t *nls, const int64_t *nws,
+                                           float neg_thr, float pos_thr, int32_t window_radius, int64_t *pos_idx,
+                                           int64_t *neg_idx, int64_t *gi, int64_t cap, int32_t *counts, int32_t *status,
+                                           void *workspace, size_t workspace_bytes, void *stream) {
+    MVX_CHECK_ARG(gt_off_host && n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
+    MVX_CHECK_ARG(l > 0 && w > 0 && anchors_per_loc > 0 && window_radius >= 1 && window_radius <= 55);
     MVX_CHECK_ARG(counts && status && cap >= 0);
     MVX_CHECK_ARG((long long)l * w < (1ll << 31));
+    GtOffsets goff;
+    for (int f = 0; f <= MVX_MAX_FRAMES; ++f) goff.off[f] = gt_off_host[f < n_frames ? f : n_frames];
+    MVX_CHECK_ARG(goff.off[0] == 0);
+    for (int f = 0; f < n_frames; ++f) MVX_CHECK_ARG(goff.off[f + 1] >= goff.off[f]);
+    const int n_gt = goff.off[n_frames];
     hipStream_t st = (hipStream_t)stream;
     const int pairs = n_gt * anchors_per_loc;
     if (pairs == 0) {
-        hipError_t e = hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), st);
+        hipError_t e = hipMemsetAsync(counts, 0, 2 * sizeof(int32_t) * n_frames, st);
         return e == hipSuccess ? MVX_OK : (int)e;
     }
     MVX_CHECK_ARG(gts && anchors && nls && nws && pos_idx && neg_idx && gi && workspace);
@@ -310,12 +326,25 @@ extern "C" int mvx_classify_anchors(const float *gts, int32_t n_gt, const float 
     int *pair_counts = (int *)workspace;
     int *pos_list = pair_counts + 2 * (size_t)pairs;
     int *neg_list = pos_list + (size_t)pairs * cap_pair;
+    // ONE walk launch for the ground truths of all frames (a workgroup per (ground truth, orientation) pair) ...
     hipLaunchKernelGGL(anchor_window_walk, dim3(pairs), dim3(256), (size_t)cap_pair * sizeof(float), st, gts, anchors, l, w,
                        anchors_per_loc, (const long long *)nls, (const long long *)nws, neg_thr, pos_thr, window_radius,
                        pair_counts, pos_list, neg_list, cap_pair, status);
     MVX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(anchor_concat, dim3(1), dim3(1024), 0, st, pair_counts, pos_list, neg_list, pairs, anchors_per_loc, w,
+    // ... and one concatenation workgroup per frame
+    hipLaunchKernelGGL(anchor_concat, dim3(n_frames), dim3(1024), 0, st, pair_counts, pos_list, neg_list, goff, anchors_per_loc, w,
                        cap_pair, (long long *)pos_idx, (long long *)neg_idx, (long long *)gi, (long long)cap, counts, status);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
+}
+
+extern "C" int mvx_classify_anchors(const float *gts, int32_t n_gt, const float *anchors, int32_t l, int32_t w,
+                                    int32_t anchors_per_loc, const int64_t *nls, const int64_t *nws, float neg_thr,
+                                    float pos_thr, int32_t window_radius, int64_t *pos_idx, int64_t *neg_idx, int64_t *gi,
+                                    int64_t cap, int32_t *counts, int32_t *status, void *workspace, size_t workspace_bytes,
+                                    void *stream) {
+    MVX_CHECK_ARG(n_gt >= 0);
+    const int32_t off[2] = {0, n_gt};
+    return mvx_classify_anchors_frames(gts, off, 1, anchors, l, w, anchors_per_loc, nls, nws, neg_thr, pos_thr, window_radius,
+                                       pos_idx, neg_idx, gi, cap, counts, status, workspace, workspace_bytes, stream);
 }

@@ -94,6 +94,55 @@ def classifyAnchors(gts: torch.Tensor, gtCenters: torch.Tensor, anchors: torch.T
     return pi, ni, gi[:n_pos]
 
 
+def classifyAnchorsFrames(frames, anchors: torch.Tensor, velorange: Sequence[float], negThr: float, posThr: float, device=None):
+    """classifyAnchors (train.py:46) for the frames of a step with ONE kernel pass and ONE host read: ``frames`` = per frame
+    ``(gts (G,4,2), gtCenters (G,2))`` or None (no box).  Returns per frame ``(pi, ni, gi)`` exactly as classifyAnchors
+    would (ground-truth ids local to the frame), or None."""
+    dev = torch.device(device) if device is not None else (anchors.device if anchors.is_cuda else X.device())
+    live = [k for k, fr in enumerate(frames) if fr is not None and fr[0].shape[0] > 0]
+    out = [None] * len(frames)
+    if not live:
+        return out
+    a_dev = anchors if anchors.is_cuda else _anchors_on(anchors, dev)
+    gts = torch.cat([frames[k][0].detach().float().cpu().reshape(-1, 4, 2) for k in live])
+    cen = torch.cat([frames[k][1].detach().float().cpu().reshape(-1, 2) for k in live])
+    off = [0]
+    for k in live:
+        off.append(off[-1] + frames[k][0].shape[0])
+    nls, nws = anchorCenterCells(cen, anchors.shape, velorange)
+    radius = _window_radius(gts, anchors[:2, :2].detach().float().cpu())
+    g_dev = gts.contiguous().to(dev)
+    nls_d, nws_d = nls.to(dev), nws.to(dev)
+    # frame sets hold at most MVX_MAX_FRAMES frames: larger batches go in groups
+    res = {}
+    step = X.MAX_FRAMES
+    for lo in range(0, len(live), step):
+        ids = live[lo:lo + step]
+        sub_off = [o - off[lo] for o in off[lo:lo + len(ids) + 1]]
+        sl = slice(off[lo], off[lo + len(ids)])
+        while True:
+            pos, neg, gi, counts, status = _hip.classify_anchors_frames(g_dev[sl], sub_off, a_dev, nls_d[sl], nws_d[sl], negThr,
+                                                                        posThr, radius)
+            host = torch.cat([counts.reshape(-1), status]).tolist()          # the one host read of the group
+            st = host[-1]
+            if st & 1 and radius < 55:              # a box much larger than estimated: widen the window and replay
+                radius = min(55, radius * 2)
+                continue
+            break
+        if st & 4:
+            raise X.MvxHipError('classifyAnchors: a ground-truth centre lies outside the anchor grid '
+                                '(the reference reads out of bounds there)')
+        if st & 1:
+            raise X.MvxHipError('classifyAnchors: a ground truth overlaps anchors more than 55 cells from its centre')
+        for j, k in enumerate(ids):
+            n_pos, n_neg = host[2 * j], host[2 * j + 1]
+            res[k] = ((pos[j, 0, :n_pos], pos[j, 1, :n_pos], pos[j, 2, :n_pos]),
+                      (neg[j, 0, :n_neg], neg[j, 1, :n_neg], neg[j, 2, :n_neg]), gi[j, :n_pos])
+    for k in live:
+        out[k] = res[k]
+    return out
+
+
 _ANCHOR_CACHE = {}
 
 

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MVX_HIP_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'libmvx_hip.so'))
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _p = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -152,6 +152,7 @@ PROTOTYPES = {
     'mvx_bbox_pairwise': (_i32, [_p, _i32, _p, _i32, _i32, _p, _p]),
     'mvx_classify_anchors_workspace_bytes': (_sz, [_i32, _i32, _i32]),
     'mvx_classify_anchors': (_i32, [_p, _i32, _p, _i32, _i32, _i32, _p, _p, _f32, _f32, _i32, _p, _p, _p, _i64, _p, _p, _p, _sz, _p]),
+    'mvx_classify_anchors_frames': (_i32, [_p, _p, _i32, _p, _i32, _i32, _i32, _p, _p, _f32, _f32, _i32, _p, _p, _p, _i64, _p, _p, _p, _sz, _p]),
     'mvx_voxel_loss': (_i32, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _p, _i32, _p,
                               _i32, _i32, _i32, _f32, _f32, _f32, _p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _p, _p]),
 }

@@ -1117,6 +1117,30 @@ def classify_anchors(gts, anchor_bevs, nls, nws, neg_thr, pos_thr, radius, cap=N
     return pos, neg, gi, counts, status
 
 
+def classify_anchors_frames(gts, gt_off, anchor_bevs, nls, nws, neg_thr, pos_thr, radius):
+    """The frames of a step in one walk launch: gts (G_total,4,2) of all frames back to back, ``gt_off`` host list (F+1).
+    Returns (pos_idx i64 (F,3,cap), neg_idx i64 (F,3,cap), gi i64 (F,cap), counts i32 (F,2), status i32 (1,))."""
+    import ctypes
+    F = len(gt_off) - 1
+    L, W, A = anchor_bevs.shape[:3]
+    dev = anchor_bevs.device
+    wn = 2 * radius + 1
+    gmax = max(gt_off[f + 1] - gt_off[f] for f in range(F))
+    cap = max(1, gmax * A * wn * wn)
+    pos = torch.empty((F, 3, cap), dtype=torch.int64, device=dev)
+    neg = torch.empty((F, 3, cap), dtype=torch.int64, device=dev)
+    gi = torch.empty((F, cap), dtype=torch.int64, device=dev)
+    counts = torch.empty((F, 2), dtype=torch.int32, device=dev)
+    status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ws = workspace(X.lib.mvx_classify_anchors_workspace_bytes(int(gt_off[-1]), A, radius), dev, 'anchors')
+    off = (ctypes.c_int32 * (F + 1))(*[int(v) for v in gt_off])
+    X.check(X.lib.mvx_classify_anchors_frames(X.ptr(gts), off, F, X.ptr(anchor_bevs), L, W, A, X.ptr(nls), X.ptr(nws),
+                                              float(neg_thr), float(pos_thr), int(radius), X.ptr(pos), X.ptr(neg), X.ptr(gi), cap,
+                                              X.ptr(counts), X.ptr(status), X.ptr(ws), ws.numel(), X.stream()),
+            'mvx_classify_anchors_frames')
+    return pos, neg, gi, counts, status
+
+
 def voxel_loss(score, reg, pos_idx, neg_idx, gi, n_pos, n_neg, gts, anchors, A, a, b, eps, want_grads=True,
                dscore_out=None, dreg_out=None):
     """score (L,W,A) / reg (L,W,7A) f32 views with arbitrary strides; pos_idx / neg_idx i64 (3,cap) or None.

@@ -1,0 +1,141 @@
+"""Batch preparation ahead of the step: what the reference does with a ProcessPoolExecutor (train.py:26-49 run in worker
+processes, train.py:185-187) done the MI355X way -- ONE worker thread with its own HIP stream prepares batch k+1 while the
+GPU runs step k:
+
+    host:   points of the B frames -> page-locked staging buffers (two sets, used alternately), the shuffle permutations
+            drawn with np.random (the reference's RNG, train.py -> Preprocessing.py:86);
+    stream: async H2D copies, lidar2Img + (row, col) swap on the GPU (train.py:31-34), classifyAnchors per frame
+            (train.py:46; its host reads wait for THIS stream only), an event;
+    main:   waits for the event, never for the copies.
+
+The worker is a thread, not a process: everything heavy it does (memcpy into pinned memory, HIP calls, numpy's shuffle)
+releases the GIL, and the prepared tensors are device memory that a process pool would have to ship back through IPC.
+``PrefetchLoader`` is an iterator over ``(FrameBatch, targets)``; ``depth`` batches are kept ready."""
+import queue
+import threading
+
+import numpy as np
+import torch
+
+import modules.config as cfg
+from modules import Calc, _hip
+
+
+class _Staging:
+    """Page-locked host buffers of one batch slot (reused: allocating pinned memory per step costs more than the copies)."""
+
+    def __init__(self, B, cap):
+        self.points = torch.zeros((B, cap, 4), dtype=torch.float32).pin_memory()
+        self.perms = torch.zeros((B, cap), dtype=torch.int32).pin_memory()
+        self.n = torch.zeros((B,), dtype=torch.int32).pin_memory()
+        self.free = None            # event recorded after the H2D copies that read this slot
+
+
+class PrefetchLoader:
+    def __init__(self, groups, names_of, device, anchor_bevs, fpn_fn, cap_points, depth=2):
+        """``groups``: iterable of lists of frames as ``modules.data.Load.createDataset`` returns them; ``names_of(frame)``:
+        the frame's name (for ``fpn_fn``); ``fpn_fn(name, device)``: the frame's FPN maps (the frozen extractor or its
+        stand-in); ``cap_points``: point capacity per frame of the resident batch."""
+        self.groups = iter(groups)
+        self.names_of, self.device, self.anchor_bevs, self.fpn_fn = names_of, device, anchor_bevs, fpn_fn
+        self.cap = int(cap_points)
+        self.stream = torch.cuda.Stream(device=device, priority=-1)
+        self.q = queue.Queue(maxsize=max(1, depth))
+        self.slots = {}
+        self.turn = 0
+        self.error = None
+        self.stop = False
+        self.thread = threading.Thread(target=self._work, name='mvx-prefetch', daemon=True)
+        self.thread.start()
+
+    # ---- worker thread
+    def _slot(self, B, cap):
+        key = (B, cap, self.turn)
+        self.turn = (self.turn + 1) % (self.q.maxsize + 2)       # more slots than batches that can be in flight
+        st = self.slots.get(key)
+        if st is None:
+            st = _Staging(B, cap)
+            self.slots[key] = st
+        elif st.free is not None:
+            st.free.synchronize()                                # its previous copies have left the host buffers
+        return st
+
+    def _prepare(self, group):
+        from modules.data.Preprocessing import _calib_products
+        from modules.pipeline import FrameBatch
+        dev = self.device
+        B = len(group)
+        cap = max(self.cap, max(d[0].shape[0] for d in group))
+        st = self._slot(B, cap)
+        for k, d in enumerate(group):
+            P = d[0].shape[0]
+            st.points[k, :P] = torch.from_numpy(np.ascontiguousarray(d[0], dtype=np.float32))
+            a = np.arange(P, dtype=np.int32)
+            np.random.shuffle(a)                                 # the reference's sampling RNG (Preprocessing.py:86)
+            st.perms[k, :P] = torch.from_numpy(a)
+            st.n[k] = P
+        with torch.cuda.stream(self.stream):
+            pts6 = torch.zeros((B, cap, 6), dtype=torch.float32, device=dev)
+            pts6[:, :, :4].copy_(st.points, non_blocking=True)
+            perms = st.perms.to(dev, non_blocking=True)
+            n = st.n.to(dev, non_blocking=True)
+            st.free = torch.cuda.Event()
+            st.free.record(self.stream)
+            fpn = []
+            for k, (velo, img, bbox2d, bbox3d, bev, calib) in enumerate(group):
+                P = velo.shape[0]
+                m, p2 = _calib_products(calib, True)
+                _hip.lidar2img(pts6[k, :P], m, p2, math_f32=True, out=pts6[k, :P], col_offset=4, swap_rc=True)    # reads x y z, writes cols 4:6 of the same rows
+                fpn.append(self.fpn_fn(self.names_of(group[k]), dev))
+            boxes = [(d[4], d[3][:, [0, 1]]) if (d[4] is not None and d[4].shape[0] != 0) else None for d in group]
+            lists = Calc.classifyAnchorsFrames(boxes, self.anchor_bevs, cfg.velorange, 0.45, 0.6)      # one pass, one host read
+            targets = [None if t is None else (t[0], t[1], t[2], d[3].to(dev)) for t, d in zip(lists, group)]
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return FrameBatch(pts6, perms, n, fpn), targets, ev
+
+    def _work(self):
+        try:
+            torch.cuda.set_device(self.device)
+            for group in self.groups:
+                if self.stop:
+                    break
+                self.q.put(self._prepare(group) if group else (None, None, None))
+        except BaseException as e:                               # noqa: BLE001 -- handed to the consumer
+            self.error = e
+        finally:
+            self.q.put(None)
+
+    # ---- consumer
+    def close(self):
+        """Stop preparing (the consumer left the loop early): lets the worker run out and drops what it had ready."""
+        self.stop = True
+        while self.thread.is_alive():
+            try:
+                self.q.get(timeout=0.05)
+            except queue.Empty:
+                pass
+        self.thread.join()
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item = self.q.get()
+        if item is None:
+            if self.error is not None:
+                raise self.error
+            raise StopIteration
+        batch, targets, ev = item
+        if batch is None:
+            return None, None
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(ev)
+        for t in [batch.points6, batch.perms, batch.n_points] + [f for lv in batch.fpn_levels for f in lv]:
+            t.record_stream(main)
+        for t in targets:
+            if t is not None:
+                for x in tuple(t[0]) + tuple(t[1]) + (t[2], t[3]):
+                    if isinstance(x, torch.Tensor) and x.is_cuda:
+                        x.record_stream(main)
+        return batch, targets

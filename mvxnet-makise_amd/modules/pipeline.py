@@ -546,7 +546,7 @@ def batch_from_dataset(group, names, device, anchorBevs, fpn_fn, cap_points):
     pts6 = torch.zeros((B, cap_points, 6), dtype=torch.float32, device=device)
     perms = np.zeros((B, cap_points), np.int32)
     n = np.zeros((B,), np.int32)
-    fpn, targets = [], []
+    fpn = []
     for k, (velo, img, bbox2d, bbox3d, bev, calib) in enumerate(group):
         P = velo.shape[0]
         src = torch.from_numpy(np.ascontiguousarray(velo, dtype=np.float32)).to(device)
@@ -558,11 +558,10 @@ def batch_from_dataset(group, names, device, anchorBevs, fpn_fn, cap_points):
         perms[k, :P] = a
         n[k] = P
         fpn.append(fpn_fn(names[k], device))
-        if bev is not None and bev.shape[0] != 0:
-            pi, ni, gi = Calc.classifyAnchors(bev, bbox3d[:, [0, 1]], anchorBevs, cfg.velorange, 0.45, 0.6)
-            targets.append((pi, ni, gi, bbox3d.to(device)))
-        else:
-            targets.append(None)
+    # target assignment of all frames in one kernel pass / one host read
+    boxes = [(d[4], d[3][:, [0, 1]]) if (d[4] is not None and d[4].shape[0] != 0) else None for d in group]
+    lists = Calc.classifyAnchorsFrames(boxes, anchorBevs, cfg.velorange, 0.45, 0.6)
+    targets = [None if t is None else (t[0], t[1], t[2], d[3].to(device)) for t, d in zip(lists, group)]
     batch = FrameBatch(pts6, torch.from_numpy(perms).to(device), torch.from_numpy(n).to(device), fpn)
     return batch, targets
 

@@ -42,13 +42,15 @@ def parse_args(argv=None):
     ap.add_argument('--checkpoints', default='./checkpoints')
     ap.add_argument('--need-crop', action='store_true', help='read training/velodyne and crop on the GPU (cropdata.py on the fly)')
     ap.add_argument('--quiet', action='store_true')
+    ap.add_argument('--no-prefetch', action='store_true', help='--mode fast: prepare every batch inside its step (no loader thread)')
     return ap.parse_args(argv)
 
 
 def fpn_maps_for(name, dev):
-    """Stand-in for the frozen extractor when torchvision is absent: deterministic maps per frame name."""
-    g = torch.Generator(device='cpu').manual_seed(3000 + int(name))
-    return [torch.randn((1, 256, h, w), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    """Stand-in for the frozen extractor when torchvision is absent: deterministic maps per frame name, generated on the
+    device (47 MB per frame: drawing them on the host would make the stand-in the slowest part of the loop)."""
+    g = torch.Generator(device=dev).manual_seed(3000 + int(name))
+    return [torch.randn((1, 256, h, w), generator=g, device=dev).contiguous(memory_format=torch.channels_last)
             for h, w in ((104, 336), (52, 168), (26, 84))]
 
 
@@ -104,7 +106,9 @@ def train(args):
             torch.distributed.barrier()
     with open(os.path.join(args.dataroot, 'ImageSets/train.txt'), 'r') as f:
         trainSet = f.read().splitlines()
+    t_ds = time.perf_counter()
     trainDataSet = load.createDataset(trainSet, needCrop=args.need_crop, root=args.dataroot)
+    dataset_s = time.perf_counter() - t_ds           # file I/O: the whole split is read into RAM first, like train.py:53-57
     names = {id(d): n for d, n in zip(trainDataSet, trainSet)}
 
     anchors = pre.createAnchors(cfg.voxelshape[0] // 2, cfg.voxelshape[1] // 2, cfg.velorange, cfg.carsize)
@@ -124,7 +128,7 @@ def train(args):
     tv = have_torchvision()
 
     forwardTime = lossTime = backwardTime = 0.0
-    steps_done, losses = 0, []
+    steps_done, losses, loop_stats = 0, [], []
     for epoch in range(args.numepochs):
         random.Random(epoch + args.lastiter).shuffle(trainDataSet)
         mine = trainDataSet
@@ -178,31 +182,68 @@ def train(args):
             # (train.py:110) -- so a rank may get fewer than B frames, or none: it still takes part in the all-reduce with
             # a zero gradient, and the divisor is the number of frames that contributed on all ranks.
             chunks = fast_chunks(len(trainDataSet), B, world)
-            for gstep, (lo, hi) in enumerate(chunks):
-                group = trainDataSet[lo + rank:hi:world]
+            groups = [trainDataSet[lo + rank:hi:world] for lo, hi in chunks]
+            cap = max(args.points, max(d[0].shape[0] for d in trainDataSet))
+            if args.no_prefetch:
+                def batches():
+                    for group in groups:
+                        if not group:
+                            yield None, None
+                        else:
+                            yield pl.batch_from_dataset(group, [names[id(d)] for d in group], device, anchorBevs, fpn_maps_for, cap_points=cap)
+                loader = batches()
+            else:
+                # batch k+1 is prepared by a worker thread on its own stream while step k runs (the reference overlaps its CPU
+                # preparation with a process pool, train.py:185-187)
+                from modules.data.Prefetch import PrefetchLoader
+                loader = PrefetchLoader(groups, lambda d: names[id(d)], device, anchorBevs, fpn_maps_for, cap)
+            pending = None                        # the losses of a step are read one step later: the host never waits for
+                                                  # the step it has just enqueued
+
+            def account(p):
+                nonlocal clsLossSum, clsCnt, regLossSum, regCnt
+                if p is None:
+                    return
+                pl.read_losses(p)
+                losses.extend(p['loss'])
+                clsLossSum += sum(p['cls'])
+                clsCnt += len(p['cls'])
+                regLossSum += sum(p['reg'])
+                regCnt += len(p['reg'])
+
+            t_epoch = time.perf_counter()
+            frames_epoch = 0
+            for gstep, ((lo, hi), (batch, targets)) in enumerate(zip(chunks, loader)):
                 st = time.perf_counter()
                 bucket.zero()
                 used = 0
-                if group:
-                    batch, targets = pl.batch_from_dataset(group, [names[id(d)] for d in group], device, anchorBevs,
-                                                           fpn_maps_for, cap_points=max(args.points, max(d[0].shape[0] for d in group)))
-                    out = pl.train_step_full(model, batch, targets, criterion, anchors, cfg.imsize)
+                out = None
+                if batch is not None:
+                    out = pl.train_step_full(model, batch, targets, criterion, anchors, cfg.imsize, read=False)
                     used = len(out['live'])
-                    if used < len(group):
-                        say('Epoch%d step %d: %d frame(s) without a voxel skipped' % (epoch + args.lastiter + 1, gstep, len(group) - used))
-                    losses.extend(out['loss'])
-                    clsLossSum += sum(out['cls'])
-                    clsCnt += len(out['cls'])
-                    regLossSum += sum(out['reg'])
-                    regCnt += len(out['reg'])
+                    if used < batch.n_frames:
+                        say('Epoch%d step %d: %d frame(s) without a voxel skipped' % (epoch + args.lastiter + 1, gstep, batch.n_frames - used))
                 forwardTime += time.perf_counter() - st
-                bucket.all_reduce_mean(parallel.global_count(used, device))
+                bucket.all_reduce_mean(parallel.global_count(used, device) if world > 1 else max(1, used))
                 opt.step()
+                account(pending)
+                pending = out
+                frames_epoch += hi - lo
                 steps_done += 1
                 say('Epoch%d %d/%d  average classification loss %.6f, average regression loss %.6f'
                     % (epoch + args.lastiter + 1, hi, len(trainDataSet), clsLossSum / max(1, clsCnt), regLossSum / max(1, regCnt)))
                 if args.steps and steps_done >= args.steps:
                     break
+            account(pending)
+            if hasattr(loader, 'close'):
+                loader.close()
+            torch.cuda.synchronize(device)
+            loop_s = time.perf_counter() - t_epoch
+            loop_stats.append({'epoch': epoch + args.lastiter + 1, 'frames': frames_epoch, 'seconds': loop_s,
+                               'frames_per_s': frames_epoch / loop_s if loop_s > 0 else 0.0})
+            say('Epoch%d: %d frames in %.2f s = %.1f frames/s (all ranks, %s)'
+                % (epoch + args.lastiter + 1, frames_epoch, loop_s, frames_epoch / max(loop_s, 1e-9),
+                   'batches prepared inside the step' if args.no_prefetch else 'prefetch thread'))
         if rank == 0:
             n = epoch + args.lastiter + 1
             torch.save(model.state_dict(), os.path.join(args.checkpoints, 'epoch%d.pkl' % n))
@@ -212,7 +253,8 @@ def train(args):
     if args.mode == 'fast':
         parallel.assert_replicas_in_sync(params)
     say('forward %.2f s, loss %.2f s, backward %.2f s' % (forwardTime, lossTime, backwardTime))
-    return {'losses': losses, 'steps': steps_done, 'model': model, 'opt': opt}
+    return {'losses': losses, 'steps': steps_done, 'model': model, 'opt': opt, 'loop': loop_stats, 'dataset_s': dataset_s,
+            'dataset_frames': len(trainDataSet)}
 
 
 if __name__ == '__main__':

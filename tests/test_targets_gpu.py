@@ -121,3 +121,30 @@ def test_voxel_loss_edge_cases(golden):
     tn = tuple(torch.from_numpy(c) for c in ni)
     np.testing.assert_allclose(score2.grad.cpu()[tn].numpy(), g['dscore_neg_nopos'], rtol=1e-5, atol=1e-10)
     np.testing.assert_allclose(score2.grad.cpu().reshape(-1)[torch.from_numpy(g['sel_nopos'])].numpy(), g['vals_nopos'], rtol=1e-5)
+
+
+def test_classify_anchors_frames_equals_per_frame_calls(golden):
+    """Calc.classifyAnchorsFrames: the frames of a step in ONE walk launch and one host read (mvx_classify_anchors_frames) give,
+    per frame, exactly the lists of a classifyAnchors call on that frame alone -- the four reference fixtures as four frames
+    of one batch (different box counts, ground-truth ids local to each frame), with a frame without boxes in between."""
+    from modules import Calc
+    tags = ('a', 'b', 'one', 'thr')
+    gs = [golden('classify_anchors_' + t) for t in tags]
+    _, bevs = _grid(gs[0])
+    frames, want = [], []
+    for g in gs[:3]:                                   # same thresholds (0.45 / 0.6) in the first three fixtures
+        assert abs(float(g['thr'][0]) - 0.45) < 1e-6 and abs(float(g['thr'][1]) - 0.6) < 1e-6
+        gt = torch.from_numpy(g['gt'])
+        frames.append((Calc.bbox3d2bev(gt), gt[:, [0, 1]]))
+        want.append(g)
+    frames.insert(1, None)
+    want.insert(1, None)
+    res = Calc.classifyAnchorsFrames(frames, bevs.cuda().contiguous(), list(gs[0]['velorange']), 0.45, 0.6)
+    assert len(res) == 4 and res[1] is None
+    for r, g in zip(res, want):
+        if g is None:
+            continue
+        pi, ni, gi = r
+        for got, key in zip(list(pi) + list(ni) + [gi], ('px', 'py', 'pz', 'nx', 'ny', 'nz', 'gi')):
+            assert got.is_cuda and got.dtype == torch.int64
+            assert np.array_equal(got.cpu().numpy(), g[key]), key
