@@ -647,7 +647,10 @@ int mvx_cl_to_bev_frames(const float *cl, float *bev, int32_t d, int32_t h, int3
  *                              bit 1 of for_dgrad set (2-D source kernel).  MVX_FLAG_TAPS2: only taps {0,1}^2 carry weight:
  *                              a stride-2 3x3 convolution (padding 1) of an image X equals this 2x2-window convolution of
  *                              space_to_depth(X) with the weight rearranged as W2[co][(pr,pc,ci)][ta][tb] = W[co][ci][a][b],
- *                              a -> (ta, pr): 0 -> (0,1), 1 -> (1,0), 2 -> (1,1), likewise b -> (tb, pc).
+ *                              a -> (ta, pr): 0 -> (0,1), 1 -> (1,0), 2 -> (1,1), likewise b -> (tb, pc).  Only 9 of the 16
+ *                              (window tap, parity) blocks of W2 hold a kernel tap; the other 7 are zero BY THIS DEFINITION
+ *                              and the three kernels do not execute them (forward / dgrad / wgrad run the true 9-tap FLOPs,
+ *                              the weight gradient of those blocks is returned as zero).
  *   mvx_conv2d_dgrad_frames    dx from dz (flipped window {1,2}^2 under MVX_FLAG_TAPS2)
  *   mvx_conv2d_wgrad_frames    dw f32 [cout][cin][3][3] summed over all frames; cin % 64 == 0, cout % 64 == 0
  *   mvx_space_to_depth_frames  in [F*planes][h][w][c] -> out [F][h/2][w/2][4][planes][c], channel block p = 2*(y&1) + (x&1)

@@ -78,16 +78,23 @@ __global__ __launch_bounds__(256) void row_stats(const float *__restrict__ y, do
 // backward, pass 1: sums[f][rep][0][c] = sum dyh, [1][c] = sum dyh * yhat   (yhat = (y - mean) * inv), per frame f.
 // A block owns a CONTIGUOUS run of rows (rows_per_block) and makes one reduction pass per row segment it meets
 // (almost always one: segments are whole frames).
+// TRIP rows per thread per trip = 2 * TRIP independent 16-byte loads in flight (the pass is pure streaming: what limits it is
+// the number of bytes in flight per CU).  The workgroup that finishes last folds the replicas of every frame into
+// ab[f][0][c] = sum dyh / count, ab[f][1][c] = sum dyh * yhat / count, so that pass 2 starts from two floats per channel
+// instead of 2 * REP device-scope f64 reads per thread (atomics-only hand-off as in bn_finalize_by_last_block, common.h).
+template <int TRIP>
 __global__ __launch_bounds__(256) void bn_bwd_reduce(const float *__restrict__ dyh, const float *__restrict__ y,
                                                      const float *__restrict__ mi, double *__restrict__ sums,
-                                                     size_t rows, int C, size_t rows_per_block, FrameMap fm) {
+                                                     size_t rows, int C, size_t rows_per_block, FrameMap fm,
+                                                     unsigned *__restrict__ done_counter, float *__restrict__ ab) {
     __shared__ double red[2][256][4];
+    __shared__ int s_last;
     const int c4 = C >> 2;
     const int rpi = max(1, 256 / c4);
     const int ct = threadIdx.x % c4, rt = threadIdx.x / c4;
     const size_t blk_lo = blockIdx.x * rows_per_block;
     const size_t blk_hi = blk_lo + rows_per_block < rows ? blk_lo + rows_per_block : rows;
-    if (blk_lo >= blk_hi) return;
+    if (blk_lo < blk_hi) {
     const int s_lo = fm.F == 1 ? 0 : fm_seg_of(fm, (long long)blk_lo), s_hi = fm.F == 1 ? 0 : fm_seg_of(fm, (long long)blk_hi - 1);
     for (int sg = s_lo; sg <= s_hi; ++sg) {
         const int f = fm.F == 1 ? 0 : (int)fm.seg_frame[sg];
@@ -101,17 +108,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const float *__restrict__ d
             if (rt < rpi && col < c4) {
                 const float4 m = *(const float4 *)(fmi + col * 4), iv = *(const float4 *)(fmi + C + col * 4);
                 const size_t stride = (size_t)rpi;
-                for (size_t r = lo + rt; r < hi; r += 4 * stride) {
-                    float4 g[4], v[4];
+                for (size_t r = lo + rt; r < hi; r += TRIP * stride) {
+                    float4 g[TRIP], v[TRIP];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {              // 8 independent 16-byte loads in flight
+                    for (int j = 0; j < TRIP; ++j) {
                         const size_t rr = r + j * stride;
                         const bool ok = rr < hi;
                         g[j] = ok ? *(const float4 *)(dyh + rr * C + col * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
                         v[j] = ok ? *(const float4 *)(y + rr * C + col * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < TRIP; ++j) {
                         s1.x += g[j].x; s1.y += g[j].y; s1.z += g[j].z; s1.w += g[j].w;
                         s2.x += g[j].x * ((v[j].x - m.x) * iv.x); s2.y += g[j].y * ((v[j].y - m.y) * iv.y);
                         s2.z += g[j].z * ((v[j].z - m.z) * iv.z); s2.w += g[j].w * ((v[j].w - m.w) * iv.w);
@@ -132,11 +139,38 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const float *__restrict__ d
             __syncthreads();
         }
     }
+    }
+    // ---- the last workgroup: (a, b) of every frame and channel
+    mvx_drain_vmem();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(done_counter, 1u) == gridDim.x - 1u);
+    __syncthreads();
+    if (!s_last) return;
+    for (int e = threadIdx.x; e < C * fm.F; e += blockDim.x) {
+        const int f = e / C, c = e - f * C;
+        const double *fs = sums + (size_t)f * REP * 3 * C;
+        double sa = 0.0, sb = 0.0;
+#pragma unroll 1
+        for (int r0 = 0; r0 < REP; r0 += 8) {
+            double v1[8], v2[8];
+#pragma unroll
+            for (int rp = 0; rp < 8; ++rp) {
+                v1[rp] = __hip_atomic_load(fs + ((size_t)(r0 + rp) * 3 + 0) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v2[rp] = __hip_atomic_load(fs + ((size_t)(r0 + rp) * 3 + 1) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int rp = 0; rp < 8; ++rp) { sa += v1[rp]; sb += v2[rp]; }
+        }
+        const double count = fm.count[f];
+        ab[(size_t)f * 2 * C + c] = (float)(sa / count);
+        ab[(size_t)f * 2 * C + C + c] = (float)(sb / count);
+    }
 }
 
 // backward, pass 2: dz = (y > 0) ? inv * (dyh - s1/N - yhat * s2/N) : 0 ; dbias[c] += sum dz (over ALL frames)
+template <int TRIP>
 __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dyh, const float *__restrict__ y,
-                                                    const float *__restrict__ mi, const double *__restrict__ sums,
+                                                    const float *__restrict__ mi, const float *__restrict__ ab,
                                                     float *__restrict__ dz, double *__restrict__ dbias,
                                                     const float *__restrict__ row_w, size_t rows, int C,
                                                     unsigned *__restrict__ done_counter, float *__restrict__ dbias_out,
@@ -158,26 +192,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dy
             const size_t lo = fm.F == 1 ? blk_lo : max(blk_lo, (size_t)fm.bound[sg]);
             const size_t hi = fm.F == 1 ? blk_hi : min(blk_hi, (size_t)fm.bound[sg + 1]);
             const float *fmi = mi + (size_t)f * 2 * C;
-            const double *fsums = sums + (size_t)f * REP * 3 * C;
-            const double count = fm.count[f];
             if (rt < rpi && col < c4) {
                 const float4 m = *(const float4 *)(fmi + col * 4), iv = *(const float4 *)(fmi + C + col * 4);
-                float a[4], b[4];
-                for (int j = 0; j < 4; ++j) {
-                    double sa = 0.0, sbb = 0.0;
-                    for (int rp = 0; rp < REP; ++rp) {
-                        sa += fsums[((size_t)rp * 3 + 0) * C + col * 4 + j];
-                        sbb += fsums[((size_t)rp * 3 + 1) * C + col * 4 + j];
-                    }
-                    a[j] = (float)(sa / count);
-                    b[j] = (float)(sbb / count);
-                }
+                // written by the last workgroup of pass 1 (an earlier kernel of this stream): plain loads
+                const float4 av = *(const float4 *)(ab + (size_t)f * 2 * C + col * 4);
+                const float4 bv = *(const float4 *)(ab + (size_t)f * 2 * C + C + col * 4);
+                const float a[4] = {av.x, av.y, av.z, av.w}, b[4] = {bv.x, bv.y, bv.z, bv.w};
                 const size_t stride = (size_t)rpi;
-                for (size_t r = lo + rt; r < hi; r += 4 * stride) {
-                    float4 g[4], v[4];
-                    float rw[4];
+                for (size_t r = lo + rt; r < hi; r += TRIP * stride) {
+                    float4 g[TRIP], v[TRIP];
+                    float rw[TRIP];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < TRIP; ++j) {
                         const size_t rr = r + j * stride;
                         const bool ok = rr < hi;
                         g[j] = ok ? *(const float4 *)(dyh + rr * C + col * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -185,7 +211,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dy
                         rw[j] = (ok && row_w) ? row_w[rr] : 1.f;   // a compact row standing for rw dense rows
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < TRIP; ++j) {
                         const size_t rr = r + j * stride;
                         if (rr >= hi) break;
                         float4 o;
@@ -244,6 +270,8 @@ __global__ void dbias_finish(const double *__restrict__ scratch, float *__restri
     b[i] = accumulate ? b[i] + (float)t : (float)t;
 }
 
+constexpr int BWD_TRIP = 4;            // rows per thread in flight in the two BatchNorm-backward passes
+
 inline unsigned row_grid(size_t rows, int C) {
     const int rpi = (256 / (C / 4)) > 1 ? 256 / (C / 4) : 1;
     size_t b = (rows + 4 * (size_t)rpi - 1) / (4 * (size_t)rpi);   // kernels take 4 rows per thread and trip
@@ -297,12 +325,13 @@ extern "C" int mvx_row_stats(const float *y, double *stats, int64_t rows, int32_
 
 extern "C" size_t mvx_bn_backward_scratch_bytes(int32_t channels) {
     // replicated sums + one slot for the "last workgroup" counter of the fused bias-gradient reduction
-    return channels > 0 ? sizeof(double) * (REP * 3 * (size_t)channels + 1) : 0;
+    return mvx_bn_backward_scratch_bytes_frames(channels, 1);
 }
 
 extern "C" size_t mvx_bn_backward_scratch_bytes_frames(int32_t channels, int32_t n_frames) {
     // per frame: replicated (sum dyh, sum dyh*yhat, dbias replica slot); the bias gradient uses frame 0's third slot
-    return channels > 0 && n_frames > 0 ? sizeof(double) * (REP * 3 * (size_t)channels * n_frames + 1) : 0;
+    // ... one slot for the two "last workgroup" counters, and the (a, b) floats of every frame [F][2][C]
+    return channels > 0 && n_frames > 0 ? sizeof(double) * ((REP * 3 + 1) * (size_t)channels * n_frames + 1) : 0;
 }
 
 extern "C" int mvx_bn_relu_backward_frames(const float *dyhat, const float *y, const float *mean_inv, double count,
@@ -320,17 +349,21 @@ extern "C" int mvx_bn_relu_backward_frames(const float *dyhat, const float *y, c
         if (e != hipSuccess) return (int)e;
     }
     if (rows > 0) {
-        const unsigned grid = row_grid(rows, channels);
         const int rpi = (256 / (channels / 4)) > 1 ? 256 / (channels / 4) : 1;
+        // up to 4 workgroups per CU, each with at least two trips of BWD_TRIP x rpi rows
+        size_t want = ((size_t)rows + 2 * BWD_TRIP * rpi - 1) / (2 * (size_t)BWD_TRIP * rpi);
+        const unsigned grid = (unsigned)(want > 1024 ? 1024 : (want ? want : 1));
         size_t rpb = ((size_t)rows + grid - 1) / grid;
-        rpb = (rpb + 4 * rpi - 1) / (4 * (size_t)rpi) * (4 * (size_t)rpi);       // whole (4 x rpi)-row trips
+        rpb = (rpb + BWD_TRIP * rpi - 1) / (BWD_TRIP * (size_t)rpi) * (BWD_TRIP * (size_t)rpi);       // whole (TRIP x rpi)-row trips
         const unsigned blocks = (unsigned)(((size_t)rows + rpb - 1) / rpb);
-        hipLaunchKernelGGL(bn_bwd_reduce, dim3(blocks), dim3(256), 0, st, dyhat, y, mean_inv, scratch, (size_t)rows, channels,
-                           rpb, fm);
+        unsigned *counters = (unsigned *)(scratch + slots);           // [0] pass 2 (bias gradient), [1] pass 1 ((a, b) finalisation)
+        float *ab = (float *)(scratch + slots + 1);
+        hipLaunchKernelGGL(bn_bwd_reduce<BWD_TRIP>, dim3(blocks), dim3(256), 0, st, dyhat, y, mean_inv, scratch, (size_t)rows,
+                           channels, rpb, fm, counters + 1, ab);
         MVX_LAUNCH_CHECK();
-        hipLaunchKernelGGL(bn_bwd_apply, dim3(blocks), dim3(256), 0, st, dyhat, y, mean_inv, (const double *)scratch, dz,
+        hipLaunchKernelGGL(bn_bwd_apply<BWD_TRIP>, dim3(blocks), dim3(256), 0, st, dyhat, y, mean_inv, (const float *)ab, dz,
                            dbias ? scratch + 2 * channels : (double *)nullptr, row_w, (size_t)rows, channels,
-                           (unsigned *)(scratch + slots), dbias, flags & MVX_FLAG_ACCUMULATE, rpb, fm);
+                           counters, dbias, flags & MVX_FLAG_ACCUMULATE, rpb, fm);
         MVX_LAUNCH_CHECK();
     } else if (dbias) {                             // no rows: the bias gradient is zero
         hipLaunchKernelGGL(dbias_finish, dim3(mvx_cdiv(channels, 128)), dim3(128), 0, st, (const double *)scratch, dbias,

@@ -43,7 +43,22 @@ struct Geom {
     int F = 1;                          // frames stacked along the depth axis: global plane = frame * planes + local plane
     int tap_lo = 0, tap_hi = 3;         // in-plane taps (rows AND columns) [tap_lo, tap_hi) carry weight; the others are skipped
                                         // (stride-2 convolutions evaluated on the space-to-depth image use a 2x2 window)
+    int s2d = 0;                        // > 0: the 2x2 window stands for a stride-2 3x3 kernel on the space-to-depth image whose
+                                        // channels are four parity blocks [pr][pc] of s2d channels each: window tap (ta, tb)
+                                        // carries weight for parity (pr, pc) only if (ta == 1 || pr == 1) && (tb == 1 || pc == 1)
+                                        // (include/mvx_hip.h, MVX_FLAG_TAPS2) -- 9 of the 16 (tap, parity) blocks; the others are
+                                        // structural zeros and are not executed
 };
+
+// valid window taps of parity block p = pr * 2 + pc as a 4-bit mask, bit (ta * 2 + tb) (see Geom::s2d)
+__device__ __forceinline__ unsigned s2d_tap_mask(int p) {
+    const int pr = p >> 1, pc = p & 1;
+    unsigned m = 8u;                                   // (1,1) always
+    if (pr) m |= 2u;                                   // (0,1)
+    if (pc) m |= 4u;                                   // (1,0)
+    if (pr && pc) m |= 1u;                             // (0,0)
+    return m;
+}
 
 // source depth plane (global) of GLOBAL output plane d for depth tap kd; -1 if the tap falls outside the frame's volume
 __device__ __forceinline__ int src_depth(const Geom &g, int d, int kd) {
@@ -227,10 +242,11 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
             *(f32x4 *)(s_w + (v >> 1) * WROW + (c >> 3) * BK + (((c & 7) ^ ((c >> 4) & 7)) * 4)) = wreg[v];
         }
     };
-    auto compute_row = [&](int row) __attribute__((always_inline)) {
+    auto compute_row = [&](int row, unsigned colmask = 7u) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             if (t < TLO || t >= THI) continue;
+            if (!((colmask >> t) & 1u)) continue;     // block-uniform: a structurally zero tap of the space-to-depth form
             const int a_off = a_base + row * HROW + t * PITCH;
 #pragma unroll
             for (int q = 0; q < BK / 8; ++q) {
@@ -275,24 +291,60 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
         compute_row(2);
     }
     } else {
-    // two tap rows [r0, r0 + 1] (2 x 2 window): the same pipeline with one row step less per stage
+    // two tap rows [r0, r0 + 1] (2 x 2 window): the same pipeline with one row step less per stage.  With g.s2d the
+    // structurally zero (tap, parity) blocks of a stride-2 kernel in space-to-depth form are skipped: forward (mode 0) the
+    // parity is that of the stage's input-channel chunk, dgrad (mode 1, flipped window {1,2}^2) that of the unit's
+    // output-channel block; window tap of row a / column t: forward (a, t), dgrad (2 - a, 2 - t).
     constexpr int r0 = TLO;
+    auto tap_masks = [&](int st, bool &row0, bool &row1, unsigned &colmask) __attribute__((always_inline)) {
+        row0 = row1 = true;
+        colmask = 7u;
+        if (g.s2d <= 0) return;
+        int p;
+        if (g.mode == 0) {
+            int kd, ds, cc;
+            stage_kd(st, kd, ds, cc);
+            p = (cc * BK) / g.s2d;
+        } else {
+            p = (nb * BN) / g.s2d;
+        }
+        const unsigned m = s2d_tap_mask(p);            // bit (ta * 2 + tb)
+        auto wt = [&](int a) { return g.mode == 0 ? a : 2 - a; };        // window tap of kernel row / column index a
+        const int ta0 = wt(r0), ta1 = wt(r0 + 1);
+        colmask = 0u;
+        bool any0 = false, any1 = false;
+#pragma unroll
+        for (int t = TLO; t < THI; ++t) {
+            const int tb = wt(t);
+            const bool v0 = (m >> (ta0 * 2 + tb)) & 1u, v1 = (m >> (ta1 * 2 + tb)) & 1u;
+            // a column is executed if either row needs it; rows are switched off as a whole below (the valid columns of
+            // the two rows coincide wherever both rows are valid: validity factorises into a row and a column condition)
+            if (v0 || v1) colmask |= 1u << t;
+            any0 |= v0;
+            any1 |= v1;
+        }
+        row0 = any0;
+        row1 = any1;
+    };
     load_wrow(0, r0);
     load_halo(0);
     for (int st = 0; st < nstages; ++st) {
         const int nxt = st + 1 < nstages ? st + 1 : st;
+        bool row0, row1;
+        unsigned colmask;
+        tap_masks(st, row0, row1, colmask);
         __syncthreads();
         store_halo();
         store_wrow();                              // tap row r0
         __syncthreads();
         load_wrow(st, r0 + 1);
         load_halo(nxt);
-        compute_row(r0);
+        if (row0) compute_row(r0, colmask);
         __syncthreads();
         store_wrow();                              // tap row r0 + 1
         __syncthreads();
         load_wrow(nxt, r0);
-        compute_row(r0 + 1);
+        if (row1) compute_row(r0 + 1, colmask);
     }
     }
     }   // active
@@ -568,9 +620,12 @@ __host__ __device__ constexpr int w4_own(bool t2, int grp, int i) {
 }
 __host__ __device__ constexpr int w4_ncomp(bool t2, int grp) { return t2 ? 2 : (grp == 0 ? 5 : 4); }
 
+// ``slots``: bit i = slot i of the group is executed (block-uniform; all ones except for the structurally zero (tap, parity)
+// blocks of a stride-2 kernel in space-to-depth form, Geom::s2d)
 template <bool T2, int GRP>
 __device__ __forceinline__ void wgrad4_mfma_step(const float *__restrict__ s_x, const float *__restrict__ s_z, f32x16 (&acc)[5],
-                                                 int wm, int wn, int li, int lh) {
+                                                 int wm, int wn, int li, int lh, unsigned slots) {
+    if (T2 && slots == 0u) return;
 #pragma unroll 2
     for (int kk = 0; kk < TH * TW / 2; ++kk) {
         const int s = 2 * kk + lh;
@@ -578,6 +633,7 @@ __device__ __forceinline__ void wgrad4_mfma_step(const float *__restrict__ s_x, 
         const float *xa = s_x + ((s >> 4) * HW + (s & 15)) * W4_C + wm * 32 + li;
 #pragma unroll
         for (int i = 0; i < w4_ncomp(T2, GRP); ++i) {
+            if (T2 && !((slots >> i) & 1u)) continue;
             const int t9 = w4_own(T2, GRP, i);
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[((t9 / 3) * HW + (t9 % 3)) * W4_C], b, acc[i], 0, 0, 0);
         }
@@ -673,6 +729,13 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restr
         while (i < nsteps && strip * per + i % per >= ntiles) ++i;      // ragged last strip
         return i < nsteps ? i : nsteps;
     };
+    // stride-2 kernel in space-to-depth form: the window taps that carry weight for this workgroup's parity block
+    // (group 0 owns window taps (0,0), (0,1) = slots 0, 1; group 1 owns (1,0), (1,1))
+    unsigned slots = 0x1fu;
+    if (T2 && g.s2d > 0) {
+        const unsigned m = s2d_tap_mask((cc * W4_C) / g.s2d);
+        slots = grp == 0 ? (m & 3u) : ((m >> 2) & 3u);
+    }
     int cur = next_live(0);
     if (cur < nsteps) load_step(cur);
     while (cur < nsteps) {
@@ -690,8 +753,8 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restr
         __syncthreads();
         const int nxt = next_live(cur + 1);
         load_step(nxt < nsteps ? nxt : cur);          // unconditional (see conv3d_gather_pf): the last one is dropped
-        if (grp == 0) wgrad4_mfma_step<T2, 0>(s_x, s_z, acc, wm, wn, li, lh);
-        else wgrad4_mfma_step<T2, 1>(s_x, s_z, acc, wm, wn, li, lh);
+        if (grp == 0) wgrad4_mfma_step<T2, 0>(s_x, s_z, acc, wm, wn, li, lh, slots);
+        else wgrad4_mfma_step<T2, 1>(s_x, s_z, acc, wm, wn, li, lh, slots);
         cur = nxt;
     }
     // slab[strip][kd][tap][c (Cin)][n (64)]: every tap is written by the group that owns it (zeros where nothing was computed)
@@ -1303,6 +1366,9 @@ extern "C" int mvx_conv2d_forward_frames(const float *in, const float *wpk, cons
         }
     }
     Geom g{1, 1, h, w, cin, cout, 1, 1, 0, n_frames, 0, (flags & MVX_FLAG_TAPS2) ? 2 : 3};
+    // the structurally zero (window tap, parity) blocks of the rearranged stride-2 kernel are not executed (7 of 16), when
+    // the parity blocks are whole K chunks
+    if ((flags & MVX_FLAG_TAPS2) && cin % 4 == 0 && (cin / 4) % BK == 0) g.s2d = cin / 4;
     launch_gather(st, in, wpk, bias, out, stats, g, flags & MVX_FLAG_RELU, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
                   (unsigned *)done_counter, (double)h * w, eps, mean_inv, (unsigned *)work_counter);
     MVX_LAUNCH_CHECK();
@@ -1315,6 +1381,7 @@ extern "C" int mvx_conv2d_dgrad_frames(const float *dz, const float *wpk_dgrad, 
     int rc = conv2d_geom_ok(h, w, cout, cin, n_frames);          // gather view: source dz (cout channels) -> dx (cin channels)
     if (rc) return rc;
     Geom g{1, 1, h, w, cout, cin, 1, 1, 1, n_frames, (flags & MVX_FLAG_TAPS2) ? 1 : 0, 3};
+    if ((flags & MVX_FLAG_TAPS2) && cin % 4 == 0 && (cin / 4) % BN == 0) g.s2d = cin / 4;      // parity of the OUTPUT channel block
     launch_gather((hipStream_t)stream, dz, wpk_dgrad, nullptr, dx, nullptr, g, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
                   nullptr, 0.0, 0.0, nullptr, (unsigned *)work_counter);
     MVX_LAUNCH_CHECK();
@@ -1350,6 +1417,7 @@ extern "C" int mvx_conv2d_wgrad_frames(const float *in, const float *dz, float *
     if (nstrips < 1) nstrips = 1;                                                       // (589 KB per strip at cin 128) stay small
     const int nblk = cout / BN;
     Geom g{1, 1, h, w, cin, cout, 1, 1, 0, n_frames, 0, (flags & MVX_FLAG_TAPS2) ? 2 : 3};
+    if ((flags & MVX_FLAG_TAPS2) && cin % 4 == 0 && (cin / 4) % W4_C == 0) g.s2d = cin / 4;
     float *slabs = (float *)workspace;
     int *list = (int *)((char *)workspace + (size_t)nblk * nstrips * 27 * cin * BN * sizeof(float));
     int *count = list + (size_t)3 * n_frames * ntiles;

@@ -155,7 +155,7 @@ def _conv(x, wpk, bias, F, h, w, cin, cout, flags, eps):
         X.check(X.lib.mvx_bn_finalize_frames(X.ptr(stats), float(h * w), float(eps), X.ptr(mi), cout, F, X.stream()),
                 'mvx_bn_finalize_frames')
         return y, mi
-    nt = 4 if flags & TAPS2 else 9
+    nt = 2.25 if flags & TAPS2 else 9          # space-to-depth form: 9 of the 16 (window tap, parity) blocks are executed
     with _hip._Timed('rpn_conv', 2.0 * F * h * w * cin * cout * nt if _hip.KERNEL_TIMERS is not None else 0):
         X.check(X.lib.mvx_conv2d_forward_frames(X.ptr(x), X.ptr(wpk), X.ptr(bias), X.ptr(y), X.ptr(stats), h, w, cin, cout,
                                                 _hip.FLAG_RELU | fz | flags, X.ptr(fin), float(eps), X.ptr(mi),
@@ -188,7 +188,7 @@ def _dgrad(dz, wpd, F, h, w, cin, cout, flags):
             X.check(X.lib.mvx_conv2d_dgrad_split_frames(X.ptr(dz), X.ptr(wpd), X.ptr(dx), h, w, cin, cout, F, X.stream()),
                     'mvx_conv2d_dgrad_split_frames')
         return dx
-    nt = 4 if flags & TAPS2 else 9
+    nt = 2.25 if flags & TAPS2 else 9
     with _hip._Timed('rpn_conv', 2.0 * F * h * w * cin * cout * nt if _hip.KERNEL_TIMERS is not None else 0):
         X.check(X.lib.mvx_conv2d_dgrad_frames(X.ptr(dz), X.ptr(wpd), X.ptr(dx), h, w, cin, cout, flags,
                                               X.ptr(_hip._work_counter(dz.device)), F, X.stream()), 'mvx_conv2d_dgrad_frames')
