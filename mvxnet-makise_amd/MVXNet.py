@@ -58,9 +58,15 @@ class MVXNet(nn.Module):
         ``compact=True`` (default) evaluates the fusion MLP and the VFE stack on the real rows + one padded row per voxel
         and the first CML layer on the voxel rows: exact for ANY input, because featureMaping zeroes every row whose
         x = y = z = 0 in place (imhead/Pipe.py:54-59), which makes all such rows of a voxel identical from there on
-        (SURVEY Q5); ``compact=False`` is the reference's dense (1,N,T,23) formulation."""
+        (SURVEY Q5).  On the GPU the whole forward is then ONE autograd node over the frame-set kernels (modules/whole.py);
+        ``compact='modules'`` keeps the same arithmetic on the per-module autograd path (modules.voxelnet / imhead / layers),
+        ``compact=False`` is the reference's dense (1,N,T,23) formulation."""
         if not compact:
             return self.backbone(self.point_features(voxels, imgs, calibs, imsize), idx)
+        if compact != 'modules':
+            from modules import whole
+            if whole.supported(self, voxels, idx):
+                return whole.forward(self, voxels, imgs, idx, imsize)
         from modules.voxelnet.Pipe import CompactInputFunction
         imfeat, cr, vox2d = self.head.forward_compact(imgs, voxels, calibs, imsize)
         rows = CompactInputFunction.apply(imfeat, vox2d, cr)

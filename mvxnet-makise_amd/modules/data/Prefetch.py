@@ -2,11 +2,18 @@
 processes, train.py:185-187) done the MI355X way -- ONE worker thread with its own HIP stream prepares batch k+1 while the
 GPU runs step k:
 
-    host:   points of the B frames -> page-locked staging buffers (two sets, used alternately), the shuffle permutations
-            drawn with np.random (the reference's RNG, train.py -> Preprocessing.py:86);
-    stream: async H2D copies, lidar2Img + (row, col) swap on the GPU (train.py:31-34), classifyAnchors per frame
-            (train.py:46; its host reads wait for THIS stream only), an event;
-    main:   waits for the event, never for the copies.
+    worker, host:   points of the B frames -> page-locked staging buffers (a few sets, used in turn), the shuffle
+                    permutations drawn with np.random (the reference's RNG, train.py -> Preprocessing.py:86);
+    worker, stream: ONE async H2D copy per buffer (DMA engines: no compute unit involved) and classifyAnchors of all frames
+                    (train.py:46: two kernels and the one host read of the list lengths, which waits for THIS stream only
+                    instead of draining the training stream), an event;
+    main:           waits for the event, then lidar2Img + (row, col) swap (train.py:31-34) and the FPN maps on the
+                    training stream.
+
+Only the copies and the target assignment run beside the step: a first version that also put the per-frame projection
+and the FPN stand-in (about 25 small launches per batch) on the loader stream was SLOWER than no prefetching at all (82 vs
+138 frames/s on the GPU box): every small kernel of a concurrent stream queues behind the persistent convolution launches
+that hold all CUs for ~0.7 ms each, so the loader needed 49 ms per batch of a 28 ms step.
 
 The worker is a thread, not a process: everything heavy it does (memcpy into pinned memory, HIP calls, numpy's shuffle)
 releases the GIL, and the prepared tensors are device memory that a process pool would have to ship back through IPC.
@@ -25,7 +32,7 @@ class _Staging:
     """Page-locked host buffers of one batch slot (reused: allocating pinned memory per step costs more than the copies)."""
 
     def __init__(self, B, cap):
-        self.points = torch.zeros((B, cap, 4), dtype=torch.float32).pin_memory()
+        self.points = torch.zeros((B, cap, 6), dtype=torch.float32).pin_memory()      # x y z r | row col (filled on the GPU)
         self.perms = torch.zeros((B, cap), dtype=torch.int32).pin_memory()
         self.n = torch.zeros((B,), dtype=torch.int32).pin_memory()
         self.free = None            # event recorded after the H2D copies that read this slot
@@ -61,38 +68,29 @@ class PrefetchLoader:
         return st
 
     def _prepare(self, group):
-        from modules.data.Preprocessing import _calib_products
-        from modules.pipeline import FrameBatch
         dev = self.device
         B = len(group)
         cap = max(self.cap, max(d[0].shape[0] for d in group))
         st = self._slot(B, cap)
         for k, d in enumerate(group):
             P = d[0].shape[0]
-            st.points[k, :P] = torch.from_numpy(np.ascontiguousarray(d[0], dtype=np.float32))
+            st.points[k, :P, :4] = torch.from_numpy(np.ascontiguousarray(d[0], dtype=np.float32))
             a = np.arange(P, dtype=np.int32)
             np.random.shuffle(a)                                 # the reference's sampling RNG (Preprocessing.py:86)
             st.perms[k, :P] = torch.from_numpy(a)
             st.n[k] = P
         with torch.cuda.stream(self.stream):
-            pts6 = torch.zeros((B, cap, 6), dtype=torch.float32, device=dev)
-            pts6[:, :, :4].copy_(st.points, non_blocking=True)
+            pts6 = st.points.to(dev, non_blocking=True)
             perms = st.perms.to(dev, non_blocking=True)
             n = st.n.to(dev, non_blocking=True)
             st.free = torch.cuda.Event()
             st.free.record(self.stream)
-            fpn = []
-            for k, (velo, img, bbox2d, bbox3d, bev, calib) in enumerate(group):
-                P = velo.shape[0]
-                m, p2 = _calib_products(calib, True)
-                _hip.lidar2img(pts6[k, :P], m, p2, math_f32=True, out=pts6[k, :P], col_offset=4, swap_rc=True)    # reads x y z, writes cols 4:6 of the same rows
-                fpn.append(self.fpn_fn(self.names_of(group[k]), dev))
             boxes = [(d[4], d[3][:, [0, 1]]) if (d[4] is not None and d[4].shape[0] != 0) else None for d in group]
             lists = Calc.classifyAnchorsFrames(boxes, self.anchor_bevs, cfg.velorange, 0.45, 0.6)      # one pass, one host read
             targets = [None if t is None else (t[0], t[1], t[2], d[3].to(dev)) for t, d in zip(lists, group)]
             ev = torch.cuda.Event()
             ev.record(self.stream)
-        return FrameBatch(pts6, perms, n, fpn), targets, ev
+        return (pts6, perms, n, group), targets, ev
 
     def _work(self):
         try:
@@ -126,16 +124,25 @@ class PrefetchLoader:
             if self.error is not None:
                 raise self.error
             raise StopIteration
-        batch, targets, ev = item
-        if batch is None:
+        raw, targets, ev = item
+        if raw is None:
             return None, None
+        from modules.data.Preprocessing import _calib_products
+        from modules.pipeline import FrameBatch
+        pts6, perms, n, group = raw
         main = torch.cuda.current_stream(self.device)
         main.wait_event(ev)
-        for t in [batch.points6, batch.perms, batch.n_points] + [f for lv in batch.fpn_levels for f in lv]:
+        for t in (pts6, perms, n):
             t.record_stream(main)
         for t in targets:
             if t is not None:
                 for x in tuple(t[0]) + tuple(t[1]) + (t[2], t[3]):
                     if isinstance(x, torch.Tensor) and x.is_cuda:
                         x.record_stream(main)
-        return batch, targets
+        fpn = []
+        for k, d in enumerate(group):                            # on the training stream: projection and the FPN maps
+            P = d[0].shape[0]
+            m, p2 = _calib_products(d[5], True)
+            _hip.lidar2img(pts6[k, :P], m, p2, math_f32=True, out=pts6[k, :P], col_offset=4, swap_rc=True)    # reads x y z, writes cols 4:6
+            fpn.append(self.fpn_fn(self.names_of(d), self.device))
+        return FrameBatch(pts6, perms, n, fpn), targets

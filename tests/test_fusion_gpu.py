@@ -158,19 +158,32 @@ def test_mvxnet_forward_compact_equals_the_dense_formulation(golden):
         idx = torch.from_numpy(g['idx']).to(DEV)
         imsize = torch.from_numpy(g['imsize_hw']).to(DEV)
         res = {}
-        for compact in (True, False):
+        from modules import _hip
+        launches = {}
+        for compact in (True, 'modules', False):           # single autograd node / per-module path on compact rows / dense
             model.zero_grad()
+            l0 = _hip.X.lib.mvx_launch_count()
             vox = torch.from_numpy(g['voxels'].copy())[None].to(DEV)
             score, reg = model(vox, feats, idx, [None], imsize, compact=compact)
             assert score.shape[:2] == (1, 2) and reg.shape[:2] == (1, 14)
             (score.square().sum() + reg.square().sum()).backward()
+            torch.cuda.synchronize()
+            launches[compact] = _hip.X.lib.mvx_launch_count() - l0
             res[compact] = (score.detach().clone(), reg.detach().clone(), vox.clone(),
                             {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
-        assert torch.equal(res[True][2], res[False][2])                    # padded rows zeroed in place, both ways
-        assert rel_err(res[True][0], res[False][0]) < 1e-4 and rel_err(res[True][1], res[False][1]) < 1e-3
-        for k in res[False][3]:
-            a, b = res[True][3][k].double(), res[False][3][k].double()
-            # tiny grid: 16 BatchNorms over <= 96 sites in the RPN amplify fp32 rounding; compared in the 2-norm
-            assert float((a - b).norm() / b.norm().clamp_min(1e-30)) < 5e-2, k
+        assert all(v > 100 for v in launches.values()), launches          # every variant runs this library's kernels
+        for variant in (True, 'modules'):
+            assert torch.equal(res[variant][2], res[False][2])                # padded rows zeroed in place, every way
+            assert rel_err(res[variant][0], res[False][0]) < 1e-4 and rel_err(res[variant][1], res[False][1]) < 1e-3
+            assert set(res[variant][3]) == set(res[False][3])
+            for k in res[False][3]:
+                a, b = res[variant][3][k].double(), res[False][3][k].double()
+                # tiny grid: 16 BatchNorms over <= 96 sites in the RPN amplify fp32 rounding; compared in the 2-norm
+                assert float((a - b).norm() / b.norm().clamp_min(1e-30)) < 5e-2, (variant, k)
+        # no-grad call: the same maps, status words checked inside
+        with torch.no_grad():
+            vox = torch.from_numpy(g['voxels'].copy())[None].to(DEV)
+            s2, r2 = model(vox, feats, idx, [None], imsize)
+        assert rel_err(s2, res[True][0]) < 1e-6 and rel_err(r2, res[True][1]) < 1e-6
     finally:
         cfg.config['voxelshape'] = old

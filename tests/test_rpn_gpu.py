@@ -289,10 +289,12 @@ def test_rpn_module_runs_on_the_hip_node_and_matches_float64():
     for k, (e_hip, e_ref) in table.items():
         # two fp32 evaluations of 17 ReLU + BatchNorm layers: either may be the closer one on a given parameter
         assert e_hip < 3 * e_ref + 1e-2, (k, e_hip, e_ref)
-    # gradients accumulate like any autograd node: a second backward doubles them
-    x = x0.clone().requires_grad_(True)
-    s, r = rpn(x)
-    (s.square().sum() + r.square().sum()).backward()
+    # gradients accumulate like any autograd node: two forward / backward passes without zero_grad give twice the gradient
+    rpn.zero_grad()
+    for _ in range(2):
+        x = x0.clone().requires_grad_(True)
+        s, r = rpn(x)
+        (s.square().sum() + r.square().sum()).backward()
     torch.cuda.synchronize()
     k0 = 'blk1.0.conv.weight'
     assert rel(dict(rpn.named_parameters())[k0].grad.cpu(), 2 * res['hip'][3][k0]) < 1e-5
