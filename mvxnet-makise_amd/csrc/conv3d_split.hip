@@ -15,6 +15,7 @@
 //   - weights are pre-split by the pack kernel and staged three taps (one kernel row) at a time, so a
 //     barrier pair covers 3 taps x 12 MFMAs per wave instead of one tap.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -335,6 +336,293 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_split(const float *__res
 
 
 // ------------------------------------------------------------------------------------------
+// The same gather with a 16 x 16-site patch per workgroup and 64 sites x 64 channels per wave (four accumulator tiles).
+//
+// At 32 cycles per bf16 MFMA a stage of the 8 x 16 kernel lasts 3,456 matrix cycles per wave, during which the workgroup
+// pulls 73 KB of (pre-split) weights and 23 KB of halo through L2: with two workgroups on each of 256 CUs that is ~17 TB/s
+// of L2 reads -- half the aggregate L2 peak -- and one ds_read_b128 per MFMA.  Twice the sites per workgroup halve the weight
+// bytes and the weight-operand reads per MFMA (12 MFMAs per 8 operand fragments instead of 6 per 6) and put twice the
+// matrix work between two barriers.  The activity flags stay per 8 x 16 tile (what activity.hip produces): a workgroup
+// covers the tiles (tx, 2 ty) and (tx, 2 ty + 1) and ORs their flags -- computing a background half is exact, just not
+// needed.  Used when the launch has enough of these larger units to fill the GPU (launch_gather_split).
+// ------------------------------------------------------------------------------------------
+constexpr int TH2 = 16, HH2 = TH2 + 2;
+
+__global__ __launch_bounds__(256, 2) void conv3d_gather_split16(const float *__restrict__ in,
+                                                                const unsigned short *__restrict__ wsp,
+                                                                const float *__restrict__ bias,
+                                                                float *__restrict__ out, double *__restrict__ stats,
+                                                                Geom g, int relu, const int *__restrict__ in_hflag,
+                                                                const unsigned char *__restrict__ out_mask,
+                                                                const float *__restrict__ bg_pre, int border_active,
+                                                                const int *__restrict__ only_tiles,
+                                                                unsigned long long *__restrict__ exec_stages) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_halo[HH2 * HW * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char s_w[3][BN * ROWB];
+    __shared__ float s_red[4][2 * BN];
+    const int tiles_x = (g.W + TW - 1) / TW, tiles_y8 = (g.H + TH - 1) / TH;
+    const int ntiles8 = tiles_x * tiles_y8;
+    const int tx = blockIdx.x % tiles_x, ty16 = blockIdx.x / tiles_x;
+    const int tx0 = tx * TW, ty0 = ty16 * TH2;
+    const int t_top = (2 * ty16) * tiles_x + tx;
+    const bool has_bot = 2 * ty16 + 1 < tiles_y8;
+    const int t_bot = has_bot ? t_top + tiles_x : t_top;
+    const int d = blockIdx.y, nb = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int nchunks = g.Cin / BK;
+    if (only_tiles && !(only_tiles[(size_t)d * ntiles8 + t_top] | only_tiles[(size_t)d * ntiles8 + t_bot])) return;
+    const bool on_border = tx0 == 0 || ty0 == 0 || tx0 + TW >= g.W || ty0 + TH2 >= g.H;
+    const bool skip_taps = in_hflag && (border_active & 2) && !on_border;
+    unsigned skipped = 0;
+    int any_flag = 0;
+    bool active = true;
+    if (in_hflag) {
+        for (int kd = 0; kd < 3; ++kd) {
+            const int ds = src_depth(g, d, kd);
+            if (ds >= 0) {
+                const int fl = in_hflag[(size_t)ds * ntiles8 + t_top] | in_hflag[(size_t)ds * ntiles8 + t_bot];
+                any_flag |= fl;
+                if (skip_taps && !fl) skipped |= 1u << kd;
+            }
+        }
+        active = (((border_active & 1) && on_border) || any_flag) != 0;
+    }
+    const bool idle_border = in_hflag && (border_active & 2) && on_border && !any_flag;
+
+    f32x16 acc[2][2];                                   // [site tile m: rows 4 wv + 2 m, + 1][channel tile: n0, n0 + 32]
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    int a_base[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) a_base[m] = ((4 * wv + 2 * m + (li >> 4)) * HW + (li & 15)) * ROWB + lh * 16;
+    const int b_base = li * ROWB + lh * 16;
+
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 wreg[6];
+    auto load_w3 = [&](int kd, int a, int cc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int c = tid + 256 * u;
+            const int t = c >> 9, rem = c & 511;
+            const unsigned char *tile = (const unsigned char *)wsp +
+                ((((size_t)kd * 9 + a * 3 + t) * nchunks + cc) * g.Cout + (size_t)nb * BN) * (2 * BK * 2);
+            wreg[u] = *(const u32x4 *)(tile + (size_t)rem * 16);
+        }
+    };
+    auto store_w3 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int c = tid + 256 * u;
+            const int t = c >> 9, rem = c & 511;
+            const int n = rem >> 3, piece = rem & 7;
+            *(u32x4 *)(s_w[t] + n * ROWB + piece * 16) = wreg[u];
+        }
+    };
+    int kd_l[3] = {0, 0, 0}, ds_l[3] = {0, 0, 0}, nk = 0;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+        const int ds = src_depth(g, d, kd);
+        if (ds >= 0 && !((skipped >> kd) & 1u) && !idle_border) {
+            if (nk == 0) { kd_l[0] = kd; ds_l[0] = ds; }
+            else if (nk == 1) { kd_l[1] = kd; ds_l[1] = ds; }
+            else { kd_l[2] = kd; ds_l[2] = ds; }
+            ++nk;
+        }
+    }
+    const int nstages = active ? nk * nchunks : 0;
+    // executed work in units of the 8 x 16-tile stage (what the roofline prices): this workgroup covers one or two of them
+    if (exec_stages && nstages > 0 && threadIdx.x == 0) atomicAdd(exec_stages, (unsigned long long)nstages * (has_bot ? 2 : 1));
+    auto stage_of = [&](int st, int &kd, int &ds, int &cc) __attribute__((always_inline)) {
+        const int i = st / nchunks;
+        cc = st - i * nchunks;
+        kd = i == 0 ? kd_l[0] : (i == 1 ? kd_l[1] : kd_l[2]);
+        ds = i == 0 ? ds_l[0] : (i == 1 ? ds_l[1] : ds_l[2]);
+    };
+    constexpr int NH = (HH2 * HW * 8 + 255) / 256;      // 16-byte halo pieces per thread (11)
+    int h_off[NH], h_lds[NH];
+#pragma unroll
+    for (int u = 0; u < NH; ++u) {
+        const int c = tid + 256 * u;
+        h_off[u] = -1;
+        h_lds[u] = -1;
+        if (c < HH2 * HW * 8) {
+            const int r = c >> 3, part = c & 7;
+            const int gy = ty0 - 1 + r / HW, gx = tx0 - 1 + r % HW;
+            h_lds[u] = r * ROWB + part * 8;
+            if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) h_off[u] = (gy * g.W + gx) * g.Cin + part * 4;
+        }
+    }
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 hreg[NH];
+    auto load_halo = [&](int st) __attribute__((always_inline)) {
+        int kd, ds, cc;
+        stage_of(st, kd, ds, cc);
+        const float *img = in + (size_t)ds * g.H * g.W * g.Cin + cc * BK;
+#pragma unroll
+        for (int u = 0; u < NH; ++u)
+            hreg[u] = h_off[u] >= 0 ? *(const f32x4 *)(img + h_off[u]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto store_halo = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < NH; ++u)
+            if (h_lds[u] >= 0) {
+                uint2 hi, lo;
+                split4(make_float4(hreg[u][0], hreg[u][1], hreg[u][2], hreg[u][3]), &hi, &lo);
+                *(uint2 *)(s_halo + h_lds[u]) = hi;
+                *(uint2 *)(s_halo + h_lds[u] + 64) = lo;
+            }
+    };
+    auto load_wrow = [&](int st, int a) __attribute__((always_inline)) {
+        int kd, ds, cc;
+        stage_of(st, kd, ds, cc);
+        load_w3(kd, a, cc);
+    };
+    auto compute_row = [&](int a) __attribute__((always_inline)) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 b0h = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_w[b] + b_base + s2 * 32));
+                const bf16x8 b0l = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_w[b] + b_base + 64 + s2 * 32));
+                const bf16x8 b1h = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_w[b] + b_base + 32 * ROWB + s2 * 32));
+                const bf16x8 b1l = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_w[b] + b_base + 32 * ROWB + 64 + s2 * 32));
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int a_off = a_base[m] + (a * HW + b) * ROWB;
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_halo + a_off + s2 * 32));
+                    const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_halo + a_off + 64 + s2 * 32));
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b0h, acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b1h, acc[m][1], 0, 0, 0);
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0l, acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1l, acc[m][1], 0, 0, 0);
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0h, acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1h, acc[m][1], 0, 0, 0);
+                }
+            }
+        }
+    };
+    if (nstages > 0) {
+        load_wrow(0, 0);
+        load_halo(0);
+    }
+    for (int st = 0; st < nstages; ++st) {
+        const int nxt = st + 1 < nstages ? st + 1 : st;
+        __syncthreads();
+        store_halo();
+        store_w3();
+        __syncthreads();
+        load_wrow(st, 1);
+        load_halo(nxt);
+        compute_row(0);
+        __syncthreads();
+        store_w3();
+        __syncthreads();
+        load_wrow(st, 2);
+        compute_row(1);
+        __syncthreads();
+        store_w3();
+        __syncthreads();
+        load_wrow(nxt, 0);
+        compute_row(2);
+    }
+
+    // ---- epilogue (same arithmetic per site as conv3d_gather_split)
+    const int n0 = nb * BN + li, n1 = n0 + 32;
+    const float bias0 = bias ? bias[n0] : 0.f, bias1 = bias ? bias[n1] : 0.f;
+    float skip0 = 0.f, skip1 = 0.f;
+    if (skipped && active) {
+        const float *bg_tap = bg_pre + (size_t)g.Dout * g.F * g.Cout + (size_t)d * 3 * g.Cout;
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+            if ((skipped >> kd) & 1u) { skip0 += bg_tap[kd * g.Cout + n0]; skip1 += bg_tap[kd * g.Cout + n1]; }
+    }
+    float bgv0 = (bg_pre ? bg_pre[(size_t)d * g.Cout + n0] : 0.f) + bias0, bgv1 = (bg_pre ? bg_pre[(size_t)d * g.Cout + n1] : 0.f) + bias1;
+    if (relu) { bgv0 = fmaxf(bgv0, 0.f); bgv1 = fmaxf(bgv1, 0.f); }
+    float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        if (idle_border) {
+            const float *bg_cls = bg_pre + (size_t)4 * g.Dout * g.F * g.Cout + (size_t)d * 9 * g.Cout;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int gy = ty0 + 4 * wv + 2 * m + (row >> 4), gx = tx0 + (row & 15);
+                const int q = 3 * (gy == 0 ? 0 : (gy >= g.H - 1 ? 2 : 1)) + (gx == 0 ? 0 : (gx >= g.W - 1 ? 2 : 1));
+                acc[m][0][r] = bg_cls[q * g.Cout + n0];
+                acc[m][1][r] = bg_cls[q * g.Cout + n1];
+            }
+        }
+        unsigned site_on = active ? 0xffffu : 0u;
+        if (out_mask && active) {
+            unsigned char mk[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int gy = min(ty0 + 4 * wv + 2 * m + (row >> 4), g.H - 1), gx = min(tx0 + (row & 15), g.W - 1);
+                mk[r] = out_mask[((size_t)d * g.H + gy) * g.W + gx];
+            }
+            site_on = 0u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) site_on |= (mk[r] ? 1u : 0u) << r;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int gy = ty0 + 4 * wv + 2 * m + (row >> 4), gx = tx0 + (row & 15);
+            float v0 = (acc[m][0][r] + skip0) + bias0, v1 = (acc[m][1][r] + skip1) + bias1;
+            if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+            if (out_mask && !((site_on >> r) & 1u)) { v0 = bgv0; v1 = bgv1; }
+            if (gy < g.H && gx < g.W) {
+                float *o = out + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout;
+                o[n0] = v0;
+                o[n1] = v1;
+                s1a += v0; s2a += v0 * v0;
+                s1b += v1; s2b += v1 * v1;
+            }
+        }
+    }
+    if (stats) {
+        s1a += __shfl_xor(s1a, 32, 64); s2a += __shfl_xor(s2a, 32, 64);
+        s1b += __shfl_xor(s1b, 32, 64); s2b += __shfl_xor(s2b, 32, 64);
+        __syncthreads();
+        if (lh == 0) {
+            s_red[wv][li] = s1a; s_red[wv][32 + li] = s1b;
+            s_red[wv][BN + li] = s2a; s_red[wv][BN + 32 + li] = s2b;
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const double t = (double)s_red[0][tid] + (double)s_red[1][tid] + (double)s_red[2][tid] + (double)s_red[3][tid];
+            const int which = tid / BN, c = tid % BN;
+            const unsigned rep = (blockIdx.x + blockIdx.y * gridDim.x) % MVX_REP;
+            double *fstats = stats + (size_t)(d / g.Dout) * MVX_REP * 2 * g.Cout;
+            atomicAdd(fstats + ((size_t)rep * 2 + which) * g.Cout + nb * BN + c, t);
+        }
+    }
+}
+
+// 16 x 16-site units when the launch has enough of them to fill two workgroup slots on every CU with a margin, else 8 x 16
+static void launch_gather_split(hipStream_t st, int planes, int nblocks, const float *in, const unsigned short *wsp,
+                                const float *bias, float *out, double *stats, const Geom &g, int relu, const int *in_hflag,
+                                const unsigned char *out_mask, const float *bg_pre, int border_active, const int *only_tiles,
+                                unsigned long long *exec_stages) {
+    const int tiles_x = (int)mvx_cdiv(g.W, TW);
+    const long long units16 = (long long)tiles_x * mvx_cdiv(g.H, TH2) * planes * nblocks;
+    // MVX_SPLIT16_MIN_UNITS: tuning / test knob (0 forces the 16 x 16 kernel, a huge value the 8 x 16 one)
+    const char *env = getenv("MVX_SPLIT16_MIN_UNITS");
+    const long long min_units = env ? atoll(env) : 768;
+    if (units16 >= min_units)
+        hipLaunchKernelGGL(conv3d_gather_split16, dim3(tiles_x * mvx_cdiv(g.H, TH2), planes, nblocks), dim3(256), 0, st, in, wsp,
+                           bias, out, stats, g, relu, in_hflag, out_mask, bg_pre, border_active, only_tiles, exec_stages);
+    else
+        hipLaunchKernelGGL(conv3d_gather_split, dim3(tiles_x * mvx_cdiv(g.H, TH), planes, nblocks), dim3(256), 0, st, in, wsp, bias,
+                           out, stats, g, relu, in_hflag, out_mask, bg_pre, border_active, only_tiles, exec_stages);
+}
+
+// ------------------------------------------------------------------------------------------
 // weight gradient, bf16x3.  dW[kd][a][b][c][n] = sum_sites x[site + tap][c] * dz[site][n]: the MFMA
 // reduction index is the SITE, so both operands are needed "k-major" while memory is channel-major.
 // The tiles are staged as [site][32 channels] bf16 rows (64 B) and fetched with ds_read_b64_tr_b16,
@@ -544,10 +832,8 @@ extern "C" int mvx_conv3d_forward_split(const float *in, const void *wsplit, con
         if (e != hipSuccess) return (int)e;
     }
     Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
-    hipLaunchKernelGGL(conv3d_gather_split, dim3(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), dout, cout / BN), dim3(256), 0, st, in,
-                       (const unsigned short *)wsplit, bias, out, stats, g, relu, (const int *)nullptr,
-                       (const unsigned char *)nullptr, (const float *)nullptr, 0, (const int *)nullptr,
-                       (unsigned long long *)nullptr);
+    launch_gather_split(st, dout, cout / BN, in, (const unsigned short *)wsplit, bias, out, stats, g, relu, nullptr, nullptr, nullptr,
+                        0, nullptr, nullptr);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -568,10 +854,9 @@ extern "C" int mvx_conv3d_forward_bg_split_frames(const float *in, const void *w
         if (e != hipSuccess) return (int)e;
     }
     Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0, n_frames};
-    hipLaunchKernelGGL(conv3d_gather_split, dim3(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), dout * n_frames, cout / BN), dim3(256), 0, st,
-                       in, (const unsigned short *)wsplit, bias, out, stats, g, flags & MVX_FLAG_RELU, in_halo_flags, out_mask,
-                       bg_pre, (border_active ? 1 : 0) | ((flags & MVX_FLAG_BG_TAPS) ? 2 : 0), (const int *)nullptr,
-                       (unsigned long long *)exec_stages);
+    launch_gather_split(st, dout * n_frames, cout / BN, in, (const unsigned short *)wsplit, bias, out, stats, g,
+                        flags & MVX_FLAG_RELU, in_halo_flags, out_mask, bg_pre,
+                        (border_active ? 1 : 0) | ((flags & MVX_FLAG_BG_TAPS) ? 2 : 0), nullptr, (unsigned long long *)exec_stages);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -593,10 +878,8 @@ static int launch_dgrad_split(const float *dz, const void *wsplit_dgrad, float *
     int rc = check_geom(din, dout, h, w, cout, cin, stride_d, pad_d);
     if (rc) return rc;
     Geom g{dout, din, h, w, cout, cin, stride_d, pad_d, 1, n_frames};
-    hipLaunchKernelGGL(conv3d_gather_split, dim3(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), din * n_frames, cin / BN), dim3(256), 0,
-                       (hipStream_t)stream, dz, (const unsigned short *)wsplit_dgrad, (const float *)nullptr, dx,
-                       (double *)nullptr, g, 0, (const int *)nullptr, (const unsigned char *)nullptr,
-                       (const float *)nullptr, 0, only_tiles, (unsigned long long *)exec_stages);
+    launch_gather_split((hipStream_t)stream, din * n_frames, cin / BN, dz, (const unsigned short *)wsplit_dgrad, nullptr, dx, nullptr,
+                        g, 0, nullptr, nullptr, nullptr, 0, only_tiles, (unsigned long long *)exec_stages);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -724,10 +1007,8 @@ extern "C" int mvx_conv2d_forward_split_frames(const float *in, const void *wspl
         if (e != hipSuccess) return (int)e;
     }
     Geom g{1, 1, h, w, cin, cout, 1, 1, 0, n_frames};
-    hipLaunchKernelGGL(conv3d_gather_split, dim3(mvx_cdiv(w, TW) * mvx_cdiv(h, TH), n_frames, cout / BN), dim3(256), 0, st, in,
-                       (const unsigned short *)wsplit, bias, out, stats, g, flags & MVX_FLAG_RELU, (const int *)nullptr,
-                       (const unsigned char *)nullptr, (const float *)nullptr, 0, (const int *)nullptr,
-                       (unsigned long long *)nullptr);
+    launch_gather_split(st, n_frames, cout / BN, in, (const unsigned short *)wsplit, bias, out, stats, g, flags & MVX_FLAG_RELU,
+                        nullptr, nullptr, nullptr, 0, nullptr, nullptr);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

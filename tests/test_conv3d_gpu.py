@@ -119,8 +119,22 @@ def test_cml_stack_matches_reference_fixture(golden):
         assert rel_err(x.cpu().permute(3, 0, 1, 2), ref) < 1e-4, key
 
 
+@pytest.fixture(params=['8x16 units', '16x16 units'])
+def split_units(request):
+    """The bf16x3 gather has two workgroup shapes (csrc/conv3d_split.hip: 8 x 16 sites, and 16 x 16 sites with 64-site wave
+    tiles, picked by the number of units of a launch): run the test with each forced."""
+    import os
+    old = os.environ.get('MVX_SPLIT16_MIN_UNITS')
+    os.environ['MVX_SPLIT16_MIN_UNITS'] = '0' if request.param.startswith('16') else str(1 << 60)
+    yield request.param
+    if old is None:
+        del os.environ['MVX_SPLIT16_MIN_UNITS']
+    else:
+        os.environ['MVX_SPLIT16_MIN_UNITS'] = old
+
+
 @pytest.mark.parametrize('cin,cout,din,H,W,sd,pd', GEOMS[:4])
-def test_conv3d_bf16x3_split_accuracy(cin, cout, din, H, W, sd, pd):
+def test_conv3d_bf16x3_split_accuracy(cin, cout, din, H, W, sd, pd, split_units):
     """bf16x3 kernels against float64: fp32-grade accuracy (well inside the 1e-4 feature bar)."""
     from modules import _hip
     g = torch.Generator().manual_seed(cin + 3 * H)
@@ -173,7 +187,7 @@ def test_conv3d_full_size_adjoint_identities(split):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(5, 40, 48, 1, 0), (3, 37, 53, 2, 1), (10, 24, 35, 2, 1)])
-def test_background_rewrite_equals_dense(shape):
+def test_background_rewrite_equals_dense(shape, split_units):
     """conv3d_forward_bg / conv3d_wgrad_bg (constant fill of voxel-free tiles, closed-form constant term)
     against the dense kernels on an input that IS a background plus a few active sites -- including
     sizes that are no multiple of the 8x16 tile and depth padding."""
@@ -268,3 +282,35 @@ def test_conv2d_3x3_on_the_conv3d_kernels(cin, cout, H, W):
     assert rel_err(y[0].cpu(), yr[0].permute(1, 2, 0).detach()) < 1e-5
     assert rel_err(dx[0].cpu(), xr.grad[0].permute(1, 2, 0)) < 1e-5
     assert rel_err(dw.cpu(), wr.grad) < 1e-5
+
+
+@pytest.mark.gpu
+def test_split_gather_workgroup_shapes_give_identical_outputs():
+    """The two workgroup shapes of the bf16x3 gather accumulate every output in the same order (stage by stage, tap by tap,
+    k by k): forward and input gradient must be BIT-identical, on a size that is no multiple of either tile (the last
+    16 x 16 unit covers a single 8 x 16 tile) and with more than one output-channel block."""
+    import os
+    from modules import _hip
+    g = torch.Generator().manual_seed(21)
+    din, H, W, cin, cout, sd, pd = 3, 40, 53, 64, 128, 1, 1
+    x = torch.randn((din, H, W, cin), generator=g).to(DEV)
+    w = (torch.randn((cout, cin, 3, 3, 3), generator=g) / np.sqrt(27 * cin)).to(DEV)
+    b = (torch.randn((cout,), generator=g) * 0.1).to(DEV)
+    dz = torch.randn((din, H, W, cout), generator=g).to(DEV)
+    wf, wd = _hip.conv3d_pack(w, False, split=True), _hip.conv3d_pack(w, True, split=True)
+    res = {}
+    old = os.environ.get('MVX_SPLIT16_MIN_UNITS')
+    try:
+        for tag, val in (('8', str(1 << 60)), ('16', '0')):
+            os.environ['MVX_SPLIT16_MIN_UNITS'] = val
+            y, st = _hip.conv3d_forward(x, wf, b, cout, sd, pd, split=True)
+            dx = _hip.conv3d_dgrad(dz, wd, din, cin, sd, pd, split=True)
+            torch.cuda.synchronize()
+            res[tag] = (y.clone(), st.sum(0).clone(), dx.clone())
+    finally:
+        if old is None:
+            os.environ.pop('MVX_SPLIT16_MIN_UNITS', None)
+        else:
+            os.environ['MVX_SPLIT16_MIN_UNITS'] = old
+    assert torch.equal(res['8'][0], res['16'][0]) and torch.equal(res['8'][2], res['16'][2])
+    assert torch.allclose(res['8'][1], res['16'][1], rtol=1e-6, atol=1e-6 * float(res['8'][1].abs().max()))
