@@ -736,16 +736,21 @@ def _run(args, rank, world, dev):
         from modules import frames as _fr
         if _fr.KNOCKOUT:
             out['INVALID_diagnostic_knockout'] = sorted(_fr.KNOCKOUT)       # kernels were skipped: timing experiment, not a result
+        # the other MFMA kernels of the step, each with EXECUTED FLOPs / event time inside the timed region (they share the
+        # chip with the kernels of the other streams: side-stream weight gradients run beside main-stream convolutions)
         other = {}
-        for name in ('conv3d_wgrad_bg', 'rpn_conv'):
+        for name in ('conv3d_wgrad_bg', 'linear_fwd', 'linear_dgrad', 'linear_wgrad', 'rpn_conv', 'rpn_wgrad'):
             evs = timers.get(name, [])
             if evs:
                 tms = sum(s.elapsed_time(e) for s, e, _ in evs)
                 other[name] = {'launches': len(evs), 'avg_launch_ms': tms / len(evs)}
-                fl = sum(f for _, _, f in evs)
+                fl = sum(float(f) for _, _, f in evs)
                 if fl > 0:
-                    other[name]['dense_tflops'] = fl / (tms * 1e-3) / 1e12
-                    other[name]['frac_of_f32_mfma_peak'] = other[name]['dense_tflops'] / FP32_MFMA_PEAK_TFLOPS
+                    mult, peak = (3.0, BF16_MFMA_PEAK_TFLOPS) if (main_math == 'bf16x3' and name in ('conv3d_wgrad_bg', 'rpn_conv', 'rpn_wgrad')) \
+                        else (1.0, FP32_MFMA_PEAK_TFLOPS)
+                    other[name]['executed_tflops'] = mult * fl / (tms * 1e-3) / 1e12
+                    other[name]['peak_tflops'] = peak
+                    other[name]['frac'] = other[name]['executed_tflops'] / peak
         out['other_kernels'] = other
         if alt:
             out['alt_modes'] = alt

@@ -703,10 +703,11 @@ def linear_forward(x, w, bias, relu=True, want_stats=True, w_transposed=False, r
     ws = None
     if bias is None and not relu and not want_stats and K >= 256 and R * N <= (1 << 22):
         ws = workspace(X.lib.mvx_linear_splitk_workspace_bytes(R, N), x.device, 'splitk')
-    X.check(X.lib.mvx_linear_forward(_vptr(x), _ld(x), _vptr(w), _ld(w), int(w_transposed), X.ptr(bias),
-                                     _vptr(out), _ld(out), X.ptr(stats), X.ptr(row_w), R, K, N,
-                                     (FLAG_RELU if relu else 0) | fz,
-                                     X.ptr(ws), ws.numel() if ws is not None else 0, X.stream()), 'mvx_linear_forward')
+    with _Timed('linear_dgrad' if w_transposed else 'linear_fwd', 2.0 * R * K * N if KERNEL_TIMERS is not None else 0):
+        X.check(X.lib.mvx_linear_forward(_vptr(x), _ld(x), _vptr(w), _ld(w), int(w_transposed), X.ptr(bias),
+                                         _vptr(out), _ld(out), X.ptr(stats), X.ptr(row_w), R, K, N,
+                                         (FLAG_RELU if relu else 0) | fz,
+                                         X.ptr(ws), ws.numel() if ws is not None else 0, X.stream()), 'mvx_linear_forward')
     if finalize is not None and want_stats:      # empty input: no launch happened, finalise the (zero) sums separately
         return out, bn_finalize(stats, finalize[0], finalize[1])
     return out, stats
@@ -724,8 +725,9 @@ def linear_wgrad(x, dz, accumulate_into=None):
     nbytes = X.lib.mvx_linear_wgrad_workspace_bytes(R, K, N)
     with _wgrad_scope(accumulate_into, x, dz) as scope:
         ws = workspace(nbytes, x.device, 'lwgrad_side' if isinstance(scope, _SideStream) else 'lwgrad')
-        X.check(X.lib.mvx_linear_wgrad(_vptr(x), _ld(x), _vptr(dz), _ld(dz), X.ptr(dw), R, K, N, flags, X.ptr(ws),
-                                       ws.numel(), X.stream()), 'mvx_linear_wgrad')
+        with _Timed('linear_wgrad', 2.0 * R * K * N if KERNEL_TIMERS is not None else 0):
+            X.check(X.lib.mvx_linear_wgrad(_vptr(x), _ld(x), _vptr(dz), _ld(dz), X.ptr(dw), R, K, N, flags, X.ptr(ws),
+                                           ws.numel(), X.stream()), 'mvx_linear_wgrad')
     return None if accumulate_into is not None else dw
 
 

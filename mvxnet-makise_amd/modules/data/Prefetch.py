@@ -39,19 +39,20 @@ class _Staging:
 
 
 class PrefetchLoader:
-    def __init__(self, groups, names_of, device, anchor_bevs, fpn_fn, cap_points, depth=2):
+    def __init__(self, groups, names_of, device, anchor_bevs, fpn_fn, cap_points, depth=2, priority=-1):
         """``groups``: iterable of lists of frames as ``modules.data.Load.createDataset`` returns them; ``names_of(frame)``:
         the frame's name (for ``fpn_fn``); ``fpn_fn(name, device)``: the frame's FPN maps (the frozen extractor or its
         stand-in); ``cap_points``: point capacity per frame of the resident batch."""
         self.groups = iter(groups)
         self.names_of, self.device, self.anchor_bevs, self.fpn_fn = names_of, device, anchor_bevs, fpn_fn
         self.cap = int(cap_points)
-        self.stream = torch.cuda.Stream(device=device, priority=-1)
+        self.stream = torch.cuda.Stream(device=device, priority=priority)
         self.q = queue.Queue(maxsize=max(1, depth))
         self.slots = {}
         self.turn = 0
         self.error = None
         self.stop = False
+        self.stats = {'batches': 0, 'prepare_s': 0.0, 'host_fill_s': 0.0, 'targets_s': 0.0, 'consumer_wait_s': 0.0}
         self.thread = threading.Thread(target=self._work, name='mvx-prefetch', daemon=True)
         self.thread.start()
 
@@ -68,6 +69,8 @@ class PrefetchLoader:
         return st
 
     def _prepare(self, group):
+        import time
+        t0 = time.perf_counter()
         dev = self.device
         B = len(group)
         cap = max(self.cap, max(d[0].shape[0] for d in group))
@@ -79,6 +82,7 @@ class PrefetchLoader:
             np.random.shuffle(a)                                 # the reference's sampling RNG (Preprocessing.py:86)
             st.perms[k, :P] = torch.from_numpy(a)
             st.n[k] = P
+        t1 = time.perf_counter()
         with torch.cuda.stream(self.stream):
             pts6 = st.points.to(dev, non_blocking=True)
             perms = st.perms.to(dev, non_blocking=True)
@@ -90,6 +94,11 @@ class PrefetchLoader:
             targets = [None if t is None else (t[0], t[1], t[2], d[3].to(dev)) for t, d in zip(lists, group)]
             ev = torch.cuda.Event()
             ev.record(self.stream)
+        t2 = time.perf_counter()
+        self.stats['batches'] += 1
+        self.stats['host_fill_s'] += t1 - t0
+        self.stats['targets_s'] += t2 - t1
+        self.stats['prepare_s'] += t2 - t0
         return (pts6, perms, n, group), targets, ev
 
     def _work(self):
@@ -119,7 +128,10 @@ class PrefetchLoader:
         return self
 
     def __next__(self):
+        import time
+        t0 = time.perf_counter()
         item = self.q.get()
+        self.stats['consumer_wait_s'] += time.perf_counter() - t0
         if item is None:
             if self.error is not None:
                 raise self.error

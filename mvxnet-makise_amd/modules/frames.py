@@ -105,10 +105,11 @@ def linear_bn(x, w, b, fs, kind, row_w, eps):
     mi = torch.empty((fs.F, 2, N), dtype=torch.float32, device=x.device)
     if 'lin_fwd' in KNOCKOUT:
         return y, mi
-    X.check(X.lib.mvx_linear_forward_bn_frames(_hip._vptr(x), _hip._ld(x), _hip._vptr(w2), _hip._ld(w2), 0, X.ptr(b),
-                                               _hip._vptr(y), _hip._ld(y), X.ptr(stats), X.ptr(row_w), Rr, K, N,
-                                               _hip.FLAG_RELU | fz, X.ptr(counter), float(eps), X.ptr(mi), fs.desc.ref(),
-                                               kind, X.stream()), 'mvx_linear_forward_bn_frames')
+    with _hip._Timed('linear_fwd', 2.0 * Rr * K * N if _hip.KERNEL_TIMERS is not None else 0):
+        X.check(X.lib.mvx_linear_forward_bn_frames(_hip._vptr(x), _hip._ld(x), _hip._vptr(w2), _hip._ld(w2), 0, X.ptr(b),
+                                                   _hip._vptr(y), _hip._ld(y), X.ptr(stats), X.ptr(row_w), Rr, K, N,
+                                                   _hip.FLAG_RELU | fz, X.ptr(counter), float(eps), X.ptr(mi), fs.desc.ref(),
+                                                   kind, X.stream()), 'mvx_linear_forward_bn_frames')
     return y, mi
 
 
@@ -399,18 +400,35 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
     return mid
 
 
+def _wgrad_bg_flops(rec, F):
+    """EXECUTED FLOPs of a background-aware weight-gradient launch (timing runs only; a device scalar): the kernel runs the
+    (plane, tile) steps whose source halo holds a non-background site, every step = 8 x 16 sites x Cin x Cout x 9 taps."""
+    din, dout, sd, pd = rec['din'], rec['dout'], rec['sd'], rec['pd']
+    hf = rec['hflag_in'].view(F, din, -1).ne(0)
+    steps = None
+    for kd in range(3):
+        for d in range(dout):
+            ds = d * sd - pd + kd
+            if 0 <= ds < din:
+                n = hf[:, ds].sum()
+                steps = n if steps is None else steps + n
+    co, ci = rec['w'].shape[0], rec['w'].shape[1]
+    return steps.double() * (2.0 * 128 * ci * co * 9)
+
+
 def _wgrad_bg(rec, dz, tap_sums, F, H, W):
     if 'wgrad_bg' in KNOCKOUT:
         return
     x, w = rec['x'], rec['w']
     co, ci = w.shape[0], w.shape[1]
     dw = _grad_of(w)
+    fl = _wgrad_bg_flops(rec, F) if _hip.KERNEL_TIMERS is not None else 0
     nbytes = X.lib.mvx_conv3d_wgrad_bg_workspace_bytes_frames(rec['dout'], H, W, ci, co, F)
     if rec.get('split'):
         nbytes = X.lib.mvx_conv3d_wgrad_bg_split_workspace_bytes_frames(rec['dout'], H, W, ci, co, F)
         with _hip._SideStream(x, dz, tap_sums, rec['c_in'], rec['hflag_in']):
             ws = _hip.workspace(nbytes, x.device, 'wgrad_bg_side')
-            with _hip._Timed('conv3d_wgrad_bg', 0):
+            with _hip._Timed('conv3d_wgrad_bg', fl):
                 X.check(X.lib.mvx_conv3d_wgrad_bg_split_frames(X.ptr(x), X.ptr(dz), X.ptr(dw), rec['din'], rec['dout'], H, W, ci, co,
                                                                rec['sd'], rec['pd'], _hip.FLAG_ACCUMULATE, X.ptr(rec['hflag_in']),
                                                                X.ptr(rec['c_in']), X.ptr(tap_sums), X.ptr(ws), ws.numel(), F,
@@ -418,7 +436,7 @@ def _wgrad_bg(rec, dz, tap_sums, F, H, W):
         return
     with _hip._SideStream(x, dz, tap_sums, rec['c_in'], rec['hflag_in']):
         ws = _hip.workspace(nbytes, x.device, 'wgrad_bg_side')
-        with _hip._Timed('conv3d_wgrad_bg', 0):
+        with _hip._Timed('conv3d_wgrad_bg', fl):
             X.check(X.lib.mvx_conv3d_wgrad_bg_frames(X.ptr(x), X.ptr(dz), X.ptr(dw), rec['din'], rec['dout'], H, W, ci, co,
                                                      rec['sd'], rec['pd'], _hip.FLAG_ACCUMULATE, X.ptr(rec['hflag_in']),
                                                      X.ptr(rec['c_in']), X.ptr(tap_sums), X.ptr(ws), ws.numel(), F, X.stream()),

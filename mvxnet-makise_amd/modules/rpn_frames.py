@@ -211,7 +211,8 @@ def _wgrad(x, dz, F, h, w, cin, cout, flags, into=None):
             return dw3[:, :, 1].contiguous()
     nbytes = X.lib.mvx_conv2d_wgrad_workspace_bytes_frames(h, w, cin, cout, F)
     dw = into if into is not None else torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
-    with _hip._SideStream(x, dz, dw):
+    nt = 2.25 if flags & TAPS2 else 9
+    with _hip._SideStream(x, dz, dw), _hip._Timed('rpn_wgrad', 2.0 * F * h * w * cin * cout * nt if _hip.KERNEL_TIMERS is not None else 0):
         ws = _hip.workspace(nbytes, dev, 'rpn_wgrad_side')
         X.check(X.lib.mvx_conv2d_wgrad_frames(X.ptr(x), X.ptr(dz), X.ptr(dw), h, w, cin, cout,
                                               flags | (_hip.FLAG_ACCUMULATE if into is not None else 0), X.ptr(ws), ws.numel(), F,

@@ -42,7 +42,11 @@ def parse_args(argv=None):
     ap.add_argument('--checkpoints', default='./checkpoints')
     ap.add_argument('--need-crop', action='store_true', help='read training/velodyne and crop on the GPU (cropdata.py on the fly)')
     ap.add_argument('--quiet', action='store_true')
-    ap.add_argument('--no-prefetch', action='store_true', help='--mode fast: prepare every batch inside its step (no loader thread)')
+    ap.add_argument('--prefetch', action='store_true',
+                    help='--mode fast: prepare batch k+1 on a worker thread + stream (modules/data/Prefetch.py); off by default: with '
+                         'the preparation on the GPU the loop already runs at the step time, and the thread costs more than it hides')
+    ap.add_argument('--prefetch-depth', type=int, default=2)
+    ap.add_argument('--prefetch-priority', type=int, default=-1, help='HIP stream priority of the loader stream (-1 high, 0 default)')
     return ap.parse_args(argv)
 
 
@@ -184,7 +188,7 @@ def train(args):
             chunks = fast_chunks(len(trainDataSet), B, world)
             groups = [trainDataSet[lo + rank:hi:world] for lo, hi in chunks]
             cap = max(args.points, max(d[0].shape[0] for d in trainDataSet))
-            if args.no_prefetch:
+            if not args.prefetch:
                 def batches():
                     for group in groups:
                         if not group:
@@ -196,7 +200,8 @@ def train(args):
                 # batch k+1 is prepared by a worker thread on its own stream while step k runs (the reference overlaps its CPU
                 # preparation with a process pool, train.py:185-187)
                 from modules.data.Prefetch import PrefetchLoader
-                loader = PrefetchLoader(groups, lambda d: names[id(d)], device, anchorBevs, fpn_maps_for, cap)
+                loader = PrefetchLoader(groups, lambda d: names[id(d)], device, anchorBevs, fpn_maps_for, cap,
+                                        depth=args.prefetch_depth, priority=args.prefetch_priority)
             pending = None                        # the losses of a step are read one step later: the host never waits for
                                                   # the step it has just enqueued
 
@@ -240,10 +245,11 @@ def train(args):
             torch.cuda.synchronize(device)
             loop_s = time.perf_counter() - t_epoch
             loop_stats.append({'epoch': epoch + args.lastiter + 1, 'frames': frames_epoch, 'seconds': loop_s,
-                               'frames_per_s': frames_epoch / loop_s if loop_s > 0 else 0.0})
+                               'frames_per_s': frames_epoch / loop_s if loop_s > 0 else 0.0,
+                               'loader': dict(getattr(loader, 'stats', {}))})
             say('Epoch%d: %d frames in %.2f s = %.1f frames/s (all ranks, %s)'
                 % (epoch + args.lastiter + 1, frames_epoch, loop_s, frames_epoch / max(loop_s, 1e-9),
-                   'batches prepared inside the step' if args.no_prefetch else 'prefetch thread'))
+                   'prefetch thread' if args.prefetch else 'batches prepared inside the step'))
         if rank == 0:
             n = epoch + args.lastiter + 1
             torch.save(model.state_dict(), os.path.join(args.checkpoints, 'epoch%d.pkl' % n))

@@ -42,14 +42,16 @@ def test_reader_matches_the_reference_conventions(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('mode', ['module', 'fast'])
+@pytest.mark.parametrize('mode', ['module', 'fast', 'fast+prefetch'])
 def test_train_like_runs_and_resumes(tmp_path, mode):
     sys.path.insert(0, PKG)
     import train_like
     root = _tree(tmp_path, n=4)
     ck = str(tmp_path / 'ck')
+    extra = ['--prefetch'] if mode.endswith('prefetch') else []          # batches prepared by the loader thread
+    mode = mode.split('+')[0]
     args = train_like.parse_args([root, '-n', '1', '--mode', mode, '--frames', '2', '--points', '3000', '--checkpoints', ck,
-                                  '--quiet'])
+                                  '--quiet'] + extra)
     np.random.seed(0)
     r1 = train_like.train(args)
     assert r1['steps'] == (4 if mode == 'module' else 2)
@@ -63,7 +65,7 @@ def test_train_like_runs_and_resumes(tmp_path, mode):
         assert k in sd
     # resume: loads model + optimizer state and continues (train.py:84-86)
     args2 = train_like.parse_args([root, '-n', '1', '-r', '1', '--mode', mode, '--frames', '2', '--points', '3000',
-                                   '--checkpoints', ck, '--quiet', '--steps', '1'])
+                                   '--checkpoints', ck, '--quiet', '--steps', '1'] + extra)
     r2 = train_like.train(args2)
     assert r2['steps'] == 1 and np.isfinite(r2['losses'][0])
     st = r2['opt'].state_dict()['state']

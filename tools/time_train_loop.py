@@ -19,7 +19,8 @@ import train_like  # noqa: E402
 root = tempfile.mkdtemp(prefix='mvx_kitti_')
 res = {'frames': n, 'frames_per_step': B, 'points': 20000}
 first = True
-for label, extra in (('prefetch', []), ('no_prefetch', ['--no-prefetch'])):
+for label, extra in (('prefetch', ['--prefetch']), ('prefetch_prio0', ['--prefetch', '--prefetch-priority', '0']),
+                     ('prefetch_depth4', ['--prefetch', '--prefetch-depth', '4']), ('no_prefetch', [])):
     args = train_like.parse_args([root, '-n', '2', '--mode', 'fast', '--frames', str(B), '--points', '20000', '--quiet',
                                   '--checkpoints', os.path.join(root, 'ck_' + label)] + extra + (['--synthetic', str(n)] if first else []))
     first = False
