@@ -451,20 +451,24 @@ def _run(args, rank, world, dev):
         the first CML layer on the voxel rows, the RPN as one node on this library's kernels (modules/voxelnet/Pipe.py)."""
         from modules import Calc
         targets_setup()
-        frames, st = pl.voxelize_batch(batch)
+        # the CPU part of train.py's iteration (cputask, train.py:26-49) for the frames of the step: voxelization (with the
+        # compact-row maps) and target assignment, each with one host read for all frames; then the model one frame at a time
+        frames, st = pl.voxelize_batch(batch, with_maps=True)
         statuses = [st]
+        gt = drop['gt']
+        tg = Calc.classifyAnchorsFrames([(drop['gt_bev'], gt[:, [0, 1]])] * len(frames), drop['bevs'], cfg.velorange, 0.45, 0.6)
         for f, (voxels, idx) in enumerate(frames):
             opt.zero_grad(set_to_none=False)
-            gt = drop['gt']
-            pi, ni, gi = Calc.classifyAnchors(Calc.bbox3d2bev(gt), gt[:, [0, 1]], drop['bevs'], cfg.velorange, 0.45, 0.6)
+            pi, ni, gi = tg[f]
             score, reg = model(voxels, batch.fpn_levels[f], idx, [None], drop['imsize'])
             score = score.squeeze(0).permute(1, 2, 0)
             reg = reg.squeeze(0).permute(1, 2, 0)
-            cls_loss, reg_loss = drop['crit'](pi, ni, gi, gt.to(dev), score, reg, drop['anchors'], 2)
+            cls_loss, reg_loss = drop['crit'](pi, ni, gi, drop['gt_dev'], score, reg, drop['anchors'], 2)
             loss = cls_loss if reg_loss is None else cls_loss + reg_loss
             loss.backward()
             opt.step()
-        pending_status.extend(statuses)
+        from modules import whole
+        pending_status.extend(statuses + whole.take_status(model))
         return [v.shape[1] for v, _ in frames]
 
     full = {}
@@ -666,8 +670,8 @@ def _run(args, rank, world, dev):
             if os.path.exists(tpath) and main_math == 'f32':
                 with open(tpath) as fh:
                     tj = json.load(fh)
-                roof['traffic'] = tj.get('conv3d_gather_pw_hbm_bytes_per_launch_r02', tj.get('conv3d_gather_pw_hbm_bytes_per_launch'))
-                roof['traffic_note'] = tj.get('note_r02', 'per launch of the round-1 single-frame form; see profiles/')
+                roof['traffic'] = tj.get('conv3d_gather_pw_hbm_bytes_per_launch_r03', tj.get('conv3d_gather_pw_hbm_bytes_per_launch_r02'))
+                roof['traffic_note'] = tj.get('note_r03', tj.get('note_r02', 'see profiles/'))
             metric = 'KITTI frames/sec (voxelize+VFE+fusion+3Dconv fwd+bwd)'
         elif args.mode == 'fusion':
             workload = ('%s, %d raw pts -> %d pts, T=35, %d frames/GPU/step: crop+cropToSight+lidar2Img (KITTI 2011_09_26 calibration), '

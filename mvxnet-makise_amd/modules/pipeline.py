@@ -65,8 +65,11 @@ class FrameBatch:
         return _hip.crop_project(self.raw, self.n_raw, cfg.velorange, m64, p64, imsize_wh, m32, p32, self.cap_points)
 
 
-def voxelize_batch(batch, T=None):
-    """One batched voxelizer call for all frames; a single host read of the voxel counts."""
+def voxelize_batch(batch, T=None, with_maps=False):
+    """One batched voxelizer call for all frames; a single host read of the voxel counts.  ``with_maps``: also build every
+    frame's compact-row map here (ONE more host read for all frames) and attach it to the frame's voxel tensor
+    (``voxels._mvx_fs``): MVXNet.forward then finds it and needs no host read of its own, so a loop that calls the model
+    one frame at a time (train.py:110-164) can enqueue frame k+1 while frame k is still running."""
     T = cfg.samplenum if T is None else T
     points6, n_points = batch.prepared()
     res = _hip.voxelize(points6, batch.perms, n_points, cfg.velorange[0:3], cfg.voxelsize, T, 9)
@@ -74,6 +77,17 @@ def voxelize_batch(batch, T=None):
     frames = []
     for f, v in enumerate(counts):
         frames.append((res.voxels[f, :v].unsqueeze(0), res.coords[f, :v]))
+    if with_maps:
+        from modules import frames as fr
+        sets = [fr.FrameSet(v[0], idx, [0, v.shape[1]], T) if v.shape[1] > 0 else None for v, idx in frames]
+        live = [fs for fs in sets if fs is not None]
+        if live:
+            offs = torch.stack([fs.enqueue_map() for fs in live]).tolist()          # the padded rows are zeroed in place here
+            for fs, off in zip(live, offs):
+                fs.finish_map(off)
+        for (v, _), fs in zip(frames, sets):
+            if fs is not None:
+                v._mvx_fs = fs
     return frames, res.status
 
 

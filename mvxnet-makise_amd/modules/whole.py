@@ -39,9 +39,11 @@ class WholeModelFunction(torch.autograd.Function):
         from modules import rpn_frames as rf
         dev = voxels.device
         n, t = voxels.shape[1], voxels.shape[2]
-        fs = fr.FrameSet(voxels[0], idx.contiguous(), [0, n], t)
-        real_off = fs.enqueue_map().tolist()         # zeroes the padded rows in place (imhead/Pipe.py:54-59); one host read
-        fs.finish_map(real_off)
+        fs = getattr(voxels, '_mvx_fs', None)        # built with the voxels by pipeline.voxelize_batch(with_maps=True)
+        if fs is None or fs.voxels.data_ptr() != voxels.data_ptr() or fs.Vt != n or fs.T != t or fs.desc is None:
+            fs = fr.FrameSet(voxels[0], idx.contiguous(), [0, n], t)
+            real_off = fs.enqueue_map().tolist()     # zeroes the padded rows in place (imhead/Pipe.py:54-59); one host read
+            fs.finish_map(real_off)
         model.prepack()
         statuses = []
         _hip.arena_begin(dev, doubles=1 << 21)
@@ -52,8 +54,7 @@ class WholeModelFunction(torch.autograd.Function):
         finally:
             _hip.arena_end()
         ctx.model, ctx.saved, ctx.rs, ctx.params = model, saved, rs, params
-        ctx.statuses = statuses
-        model.__dict__['_mvx_last_status'] = statuses          # whole.forward checks it at once when no backward will follow
+        model.__dict__.setdefault('_mvx_status', []).extend(statuses)      # checked by whole.forward / take_status, never here
         return heads
 
     @staticmethod
@@ -62,7 +63,6 @@ class WholeModelFunction(torch.autograd.Function):
         from modules import rpn_frames as rf
         model, saved, rs, params = ctx.model, ctx.saved, ctx.rs, ctx.params
         dev = g_heads.device
-        _check(ctx.statuses)                       # the forward finished long ago: this read does not stall the GPU
         direct = _hip.GRAD_SINK and all(p.grad is not None and p.grad.is_contiguous() for p in params)
         targets, views = None, None
         if not direct:
@@ -92,14 +92,25 @@ def _check(statuses):
         raise AssertionError('projected point outside the feature map')
 
 
+def take_status(model):
+    """The device status words of the forwards run since the last check (a training loop reads them with whatever it reads
+    anyway, e.g. once per logging interval: a host read drains the stream, so none is made inside forward / backward)."""
+    return model.__dict__.pop('_mvx_status', [])
+
+
+MAX_PENDING_STATUS = 512          # forwards whose status words may stay unread (then one read is made)
+
+
 def forward(model, voxels, imgs, idx, imsize):
-    """MVXNet.forward on the single node: (score (1,2,H/2,W/2), reg (1,14,H/2,W/2)); the data-dependent status words of the
-    sampling / scatter kernels are checked like the reference's assert (imhead/Pipe.py:71: one device read)."""
+    """MVXNet.forward on the single node: (score (1,2,H/2,W/2), reg (1,14,H/2,W/2)).  The data-dependent status words of the
+    sampling / scatter kernels stand for the reference's assert (imhead/Pipe.py:71); they are collected on the model and
+    read without stalling the training stream (take_status), at once for a no-grad call."""
     hw = imsize.tolist() if torch.is_tensor(imsize) else [float(imsize[0]), float(imsize[1])]
     params = [p for p in model.parameters() if p.requires_grad]
     heads = WholeModelFunction.apply(voxels, idx, model, imgs, hw, *params)
-    if not heads.requires_grad:                      # no backward will follow: check the status words now
-        _check(model.__dict__.pop('_mvx_last_status', None))
+    # no backward will follow (inference): the reference's assert, now; training: at most every MAX_PENDING_STATUS words
+    if not heads.requires_grad or len(model.__dict__.get('_mvx_status', ())) > MAX_PENDING_STATUS:
+        _check(take_status(model))
     h1, w1 = cfg.voxelshape[0] // 2, cfg.voxelshape[1] // 2
     v = heads.view(1, h1, w1, 16)
     return torch.sigmoid(v[..., :2]).permute(0, 3, 1, 2), v[..., 2:].permute(0, 3, 1, 2)
