@@ -548,7 +548,7 @@ def _run(args, rank, world, dev):
 
     def conv_roofline(tm, run, math=None):
         """Dominant kernel conv3d_gather_pw (exact f32) / conv3d_gather_split (bf16x3): conv2/conv3 forward (background-aware)
-        + tile-restricted dgrad launches.  achieved = EXECUTED matrix FLOPs (the kernel's own wave-stage counter x 1.18 MFLOP;
+        + tile-restricted dgrad launches.  achieved = EXECUTED matrix FLOPs (the kernel's own stage counter x 4.72 MFLOP;
         skipped tiles are not credited; x 3 MFMAs per product in the bf16x3 arithmetic) / sum of the launch durations from
         HIP events recorded on the launch stream inside the timed region, against the peak of the MFMA type that ran."""
         math = main_math if math is None else math
@@ -562,8 +562,8 @@ def _run(args, rank, world, dev):
              'launches': len(ev), 'avg_launch_ms': ms / max(1, len(ev)), 'flop_per_launch': fl / max(1, len(ev)),
              'dense_equivalent_tflops': dense_fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
              'note': 'exact f32 MFMA (v_mfma_f32_32x32x2_f32); FLOPs are the EXECUTED ones counted by the kernel: tiles that hold '
-                     'only the voxel-free background, depth taps whose source halo holds no voxel, idle image-border tiles and waves '
-                     'whose 32 output sites are all background sites are written from constants and not credited, while the time of filling them (about 60 % of the tiles of a launch) '
+                     'only the voxel-free background, depth taps whose source halo holds no voxel and idle image-border tiles are '
+                     'written from constants and not credited, while the time of filling them (about 60 % of the tiles of a launch) '
                      'stays in the denominator; measured while the side-stream weight-gradient kernels share the CUs; `isolated` '
                      '= the same kernel on dense launches alone'}
         if math == 'bf16x3':
@@ -572,7 +572,7 @@ def _run(args, rank, world, dev):
                      flop_per_launch=3.0 * r['flop_per_launch'],
                      kernel='conv3d_gather_split (conv2 / conv3 forward + dgrad of all frames of the step)',
                      note='bf16 hi/lo split MFMA (v_mfma_f32_32x32x16_bf16, f32 accumulate), EXECUTED stages counted by the kernel '
-                          'as wave-stages of 1.18 MFLOP x 3 MFMAs per product, against the dense bf16 peak; skipped background tiles are not credited')
+                          'x 4.72 MFLOP x 3 MFMAs per product, against the dense bf16 peak; skipped background tiles are not credited')
         return r
 
     def hbm_stages(tm):

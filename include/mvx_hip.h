@@ -247,8 +247,7 @@ int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int32_t din, i
  *   mvx_conv3d_forward_bg mvx_conv3d_forward on a source with background: tiles whose halo flags are clear
  *                         (and, with border_active, that do not touch the image border) are filled with the
  *                         constant; background SITES (out_mask == 0) inside computed tiles get it too.
- *                         exec_stages (optional) u64 [1] += executed WAVE-stages (32 sites x 64 channels x one (depth tap, 32-channel) stage = 1.18 MFLOP;
- *                         waves whose 32 output sites are all background sites issue no MFMA and are not counted)
+ *                         exec_stages (optional) u64 [1] += executed (depth tap, 32-channel) stages of 4.7 MFLOP
  *   mvx_plane_tap_sums    tap_sums f32 [planes][9][channels]: for each in-plane tap (a,b) the sum of dz over the sites
  *                         whose tap source (y+a-1, x+b-1) lies inside the image (f64 accumulation).  With tile_flags
  *                         + inactive_sums f32 [planes][channels] (both or neither): dz is only defined on the flagged
@@ -316,7 +315,7 @@ int mvx_conv3d_wgrad_bg_split(const float *in, const float *dz, float *dw, int32
                               const int32_t *in_halo_flags, const float *c_in, const float *tap_sums, void *workspace,
                               size_t workspace_bytes, void *stream);
 /* ... and their frame-set forms (planes of n_frames frames stacked along depth, per-frame statistics [F][R][2][cout];
- * exec_stages (optional) u64 [1] += executed wave-stages, the unit of the f32 kernels) */
+ * exec_stages (optional) u64 [1] += executed (depth tap, 32-channel chunk) stages, as in the f32 kernels) */
 int mvx_conv3d_forward_bg_split_frames(const float *in, const void *wsplit, const float *bias, float *out, double *stats,
                                        int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
                                        int32_t stride_d, int32_t pad_d, int32_t flags, const int32_t *in_halo_flags,

@@ -188,17 +188,7 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
     // window never leaves the image -> every output site of the tile is the per-plane constant.
     bool active = true;
     if (in_hflag) active = (((border_active & 1) && on_border) || any_flag) != 0;
-    // Wave-level skipping (forward with a site mask): a wave whose 32 output sites (two patch rows) are ALL background sites
-    // writes the plane's constant for every one of them in the epilogue, whatever it accumulated -- so it issues no MFMA
-    // (it still takes part in the cooperative staging and the barriers, and leaves the matrix pipe of its SIMD to the
-    // co-resident workgroup).  About a fifth of the waves of the computed tiles on lidar frames; outputs unchanged bit for bit.
-    bool wave_on = true;
-    if (out_mask && active && g.mode == 0) {
-        const int sy = min(ty0 + 2 * wv + ((lane & 31) >> 4), g.H - 1), sx = min(tx0 + (lane & 15), g.W - 1);
-        wave_on = __any(out_mask[((size_t)d * g.H + sy) * g.W + sx] != 0) != 0;
-    }
-    // executed work only, in WAVE-stages (32 sites x 64 channels x one (depth tap, 32-channel chunk)): 4 per tile stage
-    if (exec_stages && active && wave_on && lane == 0) atomicAdd(exec_stages, (unsigned long long)nstages);
+    if (exec_stages && active && threadIdx.x == 0) atomicAdd(exec_stages, (unsigned long long)nstages);   // executed work only
     if (active && nstages > 0) {
     auto stage_kd = [&](int st, int &kd, int &ds, int &cc) __attribute__((always_inline)) {
         const int i = st / nchunks;
@@ -288,17 +278,17 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
         __syncthreads();
         load_wrow(st, 1);                          // next weight row first ...
         load_halo(nxt);                            // ... then the long-latency halo of the next stage
-        if (wave_on) compute_row(0);
+        compute_row(0);
         __syncthreads();
         store_wrow();                              // tap row 1 (waits for its 6 loads only)
         __syncthreads();
         load_wrow(st, 2);
-        if (wave_on) compute_row(1);
+        compute_row(1);
         __syncthreads();
         store_wrow();                              // tap row 2
         __syncthreads();
         load_wrow(nxt, 0);
-        if (wave_on) compute_row(2);
+        compute_row(2);
     }
     } else {
     // two tap rows [r0, r0 + 1] (2 x 2 window): the same pipeline with one row step less per stage.  With g.s2d the
@@ -349,12 +339,12 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
         __syncthreads();
         load_wrow(st, r0 + 1);
         load_halo(nxt);
-        if (row0 && wave_on) compute_row(r0, colmask);
+        if (row0) compute_row(r0, colmask);
         __syncthreads();
         store_wrow();                              // tap row r0 + 1
         __syncthreads();
         load_wrow(nxt, r0);
-        if (row1 && wave_on) compute_row(r0 + 1, colmask);
+        if (row1) compute_row(r0 + 1, colmask);
     }
     }
     }   // active

@@ -172,8 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_split(const float *__res
         }
     }
     const int nstages = active ? nk * nchunks : 0;
-    // executed stages only, in wave-stages (4 per 8 x 16-tile stage: the unit of conv3d.hip's counter)
-    if (exec_stages && nstages > 0 && threadIdx.x == 0) atomicAdd(exec_stages, (unsigned long long)nstages * 4);
+    if (exec_stages && nstages > 0 && threadIdx.x == 0) atomicAdd(exec_stages, (unsigned long long)nstages);    // executed stages only
     auto stage_of = [&](int st, int &kd, int &ds, int &cc) __attribute__((always_inline)) {
         const int i = st / nchunks;
         cc = st - i * nchunks;
@@ -435,8 +434,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_split16(const float *__r
         }
     }
     const int nstages = active ? nk * nchunks : 0;
-    // executed work in wave-stages of the 8 x 16 kernels (32 sites x 64 channels x one stage: what the roofline prices)
-    if (exec_stages && nstages > 0 && threadIdx.x == 0) atomicAdd(exec_stages, (unsigned long long)nstages * (has_bot ? 8 : 4));
+    // executed work in units of the 8 x 16-tile stage (what the roofline prices): this workgroup covers one or two of them
+    if (exec_stages && nstages > 0 && threadIdx.x == 0) atomicAdd(exec_stages, (unsigned long long)nstages * (has_bot ? 2 : 1));
     auto stage_of = [&](int st, int &kd, int &ds, int &cc) __attribute__((always_inline)) {
         const int i = st / nchunks;
         cc = st - i * nchunks;

@@ -476,7 +476,7 @@ class Background:
 
 
 EXEC_STAGES = None       # device u64 counter of executed gather stages while KERNEL_TIMERS is on (bench roofline)
-STAGE_FLOP = 2.0 * 9 * 32 * 32 * 64      # one WAVE-stage of the gather kernels: 32 sites x 64 channels x (9 taps x 32 input channels)
+STAGE_FLOP = 2.0 * 9 * 128 * 32 * 64
 
 
 def n_tiles(H, W):

@@ -1,0 +1,83 @@
+"""Debug: bf16x3 background-aware forward with 16x16 units against 8x16 units on an odd shape; prints where they differ."""
+import os, sys
+import numpy as np
+import torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, 'mvxnet-makise_amd'))
+sys.argv = sys.argv[:1]
+from modules import _hip
+dev = torch.device('cuda')
+for shape in [(3, 37, 53, 2, 1), (5, 40, 48, 1, 0), (10, 24, 35, 2, 1)]:
+    din, H, W, sd, pd = shape
+    cin = cout = 64
+    g = torch.Generator(device='cpu').manual_seed(5)
+    dout = _hip.conv_out_depth(din, sd, pd)
+    act = torch.zeros((din, H, W), dtype=torch.uint8)
+    for _ in range(6):
+        act[int(torch.randint(0, din, (1,), generator=g)), int(torch.randint(0, H, (1,), generator=g)), int(torch.randint(0, W, (1,), generator=g))] = 1
+    act[0, 0, 0] = 1
+    c_in = torch.randn((din, cin), generator=g)
+    x = c_in[:, None, None, :].expand(din, H, W, cin).clone()
+    noise = torch.randn((din, H, W, cin), generator=g)
+    x = torch.where(act[..., None].bool(), noise, x).contiguous().to(dev)
+    w = (torch.randn((cout, cin, 3, 3, 3), generator=g) * 0.05).to(dev)
+    b = torch.randn((cout,), generator=g).to(dev)
+    th, tw = 8, 16
+    ty, tx = (H + th - 1) // th, (W + tw - 1) // tw
+    hflag = torch.zeros((din, ty * tx), dtype=torch.int32)
+    for d in range(din):
+        for t in range(ty * tx):
+            y0, x0 = (t // tx) * th - 1, (t % tx) * tw - 1
+            hflag[d, t] = int(act[d, max(y0, 0):min(y0 + th + 2, H), max(x0, 0):min(x0 + tw + 2, W)].any())
+    bg_in = _hip.Background(c_in.to(dev), act.to(dev), hflag.to(dev))
+    out_mask, _ = _hip.activity_dilate(act.to(dev), False, din, H, W, sd, pd, mark_border=True)
+    bg_pre = _hip.conv3d_background(w, c_in.to(dev), din, sd, pd)
+    wps = _hip.conv3d_pack(w, False, split=True)
+    res = {}
+    for tag, val in (('8', str(1 << 60)), ('16', '0')):
+        os.environ['MVX_SPLIT16_MIN_UNITS'] = val
+        for rep in range(3):
+            poison = torch.full((dout, H, W, cout), float('nan'), device=dev)
+            torch.cuda.synchronize()
+            del poison                           # the wrapper's torch.empty of the same size takes this block: unwritten sites show as NaN
+            y, _ = _hip.conv3d_forward_bg(x, wps, b, cout, sd, pd, bg_in, out_mask, bg_pre, split=True)
+            assert not torch.isnan(y).any(), ('bg', tag, rep, torch.isnan(y).any(-1).nonzero()[:8].tolist())
+            torch.cuda.synchronize()
+            res[(tag, rep)] = y.clone()
+    for tag, val in (('d8', str(1 << 60)), ('d16', '0')):
+        os.environ['MVX_SPLIT16_MIN_UNITS'] = val
+        for rep in range(4):
+            poison = torch.full((dout, H, W, cout), float('nan'), device=dev)
+            torch.cuda.synchronize()
+            del poison
+            y, _ = _hip.conv3d_forward(x, wps, b, cout, sd, pd, split=True)
+            if torch.isnan(y).any():
+                print('UNWRITTEN sites in dense', tag, rep, torch.isnan(y).any(-1).nonzero()[:16].tolist())
+            torch.cuda.synchronize()
+            res[(tag, rep)] = y.clone()
+    yf, _ = _hip.conv3d_forward(x, _hip.conv3d_pack(w, False), b, cout, sd, pd)
+    print(shape, 'dense split 8x16 vs exact f32: max abs', float((res[('d8', 0)] - yf).abs().max()), ' bg split vs dense split:',
+          float((res[('8', 0)] - res[('d8', 0)]).abs().max()))
+    for key in [k for k in res if k[0].startswith('d')]:
+        y = res[key]
+        bad = (y != res[('d8', 0)]).any(-1)
+        n = int(bad.sum())
+        print(shape, key, 'DENSE sites differing from dense 8x16 run 0:', n)
+        if n:
+            idx = bad.nonzero()[:12].tolist()
+            print('   first:', idx)
+            i = idx[0]
+            ch = (y[i[0], i[1], i[2]] != res[('d8', 0)][i[0], i[1], i[2]]).nonzero().flatten().tolist()
+            print('   channels:', ch[:40], 'values', y[i[0], i[1], i[2], ch[:4]].tolist(), 'ref', res[('d8', 0)][i[0], i[1], i[2], ch[:4]].tolist())
+    res = {k: v for k, v in res.items() if not k[0].startswith('d')}
+    ref = res[('8', 0)]
+    for key, y in res.items():
+        bad = (y != ref).any(-1)
+        n = int(bad.sum())
+        print(shape, key, 'sites differing from 8x16 run 0:', n)
+        if n:
+            idx = bad.nonzero()[:12].tolist()
+            print('   first:', idx, 'mask there:', [int(out_mask[i[0], i[1], i[2]]) for i in idx])
+            i = idx[0]
+            ch = (y[i[0], i[1], i[2]] != ref[i[0], i[1], i[2]]).nonzero().flatten().tolist()
+            print('   channels:', ch[:40], 'values', y[i[0], i[1], i[2], ch[:4]].tolist(), 'ref', ref[i[0], i[1], i[2], ch[:4]].tolist())
