@@ -81,6 +81,11 @@ typedef struct {
 
 /* ABI version; bumped whenever a signature changes. */
 int mvx_abi_version(void);
+/* tuning values of the library (process-wide, not stream-ordered; meant for benchmarks and tests).  Keys:
+ *   MVX_TUNE_SPLIT16_MIN_UNITS  the bf16x3 gather uses 16 x 16-site workgroup units when a launch has at least this many of them
+ *                               (default 768), else 8 x 16-site units; 0 = always 16 x 16, a huge value = never */
+#define MVX_TUNE_SPLIT16_MIN_UNITS 1
+int mvx_tuning_set(int32_t key, int64_t value);
 /* Diagnostics: number of kernel launches the library has issued since it was loaded (fills excluded). */
 uint64_t mvx_launch_count(void);
 

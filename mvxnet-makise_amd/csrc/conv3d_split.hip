@@ -15,7 +15,6 @@
 //   - weights are pre-split by the pack kernel and staged three taps (one kernel row) at a time, so a
 //     barrier pair covers 3 taps x 12 MFMAs per wave instead of one tap.
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -604,17 +603,23 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_split16(const float *__r
     }
 }
 
-// 16 x 16-site units when the launch has enough of them to fill two workgroup slots on every CU with a margin, else 8 x 16
+// 16 x 16-site units when the launch has enough of them to fill two workgroup slots on every CU with a margin, else 8 x 16.
+// The threshold is a tuning value (mvx_tuning_set(MVX_TUNE_SPLIT16_MIN_UNITS, v): 0 forces the 16 x 16 kernel, a huge
+// value the 8 x 16 one; the tests run both shapes on small inputs that way).
+static long long g_split16_min_units = 768;
+
+extern "C" int mvx_tuning_set(int32_t key, int64_t value) {
+    if (key == MVX_TUNE_SPLIT16_MIN_UNITS) { g_split16_min_units = value; return MVX_OK; }
+    return MVX_EINVAL;
+}
+
 static void launch_gather_split(hipStream_t st, int planes, int nblocks, const float *in, const unsigned short *wsp,
                                 const float *bias, float *out, double *stats, const Geom &g, int relu, const int *in_hflag,
                                 const unsigned char *out_mask, const float *bg_pre, int border_active, const int *only_tiles,
                                 unsigned long long *exec_stages) {
     const int tiles_x = (int)mvx_cdiv(g.W, TW);
     const long long units16 = (long long)tiles_x * mvx_cdiv(g.H, TH2) * planes * nblocks;
-    // MVX_SPLIT16_MIN_UNITS: tuning / test knob (0 forces the 16 x 16 kernel, a huge value the 8 x 16 one)
-    const char *env = getenv("MVX_SPLIT16_MIN_UNITS");
-    const long long min_units = env ? atoll(env) : 768;
-    if (units16 >= min_units)
+    if (units16 >= g_split16_min_units)
         hipLaunchKernelGGL(conv3d_gather_split16, dim3(tiles_x * mvx_cdiv(g.H, TH2), planes, nblocks), dim3(256), 0, st, in, wsp,
                            bias, out, stats, g, relu, in_hflag, out_mask, bg_pre, border_active, only_tiles, exec_stages);
     else

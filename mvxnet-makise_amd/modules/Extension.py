@@ -28,6 +28,7 @@ _sz = ctypes.c_size_t
 # name -> (restype, argtypes); mirrors include/mvx_hip.h one to one
 PROTOTYPES = {
     'mvx_abi_version': (_i32, []),
+    'mvx_tuning_set': (_i32, [_i32, _i64]),
     'mvx_launch_count': (ctypes.c_uint64, []),
     'mvx_voxelize_workspace_bytes': (_sz, [_i32, _i32]),
     'mvx_voxelize': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _f64, _f64, _f64, _f64, _f64, _f64,

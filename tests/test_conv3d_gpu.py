@@ -123,14 +123,10 @@ def test_cml_stack_matches_reference_fixture(golden):
 def split_units(request):
     """The bf16x3 gather has two workgroup shapes (csrc/conv3d_split.hip: 8 x 16 sites, and 16 x 16 sites with 64-site wave
     tiles, picked by the number of units of a launch): run the test with each forced."""
-    import os
-    old = os.environ.get('MVX_SPLIT16_MIN_UNITS')
-    os.environ['MVX_SPLIT16_MIN_UNITS'] = '0' if request.param.startswith('16') else str(1 << 60)
+    from modules import Extension as X
+    X.check(X.lib.mvx_tuning_set(1, 0 if request.param.startswith('16') else 1 << 60), 'mvx_tuning_set')      # MVX_TUNE_SPLIT16_MIN_UNITS
     yield request.param
-    if old is None:
-        del os.environ['MVX_SPLIT16_MIN_UNITS']
-    else:
-        os.environ['MVX_SPLIT16_MIN_UNITS'] = old
+    X.check(X.lib.mvx_tuning_set(1, 768), 'mvx_tuning_set')
 
 
 @pytest.mark.parametrize('cin,cout,din,H,W,sd,pd', GEOMS[:4])
@@ -289,8 +285,8 @@ def test_split_gather_workgroup_shapes_give_identical_outputs():
     """The two workgroup shapes of the bf16x3 gather accumulate every output in the same order (stage by stage, tap by tap,
     k by k): forward and input gradient must be BIT-identical, on a size that is no multiple of either tile (the last
     16 x 16 unit covers a single 8 x 16 tile) and with more than one output-channel block."""
-    import os
     from modules import _hip
+    from modules import Extension as X
     g = torch.Generator().manual_seed(21)
     din, H, W, cin, cout, sd, pd = 3, 40, 53, 64, 128, 1, 1
     x = torch.randn((din, H, W, cin), generator=g).to(DEV)
@@ -299,18 +295,14 @@ def test_split_gather_workgroup_shapes_give_identical_outputs():
     dz = torch.randn((din, H, W, cout), generator=g).to(DEV)
     wf, wd = _hip.conv3d_pack(w, False, split=True), _hip.conv3d_pack(w, True, split=True)
     res = {}
-    old = os.environ.get('MVX_SPLIT16_MIN_UNITS')
     try:
-        for tag, val in (('8', str(1 << 60)), ('16', '0')):
-            os.environ['MVX_SPLIT16_MIN_UNITS'] = val
+        for tag, val in (('8', 1 << 60), ('16', 0)):
+            X.check(X.lib.mvx_tuning_set(1, val), 'mvx_tuning_set')
             y, st = _hip.conv3d_forward(x, wf, b, cout, sd, pd, split=True)
             dx = _hip.conv3d_dgrad(dz, wd, din, cin, sd, pd, split=True)
             torch.cuda.synchronize()
             res[tag] = (y.clone(), st.sum(0).clone(), dx.clone())
     finally:
-        if old is None:
-            os.environ.pop('MVX_SPLIT16_MIN_UNITS', None)
-        else:
-            os.environ['MVX_SPLIT16_MIN_UNITS'] = old
+        X.check(X.lib.mvx_tuning_set(1, 768), 'mvx_tuning_set')
     assert torch.equal(res['8'][0], res['16'][0]) and torch.equal(res['8'][2], res['16'][2])
     assert torch.allclose(res['8'][1], res['16'][1], rtol=1e-6, atol=1e-6 * float(res['8'][1].abs().max()))

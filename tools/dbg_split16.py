@@ -6,6 +6,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, 'mvxnet-makise_amd'))
 sys.argv = sys.argv[:1]
 from modules import _hip
+from modules import Extension as X
 dev = torch.device('cuda')
 for shape in [(3, 37, 53, 2, 1), (5, 40, 48, 1, 0), (10, 24, 35, 2, 1)]:
     din, H, W, sd, pd = shape
@@ -34,8 +35,8 @@ for shape in [(3, 37, 53, 2, 1), (5, 40, 48, 1, 0), (10, 24, 35, 2, 1)]:
     bg_pre = _hip.conv3d_background(w, c_in.to(dev), din, sd, pd)
     wps = _hip.conv3d_pack(w, False, split=True)
     res = {}
-    for tag, val in (('8', str(1 << 60)), ('16', '0')):
-        os.environ['MVX_SPLIT16_MIN_UNITS'] = val
+    for tag, val in (('8', 1 << 60), ('16', 0)):
+        X.lib.mvx_tuning_set(1, val)
         for rep in range(3):
             poison = torch.full((dout, H, W, cout), float('nan'), device=dev)
             torch.cuda.synchronize()
@@ -44,8 +45,8 @@ for shape in [(3, 37, 53, 2, 1), (5, 40, 48, 1, 0), (10, 24, 35, 2, 1)]:
             assert not torch.isnan(y).any(), ('bg', tag, rep, torch.isnan(y).any(-1).nonzero()[:8].tolist())
             torch.cuda.synchronize()
             res[(tag, rep)] = y.clone()
-    for tag, val in (('d8', str(1 << 60)), ('d16', '0')):
-        os.environ['MVX_SPLIT16_MIN_UNITS'] = val
+    for tag, val in (('d8', 1 << 60), ('d16', 0)):
+        X.lib.mvx_tuning_set(1, val)
         for rep in range(4):
             poison = torch.full((dout, H, W, cout), float('nan'), device=dev)
             torch.cuda.synchronize()
