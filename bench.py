@@ -554,8 +554,8 @@ def _run(args, rank, world, dev):
         math = main_math if math is None else math
         ev = tm.get('conv3d_gather_bg', []) + tm.get('conv3d_gather_tiles', []) + tm.get('conv3d_gather', [])
         ms = sum(s.elapsed_time(e) for s, e, _ in ev)
-        dense_fl = sum(f for _, _, f in ev)
-        fl = float(exec_stages[run]) * _hip.STAGE_FLOP + sum(f for _, _, f in tm.get('conv3d_gather', []))
+        dense_fl = sum(_hip.timer_value(f) for _, _, f in ev)
+        fl = float(exec_stages[run]) * _hip.STAGE_FLOP + sum(_hip.timer_value(f) for _, _, f in tm.get('conv3d_gather', []))
         alg = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         r = {'bound': 'mfma', 'achieved': alg, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': alg / FP32_MFMA_PEAK_TFLOPS,
              'traffic': None, 'kernel': 'conv3d_gather_pw (conv2 / conv3 forward + dgrad of all frames of the step: 4 launches per step)',
@@ -580,7 +580,7 @@ def _run(args, rank, world, dev):
         for name, evs in tm.items():
             if name.startswith('hbm:') and evs:
                 tms = sum(s.elapsed_time(e) for s, e, _ in evs)
-                tb = sum(float(b) for _, _, b in evs)       # device scalars (data-dependent byte counts) are read here
+                tb = sum(_hip.timer_value(b) for _, _, b in evs)       # data-dependent byte counts are evaluated here, after the run
                 out[name[4:]] = {'launches': len(evs), 'avg_ms': tms / len(evs),
                                  'algorithmic_GBps': tb / (tms * 1e-3) / 1e9 if tms > 0 and tb > 0 else None,
                                  'frac_of_8TBps': tb / (tms * 1e-3) / 8e12 if tms > 0 and tb > 0 else None}
@@ -685,7 +685,7 @@ def _run(args, rank, world, dev):
                         % (wl, RAW_POINTS, args.points, args.frames))
             ev = timers.get('hbm:feature_sample', [])
             ms = sum(s.elapsed_time(e) for s, e, _ in ev)
-            tb = sum(float(b) for _, _, b in ev)
+            tb = sum(_hip.timer_value(b) for _, _, b in ev)
             ach = tb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             roof = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS, 'traffic': None,
                     'kernel': 'feature_sample_rows (bilinear FPN sampling of all frames of the step)', 'launches': len(ev),
@@ -699,7 +699,7 @@ def _run(args, rank, world, dev):
                         % (wl, RAW_POINTS, args.points, args.frames, vfe_check))
             ev = timers.get('hbm:voxelize', [])
             ms = sum(s.elapsed_time(e) for s, e, _ in ev)
-            tb = sum(b for _, _, b in ev)
+            tb = sum(_hip.timer_value(b) for _, _, b in ev)
             ach = tb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             roof = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS, 'traffic': None,
                     'kernel': 'voxelizer (all its launches, %d frames per call)' % args.frames, 'launches': len(ev),
@@ -754,7 +754,7 @@ def _run(args, rank, world, dev):
             if evs:
                 tms = sum(s.elapsed_time(e) for s, e, _ in evs)
                 other[name] = {'launches': len(evs), 'avg_launch_ms': tms / len(evs)}
-                fl = sum(float(f) for _, _, f in evs)
+                fl = sum(_hip.timer_value(f) for _, _, f in evs)
                 if fl > 0:
                     mult, peak = (3.0, BF16_MFMA_PEAK_TFLOPS) if (main_math == 'bf16x3' and name in ('conv3d_wgrad_bg', 'rpn_conv', 'rpn_wgrad')) \
                         else (1.0, FP32_MFMA_PEAK_TFLOPS)

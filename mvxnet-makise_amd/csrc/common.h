@@ -24,6 +24,10 @@ static inline unsigned mvx_cdiv(long long a, long long b) { return (unsigned)((a
 
 // ---- internal helpers shared between translation units (NOT part of the C ABI) -----------------------
 // conv3d.hip: compacted (plane, tile) step lists of the background-aware weight gradient and its closed-form term
+struct FrameMap;
+int mvxi_linear_forward_split(const float *x, int ldx, const float *w, int ldw, const float *bias, float *y,
+                              int ldy, double *stats, const float *row_w, long long rows, int k, int n, int relu,
+                              unsigned *fin_counter, double fin_eps, float *fin_mean_inv, const FrameMap &fm, hipStream_t st);
 int mvxi_wgrad_step_list(const int32_t *in_halo_flags, int din, int dout, int ntiles, int stride_d, int pad_d, int *list,
                          int *count, hipStream_t st, int n_frames = 1);
 int mvxi_wgrad_rank1(const float *tap_sums, const float *c_in, float *dw, int din, int dout, int cin, int cout, int stride_d,

@@ -430,6 +430,9 @@ static int linear_forward_impl(const float *x, int32_t ldx, const float *w, int3
         ydst = (float *)splitk_workspace;
         ld_dst = n;
     }
+    if ((flags & MVX_FLAG_SPLIT) && vec && wide && splits == 1 && !w_transposed)    // bf16x3 arithmetic for the wide layers
+        return mvxi_linear_forward_split(x, ldx, w, ldw, bias, y, ldy, stats, row_w, (long long)rows, k, n, relu, fin_counter,
+                                         fin_eps, fin_mean_inv, fm, st);
     const dim3 grid(mvx_cdiv(n, wide ? 128 : 64), mvx_cdiv(rows, BM), splits);
 #define MVX_LAUNCH_LIN(WT, NT, VEC)                                                                               \
     hipLaunchKernelGGL((linear_fwd<WT, NT, VEC>), grid, dim3(256), 0, st, x, ldx, w, ldw, bias, ydst, ld_dst, stats, \

@@ -1,0 +1,223 @@
+// Row GEMMs on the bf16 matrix cores with fp32-grade accuracy ("bf16x3" split), the opt-in arithmetic of
+// `convmath: bf16x3` for the wide row layers (the fusion MLP's 768 -> 768 and 768 -> 128 layers and their input
+// gradients: nn.Linear / 1x1 Conv2d of modules/layers/Blocks.py:9,14,35,39 as used by modules/imhead/Pipe.py:88-92).
+//
+// Same contract as linear_fwd (linear.hip): y[r][n] = [ReLU](sum_k x[r][k] * W[n][k] + b[n]) with optional per-frame
+// BatchNorm sums / in-kernel finalisation, W row-major [n][k] (the input gradient passes the transposed weight as a
+// row-major matrix: modules/frames.py keeps that copy per parameter version).  Every f32 operand is
+// split while it is staged into hi = bf16(v), lo = bf16(v - hi) and a product is hi*hi + hi*lo + lo*hi with f32
+// accumulation: three v_mfma_f32_32x32x16_bf16 per product (csrc/conv3d_split.hip has the error analysis: ~2e-5 relative).
+//
+// Tile: 128 rows x 128 columns per workgroup, wave w owns 32 rows x 128 columns (four accumulator tiles); K in chunks
+// of 64: LDS rows are 272 bytes = 64 hi (128 B) | 64 lo (128 B) | 16 B pad (17 16-byte slots, odd: the ds_read_b128
+// fragment reads of 32 consecutive rows spread over all banks).  Per 16-k step a wave reads 2 A and 8 B fragments for
+// 12 MFMAs.  The next chunk's global loads are issued before the current chunk's MFMAs (register prefetch).
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BM = 128, BNL = 128, BK = 64, ROWB = 2 * BK * 2 + 16, NT = 4;
+
+__device__ __forceinline__ void split4(const f32x4 v, uint2 *hi, uint2 *lo) {
+    unsigned short h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const __bf16 hb = (__bf16)v[j];
+        const __bf16 lb = (__bf16)(v[j] - (float)hb);
+        h[j] = __builtin_bit_cast(unsigned short, hb);
+        l[j] = __builtin_bit_cast(unsigned short, lb);
+    }
+    hi->x = (unsigned)h[0] | ((unsigned)h[1] << 16); hi->y = (unsigned)h[2] | ((unsigned)h[3] << 16);
+    lo->x = (unsigned)l[0] | ((unsigned)l[1] << 16); lo->y = (unsigned)l[2] | ((unsigned)l[3] << 16);
+}
+
+__global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restrict__ x, int ldx, const float *__restrict__ w,
+                                                        int ldw, const float *__restrict__ bias, float *__restrict__ y,
+                                                        int ldy, double *__restrict__ stats, const float *__restrict__ row_w,
+                                                        long long R, int K, int N, int relu,
+                                                        unsigned *__restrict__ done_counter, double fin_eps,
+                                                        float *__restrict__ fin_mean_inv, FrameMap fm) {
+    constexpr int XV = BM * BK / 4 / 256;          // float4 per thread for the x tile (8)
+    constexpr int WV = BNL * BK / 4 / 256;         // ... and for the w tile (8)
+    __shared__ __attribute__((aligned(16))) unsigned char s_x[BM * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char s_w[BNL * ROWB];
+    __shared__ double s_red[4][2 * BNL];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const long long r0 = (long long)blockIdx.y * BM;
+    const int n0 = blockIdx.x * BNL;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int a_base = (wv * 32 + li) * ROWB + lh * 16;
+    const int b_base = li * ROWB + lh * 16;
+
+    // prefetch registers: unconditional loads from clamped addresses (see linear_fwd); the K tail is zeroed when stored
+    f32x4 xr[XV], wr[WV];
+    auto load_tiles = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < XV; ++u) {
+            const int c = tid + 256 * u, r = c >> 4, part = c & 15;
+            const long long gr = r0 + r;
+            const bool ok = gr < R && k0 + part * 4 < K;
+            xr[u] = *(const f32x4 *)(ok ? x + gr * ldx + k0 + part * 4 : x);
+        }
+#pragma unroll
+        for (int u = 0; u < WV; ++u) {
+            const int c = tid + 256 * u;
+            const int n = c >> 4, part = c & 15;
+            const bool ok = n0 + n < N && k0 + part * 4 < K;
+            wr[u] = *(const f32x4 *)(ok ? w + (long long)(n0 + n) * ldw + k0 + part * 4 : w);
+        }
+    };
+    auto store_tiles = [&](int k0) __attribute__((always_inline)) {
+        const bool tail = k0 + BK > K;
+#pragma unroll
+        for (int u = 0; u < XV; ++u) {
+            const int c = tid + 256 * u, r = c >> 4, part = c & 15;
+            f32x4 v = xr[u];
+            if (tail && k0 + part * 4 >= K) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            uint2 hi, lo;
+            split4(v, &hi, &lo);
+            *(uint2 *)(s_x + r * ROWB + part * 8) = hi;
+            *(uint2 *)(s_x + r * ROWB + 2 * BK + part * 8) = lo;
+        }
+#pragma unroll
+        for (int u = 0; u < WV; ++u) {
+            const int c = tid + 256 * u;
+            f32x4 v = wr[u];
+            const int n = c >> 4, part = c & 15;
+            if (tail) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (k0 + part * 4 + j >= K) v[j] = 0.f;
+            }
+            uint2 hi, lo;
+            split4(v, &hi, &lo);
+            *(uint2 *)(s_w + n * ROWB + part * 8) = hi;
+            *(uint2 *)(s_w + n * ROWB + 2 * BK + part * 8) = lo;
+        }
+    };
+
+    load_tiles(0);
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        __syncthreads();
+        store_tiles(k0);
+        __syncthreads();
+        if (k0 + BK < K) load_tiles(k0 + BK);
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_x + a_base + s * 32));
+            const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_x + a_base + 2 * BK + s * 32));
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_w + b_base + t * 32 * ROWB + s * 32));
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_w + b_base + t * 32 * ROWB + 2 * BK + s * 32));
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: the one of linear_fwd (loads first, then the stores, then the per-frame BatchNorm sums in f64)
+    float bsv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int c = n0 + t * 32 + li;
+        bsv[t] = bias ? bias[c < N ? c : N - 1] : 0.f;
+    }
+    float rwv[16];
+    if (stats && row_w) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const long long gr = r0 + wv * 32 + row;
+            rwv[r] = row_w[gr < R ? gr : R - 1];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rwv[r] = 1.f;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[t][r] + bsv[t];
+            if (relu) v = fmaxf(v, 0.f);
+            acc[t][r] = v;
+        }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int c = n0 + t * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const long long gr = r0 + wv * 32 + row;
+            if (gr < R && c < N) y[gr * ldy + c] = acc[t][r];
+        }
+    }
+    if (stats) {
+        const long long r_last = (r0 + BM - 1 < R ? r0 + BM - 1 : R - 1);
+        const int s_lo = fm.F == 1 ? 0 : fm_seg_of(fm, r0), s_hi = fm.F == 1 ? 0 : fm_seg_of(fm, r_last);
+        for (int sg = s_lo; sg <= s_hi; ++sg) {
+            const int f = fm.F == 1 ? 0 : (int)fm.seg_frame[sg];
+            const long long lo = fm.F == 1 ? 0 : fm.bound[sg], hi = fm.F == 1 ? R : fm.bound[sg + 1];
+            double s1[NT], s2[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int c = n0 + t * 32 + li;
+                s1[t] = 0.0; s2[t] = 0.0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const long long gr = r0 + wv * 32 + row;
+                    float v = acc[t][r];
+                    asm volatile("" : "+v"(v));
+                    if (gr < R && c < N && gr >= lo && gr < hi) {
+                        const double rw = (double)rwv[r];
+                        s1[t] += rw * (double)v;
+                        s2[t] += rw * (double)v * (double)v;
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const double a = s1[t] + __shfl_xor(s1[t], 32, 64), b = s2[t] + __shfl_xor(s2[t], 32, 64);
+                if (lh == 0) { s_red[wv][t * 32 + li] = a; s_red[wv][BNL + t * 32 + li] = b; }
+            }
+            __syncthreads();
+            double *fstats = stats + (size_t)f * MVX_REP * 2 * N;
+            for (int e = tid; e < 2 * BNL; e += 256) {
+                const int which = e / BNL, c = e % BNL;
+                if (n0 + c < N) {
+                    const double t = s_red[0][e] + s_red[1][e] + s_red[2][e] + s_red[3][e];
+                    atomicAdd(fstats + ((size_t)(blockIdx.y % MVX_REP) * 2 + which) * N + n0 + c, t);
+                }
+            }
+        }
+        if (done_counter) {
+            __shared__ int s_last;
+            bn_finalize_by_last_block(done_counter, gridDim.x * gridDim.y, stats, N, fm, fin_eps, fin_mean_inv, &s_last);
+        }
+    }
+}
+
+}  // namespace
+
+// Launched by linear.hip (linear_forward_impl) when MVX_FLAG_SPLIT is set and the shape qualifies.
+int mvxi_linear_forward_split(const float *x, int ldx, const float *w, int ldw, const float *bias, float *y,
+                              int ldy, double *stats, const float *row_w, long long rows, int k, int n, int relu,
+                              unsigned *fin_counter, double fin_eps, float *fin_mean_inv, const FrameMap &fm, hipStream_t st) {
+    const dim3 grid(mvx_cdiv(n, BNL), mvx_cdiv(rows, BM));
+    hipLaunchKernelGGL(linear_fwd_split, grid, dim3(256), 0, st, x, ldx, w, ldw, bias, y, ldy, stats, row_w, rows, k, n, relu,
+                       fin_counter, fin_eps, fin_mean_inv, fm);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}

@@ -10,6 +10,7 @@ VoxelizeResult = collections.namedtuple('VoxelizeResult', 'voxels coords counts 
 _ws_cache = {}
 STATS_REPLICAS = 32      # MVX_STATS_REPLICAS of include/mvx_hip.h
 FLAG_RELU, FLAG_PREZEROED, FLAG_ACCUMULATE, FLAG_CONV2D = 1, 2, 4, 8      # MVX_FLAG_* of include/mvx_hip.h
+FLAG_SPLIT = 64                                                          # MVX_FLAG_SPLIT: bf16x3 arithmetic of the wide row GEMMs
 FLAG_BG_TAPS = 32
 
 # When True, the backward of the hot-path layers adds weight / bias gradients straight into the existing
@@ -178,9 +179,17 @@ def _timed_bytes(name, nbytes):
     """Timer for an HBM-bound stage: the third tuple field carries ALGORITHMIC bytes (negative marks bytes)."""
     if KERNEL_TIMERS is None:
         return _Timed('hbm:' + name, 0)
-    # a device scalar (data-dependent byte count, e.g. bytes of the flagged tiles) is kept as a tensor and read by the
-    # consumer of the timers after the run: no host read inside the step
-    return _Timed('hbm:' + name, nbytes if isinstance(nbytes, torch.Tensor) else float(nbytes))
+    # a data-dependent byte count (e.g. bytes of the flagged tiles) is passed as a zero-argument CALLABLE that the
+    # consumer of the timers evaluates after the run (timer_value): neither a host read nor an extra launch inside the step
+    return _Timed('hbm:' + name, nbytes if (callable(nbytes) or isinstance(nbytes, torch.Tensor)) else float(nbytes))
+
+
+def timer_value(v):
+    """The FLOP / byte figure of a timer entry as a float: numbers as they are, device scalars read, callables evaluated
+    (data-dependent counts are deferred until after the timed region)."""
+    if callable(v):
+        v = v()
+    return float(v)
 
 
 def require_plain_batchnorm():
@@ -681,10 +690,12 @@ def _work_counter(device):
     return torch.zeros((1,), dtype=torch.float64, device=device)
 
 
-def linear_forward(x, w, bias, relu=True, want_stats=True, w_transposed=False, row_w=None, out=None, finalize=None):
+def linear_forward(x, w, bias, relu=True, want_stats=True, w_transposed=False, row_w=None, out=None, finalize=None,
+                   label=None, split=False):
     """x (R,K) view, w (N,K) [or (K,N) if w_transposed] -> y (R,N), stats f64 (2,N) or None.
     ``finalize=(count, eps)``: the BatchNorm mean / inverse std are formed by the kernel's last workgroup
-    (mvx_linear_forward_bn); returns (y, mean_inv) then."""
+    (mvx_linear_forward_bn); returns (y, mean_inv) then.  ``split``: bf16x3 arithmetic where the shape qualifies
+    (MVX_FLAG_SPLIT); ``label``: timer name of this call (default linear_fwd / linear_dgrad by w_transposed)."""
     R, K = x.shape
     N = w.shape[1] if w_transposed else w.shape[0]
     if out is None:
@@ -697,16 +708,16 @@ def linear_forward(x, w, bias, relu=True, want_stats=True, w_transposed=False, r
         mi = torch.empty((2, N), dtype=torch.float32, device=x.device)
         X.check(X.lib.mvx_linear_forward_bn(_vptr(x), _ld(x), _vptr(w), _ld(w), int(w_transposed), X.ptr(bias),
                                             _vptr(out), _ld(out), X.ptr(stats), X.ptr(row_w), R, K, N,
-                                            (FLAG_RELU if relu else 0) | fz, X.ptr(counter), float(finalize[0]),
+                                            (FLAG_RELU if relu else 0) | fz | (FLAG_SPLIT if split else 0), X.ptr(counter), float(finalize[0]),
                                             float(finalize[1]), X.ptr(mi), X.stream()), 'mvx_linear_forward_bn')
         return out, mi
     ws = None
     if bias is None and not relu and not want_stats and K >= 256 and R * N <= (1 << 22):
         ws = workspace(X.lib.mvx_linear_splitk_workspace_bytes(R, N), x.device, 'splitk')
-    with _Timed('linear_dgrad' if w_transposed else 'linear_fwd', 2.0 * R * K * N if KERNEL_TIMERS is not None else 0):
+    with _Timed(label or ('linear_dgrad' if w_transposed else 'linear_fwd'), 2.0 * R * K * N if KERNEL_TIMERS is not None else 0):
         X.check(X.lib.mvx_linear_forward(_vptr(x), _ld(x), _vptr(w), _ld(w), int(w_transposed), X.ptr(bias),
                                          _vptr(out), _ld(out), X.ptr(stats), X.ptr(row_w), R, K, N,
-                                         (FLAG_RELU if relu else 0) | fz,
+                                         (FLAG_RELU if relu else 0) | fz | (FLAG_SPLIT if split else 0),
                                          X.ptr(ws), ws.numel() if ws is not None else 0, X.stream()), 'mvx_linear_forward')
     if finalize is not None and want_stats:      # empty input: no launch happened, finalise the (zero) sums separately
         return out, bn_finalize(stats, finalize[0], finalize[1])

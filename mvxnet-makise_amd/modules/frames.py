@@ -105,10 +105,11 @@ def linear_bn(x, w, b, fs, kind, row_w, eps):
     mi = torch.empty((fs.F, 2, N), dtype=torch.float32, device=x.device)
     if 'lin_fwd' in KNOCKOUT:
         return y, mi
+    sp = _hip.FLAG_SPLIT if conv_split_math() else 0        # convmath bf16x3: the wide layers on the split-MFMA row GEMM
     with _hip._Timed('linear_fwd', 2.0 * Rr * K * N if _hip.KERNEL_TIMERS is not None else 0):
         X.check(X.lib.mvx_linear_forward_bn_frames(_hip._vptr(x), _hip._ld(x), _hip._vptr(w2), _hip._ld(w2), 0, X.ptr(b),
                                                    _hip._vptr(y), _hip._ld(y), X.ptr(stats), X.ptr(row_w), Rr, K, N,
-                                                   _hip.FLAG_RELU | fz, X.ptr(counter), float(eps), X.ptr(mi), fs.desc.ref(),
+                                                   _hip.FLAG_RELU | fz | sp, X.ptr(counter), float(eps), X.ptr(mi), fs.desc.ref(),
                                                    kind, X.stream()), 'mvx_linear_forward_bn_frames')
     return y, mi
 
@@ -272,7 +273,7 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
     w1, b1 = c1.conv.weight, c1.conv.bias
     cout, cin = w1.shape[0], w1.shape[1]
     w_all = w1.permute(2, 3, 4, 0, 1).reshape(27 * cout, cin).contiguous()
-    P, _ = _hip.linear_forward(feat, w_all, None, relu=False, want_stats=False)
+    P, _ = _hip.linear_forward(feat, w_all, None, relu=False, want_stats=False, split=conv_split_math())
     idx_grid = torch.empty((X.lib.mvx_index_grid_bytes_frames(D0, H, W, F) // 4,), dtype=torch.int32, device=dev)
     st2 = torch.zeros((1,), dtype=torch.int32, device=dev)
     X.check(X.lib.mvx_index_grid_frames(X.ptr(fs.coords), Vt, D0, H, W, X.ptr(idx_grid), X.ptr(st2), fs.desc.ref(), X.stream()),
@@ -315,7 +316,7 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
         out = torch.empty_like(y)
         Cn = y.shape[-1]
         # algorithmic bytes (timing runs only): flagged tiles are read and written, the others only written
-        nbytes = (tflag.ne(0).sum() + tflag.numel()) * (128 * Cn * 4) if _hip.KERNEL_TIMERS is not None else 0
+        nbytes = (lambda: (tflag.ne(0).sum() + tflag.numel()) * (128 * Cn * 4)) if _hip.KERNEL_TIMERS is not None else 0
         with _hip._timed_bytes('bn_apply', nbytes):
             X.check(X.lib.mvx_bn_apply_tiles_frames(X.ptr(y), X.ptr(mi), X.ptr(c_bg), X.ptr(tflag), X.ptr(out), planes, H, W, Cn, F,
                                                     X.stream()), 'mvx_bn_apply_tiles_frames')
@@ -401,19 +402,23 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
 
 
 def _wgrad_bg_flops(rec, F):
-    """EXECUTED FLOPs of a background-aware weight-gradient launch (timing runs only; a device scalar): the kernel runs the
-    (plane, tile) steps whose source halo holds a non-background site, every step = 8 x 16 sites x Cin x Cout x 9 taps."""
+    """EXECUTED FLOPs of a background-aware weight-gradient launch as a zero-argument callable (timing runs only; evaluated
+    after the timed region): the kernel runs the (plane, tile) steps whose source halo holds a non-background site, every
+    step = 8 x 16 sites x Cin x Cout x 9 taps.  Only the flag tensor is captured, not the activations."""
     din, dout, sd, pd = rec['din'], rec['dout'], rec['sd'], rec['pd']
-    hf = rec['hflag_in'].view(F, din, -1).ne(0)
-    steps = None
-    for kd in range(3):
-        for d in range(dout):
-            ds = d * sd - pd + kd
-            if 0 <= ds < din:
-                n = hf[:, ds].sum()
-                steps = n if steps is None else steps + n
+    hflag = rec['hflag_in']
     co, ci = rec['w'].shape[0], rec['w'].shape[1]
-    return steps.double() * (2.0 * 128 * ci * co * 9)
+
+    def count():
+        hf = hflag.view(F, din, -1).ne(0)
+        steps = 0
+        for kd in range(3):
+            for d in range(dout):
+                ds = d * sd - pd + kd
+                if 0 <= ds < din:
+                    steps = steps + hf[:, ds].sum()
+        return float(steps) * (2.0 * 128 * ci * co * 9)
+    return count
 
 
 def _wgrad_bg(rec, dz, tap_sums, F, H, W):
@@ -422,7 +427,7 @@ def _wgrad_bg(rec, dz, tap_sums, F, H, W):
     x, w = rec['x'], rec['w']
     co, ci = w.shape[0], w.shape[1]
     dw = _grad_of(w)
-    fl = _wgrad_bg_flops(rec, F) if _hip.KERNEL_TIMERS is not None else 0
+    fl = _wgrad_bg_flops(rec, F) if _hip.KERNEL_TIMERS is not None else 0      # a callable, evaluated after the timed region
     nbytes = X.lib.mvx_conv3d_wgrad_bg_workspace_bytes_frames(rec['dout'], H, W, ci, co, F)
     if rec.get('split'):
         nbytes = X.lib.mvx_conv3d_wgrad_bg_split_workspace_bytes_frames(rec['dout'], H, W, ci, co, F)
@@ -536,7 +541,7 @@ def cml_backward(model, S, grad_mid, g_cl=None):
         if 'bn_bwd_tiles' in KNOCKOUT:
             return dz, inact
         # algorithmic bytes (timing runs only): the flagged 8x16 tiles, two passes reading dyhat and y, the second writing dz
-        nbytes = bflag.ne(0).sum() * (128 * Cn * 4 * 5) if _hip.KERNEL_TIMERS is not None else 0
+        nbytes = (lambda: bflag.ne(0).sum() * (128 * Cn * 4 * 5)) if _hip.KERNEL_TIMERS is not None else 0
         with _hip._timed_bytes('bn_relu_backward_tiles', nbytes):
             X.check(X.lib.mvx_bn_relu_backward_tiles_frames(X.ptr(gin), X.ptr(y), X.ptr(mi), X.ptr(c_bg), X.ptr(y_bg), X.ptr(A),
                                                             X.ptr(bflag), planes, H, W, Cn, X.ptr(dz), X.ptr(_grad_of(bias)),
@@ -571,15 +576,35 @@ def cml_backward(model, S, grad_mid, g_cl=None):
     dw_all = _hip.linear_wgrad(c1['feat'], G)                              # (27*cout, cin), main stream (small)
     with _hip._SideStream(dw_all):
         _grad_of(w1).add_(dw_all.reshape(3, 3, 3, cout, cin).permute(3, 4, 0, 1, 2))
-    dfeat, _ = _hip.linear_forward(G, c1['w_all'], None, relu=False, want_stats=False, w_transposed=True)
+    # dfeat = G w_all: the weight as a row-major [cin][27 cout] matrix, so that both operands are read along k
+    dfeat, _ = _hip.linear_forward(G, c1['w_all'].t().contiguous(), None, relu=False, want_stats=False, label='linear_dgrad',
+                                   split=conv_split_math())
     return dfeat
+
+
+_WT_CACHE = {}          # id(weight storage) -> (version, data_ptr, W^T contiguous): refreshed when the optimizer changes the weight
+
+
+def _transposed(w2):
+    """W^T as a contiguous row-major matrix, kept per parameter version: the input-gradient GEMM then reads both operands
+    with 16-byte loads along k (the transposed-read form of the kernel collects its weight tile with 4-byte loads and ran
+    at 0.43 matrix-pipe busy against 0.61 for the forward form)."""
+    base = w2._base if w2._base is not None else w2
+    key = (base.data_ptr(), tuple(w2.shape))
+    hit = _WT_CACHE.get(key)
+    tag = (base._version, w2.data_ptr())
+    if hit is None or hit[0] != tag:
+        hit = (tag, w2.detach().t().contiguous())
+        _WT_CACHE[key] = hit
+    return hit[1]
 
 
 def _rows_dgrad(dz, w2):
     """dx = dz w (rows x K): the input gradient of a row layer."""
     if 'lin_dgrad' in KNOCKOUT:
         return torch.empty((dz.shape[0], w2.shape[1]), dtype=torch.float32, device=dz.device)
-    gx, _ = _hip.linear_forward(dz, w2, None, relu=False, want_stats=False, w_transposed=True)
+    gx, _ = _hip.linear_forward(dz, _transposed(w2), None, relu=False, want_stats=False, label='linear_dgrad',
+                                split=conv_split_math())
     return gx
 
 

@@ -401,3 +401,24 @@ def test_pipeline_skips_empty_frames(executor):
         bucket.zero()
         _, _, ready = train_step_frames(model, one, grad_mid, imsize, ready=ready, prepare_next=one)
         assert rel_err(bucket.flat, again) < 1e-6
+
+
+@pytest.mark.parametrize('R,K,N', [(1000, 768, 768), (4099, 128, 768), (517, 768, 128), (300, 1728, 128)])
+def test_row_gemm_bf16x3_split_accuracy(R, K, N):
+    """MVX_FLAG_SPLIT: the wide row GEMMs of `convmath: bf16x3` (csrc/linear_split.hip: three bf16 MFMAs per product, f32
+    accumulate) against float64 -- forward with bias + ReLU + BatchNorm sums, and the input-gradient form (no epilogue);
+    fp32-grade accuracy like the split convolutions (2e-5), row counts that are no multiple of the 128-row tile."""
+    from modules import _hip
+    g = torch.Generator().manual_seed(R + K)
+    x = torch.randn((R, K), generator=g)
+    w = torch.randn((N, K), generator=g) / np.sqrt(K)
+    b = torch.randn((N,), generator=g) * 0.1
+    ref = torch.relu(x.double() @ w.double().t() + b.double())
+    y, stats = _hip.linear_forward(x.to(DEV), w.to(DEV), b.to(DEV), relu=True, want_stats=True, split=True)
+    assert rel_err(y.cpu(), ref) < 2e-5
+    st = stats.sum(0).cpu().double()
+    assert rel_err(st[0], ref.sum(0)) < 1e-4 and rel_err(st[1], (ref * ref).sum(0)) < 1e-4
+    y32, _ = _hip.linear_forward(x.to(DEV), w.to(DEV), b.to(DEV), relu=True, want_stats=True)
+    assert rel_err(y32.cpu(), ref) < 2e-6                      # the exact-f32 kernel, for scale
+    yn, _ = _hip.linear_forward(x.to(DEV), w.to(DEV), None, relu=False, want_stats=False, split=True)
+    assert rel_err(yn.cpu(), x.double() @ w.double().t()) < 2e-5
