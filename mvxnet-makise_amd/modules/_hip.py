@@ -1,6 +1,8 @@
 """Typed torch-tensor wrappers over the C ABI (plumbing only: allocation, pointers, stream)."""
 import collections
 
+import os
+
 import torch
 
 from modules import Extension as X
@@ -688,6 +690,43 @@ def _work_counter(device):
         if v is not None:
             return v
     return torch.zeros((1,), dtype=torch.float64, device=device)
+
+
+ROW_SPLIT = frozenset(k for k in os.environ.get('MVX_ROW_SPLIT', 'fusion,vfe,conv1,rpn').split(',') if k)
+
+
+def row_split(tag):
+    """Do the wide row GEMMs of group ``tag`` ('fusion', 'vfe', 'conv1', 'rpn') run in bf16x3 arithmetic?  Yes under
+    ``convmath: bf16x3`` unless the group is taken out with MVX_ROW_SPLIT (accuracy experiments, tools/split_accuracy.py)."""
+    import modules.config as cfg
+    return cfg.config.get('convmath', 'f32') == 'bf16x3' and tag in ROW_SPLIT
+
+
+def transposed_weight(w2):
+    """Row-major W^T of a (N, K) weight view, cached ON the parameter it views (so it dies with the model) and keyed by the
+    parameter's version counter and the view's address: an optimizer step, load_state_dict or .to() makes the copy stale
+    and it is made again.  (Not a module-level cache keyed by address: a new model may reuse a freed model's addresses at
+    version 0.)  The input-gradient GEMM then reads both operands with 16-byte loads along k -- the transposed-read form of
+    the f32 kernel collects its weight tile with 4-byte loads and ran at 0.43 matrix-pipe busy against 0.61 for the forward
+    form -- and the split row GEMM reads row-major weights only (csrc/linear_split.hip)."""
+    base = w2._base if w2._base is not None else w2
+    cache = base.__dict__.setdefault('_mvx_wt', {})
+    tag = (base._version, w2.data_ptr())
+    hit = cache.get(tuple(w2.shape))
+    if hit is None or hit[0] != tag:
+        hit = (tag, w2.detach().t().contiguous())
+        cache[tuple(w2.shape)] = hit
+    return hit[1]
+
+
+def rows_dgrad(dz, w2, tag, label='linear_dgrad'):
+    """dx = dz w2 of a row layer with weight (N, K): in bf16x3 arithmetic (group ``tag`` of ``row_split``) through the
+    cached transposed copy, otherwise through the f32 kernel's transposed-weight read."""
+    if row_split(tag):
+        dx, _ = linear_forward(dz, transposed_weight(w2), None, relu=False, want_stats=False, label=label, split=True)
+    else:
+        dx, _ = linear_forward(dz, w2, None, relu=False, want_stats=False, w_transposed=True, label=label)
+    return dx
 
 
 def linear_forward(x, w, bias, relu=True, want_stats=True, w_transposed=False, row_w=None, out=None, finalize=None,

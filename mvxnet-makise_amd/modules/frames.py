@@ -92,7 +92,7 @@ TAP_SKIP = os.environ.get('MVX_TAP_SKIP', '1') != '0'     # conv2 / conv3 forwar
 KNOCKOUT = frozenset(k for k in os.environ.get('MVX_KNOCKOUT', '').split(',') if k)
 
 
-def linear_bn(x, w, b, fs, kind, row_w, eps):
+def linear_bn(x, w, b, fs, kind, row_w, eps, tag='fusion'):
     """rows -> (y = ReLU(x w^T + b), mean_inv (F,2,N)) with per-frame statistics formed inside the launch."""
     Rr, K = x.shape
     N = w.shape[0]
@@ -105,7 +105,7 @@ def linear_bn(x, w, b, fs, kind, row_w, eps):
     mi = torch.empty((fs.F, 2, N), dtype=torch.float32, device=x.device)
     if 'lin_fwd' in KNOCKOUT:
         return y, mi
-    sp = _hip.FLAG_SPLIT if conv_split_math() else 0        # convmath bf16x3: the wide layers on the split-MFMA row GEMM
+    sp = _hip.FLAG_SPLIT if _hip.row_split(tag) else 0        # convmath bf16x3: the wide layers on the split-MFMA row GEMM
     with _hip._Timed('linear_fwd', 2.0 * Rr * K * N if _hip.KERNEL_TIMERS is not None else 0):
         X.check(X.lib.mvx_linear_forward_bn_frames(_hip._vptr(x), _hip._ld(x), _hip._vptr(w2), _hip._ld(w2), 0, X.ptr(b),
                                                    _hip._vptr(y), _hip._ld(y), X.ptr(stats), X.ptr(row_w), Rr, K, N,
@@ -238,7 +238,7 @@ def _vfe_forward(bb, fs, x, S, eps):
     x = rows23
     for vfe in (bb.svfe.vfe1, bb.svfe.vfe2):
         w, b = vfe.fcn.fc.weight, vfe.fcn.fc.bias
-        y, mi = linear_bn(x, w, b, fs, X.ROWS_VFE, fs.row_w, eps)
+        y, mi = linear_bn(x, w, b, fs, X.ROWS_VFE, fs.row_w, eps, 'vfe')
         Cn = w.shape[0]
         out = torch.empty((Rt + Vt, 2 * Cn), dtype=torch.float32, device=dev)
         am = torch.empty((Vt, Cn), dtype=torch.int32, device=dev)
@@ -248,7 +248,7 @@ def _vfe_forward(bb, fs, x, S, eps):
         S.vfe.append((x, w, b, y, mi, am))
         x = out
     w, b = bb.fcn.fc.weight, bb.fcn.fc.bias
-    y, mi = linear_bn(x, w, b, fs, X.ROWS_VFE, fs.row_w, eps)
+    y, mi = linear_bn(x, w, b, fs, X.ROWS_VFE, fs.row_w, eps, 'vfe')
     feat = torch.empty((Vt, w.shape[0]), dtype=torch.float32, device=dev)
     am = torch.empty((Vt, w.shape[0]), dtype=torch.int32, device=dev)
     with _hip._timed_bytes('vfe_bn_segment_max', (Rt + Vt) * w.shape[0] * 4 + Vt * w.shape[0] * 8):   # read y, write max + argmax
@@ -273,7 +273,7 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
     w1, b1 = c1.conv.weight, c1.conv.bias
     cout, cin = w1.shape[0], w1.shape[1]
     w_all = w1.permute(2, 3, 4, 0, 1).reshape(27 * cout, cin).contiguous()
-    P, _ = _hip.linear_forward(feat, w_all, None, relu=False, want_stats=False, split=conv_split_math())
+    P, _ = _hip.linear_forward(feat, w_all, None, relu=False, want_stats=False, split=_hip.row_split('conv1'))
     idx_grid = torch.empty((X.lib.mvx_index_grid_bytes_frames(D0, H, W, F) // 4,), dtype=torch.int32, device=dev)
     st2 = torch.zeros((1,), dtype=torch.int32, device=dev)
     X.check(X.lib.mvx_index_grid_frames(X.ptr(fs.coords), Vt, D0, H, W, X.ptr(idx_grid), X.ptr(st2), fs.desc.ref(), X.stream()),
@@ -578,33 +578,16 @@ def cml_backward(model, S, grad_mid, g_cl=None):
         _grad_of(w1).add_(dw_all.reshape(3, 3, 3, cout, cin).permute(3, 4, 0, 1, 2))
     # dfeat = G w_all: the weight as a row-major [cin][27 cout] matrix, so that both operands are read along k
     dfeat, _ = _hip.linear_forward(G, c1['w_all'].t().contiguous(), None, relu=False, want_stats=False, label='linear_dgrad',
-                                   split=conv_split_math())
+                                   split=_hip.row_split('conv1'))
     return dfeat
 
 
-_WT_CACHE = {}          # id(weight storage) -> (version, data_ptr, W^T contiguous): refreshed when the optimizer changes the weight
-
-
-def _transposed(w2):
-    """W^T as a contiguous row-major matrix, kept per parameter version: the input-gradient GEMM then reads both operands
-    with 16-byte loads along k (the transposed-read form of the kernel collects its weight tile with 4-byte loads and ran
-    at 0.43 matrix-pipe busy against 0.61 for the forward form)."""
-    base = w2._base if w2._base is not None else w2
-    key = (base.data_ptr(), tuple(w2.shape))
-    hit = _WT_CACHE.get(key)
-    tag = (base._version, w2.data_ptr())
-    if hit is None or hit[0] != tag:
-        hit = (tag, w2.detach().t().contiguous())
-        _WT_CACHE[key] = hit
-    return hit[1]
-
-
-def _rows_dgrad(dz, w2):
+def _rows_dgrad(dz, w2, tag='fusion'):
     """dx = dz w (rows x K): the input gradient of a row layer."""
     if 'lin_dgrad' in KNOCKOUT:
         return torch.empty((dz.shape[0], w2.shape[1]), dtype=torch.float32, device=dz.device)
-    gx, _ = _hip.linear_forward(dz, _transposed(w2), None, relu=False, want_stats=False, label='linear_dgrad',
-                                split=conv_split_math())
+    gx, _ = _hip.linear_forward(dz, _hip.transposed_weight(w2), None, relu=False, want_stats=False, label='linear_dgrad',
+                                split=_hip.row_split(tag))
     return gx
 
 
@@ -621,7 +604,7 @@ def rows_backward(model, S, dfeat):
                                            X.stream()), 'mvx_segment_max_backward')
     dz = bn_relu_backward(dyh, y, mi, fs, X.ROWS_VFE, fs.row_w, _grad_of(b), dz=dyh)
     _linear_wgrad_side(x, dz, w)
-    gx = _rows_dgrad(dz, w)
+    gx = _rows_dgrad(dz, w, 'vfe')
     # ---- VFE 2, VFE 1
     for x, w, b, y, mi, am in reversed(S.vfe):
         Cn = w.shape[0]
@@ -631,7 +614,7 @@ def rows_backward(model, S, dfeat):
                                                       Rt, X.stream()), 'mvx_vfe_max_concat_backward')
         dz = bn_relu_backward(dyh, y, mi, fs, X.ROWS_VFE, fs.row_w, _grad_of(b), dz=dyh)
         _linear_wgrad_side(x, dz, w)
-        gx = _rows_dgrad(dz, w)
+        gx = _rows_dgrad(dz, w, 'vfe')
     # ---- concat backward: gradient of the fused image features ([real rows | shared padded row per frame])
     Fc = S.fc
     gim = torch.empty((Rt + F, Fc), dtype=torch.float32, device=dev)

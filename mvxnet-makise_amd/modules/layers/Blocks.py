@@ -27,7 +27,8 @@ class FCNFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, eps, row_w, count):
         w2 = w.reshape(w.shape[0], -1)
-        y, mi = _hip.linear_forward(x, w2, b, relu=True, want_stats=True, row_w=row_w, finalize=(count, eps))
+        y, mi = _hip.linear_forward(x, w2, b, relu=True, want_stats=True, row_w=row_w, finalize=(count, eps),
+                                    split=_hip.row_split('fusion'))
         out = _hip.bn_apply(y, mi)
         ctx.save_for_backward(x, w, y, mi, row_w)
         ctx.count = count
@@ -45,7 +46,7 @@ class FCNFunction(torch.autograd.Function):
         dw = dw.reshape(w.shape) if dw is not None else None
         dx = None
         if ctx.needs_input_grad[0]:
-            dx, _ = _hip.linear_forward(dz, w2, None, relu=False, want_stats=False, w_transposed=True)
+            dx = _hip.rows_dgrad(dz, w2, 'fusion')
         return dx, dw, db, None, None, None
 
 
@@ -195,7 +196,7 @@ class VoxelGemmCRB3dFunction(torch.autograd.Function):
         cout, cin = w.shape[0], w.shape[1]
         feat = feat.contiguous()
         w_all = w.permute(2, 3, 4, 0, 1).reshape(27 * cout, cin).contiguous()
-        P, _ = _hip.linear_forward(feat, w_all, None, relu=False, want_stats=False)
+        P, _ = _hip.linear_forward(feat, w_all, None, relu=False, want_stats=False, split=_hip.row_split('conv1'))
         idx_grid, status = _hip.index_grid(coords, dhw)
         y, stats = _hip.sparse_conv_output(P, idx_grid, dhw, b, cout, sd, pd, relu=True, want_stats=True)
         count = y.numel() // cout
@@ -231,7 +232,7 @@ class VoxelGemmCRB3dFunction(torch.autograd.Function):
         dw = _hip.accumulate_grad(ctx.params[0], dw_all.reshape(3, 3, 3, cout, cin).permute(3, 4, 0, 1, 2))
         dfeat = None
         if ctx.needs_input_grad[0]:
-            dfeat, _ = _hip.linear_forward(G, w_all, None, relu=False, want_stats=False, w_transposed=True)
+            dfeat = _hip.rows_dgrad(G, w_all, 'conv1')
         return dfeat, None, dw, db, None, None, None, None, None
 
 

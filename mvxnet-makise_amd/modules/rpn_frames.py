@@ -279,7 +279,7 @@ def rpn_forward(rpn, x_cl, F, planes, H, W, Cp):
         cin, cout = wt.shape[0], wt.shape[1]
         w_all = wt.permute(2, 3, 1, 0).reshape(s * s * cout, cin).contiguous()     # row (i*s+j)*Cout + co
         xr = xk.view(F * hk * wk, cin)
-        t, _ = _hip.linear_forward(xr, w_all, b.repeat(s * s), relu=True, want_stats=False, split=_split())
+        t, _ = _hip.linear_forward(xr, w_all, b.repeat(s * s), relu=True, want_stats=False, split=_hip.row_split('rpn'))
         stats = torch.empty((F, R, 2, cout), dtype=torch.float64, device=dev)
         X.check(X.lib.mvx_row_stats_frames(X.ptr(t), X.ptr(stats), t.numel() // cout, cout, F, X.stream()), 'mvx_row_stats_frames')
         mi = torch.empty((F, 2, cout), dtype=torch.float32, device=dev)
@@ -335,7 +335,7 @@ def rpn_backward(rpn, S, d_heads):
             _grad_of(m.deconv.weight).add_(dw_all.view(s, s, cout, cin).permute(3, 2, 0, 1))
         # input gradient with the weight as a row-major [cin][s*s*cout] matrix (both operands read along k)
         gx, _ = _hip.linear_forward(dz, rec['w_all'].t().contiguous(), None, relu=False, want_stats=False, label='linear_dgrad',
-                                    split=_split())
+                                    split=_hip.row_split('rpn'))
         g_in[s] = gx.view(F, hk, wk, cin)
     # deconv1
     d1 = rpn.deconv1

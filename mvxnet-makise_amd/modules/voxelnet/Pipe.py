@@ -19,7 +19,8 @@ class VFEFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, V, T, eps, cr):
         row_w = cr.row_w if cr is not None else None
-        y, mi = _hip.linear_forward(x, w, b, relu=True, want_stats=True, row_w=row_w, finalize=(V * T, eps))
+        y, mi = _hip.linear_forward(x, w, b, relu=True, want_stats=True, row_w=row_w, finalize=(V * T, eps),
+                                    split=_hip.row_split('vfe'))
         out, am = _hip.vfe_bn_max_concat(y, mi, V, T, cr)
         ctx.save_for_backward(x, w, y, mi, am)
         ctx.vt = (V, T, cr)
@@ -37,7 +38,7 @@ class VFEFunction(torch.autograd.Function):
         dw = _hip.linear_wgrad(x, dz, accumulate_into=_hip.sink_of(ctx.params[0]))
         dx = None
         if ctx.needs_input_grad[0]:
-            dx, _ = _hip.linear_forward(dz, w, None, relu=False, want_stats=False, w_transposed=True)
+            dx = _hip.rows_dgrad(dz, w, 'vfe')
         return dx, dw, db, None, None, None, None
 
 
@@ -47,7 +48,8 @@ class FCNMaxFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, V, T, eps, cr):
         row_w = cr.row_w if cr is not None else None
-        y, mi = _hip.linear_forward(x, w, b, relu=True, want_stats=True, row_w=row_w, finalize=(V * T, eps))
+        y, mi = _hip.linear_forward(x, w, b, relu=True, want_stats=True, row_w=row_w, finalize=(V * T, eps),
+                                    split=_hip.row_split('vfe'))
         out, am = _hip.bn_segment_max(y, mi, V, T, cr)
         ctx.save_for_backward(x, w, y, mi, am)
         ctx.vt = (V, T, cr)
@@ -65,7 +67,7 @@ class FCNMaxFunction(torch.autograd.Function):
         dw = _hip.linear_wgrad(x, dz, accumulate_into=_hip.sink_of(ctx.params[0]))
         dx = None
         if ctx.needs_input_grad[0]:
-            dx, _ = _hip.linear_forward(dz, w, None, relu=False, want_stats=False, w_transposed=True)
+            dx = _hip.rows_dgrad(dz, w, 'vfe')
         return dx, dw, db, None, None, None, None
 
 
