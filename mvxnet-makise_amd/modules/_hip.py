@@ -692,14 +692,20 @@ def _work_counter(device):
     return torch.zeros((1,), dtype=torch.float64, device=device)
 
 
-ROW_SPLIT = frozenset(k for k in os.environ.get('MVX_ROW_SPLIT', 'fusion,vfe,conv1,rpn').split(',') if k)
+ROW_SPLIT = tuple(k for k in os.environ.get('MVX_ROW_SPLIT', 'fusion_768x768,dgrad').split(',') if k)
 
 
 def row_split(tag):
-    """Do the wide row GEMMs of group ``tag`` ('fusion', 'vfe', 'conv1', 'rpn') run in bf16x3 arithmetic?  Yes under
-    ``convmath: bf16x3`` unless the group is taken out with MVX_ROW_SPLIT (accuracy experiments, tools/split_accuracy.py)."""
+    """Does the wide row GEMM ``tag`` run in bf16x3 arithmetic?  Under ``convmath: bf16x3``, when an entry of ROW_SPLIT is a
+    prefix of the tag.  Tags: 'fusion_<N>x<K>' (forward of a fusion MLP layer), 'vfe', 'conv1', 'rpn' (forward of the wide VFE
+    layer, of conv1's per-voxel GEMM, of the RPN's deconvolution GEMMs), 'dgrad' (every input-gradient row GEMM).
+    Default: the 768 -> 768 fusion layer (81 % of the row-GEMM flops of a step) and the input gradients.  Every forward
+    layer in split arithmetic adds ~5e-6 relative error to its output (f32: ~8e-7) that the following BatchNorm chain carries
+    on; measured on one full-size frame against the float64 oracle (tools/split_accuracy.py, profiles/r03_split_accuracy.json)
+    all fusion layers in split arithmetic take the BEV map from 7.6e-6 to 4.4e-5 and the RPN maps from 1.4e-4 to 6.1e-4, so
+    only the layer that pays is switched."""
     import modules.config as cfg
-    return cfg.config.get('convmath', 'f32') == 'bf16x3' and tag in ROW_SPLIT
+    return cfg.config.get('convmath', 'f32') == 'bf16x3' and any(tag.startswith(k) for k in ROW_SPLIT)
 
 
 def transposed_weight(w2):
@@ -719,10 +725,10 @@ def transposed_weight(w2):
     return hit[1]
 
 
-def rows_dgrad(dz, w2, tag, label='linear_dgrad'):
-    """dx = dz w2 of a row layer with weight (N, K): in bf16x3 arithmetic (group ``tag`` of ``row_split``) through the
-    cached transposed copy, otherwise through the f32 kernel's transposed-weight read."""
-    if row_split(tag):
+def rows_dgrad(dz, w2, label='linear_dgrad'):
+    """dx = dz w2 of a row layer with weight (N, K): in bf16x3 arithmetic (``row_split('dgrad')``) through the cached
+    transposed copy, otherwise through the f32 kernel's transposed-weight read."""
+    if row_split('dgrad'):
         dx, _ = linear_forward(dz, transposed_weight(w2), None, relu=False, want_stats=False, label=label, split=True)
     else:
         dx, _ = linear_forward(dz, w2, None, relu=False, want_stats=False, w_transposed=True, label=label)

@@ -218,7 +218,7 @@ def rows_forward(model, fs, fpn_levels, imsize, status_sink, imfeat=None):
     # ---- fusion MLP (imhead/Pipe.py:84-104) on [real rows | one shared padded row per frame]
     x = compact
     for w, b in head.fusion._layers():
-        y, mi = linear_bn(x, w, b, fs, X.ROWS_FUSION, fs.fusion_row_w, eps)
+        y, mi = linear_bn(x, w, b, fs, X.ROWS_FUSION, fs.fusion_row_w, eps, 'fusion_%dx%d' % (w.shape[0], w[0].numel()))
         S.fusion.append((x, w, b, y, mi))
         x = bn_apply(y, mi, fs, X.ROWS_FUSION)
     return _vfe_forward(bb, fs, x, S, eps)
@@ -578,16 +578,16 @@ def cml_backward(model, S, grad_mid, g_cl=None):
         _grad_of(w1).add_(dw_all.reshape(3, 3, 3, cout, cin).permute(3, 4, 0, 1, 2))
     # dfeat = G w_all: the weight as a row-major [cin][27 cout] matrix, so that both operands are read along k
     dfeat, _ = _hip.linear_forward(G, c1['w_all'].t().contiguous(), None, relu=False, want_stats=False, label='linear_dgrad',
-                                   split=_hip.row_split('conv1'))
+                                   split=_hip.row_split('dgrad'))
     return dfeat
 
 
-def _rows_dgrad(dz, w2, tag='fusion'):
+def _rows_dgrad(dz, w2):
     """dx = dz w (rows x K): the input gradient of a row layer."""
     if 'lin_dgrad' in KNOCKOUT:
         return torch.empty((dz.shape[0], w2.shape[1]), dtype=torch.float32, device=dz.device)
     gx, _ = _hip.linear_forward(dz, _hip.transposed_weight(w2), None, relu=False, want_stats=False, label='linear_dgrad',
-                                split=_hip.row_split(tag))
+                                split=_hip.row_split('dgrad'))
     return gx
 
 
@@ -604,7 +604,7 @@ def rows_backward(model, S, dfeat):
                                            X.stream()), 'mvx_segment_max_backward')
     dz = bn_relu_backward(dyh, y, mi, fs, X.ROWS_VFE, fs.row_w, _grad_of(b), dz=dyh)
     _linear_wgrad_side(x, dz, w)
-    gx = _rows_dgrad(dz, w, 'vfe')
+    gx = _rows_dgrad(dz, w)
     # ---- VFE 2, VFE 1
     for x, w, b, y, mi, am in reversed(S.vfe):
         Cn = w.shape[0]
@@ -614,7 +614,7 @@ def rows_backward(model, S, dfeat):
                                                       Rt, X.stream()), 'mvx_vfe_max_concat_backward')
         dz = bn_relu_backward(dyh, y, mi, fs, X.ROWS_VFE, fs.row_w, _grad_of(b), dz=dyh)
         _linear_wgrad_side(x, dz, w)
-        gx = _rows_dgrad(dz, w, 'vfe')
+        gx = _rows_dgrad(dz, w)
     # ---- concat backward: gradient of the fused image features ([real rows | shared padded row per frame])
     Fc = S.fc
     gim = torch.empty((Rt + F, Fc), dtype=torch.float32, device=dev)

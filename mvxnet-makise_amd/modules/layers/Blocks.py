@@ -28,7 +28,7 @@ class FCNFunction(torch.autograd.Function):
     def forward(ctx, x, w, b, eps, row_w, count):
         w2 = w.reshape(w.shape[0], -1)
         y, mi = _hip.linear_forward(x, w2, b, relu=True, want_stats=True, row_w=row_w, finalize=(count, eps),
-                                    split=_hip.row_split('fusion'))
+                                    split=_hip.row_split('fusion_%dx%d' % tuple(w2.shape)))
         out = _hip.bn_apply(y, mi)
         ctx.save_for_backward(x, w, y, mi, row_w)
         ctx.count = count
@@ -46,7 +46,7 @@ class FCNFunction(torch.autograd.Function):
         dw = dw.reshape(w.shape) if dw is not None else None
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _hip.rows_dgrad(dz, w2, 'fusion')
+            dx = _hip.rows_dgrad(dz, w2)
         return dx, dw, db, None, None, None
 
 
@@ -232,7 +232,7 @@ class VoxelGemmCRB3dFunction(torch.autograd.Function):
         dw = _hip.accumulate_grad(ctx.params[0], dw_all.reshape(3, 3, 3, cout, cin).permute(3, 4, 0, 1, 2))
         dfeat = None
         if ctx.needs_input_grad[0]:
-            dfeat = _hip.rows_dgrad(G, w_all, 'conv1')
+            dfeat = _hip.rows_dgrad(G, w_all)
         return dfeat, None, dw, db, None, None, None, None, None
 
 

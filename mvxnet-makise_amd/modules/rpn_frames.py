@@ -335,7 +335,7 @@ def rpn_backward(rpn, S, d_heads):
             _grad_of(m.deconv.weight).add_(dw_all.view(s, s, cout, cin).permute(3, 2, 0, 1))
         # input gradient with the weight as a row-major [cin][s*s*cout] matrix (both operands read along k)
         gx, _ = _hip.linear_forward(dz, rec['w_all'].t().contiguous(), None, relu=False, want_stats=False, label='linear_dgrad',
-                                    split=_hip.row_split('rpn'))
+                                    split=_hip.row_split('dgrad'))
         g_in[s] = gx.view(F, hk, wk, cin)
     # deconv1
     d1 = rpn.deconv1

@@ -38,7 +38,7 @@ class VFEFunction(torch.autograd.Function):
         dw = _hip.linear_wgrad(x, dz, accumulate_into=_hip.sink_of(ctx.params[0]))
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _hip.rows_dgrad(dz, w, 'vfe')
+            dx = _hip.rows_dgrad(dz, w)
         return dx, dw, db, None, None, None, None
 
 
@@ -67,7 +67,7 @@ class FCNMaxFunction(torch.autograd.Function):
         dw = _hip.linear_wgrad(x, dz, accumulate_into=_hip.sink_of(ctx.params[0]))
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _hip.rows_dgrad(dz, w, 'vfe')
+            dx = _hip.rows_dgrad(dz, w)
         return dx, dw, db, None, None, None, None
 
 

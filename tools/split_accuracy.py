@@ -53,10 +53,11 @@ def rel(a, b):
 
 
 res = {}
-for math, groups in (('f32', ''), ('bf16x3', ''), ('bf16x3', 'fusion'), ('bf16x3', 'vfe'), ('bf16x3', 'conv1'), ('bf16x3', 'rpn'),
-                     ('bf16x3', 'fusion,vfe,conv1'), ('bf16x3', 'fusion,vfe,conv1,rpn')):
+for math, groups in (('f32', ''), ('bf16x3', ''), ('bf16x3', 'fusion_768x768'), ('bf16x3', 'fusion_768x768,fusion_128x768'),
+                     ('bf16x3', 'fusion_768x768,conv1,rpn'), ('bf16x3', 'fusion'), ('bf16x3', 'vfe'), ('bf16x3', 'conv1'), ('bf16x3', 'rpn'),
+                     ('bf16x3', 'fusion,vfe,conv1,rpn')):
     cfg.config['convmath'] = math
-    _hip.ROW_SPLIT = frozenset(k for k in groups.split(',') if k)
+    _hip.ROW_SPLIT = tuple(k for k in groups.split(',') if k) + ('dgrad',)
     bucket.zero()
     keep = {}
     out = pl.train_step_full(model, batch, targets, VoxelLoss(), anchors.to(dev), cfg.imsize, keep=keep)
