@@ -692,18 +692,32 @@ def _work_counter(device):
     return torch.zeros((1,), dtype=torch.float64, device=device)
 
 
-ROW_SPLIT = tuple(k for k in os.environ.get('MVX_ROW_SPLIT', 'fusion_768x768,dgrad').split(',') if k)
+ROW_SPLIT = tuple(k for k in os.environ.get('MVX_ROW_SPLIT', 'dgrad,rpn').split(',') if k)
 
 
 def row_split(tag):
-    """Does the wide row GEMM ``tag`` run in bf16x3 arithmetic?  Under ``convmath: bf16x3``, when an entry of ROW_SPLIT is a
-    prefix of the tag.  Tags: 'fusion_<N>x<K>' (forward of a fusion MLP layer), 'vfe', 'conv1', 'rpn' (forward of the wide VFE
-    layer, of conv1's per-voxel GEMM, of the RPN's deconvolution GEMMs), 'dgrad' (every input-gradient row GEMM).
-    Default: the 768 -> 768 fusion layer (81 % of the row-GEMM flops of a step) and the input gradients.  Every forward
-    layer in split arithmetic adds ~5e-6 relative error to its output (f32: ~8e-7) that the following BatchNorm chain carries
-    on; measured on one full-size frame against the float64 oracle (tools/split_accuracy.py, profiles/r03_split_accuracy.json)
-    all fusion layers in split arithmetic take the BEV map from 7.6e-6 to 4.4e-5 and the RPN maps from 1.4e-4 to 6.1e-4, so
-    only the layer that pays is switched."""
+    """Does the wide row GEMM ``tag`` run in bf16x3 arithmetic (csrc/linear_split.hip)?  Under ``convmath: bf16x3``, when an
+    entry of ROW_SPLIT is a prefix of the tag.  Tags: 'fusion_<N>x<K>' (forward of a fusion MLP layer), 'vfe', 'conv1',
+    'rpn' (forward of the wide VFE layer, of conv1's per-voxel GEMM, of the RPN's deconvolution GEMMs), 'dgrad' (every
+    input-gradient row GEMM).
+
+    Default: the input gradients and the RPN's GEMMs only.  A forward layer in split arithmetic carries ~5e-6 relative
+    error (exact-f32 MFMA: ~8e-7) and the BatchNorm chain behind the FIRST layers of the network amplifies it 5-7x on the
+    way to the BEV map.  Measured on one full-size frame against the float64 oracle and on bench.py --convmath bf16x3
+    (tools/split_accuracy.py, tools/split_speed.sh -> profiles/r03_split_accuracy.json, r03_split_speed.txt):
+
+        forward rows in bf16x3          BEV map   cls logits  hot frames/s  full frames/s
+        none (convolutions only)        7.6e-6    1.36e-4     443           200
+        rpn                             7.6e-6    1.37e-4       (within noise of the row above)
+        conv1                           1.3e-5    1.49e-4
+        vfe                             1.1e-5    1.82e-4
+        fusion_768x768                  3.1e-5    4.5e-4      466           202
+        fusion (all five layers)        4.4e-5    6.1e-4
+        fusion,vfe,conv1,rpn            4.8e-5    6.3e-4      472           208
+
+    i.e. the 768 -> 768 layer, the only one whose speed matters (81 % of the row-GEMM flops of a step, +5 % frames/s), is
+    also the one that costs a factor 3-4 in accuracy of every later map: it stays on the exact-f32 kernel unless
+    MVX_ROW_SPLIT asks otherwise."""
     import modules.config as cfg
     return cfg.config.get('convmath', 'f32') == 'bf16x3' and any(tag.startswith(k) for k in ROW_SPLIT)
 
