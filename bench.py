@@ -451,12 +451,35 @@ def _run(args, rank, world, dev):
         the first CML layer on the voxel rows, the RPN as one node on this library's kernels (modules/voxelnet/Pipe.py)."""
         from modules import Calc
         targets_setup()
-        # the CPU part of train.py's iteration (cputask, train.py:26-49) for the frames of the step: voxelization (with the
-        # compact-row maps) and target assignment, each with one host read for all frames; then the model one frame at a time
-        frames, st = pl.voxelize_batch(batch, with_maps=True)
+
+        def prepare():
+            """The CPU part of train.py's iteration (cputask, train.py:26-49) for the frames of a step: voxelization (with
+            the compact-row maps) and target assignment, each with one host read for all frames."""
+            fr_, st_ = pl.voxelize_batch(batch, with_maps=True)
+            gt = drop['gt']
+            tg_ = Calc.classifyAnchorsFrames([(drop['gt_bev'], gt[:, [0, 1]])] * len(fr_), drop['bevs'], cfg.velorange, 0.45, 0.6)
+            return fr_, st_, tg_
+
+        # ... done one step ahead on the preparation stream (the reference prepares its batches in worker processes while the
+        # model runs, train.py:185-187): the three host reads then wait for a few small kernels instead of draining the
+        # training stream at every step boundary; then the model one frame at a time
+        main = torch.cuda.current_stream(dev)
+        if drop.get('ready') is None:
+            frames, st, tg = prepare()
+        else:
+            frames, st, tg, ev = drop['ready']
+            main.wait_event(ev)
+            st.record_stream(main)
+            for v, idx in frames:
+                v.record_stream(main)
+                idx.record_stream(main)
+                if getattr(v, '_mvx_fs', None) is not None:
+                    v._mvx_fs.hand_over(main)
+            for t3 in tg:
+                for x in tuple(t3[0]) + tuple(t3[1]) + (t3[2],):
+                    if isinstance(x, torch.Tensor) and x.is_cuda:
+                        x.record_stream(main)
         statuses = [st]
-        gt = drop['gt']
-        tg = Calc.classifyAnchorsFrames([(drop['gt_bev'], gt[:, [0, 1]])] * len(frames), drop['bevs'], cfg.velorange, 0.45, 0.6)
         # the parameters' .grad are views of the flat bucket (GradBucket) and stay so (zero_grad(set_to_none=False)): let the
         # node add its gradients straight into them instead of handing 80 tensors back to the autograd engine
         old_sink, _hip.GRAD_SINK = _hip.GRAD_SINK, True
@@ -473,6 +496,11 @@ def _run(args, rank, world, dev):
                 opt.step()
         finally:
             _hip.GRAD_SINK = old_sink
+        with torch.cuda.stream(pl._prep_stream(dev)):
+            nxt = prepare()
+            ev = torch.cuda.Event()
+            ev.record()
+        drop['ready'] = nxt + (ev,)
         from modules import whole
         pending_status.extend(statuses + whole.take_status(model))
         return [v.shape[1] for v, _ in frames]
@@ -525,10 +553,23 @@ def _run(args, rank, world, dev):
         if _hip.EXEC_STAGES is not None:
             _hip.EXEC_STAGES.zero_()
         l0 = _hip.X.lib.mvx_launch_count()
+        prof = None
+        if os.environ.get('MVX_BENCH_CPROFILE'):          # developer aid: where the host side of the timed steps goes
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
         t0 = time.perf_counter()
         for _ in range(steps):
             nv = fn()
         host_dt = time.perf_counter() - t0
+        if prof is not None:
+            import io
+            import pstats
+            prof.disable()
+            buf = io.StringIO()
+            pstats.Stats(prof, stream=buf).sort_stats('tottime').print_stats(60)
+            with open(os.environ['MVX_BENCH_CPROFILE'], 'w') as fh:
+                fh.write('INVALID as a timing: cProfile was on.  %d steps\n' % steps + buf.getvalue())
         fence()
         dt_ = time.perf_counter() - t0
         launches.append((_hip.X.lib.mvx_launch_count() - l0) / steps)

@@ -159,6 +159,21 @@ def recycle_timing_events(timers):
             _EVENT_POOL.append(e_)
 
 
+_STREAM_OBJS = {}
+
+
+def _current_stream_obj():
+    """torch.cuda.current_stream() without its ~10 us of Python per call (Event.record() without a stream argument pays it
+    too): the Stream object of the current raw stream, looked up once per (device, raw stream)."""
+    idx = torch.cuda.current_device()
+    key = (idx, X.raw_stream(idx))
+    st = _STREAM_OBJS.get(key)
+    if st is None:
+        st = torch.cuda.current_stream()
+        _STREAM_OBJS[key] = st
+    return st
+
+
 class _Timed:
     def __init__(self, name, flops):
         self.name, self.flops = name, flops
@@ -167,12 +182,12 @@ class _Timed:
         if KERNEL_TIMERS is not None:
             self.s = _timing_event()
             self.e = _timing_event()
-            self.s.record()
+            self.s.record(_current_stream_obj())
         return self
 
     def __exit__(self, *exc):
         if KERNEL_TIMERS is not None:
-            self.e.record()
+            self.e.record(_current_stream_obj())
             KERNEL_TIMERS.setdefault(self.name, []).append((self.s, self.e, self.flops))
         return False
 

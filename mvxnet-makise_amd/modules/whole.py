@@ -101,12 +101,35 @@ def take_status(model):
 MAX_PENDING_STATUS = 512          # forwards whose status words may stay unread (then one read is made)
 
 
+def _imsize_hw(imsize):
+    """[height, width] as Python floats.  A device tensor is read ONCE per (tensor, version): the reference hands the same
+    ``imsize`` tensor to every forward (train.py:131), and a read per call would drain the stream per frame."""
+    if not torch.is_tensor(imsize):
+        return [float(imsize[0]), float(imsize[1])]
+    hit = imsize.__dict__.get('_mvx_hw')
+    if hit is None or hit[0] != imsize._version:
+        hit = (imsize._version, [float(v) for v in imsize.tolist()])
+        imsize.__dict__['_mvx_hw'] = hit
+    return hit[1]
+
+
+def _all_params(model):
+    """model.parameters() as a list kept on the model (walking the module tree costs ~0.3 ms per call); made again when a
+    direct child module of the model, its head or its backbone was added or removed."""
+    sig = (len(model._modules), len(model.head._modules), len(model.backbone._modules))
+    hit = model.__dict__.get('_mvx_params')
+    if hit is None or hit[0] != sig:
+        hit = (sig, list(model.parameters()))
+        model.__dict__['_mvx_params'] = hit
+    return hit[1]
+
+
 def forward(model, voxels, imgs, idx, imsize):
     """MVXNet.forward on the single node: (score (1,2,H/2,W/2), reg (1,14,H/2,W/2)).  The data-dependent status words of the
     sampling / scatter kernels stand for the reference's assert (imhead/Pipe.py:71); they are collected on the model and
     read without stalling the training stream (take_status), at once for a no-grad call."""
-    hw = imsize.tolist() if torch.is_tensor(imsize) else [float(imsize[0]), float(imsize[1])]
-    params = [p for p in model.parameters() if p.requires_grad]
+    hw = _imsize_hw(imsize)
+    params = [p for p in _all_params(model) if p.requires_grad]
     heads = WholeModelFunction.apply(voxels, idx, model, imgs, hw, *params)
     # no backward will follow (inference): the reference's assert, now; training: at most every MAX_PENDING_STATUS words
     if not heads.requires_grad or len(model.__dict__.get('_mvx_status', ())) > MAX_PENDING_STATUS:
