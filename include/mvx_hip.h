@@ -86,8 +86,11 @@ typedef struct {
 int mvx_abi_version(void);
 /* tuning values of the library (process-wide, not stream-ordered; meant for benchmarks and tests).  Keys:
  *   MVX_TUNE_SPLIT16_MIN_UNITS  the bf16x3 gather uses 16 x 16-site workgroup units when a launch has at least this many of them
- *                               (default 768), else 8 x 16-site units; 0 = always 16 x 16, a huge value = never */
+ *                               (default 768), else 8 x 16-site units; 0 = always 16 x 16, a huge value = never
+ *   MVX_TUNE_GATHER_NARROW_MAX_UNITS  the f32 gather (conv3d / conv2d forward and dgrad) runs a launch with fewer 64-channel
+ *                               workgroup units than this (default 1024) as twice as many 32-channel units; 0 = never */
 #define MVX_TUNE_SPLIT16_MIN_UNITS 1
+#define MVX_TUNE_GATHER_NARROW_MAX_UNITS 2
 int mvx_tuning_set(int32_t key, int64_t value);
 /* Diagnostics: number of kernel launches the library has issued since it was loaded (fills excluded). */
 uint64_t mvx_launch_count(void);

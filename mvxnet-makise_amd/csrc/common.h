@@ -12,6 +12,7 @@
         if (!(cond)) return MVX_EINVAL; \
     } while (0)
 
+void mvxi_gather_narrow_max_units(long long v);      // csrc/conv3d.hip: tuning value MVX_TUNE_GATHER_NARROW_MAX_UNITS
 void mvxi_count_launch();       // diagnostics only: kernel launches issued by the library (mvx_launch_count)
 #define MVX_LAUNCH_CHECK()                              \
     do {                                                \

@@ -124,7 +124,9 @@ inline dim3 gather_grid(const Geom &g) { return dim3(mvx_cdiv(g.W, TW) * mvx_cdi
 // TLO / THI: in-plane taps [TLO, THI) (rows and columns) carry weight -- compile-time, so that the two-row pipeline
 // of the 2 x 2 window keeps its prefetch registers in VGPRs (a run-time choice between two pipelines demoted them
 // to scratch).
-template <int TLO, int THI>
+// NB2: 32-channel accumulator tiles per wave -- 2: the unit covers 64 output channels (BN); 1: 32 (the "narrow" unit, twice
+// the units of half the work each: launches too small to fill the GPU with 64-channel units, see launch_gather).
+template <int TLO, int THI, int NB2 = 2>
 __device__ __forceinline__ void gather_unit(const int tile, const int d, const int nb, const int ntiles,
                                             float *__restrict__ s_halo, float *__restrict__ s_w, double (*s_red)[2 * BN],
                                             const float *__restrict__ in, const float *__restrict__ wpk,
@@ -139,6 +141,7 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int nchunks = g.Cin / BK;
+    constexpr int BNW = 32 * NB2;                    // output channels of this unit
     // restricted launch: only the flagged output tiles are produced, the others are left untouched
     if (only_tiles && !only_tiles[(size_t)d * ntiles + tile]) return;
 
@@ -188,7 +191,9 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
     // window never leaves the image -> every output site of the tile is the per-plane constant.
     bool active = true;
     if (in_hflag) active = (((border_active & 1) && on_border) || any_flag) != 0;
-    if (exec_stages && active && threadIdx.x == 0) atomicAdd(exec_stages, (unsigned long long)nstages);   // executed work only
+    // executed work only, in 64-channel stages: the two narrow units of a channel pair run the same stages (activity
+    // does not depend on nb), so the even one reports for both
+    if (exec_stages && active && threadIdx.x == 0 && (NB2 == 2 || !(nb & 1))) atomicAdd(exec_stages, (unsigned long long)nstages);
     if (active && nstages > 0) {
     auto stage_kd = [&](int st, int &kd, int &ds, int &cc) __attribute__((always_inline)) {
         const int i = st / nchunks;
@@ -230,16 +235,27 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
     auto load_wrow = [&](int st, int row) __attribute__((always_inline)) {
         int kd, ds, cc;
         stage_kd(st, kd, ds, cc);
-        const float *row0 = wpk + ((((size_t)kd * 9 + row * 3) * nchunks + cc) * g.Cout + (size_t)nb * BN) * BK + (size_t)tid * 4;
+        const float *row0 = wpk + ((((size_t)kd * 9 + row * 3) * nchunks + cc) * g.Cout + (size_t)nb * BNW) * BK + (size_t)tid * 4;
         const size_t tap_stride = (size_t)nchunks * g.Cout * BK;
+        if (NB2 == 2) {
 #pragma unroll
-        for (int v = 0; v < 6; ++v) wreg[v] = *(const f32x4 *)(row0 + (v >> 1) * tap_stride + (v & 1) * 1024);
+            for (int v = 0; v < 6; ++v) wreg[v] = *(const f32x4 *)(row0 + (v >> 1) * tap_stride + (v & 1) * 1024);
+        } else {                                     // 32 x 32 floats per tap: one 16-byte piece per thread
+#pragma unroll
+            for (int v = 0; v < 3; ++v) wreg[v] = *(const f32x4 *)(row0 + v * tap_stride);
+        }
     };
     auto store_wrow = [&]() __attribute__((always_inline)) {
+        if (NB2 == 2) {
 #pragma unroll
-        for (int v = 0; v < 6; ++v) {
-            const int c = tid + 256 * (v & 1);
-            *(f32x4 *)(s_w + (v >> 1) * WROW + (c >> 3) * BK + (((c & 7) ^ ((c >> 4) & 7)) * 4)) = wreg[v];
+            for (int v = 0; v < 6; ++v) {
+                const int c = tid + 256 * (v & 1);
+                *(f32x4 *)(s_w + (v >> 1) * WROW + (c >> 3) * BK + (((c & 7) ^ ((c >> 4) & 7)) * 4)) = wreg[v];
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < 3; ++v)
+                *(f32x4 *)(s_w + v * WROW + (tid >> 3) * BK + (((tid & 7) ^ ((tid >> 4) & 7)) * 4)) = wreg[v];
         }
     };
     auto compute_row = [&](int row, unsigned colmask = 7u) __attribute__((always_inline)) {
@@ -252,15 +268,22 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
             for (int q = 0; q < BK / 8; ++q) {
                 const float4 av = *(const float4 *)(s_halo + a_off + 8 * q);
                 const float4 b0 = *(const float4 *)(s_w + t * WROW + b_off[q]);
-                const float4 b1 = *(const float4 *)(s_w + t * WROW + 32 * BK + b_off[q]);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b1.z, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b1.w, acc1, 0, 0, 0);
+                if (NB2 == 2) {
+                    const float4 b1 = *(const float4 *)(s_w + t * WROW + 32 * BK + b_off[q]);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b1.z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b1.w, acc1, 0, 0, 0);
+                } else {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc0, 0, 0, 0);
+                }
             }
         }
     };
@@ -306,7 +329,7 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
             stage_kd(st, kd, ds, cc);
             p = (cc * BK) / g.s2d;
         } else {
-            p = (nb * BN) / g.s2d;
+            p = (nb * BNW) / g.s2d;
         }
         const unsigned m = s2d_tap_mask(p);            // bit (ta * 2 + tb)
         auto wt = [&](int a) { return g.mode == 0 ? a : 2 - a; };        // window tap of kernel row / column index a
@@ -350,7 +373,7 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
     }   // active
 
     // ---- epilogue: bias, ReLU, store, BatchNorm statistics (identical to conv3d_gather)
-    const int n0 = nb * BN + li, n1 = n0 + 32;
+    const int n0 = nb * BNW + li, n1 = NB2 == 2 ? n0 + 32 : n0;      // narrow unit: the second channel tile does not exist
     const float bias0 = bias ? bias[n0] : 0.f, bias1 = bias ? bias[n1] : 0.f;
     if (idle_border) {                         // the accumulators are still zero: they take the position-class constants
         const float *bg_cls = bg_pre + (size_t)4 * g.Dout * g.F * g.Cout + (size_t)d * 9 * g.Cout;
@@ -402,7 +425,7 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
         if (gy < g.H && gx < g.W) {
             float *o = out + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout;
             o[n0] = v0;
-            o[n1] = v1;
+            if (NB2 == 2) o[n1] = v1;
             s1a += (double)v0; s2a += (double)v0 * (double)v0;
             s1b += (double)v1; s2b += (double)v1 * (double)v1;
         }
@@ -416,12 +439,12 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
             s_red[wv][BN + li] = s2a; s_red[wv][BN + 32 + li] = s2b;
         }
         __syncthreads();
-        if (tid < 2 * BN) {
-            const double t = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
-            const int which = tid / BN, c = tid % BN;
+        if (tid < 2 * BNW) {
+            const int which = tid / BNW, c = tid % BNW, j = which * BN + c;
+            const double t = s_red[0][j] + s_red[1][j] + s_red[2][j] + s_red[3][j];
             const unsigned rep = (unsigned)(tile + d * ntiles) % MVX_REP;
             double *fstats = stats + (size_t)(d / g.Dout) * MVX_REP * 2 * g.Cout;       // the plane's frame
-            atomicAdd(fstats + ((size_t)rep * 2 + which) * g.Cout + nb * BN + c, t);
+            atomicAdd(fstats + ((size_t)rep * 2 + which) * g.Cout + nb * BNW + c, t);
         }
     }
 }
@@ -429,7 +452,7 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
 
 
 // Classic launch: one unit per workgroup, grid = (tiles, planes, channel blocks).
-template <int TLO, int THI>
+template <int TLO, int THI, int NB2 = 2>
 __global__ __launch_bounds__(256, 3) void conv3d_gather_pf(const float *__restrict__ in,
                                                            const float *__restrict__ wpk,
                                                            const float *__restrict__ bias,
@@ -444,8 +467,8 @@ __global__ __launch_bounds__(256, 3) void conv3d_gather_pf(const float *__restri
     __shared__ __attribute__((aligned(16))) float s_halo[HH * HROW];
     __shared__ __attribute__((aligned(16))) float s_w[3 * WROW];
     double (*s_red)[2 * BN] = reinterpret_cast<double (*)[2 * BN]>(s_w);      // epilogue scratch: the weights are done by then
-    gather_unit<TLO, THI>(blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, s_halo, s_w, s_red, in, wpk, bias, out, stats, g, relu,
-                          in_hflag, out_mask, bg_pre, border_active, exec_stages, only_tiles);
+    gather_unit<TLO, THI, NB2>(blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, s_halo, s_w, s_red, in, wpk, bias, out, stats, g,
+                               relu, in_hflag, out_mask, bg_pre, border_active, exec_stages, only_tiles);
     if (stats && done_counter) {
         __shared__ int s_last;
         bn_finalize_by_last_block(done_counter, gridDim.x * gridDim.y * gridDim.z, stats, g.Cout, fin_count, fin_eps,
@@ -457,7 +480,7 @@ __global__ __launch_bounds__(256, 3) void conv3d_gather_pf(const float *__restri
 // workgroup reaches the exit (`u >= units`), so the grid always drains.  Units are handed out in the classic order
 // (tile fastest), dynamically: no tail round with idle CUs (3,300 units over 512 slots = 6.45 rounds) and background
 // tiles, which only write a constant, do not unbalance the workgroups.
-template <int TLO, int THI>
+template <int TLO, int THI, int NB2 = 2>
 __global__ __launch_bounds__(256, 3) void conv3d_gather_pw(const float *__restrict__ in,
                                                            const float *__restrict__ wpk,
                                                            const float *__restrict__ bias,
@@ -483,8 +506,8 @@ __global__ __launch_bounds__(256, 3) void conv3d_gather_pw(const float *__restri
         const unsigned u = s_unit;
         if (u >= units) break;                      // block-uniform
         const int tile = u % ntiles, d = (u / ntiles) % nplanes, nb = u / (ntiles * nplanes);
-        gather_unit<TLO, THI>(tile, d, nb, ntiles, s_halo, s_w, s_red, in, wpk, bias, out, stats, g, relu, in_hflag, out_mask,
-                              bg_pre, border_active, exec_stages, only_tiles);
+        gather_unit<TLO, THI, NB2>(tile, d, nb, ntiles, s_halo, s_w, s_red, in, wpk, bias, out, stats, g, relu, in_hflag, out_mask,
+                                   bg_pre, border_active, exec_stages, only_tiles);
     }
     if (stats && done_counter) {
         __shared__ int s_last;
@@ -1011,27 +1034,42 @@ static int persistent_grid() {
     return cached;
 }
 
+// Narrow units: a launch with fewer 64-channel units than this runs as twice as many 32-channel units (gather_unit<.., 1>),
+// each half the matrix work -- the small RPN maps (88 x 100 and 44 x 50: 616 and 384 units for four frames on 512-768
+// workgroup slots, a quarter of that for one frame) leave CUs idle or with one wave per SIMD otherwise.  Results are bit
+// identical (the K order of an output element does not change).  Tuning value MVX_TUNE_GATHER_NARROW_MAX_UNITS.
+static long long g_gather_narrow_max_units = 1024;
+void mvxi_gather_narrow_max_units(long long v) { g_gather_narrow_max_units = v; }
+
 static void launch_gather(hipStream_t st, const float *in, const float *wpk, const float *bias, float *out, double *stats,
                           const Geom &g, int relu, const int *in_hflag, const unsigned char *out_mask, const float *bg_pre,
                           int border_active, unsigned long long *exec_stages, const int *only_tiles, unsigned *done_counter,
                           double fin_count, double fin_eps, float *fin_mean_inv, unsigned *work_counter) {
-    const dim3 grid = gather_grid(g);
+    dim3 grid = gather_grid(g);
+    const bool narrow = (long long)grid.x * grid.y * grid.z < g_gather_narrow_max_units;
+    if (narrow) grid.z *= 2;
     const long long units = (long long)grid.x * grid.y * grid.z;
-#define MVX_LAUNCH_GATHER(TLO, THI)                                                                                              \
+#define MVX_LAUNCH_GATHER_N(TLO, THI, NB2)                                                                                       \
     do {                                                                                                                         \
         if (work_counter && units > persistent_grid())                                                                           \
-            hipLaunchKernelGGL((conv3d_gather_pw<TLO, THI>), dim3(persistent_grid()), dim3(256), 0, st, in, wpk, bias, out, stats, g, \
-                               relu, in_hflag, out_mask, bg_pre, border_active, exec_stages, only_tiles, done_counter, fin_count,   \
-                               fin_eps, fin_mean_inv, work_counter, (int)grid.x, (int)grid.y, (int)grid.z);                        \
+            hipLaunchKernelGGL((conv3d_gather_pw<TLO, THI, NB2>), dim3(persistent_grid()), dim3(256), 0, st, in, wpk, bias, out,  \
+                               stats, g, relu, in_hflag, out_mask, bg_pre, border_active, exec_stages, only_tiles, done_counter,  \
+                               fin_count, fin_eps, fin_mean_inv, work_counter, (int)grid.x, (int)grid.y, (int)grid.z);            \
         else                                                                                                                     \
-            hipLaunchKernelGGL((conv3d_gather_pf<TLO, THI>), grid, dim3(256), 0, st, in, wpk, bias, out, stats, g, relu, in_hflag,  \
-                               out_mask, bg_pre, border_active, exec_stages, only_tiles, done_counter, fin_count, fin_eps,          \
-                               fin_mean_inv);                                                                                      \
+            hipLaunchKernelGGL((conv3d_gather_pf<TLO, THI, NB2>), grid, dim3(256), 0, st, in, wpk, bias, out, stats, g, relu,     \
+                               in_hflag, out_mask, bg_pre, border_active, exec_stages, only_tiles, done_counter, fin_count,       \
+                               fin_eps, fin_mean_inv);                                                                            \
+    } while (0)
+#define MVX_LAUNCH_GATHER(TLO, THI)                                                                                              \
+    do {                                                                                                                         \
+        if (narrow) MVX_LAUNCH_GATHER_N(TLO, THI, 1);                                                                            \
+        else MVX_LAUNCH_GATHER_N(TLO, THI, 2);                                                                                   \
     } while (0)
     if (g.tap_lo == 0 && g.tap_hi == 3) MVX_LAUNCH_GATHER(0, 3);
     else if (g.tap_lo == 0 && g.tap_hi == 2) MVX_LAUNCH_GATHER(0, 2);
     else MVX_LAUNCH_GATHER(1, 3);
 #undef MVX_LAUNCH_GATHER
+#undef MVX_LAUNCH_GATHER_N
 }
 
 extern "C" void mvx_conv3d_tile_shape(int32_t *tile_h, int32_t *tile_w) {

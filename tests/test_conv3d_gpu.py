@@ -119,6 +119,17 @@ def test_cml_stack_matches_reference_fixture(golden):
         assert rel_err(x.cpu().permute(3, 0, 1, 2), ref) < 1e-4, key
 
 
+@pytest.fixture(autouse=True, params=['narrow units where small', '64-channel units only'])
+def gather_units(request):
+    """The f32 gather runs small launches as 32-channel ("narrow") workgroup units (csrc/conv3d.hip launch_gather,
+    MVX_TUNE_GATHER_NARROW_MAX_UNITS = key 2) -- which is every launch at these test sizes: each test of this file runs
+    with the default rule and with narrow units off."""
+    from modules import Extension as X
+    X.check(X.lib.mvx_tuning_set(2, 1024 if request.param.startswith('narrow') else 0), 'mvx_tuning_set')
+    yield request.param
+    X.check(X.lib.mvx_tuning_set(2, 1024), 'mvx_tuning_set')
+
+
 @pytest.fixture(params=['8x16 units', '16x16 units'])
 def split_units(request):
     """The bf16x3 gather has two workgroup shapes (csrc/conv3d_split.hip: 8 x 16 sites, and 16 x 16 sites with 64-site wave

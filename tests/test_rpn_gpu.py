@@ -14,6 +14,42 @@ def rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
+@pytest.fixture(autouse=True, params=['narrow units where small', '64-channel units only'])
+def gather_units(request):
+    """The f32 gather runs small launches as 32-channel ("narrow") workgroup units (csrc/conv3d.hip launch_gather,
+    MVX_TUNE_GATHER_NARROW_MAX_UNITS = key 2): every test of this file with the default rule and with narrow units off."""
+    from modules import Extension as X
+    X.check(X.lib.mvx_tuning_set(2, 1024 if request.param.startswith('narrow') else 0), 'mvx_tuning_set')
+    yield request.param
+    X.check(X.lib.mvx_tuning_set(2, 1024), 'mvx_tuning_set')
+
+
+def test_narrow_and_wide_gather_units_give_identical_maps():
+    """The same 2-D layers (stride 1; stride 2 in space-to-depth form, forward and input gradient) with 64- and 32-channel
+    units: outputs bit-identical (the K order of an output element does not depend on the unit width), BatchNorm sums
+    equal to f64 rounding (atomics in a different order)."""
+    from modules import Extension as X
+    from modules import _hip
+    from modules import rpn_frames as rf
+    import modules.config as cfg
+    F, h, w = 3, 21, 37                                   # ragged: no multiple of the 8 x 16 tile
+    g = torch.Generator().manual_seed(3)
+    got = {}
+    for cin, cout, flags in ((128, 128, 0), (64, 192, 0), (4 * 64, 128, rf.TAPS2)):
+        x = torch.randn((F, h, w, cin), generator=g).to(DEV)
+        wt = (torch.randn((cout, cin, 3, 3), generator=g) * 0.05).to(DEV)
+        b = torch.randn((cout,), generator=g).to(DEV)
+        dz = torch.randn((F, h, w, cout), generator=g).to(DEV)
+        for units, limit in (('wide', 0), ('narrow', 1 << 60)):
+            X.check(X.lib.mvx_tuning_set(2, limit), 'mvx_tuning_set')
+            y, mi = rf._conv(x, _hip.conv3d_pack(wt, False), b, F, h, w, cin, cout, flags, cfg.eps)
+            dx = rf._dgrad(dz, _hip.conv3d_pack(wt, True), F, h, w, cin, cout, flags)
+            got[(cin, cout, flags, units)] = (y.clone(), mi.clone(), dx.clone())
+        a, bq = got[(cin, cout, flags, 'wide')], got[(cin, cout, flags, 'narrow')]
+        assert torch.equal(a[0], bq[0]) and torch.equal(a[2], bq[2]), (cin, cout, flags)
+        assert rel(bq[1].double(), a[1].double()) < 1e-6
+
+
 def _to_planes(mid):
     """(F,128,H,W) BEV map (channel = c*2+d) -> channels-last planes [F*2][H][W][64] (what CML produces)."""
     F, _, H, W = mid.shape
