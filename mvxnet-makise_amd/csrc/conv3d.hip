@@ -1035,10 +1035,13 @@ static int persistent_grid() {
 }
 
 // Narrow units: a launch with fewer 64-channel units than this runs as twice as many 32-channel units (gather_unit<.., 1>),
-// each half the matrix work -- the small RPN maps (88 x 100 and 44 x 50: 616 and 384 units for four frames on 512-768
-// workgroup slots, a quarter of that for one frame) leave CUs idle or with one wave per SIMD otherwise.  Results are bit
-// identical (the K order of an output element does not change).  Tuning value MVX_TUNE_GATHER_NARROW_MAX_UNITS.
-static long long g_gather_narrow_max_units = 1024;
+// each half the matrix work.  Measured per RPN layer shape (tools/time_conv2d.py <frames> <limit>): it pays only when the
+// launch has fewer units than about half the CUs -- the 44 x 50 maps of ONE frame (96 units: 0.092 -> 0.060 ms forward,
+// 0.083 -> 0.051 ms input gradient, the stride-2 layer 0.069 -> 0.050); from 154 units on it is neutral and from 384
+// units on (four frames) slower, because a unit is bound by the latency chain of its eight K stages, not by its MFMAs
+// (one 64-channel unit alone on a CU: 92 us for 61 us of matrix work).  Results are bit identical (the K order of an output
+// element does not change).  Tuning value MVX_TUNE_GATHER_NARROW_MAX_UNITS.
+static long long g_gather_narrow_max_units = 160;
 void mvxi_gather_narrow_max_units(long long v) { g_gather_narrow_max_units = v; }
 
 static void launch_gather(hipStream_t st, const float *in, const float *wpk, const float *bias, float *out, double *stats,

@@ -119,15 +119,15 @@ def test_cml_stack_matches_reference_fixture(golden):
         assert rel_err(x.cpu().permute(3, 0, 1, 2), ref) < 1e-4, key
 
 
-@pytest.fixture(autouse=True, params=['narrow units where small', '64-channel units only'])
+@pytest.fixture(autouse=True, params=['32-channel units', '64-channel units'])
 def gather_units(request):
     """The f32 gather runs small launches as 32-channel ("narrow") workgroup units (csrc/conv3d.hip launch_gather,
-    MVX_TUNE_GATHER_NARROW_MAX_UNITS = key 2) -- which is every launch at these test sizes: each test of this file runs
-    with the default rule and with narrow units off."""
+    MVX_TUNE_GATHER_NARROW_MAX_UNITS = key 2) -- each test of this file runs with narrow units forced and with
+    narrow units off."""
     from modules import Extension as X
-    X.check(X.lib.mvx_tuning_set(2, 1024 if request.param.startswith('narrow') else 0), 'mvx_tuning_set')
+    X.check(X.lib.mvx_tuning_set(2, (1 << 60) if request.param.startswith('32') else 0), 'mvx_tuning_set')
     yield request.param
-    X.check(X.lib.mvx_tuning_set(2, 1024), 'mvx_tuning_set')
+    X.check(X.lib.mvx_tuning_set(2, 160), 'mvx_tuning_set')
 
 
 @pytest.fixture(params=['8x16 units', '16x16 units'])

@@ -14,14 +14,14 @@ def rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-@pytest.fixture(autouse=True, params=['narrow units where small', '64-channel units only'])
+@pytest.fixture(autouse=True, params=['32-channel units', '64-channel units'])
 def gather_units(request):
     """The f32 gather runs small launches as 32-channel ("narrow") workgroup units (csrc/conv3d.hip launch_gather,
-    MVX_TUNE_GATHER_NARROW_MAX_UNITS = key 2): every test of this file with the default rule and with narrow units off."""
+    MVX_TUNE_GATHER_NARROW_MAX_UNITS = key 2): every test of this file with narrow units forced and with narrow units off."""
     from modules import Extension as X
-    X.check(X.lib.mvx_tuning_set(2, 1024 if request.param.startswith('narrow') else 0), 'mvx_tuning_set')
+    X.check(X.lib.mvx_tuning_set(2, (1 << 60) if request.param.startswith('32') else 0), 'mvx_tuning_set')
     yield request.param
-    X.check(X.lib.mvx_tuning_set(2, 1024), 'mvx_tuning_set')
+    X.check(X.lib.mvx_tuning_set(2, 160), 'mvx_tuning_set')
 
 
 def test_narrow_and_wide_gather_units_give_identical_maps():

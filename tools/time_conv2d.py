@@ -1,5 +1,5 @@
 """Isolated timings of the 2-D convolution entry points (forward, dgrad, wgrad) at the RPN's layer shapes, one stream, nothing
-else on the GPU (developer tool).  usage: python tools/time_conv2d.py [frames]"""
+else on the GPU (developer tool).  usage: python tools/time_conv2d.py [frames] [narrow-unit limit, MVX_TUNE_GATHER_NARROW_MAX_UNITS]"""
 import os
 import sys
 
@@ -7,6 +7,7 @@ import torch
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+NARROW = int(sys.argv[2]) if len(sys.argv) > 2 else None
 sys.argv = sys.argv[:1]
 sys.path.insert(0, os.path.join(REPO, 'mvxnet-makise_amd'))
 from modules import _hip  # noqa: E402
@@ -15,6 +16,10 @@ import modules.config as cfg  # noqa: E402
 
 dev = torch.device('cuda')
 _hip.ASYNC_WGRAD = False
+if NARROW is not None:
+    from modules import Extension as X
+    X.check(X.lib.mvx_tuning_set(2, NARROW), 'mvx_tuning_set')
+    print('narrow-unit limit', NARROW)
 SHAPES = [('blk1 s1 128>128 @176x200', 176, 200, 128, 128, 0), ('blk2 s1 128>128 @88x100', 88, 100, 128, 128, 0),
           ('blk3 s1 256>256 @44x50', 44, 50, 256, 256, 0), ('deconv1 128>256 @176x200', 176, 200, 128, 256, 0),
           ('blk1 s2 512>128 @176x200 (4 taps)', 176, 200, 512, 128, rf.TAPS2), ('blk2 s2 512>128 @88x100 (4 taps)', 88, 100, 512, 128, rf.TAPS2),
