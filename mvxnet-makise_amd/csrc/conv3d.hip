@@ -30,6 +30,21 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// In-kernel time stamps of ONE unit of the gather kernel (tools/probes/gather_stamps.hip compiles this file with
+// -DMVX_GATHER_STAMPS; the library build has none of it): s_memtime read by thread 0 right after a barrier, where
+// lgkmcnt is zero anyway.
+#ifdef MVX_GATHER_STAMPS
+__device__ unsigned long long g_stamps[256];
+__device__ int g_stamp_unit[3] = {0, 0, 0};            // (tile, plane, channel block) of the stamped unit
+__device__ volatile int g_stamp_wg = -1;               // workgroup that ran the stamped unit: its NEXT unit stamps 201 / 202
+#define MVX_STAMP(k)                                                                                       \
+    do {                                                                                                   \
+        if (stamped && threadIdx.x == 0 && (k) < 256) g_stamps[(k)] = __builtin_amdgcn_s_memtime();        \
+    } while (0)
+#else
+#define MVX_STAMP(k) do { } while (0)
+#endif
+
 constexpr int TH = 8, TW = 16;          // output patch of a workgroup
 constexpr int HH = TH + 2, HW = TW + 2; // halo
 constexpr int BK = 32;                  // channels per K chunk
@@ -291,28 +306,51 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
     // Prefetches are unconditional (the last stage re-fetches its own operands and drops them): a
     // conditionally written register array would be demoted to scratch memory.
     if (TLO == 0 && THI == 3) {
+#ifdef MVX_GATHER_STAMPS
+    const bool stamped = tile == g_stamp_unit[0] && d == g_stamp_unit[1] && nb == g_stamp_unit[2];
+    bool follow = false;
+    if (threadIdx.x == 0 && !stamped && g_stamp_wg == (int)blockIdx.x) {
+        follow = true;
+        g_stamp_wg = -1;
+        g_stamps[201] = __builtin_amdgcn_s_memtime();          // the next unit of the same workgroup enters its K loop
+    }
+#endif
+    MVX_STAMP(0);
     load_wrow(0, 0);
     load_halo(0);
     for (int st = 0; st < nstages; ++st) {
         const int nxt = st + 1 < nstages ? st + 1 : st;
         __syncthreads();                           // previous stage's LDS reads are done
+        MVX_STAMP(1 + 6 * st);
         store_halo();
         store_wrow();                              // tap row 0
         __syncthreads();
+        MVX_STAMP(2 + 6 * st);
+#ifdef MVX_GATHER_STAMPS
+        if (follow && st == 0) g_stamps[202] = __builtin_amdgcn_s_memtime();       // ... and has its first operands in LDS
+#endif
         load_wrow(st, 1);                          // next weight row first ...
         load_halo(nxt);                            // ... then the long-latency halo of the next stage
         compute_row(0);
         __syncthreads();
+        MVX_STAMP(3 + 6 * st);
         store_wrow();                              // tap row 1 (waits for its 6 loads only)
         __syncthreads();
+        MVX_STAMP(4 + 6 * st);
         load_wrow(st, 2);
         compute_row(1);
         __syncthreads();
+        MVX_STAMP(5 + 6 * st);
         store_wrow();                              // tap row 2
         __syncthreads();
+        MVX_STAMP(6 + 6 * st);
         load_wrow(nxt, 0);
         compute_row(2);
     }
+#ifdef MVX_GATHER_STAMPS
+    __syncthreads();
+    MVX_STAMP(1 + 6 * nstages);
+#endif
     } else {
     // two tap rows [r0, r0 + 1] (2 x 2 window): the same pipeline with one row step less per stage.  With g.s2d the
     // structurally zero (tap, parity) blocks of a stride-2 kernel in space-to-depth form are skipped: forward (mode 0) the
@@ -447,6 +485,13 @@ __device__ __forceinline__ void gather_unit(const int tile, const int d, const i
             atomicAdd(fstats + ((size_t)rep * 2 + which) * g.Cout + nb * BNW + c, t);
         }
     }
+#ifdef MVX_GATHER_STAMPS
+    if (TLO == 0 && THI == 3 && threadIdx.x == 0 && tile == g_stamp_unit[0] && d == g_stamp_unit[1] && nb == g_stamp_unit[2]) {
+        __builtin_amdgcn_s_waitcnt(0);                          // the unit's stores have been issued and its loads returned
+        g_stamps[200] = __builtin_amdgcn_s_memtime();
+        g_stamp_wg = (int)blockIdx.x;
+    }
+#endif
 }
 
 
