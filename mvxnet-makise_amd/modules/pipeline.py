@@ -271,10 +271,11 @@ def train_step_frames(model, batch, grad_mid, imsize, ready=None, prepare_next=N
 BATCHED = _os.environ.get('MVX_FRAME_SETS', '1') != '0'
 
 
-def prepare_frame_set(batch, T=None):
+def prepare_frame_set(batch, T=None, sample=None):
     """Voxelize the batch and build the frame set (voxels of all non-empty frames back to back + compact-row maps) with TWO
     host reads: the voxel counts, then the real-row offsets.  Returns (frame set or None, frame ids in it, voxel counts of
-    every frame of the batch, status word)."""
+    every frame of the batch, status word).  ``sample`` = (fusion head, imsize): also sample the FPN features of the real
+    rows here (frames.sample_rows) -- input preparation like the rest, no parameter involved."""
     from modules import frames as fr
     T = cfg.samplenum if T is None else T
     points6, n_points = batch.prepared()
@@ -293,10 +294,13 @@ def prepare_frame_set(batch, T=None):
     fs = fr.FrameSet(voxels, coords, off, T)
     real_off = fs.enqueue_map().tolist()            # host read 2
     fs.finish_map(real_off)
+    if sample is not None:
+        fs.sampled = fr.sample_rows(sample[0], fs, [batch.fpn_levels[f] for f in live], sample[1])
     return fs, live, counts, status_v
 
 
 PREP_STREAM = _os.environ.get('MVX_PREP_STREAM', '1') != '0'    # next batch prepared on its own stream (host reads return early)
+PRESAMPLE = _os.environ.get('MVX_PRESAMPLE', '1') != '0'        # ... including the FPN feature sampling of its real rows (frames.sample_rows)
 # Frame-set lanes: the frames of a step split into this many frame sets that run on their own streams, so that the small
 # latency-bound kernels of one set (BatchNorm passes, VFE, list builders) execute beside the MFMA-bound kernels of the other.
 # Every set keeps per-frame BatchNorm statistics, so the result per frame is unchanged; lane k > 0 accumulates its parameter
@@ -472,7 +476,7 @@ def train_step_frame_set(model, batch, grad_mid, imsize, ready=None, prepare_nex
             if PREP_STREAM:
                 prep = _prep_stream(dev)
                 with torch.cuda.stream(prep):
-                    nr = prepare_frame_set(prepare_next)
+                    nr = prepare_frame_set(prepare_next, sample=(model.head, imsize) if PRESAMPLE else None)
                     ev = torch.cuda.Event()
                     ev.record(prep)
                 next_ready = nr + (ev,)
@@ -700,7 +704,7 @@ def train_step_full(model, batch, targets, criterion, anchors, imsize, ready=Non
             if PREP_STREAM:
                 prep = _prep_stream(dev)
                 with torch.cuda.stream(prep):
-                    nr = prepare_frame_set(nb)
+                    nr = prepare_frame_set(nb, sample=(model.head, hw) if PRESAMPLE else None)
                     nt = target_fn()
                     ev = torch.cuda.Event()
                     ev.record(prep)
