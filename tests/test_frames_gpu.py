@@ -187,3 +187,37 @@ def test_frame_set_lanes_equal_one_frame_set(golden, small_cfg, B, with_empty):
             assert rel_err(bucket.flat, ref) < 2e-4
     finally:
         pl.SET_LANES = old
+
+
+def test_batch_prepared_a_step_ahead_with_its_fpn_sampling_gives_the_same_step(golden, small_cfg):
+    """The next batch is voxelized, mapped AND its FPN features sampled on the preparation stream
+    (pipeline.prepare_frame_set(sample=...), frames.sample_rows): the step that consumes it must equal the step that prepares
+    its batch itself -- maps bit-identical, parameter gradients up to the order of the f64 atomics."""
+    import modules.pipeline as pl
+    from MVXNet import MVXNet
+    from modules import parallel
+    torch.manual_seed(5)
+    model = MVXNet().to(DEV)
+    B = 3
+    batch, G = _small_batch(golden, B, False)
+    hot = [(k, p) for k, p in model.named_parameters() if p.requires_grad and '.rpn.' not in k]
+    bucket = parallel.GradBucket([p for _, p in hot])
+    imsize = [370.0, 1224.0]
+    Gb = torch.stack([G[0] * (1.0 + 0.5 * f) for f in range(B)])
+    bucket.zero()
+    mids_ref = []
+    pl.train_step_frame_set(model, batch, Gb, imsize, keep_mid=mids_ref)
+    torch.cuda.synchronize()
+    ref = bucket.flat.clone()
+    assert pl.PRESAMPLE and pl.PREP_STREAM
+    ready = None
+    for rep in range(3):                                  # rep 0 prepares its own batch, reps 1-2 consume a prepared one
+        bucket.zero()
+        mids = []
+        _, st, ready = pl.train_step_frame_set(model, batch, Gb, imsize, ready=ready, prepare_next=batch, keep_mid=mids)
+        assert ready[0].sampled is not None               # the prepared set carries its sampled rows
+        torch.cuda.synchronize()
+        assert int(torch.stack([s.reshape(()) for s in st]).max()) == 0
+        for a, b in zip(mids, mids_ref):
+            assert torch.equal(a, b)
+        assert rel_err(bucket.flat, ref) < 1e-6
