@@ -41,7 +41,7 @@ extern "C" {
                                   [planes][3][cout] per-depth-tap constants | [planes][9][cout] image-border position classes): in interior
                                   tiles a depth tap whose source halo holds no active site is not executed (its constant is added in the
                                   epilogue), and a border tile without any active source is filled from the class constants (exact rewrites) */
-#define MVX_FLAG_SPLIT 64      /* mvx_linear_forward*: bf16x3 split arithmetic (three bf16 MFMAs per product, f32 accumulate, ~2e-5 per
+#define MVX_FLAG_SPLIT 64      /* mvx_linear_forward*, mvx_linear_wgrad: bf16x3 split arithmetic (three bf16 MFMAs per product, f32 accumulate, ~2e-5 per
                                   product: the row-GEMM side of `convmath: bf16x3`) for layers with n > 64, k % 4 == 0, 16-byte aligned
                                   operands and a row-major weight (w_transposed = 0); other calls run the exact-f32 kernel */
 

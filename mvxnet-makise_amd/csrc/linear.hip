@@ -515,7 +515,11 @@ extern "C" int mvx_linear_wgrad(const float *x, int32_t ldx, const float *dz, in
     MVX_CHECK_ARG(workspace_bytes >= (size_t)strips * n * k * sizeof(float));
     const bool vec = aligned16(x) && aligned16(dz) && ldx % 4 == 0 && lddz % 4 == 0 && k % 4 == 0 && n % 4 == 0;
     const dim3 grid((unsigned)strips, mvx_cdiv(n, 128), mvx_cdiv(k, 128));
-    if (vec)
+    if (vec && (flags & MVX_FLAG_SPLIT)) {
+        // rows_per_strip is a multiple of the 32-row LDS step in both kernels (strip_rows)
+        int rc = mvxi_linear_wgrad_split(x, ldx, dz, lddz, (float *)workspace, (long long)rows, k, n, per, strips, st);
+        if (rc) return rc;
+    } else if (vec)
         hipLaunchKernelGGL(linear_wgrad<true>, grid, dim3(256), 0, st, x, ldx, dz, lddz, (float *)workspace,
                            (long long)rows, k, n, per);
     else

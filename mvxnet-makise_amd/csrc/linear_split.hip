@@ -209,7 +209,125 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Weight gradient of a row layer in bf16x3: slab[strip][n][k] = sum over the rows of the strip of dz[r][n] * x[r][k].
+// The MFMA reduction index is the ROW, so both operands are needed row-major along k while memory is channel-major:
+// 32-row x 128-column tiles of dz and x are split (hi, lo) while they are staged as [column block of 32][row][32] bf16
+// (64-byte rows) and fetched with ds_read_b64_tr_b16, the LDS transpose read (the recipe of conv3d_wgrad_split,
+// csrc/conv3d_split.hip): a 16-lane group reads 4 rows x 16 columns and every lane receives 4 consecutive rows of its
+// column.  Workgroup block 128(n) x 128(k); wave (wn, wk) owns 64 x 64 = 2 x 2 accumulator tiles: per 16-row k-step 8
+// operand fragments (16 transpose reads) feed 12 MFMAs.  Same strips / slabs / slab_reduce as the f32 kernel (linear.hip).
+// ------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+constexpr int WRS = 32;                 // rows per LDS step (two MFMA k-steps)
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned short *row0, const unsigned short *row1) {
+    typedef __attribute__((address_space(3))) s16x4 lds4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4 *)row0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4 *)row1);
+    s16x8 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256) void linear_wgrad_split(const float *__restrict__ x, int ldx, const float *__restrict__ dz,
+                                                          int lddz, float *__restrict__ slabs, long long R, int K, int N,
+                                                          long long rows_per_strip) {
+    __shared__ __attribute__((aligned(16))) unsigned short s_zh[4][WRS][32], s_zl[4][WRS][32];
+    __shared__ __attribute__((aligned(16))) unsigned short s_xh[4][WRS][32], s_xl[4][WRS][32];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int wn = wv >> 1, wk = wv & 1;
+    const int n0 = blockIdx.y * 128, k0 = blockIdx.z * 128;
+    const long long rbeg = (long long)blockIdx.x * rows_per_strip;
+    const long long rend = rbeg + rows_per_strip < R ? rbeg + rows_per_strip : R;
+    // transpose-read roles of this lane (conv3d_wgrad_split)
+    const int grp = lane >> 4, i16 = lane & 15, q = i16 >> 2, pcol = (grp & 1) * 16 + 4 * (i16 & 3), kbase = (grp >> 1) * 8;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const bool wave_on = (n0 + wn * 64 < N) && (k0 + wk * 64 < K);
+
+    f32x4 zr[4], xr[4];
+    auto load_tiles = [&](long long rr) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = tid + 256 * u, r = c >> 5, part = c & 31;
+            const long long gr = rr + r;
+            const bool ok = gr < rend;
+            zr[u] = (ok && n0 + part * 4 < N) ? *(const f32x4 *)(dz + gr * lddz + n0 + part * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            xr[u] = (ok && k0 + part * 4 < K) ? *(const f32x4 *)(x + gr * ldx + k0 + part * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    load_tiles(rbeg);
+    for (long long rr = rbeg; rr < rend; rr += WRS) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = tid + 256 * u, r = c >> 5, part = c & 31;
+            uint2 hi, lo;
+            split4(zr[u], &hi, &lo);
+            *(uint2 *)(&s_zh[part >> 3][r][(part & 7) * 4]) = hi;
+            *(uint2 *)(&s_zl[part >> 3][r][(part & 7) * 4]) = lo;
+            split4(xr[u], &hi, &lo);
+            *(uint2 *)(&s_xh[part >> 3][r][(part & 7) * 4]) = hi;
+            *(uint2 *)(&s_xl[part >> 3][r][(part & 7) * 4]) = lo;
+        }
+        __syncthreads();
+        if (rr + WRS < rend) load_tiles(rr + WRS);
+        if (wave_on) {
+#pragma unroll
+            for (int ks = 0; ks < WRS / 16; ++ks) {
+                const int r0 = ks * 16 + kbase + q, r1 = r0 + 4;
+                bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    ah[t] = tr_frag(&s_zh[wn * 2 + t][r0][pcol], &s_zh[wn * 2 + t][r1][pcol]);
+                    al[t] = tr_frag(&s_zl[wn * 2 + t][r0][pcol], &s_zl[wn * 2 + t][r1][pcol]);
+                    bh[t] = tr_frag(&s_xh[wk * 2 + t][r0][pcol], &s_xh[wk * 2 + t][r1][pcol]);
+                    bl[t] = tr_frag(&s_xl[wk * 2 + t][r0][pcol], &s_xl[wk * 2 + t][r1][pcol]);
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    if (wave_on) {
+        float *o = slabs + (size_t)blockIdx.x * N * K;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + wn * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int k = k0 + wk * 64 + b * 32 + li;
+                    if (n < N && k < K) o[(size_t)n * K + k] = acc[a][b][r];
+                }
+    }
+}
+
 }  // namespace
+
+// Launched by linear.hip (mvx_linear_wgrad) when MVX_FLAG_SPLIT is set and the operands are 16-byte aligned.
+int mvxi_linear_wgrad_split(const float *x, int ldx, const float *dz, int lddz, float *slabs, long long rows, int k, int n,
+                            long long rows_per_strip, long long strips, hipStream_t st) {
+    const dim3 grid((unsigned)strips, mvx_cdiv(n, 128), mvx_cdiv(k, 128));
+    hipLaunchKernelGGL(linear_wgrad_split, grid, dim3(256), 0, st, x, ldx, dz, lddz, slabs, rows, k, n, rows_per_strip);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
 
 // Launched by linear.hip (linear_forward_impl) when MVX_FLAG_SPLIT is set and the shape qualifies.
 int mvxi_linear_forward_split(const float *x, int ldx, const float *w, int ldw, const float *bias, float *y,

@@ -707,21 +707,21 @@ def _work_counter(device):
     return torch.zeros((1,), dtype=torch.float64, device=device)
 
 
-ROW_SPLIT = tuple(k for k in os.environ.get('MVX_ROW_SPLIT', 'dgrad,rpn').split(',') if k)
+ROW_SPLIT = tuple(k for k in os.environ.get('MVX_ROW_SPLIT', 'dgrad,wgrad,rpn').split(',') if k)
 
 
 def row_split(tag):
     """Does the wide row GEMM ``tag`` run in bf16x3 arithmetic (csrc/linear_split.hip)?  Under ``convmath: bf16x3``, when an
     entry of ROW_SPLIT is a prefix of the tag.  Tags: 'fusion_<N>x<K>' (forward of a fusion MLP layer), 'vfe', 'conv1',
     'rpn' (forward of the wide VFE layer, of conv1's per-voxel GEMM, of the RPN's deconvolution GEMMs), 'dgrad' (every
-    input-gradient row GEMM).
+    input-gradient row GEMM), 'wgrad' (every weight-gradient row GEMM).
 
-    Default: the input gradients and the RPN's GEMMs only.  A forward layer in split arithmetic carries ~5e-6 relative
+    Default: the input and weight gradients and the RPN's forward GEMMs only.  A forward layer in split arithmetic carries ~5e-6 relative
     error (exact-f32 MFMA: ~8e-7) and the BatchNorm chain behind the FIRST layers of the network amplifies it 5-7x on the
     way to the BEV map.  Measured on one full-size frame against the float64 oracle and on bench.py --convmath bf16x3
     (tools/split_accuracy.py, tools/split_speed.sh -> profiles/r03_split_accuracy.json, r03_split_speed.txt):
 
-        forward rows in bf16x3          BEV map   cls logits  hot frames/s  full frames/s
+        forward rows in bf16x3          BEV map   cls logits  hot frames/s  full frames/s   (input gradients split, weight gradients f32)
         none (convolutions only)        7.6e-6    1.36e-4     443           200
         rpn                             7.6e-6    1.37e-4       (within noise of the row above)
         conv1                           1.3e-5    1.49e-4
@@ -732,7 +732,8 @@ def row_split(tag):
 
     i.e. the 768 -> 768 layer, the only one whose speed matters (81 % of the row-GEMM flops of a step, +5 % frames/s), is
     also the one that costs a factor 3-4 in accuracy of every later map: it stays on the exact-f32 kernel unless
-    MVX_ROW_SPLIT asks otherwise."""
+    MVX_ROW_SPLIT asks otherwise.  The weight-gradient GEMMs ('wgrad', linear_wgrad_split: 0.955 -> 0.517 ms for the
+    768 x 768 layer over 80 k rows) touch no forward map and are split by default: hot 443 -> 470, full 200 -> 210 frames/s."""
     import modules.config as cfg
     return cfg.config.get('convmath', 'f32') == 'bf16x3' and any(tag.startswith(k) for k in ROW_SPLIT)
 
@@ -798,8 +799,9 @@ def linear_forward(x, w, bias, relu=True, want_stats=True, w_transposed=False, r
     return out, stats
 
 
-def linear_wgrad(x, dz, accumulate_into=None):
-    """dW (N,K) = dz^T x; accumulate_into: existing contiguous (N,K)-sized gradient buffer to ADD to."""
+def linear_wgrad(x, dz, accumulate_into=None, split=None):
+    """dW (N,K) = dz^T x; accumulate_into: existing contiguous (N,K)-sized gradient buffer to ADD to.  ``split``: bf16x3
+    arithmetic (MVX_FLAG_SPLIT, csrc/linear_split.hip linear_wgrad_split); None = as ``row_split('wgrad')`` says."""
     R, K = x.shape
     N = dz.shape[1]
     if accumulate_into is not None:
@@ -807,6 +809,8 @@ def linear_wgrad(x, dz, accumulate_into=None):
         dw, flags = accumulate_into, FLAG_ACCUMULATE
     else:
         dw, flags = torch.empty((N, K), dtype=torch.float32, device=x.device), 0
+    if row_split('wgrad') if split is None else split:
+        flags |= FLAG_SPLIT
     nbytes = X.lib.mvx_linear_wgrad_workspace_bytes(R, K, N)
     with _wgrad_scope(accumulate_into, x, dz) as scope:
         ws = workspace(nbytes, x.device, 'lwgrad_side' if isinstance(scope, _SideStream) else 'lwgrad')

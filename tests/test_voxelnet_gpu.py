@@ -422,3 +422,23 @@ def test_row_gemm_bf16x3_split_accuracy(R, K, N):
     assert rel_err(y32.cpu(), ref) < 2e-6                      # the exact-f32 kernel, for scale
     yn, _ = _hip.linear_forward(x.to(DEV), w.to(DEV), None, relu=False, want_stats=False, split=True)
     assert rel_err(yn.cpu(), x.double() @ w.double().t()) < 2e-5
+
+
+@pytest.mark.parametrize('R,K,N', [(1000, 768, 768), (4099, 128, 768), (517, 768, 128), (300, 1728, 128), (777, 24, 16), (9000, 128, 128)])
+def test_row_gemm_weight_gradient_bf16x3_split_accuracy(R, K, N):
+    """MVX_FLAG_SPLIT on mvx_linear_wgrad (csrc/linear_split.hip linear_wgrad_split: hi/lo split while staging, LDS
+    transpose reads, three bf16 MFMAs per product): dW = dz^T x against float64, fp32-grade like the other split kernels;
+    row counts that are no multiple of the 32-row step, column counts that are no multiple of the 128 x 128 block, and the
+    accumulate form."""
+    from modules import _hip
+    g = torch.Generator().manual_seed(R + N)
+    x = torch.randn((R, K), generator=g)
+    dz = torch.randn((R, N), generator=g)
+    ref = dz.double().t() @ x.double()
+    dw = _hip.linear_wgrad(x.to(DEV), dz.to(DEV), split=True)
+    assert rel_err(dw.cpu(), ref) < 2e-5
+    dw32 = _hip.linear_wgrad(x.to(DEV), dz.to(DEV), split=False)
+    assert rel_err(dw32.cpu(), ref) < 2e-6                     # the exact-f32 kernel, for scale
+    into = torch.full((N, K), 0.5, device=DEV)
+    _hip.linear_wgrad(x.to(DEV), dz.to(DEV), accumulate_into=into, split=True)
+    assert rel_err(into.cpu() - 0.5, ref) < 2e-5
