@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
 // ------------------------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
-constexpr int WRS = 32;                 // rows per LDS step (two MFMA k-steps)
+constexpr int WRS = 32;                 // rows per LDS step (two MFMA k-steps; 64 rows: 232 VGPRs, one wave per SIMD, 0.517 -> 0.585 ms)
 
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned short *row0, const unsigned short *row1) {
     typedef __attribute__((address_space(3))) s16x4 lds4;
@@ -253,10 +253,11 @@ __global__ __launch_bounds__(256) void linear_wgrad_split(const float *__restric
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const bool wave_on = (n0 + wn * 64 < N) && (k0 + wk * 64 < K);
 
-    f32x4 zr[4], xr[4];
+    constexpr int NU = WRS * 32 / 256;       // 16-byte pieces per thread and tile
+    f32x4 zr[NU], xr[NU];
     auto load_tiles = [&](long long rr) __attribute__((always_inline)) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NU; ++u) {
             const int c = tid + 256 * u, r = c >> 5, part = c & 31;
             const long long gr = rr + r;
             const bool ok = gr < rend;
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_split(const float *__restric
     for (long long rr = rbeg; rr < rend; rr += WRS) {
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NU; ++u) {
             const int c = tid + 256 * u, r = c >> 5, part = c & 31;
             uint2 hi, lo;
             split4(zr[u], &hi, &lo);
