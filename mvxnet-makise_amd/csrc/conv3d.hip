@@ -805,9 +805,17 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restr
         slots = grp == 0 ? (m & 3u) : ((m >> 2) & 3u);
     }
     int cur = next_live(0);
+#ifdef MVX_GATHER_STAMPS
+    const bool stamped = strip == g_stamp_unit[0] && (int)blockIdx.y == g_stamp_unit[1] && nb == g_stamp_unit[2];
+    int sidx = 0;
+#endif
+    MVX_STAMP(0);
     if (cur < nsteps) load_step(cur);
     while (cur < nsteps) {
         __syncthreads();
+#ifdef MVX_GATHER_STAMPS
+        MVX_STAMP(1 + 3 * sidx);
+#endif
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
             const int c = tid + W4_THREADS * u;
@@ -819,12 +827,24 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restr
             *(f32x4 *)(s_z + (c >> 4) * ZP + (c & 15) * 4) = zr[u];
         }
         __syncthreads();
+#ifdef MVX_GATHER_STAMPS
+        MVX_STAMP(2 + 3 * sidx);
+#endif
         const int nxt = next_live(cur + 1);
         load_step(nxt < nsteps ? nxt : cur);          // unconditional (see conv3d_gather_pf): the last one is dropped
         if (grp == 0) wgrad4_mfma_step<T2, 0>(s_x, s_z, acc, wm, wn, li, lh, slots);
         else wgrad4_mfma_step<T2, 1>(s_x, s_z, acc, wm, wn, li, lh, slots);
+#ifdef MVX_GATHER_STAMPS
+        MVX_STAMP(3 + 3 * sidx);                      // thread 0 (wave 0) has ISSUED its MFMAs of the step
+        ++sidx;
+#endif
         cur = nxt;
     }
+#ifdef MVX_GATHER_STAMPS
+    __syncthreads();
+    MVX_STAMP(250);
+    if (stamped && threadIdx.x == 0) g_stamps[251] = (unsigned long long)nsteps;
+#endif
     // slab[strip][kd][tap][c (Cin)][n (64)]: every tap is written by the group that owns it (zeros where nothing was computed)
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -837,6 +857,12 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restr
             o[(size_t)row * BN + li] = acc[i][r];
         }
     }
+#ifdef MVX_GATHER_STAMPS
+    if (stamped && threadIdx.x == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        g_stamps[252] = __builtin_amdgcn_s_memtime();
+    }
+#endif
 }
 
 // step_list[kd][j] = d * ntiles + tile for the (plane, tile) steps of depth tap kd whose source halo holds a

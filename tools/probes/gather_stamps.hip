@@ -3,7 +3,7 @@
 // shape, reads the stamps back and prints the time of each phase of a stage:
 //   [top barrier] store halo + weight row 0 | [barrier] row 0 MFMAs | store row 1 | row 1 MFMAs | store row 2 | row 2 MFMAs
 // build: hipcc --offload-arch=gfx950 -O3 -DMVX_GATHER_STAMPS -I include -I mvxnet-makise_amd/csrc tools/probes/gather_stamps.hip -o gather_stamps.bin
-// usage: gather_stamps.bin <frames> <h> <w> <cin> <cout> [tile of the stamped unit] [depth planes of a 3-D layer]
+// usage: gather_stamps.bin <frames> <h> <w> <cin> <cout> [tile of the stamped unit / strip] [depth planes of a 3-D layer] [1 = the weight-gradient kernel]
 #include "conv3d.hip"
 #include <cstdio>
 #include <cstdlib>
@@ -48,6 +48,39 @@ int main(int argc, char **argv) {
         CK(hipEventElapsedTime(&ms, e0, e1));
     }
     unsigned long long st[256];
+    if (argc > 8 && atoi(argv[8]) == 1) {
+        // ---- weight-gradient kernel (conv3d_wgrad4) of the same 2-D layer: stamps of workgroup (strip = tile argument, kd 1, chunk 0, block 0)
+        float *dz, *dw;
+        void *ws;
+        CK(hipMalloc(&dz, ny * 4)); CK(hipMalloc(&dw, (size_t)cout * cin * 9 * 4));
+        CK(hipMemcpy(dz, hx.data(), (ny < nx ? ny : nx) * 4, hipMemcpyHostToDevice));
+        const size_t wsb = mvx_conv2d_wgrad_workspace_bytes_frames(h, w, cin, cout, F);
+        CK(hipMalloc(&ws, wsb));
+        int wunit[3] = {tile, 1 * (cin / 64) + 0, 0};
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_unit), wunit, sizeof(wunit)));
+        for (int it = 0; it < 5; ++it) {
+            CK(hipEventRecord(e0, 0));
+            int rc = mvx_conv2d_wgrad_frames(x, dz, dw, h, w, cin, cout, 0, ws, wsb, F, nullptr);
+            if (rc) { fprintf(stderr, "wgrad: %d\n", rc); return 1; }
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+        }
+        CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st)));
+        const int nsteps = (int)st[251];
+        printf("wgrad4 %d frames %dx%d %d->%d: three launches %.1f us; workgroup strip %d: %d steps (tiles)\n", F, h, w, cin, cout, ms * 1e3, tile, nsteps);
+        printf("%-6s %12s %12s %12s\n", "step", "to barrier", "LDS stores", "MFMA issue");
+        double sm[3] = {0, 0, 0};
+        for (int i = 0; i < nsteps && 3 + 3 * i < 250; ++i) {
+            const double a = (double)(st[1 + 3 * i] - (i == 0 ? st[0] : st[3 * i])), b = (double)(st[2 + 3 * i] - st[1 + 3 * i]),
+                         c = (double)(st[3 + 3 * i] - st[2 + 3 * i]);
+            printf("%-6d %12.0f %12.0f %12.0f\n", i, a, b, c);
+            sm[0] += a; sm[1] += b; sm[2] += c;
+        }
+        printf("sum    %12.0f %12.0f %12.0f   loop %.0f clocks (5 or 4 taps x 64 k-steps x 64 clocks = 20,480 / 16,384 of MFMA per wave and step, two waves per SIMD);"
+               " slab stores %.0f\n", sm[0], sm[1], sm[2], (double)(st[250] - st[0]), (double)(st[252] - st[250]));
+        return 0;
+    }
     CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st)));
     const int nst = (planes > 0 ? 3 : 1) * (cin / 32);          // depth taps x chunks
     printf("layer %d frames %dx%d %d->%d: launch %.1f us; unit tile %d; s_memtime ticks (shader clocks)\n", F, h, w, cin, cout, ms * 1e3, tile);
