@@ -88,7 +88,8 @@ int mvx_abi_version(void);
  *   MVX_TUNE_SPLIT16_MIN_UNITS  the bf16x3 gather uses 16 x 16-site workgroup units when a launch has at least this many of them
  *                               (default 768), else 8 x 16-site units; 0 = always 16 x 16, a huge value = never
  *   MVX_TUNE_GATHER_NARROW_MAX_UNITS  the f32 gather (conv3d / conv2d forward and dgrad) runs a launch with fewer 64-channel
- *                               workgroup units than this (default 160) as twice as many 32-channel units; 0 = never */
+ *                               workgroup units than this as twice as many 32-channel units; 0 = never, negative (default) = fewer than
+ *                               1.5 units per CU, i.e. while the doubled units are all resident at once */
 #define MVX_TUNE_SPLIT16_MIN_UNITS 1
 #define MVX_TUNE_GATHER_NARROW_MAX_UNITS 2
 int mvx_tuning_set(int32_t key, int64_t value);

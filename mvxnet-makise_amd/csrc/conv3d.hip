@@ -1106,13 +1106,15 @@ static int persistent_grid() {
 }
 
 // Narrow units: a launch with fewer 64-channel units than this runs as twice as many 32-channel units (gather_unit<.., 1>),
-// each half the matrix work.  Measured per RPN layer shape (tools/time_conv2d.py <frames> <limit>): it pays only when the
-// launch has fewer units than about half the CUs -- the 44 x 50 maps of ONE frame (96 units: 0.092 -> 0.060 ms forward,
-// 0.083 -> 0.051 ms input gradient, the stride-2 layer 0.069 -> 0.050); from 154 units on it is neutral and from 384
-// units on (four frames) slower, because a unit is bound by the latency chain of its eight K stages, not by its MFMAs
-// (one 64-channel unit alone on a CU: 92 us for 61 us of matrix work).  Results are bit identical (the K order of an output
-// element does not change).  Tuning value MVX_TUNE_GATHER_NARROW_MAX_UNITS.
-static long long g_gather_narrow_max_units = 160;
+// each half the matrix work -- when that lets ALL units be resident at once (three workgroups per CU): up to 1.5 units per
+// CU.  Measured per RPN layer shape (tools/time_conv2d.py <frames> <limit>), together with the classic launch up to three
+// units per CU (pf_max in launch_gather): four frames, 44 x 50 maps (384 -> 768 units) 0.165 -> 0.135 ms forward, 0.150 ->
+// 0.119 input gradient, the stride-2 layer 0.119 -> 0.089; 88 x 100 (616 units, stay 64-channel) 0.144 -> 0.133; two frames
+// 88 x 100 (308 -> 616) 0.092 -> 0.078; one frame 44 x 50 (96 -> 192) 0.092 -> 0.060.  Narrow units beyond that point
+// (more units than fit at once) are slower: a unit is bound by the serial chain of its K stages, not by its MFMAs.
+// Results are bit identical (the K order of an output element does not change).  Tuning value
+// MVX_TUNE_GATHER_NARROW_MAX_UNITS (negative = this rule).
+static long long g_gather_narrow_max_units = -1;
 void mvxi_gather_narrow_max_units(long long v) { g_gather_narrow_max_units = v; }
 
 static void launch_gather(hipStream_t st, const float *in, const float *wpk, const float *bias, float *out, double *stats,
@@ -1120,12 +1122,16 @@ static void launch_gather(hipStream_t st, const float *in, const float *wpk, con
                           int border_active, unsigned long long *exec_stages, const int *only_tiles, unsigned *done_counter,
                           double fin_count, double fin_eps, float *fin_mean_inv, unsigned *work_counter) {
     dim3 grid = gather_grid(g);
-    const bool narrow = (long long)grid.x * grid.y * grid.z < g_gather_narrow_max_units;
+    const long long narrow_max = g_gather_narrow_max_units >= 0 ? g_gather_narrow_max_units : 3ll * (persistent_grid() / 2) / 2 + 1;
+    const bool narrow = (long long)grid.x * grid.y * grid.z < narrow_max;
     if (narrow) grid.z *= 2;
     const long long units = (long long)grid.x * grid.y * grid.z;
+    // one workgroup per unit while all units fit on the GPU at once (three per CU: 52.7 KB of LDS, <= 168 VGPRs): a persistent
+    // grid of two per CU would run 513..768 units in two rounds
+    const long long pf_max = 3ll * (persistent_grid() / 2);
 #define MVX_LAUNCH_GATHER_N(TLO, THI, NB2)                                                                                       \
     do {                                                                                                                         \
-        if (work_counter && units > persistent_grid())                                                                           \
+        if (work_counter && units > pf_max)                                                                                      \
             hipLaunchKernelGGL((conv3d_gather_pw<TLO, THI, NB2>), dim3(persistent_grid()), dim3(256), 0, st, in, wpk, bias, out,  \
                                stats, g, relu, in_hflag, out_mask, bg_pre, border_active, exec_stages, only_tiles, done_counter,  \
                                fin_count, fin_eps, fin_mean_inv, work_counter, (int)grid.x, (int)grid.y, (int)grid.z);            \

@@ -127,7 +127,7 @@ def gather_units(request):
     from modules import Extension as X
     X.check(X.lib.mvx_tuning_set(2, (1 << 60) if request.param.startswith('32') else 0), 'mvx_tuning_set')
     yield request.param
-    X.check(X.lib.mvx_tuning_set(2, 160), 'mvx_tuning_set')
+    X.check(X.lib.mvx_tuning_set(2, -1), 'mvx_tuning_set')
 
 
 @pytest.fixture(params=['8x16 units', '16x16 units'])
