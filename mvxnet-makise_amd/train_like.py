@@ -121,7 +121,8 @@ def train(args):
     model = MVXNet().to(device)
     criterion = VoxelLoss()
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.AdamW(params, lr=0.001, eps=cfg.eps)
+    # train.py:64; on the GPU as one fused multi-tensor kernel per step (same update, ~10 launches fewer; bench.py has the numbers)
+    opt = torch.optim.AdamW(params, lr=0.001, eps=cfg.eps, fused=(device.type == 'cuda'))
     anchors = anchors.to(device)
     imsize = torch.Tensor(cfg.imsize).to(device)
     os.makedirs(args.checkpoints, exist_ok=True)
