@@ -45,6 +45,9 @@ extern "C" {
                                   product: the row-GEMM side of `convmath: bf16x3`) for layers with n > 64, k % 4 == 0, 16-byte aligned
                                   operands and a row-major weight (w_transposed = 0); other calls run the exact-f32 kernel */
 
+#define MVX_FLAG_SPLIT3 128    /* with MVX_FLAG_SPLIT, and on the *_split entry points: THREE bf16 pieces per f32 operand and six bf16 MFMAs per product
+                                  ("bf16x6": hi + mid + lo is the operand exactly, dropped cross terms < 2^-25: fp32-grade accuracy) instead of two / three */
+
 #define MVX_OK 0
 #define MVX_EINVAL (-1)   /* bad argument (null pointer, size, unsupported combination) */
 #define MVX_ESIZE (-2)    /* a size exceeds what the kernel supports */
@@ -320,7 +323,7 @@ int mvx_conv3d_forward_bg_split(const float *in, const void *wsplit, const float
                                 const uint8_t *out_mask, const float *bg_pre, int32_t border_active, void *stream);
 int mvx_conv3d_dgrad_tiles_split(const float *dz, const void *wsplit_dgrad, float *dx, int32_t din, int32_t dout,
                                  int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
-                                 const int32_t *dx_tile_flags, void *stream);
+                                 int32_t flags, const int32_t *dx_tile_flags, void *stream);
 size_t mvx_conv3d_wgrad_bg_split_workspace_bytes(int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout);
 int mvx_conv3d_wgrad_bg_split(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
                               int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, int32_t flags,
@@ -335,7 +338,8 @@ int mvx_conv3d_forward_bg_split_frames(const float *in, const void *wsplit, cons
                                        uint64_t *exec_stages, int32_t n_frames, void *stream);
 int mvx_conv3d_dgrad_tiles_split_frames(const float *dz, const void *wsplit_dgrad, float *dx, int32_t din, int32_t dout,
                                         int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
-                                        const int32_t *dx_tile_flags, uint64_t *exec_stages, int32_t n_frames, void *stream);
+                                        int32_t flags, const int32_t *dx_tile_flags, uint64_t *exec_stages, int32_t n_frames,
+                                        void *stream);
 size_t mvx_conv3d_wgrad_bg_split_workspace_bytes_frames(int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
                                                         int32_t n_frames);
 int mvx_conv3d_wgrad_bg_split_frames(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
@@ -349,10 +353,11 @@ int mvx_conv2d_forward_split_frames(const float *in, const void *wsplit, const f
                                     int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t flags, int32_t n_frames,
                                     void *stream);
 int mvx_conv2d_dgrad_split_frames(const float *dz, const void *wsplit_dgrad, float *dx, int32_t h, int32_t w, int32_t cin,
-                                  int32_t cout, int32_t n_frames, void *stream);
+                                  int32_t cout, int32_t flags, int32_t n_frames, void *stream);
 size_t mvx_conv2d_wgrad_split_workspace_bytes_frames(int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t n_frames);
 int mvx_conv2d_wgrad_split_frames(const float *in, const float *dz, float *dw3, int32_t h, int32_t w, int32_t cin,
-                                  int32_t cout, void *workspace, size_t workspace_bytes, int32_t n_frames, void *stream);
+                                  int32_t cout, int32_t flags, void *workspace, size_t workspace_bytes, int32_t n_frames,
+                                  void *stream);
 size_t mvx_bn_relu_backward_tiles_workspace_bytes(int32_t planes, int32_t h, int32_t w, int32_t channels);
 int mvx_bn_relu_backward_tiles(const float *dyhat, const float *y, const float *mean_inv, const float *c_bg,
                                const float *y_bg, const float *plane_grad_sums, const int32_t *tile_flags,
@@ -534,16 +539,22 @@ int mvx_sparse_conv_gather_dz(const float *dz, const int64_t *coords, int32_t n_
  * product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with f32 accumulation (per-product
  * relative error ~2e-5, i.e. fp32-grade for the 1e-4 feature bar; ~5x the rate of the exact-f32
  * MFMA).  Same arguments and layouts as the f32 entry points; weights are packed (and pre-split) by
- * mvx_conv3d_pack_weights_split (same byte size as mvx_conv3d_packed_weight_bytes).
+ * mvx_conv3d_pack_weights_split into mvx_conv3d_packed_weight_bytes_split(cout, cin, flags) bytes.
+ *
+ * "bf16x6" (MVX_FLAG_SPLIT3 in `flags` of the pack AND of every call that uses the pack): THREE pieces per operand
+ * (hi + mid + lo = the f32 value exactly) and the six products hh + hm + mh + hl + lh + mm; the dropped cross terms are
+ * below 2^-25 of a product, i.e. under its f32 rounding: fp32-GRADE accuracy (tests hold it to the bounds of the
+ * exact-f32 kernels) at 6/16 of the exact-f32 MFMA's matrix cycles.  Every `flags` below takes MVX_FLAG_SPLIT3.
  */
+size_t mvx_conv3d_packed_weight_bytes_split(int32_t cout, int32_t cin, int32_t flags);
 int mvx_conv3d_pack_weights_split(const float *w, void *wsplit, int32_t cout, int32_t cin, int32_t for_dgrad,
-                                  void *stream);
+                                  int32_t flags, void *stream);
 int mvx_conv3d_forward_split(const float *in, const void *wsplit, const float *bias, float *out, double *stats,
                              int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout,
                              int32_t stride_d, int32_t pad_d, int32_t flags, void *stream);
 int mvx_conv3d_dgrad_split(const float *dz, const void *wsplit_dgrad, float *dx, int32_t din, int32_t dout,
                            int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
-                           void *stream);
+                           int32_t flags, void *stream);
 int mvx_conv3d_wgrad_split(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
                            int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, int32_t flags,
                            void *workspace, size_t workspace_bytes, void *stream);

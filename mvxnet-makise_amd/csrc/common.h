@@ -28,9 +28,10 @@ static inline unsigned mvx_cdiv(long long a, long long b) { return (unsigned)((a
 struct FrameMap;
 int mvxi_linear_forward_split(const float *x, int ldx, const float *w, int ldw, const float *bias, float *y,
                               int ldy, double *stats, const float *row_w, long long rows, int k, int n, int relu,
-                              unsigned *fin_counter, double fin_eps, float *fin_mean_inv, const FrameMap &fm, hipStream_t st);
+                              unsigned *fin_counter, double fin_eps, float *fin_mean_inv, const FrameMap &fm, int pieces,
+                              hipStream_t st);
 int mvxi_linear_wgrad_split(const float *x, int ldx, const float *dz, int lddz, float *slabs, long long rows, int k, int n,
-                            long long rows_per_strip, long long strips, hipStream_t st);
+                            long long rows_per_strip, long long strips, int pieces, hipStream_t st);
 int mvxi_wgrad_step_list(const int32_t *in_halo_flags, int din, int dout, int ntiles, int stride_d, int pad_d, int *list,
                          int *count, hipStream_t st, int n_frames = 1);
 int mvxi_wgrad_rank1(const float *tap_sums, const float *c_in, float *dw, int din, int dout, int cin, int cout, int stride_d,

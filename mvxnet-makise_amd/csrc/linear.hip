@@ -432,7 +432,7 @@ static int linear_forward_impl(const float *x, int32_t ldx, const float *w, int3
     }
     if ((flags & MVX_FLAG_SPLIT) && vec && wide && splits == 1 && !w_transposed)    // bf16x3 arithmetic for the wide layers
         return mvxi_linear_forward_split(x, ldx, w, ldw, bias, y, ldy, stats, row_w, (long long)rows, k, n, relu, fin_counter,
-                                         fin_eps, fin_mean_inv, fm, st);
+                                         fin_eps, fin_mean_inv, fm, (flags & MVX_FLAG_SPLIT3) ? 3 : 2, st);
     const dim3 grid(mvx_cdiv(n, wide ? 128 : 64), mvx_cdiv(rows, BM), splits);
 #define MVX_LAUNCH_LIN(WT, NT, VEC)                                                                               \
     hipLaunchKernelGGL((linear_fwd<WT, NT, VEC>), grid, dim3(256), 0, st, x, ldx, w, ldw, bias, ydst, ld_dst, stats, \
@@ -517,7 +517,8 @@ extern "C" int mvx_linear_wgrad(const float *x, int32_t ldx, const float *dz, in
     const dim3 grid((unsigned)strips, mvx_cdiv(n, 128), mvx_cdiv(k, 128));
     if (vec && (flags & MVX_FLAG_SPLIT)) {
         // rows_per_strip is a multiple of the 32-row LDS step in both kernels (strip_rows)
-        int rc = mvxi_linear_wgrad_split(x, ldx, dz, lddz, (float *)workspace, (long long)rows, k, n, per, strips, st);
+        int rc = mvxi_linear_wgrad_split(x, ldx, dz, lddz, (float *)workspace, (long long)rows, k, n, per, strips,
+                                         (flags & MVX_FLAG_SPLIT3) ? 3 : 2, st);
         if (rc) return rc;
     } else if (vec)
         hipLaunchKernelGGL(linear_wgrad<true>, grid, dim3(256), 0, st, x, ldx, dz, lddz, (float *)workspace,

@@ -13,35 +13,25 @@
 // fragment reads of 32 consecutive rows spread over all banks).  Per 16-k step a wave reads 2 A and 8 B fragments for
 // 12 MFMAs.  The next chunk's global loads are issued before the current chunk's MFMAs (register prefetch).
 #include "common.h"
+#include "split_common.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int BM = 128, BNL = 128, BK = 64, ROWB = 2 * BK * 2 + 16, NT = 4;
+constexpr int BM = 128, BNL = 128, NT = 4;
 
-__device__ __forceinline__ void split4(const f32x4 v, uint2 *hi, uint2 *lo) {
-    unsigned short h[4], l[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const __bf16 hb = (__bf16)v[j];
-        const __bf16 lb = (__bf16)(v[j] - (float)hb);
-        h[j] = __builtin_bit_cast(unsigned short, hb);
-        l[j] = __builtin_bit_cast(unsigned short, lb);
-    }
-    hi->x = (unsigned)h[0] | ((unsigned)h[1] << 16); hi->y = (unsigned)h[2] | ((unsigned)h[3] << 16);
-    lo->x = (unsigned)l[0] | ((unsigned)l[1] << 16); lo->y = (unsigned)l[2] | ((unsigned)l[3] << 16);
-}
-
+// NP pieces per operand; K in chunks of BK (64 for bf16x3, 32 for bf16x6: 61 KB of LDS either way, two workgroups per CU)
+template <int NP, int BK>
 __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restrict__ x, int ldx, const float *__restrict__ w,
                                                         int ldw, const float *__restrict__ bias, float *__restrict__ y,
                                                         int ldy, double *__restrict__ stats, const float *__restrict__ row_w,
                                                         long long R, int K, int N, int relu,
                                                         unsigned *__restrict__ done_counter, double fin_eps,
                                                         float *__restrict__ fin_mean_inv, FrameMap fm) {
-    constexpr int XV = BM * BK / 4 / 256;          // float4 per thread for the x tile (8)
-    constexpr int WV = BNL * BK / 4 / 256;         // ... and for the w tile (8)
+    constexpr int ROWB = NP * BK * 2 + 16;         // LDS row: NP pieces of BK bf16 + 16 B pad (an odd number of 16-byte slots)
+    constexpr int PQ = BK / 4;                     // float4 per row and chunk
+    constexpr int XV = BM * BK / 4 / 256;          // float4 per thread for the x tile
+    constexpr int WV = BNL * BK / 4 / 256;         // ... and for the w tile
     __shared__ __attribute__((aligned(16))) unsigned char s_x[BM * ROWB];
     __shared__ __attribute__((aligned(16))) unsigned char s_w[BNL * ROWB];
     __shared__ double s_red[4][2 * BNL];
@@ -62,7 +52,7 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
     auto load_tiles = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < XV; ++u) {
-            const int c = tid + 256 * u, r = c >> 4, part = c & 15;
+            const int c = tid + 256 * u, r = c / PQ, part = c % PQ;
             const long long gr = r0 + r;
             const bool ok = gr < R && k0 + part * 4 < K;
             xr[u] = *(const f32x4 *)(ok ? x + gr * ldx + k0 + part * 4 : x);
@@ -70,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
 #pragma unroll
         for (int u = 0; u < WV; ++u) {
             const int c = tid + 256 * u;
-            const int n = c >> 4, part = c & 15;
+            const int n = c / PQ, part = c % PQ;
             const bool ok = n0 + n < N && k0 + part * 4 < K;
             wr[u] = *(const f32x4 *)(ok ? w + (long long)(n0 + n) * ldw + k0 + part * 4 : w);
         }
@@ -79,28 +69,28 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
         const bool tail = k0 + BK > K;
 #pragma unroll
         for (int u = 0; u < XV; ++u) {
-            const int c = tid + 256 * u, r = c >> 4, part = c & 15;
+            const int c = tid + 256 * u, r = c / PQ, part = c % PQ;
             f32x4 v = xr[u];
             if (tail && k0 + part * 4 >= K) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            uint2 hi, lo;
-            split4(v, &hi, &lo);
-            *(uint2 *)(s_x + r * ROWB + part * 8) = hi;
-            *(uint2 *)(s_x + r * ROWB + 2 * BK + part * 8) = lo;
+            uint2 pc[NP];
+            split_n<NP>(v[0], v[1], v[2], v[3], pc);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *(uint2 *)(s_x + r * ROWB + q * 2 * BK + part * 8) = pc[q];
         }
 #pragma unroll
         for (int u = 0; u < WV; ++u) {
             const int c = tid + 256 * u;
             f32x4 v = wr[u];
-            const int n = c >> 4, part = c & 15;
+            const int n = c / PQ, part = c % PQ;
             if (tail) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (k0 + part * 4 + j >= K) v[j] = 0.f;
             }
-            uint2 hi, lo;
-            split4(v, &hi, &lo);
-            *(uint2 *)(s_w + n * ROWB + part * 8) = hi;
-            *(uint2 *)(s_w + n * ROWB + 2 * BK + part * 8) = lo;
+            uint2 pc[NP];
+            split_n<NP>(v[0], v[1], v[2], v[3], pc);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *(uint2 *)(s_w + n * ROWB + q * 2 * BK + part * 8) = pc[q];
         }
     };
 
@@ -112,15 +102,18 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
         if (k0 + BK < K) load_tiles(k0 + BK);
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_x + a_base + s * 32));
-            const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_x + a_base + 2 * BK + s * 32));
+            bf16x8 av[NP];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_w + b_base + t * 32 * ROWB + s * 32));
-                const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_w + b_base + t * 32 * ROWB + 2 * BK + s * 32));
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+            for (int q = 0; q < NP; ++q) av[q] = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_x + a_base + q * 2 * BK + s * 32));
+#pragma unroll
+            for (int t = 0; t < NT; t += 2) {
+                bf16x8 b0[NP], b1[NP];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    b0[q] = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_w + b_base + t * 32 * ROWB + q * 2 * BK + s * 32));
+                    b1[q] = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_w + b_base + (t + 1) * 32 * ROWB + q * 2 * BK + s * 32));
+                }
+                split_mac2<NP>(acc[t], acc[t + 1], av, b0, b1);
             }
         }
     }
@@ -232,11 +225,12 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned short *row0, const unsi
     return __builtin_bit_cast(bf16x8, v);
 }
 
+template <int NP>
 __global__ __launch_bounds__(256) void linear_wgrad_split(const float *__restrict__ x, int ldx, const float *__restrict__ dz,
                                                           int lddz, float *__restrict__ slabs, long long R, int K, int N,
                                                           long long rows_per_strip) {
-    __shared__ __attribute__((aligned(16))) unsigned short s_zh[4][WRS][32], s_zl[4][WRS][32];
-    __shared__ __attribute__((aligned(16))) unsigned short s_xh[4][WRS][32], s_xl[4][WRS][32];
+    __shared__ __attribute__((aligned(16))) unsigned short s_z[NP][4][WRS][32];      // [piece][32-column block][row][column]
+    __shared__ __attribute__((aligned(16))) unsigned short s_x[NP][4][WRS][32];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int wn = wv >> 1, wk = wv & 1;
     const int n0 = blockIdx.y * 128, k0 = blockIdx.z * 128;
@@ -271,13 +265,13 @@ __global__ __launch_bounds__(256) void linear_wgrad_split(const float *__restric
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int c = tid + 256 * u, r = c >> 5, part = c & 31;
-            uint2 hi, lo;
-            split4(zr[u], &hi, &lo);
-            *(uint2 *)(&s_zh[part >> 3][r][(part & 7) * 4]) = hi;
-            *(uint2 *)(&s_zl[part >> 3][r][(part & 7) * 4]) = lo;
-            split4(xr[u], &hi, &lo);
-            *(uint2 *)(&s_xh[part >> 3][r][(part & 7) * 4]) = hi;
-            *(uint2 *)(&s_xl[part >> 3][r][(part & 7) * 4]) = lo;
+            uint2 pc[NP];
+            split_n<NP>(zr[u][0], zr[u][1], zr[u][2], zr[u][3], pc);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *(uint2 *)(&s_z[p][part >> 3][r][(part & 7) * 4]) = pc[p];
+            split_n<NP>(xr[u][0], xr[u][1], xr[u][2], xr[u][3], pc);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *(uint2 *)(&s_x[p][part >> 3][r][(part & 7) * 4]) = pc[p];
         }
         __syncthreads();
         if (rr + WRS < rend) load_tiles(rr + WRS);
@@ -285,22 +279,16 @@ __global__ __launch_bounds__(256) void linear_wgrad_split(const float *__restric
 #pragma unroll
             for (int ks = 0; ks < WRS / 16; ++ks) {
                 const int r0 = ks * 16 + kbase + q, r1 = r0 + 4;
-                bf16x8 ah[2], al[2], bh[2], bl[2];
+                bf16x8 az[2][NP], bx[2][NP];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    ah[t] = tr_frag(&s_zh[wn * 2 + t][r0][pcol], &s_zh[wn * 2 + t][r1][pcol]);
-                    al[t] = tr_frag(&s_zl[wn * 2 + t][r0][pcol], &s_zl[wn * 2 + t][r1][pcol]);
-                    bh[t] = tr_frag(&s_xh[wk * 2 + t][r0][pcol], &s_xh[wk * 2 + t][r1][pcol]);
-                    bl[t] = tr_frag(&s_xl[wk * 2 + t][r0][pcol], &s_xl[wk * 2 + t][r1][pcol]);
-                }
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                    for (int p = 0; p < NP; ++p) {
+                        az[t][p] = tr_frag(&s_z[p][wn * 2 + t][r0][pcol], &s_z[p][wn * 2 + t][r1][pcol]);
+                        bx[t][p] = tr_frag(&s_x[p][wk * 2 + t][r0][pcol], &s_x[p][wk * 2 + t][r1][pcol]);
                     }
+#pragma unroll
+                for (int a = 0; a < 2; ++a) split_mac2<NP>(acc[a][0], acc[a][1], az[a], bx[0], bx[1]);
             }
         }
     }
@@ -323,9 +311,12 @@ __global__ __launch_bounds__(256) void linear_wgrad_split(const float *__restric
 
 // Launched by linear.hip (mvx_linear_wgrad) when MVX_FLAG_SPLIT is set and the operands are 16-byte aligned.
 int mvxi_linear_wgrad_split(const float *x, int ldx, const float *dz, int lddz, float *slabs, long long rows, int k, int n,
-                            long long rows_per_strip, long long strips, hipStream_t st) {
+                            long long rows_per_strip, long long strips, int pieces, hipStream_t st) {
     const dim3 grid((unsigned)strips, mvx_cdiv(n, 128), mvx_cdiv(k, 128));
-    hipLaunchKernelGGL(linear_wgrad_split, grid, dim3(256), 0, st, x, ldx, dz, lddz, slabs, rows, k, n, rows_per_strip);
+    if (pieces == 3)
+        hipLaunchKernelGGL(linear_wgrad_split<3>, grid, dim3(256), 0, st, x, ldx, dz, lddz, slabs, rows, k, n, rows_per_strip);
+    else
+        hipLaunchKernelGGL(linear_wgrad_split<2>, grid, dim3(256), 0, st, x, ldx, dz, lddz, slabs, rows, k, n, rows_per_strip);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -333,10 +324,15 @@ int mvxi_linear_wgrad_split(const float *x, int ldx, const float *dz, int lddz, 
 // Launched by linear.hip (linear_forward_impl) when MVX_FLAG_SPLIT is set and the shape qualifies.
 int mvxi_linear_forward_split(const float *x, int ldx, const float *w, int ldw, const float *bias, float *y,
                               int ldy, double *stats, const float *row_w, long long rows, int k, int n, int relu,
-                              unsigned *fin_counter, double fin_eps, float *fin_mean_inv, const FrameMap &fm, hipStream_t st) {
+                              unsigned *fin_counter, double fin_eps, float *fin_mean_inv, const FrameMap &fm, int pieces,
+                              hipStream_t st) {
     const dim3 grid(mvx_cdiv(n, BNL), mvx_cdiv(rows, BM));
-    hipLaunchKernelGGL(linear_fwd_split, grid, dim3(256), 0, st, x, ldx, w, ldw, bias, y, ldy, stats, row_w, rows, k, n, relu,
-                       fin_counter, fin_eps, fin_mean_inv, fm);
+    if (pieces == 3)
+        hipLaunchKernelGGL((linear_fwd_split<3, 32>), grid, dim3(256), 0, st, x, ldx, w, ldw, bias, y, ldy, stats, row_w, rows, k, n,
+                           relu, fin_counter, fin_eps, fin_mean_inv, fm);
+    else
+        hipLaunchKernelGGL((linear_fwd_split<2, 64>), grid, dim3(256), 0, st, x, ldx, w, ldw, bias, y, ldy, stats, row_w, rows, k, n,
+                           relu, fin_counter, fin_eps, fin_mean_inv, fm);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

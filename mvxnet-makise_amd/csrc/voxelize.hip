@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void vox_gather(const float *__restrict__ pcd,
 
 }  // namespace
 
-extern "C" int mvx_abi_version(void) { return 4; }
+extern "C" int mvx_abi_version(void) { return 5; }
 
 // Diagnostics: kernel launches issued through the library since it was loaded (the only process-wide state it keeps;
 // hipMemsetAsync fills are not counted).  bench.py reports the difference over the timed steps.

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MVX_HIP_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'libmvx_hip.so'))
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _p = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -73,9 +73,10 @@ PROTOTYPES = {
     'mvx_conv3d_pack_weights': (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     'mvx_conv3d_tile_shape': (None, [_p, _p]),
     'mvx_conv3d_forward': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
-    'mvx_conv3d_pack_weights_split': (_i32, [_p, _p, _i32, _i32, _i32, _p]),
+    'mvx_conv3d_packed_weight_bytes_split': (_sz, [_i32, _i32, _i32]),
+    'mvx_conv3d_pack_weights_split': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p]),
     'mvx_conv3d_forward_split': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
-    'mvx_conv3d_dgrad_split': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    'mvx_conv3d_dgrad_split': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_conv3d_wgrad_split': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _sz, _p]),
     'mvx_conv3d_dgrad': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     'mvx_conv3d_wgrad_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32]),
@@ -90,19 +91,19 @@ PROTOTYPES = {
     'mvx_conv3d_wgrad_bg': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
     'mvx_conv3d_forward_bg_split': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p,
                                            _i32, _p]),
-    'mvx_conv3d_dgrad_tiles_split': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
+    'mvx_conv3d_dgrad_tiles_split': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     'mvx_conv3d_wgrad_bg_split_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32, _i32]),
     'mvx_conv3d_wgrad_bg_split': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
     'mvx_conv3d_forward_bg_split_frames': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p,
                                                   _p, _i32, _p, _i32, _p]),
-    'mvx_conv3d_dgrad_tiles_split_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _i32, _p]),
+    'mvx_conv3d_dgrad_tiles_split_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _i32, _p]),
     'mvx_conv3d_wgrad_bg_split_workspace_bytes_frames': (_sz, [_i32, _i32, _i32, _i32, _i32, _i32]),
     'mvx_conv3d_wgrad_bg_split_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _sz,
                                                 _i32, _p]),
     'mvx_conv2d_forward_split_frames': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
-    'mvx_conv2d_dgrad_split_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    'mvx_conv2d_dgrad_split_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_conv2d_wgrad_split_workspace_bytes_frames': (_sz, [_i32, _i32, _i32, _i32, _i32]),
-    'mvx_conv2d_wgrad_split_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _p, _sz, _i32, _p]),
+    'mvx_conv2d_wgrad_split_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _sz, _i32, _p]),
     'mvx_plane_tap_sums_workspace_bytes': (_sz, [_i32, _i32]),
     'mvx_plane_tap_sums': (_i32, [_p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
     'mvx_tile_dilate_flags': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),

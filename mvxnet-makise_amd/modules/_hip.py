@@ -13,6 +13,24 @@ _ws_cache = {}
 STATS_REPLICAS = 32      # MVX_STATS_REPLICAS of include/mvx_hip.h
 FLAG_RELU, FLAG_PREZEROED, FLAG_ACCUMULATE, FLAG_CONV2D = 1, 2, 4, 8      # MVX_FLAG_* of include/mvx_hip.h
 FLAG_SPLIT = 64                                                          # MVX_FLAG_SPLIT: bf16x3 arithmetic of the wide row GEMMs
+FLAG_SPLIT3 = 128                                                        # MVX_FLAG_SPLIT3: three bf16 pieces per operand (bf16x6, fp32-grade)
+
+
+def split_flags(split, row=False):
+    """``split``: 0 / False = exact-f32 MFMA, 2 / True = bf16x3, 3 = bf16x6 -> the flag bits of a call (row GEMMs also need
+    MVX_FLAG_SPLIT; the *_split convolution entry points only look at MVX_FLAG_SPLIT3)."""
+    if not split:
+        return 0
+    return (FLAG_SPLIT if row else 0) | (FLAG_SPLIT3 if int(split) == 3 else 0)
+
+
+def split_pieces():
+    """convmath of config.yml -> 0 (f32: exact-f32 MFMA), 2 (bf16x3) or 3 (bf16x6)."""
+    import modules.config as cfg
+    m = cfg.config.get('convmath', 'f32')
+    if m not in ('f32', 'bf16x3', 'bf16x6'):
+        raise X.MvxHipError('convmath must be f32, bf16x3 or bf16x6, not %r' % (m,))
+    return {'f32': 0, 'bf16x3': 2, 'bf16x6': 3}[m]
 FLAG_BG_TAPS = 32
 
 # When True, the backward of the hot-path layers adds weight / bias gradients straight into the existing
@@ -416,10 +434,15 @@ def conv3d_pack(weight, for_dgrad, split=False):
     two_d = tuple(weight.shape[2:]) == (3, 3)
     assert two_d or tuple(weight.shape[2:]) == (3, 3, 3)
     assert not (two_d and split)
+    if split:
+        sf = split_flags(split)
+        wpk = torch.empty((X.lib.mvx_conv3d_packed_weight_bytes_split(cout, cin, sf) // 2,), dtype=torch.int16, device=weight.device)
+        X.check(X.lib.mvx_conv3d_pack_weights_split(X.ptr(weight.contiguous()), X.ptr(wpk), cout, cin, int(for_dgrad), sf, X.stream()),
+                'mvx_conv3d_pack_weights_split')
+        return wpk
     wpk = torch.empty((27 * cout * cin,), dtype=torch.float32, device=weight.device)
-    fn = X.lib.mvx_conv3d_pack_weights_split if split else X.lib.mvx_conv3d_pack_weights
-    X.check(fn(X.ptr(weight.contiguous()), X.ptr(wpk), cout, cin, int(for_dgrad) | (2 if two_d else 0), X.stream()),
-            'mvx_conv3d_pack_weights')
+    X.check(X.lib.mvx_conv3d_pack_weights(X.ptr(weight.contiguous()), X.ptr(wpk), cout, cin, int(for_dgrad) | (2 if two_d else 0),
+                                          X.stream()), 'mvx_conv3d_pack_weights')
     return wpk
 
 
@@ -433,7 +456,7 @@ def conv3d_forward(x, wpk, bias, cout, sd, pd, relu=True, want_stats=True, split
     dout = conv_out_depth(din, sd, pd)
     out = torch.empty((dout, H, W, cout), dtype=torch.float32, device=x.device)
     stats, fz = _acc_f64((STATS_REPLICAS, 2, cout), x.device) if want_stats else (None, 0)
-    flags = (FLAG_RELU if relu else 0) | fz
+    flags = (FLAG_RELU if relu else 0) | fz | split_flags(split)
     if split:
         with _Timed('conv3d_gather_split', conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None else 0):
             X.check(X.lib.mvx_conv3d_forward_split(X.ptr(x), X.ptr(wpk), X.ptr(bias), X.ptr(out), X.ptr(stats), din, dout,
@@ -453,7 +476,7 @@ def conv3d_dgrad(dz, wpk_d, din, cin, sd, pd, split=False):
     if split:
         with _Timed('conv3d_gather_split', conv_flops(din, dout, H, W, cout, cin, sd, pd, True) if KERNEL_TIMERS is not None else 0):
             X.check(X.lib.mvx_conv3d_dgrad_split(X.ptr(dz), X.ptr(wpk_d), X.ptr(dx), din, dout, H, W, cin, cout, sd, pd,
-                                                 X.stream()), 'mvx_conv3d_dgrad_split')
+                                                 split_flags(split), X.stream()), 'mvx_conv3d_dgrad_split')
         return dx
     with _Timed('conv3d_gather', conv_flops(din, dout, H, W, cout, cin, sd, pd, True) if KERNEL_TIMERS is not None else 0):
         X.check(X.lib.mvx_conv3d_dgrad(X.ptr(dz), X.ptr(wpk_d), X.ptr(dx), din, dout, H, W, cin, cout, sd, pd,
@@ -474,6 +497,7 @@ def conv3d_wgrad(x, dz, sd, pd, split=False, accumulate_into=None, two_d=False):
     if two_d:
         assert not split and din == 1 and dout == 1 and pd == 1
         flags |= FLAG_CONV2D
+    flags |= split_flags(split)
     nbytes = X.lib.mvx_conv3d_wgrad_workspace_bytes(H, W, cin, cout)
     fn, name = (X.lib.mvx_conv3d_wgrad_split, 'conv3d_wgrad_split') if split else (X.lib.mvx_conv3d_wgrad, 'conv3d_wgrad')
     with _wgrad_scope(accumulate_into, x, dz) as scope:
@@ -572,7 +596,7 @@ def conv3d_dgrad_tiles(dz, wpk_d, din, cin, sd, pd, tflag, split=False):
     if split:
         with _Timed('conv3d_gather_split', 0):
             X.check(X.lib.mvx_conv3d_dgrad_tiles_split(X.ptr(dz), X.ptr(wpk_d), X.ptr(dx), din, dout, H, W, cin, cout, sd, pd,
-                                                       X.ptr(tflag), X.stream()), 'mvx_conv3d_dgrad_tiles_split')
+                                                       split_flags(split), X.ptr(tflag), X.stream()), 'mvx_conv3d_dgrad_tiles_split')
         return dx
     global EXEC_STAGES
     counter = None
@@ -616,7 +640,7 @@ def conv3d_forward_bg(x, wpk, bias, cout, sd, pd, bg_in, out_mask, bg_pre, relu=
     dout = conv_out_depth(din, sd, pd)
     out = torch.empty((dout, H, W, cout), dtype=torch.float32, device=x.device)
     stats, fz = _acc_f64((STATS_REPLICAS, 2, cout), x.device) if want_stats else (None, 0)
-    flags = (FLAG_RELU if relu else 0) | fz
+    flags = (FLAG_RELU if relu else 0) | fz | split_flags(split)
     if split:
         with _Timed('conv3d_gather_split', conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None else 0):
             X.check(X.lib.mvx_conv3d_forward_bg_split(X.ptr(x), X.ptr(wpk), X.ptr(bias), X.ptr(out), X.ptr(stats), din, dout,
@@ -651,6 +675,7 @@ def conv3d_wgrad_bg(x, dz, sd, pd, bg_in, tap_sums=None, accumulate_into=None, s
         dw, flags = accumulate_into, FLAG_ACCUMULATE
     else:
         dw, flags = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device=x.device), 0
+    flags |= split_flags(split)
     fn_bytes = X.lib.mvx_conv3d_wgrad_bg_split_workspace_bytes if split else X.lib.mvx_conv3d_wgrad_bg_workspace_bytes
     fn = X.lib.mvx_conv3d_wgrad_bg_split if split else X.lib.mvx_conv3d_wgrad_bg
     nbytes = fn_bytes(dout, H, W, cin, cout)
@@ -708,6 +733,8 @@ def _work_counter(device):
 
 
 ROW_SPLIT = tuple(k for k in os.environ.get('MVX_ROW_SPLIT', 'dgrad,wgrad,rpn').split(',') if k)
+# ... and under convmath: bf16x6 (fp32-grade arithmetic: every wide row GEMM may use it)
+ROW_SPLIT6 = tuple(k for k in os.environ.get('MVX_ROW_SPLIT6', 'fusion,vfe,conv1,rpn,dgrad,wgrad').split(',') if k)
 
 
 def row_split(tag):
@@ -733,9 +760,16 @@ def row_split(tag):
     i.e. the 768 -> 768 layer, the only one whose speed matters (81 % of the row-GEMM flops of a step, +5 % frames/s), is
     also the one that costs a factor 3-4 in accuracy of every later map: it stays on the exact-f32 kernel unless
     MVX_ROW_SPLIT asks otherwise.  The weight-gradient GEMMs ('wgrad', linear_wgrad_split: 0.955 -> 0.517 ms for the
-    768 x 768 layer over 80 k rows) touch no forward map and are split by default: hot 443 -> 470, full 200 -> 210 frames/s."""
-    import modules.config as cfg
-    return cfg.config.get('convmath', 'f32') == 'bf16x3' and any(tag.startswith(k) for k in ROW_SPLIT)
+    768 x 768 layer over 80 k rows) touch no forward map and are split by default: hot 443 -> 470, full 200 -> 210 frames/s.
+
+    Returns the number of bf16 pieces (0 = exact-f32 kernel, 2 = bf16x3, 3 = bf16x6).  Under ``convmath: bf16x6`` the split is
+    fp32-grade (three pieces = the whole f32 mantissa), so every tag of ROW_SPLIT6 -- by default all of them -- uses it."""
+    np_ = split_pieces()
+    if np_ == 2:
+        return 2 if any(tag.startswith(k) for k in ROW_SPLIT) else 0
+    if np_ == 3:
+        return 3 if any(tag.startswith(k) for k in ROW_SPLIT6) else 0
+    return 0
 
 
 def transposed_weight(w2):
@@ -759,7 +793,7 @@ def rows_dgrad(dz, w2, label='linear_dgrad'):
     """dx = dz w2 of a row layer with weight (N, K): in bf16x3 arithmetic (``row_split('dgrad')``) through the cached
     transposed copy, otherwise through the f32 kernel's transposed-weight read."""
     if row_split('dgrad'):
-        dx, _ = linear_forward(dz, transposed_weight(w2), None, relu=False, want_stats=False, label=label, split=True)
+        dx, _ = linear_forward(dz, transposed_weight(w2), None, relu=False, want_stats=False, label=label, split=row_split('dgrad'))
     else:
         dx, _ = linear_forward(dz, w2, None, relu=False, want_stats=False, w_transposed=True, label=label)
     return dx
@@ -783,7 +817,7 @@ def linear_forward(x, w, bias, relu=True, want_stats=True, w_transposed=False, r
         mi = torch.empty((2, N), dtype=torch.float32, device=x.device)
         X.check(X.lib.mvx_linear_forward_bn(_vptr(x), _ld(x), _vptr(w), _ld(w), int(w_transposed), X.ptr(bias),
                                             _vptr(out), _ld(out), X.ptr(stats), X.ptr(row_w), R, K, N,
-                                            (FLAG_RELU if relu else 0) | fz | (FLAG_SPLIT if split else 0), X.ptr(counter), float(finalize[0]),
+                                            (FLAG_RELU if relu else 0) | fz | split_flags(split, True), X.ptr(counter), float(finalize[0]),
                                             float(finalize[1]), X.ptr(mi), X.stream()), 'mvx_linear_forward_bn')
         return out, mi
     ws = None
@@ -792,7 +826,7 @@ def linear_forward(x, w, bias, relu=True, want_stats=True, w_transposed=False, r
     with _Timed(label or ('linear_dgrad' if w_transposed else 'linear_fwd'), 2.0 * R * K * N if KERNEL_TIMERS is not None else 0):
         X.check(X.lib.mvx_linear_forward(_vptr(x), _ld(x), _vptr(w), _ld(w), int(w_transposed), X.ptr(bias),
                                          _vptr(out), _ld(out), X.ptr(stats), X.ptr(row_w), R, K, N,
-                                         (FLAG_RELU if relu else 0) | fz | (FLAG_SPLIT if split else 0),
+                                         (FLAG_RELU if relu else 0) | fz | split_flags(split, True),
                                          X.ptr(ws), ws.numel() if ws is not None else 0, X.stream()), 'mvx_linear_forward')
     if finalize is not None and want_stats:      # empty input: no launch happened, finalise the (zero) sums separately
         return out, bn_finalize(stats, finalize[0], finalize[1])
@@ -809,8 +843,7 @@ def linear_wgrad(x, dz, accumulate_into=None, split=None):
         dw, flags = accumulate_into, FLAG_ACCUMULATE
     else:
         dw, flags = torch.empty((N, K), dtype=torch.float32, device=x.device), 0
-    if row_split('wgrad') if split is None else split:
-        flags |= FLAG_SPLIT
+    flags |= split_flags(row_split('wgrad') if split is None else split, True)
     nbytes = X.lib.mvx_linear_wgrad_workspace_bytes(R, K, N)
     with _wgrad_scope(accumulate_into, x, dz) as scope:
         ws = workspace(nbytes, x.device, 'lwgrad_side' if isinstance(scope, _SideStream) else 'lwgrad')

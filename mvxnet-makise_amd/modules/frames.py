@@ -106,7 +106,7 @@ def linear_bn(x, w, b, fs, kind, row_w, eps, tag='fusion'):
     mi = torch.empty((fs.F, 2, N), dtype=torch.float32, device=x.device)
     if 'lin_fwd' in KNOCKOUT:
         return y, mi
-    sp = _hip.FLAG_SPLIT if _hip.row_split(tag) else 0        # convmath bf16x3: the wide layers on the split-MFMA row GEMM
+    sp = _hip.split_flags(_hip.row_split(tag), True)        # convmath bf16x3 / bf16x6: the wide layers on the split-MFMA row GEMM
     with _hip._Timed('linear_fwd', 2.0 * Rr * K * N if _hip.KERNEL_TIMERS is not None else 0):
         X.check(X.lib.mvx_linear_forward_bn_frames(_hip._vptr(x), _hip._ld(x), _hip._vptr(w2), _hip._ld(w2), 0, X.ptr(b),
                                                    _hip._vptr(y), _hip._ld(y), X.ptr(stats), X.ptr(row_w), Rr, K, N,
@@ -380,7 +380,7 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
             with _hip._Timed('conv3d_gather_bg', F * _hip.conv_flops(dout, din, H, W, ci, co, sd, pd) if _hip.KERNEL_TIMERS is not None else 0):
                 X.check(X.lib.mvx_conv3d_forward_bg_split_frames(X.ptr(x_in), X.ptr(wpk), X.ptr(b), X.ptr(y), X.ptr(stats), din, dout,
                                                                  H, W, ci, co, sd, pd,
-                                                                 _hip.FLAG_RELU | fz | (_hip.FLAG_BG_TAPS if TAP_SKIP else 0),
+                                                                 _hip.FLAG_RELU | fz | (_hip.FLAG_BG_TAPS if TAP_SKIP else 0) | _hip.split_flags(split),
                                                                  X.ptr(hflag_in), X.ptr(mask_o), X.ptr(bg_pre), 1, X.ptr(counter), F,
                                                                  X.stream()),
                         'mvx_conv3d_forward_bg_split_frames')
@@ -452,8 +452,8 @@ def _wgrad_bg(rec, dz, tap_sums, F, H, W):
             ws = _hip.workspace(nbytes, x.device, 'wgrad_bg_side')
             with _hip._Timed('conv3d_wgrad_bg', fl):
                 X.check(X.lib.mvx_conv3d_wgrad_bg_split_frames(X.ptr(x), X.ptr(dz), X.ptr(dw), rec['din'], rec['dout'], H, W, ci, co,
-                                                               rec['sd'], rec['pd'], _hip.FLAG_ACCUMULATE, X.ptr(rec['hflag_in']),
-                                                               X.ptr(rec['c_in']), X.ptr(tap_sums), X.ptr(ws), ws.numel(), F,
+                                                               rec['sd'], rec['pd'], _hip.FLAG_ACCUMULATE | _hip.split_flags(rec['split']),
+                                                               X.ptr(rec['hflag_in']), X.ptr(rec['c_in']), X.ptr(tap_sums), X.ptr(ws), ws.numel(), F,
                                                                X.stream()), 'mvx_conv3d_wgrad_bg_split_frames')
         return
     with _hip._SideStream(x, dz, tap_sums, rec['c_in'], rec['hflag_in']):
@@ -522,7 +522,7 @@ def cml_backward(model, S, grad_mid, g_cl=None):
         w = rec['w']
         co, ci = w.shape[0], w.shape[1]
         dx = torch.empty((F * rec['din'], H, W, ci), dtype=torch.float32, device=dev)
-        wpd = rec['m']._packer(True, bool(rec.get('split')))
+        wpd = rec['m']._packer(True, rec.get('split') or 0)
         counter = None
         if _hip.KERNEL_TIMERS is not None:
             if _hip.EXEC_STAGES is None:
@@ -532,8 +532,8 @@ def cml_backward(model, S, grad_mid, g_cl=None):
             with _hip._Timed('conv3d_gather_tiles', F * _hip.conv_flops(rec['din'], rec['dout'], H, W, co, ci, rec['sd'], rec['pd'], True)
                              if _hip.KERNEL_TIMERS is not None else 0):
                 X.check(X.lib.mvx_conv3d_dgrad_tiles_split_frames(X.ptr(dz), X.ptr(wpd), X.ptr(dx), rec['din'], rec['dout'], H, W, ci,
-                                                                  co, rec['sd'], rec['pd'], X.ptr(bflag), X.ptr(counter), F,
-                                                                  X.stream()), 'mvx_conv3d_dgrad_tiles_split_frames')
+                                                                  co, rec['sd'], rec['pd'], _hip.split_flags(rec['split']), X.ptr(bflag),
+                                                                  X.ptr(counter), F, X.stream()), 'mvx_conv3d_dgrad_tiles_split_frames')
             return dx
         if 'gather_dgrad' in KNOCKOUT:
             return dx

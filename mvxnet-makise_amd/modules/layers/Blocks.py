@@ -71,10 +71,10 @@ class FCN(nn.Module):
 
 
 def conv_split_math():
-    """True -> dense convolutions run on the bf16 matrix cores with the hi/lo split ("bf16x3",
-    fp32-grade accuracy, csrc/conv3d_split.hip); False -> exact-f32 MFMA (csrc/conv3d.hip).
-    Selected by ``convmath`` in config.yml / cfg.config (default f32)."""
-    return cfg.config.get('convmath', 'f32') == 'bf16x3'
+    """Number of bf16 pieces per operand of the dense convolutions: 0 -> exact-f32 MFMA (csrc/conv3d.hip); 2 -> hi/lo split
+    ("bf16x3": three bf16 MFMAs per product, ~2e-5 per product); 3 -> hi/mid/lo ("bf16x6": six MFMAs, fp32-grade)
+    (csrc/conv3d_split.hip).  Selected by ``convmath`` in config.yml / cfg.config (default f32)."""
+    return _hip.split_pieces()
 
 
 class PackedWeights:

@@ -30,8 +30,9 @@ TAPS2 = 16          # MVX_FLAG_TAPS2
 
 
 def _split():
-    """convmath: bf16x3 -> the 3x3 convolutions run on the split-MFMA kernels (csrc/conv3d_split.hip)."""
-    return cfg.config.get('convmath', 'f32') == 'bf16x3'
+    """convmath: bf16x3 / bf16x6 -> the 3x3 convolutions run on the split-MFMA kernels (csrc/conv3d_split.hip): the number of
+    bf16 pieces per operand (0 = exact-f32 kernels)."""
+    return _hip.split_pieces()
 
 
 _GRAD_TARGETS = None        # id(parameter) -> tensor the gradient is ADDED into instead of .grad (the autograd wrapper)
@@ -120,7 +121,7 @@ class _Packs:
             if split:                      # bf16x3: the 2-D kernel as the middle depth slice of a 3-D one, hi/lo split pack
                 w3 = torch.zeros(w2.shape[:2] + (3, 3, 3), dtype=torch.float32, device=w2.device)
                 w3[:, :, 1] = w2
-                hit = (tag, _hip.conv3d_pack(w3, for_dgrad, split=True))
+                hit = (tag, _hip.conv3d_pack(w3, for_dgrad, split=split))
             else:
                 hit = (tag, _hip.conv3d_pack(w2, for_dgrad))
             self.cache[(key, for_dgrad, split)] = hit
@@ -151,7 +152,7 @@ def _conv(x, wpk, bias, F, h, w, cin, cout, flags, eps):
     if _split():                               # all nine taps of the rearranged stride-2 kernels are executed here
         with _hip._Timed('rpn_conv', 2.0 * F * h * w * cin * cout * 9 if _hip.KERNEL_TIMERS is not None else 0):
             X.check(X.lib.mvx_conv2d_forward_split_frames(X.ptr(x), X.ptr(wpk), X.ptr(bias), X.ptr(y), X.ptr(stats), h, w, cin, cout,
-                                                          _hip.FLAG_RELU | fz, F, X.stream()), 'mvx_conv2d_forward_split_frames')
+                                                          _hip.FLAG_RELU | fz | _hip.split_flags(_split()), F, X.stream()), 'mvx_conv2d_forward_split_frames')
         X.check(X.lib.mvx_bn_finalize_frames(X.ptr(stats), float(h * w), float(eps), X.ptr(mi), cout, F, X.stream()),
                 'mvx_bn_finalize_frames')
         return y, mi
@@ -185,7 +186,7 @@ def _dgrad(dz, wpd, F, h, w, cin, cout, flags):
     dx = torch.empty((F, h, w, cin), dtype=torch.float32, device=dz.device)
     if _split():
         with _hip._Timed('rpn_conv', 2.0 * F * h * w * cin * cout * 9 if _hip.KERNEL_TIMERS is not None else 0):
-            X.check(X.lib.mvx_conv2d_dgrad_split_frames(X.ptr(dz), X.ptr(wpd), X.ptr(dx), h, w, cin, cout, F, X.stream()),
+            X.check(X.lib.mvx_conv2d_dgrad_split_frames(X.ptr(dz), X.ptr(wpd), X.ptr(dx), h, w, cin, cout, _hip.split_flags(_split()), F, X.stream()),
                     'mvx_conv2d_dgrad_split_frames')
         return dx
     nt = 2.25 if flags & TAPS2 else 9
@@ -203,7 +204,7 @@ def _wgrad(x, dz, F, h, w, cin, cout, flags, into=None):
         dw3 = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device=dev)
         with _hip._SideStream(x, dz, dw3, into):
             ws = _hip.workspace(nbytes, dev, 'rpn_wgrad_side')
-            X.check(X.lib.mvx_conv2d_wgrad_split_frames(X.ptr(x), X.ptr(dz), X.ptr(dw3), h, w, cin, cout, X.ptr(ws), ws.numel(), F,
+            X.check(X.lib.mvx_conv2d_wgrad_split_frames(X.ptr(x), X.ptr(dz), X.ptr(dw3), h, w, cin, cout, _hip.split_flags(_split()), X.ptr(ws), ws.numel(), F,
                                                         X.stream()), 'mvx_conv2d_wgrad_split_frames')
             if into is not None:
                 into.add_(dw3[:, :, 1])

@@ -140,10 +140,14 @@ def split_units(request):
     X.check(X.lib.mvx_tuning_set(1, 768), 'mvx_tuning_set')
 
 
+@pytest.mark.parametrize('pieces,tol', [(2, 2e-5), (3, 4e-6)])
 @pytest.mark.parametrize('cin,cout,din,H,W,sd,pd', GEOMS[:4])
-def test_conv3d_bf16x3_split_accuracy(cin, cout, din, H, W, sd, pd, split_units):
-    """bf16x3 kernels against float64: fp32-grade accuracy (well inside the 1e-4 feature bar)."""
+def test_conv3d_bf16x3_split_accuracy(cin, cout, din, H, W, sd, pd, split_units, pieces, tol):
+    """Split kernels against float64.  bf16x3 (two pieces): 2e-5, well inside the 1e-4 feature bar; bf16x6 (three pieces = the
+    whole f32 mantissa, six MFMAs per product): 4e-6 (an f32 accumulation chain over up to K = 3,456 products) AND never more
+    than twice the exact-f32 kernel's own distance from float64 on the same inputs (+ 5e-7)."""
     from modules import _hip
+    split = pieces
     g = torch.Generator().manual_seed(cin + 3 * H)
     x = torch.randn((cin, din, H, W), generator=g)
     w = torch.randn((cout, cin, 3, 3, 3), generator=g) / np.sqrt(27 * cin)
@@ -151,24 +155,27 @@ def test_conv3d_bf16x3_split_accuracy(cin, cout, din, H, W, sd, pd, split_units)
     y = F.relu(F.conv3d(x[None].double(), w.double(), b.double(), (sd, 1, 1), (pd, 1, 1)))[0]
     xc = to_cl(x).to(DEV)
     wd = w.to(DEV)
-    out, stats = _hip.conv3d_forward(xc, _hip.conv3d_pack(wd, False, split=True), b.to(DEV), cout, sd, pd, split=True)
-    assert rel_err(out.cpu().permute(3, 0, 1, 2), y) < 2e-5
+    out, stats = _hip.conv3d_forward(xc, _hip.conv3d_pack(wd, False, split=split), b.to(DEV), cout, sd, pd, split=split)
+    assert rel_err(out.cpu().permute(3, 0, 1, 2), y) < tol
+    if pieces == 3:
+        o32, _ = _hip.conv3d_forward(xc, _hip.conv3d_pack(wd, False), b.to(DEV), cout, sd, pd)
+        assert rel_err(out.cpu().permute(3, 0, 1, 2), y) < 2 * rel_err(o32.cpu().permute(3, 0, 1, 2), y) + 5e-7
     np.testing.assert_allclose(stats.sum(0)[0].cpu().numpy(), y.numpy().reshape(cout, -1).sum(1), rtol=1e-4, atol=5e-2)
     if cin % 64 == 0:
         dz = torch.randn(y.shape, generator=g)
         xg = x[None].double().requires_grad_(True)
         F.conv3d(xg, w.double(), None, (sd, 1, 1), (pd, 1, 1)).backward(dz[None].double())
-        dx = _hip.conv3d_dgrad(to_cl(dz).to(DEV), _hip.conv3d_pack(wd, True, split=True), din, cin, sd, pd, split=True)
-        assert rel_err(dx.cpu().permute(3, 0, 1, 2), xg.grad[0]) < 2e-5
+        dx = _hip.conv3d_dgrad(to_cl(dz).to(DEV), _hip.conv3d_pack(wd, True, split=split), din, cin, sd, pd, split=split)
+        assert rel_err(dx.cpu().permute(3, 0, 1, 2), xg.grad[0]) < tol
     if cout == 64:
         dz = torch.randn(y.shape, generator=g)
         wg = w.double().requires_grad_(True)
         F.conv3d(x[None].double(), wg, None, (sd, 1, 1), (pd, 1, 1)).backward(dz[None].double())
-        dw = _hip.conv3d_wgrad(xc, to_cl(dz).to(DEV), sd, pd, split=True)
-        assert rel_err(dw.cpu(), wg.grad) < 2e-5
+        dw = _hip.conv3d_wgrad(xc, to_cl(dz).to(DEV), sd, pd, split=split)
+        assert rel_err(dw.cpu(), wg.grad) < tol
 
 
-@pytest.mark.parametrize('split', [False, True])
+@pytest.mark.parametrize('split', [False, 2, 3])
 def test_conv3d_full_size_adjoint_identities(split):
     """BASELINE-size grid (conv2 geometry, 5x352x400x64): the three passes must be mutually adjoint,
     <dz, conv(x)> = <dgrad(dz), x> = <wgrad(x, dz), w> -- a size-independent check that needs no CPU
@@ -188,7 +195,7 @@ def test_conv3d_full_size_adjoint_identities(split):
     b = float((dx.double() * x.double()).sum())
     c = float((dw.double() * w.double()).sum())
     scale = float(dz.double().norm() * y.double().norm())
-    tol = 2e-5 if split else 2e-6
+    tol = 2e-5 if split == 2 else 2e-6            # bf16x6 is held to the exact-f32 bound
     assert abs(a - b) / scale < tol and abs(a - c) / scale < tol, (a, b, c, scale)
 
 

@@ -403,29 +403,31 @@ def test_pipeline_skips_empty_frames(executor):
         assert rel_err(bucket.flat, again) < 1e-6
 
 
+@pytest.mark.parametrize('pieces,tol', [(2, 2e-5), (3, 2e-6)])
 @pytest.mark.parametrize('R,K,N', [(1000, 768, 768), (4099, 128, 768), (517, 768, 128), (300, 1728, 128)])
-def test_row_gemm_bf16x3_split_accuracy(R, K, N):
+def test_row_gemm_bf16x3_split_accuracy(R, K, N, pieces, tol):
     """MVX_FLAG_SPLIT: the wide row GEMMs of `convmath: bf16x3` (csrc/linear_split.hip: three bf16 MFMAs per product, f32
     accumulate) against float64 -- forward with bias + ReLU + BatchNorm sums, and the input-gradient form (no epilogue);
-    fp32-grade accuracy like the split convolutions (2e-5), row counts that are no multiple of the 128-row tile."""
+    fp32-grade accuracy like the split convolutions (2e-5; bf16x6, MVX_FLAG_SPLIT3: the exact-f32 kernel's 2e-6), row counts that are no multiple of the 128-row tile."""
     from modules import _hip
     g = torch.Generator().manual_seed(R + K)
     x = torch.randn((R, K), generator=g)
     w = torch.randn((N, K), generator=g) / np.sqrt(K)
     b = torch.randn((N,), generator=g) * 0.1
     ref = torch.relu(x.double() @ w.double().t() + b.double())
-    y, stats = _hip.linear_forward(x.to(DEV), w.to(DEV), b.to(DEV), relu=True, want_stats=True, split=True)
-    assert rel_err(y.cpu(), ref) < 2e-5
+    y, stats = _hip.linear_forward(x.to(DEV), w.to(DEV), b.to(DEV), relu=True, want_stats=True, split=pieces)
+    assert rel_err(y.cpu(), ref) < tol
     st = stats.sum(0).cpu().double()
     assert rel_err(st[0], ref.sum(0)) < 1e-4 and rel_err(st[1], (ref * ref).sum(0)) < 1e-4
     y32, _ = _hip.linear_forward(x.to(DEV), w.to(DEV), b.to(DEV), relu=True, want_stats=True)
     assert rel_err(y32.cpu(), ref) < 2e-6                      # the exact-f32 kernel, for scale
-    yn, _ = _hip.linear_forward(x.to(DEV), w.to(DEV), None, relu=False, want_stats=False, split=True)
-    assert rel_err(yn.cpu(), x.double() @ w.double().t()) < 2e-5
+    yn, _ = _hip.linear_forward(x.to(DEV), w.to(DEV), None, relu=False, want_stats=False, split=pieces)
+    assert rel_err(yn.cpu(), x.double() @ w.double().t()) < tol
 
 
+@pytest.mark.parametrize('pieces,tol', [(2, 2e-5), (3, 2e-6)])
 @pytest.mark.parametrize('R,K,N', [(1000, 768, 768), (4099, 128, 768), (517, 768, 128), (300, 1728, 128), (777, 24, 16), (9000, 128, 128)])
-def test_row_gemm_weight_gradient_bf16x3_split_accuracy(R, K, N):
+def test_row_gemm_weight_gradient_bf16x3_split_accuracy(R, K, N, pieces, tol):
     """MVX_FLAG_SPLIT on mvx_linear_wgrad (csrc/linear_split.hip linear_wgrad_split: hi/lo split while staging, LDS
     transpose reads, three bf16 MFMAs per product): dW = dz^T x against float64, fp32-grade like the other split kernels;
     row counts that are no multiple of the 32-row step, column counts that are no multiple of the 128 x 128 block, and the
@@ -435,10 +437,10 @@ def test_row_gemm_weight_gradient_bf16x3_split_accuracy(R, K, N):
     x = torch.randn((R, K), generator=g)
     dz = torch.randn((R, N), generator=g)
     ref = dz.double().t() @ x.double()
-    dw = _hip.linear_wgrad(x.to(DEV), dz.to(DEV), split=True)
-    assert rel_err(dw.cpu(), ref) < 2e-5
+    dw = _hip.linear_wgrad(x.to(DEV), dz.to(DEV), split=pieces)
+    assert rel_err(dw.cpu(), ref) < tol
     dw32 = _hip.linear_wgrad(x.to(DEV), dz.to(DEV), split=False)
     assert rel_err(dw32.cpu(), ref) < 2e-6                     # the exact-f32 kernel, for scale
     into = torch.full((N, K), 0.5, device=DEV)
-    _hip.linear_wgrad(x.to(DEV), dz.to(DEV), accumulate_into=into, split=True)
-    assert rel_err(into.cpu() - 0.5, ref) < 2e-5
+    _hip.linear_wgrad(x.to(DEV), dz.to(DEV), accumulate_into=into, split=pieces)
+    assert rel_err(into.cpu() - 0.5, ref) < tol
