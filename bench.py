@@ -277,12 +277,16 @@ def cpu_baseline_vfe(P, workload, budget_s=20.0):
                       '(V,35,23) rows, median %.3f s/frame' % (workload, P, len(times) - 1, med)}
 
 
+MATH_PIECES = {'f32': 0, 'bf16x3': 2, 'bf16x6': 3}          # bf16 pieces per f32 operand
+MATH_MFMAS = {'f32': 1.0, 'bf16x3': 3.0, 'bf16x6': 6.0}      # bf16 MFMAs per product (executed matrix FLOPs = this x the algorithmic ones)
+
+
 def isolated_conv_roofline(dev, math):
     """The dominant kernel's launches (conv2/conv3 forward + dgrad, dense) on an otherwise idle GPU."""
     from modules import _hip
     import modules.config as cfg
     H, W = cfg.voxelshape[0], cfg.voxelshape[1]
-    split = math == 'bf16x3'
+    split = MATH_PIECES[math]
     tot_ms, tot_fl = 0.0, 0.0
     for cin, cout, din, sd, pd in ((64, 64, 5, 1, 0), (64, 64, 3, 2, 1)):
         dout = _hip.conv_out_depth(din, sd, pd)
@@ -303,7 +307,7 @@ def isolated_conv_roofline(dev, math):
             torch.cuda.synchronize()
             tot_ms += s.elapsed_time(e) / 5
             tot_fl += fl
-    mult, peak = (3.0, BF16_MFMA_PEAK_TFLOPS) if split else (1.0, FP32_MFMA_PEAK_TFLOPS)
+    mult, peak = (MATH_MFMAS[math], BF16_MFMA_PEAK_TFLOPS) if split else (1.0, FP32_MFMA_PEAK_TFLOPS)
     ach = mult * tot_fl / (tot_ms * 1e-3) / 1e12
     return {'achieved': ach, 'frac': ach / peak, 'avg_launch_ms': tot_ms / 4,
             'note': 'the same kernel, one frame, dense (no tile skipping), alone on the GPU'}
@@ -319,7 +323,7 @@ def parse_args(argv=None):
     ap.add_argument('--frames', type=int, default=None, help='frames per GPU per step (default 4; 16 in --mode vfe, 2 in --mode fusion)')
     ap.add_argument('--points', type=int, default=20000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--convmath', choices=['bf16x3', 'f32'], default=None, help='override config.yml convmath')
+    ap.add_argument('--convmath', choices=['bf16x6', 'bf16x3', 'f32'], default=None, help='override config.yml convmath')
     ap.add_argument('--no-alt', action='store_true', help='skip the extra runs (other workload, bf16x3 arithmetic, the other BASELINE configs)')
     ap.add_argument('--timed-only', action='store_true',
                     help='only warm-up + the timed steps (no alt / isolated / CPU passes): what profiles/ is made from')
@@ -609,13 +613,15 @@ def _run(args, rank, world, dev):
                      'written from constants and not credited, while the time of filling them (about 60 % of the tiles of a launch) '
                      'stays in the denominator; measured while the side-stream weight-gradient kernels share the CUs; `isolated` '
                      '= the same kernel on dense launches alone'}
-        if math == 'bf16x3':
-            # every product is three bf16 MFMAs (hi*hi + hi*lo + lo*hi): executed matrix FLOPs = 3 x the algorithmic ones
-            r.update(achieved=3.0 * alg, peak=BF16_MFMA_PEAK_TFLOPS, frac=3.0 * alg / BF16_MFMA_PEAK_TFLOPS, algorithmic_tflops=alg,
-                     flop_per_launch=3.0 * r['flop_per_launch'],
-                     kernel='conv3d_gather_split (conv2 / conv3 forward + dgrad of all frames of the step)',
-                     note='bf16 hi/lo split MFMA (v_mfma_f32_32x32x16_bf16, f32 accumulate), EXECUTED stages counted by the kernel '
-                          'x 4.72 MFLOP x 3 MFMAs per product, against the dense bf16 peak; skipped background tiles are not credited')
+        if math != 'f32':
+            # every product is three (bf16x3) or six (bf16x6) bf16 MFMAs: executed matrix FLOPs = that multiple of the algorithmic ones
+            mm = MATH_MFMAS[math]
+            r.update(achieved=mm * alg, peak=BF16_MFMA_PEAK_TFLOPS, frac=mm * alg / BF16_MFMA_PEAK_TFLOPS, algorithmic_tflops=alg,
+                     flop_per_launch=mm * r['flop_per_launch'],
+                     kernel='conv3d_gather_splitT (conv2 / conv3 forward + dgrad of all frames of the step)',
+                     note='%s split MFMA (v_mfma_f32_32x32x16_bf16, f32 accumulate), EXECUTED stages counted by the kernel '
+                          'x 4.72 MFLOP x %d MFMAs per product, against the dense bf16 peak; skipped background tiles are not credited;'
+                          ' algorithmic_tflops = the same work priced as one multiply-add per product' % (math, int(mm)))
         return r
 
     def hbm_stages(tm):
@@ -668,27 +674,33 @@ def _run(args, rank, world, dev):
                     'roofline': conv_roofline(tm2, len(exec_stages) - 1), 'hbm_stages': hbm_stages(tm2)})
         del b2
         state['ready'] = None
-        # (2) BASELINE config 3's arithmetic: bf16x3 split MFMA for the dense convolutions of the CML (same frame-set executor)
-        if main_math == 'f32':
-            cfg.config['convmath'] = 'bf16x3'
+        # (2) the same step in the other arithmetics (config.yml convmath: exact-f32 MFMA, bf16x6 = three bf16 pieces / six MFMAs per
+        # product = fp32-grade, bf16x3 = two pieces / three MFMAs, ~2e-5 per product)
+        for math in ('f32', 'bf16x6', 'bf16x3'):
+            if math == main_math:
+                continue
+            cfg.config['convmath'] = math
             try:
                 _, dt3, tm3 = timed_run(2, max(3, args.steps // 2))
             finally:
-                cfg.config['convmath'] = 'f32'
+                cfg.config['convmath'] = main_math
                 state['ready'] = None
             check_status()
-            r3 = conv_roofline(tm3, len(exec_stages) - 1, 'bf16x3')
-            alt.append({'workload': args.workload, 'convmath': 'bf16x3', 'value': frames_total * max(3, args.steps // 2) / dt3,
+            r3 = conv_roofline(tm3, len(exec_stages) - 1, math)
+            alt.append({'workload': args.workload, 'convmath': math, 'value': frames_total * max(3, args.steps // 2) / dt3,
                         'unit': 'frames/s', 'ms_per_step': dt3 / max(3, args.steps // 2) * 1e3, 'roofline': r3,
-                        'note': 'conv2 / conv3 forward, input and weight gradients on the bf16x3 kernels (forward maps within 1e-5 of '
-                                'the exact-f32 mode; gradients carry the split\'s 2e-5 per product), everything else unchanged'})
+                        'note': {'f32': 'every MFMA kernel on the exact-f32 matrix instruction (v_mfma_f32_32x32x2_f32)',
+                                 'bf16x6': 'convolutions and wide row GEMMs, forward and both gradients, in three-piece split arithmetic',
+                                 'bf16x3': 'convolutions, row-GEMM gradients and the RPN GEMMs in two-piece split arithmetic (forward maps '
+                                           'within 1e-5 of exact f32 on the CML; gradients carry 2e-5 per product)'}[math]})
 
     if not args.no_alt and args.mode == 'hot' and world == 1:
         # (3) the other BASELINE.json configs as short runs of their own modes, so that the driver's default invocation
         # carries a timed number and a roofline for each of them: config 2 (--mode vfe, 16 frames), config 4 (--mode fusion,
         # 2 frames), config 3 (--mode full, 4 frames: exact f32 and "bf16 MFMA conv" = convmath bf16x3)
         import copy
-        for cfg_no, mode, math in ((2, 'vfe', main_math), (4, 'fusion', main_math), (3, 'full', 'f32'), (3, 'full', 'bf16x3')):
+        for cfg_no, mode, math in ((2, 'vfe', main_math), (4, 'fusion', main_math), (3, 'full', main_math)) + tuple(
+                (3, 'full', m) for m in ('f32', 'bf16x6', 'bf16x3') if m != main_math):
             a2 = copy.copy(args)
             a2.mode, a2.convmath, a2.frames = mode, math, None
             a2.steps, a2.warmup = 5, 2
@@ -706,7 +718,7 @@ def _run(args, rank, world, dev):
         state['ready'] = None
 
     if rank == 0:
-        dtype = 'f32' if main_math == 'f32' else 'f32 (bf16x3 split MFMA, f32 accumulate)'
+        dtype = 'f32' if main_math == 'f32' else 'f32 (%s split MFMA, f32 accumulate)' % main_math
         wl = {'S2': 'S2 ring frames (64-beam model, KITTI-like occupancy)', 'S1': 'S1 uniform frames (worst-case voxel count)'}[args.workload]
         if args.mode == 'hot':
             workload = ('%s, %d raw pts -> %d pts after crop, grid 10x352x400, T=35, %d frames/GPU/step: crop+cropToSight+lidar2Img, '
@@ -799,7 +811,7 @@ def _run(args, rank, world, dev):
                 other[name] = {'launches': len(evs), 'avg_launch_ms': tms / len(evs)}
                 fl = sum(_hip.timer_value(f) for _, _, f in evs)
                 if fl > 0:
-                    mult, peak = (3.0, BF16_MFMA_PEAK_TFLOPS) if (main_math == 'bf16x3' and name in ('conv3d_wgrad_bg', 'rpn_conv', 'rpn_wgrad')) \
+                    mult, peak = (MATH_MFMAS[main_math], BF16_MFMA_PEAK_TFLOPS) if (main_math != 'f32' and name in ('conv3d_wgrad_bg', 'rpn_conv', 'rpn_wgrad')) \
                         else (1.0, FP32_MFMA_PEAK_TFLOPS)
                     other[name]['executed_tflops'] = mult * fl / (tms * 1e-3) / 1e12
                     other[name]['peak_tflops'] = peak

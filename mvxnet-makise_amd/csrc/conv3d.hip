@@ -24,6 +24,7 @@
 //     and a 32(c) x 64(n) accumulator; the reduction runs over sites; per-strip partial slabs
 //     are summed by a second, deterministic kernel (no float atomics).
 #include "common.h"
+#include "split_common.h"
 
 namespace {
 
@@ -865,6 +866,195 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4(const float *__restr
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// conv3d_wgrad4s<T2, NP>: conv3d_wgrad4 in split arithmetic on the bf16 matrix cores (split_common.h: NP = 2 "bf16x3",
+// NP = 3 "bf16x6" = fp32-grade).  Same workgroup decomposition, step lists, strips and slab layout as conv3d_wgrad4 --
+// eight waves, wave (grp, wm, wn) owns the 32(c) x 32(n) block (wm, wn) of the taps of its group, waves w and w + 4 share
+// a SIMD so that every SIMD carries nine taps per k step -- so the host code and wgrad_reduce are shared.  The MFMA
+// reduction index is the SITE while memory is channel-major: the 10 x 18-site halo of x and the 8 x 16-site tile of dz are
+// cut into their bf16 pieces while they are staged as [piece][32-channel block][site][32] (64-byte rows) and fetched with
+// ds_read_b64_tr_b16, the LDS transpose read (a 16-lane group reads 4 sites x 16 channels, every lane gets 4 consecutive
+// sites of its channel = half of a 32x32x16 operand fragment); a tap shift only changes the rows addressed.  Per 16-site k
+// step a wave reads NP fragments of dz once and NP fragments of x per tap: (taps + 1) NP fragments for taps x 3 (6) MFMAs.
+// LDS 79 KB (NP = 2) / 118 KB (NP = 3): one workgroup, two waves per SIMD, per CU.
+// ------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 w4s_frag(const unsigned short *row0, const unsigned short *row1) {
+    typedef __attribute__((address_space(3))) s16x4 lds4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4 *)row0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4 *)row1);
+    s16x8 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool T2, int NP>
+__global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4s(const float *__restrict__ in,
+                                                             const float *__restrict__ dz,
+                                                             float *__restrict__ slabs, Geom g,
+                                                             int tiles_per_strip, const int *__restrict__ step_list,
+                                                             const int *__restrict__ step_count,
+                                                             const float *__restrict__ c_in, Strips ks) {
+    __shared__ __attribute__((aligned(16))) unsigned short s_x[NP][2][HH * HW][32];      // [piece][32-channel block][halo site][channel]
+    __shared__ __attribute__((aligned(16))) unsigned short s_z[NP][2][TH * TW][32];      // [piece][32-channel block][site][channel]
+    const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
+    const int ntiles = tiles_x * tiles_y;
+    const int nchunks = g.Cin / W4_C;
+    const int kd = blockIdx.y / nchunks, cc = blockIdx.y % nchunks;
+    const int strip = blockIdx.x, nstrips = step_list ? (kd == 0 ? ks.n[0] : (kd == 1 ? ks.n[1] : ks.n[2])) : (int)gridDim.x;
+    if (strip >= nstrips) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int grp = wv >> 2;                         // tap group
+    const int wm = (wv >> 1) & 1, wn = wv & 1;
+    const int nb = blockIdx.z;                       // 64-channel block of dz / dW (Cout = 64 * gridDim.z)
+    dz += (size_t)nb * BN;
+    slabs += (size_t)nb * gridDim.x * 27 * g.Cin * BN;
+    // transpose-read roles of this lane: 16-lane group -> (k half, 16-column half), lane -> (4-site row group, 4 columns)
+    const int g16 = lane >> 4, i16 = lane & 15, q = i16 >> 2, pcol = (g16 & 1) * 16 + 4 * (i16 & 3), kbase = (g16 >> 1) * 8;
+
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    int dlo = 0, dhi = -1;                           // valid output planes form a contiguous range
+    for (int d = 0; d < g.Dout; ++d) {
+        const int ds = d * g.sd - g.pd + kd;
+        if (ds >= 0 && ds < g.Din) { if (dhi < 0) dlo = d; dhi = d; }
+    }
+    const int nd = dhi >= dlo ? dhi - dlo + 1 : 0;
+    const int per = tiles_per_strip;
+    const int *my_list = step_list ? step_list + (size_t)kd * g.Dout * g.F * ntiles : nullptr;
+    const int nlist = step_list ? step_count[kd] : 0;
+    const int nsteps = step_list ? (nlist > strip ? (nlist - strip + nstrips - 1) / nstrips : 0) : nd * per;
+    auto step_of = [&](int i, int &d, int &t) {
+        if (my_list) { const int e = my_list[strip + i * nstrips]; d = e / ntiles; t = e - d * ntiles; }
+        else { d = dlo + i / per; t = strip * per + i % per; }
+    };
+    constexpr int NX = (HH * HW * 16 + W4_THREADS - 1) / W4_THREADS;    // float4 per thread, halo (64 ch)
+    constexpr int NZ = TH * TW * 16 / W4_THREADS;                       // float4 per thread, dz
+    f32x4 xr[NX], zr[NZ];
+    auto load_step = [&](int i) __attribute__((always_inline)) {
+        int d, t;
+        step_of(i, d, t);
+        const int ds = mvx_src_plane(d, g.Din, g.Dout, g.sd, g.pd, kd);      // listed / dense steps always have a valid source
+        const int tx0 = (t % tiles_x) * TW, ty0 = (t / tiles_x) * TH;
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int c = tid + W4_THREADS * u;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (c < HH * HW * 16) {
+                const int r = c >> 4, part = c & 15;
+                const int gy = ty0 - 1 + r / HW, gx = tx0 - 1 + r % HW;
+                if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) {
+                    v = *(const f32x4 *)(in + (((size_t)ds * g.H + gy) * g.W + gx) * g.Cin + cc * W4_C + part * 4);
+                    if (c_in) v -= *(const f32x4 *)(c_in + (size_t)ds * g.Cin + cc * W4_C + part * 4);
+                }
+            }
+            xr[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < NZ; ++u) {
+            const int c = tid + W4_THREADS * u;
+            const int r = c >> 4, part = c & 15;
+            const int gy = ty0 + (r >> 4), gx = tx0 + (r & 15);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gy < g.H && gx < g.W)
+                v = *(const f32x4 *)(dz + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout + part * 4);
+            zr[u] = v;
+        }
+    };
+    auto next_live = [&](int i) {
+        if (my_list) return i < nsteps ? i : nsteps;
+        while (i < nsteps && strip * per + i % per >= ntiles) ++i;      // ragged last strip
+        return i < nsteps ? i : nsteps;
+    };
+    unsigned slots = 0x1fu;                          // see conv3d_wgrad4: the window taps that carry weight for this parity block
+    if (T2 && g.s2d > 0) {
+        const unsigned m = s2d_tap_mask((cc * W4_C) / g.s2d);
+        slots = grp == 0 ? (m & 3u) : ((m >> 2) & 3u);
+    }
+    int cur = next_live(0);
+    if (cur < nsteps) load_step(cur);
+    while (cur < nsteps) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int c = tid + W4_THREADS * u;
+            if (c < HH * HW * 16) {
+                const int r = c >> 4, part = c & 15;
+                uint2 pc[NP];
+                split_n<NP>(xr[u][0], xr[u][1], xr[u][2], xr[u][3], pc);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) *(uint2 *)(&s_x[p][part >> 3][r][(part & 7) * 4]) = pc[p];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NZ; ++u) {
+            const int c = tid + W4_THREADS * u;
+            const int r = c >> 4, part = c & 15;
+            uint2 pc[NP];
+            split_n<NP>(zr[u][0], zr[u][1], zr[u][2], zr[u][3], pc);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *(uint2 *)(&s_z[p][part >> 3][r][(part & 7) * 4]) = pc[p];
+        }
+        __syncthreads();
+        const int nxt = next_live(cur + 1);
+        load_step(nxt < nsteps ? nxt : cur);          // unconditional (see conv3d_gather_pf): the last one is dropped
+        if (!(T2 && slots == 0u)) {
+#pragma unroll 2
+            for (int ks16 = 0; ks16 < TH; ++ks16) {   // 16 sites (one patch row) per MFMA k step
+                const int zr0 = ks16 * TW + kbase + q, zr1 = zr0 + 4;
+                bf16x8 bz[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) bz[p] = w4s_frag(&s_z[p][wn][zr0][pcol], &s_z[p][wn][zr1][pcol]);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const int t9 = grp == 0 ? w4_own(T2, 0, i) : w4_own(T2, 1, i);
+                    const int ncomp = grp == 0 ? w4_ncomp(T2, 0) : w4_ncomp(T2, 1);
+                    if (i >= ncomp) continue;
+                    if (T2 && !((slots >> i) & 1u)) continue;
+                    const int hr0 = (ks16 + t9 / 3) * HW + (t9 % 3) + kbase + q, hr1 = hr0 + 4;
+                    bf16x8 ax[NP];
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) ax[p] = w4s_frag(&s_x[p][wm][hr0][pcol], &s_x[p][wm][hr1][pcol]);
+                    split_mac1<NP>(acc[i], ax, bz);
+                }
+            }
+        }
+        cur = nxt;
+    }
+    // slab[strip][kd][tap][c (Cin)][n (64)]: every tap is written by the group that owns it (zeros where nothing was computed)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int t9 = grp == 0 ? w4_own(T2, 0, i) : w4_own(T2, 1, i);
+        if (t9 < 0) continue;
+        float *o = slabs + ((((size_t)strip * 3 + kd) * 9 + t9) * g.Cin + cc * W4_C + wm * 32) * BN + wn * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            o[(size_t)row * BN + li] = acc[i][r];
+        }
+    }
+}
+
+// conv3d_wgrad4 in the arithmetic the flags ask for: exact f32, or the split forms (MVX_FLAG_SPLIT: bf16x3, + MVX_FLAG_SPLIT3: bf16x6)
+template <bool T2>
+static void launch_wgrad4(int flags, dim3 grid, hipStream_t st, const float *in, const float *dz, float *slabs, const Geom &g,
+                          int per, const int *list, const int *count, const float *c_in, const Strips &ks) {
+    if (flags & MVX_FLAG_SPLIT3)
+        hipLaunchKernelGGL((conv3d_wgrad4s<T2, 3>), grid, dim3(W4_THREADS), 0, st, in, dz, slabs, g, per, list, count, c_in, ks);
+    else if (flags & MVX_FLAG_SPLIT)
+        hipLaunchKernelGGL((conv3d_wgrad4s<T2, 2>), grid, dim3(W4_THREADS), 0, st, in, dz, slabs, g, per, list, count, c_in, ks);
+    else
+        hipLaunchKernelGGL(conv3d_wgrad4<T2>, grid, dim3(W4_THREADS), 0, st, in, dz, slabs, g, per, list, count, c_in, ks);
+}
+
 // step_list[kd][j] = d * ntiles + tile for the (plane, tile) steps of depth tap kd whose source halo holds a
 // non-background site, in ascending (d, tile) order; step_count[kd] = how many.  One workgroup per kd.
 __global__ __launch_bounds__(1024) void wgrad_step_list(const int *__restrict__ in_hflag, Geom g, int ntiles,
@@ -1295,9 +1485,8 @@ extern "C" int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int
     Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
     hipStream_t st = (hipStream_t)stream;
     if (cin % W4_C == 0)
-        hipLaunchKernelGGL(conv3d_wgrad4<false>, dim3(nstrips, 3 * (cin / W4_C), nblk), dim3(W4_THREADS), 0, st, in, dz,
-                           (float *)workspace, g, per, (const int *)nullptr, (const int *)nullptr, (const float *)nullptr,
-                           Strips{{nstrips, nstrips, nstrips}});
+        launch_wgrad4<false>(flags, dim3(nstrips, 3 * (cin / W4_C), nblk), st, in, dz, (float *)workspace, g, per, nullptr, nullptr,
+                             nullptr, Strips{{nstrips, nstrips, nstrips}});
     else
         hipLaunchKernelGGL(conv3d_wgrad, dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz,
                            (float *)workspace, g, per);
@@ -1432,8 +1621,7 @@ extern "C" int mvx_conv3d_wgrad_bg_frames(const float *in, const float *dz, floa
     int *count = list + (size_t)3 * dout * n_frames * ntiles;
     hipLaunchKernelGGL(wgrad_step_list, dim3(3), dim3(1024), 0, st, in_halo_flags, g, ntiles, list, count);
     MVX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(conv3d_wgrad4<false>, dim3(widest, 3 * (cin / W4_C)), dim3(W4_THREADS), 0, st, in, dz, slabs, g, 0,
-                       (const int *)list, (const int *)count, c_in, ks);
+    launch_wgrad4<false>(flags, dim3(widest, 3 * (cin / W4_C)), st, in, dz, slabs, g, 0, list, count, c_in, ks);
     MVX_LAUNCH_CHECK();
     const size_t per_slab = (size_t)27 * cin * BN;
     hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)slabs, dw, widest, cin,
@@ -1547,11 +1735,9 @@ extern "C" int mvx_conv2d_wgrad_frames(const float *in, const float *dz, float *
     Strips ks;
     ks.n[0] = 1; ks.n[1] = nstrips; ks.n[2] = 1;                    // depth tap 1 is the only one with a source plane
     if (flags & MVX_FLAG_TAPS2)
-        hipLaunchKernelGGL(conv3d_wgrad4<true>, dim3(nstrips, 3 * (cin / W4_C), nblk), dim3(W4_THREADS), 0, st, in, dz, slabs, g, 0,
-                           (const int *)list, (const int *)count, (const float *)nullptr, ks);
+        launch_wgrad4<true>(flags, dim3(nstrips, 3 * (cin / W4_C), nblk), st, in, dz, slabs, g, 0, list, count, nullptr, ks);
     else
-        hipLaunchKernelGGL(conv3d_wgrad4<false>, dim3(nstrips, 3 * (cin / W4_C), nblk), dim3(W4_THREADS), 0, st, in, dz, slabs, g, 0,
-                           (const int *)list, (const int *)count, (const float *)nullptr, ks);
+        launch_wgrad4<false>(flags, dim3(nstrips, 3 * (cin / W4_C), nblk), st, in, dz, slabs, g, 0, list, count, nullptr, ks);
     MVX_LAUNCH_CHECK();
     const size_t per_slab = (size_t)27 * cin * BN;
     hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256), nblk), dim3(256), 0, st, (const float *)slabs, dw, nstrips, cin,

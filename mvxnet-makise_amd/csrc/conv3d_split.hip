@@ -29,7 +29,21 @@ constexpr int TH2 = 16;                           // patch height of the 16 x 16
 struct Geom {
     int Din, Dout, H, W, Cin, Cout, sd, pd, mode;
     int F = 1;                                     // frames stacked along depth: planes [F * Dout] <- [F * Din]
+    int tap_lo = 0, tap_hi = 3;                    // in-plane taps (rows AND columns) [tap_lo, tap_hi) carry weight (MVX_FLAG_TAPS2:
+                                                   // the 2x2 window of a stride-2 kernel on the space-to-depth image)
+    int s2d = 0;                                   // > 0: channels per parity block of that image: the structurally zero (window tap,
+                                                   // parity) blocks are not executed (see Geom::s2d in conv3d.hip)
 };
+
+// valid window taps of parity block p = pr * 2 + pc as a 4-bit mask, bit (ta * 2 + tb) (conv3d.hip: s2d_tap_mask)
+__device__ __forceinline__ unsigned s2d_tap_mask(int p) {
+    const int pr = p >> 1, pc = p & 1;
+    unsigned m = 8u;
+    if (pr) m |= 2u;
+    if (pc) m |= 4u;
+    if (pr && pc) m |= 1u;
+    return m;
+}
 
 // source plane of output plane d (a GLOBAL plane index: frame * Dout + plane) for depth tap kd, or -1; planes of
 // different frames never connect (same rule as mvx_src_plane / mvx_dst_plane in common.h)
@@ -246,9 +260,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_splitT(const float *__re
         stage_of(st, kd, ds, cc);
         load_w3(kd, a, cc);
     };
-    auto compute_row = [&](int a) __attribute__((always_inline)) {
+    auto compute_row = [&](int a, unsigned colmask) __attribute__((always_inline)) {
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
+            if (!((colmask >> b) & 1u)) continue;             // block-uniform: taps outside the window / structural zeros
 #pragma unroll
             for (int s2 = 0; s2 < KS; ++s2) {
                 bf16x8 b0[NP], b1[NP];
@@ -268,29 +283,55 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_splitT(const float *__re
             }
         }
     };
+    // taps executed in a stage, bit (a * 3 + b): all nine, or the window [tap_lo, tap_hi)^2, minus the structural zeros of a
+    // stride-2 kernel in space-to-depth form (forward: by the parity block of the stage's input channels; dgrad: of this
+    // unit's output channels).  Block-uniform, and never empty (tap (1,1) of the window always carries weight).
+    auto taps_of = [&](int st) __attribute__((always_inline)) -> unsigned {
+        unsigned m4 = 0xfu;
+        if (g.s2d > 0) m4 = s2d_tap_mask(g.mode == 0 ? ((st % nchunks) * BKT) / g.s2d : (nb * BN) / g.s2d);
+        unsigned m9 = 0u;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int ta = g.mode == 0 ? a : 2 - a, tb = g.mode == 0 ? b : 2 - b;       // window tap of kernel row / column
+                const bool in = a >= g.tap_lo && a < g.tap_hi && b >= g.tap_lo && b < g.tap_hi;
+                const bool on = g.s2d > 0 ? ((m4 >> ((ta & 1) * 2 + (tb & 1))) & 1u) && ta < 2 && tb < 2 : true;
+                if (in && on) m9 |= 1u << (a * 3 + b);
+            }
+        return m9;
+    };
+    auto first_row = [&](unsigned m9) __attribute__((always_inline)) { return (m9 & 7u) ? 0 : ((m9 & 0x38u) ? 1 : 2); };
+    auto next_row = [&](unsigned m9, int a) __attribute__((always_inline)) {      // next executed kernel row after a, or -1
+        for (int r = a + 1; r < 3; ++r)
+            if ((m9 >> (3 * r)) & 7u) return r;
+        return -1;
+    };
+    int st = 0;
+    unsigned m9 = nstages > 0 ? taps_of(0) : 0x1ffu;
+    int a = first_row(m9);
     if (nstages > 0) {
-        load_wrow(0, 0);
+        load_wrow(0, a);
         load_halo(0);
     }
-    for (int st = 0; st < nstages; ++st) {
-        const int nxt = st + 1 < nstages ? st + 1 : st;      // unconditional prefetches: the last stage re-fetches and drops
-        __syncthreads();                                      // the previous stage's LDS reads are done
-        store_halo();
-        store_w3();                                           // kernel row 0
+    while (st < nstages) {
+        const bool first = a == first_row(m9);
+        int a2 = next_row(m9, a), st2 = st;
+        unsigned m9n = m9;
+        if (a2 < 0) {
+            st2 = st + 1;
+            m9n = st2 < nstages ? taps_of(st2) : m9;
+            a2 = first_row(m9n);
+        }
+        const int stp = st2 < nstages ? st2 : st;            // unconditional prefetches: the last one re-fetches and drops
+        __syncthreads();                                      // the previous row's LDS reads are done
+        if (first) store_halo();
+        store_w3();
         __syncthreads();
-        load_wrow(st, 1);                                     // next weight row first ...
-        load_halo(nxt);                                       // ... then the long-latency halo of the next stage
-        compute_row(0);
-        __syncthreads();
-        store_w3();                                           // kernel row 1
-        __syncthreads();
-        load_wrow(st, 2);
-        compute_row(1);
-        __syncthreads();
-        store_w3();                                           // kernel row 2
-        __syncthreads();
-        load_wrow(nxt, 0);
-        compute_row(2);
+        load_wrow(stp, a2);                                   // next weight row first ...
+        if (first) load_halo(st + 1 < nstages ? st + 1 : st); // ... then the long-latency halo of the next stage
+        compute_row(a, (m9 >> (3 * a)) & 7u);
+        st = st2; a = a2; m9 = m9n;
     }
 
     // ---- epilogue
@@ -656,6 +697,10 @@ static int launch_dgrad_split(const float *dz, const void *wsplit_dgrad, float *
     int rc = check_geom(din, dout, h, w, cout, cin, stride_d, pad_d);
     if (rc) return rc;
     Geom g{dout, din, h, w, cout, cin, stride_d, pad_d, 1, n_frames};
+    if (flags & MVX_FLAG_TAPS2) {                   // the input gradient of such a layer reads the flipped window {1,2}^2
+        g.tap_lo = 1; g.tap_hi = 3;
+        if (cin % 4 == 0 && (cin / 4) % BN == 0) g.s2d = cin / 4;      // parity of the OUTPUT channel block
+    }
     launch_gather_split((hipStream_t)stream, pieces_of(flags), din * n_frames, cin / BN, dz, (const unsigned short *)wsplit_dgrad, nullptr, dx, nullptr,
                         g, 0, nullptr, nullptr, nullptr, 0, only_tiles, (unsigned long long *)exec_stages);
     MVX_LAUNCH_CHECK();
@@ -795,6 +840,10 @@ extern "C" int mvx_conv2d_forward_split_frames(const float *in, const void *wspl
         if (e != hipSuccess) return (int)e;
     }
     Geom g{1, 1, h, w, cin, cout, 1, 1, 0, n_frames};
+    if (flags & MVX_FLAG_TAPS2) {                   // stride-2 kernel on the space-to-depth image: window {0,1}^2, structural zeros skipped
+        g.tap_lo = 0; g.tap_hi = 2;
+        if (cin % 4 == 0 && (cin / 4) % BK == 0) g.s2d = cin / 4;
+    }
     launch_gather_split(st, pieces_of(flags), n_frames, cout / BN, in, (const unsigned short *)wsplit, bias, out, stats, g, flags & MVX_FLAG_RELU,
                         nullptr, nullptr, nullptr, 0, nullptr, nullptr);
     MVX_LAUNCH_CHECK();

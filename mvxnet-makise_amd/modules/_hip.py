@@ -497,9 +497,11 @@ def conv3d_wgrad(x, dz, sd, pd, split=False, accumulate_into=None, two_d=False):
     if two_d:
         assert not split and din == 1 and dout == 1 and pd == 1
         flags |= FLAG_CONV2D
-    flags |= split_flags(split)
+    # split arithmetic: conv3d_wgrad4s behind the same entry point (cin a multiple of 64), else the older 9-wave split kernel
+    new_split = bool(split) and cin % 64 == 0
+    flags |= split_flags(split, new_split)
     nbytes = X.lib.mvx_conv3d_wgrad_workspace_bytes(H, W, cin, cout)
-    fn, name = (X.lib.mvx_conv3d_wgrad_split, 'conv3d_wgrad_split') if split else (X.lib.mvx_conv3d_wgrad, 'conv3d_wgrad')
+    fn, name = (X.lib.mvx_conv3d_wgrad_split, 'conv3d_wgrad_split') if (split and not new_split) else (X.lib.mvx_conv3d_wgrad, 'conv3d_wgrad')
     with _wgrad_scope(accumulate_into, x, dz) as scope:
         ws = workspace(nbytes, x.device, 'wgrad_side' if isinstance(scope, _SideStream) else 'wgrad')
         with _Timed(name, conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None else 0):
@@ -675,9 +677,9 @@ def conv3d_wgrad_bg(x, dz, sd, pd, bg_in, tap_sums=None, accumulate_into=None, s
         dw, flags = accumulate_into, FLAG_ACCUMULATE
     else:
         dw, flags = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device=x.device), 0
-    flags |= split_flags(split)
-    fn_bytes = X.lib.mvx_conv3d_wgrad_bg_split_workspace_bytes if split else X.lib.mvx_conv3d_wgrad_bg_workspace_bytes
-    fn = X.lib.mvx_conv3d_wgrad_bg_split if split else X.lib.mvx_conv3d_wgrad_bg
+    flags |= split_flags(split, True)              # split arithmetic: conv3d_wgrad4s behind the same entry point
+    fn_bytes = X.lib.mvx_conv3d_wgrad_bg_workspace_bytes
+    fn = X.lib.mvx_conv3d_wgrad_bg
     nbytes = fn_bytes(dout, H, W, cin, cout)
     if tap_sums is None:
         tap_sums = plane_tap_sums(dz)

@@ -446,21 +446,13 @@ def _wgrad_bg(rec, dz, tap_sums, F, H, W):
     dw = _grad_of(w)
     fl = _wgrad_bg_flops(rec, F) if _hip.KERNEL_TIMERS is not None else 0      # a callable, evaluated after the timed region
     nbytes = X.lib.mvx_conv3d_wgrad_bg_workspace_bytes_frames(rec['dout'], H, W, ci, co, F)
-    if rec.get('split'):
-        nbytes = X.lib.mvx_conv3d_wgrad_bg_split_workspace_bytes_frames(rec['dout'], H, W, ci, co, F)
-        with _hip._SideStream(x, dz, tap_sums, rec['c_in'], rec['hflag_in']):
-            ws = _hip.workspace(nbytes, x.device, 'wgrad_bg_side')
-            with _hip._Timed('conv3d_wgrad_bg', fl):
-                X.check(X.lib.mvx_conv3d_wgrad_bg_split_frames(X.ptr(x), X.ptr(dz), X.ptr(dw), rec['din'], rec['dout'], H, W, ci, co,
-                                                               rec['sd'], rec['pd'], _hip.FLAG_ACCUMULATE | _hip.split_flags(rec['split']),
-                                                               X.ptr(rec['hflag_in']), X.ptr(rec['c_in']), X.ptr(tap_sums), X.ptr(ws), ws.numel(), F,
-                                                               X.stream()), 'mvx_conv3d_wgrad_bg_split_frames')
-        return
+    # split arithmetic (bf16x3 / bf16x6): the same entry point, conv3d_wgrad4s (csrc/conv3d.hip) under MVX_FLAG_SPLIT[3]
+    sp = _hip.split_flags(rec.get('split'), True)
     with _hip._SideStream(x, dz, tap_sums, rec['c_in'], rec['hflag_in']):
         ws = _hip.workspace(nbytes, x.device, 'wgrad_bg_side')
         with _hip._Timed('conv3d_wgrad_bg', fl):
             X.check(X.lib.mvx_conv3d_wgrad_bg_frames(X.ptr(x), X.ptr(dz), X.ptr(dw), rec['din'], rec['dout'], H, W, ci, co,
-                                                     rec['sd'], rec['pd'], _hip.FLAG_ACCUMULATE, X.ptr(rec['hflag_in']),
+                                                     rec['sd'], rec['pd'], _hip.FLAG_ACCUMULATE | sp, X.ptr(rec['hflag_in']),
                                                      X.ptr(rec['c_in']), X.ptr(tap_sums), X.ptr(ws), ws.numel(), F, X.stream()),
                     'mvx_conv3d_wgrad_bg_frames')
 

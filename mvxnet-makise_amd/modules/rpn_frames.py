@@ -149,10 +149,10 @@ def _conv(x, wpk, bias, F, h, w, cin, cout, flags, eps):
     if fin is None:
         fin = torch.zeros((1,), dtype=torch.float64, device=dev)
     mi = torch.empty((F, 2, cout), dtype=torch.float32, device=dev)
-    if _split():                               # all nine taps of the rearranged stride-2 kernels are executed here
-        with _hip._Timed('rpn_conv', 2.0 * F * h * w * cin * cout * 9 if _hip.KERNEL_TIMERS is not None else 0):
+    if _split():                               # split arithmetic (bf16x3 / bf16x6), same window / structural-zero skipping
+        with _hip._Timed('rpn_conv', 2.0 * F * h * w * cin * cout * (2.25 if flags & TAPS2 else 9) if _hip.KERNEL_TIMERS is not None else 0):
             X.check(X.lib.mvx_conv2d_forward_split_frames(X.ptr(x), X.ptr(wpk), X.ptr(bias), X.ptr(y), X.ptr(stats), h, w, cin, cout,
-                                                          _hip.FLAG_RELU | fz | _hip.split_flags(_split()), F, X.stream()), 'mvx_conv2d_forward_split_frames')
+                                                          _hip.FLAG_RELU | fz | flags | _hip.split_flags(_split()), F, X.stream()), 'mvx_conv2d_forward_split_frames')
         X.check(X.lib.mvx_bn_finalize_frames(X.ptr(stats), float(h * w), float(eps), X.ptr(mi), cout, F, X.stream()),
                 'mvx_bn_finalize_frames')
         return y, mi
@@ -185,8 +185,8 @@ def _bn_bwd(g, y, mi, F, bias):
 def _dgrad(dz, wpd, F, h, w, cin, cout, flags):
     dx = torch.empty((F, h, w, cin), dtype=torch.float32, device=dz.device)
     if _split():
-        with _hip._Timed('rpn_conv', 2.0 * F * h * w * cin * cout * 9 if _hip.KERNEL_TIMERS is not None else 0):
-            X.check(X.lib.mvx_conv2d_dgrad_split_frames(X.ptr(dz), X.ptr(wpd), X.ptr(dx), h, w, cin, cout, _hip.split_flags(_split()), F, X.stream()),
+        with _hip._Timed('rpn_conv', 2.0 * F * h * w * cin * cout * (2.25 if flags & TAPS2 else 9) if _hip.KERNEL_TIMERS is not None else 0):
+            X.check(X.lib.mvx_conv2d_dgrad_split_frames(X.ptr(dz), X.ptr(wpd), X.ptr(dx), h, w, cin, cout, flags | _hip.split_flags(_split()), F, X.stream()),
                     'mvx_conv2d_dgrad_split_frames')
         return dx
     nt = 2.25 if flags & TAPS2 else 9
@@ -199,24 +199,15 @@ def _dgrad(dz, wpd, F, h, w, cin, cout, flags):
 def _wgrad(x, dz, F, h, w, cin, cout, flags, into=None):
     """dW (cout, cin, 3, 3) over all frames, on the side stream; ADDED into ``into`` or returned."""
     dev = x.device
-    if _split():
-        nbytes = X.lib.mvx_conv2d_wgrad_split_workspace_bytes_frames(h, w, cin, cout, F)
-        dw3 = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device=dev)
-        with _hip._SideStream(x, dz, dw3, into):
-            ws = _hip.workspace(nbytes, dev, 'rpn_wgrad_side')
-            X.check(X.lib.mvx_conv2d_wgrad_split_frames(X.ptr(x), X.ptr(dz), X.ptr(dw3), h, w, cin, cout, _hip.split_flags(_split()), X.ptr(ws), ws.numel(), F,
-                                                        X.stream()), 'mvx_conv2d_wgrad_split_frames')
-            if into is not None:
-                into.add_(dw3[:, :, 1])
-                return into
-            return dw3[:, :, 1].contiguous()
+    # split arithmetic: the same entry point and workgroup decomposition (conv3d_wgrad4s, csrc/conv3d.hip) -- MVX_FLAG_SPLIT[3]
+    sp = _hip.split_flags(_split(), True)
     nbytes = X.lib.mvx_conv2d_wgrad_workspace_bytes_frames(h, w, cin, cout, F)
     dw = into if into is not None else torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
     nt = 2.25 if flags & TAPS2 else 9
     with _hip._SideStream(x, dz, dw), _hip._Timed('rpn_wgrad', 2.0 * F * h * w * cin * cout * nt if _hip.KERNEL_TIMERS is not None else 0):
         ws = _hip.workspace(nbytes, dev, 'rpn_wgrad_side')
         X.check(X.lib.mvx_conv2d_wgrad_frames(X.ptr(x), X.ptr(dz), X.ptr(dw), h, w, cin, cout,
-                                              flags | (_hip.FLAG_ACCUMULATE if into is not None else 0), X.ptr(ws), ws.numel(), F,
+                                              flags | sp | (_hip.FLAG_ACCUMULATE if into is not None else 0), X.ptr(ws), ws.numel(), F,
                                               X.stream()), 'mvx_conv2d_wgrad_frames')
     return dw
 

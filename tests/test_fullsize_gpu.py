@@ -73,13 +73,17 @@ def _smooth_gradient(C=128, H=352, W=400):
 
 def _smooth_bound(name):
     """Bound on the max-norm relative distance of a parameter gradient from float64 under the smooth upstream gradient:
-    2.5e-3 for the CML / VFE parameters (measured <= 1.1e-3), 1.2e-2 for the fusion MLP (five BatchNorms over 176 k rows with
-    K = 768 sums in front of them: measured <= 5.9e-3)."""
-    return 1.2e-2 if name.startswith('head.fusion.') else 2.5e-3
+    5e-3 for the CML / VFE parameters (measured <= 1.1e-3 exact f32, <= 3.4e-3 bf16x6), 3e-2 for the fusion MLP (five
+    BatchNorms over 176 k rows with K = 768 sums in front of them: measured <= 5.9e-3 exact f32, <= 2.1e-2 bf16x6 -- single
+    elements of the 768 x 768 gradient that belong to almost-dead channels, whose inverse std of ~1000 multiplies whatever
+    rounding the forward GEMM left; the 2-norm below does not move).  One bound for both arithmetics."""
+    return 3e-2 if name.startswith('head.fusion.') else 5e-3
 
 
-# 2-norm distances from float64 under the smooth upstream gradient measured on MI355X (profiles/r03_fullsize_parity.json); the
-# asserted bound is 1.6 x the measurement, which every 1 % mutation of a closed-form term breaks (5.4 x .. 178 x)
+# 2-norm distances from float64 under the smooth upstream gradient measured on MI355X in the exact-f32 arithmetic
+# (profiles/r03_fullsize_parity.json); the asserted bound is 2.0 x that measurement for BOTH arithmetics (bf16x6 lands at
+# 0.38 x .. 1.85 x the exact-f32 figure per parameter, profiles/r04_fullsize_parity_bf16x6.json), which every 1 % mutation of a
+# closed-form term still breaks (2.6 x .. 90 x over the bound)
 _SMOOTH_2NORM = {
     'head.fusion.fcn1.fc.bias': 2.05e-3, 'head.fusion.conv1.conv.weight': 2.00e-3, 'head.fusion.fcn1.fc.weight': 1.98e-3,
     'head.fusion.fcn2.fc.weight': 1.84e-3, 'head.fusion.conv1.conv.bias': 1.80e-3, 'head.fusion.conv2.conv.bias': 1.71e-3,
@@ -94,7 +98,7 @@ _SMOOTH_2NORM = {
 
 def _smooth_bound2(name):
     """The same in the 2-norm (what the mutation check uses)."""
-    return 1.6 * _SMOOTH_2NORM[name]
+    return 2.0 * _SMOOTH_2NORM[name]
 
 
 def test_bench_path_matches_oracle_at_full_size():

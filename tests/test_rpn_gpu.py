@@ -35,6 +35,15 @@ def test_narrow_and_wide_gather_units_give_identical_maps():
     F, h, w = 3, 21, 37                                   # ragged: no multiple of the 8 x 16 tile
     g = torch.Generator().manual_seed(3)
     got = {}
+    old_math, cfg.config['convmath'] = cfg.config.get('convmath', 'f32'), 'f32'      # the unit widths of the exact-f32 gather
+    try:
+        _narrow_wide_body(X, _hip, rf, cfg, F, h, w, g, got)
+    finally:
+        cfg.config['convmath'] = old_math
+        X.check(X.lib.mvx_tuning_set(2, -1), 'mvx_tuning_set')
+
+
+def _narrow_wide_body(X, _hip, rf, cfg, F, h, w, g, got):
     for cin, cout, flags in ((128, 128, 0), (64, 192, 0), (4 * 64, 128, rf.TAPS2)):
         x = torch.randn((F, h, w, cin), generator=g).to(DEV)
         wt = (torch.randn((cout, cin, 3, 3), generator=g) * 0.05).to(DEV)
@@ -48,6 +57,57 @@ def test_narrow_and_wide_gather_units_give_identical_maps():
         a, bq = got[(cin, cout, flags, 'wide')], got[(cin, cout, flags, 'narrow')]
         assert torch.equal(a[0], bq[0]) and torch.equal(a[2], bq[2]), (cin, cout, flags)
         assert rel(bq[1].double(), a[1].double()) < 1e-6
+
+
+
+def test_stride2_and_stride1_layers_in_split_arithmetic_match_exact_f32():
+    """The RPN's 3x3 layers in convmath bf16x6 / bf16x3 against the exact-f32 kernels on the same inputs: forward (with the
+    BatchNorm statistics), input gradient and weight gradient, stride 1 and stride 2 (MVX_FLAG_TAPS2: the 2x2 window on the
+    space-to-depth image, with the structurally zero (window tap, parity) blocks skipped in all three arithmetics), on a
+    ragged map and with both gather unit shapes of the split kernels."""
+    from modules import Extension as X
+    from modules import _hip
+    from modules import rpn_frames as rf
+    import modules.config as cfg
+    F, h, w = 2, 21, 37
+    g = torch.Generator().manual_seed(13)
+    old = cfg.config.get('convmath', 'f32')
+    try:
+        for cin0, cout, s2 in ((128, 128, False), (64, 128, True), (128, 256, True)):
+            wt = (torch.randn((cout, cin0, 3, 3), generator=g) * 0.05).to(DEV)
+            w_eff = rf._s2d_weight(wt, 1) if s2 else wt
+            cin = w_eff.shape[1]
+            flags = rf.TAPS2 if s2 else 0
+            x = torch.randn((F, h, w, cin), generator=g).to(DEV)
+            b = torch.randn((cout,), generator=g).to(DEV)
+            dz = torch.randn((F, h, w, cout), generator=g).to(DEV)
+            res = {}
+            for math, units in (('f32', 0), ('bf16x6', 0), ('bf16x6', 1 << 60), ('bf16x3', 0)):
+                cfg.config['convmath'] = math
+                sp = _hip.split_pieces()
+                X.check(X.lib.mvx_tuning_set(1, units), 'mvx_tuning_set')          # MVX_TUNE_SPLIT16_MIN_UNITS: 16x16 / 8x16 units
+                if sp:
+                    w3 = torch.zeros(w_eff.shape[:2] + (3, 3, 3), device=DEV)
+                    w3[:, :, 1] = w_eff
+                    wf, wd = _hip.conv3d_pack(w3, False, split=sp), _hip.conv3d_pack(w3, True, split=sp)
+                else:
+                    wf, wd = _hip.conv3d_pack(w_eff, False), _hip.conv3d_pack(w_eff, True)
+                y, mi = rf._conv(x, wf, b, F, h, w, cin, cout, flags, cfg.eps)
+                dx = rf._dgrad(dz, wd, F, h, w, cin, cout, flags)
+                dw = rf._wgrad(x, dz, F, h, w, cin, cout, flags)
+                _hip.join_side_stream()
+                torch.cuda.synchronize()
+                res[(math, units)] = (y.clone(), mi.clone(), dx.clone(), dw.clone())
+            ref = res[('f32', 0)]
+            for key, tol in ((('bf16x6', 0), 3e-6), (('bf16x6', 1 << 60), 3e-6), (('bf16x3', 0), 3e-5)):
+                r = res[key]
+                for name, a, bb in zip(('y', 'mean_inv', 'dx', 'dw'), r, ref):
+                    assert rel(a, bb) < tol * (10 if name == 'mean_inv' else 1), (cin0, cout, s2, key, name, rel(a, bb))
+                if s2:      # the structural zeros of the rearranged kernel stay exact zeros in its gradient
+                    assert float(r[3][w_eff == 0].abs().max()) == 0.0
+    finally:
+        cfg.config['convmath'] = old
+        X.check(X.lib.mvx_tuning_set(1, 768), 'mvx_tuning_set')
 
 
 def _to_planes(mid):
@@ -227,7 +287,7 @@ def test_rpn_bf16x3_mode_stays_within_the_feature_bar(golden):
     res = {}
     old = cfg.config.get('convmath', 'f32')
     try:
-        for math in ('f32', 'bf16x3'):
+        for math in ('f32', 'bf16x3', 'bf16x6'):
             cfg.config['convmath'] = math
             bucket.zero()
             heads, S = rf.rpn_forward(rpn, x_cl, F, 2, H, W, 64)
@@ -238,15 +298,17 @@ def test_rpn_bf16x3_mode_stays_within_the_feature_bar(golden):
     finally:
         cfg.config['convmath'] = old
     assert rel(res['bf16x3'][0], res['f32'][0]) < 3e-4
-    assert rel(res['bf16x3'][1], res['f32'][1]) < 1e-1          # input gradient: the ReLU-kink sensitivity of these small maps
-    a, b = res['bf16x3'][2], res['f32'][2]
-    off = 0
-    for k, p in rpn.named_parameters():
-        ga, gb = a[off:off + p.numel()], b[off:off + p.numel()]
-        off += p.numel()
-        # 2-norm, not max-norm: a handful of ReLU flips on the 8x12-site maps moves single weight-gradient entries by tens of
-        # per cent in either arithmetic (tools/rpn_diag.py); the gradient as a whole must agree
-        assert float((ga - gb).norm() / gb.norm().clamp_min(1e-30)) < 1e-1, k
+    assert rel(res['bf16x6'][0], res['f32'][0]) < 5e-5          # bf16x6 (three pieces, fp32-grade): both are ~2e-5 from float64
+    for math in ('bf16x3', 'bf16x6'):
+        assert rel(res[math][1], res['f32'][1]) < 1e-1          # input gradient: the ReLU-kink sensitivity of these small maps
+        a, b = res[math][2], res['f32'][2]
+        off = 0
+        for k, p in rpn.named_parameters():
+            ga, gb = a[off:off + p.numel()], b[off:off + p.numel()]
+            off += p.numel()
+            # 2-norm, not max-norm: a handful of ReLU flips on the 8x12-site maps moves single weight-gradient entries by tens
+            # of per cent in either arithmetic (tools/rpn_diag.py); the gradient as a whole must agree
+            assert float((ga - gb).norm() / gb.norm().clamp_min(1e-30)) < 1e-1, (math, k)
 
 
 def test_rpn_full_size_maps_match_the_float64_oracle(golden):
@@ -259,7 +321,13 @@ def test_rpn_full_size_maps_match_the_float64_oracle(golden):
     F, H, W = 2, 352, 400
     gen = torch.Generator().manual_seed(11)
     mids = torch.randn((F, 128, H, W), generator=gen)
-    heads, S = rf.rpn_forward(rpn, _to_planes(mids.to(DEV)), F, 2, H, W, 64)
+    import modules.config as cfg
+    old = cfg.config.get('convmath', 'f32')
+    cfg.config['convmath'] = 'f32'
+    try:
+        heads, S = rf.rpn_forward(rpn, _to_planes(mids.to(DEV)), F, 2, H, W, 64)
+    finally:
+        cfg.config['convmath'] = old
     got = heads.view(F, H // 2, W // 2, 16)[1].cpu().double()
     torch.set_num_threads(max(1, torch.get_num_threads()))
     with torch.no_grad():
@@ -281,6 +349,17 @@ def test_rpn_full_size_maps_match_the_float64_oracle(golden):
     e2_reg = rel(got2[..., 2:], reg[0].permute(1, 2, 0))
     print('  bf16x3: score %.2e (abs), reg %.2e (max-norm rel)' % (e2_score, e2_reg))
     assert e2_score < 5e-4 and e2_reg < 5e-4
+    # ... and in convmath: bf16x6 (three bf16 pieces per operand, fp32-grade): north_star's 1e-4 bar like the exact-f32 mode
+    cfg.config['convmath'] = 'bf16x6'
+    try:
+        heads3, _ = rf.rpn_forward(rpn, _to_planes(mids.to(DEV)), F, 2, H, W, 64)
+    finally:
+        cfg.config['convmath'] = old
+    got3 = heads3.view(F, H // 2, W // 2, 16)[1].cpu().double()
+    e3_score = float((torch.sigmoid(got3[..., :2]) - score[0].permute(1, 2, 0)).abs().max())
+    e3_reg = rel(got3[..., 2:], reg[0].permute(1, 2, 0))
+    print('  bf16x6: score %.2e (abs), reg %.2e (max-norm rel)' % (e3_score, e3_reg))
+    assert e3_score < 1e-4 and e3_reg < 1e-4
 
 
 def test_rpn_module_runs_on_the_hip_node_and_matches_float64():
