@@ -200,8 +200,9 @@ def test_conv3d_full_size_adjoint_identities(split):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('pieces', [2, 3])
 @pytest.mark.parametrize('shape', [(5, 40, 48, 1, 0), (3, 37, 53, 2, 1), (10, 24, 35, 2, 1)])
-def test_background_rewrite_equals_dense(shape, split_units):
+def test_background_rewrite_equals_dense(shape, split_units, pieces):
     """conv3d_forward_bg / conv3d_wgrad_bg (constant fill of voxel-free tiles, closed-form constant term)
     against the dense kernels on an input that IS a background plus a few active sites -- including
     sizes that are no multiple of the 8x16 tile and depth padding."""
@@ -261,12 +262,12 @@ def test_background_rewrite_equals_dense(shape, split_units):
     dw_dn = _hip.conv3d_wgrad(x, dz, sd, pd)
     assert float((dw_bg - dw_dn).abs().max()) < 2e-5 * float(dw_dn.abs().max())
     # the bf16x3 forms of the same two entry points against their dense bf16x3 counterparts
-    wps = _hip.conv3d_pack(w, False, split=True)
-    ys_bg, _ = _hip.conv3d_forward_bg(x, wps, b, cout, sd, pd, bg_in, out_mask, bg_pre, split=True)
-    ys_dn, _ = _hip.conv3d_forward(x, wps, b, cout, sd, pd, split=True)
+    wps = _hip.conv3d_pack(w, False, split=pieces)
+    ys_bg, _ = _hip.conv3d_forward_bg(x, wps, b, cout, sd, pd, bg_in, out_mask, bg_pre, split=pieces)
+    ys_dn, _ = _hip.conv3d_forward(x, wps, b, cout, sd, pd, split=pieces)
     assert float((ys_bg - ys_dn).abs().max()) < 1e-4 * scale
-    dws_bg = _hip.conv3d_wgrad_bg(x, dz, sd, pd, bg_in, split=True)
-    dws_dn = _hip.conv3d_wgrad(x, dz, sd, pd, split=True)
+    dws_bg = _hip.conv3d_wgrad_bg(x, dz, sd, pd, bg_in, split=pieces)
+    dws_dn = _hip.conv3d_wgrad(x, dz, sd, pd, split=pieces)
     assert float((dws_bg - dws_dn).abs().max()) < 1e-4 * float(dws_dn.abs().max())
     assert float((dws_bg - dw_dn).abs().max()) < 1e-4 * float(dw_dn.abs().max())
 
