@@ -379,7 +379,10 @@ def _run(args, rank, world, dev):
     model = MVXNet().to(dev)
     with_rpn = args.mode in ('dropin', 'full')
     hot = [p for k, p in model.named_parameters() if p.requires_grad and (with_rpn or '.rpn.' not in k)]
-    bucket = parallel.GradBucket(hot)
+    # the weight gradient of the fusion MLP's first layer is the last kernel of a step: it goes out in the second, small part
+    # of the exchange (modules/parallel.py)
+    bucket = parallel.GradBucket(hot, late=[model.head.fusion.fcn1.fc.weight])
+    bucket.timing = world > 1
     # train.py:64's optimizer; fused=True is the same update as ONE multi-tensor kernel instead of ~10 foreach launches with
     # Python between them (hot 348 -> 364, one-frame-at-a-time 88 -> 105 frames/s on the same box; MVX_FUSED_OPT=0 for the default)
     opt = torch.optim.AdamW(hot, lr=1e-3, eps=cfg.eps, fused=os.environ.get('MVX_FUSED_OPT', '1') == '1')
@@ -817,6 +820,10 @@ def _run(args, rank, world, dev):
                     other[name]['peak_tflops'] = peak
                     other[name]['frac'] = other[name]['executed_tflops'] / peak
         out['other_kernels'] = other
+        if world > 1 and bucket.times:
+            # the gradient exchange's own duration (events on its streams): 'early' = everything but the step's last weight
+            # gradient, on the communication stream while that kernel still runs; 'late' = the rest (modules/parallel.py)
+            out['allreduce_ms_per_call'] = bucket.collective_ms()
         if alt:
             out['alt_modes'] = alt
         if world == 1 and not args.no_cpu_baseline:
@@ -832,6 +839,18 @@ def _run(args, rank, world, dev):
             out['config']['voxel_indices_vs_oracle'] = vfe_check
         if args.mode == 'full' and full.get('last'):
             out['last_losses'] = full['last']
+        # one compact record of every BASELINE config measured in this run (frames/s), FIRST and LAST in the line, so that a
+        # truncated copy of the line keeps it whichever end survives
+        summ = {'%s_%s_%s' % (args.mode, args.workload, main_math): round(out['value'], 1)}
+        for a in alt:
+            if 'baseline_config' in a:
+                summ['cfg%d_%s_%s' % (a['baseline_config'], a['mode'], a['convmath'])] = round(a['value'], 1)
+            else:
+                summ['%s_%s_%s' % (args.mode, a['workload'], a['convmath'])] = round(a['value'], 1)
+        if 'cpu_baseline' in out:
+            summ['cpu_baseline_frames_per_s'] = round(out['cpu_baseline']['value'], 4)
+        out = dict([('metric', out['metric']), ('value', out['value']), ('unit', out['unit']), ('summary', summ)] +
+                   [(k, v) for k, v in out.items() if k not in ('metric', 'value', 'unit')] + [('summary_tail', summ)])
         return out
     return None
 

@@ -330,8 +330,9 @@ extern "C" size_t mvx_bn_backward_scratch_bytes(int32_t channels) {
 
 extern "C" size_t mvx_bn_backward_scratch_bytes_frames(int32_t channels, int32_t n_frames) {
     // per frame: replicated (sum dyh, sum dyh*yhat, dbias replica slot); the bias gradient uses frame 0's third slot
-    // ... one slot for the two "last workgroup" counters, and the (a, b) floats of every frame [F][2][C]
-    return channels > 0 && n_frames > 0 ? sizeof(double) * ((REP * 3 + 1) * (size_t)channels * n_frames + 1) : 0;
+    // ... TWO slots (16 bytes: what follows stays 16-byte aligned for its float4 loads) for the two "last workgroup" counters,
+    // and the (a, b) floats of every frame [F][2][C]
+    return channels > 0 && n_frames > 0 ? sizeof(double) * ((REP * 3 + 1) * (size_t)channels * n_frames + 2) : 0;
 }
 
 extern "C" int mvx_bn_relu_backward_frames(const float *dyhat, const float *y, const float *mean_inv, double count,
@@ -340,12 +341,13 @@ extern "C" int mvx_bn_relu_backward_frames(const float *dyhat, const float *y, c
                                            int32_t row_kind, void *stream) {
     MVX_CHECK_ARG(dyhat && y && mean_inv && dz && scratch && rows >= 0 && channels > 0 && channels % 4 == 0);
     MVX_CHECK_ARG(count > 0);
+    MVX_CHECK_ARG(((uintptr_t)scratch & 15) == 0);          // bn_bwd_apply reads the (a, b) floats behind the sums with float4 loads
     FrameMap fm;
     MVX_CHECK_ARG(mvx_build_frame_map(fm, frames_host, row_kind, rows, count));
     hipStream_t st = (hipStream_t)stream;
     const size_t slots = (size_t)REP * 3 * channels * fm.F;
     if (!(flags & MVX_FLAG_PREZEROED)) {
-        hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * (slots + 1), st);
+        hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * (slots + 2), st);
         if (e != hipSuccess) return (int)e;
     }
     if (rows > 0) {
@@ -357,7 +359,7 @@ extern "C" int mvx_bn_relu_backward_frames(const float *dyhat, const float *y, c
         rpb = (rpb + BWD_TRIP * rpi - 1) / (BWD_TRIP * (size_t)rpi) * (BWD_TRIP * (size_t)rpi);       // whole (TRIP x rpi)-row trips
         const unsigned blocks = (unsigned)(((size_t)rows + rpb - 1) / rpb);
         unsigned *counters = (unsigned *)(scratch + slots);           // [0] pass 2 (bias gradient), [1] pass 1 ((a, b) finalisation)
-        float *ab = (float *)(scratch + slots + 1);
+        float *ab = (float *)(scratch + slots + 2);
         hipLaunchKernelGGL(bn_bwd_reduce<BWD_TRIP>, dim3(blocks), dim3(256), 0, st, dyhat, y, mean_inv, scratch, (size_t)rows,
                            channels, rpb, fm, counters + 1, ab);
         MVX_LAUNCH_CHECK();

@@ -456,12 +456,7 @@ static void launch_gather_split(hipStream_t st, int np, int planes, int nblocks,
                                 unsigned long long *exec_stages) {
     const int tiles_x = (int)mvx_cdiv(g.W, TW);
     const long long units16 = (long long)tiles_x * mvx_cdiv(g.H, TH2) * planes * nblocks;
-    // Tile-restricted launches (only_tiles: the input gradients of the background rewrite) keep the 8 x 16 units their flags are
-    // made for: a 16 x 16 unit with ONE flagged tile also evaluates its partner tile from source sites the producer never
-    // wrote (the restricted backward hands over gradients that are valid on flagged tiles only), and at full size the voxel
-    // gradients of single voxels then differed from the dense evaluation (found in round 4, when the full-size background test
-    // first ran in a split arithmetic: 1.6e-2 on one voxel in bf16x6, 2.6e-3 in bf16x3; 8 x 16 units: 4.9e-7 like exact f32).
-    const bool big = !only_tiles && units16 >= g_split16_min_units;
+    const bool big = units16 >= g_split16_min_units;
     const dim3 grid(tiles_x * mvx_cdiv(g.H, big ? TH2 : TH), planes, nblocks);
     const bool win = g.tap_lo != 0 || g.tap_hi != 3 || g.s2d > 0;
 #define MVX_GO(NP_, BK_, MT_)                                                                                                        \

@@ -635,6 +635,8 @@ def rows_backward(model, S, dfeat):
     for i in range(len(S.fusion) - 1, -1, -1):
         x, w, b, y, mi = S.fusion[i]
         dz = bn_relu_backward(gx, y, mi, fs, X.ROWS_FUSION, fs.fusion_row_w, _grad_of(b))
+        if i == 0:
+            _hip.mark_tail(dev)          # the step's last weight gradient follows: everything else of the bucket may go out (parallel.py)
         _linear_wgrad_side(x, dz, w)
         if i > 0:
             gx = _rows_dgrad(dz, w.reshape(w.shape[0], -1))

@@ -43,20 +43,35 @@ def global_count(n_local, device=None):
 
 
 class GradBucket:
-    """Flat view over the gradients of the trainable parameters that took part in the step."""
+    """Flat view over the gradients of the trainable parameters that took part in the step.
 
-    def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
+    Layout of the buffer: [early parameters | late parameters | one count slot].  ``late``: parameters whose gradient is the
+    LAST thing a step produces (the hot step ends with 0.7-0.9 ms in which only the weight gradient of the fusion MLP's first
+    layer runs): with more than one rank the early part is all-reduced on a communication stream while
+    that kernel is still running and the small late part after it (``all_reduce_mean`` does both; with no late parameters or
+    one rank it is the single call it always was).  The count slot carries this rank's number of frames through the same
+    collective, so that a step whose ranks contributed different numbers of frames (short last chunk, frames without
+    voxels) is divided by the global count ON THE DEVICE -- no second collective, no host read (``frames_local=``)."""
+
+    def __init__(self, params, late=()):
+        late_ids = {id(p) for p in late}
+        ps = [p for p in params if p.requires_grad]
+        self.params = [p for p in ps if id(p) not in late_ids] + [p for p in ps if id(p) in late_ids]
         n = sum(p.numel() for p in self.params)
+        self.n_early = sum(p.numel() for p in self.params if id(p) not in late_ids)
         dev = self.params[0].device if self.params else torch.device('cpu')
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._buf = torch.zeros(n + 1, dtype=torch.float32, device=dev)
+        self.flat = self._buf[:n]                # the gradients (what tests and optimizers look at)
+        self._count = self._buf[n:]
+        self.times = []                           # (start, end) event pairs of the collectives, when timing is on
+        self.timing = False
         off = 0
         for p in self.params:                 # parameters' .grad become views of the bucket
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
 
     def zero(self):
-        self.flat.zero_()
+        self._buf.zero_()
 
     def check_views(self):
         """Every parameter's .grad must still be its view of the flat buffer: ``zero_grad(set_to_none=True)`` or an
@@ -67,12 +82,66 @@ class GradBucket:
                 raise RuntimeError('a parameter gradient is no longer a view of the GradBucket (use bucket.zero(), or '
                                    'optimizer.zero_grad(set_to_none=False))')
 
-    def all_reduce_mean(self, frames_total):
-        """Sum over ranks, then divide by the global number of frames."""
+    def _timed(self, stream):
+        if not (self.timing and self.flat.is_cuda):
+            return None
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(stream)
+        return s, e
+
+    def all_reduce_mean(self, frames_total=None, frames_local=None):
+        """Sum over ranks, then divide by the global number of frames: ``frames_total`` when the caller knows it (every rank
+        ran the same number of frames), else ``frames_local`` = this rank's count, summed through the bucket's count slot and
+        applied on the device (at least 1)."""
         self.check_views()
+        assert (frames_total is None) != (frames_local is None)
+        n = self.flat.numel()
+        if frames_local is not None:
+            self._count.fill_(float(frames_local))
         if dist.is_initialized():             # also with one rank: the collective path is the same code at every world size
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.flat.mul_(1.0 / float(frames_total))
+            two = self.n_early < n and self.flat.is_cuda      # also with one rank: the same two calls at every world size
+            if two:
+                from modules import _hip
+                dev = self.flat.device
+                main = torch.cuda.current_stream(dev)
+                comm = _hip.comm_stream(dev)
+                evs = _hip.tail_events(dev)          # (side stream before the tail kernel, main stream at the end of the backward)
+                if evs is None:
+                    comm.wait_stream(main)
+                else:
+                    comm.wait_event(evs[0])
+                    comm.wait_event(evs[1])
+                self._buf.record_stream(comm)
+                with torch.cuda.stream(comm):
+                    t = self._timed(comm)
+                    w_early = dist.all_reduce(self._buf[:self.n_early], op=dist.ReduceOp.SUM, async_op=True)
+                    if t:
+                        t[1].record(comm)
+                        self.times.append(('early', ) + t)
+                t = self._timed(main)
+                dist.all_reduce(self._buf[self.n_early:], op=dist.ReduceOp.SUM)      # late parameters + the count slot
+                if t:
+                    t[1].record(main)
+                    self.times.append(('late', ) + t)
+                w_early.wait()                       # the current stream waits for the early part
+                main.wait_stream(comm)
+            else:
+                t = self._timed(torch.cuda.current_stream(self.flat.device)) if self.flat.is_cuda else None
+                dist.all_reduce(self._buf if frames_local is not None else self.flat, op=dist.ReduceOp.SUM)
+                if t:
+                    t[1].record(torch.cuda.current_stream(self.flat.device))
+                    self.times.append(('all', ) + t)
+        if frames_local is not None:
+            self.flat.div_(self._count.clamp_min(1.0))
+        else:
+            self.flat.mul_(1.0 / float(frames_total))
+
+    def collective_ms(self):
+        """Average duration of the collectives recorded since ``timing`` was switched on, by kind (call after a sync)."""
+        out = {}
+        for kind, s, e in self.times:
+            out.setdefault(kind, []).append(s.elapsed_time(e))
+        return {k: sum(v) / len(v) for k, v in out.items()}
 
 
 def assert_replicas_in_sync(params):

@@ -41,6 +41,18 @@ class FrameBatch:
         self.raw, self.n_raw, self.calib = raw, n_raw, calib
         self.cap_points = cap_points if cap_points is not None else (points6.shape[1] if points6 is not None else None)
         self._mats = None
+        self.created = None             # event after the last kernel / copy that WRITES this batch's tensors (mark_created)
+
+    def mark_created(self):
+        """Record that everything enqueued so far on the current stream produced this batch.  A batch that is handed to a
+        step as ``prepare_next`` is read on the preparation stream, which does NOT wait for the training stream (it would
+        queue behind the step just enqueued): it waits for this event instead.  Batches whose tensors are complete and
+        synchronised (bench.py's resident batch) need no mark."""
+        dev = self.device
+        if dev.type == 'cuda':
+            self.created = torch.cuda.Event()
+            self.created.record(torch.cuda.current_stream(dev))
+        return self
 
     @property
     def n_frames(self):
@@ -63,6 +75,14 @@ class FrameBatch:
         m64, p64, m32, p32 = self._mats
         imsize_wh = (float(cfg.imsize[1]), float(cfg.imsize[0]))
         return _hip.crop_project(self.raw, self.n_raw, cfg.velorange, m64, p64, imsize_wh, m32, p32, self.cap_points)
+
+
+def _wait_created(prep, nxt):
+    """The preparation stream reads the next batch: wait for the event of its creation, if it has one (FrameBatch.mark_created)."""
+    b = nxt[0] if isinstance(nxt, tuple) else nxt
+    ev = getattr(b, 'created', None)
+    if ev is not None:
+        prep.wait_event(ev)
 
 
 def voxelize_batch(batch, T=None, with_maps=False):
@@ -367,6 +387,7 @@ def _train_step_frame_set_lanes(model, batch, grad_mid, imsize, ready, prepare_n
     old_async, _hip.ASYNC_WGRAD = _hip.ASYNC_WGRAD, True
     next_ready = None
     streams = [main] + lane_streams(dev, max(0, len(sets) - 1))
+    flat, done = None, False
     try:
         if sets:
             model.prepack()
@@ -414,6 +435,7 @@ def _train_step_frame_set_lanes(model, batch, grad_mid, imsize, ready, prepare_n
         if prepare_next is not None:
             if PREP_STREAM:
                 prep = _prep_stream(dev)
+                _wait_created(prep, prepare_next)
                 with torch.cuda.stream(prep):
                     nr = prepare_frame_sets(prepare_next, SET_LANES)
                     ev = torch.cuda.Event()
@@ -421,6 +443,7 @@ def _train_step_frame_set_lanes(model, batch, grad_mid, imsize, ready, prepare_n
                 next_ready = nr + (ev,)
             else:
                 next_ready = prepare_frame_sets(prepare_next, SET_LANES)
+        done = True
     finally:
         _hip.GRAD_SINK = old_sink
         _hip.ASYNC_WGRAD = old_async
@@ -428,7 +451,7 @@ def _train_step_frame_set_lanes(model, batch, grad_mid, imsize, ready, prepare_n
         for st in streams[1:]:
             main.wait_stream(st)
         _hip.join_side_stream()
-        if sets:
+        if done and sets and flat is not None:                  # success only: partial lane gradients never reach the bucket
             for k in range(1, len(sets)):                       # the other lanes' gradients join the bucket (main stream)
                 flat.add_(_lane_flat(flat, k))
     if prepare_next is not None:
@@ -475,6 +498,7 @@ def train_step_frame_set(model, batch, grad_mid, imsize, ready=None, prepare_nex
         if prepare_next is not None:
             if PREP_STREAM:
                 prep = _prep_stream(dev)
+                _wait_created(prep, prepare_next)
                 with torch.cuda.stream(prep):
                     nr = prepare_frame_set(prepare_next, sample=(model.head, imsize) if PRESAMPLE else None)
                     ev = torch.cuda.Event()
@@ -534,6 +558,7 @@ def train_step_rows_only(model, batch, state, ready=None, prepare_next=None, wit
         if prepare_next is not None:
             if PREP_STREAM:
                 prep = _prep_stream(dev)
+                _wait_created(prep, prepare_next)
                 with torch.cuda.stream(prep):
                     nr = prepare_frame_set(prepare_next)
                     ev = torch.cuda.Event()
@@ -580,7 +605,7 @@ def batch_from_dataset(group, names, device, anchorBevs, fpn_fn, cap_points):
     boxes = [(d[4], d[3][:, [0, 1]]) if (d[4] is not None and d[4].shape[0] != 0) else None for d in group]
     lists = Calc.classifyAnchorsFrames(boxes, anchorBevs, cfg.velorange, 0.45, 0.6)
     targets = [None if t is None else (t[0], t[1], t[2], d[3].to(device)) for t, d in zip(lists, group)]
-    batch = FrameBatch(pts6, torch.from_numpy(perms).to(device), torch.from_numpy(n).to(device), fpn)
+    batch = FrameBatch(pts6, torch.from_numpy(perms).to(device), torch.from_numpy(n).to(device), fpn).mark_created()
     return batch, targets
 
 
@@ -703,6 +728,7 @@ def train_step_full(model, batch, targets, criterion, anchors, imsize, ready=Non
             nb, target_fn = prepare_next
             if PREP_STREAM:
                 prep = _prep_stream(dev)
+                _wait_created(prep, nb)
                 with torch.cuda.stream(prep):
                     nr = prepare_frame_set(nb, sample=(model.head, hw) if PRESAMPLE else None)
                     nt = target_fn()

@@ -294,6 +294,15 @@ def split_heads(heads, F, h1, w1):
     return torch.sigmoid(v[..., :2]).permute(0, 3, 1, 2), v[..., 2:].permute(0, 3, 1, 2)
 
 
+_MUTATE = {}        # TESTS ONLY (tests/test_rpn_gpu.py): name -> factor applied to one term of the RPN backward, to prove that the
+                    # full-size gradient check would notice a 1 % error in it.  Empty in every product run.
+
+
+def _mut(name, t):
+    f = _MUTATE.get(name)
+    return t if f is None else t * f
+
+
 def rpn_backward(rpn, S, d_heads):
     """Backward from dL/d(heads) (F*h1*w1, 16); returns dL/d(x_cl) in the layout of rpn_forward's input.
     Needs _hip.ASYNC_WGRAD semantics: weight gradients are produced on the side stream (join before the optimizer)."""
@@ -314,6 +323,7 @@ def rpn_backward(rpn, S, d_heads):
         _grad_of(rpn.cls.bias).add_(db[:2])
         _grad_of(rpn.reg.bias).add_(db[2:])
     g_up, _ = _hip.linear_forward(d_heads, w_heads, None, relu=False, want_stats=False, w_transposed=True)      # (rows, 768)
+    g_up = _mut('heads_dgrad', g_up)
     # deconv2 / deconv3
     g_in = {}
     for rec in S['dk']:
@@ -328,7 +338,7 @@ def rpn_backward(rpn, S, d_heads):
         # input gradient with the weight as a row-major [cin][s*s*cout] matrix (both operands read along k)
         gx, _ = _hip.linear_forward(dz, rec['w_all'].t().contiguous(), None, relu=False, want_stats=False, label='linear_dgrad',
                                     split=_hip.row_split('dgrad'))
-        g_in[s] = gx.view(F, hk, wk, cin)
+        g_in[s] = _mut('deconv%d_dgrad' % s, gx).view(F, hk, wk, cin)
     # deconv1
     d1 = rpn.deconv1
     g1 = torch.empty((rows, 256), dtype=torch.float32, device=dev)
@@ -340,7 +350,7 @@ def rpn_backward(rpn, S, d_heads):
     with _hip._SideStream(dwc):
         _grad_of(d1.deconv.weight).add_(dwc.transpose(0, 1).flip(2, 3))
     wcd = pk.get(('d1',), d1.deconv.weight, lambda: d1.deconv.weight.flip(2, 3).transpose(0, 1).contiguous(), True)
-    g_x1 = _dgrad(dz, wcd, F, h1, w1, 128, 256, 0)
+    g_x1 = _mut('deconv1_dgrad', _dgrad(dz, wcd, F, h1, w1, 128, 256, 0))
     # blocks, last first; x2 and x1 collect the gradients of both their consumers
     g_next = {2: g_in[4], 1: g_in[2], 0: g_x1}
     g = g_next[2]
@@ -352,18 +362,18 @@ def rpn_backward(rpn, S, d_heads):
             wt = m.conv.weight
             h, w, cin, cout = rec['h'], rec['w'], rec['cin'], rec['cout']
             g_up_layer = g
-            dz = _bn_bwd(g, rec['y'], rec['mi'], F, m.conv.bias)
+            dz = _mut('bn_bwd_b%d' % bi, _bn_bwd(g, rec['y'], rec['mi'], F, m.conv.bias))
             if rec['kind'] == 's1':
                 _wgrad(rec['x'], dz, F, h, w, cin, cout, 0, into=_grad_of(wt))
                 wpd = pk.get(('s1', rec['bi'], rec['li']), wt, lambda wt=wt: wt, True)
-                g = _dgrad(dz, wpd, F, h, w, cin, cout, 0)
+                g = _mut('s1_dgrad_b%d' % bi, _dgrad(dz, wpd, F, h, w, cin, cout, 0))
             else:
                 pl, Cf = rec['planes'], rec['cfull']
                 dw2 = _wgrad(rec['x'], dz, F, h, w, cin, cout, TAPS2)
                 with _hip._SideStream(dw2):
                     _s2d_weight_grad(dw2, wt, pl)
                 wpd = pk.get(('s2', rec['bi']), wt, lambda wt=wt, pl=pl: _s2d_weight(wt, pl), True)
-                gs = _dgrad(dz, wpd, F, h, w, cin, cout, TAPS2)             # gradient of the space-to-depth image
+                gs = _mut('s2_dgrad_b%d' % bi, _dgrad(dz, wpd, F, h, w, cin, cout, TAPS2))             # gradient of the space-to-depth image
                 g = _d2s(gs, F, pl, 2 * h, 2 * w, Cf)
                 if pl == 1:
                     g = g.view(F, 2 * h, 2 * w, Cf)

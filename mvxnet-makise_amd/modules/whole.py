@@ -114,9 +114,21 @@ def _imsize_hw(imsize):
 
 
 def _all_params(model):
-    """model.parameters() as a list kept on the model (walking the module tree costs ~0.3 ms per call); made again when a
-    direct child module of the model, its head or its backbone was added or removed."""
-    sig = (len(model._modules), len(model.head._modules), len(model.backbone._modules))
+    """model.parameters() as a list kept on the model (walking the module tree costs ~0.3 ms per call); made again when any
+    module of the tree was added, removed or REPLACED (the signature is the identity of every module's sub-module table and
+    of the sub-modules themselves, four levels deep = every module of MVXNet: replacing backbone.rpn.cls keeps the counts but
+    not the identities; ~10 us)."""
+    sig = []
+    level = [model]
+    for _ in range(4):              # model -> head / backbone -> svfe, cml, rpn, fusion ... -> their blocks -> conv / bn / fc
+        nxt = []
+        for m in level:
+            for c in m._modules.values():
+                if c is not None:
+                    sig.append(id(c))
+                    nxt.append(c)
+        level = nxt
+    sig = tuple(sig)
     hit = model.__dict__.get('_mvx_params')
     if hit is None or hit[0] != sig:
         hit = (sig, list(model.parameters()))

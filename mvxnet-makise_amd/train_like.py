@@ -129,7 +129,7 @@ def train(args):
     if args.lastiter > 0:
         model.load_state_dict(torch.load(os.path.join(args.checkpoints, 'epoch%d.pkl' % args.lastiter), map_location=device))
         opt.load_state_dict(torch.load(os.path.join(args.checkpoints, 'epoch%d_opt.pkl' % args.lastiter), map_location=device))
-    bucket = parallel.GradBucket(params) if args.mode == 'fast' else None
+    bucket = parallel.GradBucket(params, late=[model.head.fusion.fcn1.fc.weight]) if args.mode == 'fast' else None
     tv = have_torchvision()
 
     forwardTime = lossTime = backwardTime = 0.0
@@ -230,7 +230,9 @@ def train(args):
                     if used < batch.n_frames:
                         say('Epoch%d step %d: %d frame(s) without a voxel skipped' % (epoch + args.lastiter + 1, gstep, batch.n_frames - used))
                 forwardTime += time.perf_counter() - st
-                bucket.all_reduce_mean(parallel.global_count(used, device) if world > 1 else max(1, used))
+                # this rank's frame count rides in the bucket's count slot: the global divisor is applied on the device, with no
+                # second collective and no host read (a blocking count exchange undid read=False)
+                bucket.all_reduce_mean(frames_local=used)
                 opt.step()
                 account(pending)
                 pending = out

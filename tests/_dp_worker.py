@@ -1,7 +1,7 @@
 """Worker of the world_size-2 gloo tests (CPU): gradient exchange of the data-parallel step.
 
 mode toy   : two small parameters, every rank adds the gradients of its frames, one all-reduce -> mean over all frames.
-mode chunks: train_like.py's --mode fast step schedule on an ODD frame count (7 and 9 frames, 2 per rank per step): every rank
+mode chunks: (the divisor travels in the bucket's count slot: one collective per step) train_like.py's --mode fast step schedule on an ODD frame count (7 and 9 frames, 2 per rank per step): every rank
              runs the same number of steps, a rank without a frame in the short last chunk still joins the all-reduce, the
              divisor is the global number of contributing frames, every frame is used exactly once.
 mode model : the REAL flat bucket over MVXNet's hot-path parameters (same construction as bench.py / train_like.py): every
@@ -51,11 +51,12 @@ elif mode == 'chunks':
             bucket.zero()
             for f in mine:
                 params[0].grad.add_(float(f + 1))
-            total = parallel.global_count(len(mine))
-            assert total == hi - lo, (total, lo, hi)
-            bucket.all_reduce_mean(total)
+            # this rank's frame count rides in the bucket's count slot: ONE collective, the divisor applied on the device
+            bucket.all_reduce_mean(frames_local=len(mine))
             want = sum(f + 1.0 for f in range(lo, hi)) / (hi - lo)
             assert torch.allclose(bucket.flat, torch.full_like(bucket.flat, want)), (bucket.flat, want)
+            assert int(bucket._count[0]) == hi - lo, (bucket._count, lo, hi)
+            assert parallel.global_count(len(mine)) == hi - lo
             seen.extend(mine)
         cnt = torch.tensor([float(len(seen)), float(len(chunks))])
         both = [torch.empty_like(cnt) for _ in range(world)]
@@ -65,8 +66,11 @@ else:
     from MVXNet import MVXNet
     model = MVXNet()                                 # CPU parameters: only the bucket / optimizer logic runs here
     hot = [(k, p) for k, p in model.named_parameters() if p.requires_grad and '.rpn.' not in k]
-    bucket = parallel.GradBucket([p for _, p in hot])
+    # the two-part layout of bench.py / train_like.py: the first fusion layer's weight (the step's last gradient) goes last
+    late = model.head.fusion.fcn1.fc.weight
+    bucket = parallel.GradBucket([p for _, p in hot], late=[late])
     assert bucket.flat.numel() == sum(p.numel() for _, p in hot) == 1169440
+    assert bucket.n_early == 1169440 - late.numel() and late.grad.data_ptr() == bucket.flat[bucket.n_early:].data_ptr()
     opt = torch.optim.AdamW([p for _, p in hot], lr=1e-3, eps=1e-6)
     frames_total = 8                                 # 4 frames per rank, frames {i : i mod world == rank}
 
@@ -80,7 +84,7 @@ else:
     for f in mine:                                   # what the reduction kernels do: ADD into the existing .grad views
         for j, (_, p) in enumerate(hot):
             p.grad.add_(frame_grad(f, p, j))
-    bucket.all_reduce_mean(frames_total)
+    bucket.all_reduce_mean(frames_local=len(mine))    # count slot: 4 + 4 frames
     for j, (k, p) in enumerate(hot):
         want = sum(frame_grad(f, p, j) for f in range(frames_total)) / frames_total
         assert torch.allclose(p.grad, want, rtol=1e-5, atol=1e-6), k
