@@ -419,9 +419,9 @@ def test_rpn_module_runs_on_the_hip_node_and_matches_float64():
     assert rel(dict(rpn.named_parameters())[k0].grad.cpu(), 2 * res['hip'][3][k0]) < 1e-5
 
 
-# 2-norm distances of the RPN + loss gradients from float64 at full size with a well-conditioned RPN (measured on MI355X,
-# profiles/r04_rpn_loss_grads.json); asserted at 2e-3 for every tensor, which every 1 % mutation of a backward term breaks
-_RPN_GRAD_BOUND = 2e-3
+# The RPN + loss gradients against float64 WITH THE SAME ReLU MASKS (see the test): measured 2-norm distances on MI355X are in
+# profiles/r04_rpn_loss_grads.json; asserted at 1e-3 for every tensor, which every 1 % mutation of a backward term breaks
+_RPN_GRAD_BOUND = 1e-3
 _RPN_MUTATIONS = ('heads_dgrad', 'deconv2_dgrad', 'deconv4_dgrad', 'deconv1_dgrad', 'bn_bwd_b0', 'bn_bwd_b1', 'bn_bwd_b2',
                   's1_dgrad_b0', 's1_dgrad_b1', 's1_dgrad_b2', 's2_dgrad_b1', 's2_dgrad_b2')
 
@@ -430,14 +430,20 @@ def test_rpn_and_loss_gradients_tight_at_full_size():
     """The RPN + VoxelLoss backward chain (voxelnet/Pipe.py:45-75, voxelnet/Loss.py:15-45) at the benchmark's size -- the part
     of `--mode full` that the hot-path gradient check does not cover -- against float64: the REAL loss (classification +
     regression on anchor targets of eight boxes) on a 352x400 BEV map, every rpn.* parameter gradient and the gradient handed
-    to the CML within 2e-3 (2-norm).  The network is made well conditioned for this (biases of the BatchNorm-ed layers at +0.5,
-    so no channel is almost dead: at the reference's random initialisation BatchNorm without affine multiplies rounding noise
-    by up to 1000 and ANY fp32 evaluation sits 1e-2 .. 1e-1 from float64, see tests/test_fullsize_gpu.py) -- what is tested is
-    the backward ARITHMETIC of every layer kind: heads, kernel = stride deconvolutions (pixel shuffle backwards), the stride-1
-    transposed convolution, stride-1 and stride-2 (space-to-depth) 3x3 layers, BatchNorm backward.  **Mutation check**: each
-    of those terms scaled by 1.01 through rpn_frames._MUTATE must break the asserted bound."""
+    to the CML.
+
+    What makes this comparison TIGHT: the float64 evaluation uses the ReLU masks of the HIP forward (y > 0 of every layer,
+    taken from the saved activations).  Seventeen Conv-ReLU-BatchNorm layers are chaotic under ReLU flips: an activation within
+    1e-6 of zero lands on different sides in fp32 and float64, and ONE such flip in a deep layer moves every gradient below it
+    by 1e-3 .. 1e-2 (torch's own CPU fp32 against float64 on this network: 4e-4 .. 1e-2 with a loss-shaped and with a smooth
+    upstream gradient alike, uniform below the flipped layer; tools/dbg_rpn_grads.py).  With the masks shared, what is left
+    is the backward ARITHMETIC of every layer kind -- heads, kernel = stride deconvolutions (pixel shuffle backwards), the
+    stride-1 transposed convolution, stride-1 and stride-2 (space-to-depth) 3x3 layers, BatchNorm backward -- and that is
+    held to 1e-3 (2-norm) per tensor.  The forward values differ from the plain float64 evaluation only at the flipped
+    elements, by < 1e-5 (losses asserted at 1e-4).  **Mutation check**: each backward term scaled by 1.01 through
+    rpn_frames._MUTATE must break the bound."""
     import json
-    import os
+    import torch.nn.functional as Fn
     import modules.config as cfg
     from modules import _hip, parallel, Calc
     from modules import rpn_frames as rf
@@ -455,7 +461,7 @@ def test_rpn_and_loss_gradients_tight_at_full_size():
             v = torch.randn(p.shape, generator=gen) / np.sqrt(fan)
             if k.startswith(('cls', 'reg')):
                 v = v * 0.3
-        else:
+        else:       # biases of the BatchNorm-ed layers at +0.5: no channel is almost dead (BatchNorm without affine, eps 1e-6)
             v = torch.zeros(p.shape) if k.startswith(('cls', 'reg')) else torch.full(p.shape, 0.5)
         P['rpn.' + k] = v
     rpn.load_state_dict({k[4:]: v for k, v in P.items()})
@@ -490,10 +496,35 @@ def test_rpn_and_loss_gradients_tight_at_full_size():
         losses, has_reg, d_heads = heads_loss(heads, F_, S['h1'], S['w1'], [(pi, ni, gi, gt.to(DEV))], crit, anchors.to(DEV))
         got = backward(S, d_heads)
     assert has_reg[0]
-    # ---- float64 oracle with autograd
+    # ---- the ReLU masks of the HIP forward, in the oracle's NCHW layout
+    masks = {}
+    for bi, blk in enumerate(S['blocks']):
+        for li, rec in enumerate(blk['layers']):
+            masks[('blk', bi, li)] = (rec['y'] > 0).permute(0, 3, 1, 2).cpu().double()
+    masks['d1'] = (S['d1']['y'] > 0).permute(0, 3, 1, 2).cpu().double()
+    for rec in S['dk']:
+        s_, hk, wk, co = rec['s'], rec['h'], rec['w'], rec['cout']
+        t = (rec['t'] > 0).view(F_, hk, wk, s_, s_, co).permute(0, 5, 1, 3, 2, 4).reshape(F_, co, hk * s_, wk * s_)
+        masks[('dk', s_)] = t.cpu().double()
+    # ---- float64 with autograd, ReLU replaced by the multiplication with those masks
     P64 = {k: v.double().requires_grad_(True) for k, v in P.items()}
     m64 = mid.double().requires_grad_(True)
-    score, reg = O.rpn(m64, P64)
+
+    def bn(y):
+        return Fn.batch_norm(y, None, None, None, None, True, 0.0, O.EPS)
+    x = m64
+    outs = []
+    for bi, (name, nl) in enumerate((('blk1', 4), ('blk2', 6), ('blk3', 6))):
+        for li in range(nl):
+            x = bn(Fn.conv2d(x, P64['rpn.%s.%d.conv.weight' % (name, li)], P64['rpn.%s.%d.conv.bias' % (name, li)],
+                             2 if li == 0 else 1, 1) * masks[('blk', bi, li)])
+        outs.append(x)
+    ups = [bn(Fn.conv_transpose2d(outs[0], P64['rpn.deconv1.deconv.weight'], P64['rpn.deconv1.deconv.bias'], 1, 1) * masks['d1']),
+           bn(Fn.conv_transpose2d(outs[1], P64['rpn.deconv2.deconv.weight'], P64['rpn.deconv2.deconv.bias'], 2, 0) * masks[('dk', 2)]),
+           bn(Fn.conv_transpose2d(outs[2], P64['rpn.deconv3.deconv.weight'], P64['rpn.deconv3.deconv.bias'], 4, 0) * masks[('dk', 4)])]
+    up = torch.cat(ups, dim=1)
+    score = torch.sigmoid(Fn.conv2d(up, P64['rpn.cls.weight'], P64['rpn.cls.bias']))
+    reg = Fn.conv2d(up, P64['rpn.reg.weight'], P64['rpn.reg.bias'])
     cls, rl = O.voxel_loss([t.cpu().numpy() for t in pi], [t.cpu().numpy() for t in ni], gi.cpu().numpy(), gt.double(),
                            score[0].permute(1, 2, 0), reg[0].permute(1, 2, 0), O.create_anchors(H // 2, W // 2).double(), 2)
     (cls + rl).backward()
@@ -504,7 +535,7 @@ def test_rpn_and_loss_gradients_tight_at_full_size():
     def dist(g):
         return {k: float((g[k] - ref[k]).norm() / ref[k].norm()) for k in ref}
     d0 = dist(got)
-    report = {'convmath': cfg.config.get('convmath', 'f32'), 'loss_rel': e_loss, 'rel_2norm_vs_float64': d0, 'mutations': {}}
+    report = {'convmath': cfg.config.get('convmath', 'f32'), 'loss_rel': e_loss, 'rel_2norm_vs_float64_same_masks': d0, 'mutations': {}}
     # ---- every backward term mutated by 1 %: the worst tensor must leave the bound
     try:
         for name in _RPN_MUTATIONS:

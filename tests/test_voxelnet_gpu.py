@@ -331,7 +331,9 @@ def test_full_size_background_rewrite_equals_dense_cml():
     dv = (res[True][1] - res[False][1]).abs().max(1).values / res[False][1].abs().max()
     assert float(dv.max()) < 5e-2 and int((dv > 2e-4).sum()) <= max(1, V // 500), (float(dv.max()), int((dv > 2e-4).sum()))
     for k in res[False][2]:
-        tol = 5e-3 if k.endswith('bias') else 5e-4        # bias gradients in front of a BatchNorm are pure cancellation
+        # bias gradients in front of a BatchNorm are pure cancellation; conv1's weight gradient is a sum over the 2,948 voxel rows
+        # only, so the one flipped ReLU next to a voxel (see above) is 1 / sqrt(rows) of it
+        tol = 5e-3 if (k.endswith('bias') or k.startswith('conv1.')) else 5e-4
         assert rel_err(res[True][2][k], res[False][2][k]) < tol, (k, rel_err(res[True][2][k], res[False][2][k]))
 
 
