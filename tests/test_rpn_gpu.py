@@ -420,8 +420,9 @@ def test_rpn_module_runs_on_the_hip_node_and_matches_float64():
 
 
 # The RPN + loss gradients against float64 WITH THE SAME ReLU MASKS (see the test): measured 2-norm distances on MI355X are in
-# profiles/r04_rpn_loss_grads.json; asserted at 1e-3 for every tensor, which every 1 % mutation of a backward term breaks
-_RPN_GRAD_BOUND = 1e-3
+# profiles/r04_rpn_loss_grads.json; measured <= 8e-6 in exact f32 and <= 6.7e-6 in bf16x6; asserted at 1e-4 for every tensor, which every 1 % mutation of a backward term
+# breaks (2.2e-3 .. 6.2e-2)
+_RPN_GRAD_BOUND = 1e-4
 _RPN_MUTATIONS = ('heads_dgrad', 'deconv2_dgrad', 'deconv4_dgrad', 'deconv1_dgrad', 'bn_bwd_b0', 'bn_bwd_b1', 'bn_bwd_b2',
                   's1_dgrad_b0', 's1_dgrad_b1', 's1_dgrad_b2', 's2_dgrad_b1', 's2_dgrad_b2')
 
@@ -439,7 +440,7 @@ def test_rpn_and_loss_gradients_tight_at_full_size():
     upstream gradient alike, uniform below the flipped layer; tools/dbg_rpn_grads.py).  With the masks shared, what is left
     is the backward ARITHMETIC of every layer kind -- heads, kernel = stride deconvolutions (pixel shuffle backwards), the
     stride-1 transposed convolution, stride-1 and stride-2 (space-to-depth) 3x3 layers, BatchNorm backward -- and that is
-    held to 1e-3 (2-norm) per tensor.  The forward values differ from the plain float64 evaluation only at the flipped
+    held to 1e-4 (2-norm) per tensor (measured 3e-6 median, 8e-6 worst).  The forward values differ from the plain float64 evaluation only at the flipped
     elements, by < 1e-5 (losses asserted at 1e-4).  **Mutation check**: each backward term scaled by 1.01 through
     rpn_frames._MUTATE must break the bound."""
     import json
