@@ -167,6 +167,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const float *__restrict__ d
     }
 }
 
+// (a, b) of every frame and channel from sums a producer's epilogue filled (MVX_FLAG_SUMS_READY): one workgroup
+__global__ __launch_bounds__(256) void bn_bwd_ab(const double *__restrict__ sums, int C, FrameMap fm, float *__restrict__ ab) {
+    for (int e = threadIdx.x; e < C * fm.F; e += blockDim.x) {
+        const int f = e / C, c = e - f * C;
+        const double *fs = sums + (size_t)f * REP * 3 * C;
+        double sa = 0.0, sb = 0.0;
+        for (int rp = 0; rp < REP; ++rp) { sa += fs[((size_t)rp * 3 + 0) * C + c]; sb += fs[((size_t)rp * 3 + 1) * C + c]; }
+        const double count = fm.count[f];
+        ab[(size_t)f * 2 * C + c] = (float)(sa / count);
+        ab[(size_t)f * 2 * C + C + c] = (float)(sb / count);
+    }
+}
+
 // backward, pass 2: dz = (y > 0) ? inv * (dyh - s1/N - yhat * s2/N) : 0 ; dbias[c] += sum dz (over ALL frames)
 template <int TRIP>
 __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dyh, const float *__restrict__ y,
@@ -346,7 +359,7 @@ extern "C" int mvx_bn_relu_backward_frames(const float *dyhat, const float *y, c
     MVX_CHECK_ARG(mvx_build_frame_map(fm, frames_host, row_kind, rows, count));
     hipStream_t st = (hipStream_t)stream;
     const size_t slots = (size_t)REP * 3 * channels * fm.F;
-    if (!(flags & MVX_FLAG_PREZEROED)) {
+    if (!(flags & (MVX_FLAG_PREZEROED | MVX_FLAG_SUMS_READY))) {
         hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * (slots + 2), st);
         if (e != hipSuccess) return (int)e;
     }
@@ -360,8 +373,11 @@ extern "C" int mvx_bn_relu_backward_frames(const float *dyhat, const float *y, c
         const unsigned blocks = (unsigned)(((size_t)rows + rpb - 1) / rpb);
         unsigned *counters = (unsigned *)(scratch + slots);           // [0] pass 2 (bias gradient), [1] pass 1 ((a, b) finalisation)
         float *ab = (float *)(scratch + slots + 2);
-        hipLaunchKernelGGL(bn_bwd_reduce<BWD_TRIP>, dim3(blocks), dim3(256), 0, st, dyhat, y, mean_inv, scratch, (size_t)rows,
-                           channels, rpb, fm, counters + 1, ab);
+        if (flags & MVX_FLAG_SUMS_READY)      // the producer of dyhat accumulated (sum g, sum g yhat) in its epilogue
+            hipLaunchKernelGGL(bn_bwd_ab, dim3(1), dim3(256), 0, st, (const double *)scratch, channels, fm, ab);
+        else
+            hipLaunchKernelGGL(bn_bwd_reduce<BWD_TRIP>, dim3(blocks), dim3(256), 0, st, dyhat, y, mean_inv, scratch, (size_t)rows,
+                               channels, rpb, fm, counters + 1, ab);
         MVX_LAUNCH_CHECK();
         hipLaunchKernelGGL(bn_bwd_apply<BWD_TRIP>, dim3(blocks), dim3(256), 0, st, dyhat, y, mean_inv, (const float *)ab, dz,
                            dbias ? scratch + 2 * channels : (double *)nullptr, row_w, (size_t)rows, channels,

@@ -29,7 +29,7 @@ struct FrameMap;
 int mvxi_linear_forward_split(const float *x, int ldx, const float *w, int ldw, const float *bias, float *y,
                               int ldy, double *stats, const float *row_w, long long rows, int k, int n, int relu,
                               unsigned *fin_counter, double fin_eps, float *fin_mean_inv, const FrameMap &fm, int pieces,
-                              hipStream_t st);
+                              hipStream_t st, const float *bn_y = nullptr, int bn_ldy = 0, const float *bn_mi = nullptr);
 int mvxi_linear_wgrad_split(const float *x, int ldx, const float *dz, int lddz, float *slabs, long long rows, int k, int n,
                             long long rows_per_strip, long long strips, int pieces, hipStream_t st);
 int mvxi_wgrad_step_list(const int32_t *in_halo_flags, int din, int dout, int ntiles, int stride_d, int pad_d, int *list,

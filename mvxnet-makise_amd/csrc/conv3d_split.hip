@@ -109,7 +109,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_splitT(const float *__re
                                                                const unsigned char *__restrict__ out_mask,
                                                                const float *__restrict__ bg_pre, int border_active,
                                                                const int *__restrict__ only_tiles,
-                                                               unsigned long long *__restrict__ exec_stages) {
+                                                               unsigned long long *__restrict__ exec_stages,
+                                                               const float *__restrict__ bn_y, const float *__restrict__ bn_mi) {
+    // bn_y != NULL (dense input-gradient launches): the output is dL/dyhat of the BatchNorm-ed layer whose pre-BN output is bn_y
+    // ([planes][H][W][Cout], mean / inverse std bn_mi [F][2][Cout]); `stats` is then that layer's BatchNorm-BACKWARD accumulator
+    // [F][REP][3][Cout] and takes sum g and sum g * yhat -- the reduction pass of mvx_bn_relu_backward_frames
+    // (MVX_FLAG_SUMS_READY) from the tile in registers, for one extra read of bn_y in the epilogue
     constexpr int THT = TH * MT, HHT = THT + 2;
     constexpr int ROWBT = NP * BKT * 2 + 16;                 // bytes per LDS row
     constexpr int HROW = (HW * ROWBT + 255) / 256 * 256;     // halo row pitch
@@ -404,6 +409,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_splitT(const float *__re
 #pragma unroll
             for (int r = 0; r < 16; ++r) site_on |= (mk[r] ? 1u : 0u) << r;
         }
+        float yh0[16], yh1[16];                          // yhat of the BatchNorm-backward sums (loads first, clamped addresses)
+        if (bn_y) {
+            const float *fmi = bn_mi + (size_t)(d / g.Dout) * 2 * g.Cout;
+            const float m0 = fmi[n0], m1 = fmi[n1], i0 = fmi[g.Cout + n0], i1 = fmi[g.Cout + n1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int gy = min(py + (row >> 4), g.H - 1), gx = min(tx0 + (row & 15), g.W - 1);
+                const float *yp = bn_y + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout;
+                yh0[r] = yp[n0];
+                yh1[r] = yp[n1];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { yh0[r] = (yh0[r] - m0) * i0; yh1[r] = (yh1[r] - m1) * i1; }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -415,8 +435,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_splitT(const float *__re
                 float *o = out + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout;
                 o[n0] = v0;
                 o[n1] = v1;
-                s1a += v0; s2a += v0 * v0;
-                s1b += v1; s2b += v1 * v1;
+                s1a += v0; s2a += v0 * (bn_y ? yh0[r] : v0);
+                s1b += v1; s2b += v1 * (bn_y ? yh1[r] : v1);
             }
         }
     }
@@ -433,8 +453,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_splitT(const float *__re
             const double t = (double)s_red[0][tid] + (double)s_red[1][tid] + (double)s_red[2][tid] + (double)s_red[3][tid];
             const int which = tid / BN, c = tid % BN;
             const unsigned rep = (blockIdx.x + blockIdx.y * gridDim.x) % MVX_REP;
-            double *fstats = stats + (size_t)(d / g.Dout) * MVX_REP * 2 * g.Cout;       // the plane's frame
-            atomicAdd(fstats + ((size_t)rep * 2 + which) * g.Cout + nb * BN + c, t);
+            const int sst = bn_y ? 3 : 2;             // slots per replica: (sum, sum of squares) or (sum g, sum g yhat, dbias)
+            double *fstats = stats + (size_t)(d / g.Dout) * MVX_REP * sst * g.Cout;     // the plane's frame
+            atomicAdd(fstats + ((size_t)rep * sst + which) * g.Cout + nb * BN + c, t);
         }
     }
 }
@@ -453,7 +474,7 @@ extern "C" int mvx_tuning_set(int32_t key, int64_t value) {
 static void launch_gather_split(hipStream_t st, int np, int planes, int nblocks, const float *in, const unsigned short *wsp,
                                 const float *bias, float *out, double *stats, const Geom &g, int relu, const int *in_hflag,
                                 const unsigned char *out_mask, const float *bg_pre, int border_active, const int *only_tiles,
-                                unsigned long long *exec_stages) {
+                                unsigned long long *exec_stages, const float *bn_y = nullptr, const float *bn_mi = nullptr) {
     const int tiles_x = (int)mvx_cdiv(g.W, TW);
     const long long units16 = (long long)tiles_x * mvx_cdiv(g.H, TH2) * planes * nblocks;
     const bool big = units16 >= g_split16_min_units;
@@ -463,10 +484,10 @@ static void launch_gather_split(hipStream_t st, int np, int planes, int nblocks,
     do {                                                                                                                             \
         if (win)                                                                                                                     \
             hipLaunchKernelGGL((conv3d_gather_splitT<NP_, BK_, MT_, true>), grid, dim3(256), 0, st, in, wsp, bias, out, stats, g,    \
-                               relu, in_hflag, out_mask, bg_pre, border_active, only_tiles, exec_stages);                            \
+                               relu, in_hflag, out_mask, bg_pre, border_active, only_tiles, exec_stages, bn_y, bn_mi);               \
         else                                                                                                                         \
             hipLaunchKernelGGL((conv3d_gather_splitT<NP_, BK_, MT_, false>), grid, dim3(256), 0, st, in, wsp, bias, out, stats, g,   \
-                               relu, in_hflag, out_mask, bg_pre, border_active, only_tiles, exec_stages);                            \
+                               relu, in_hflag, out_mask, bg_pre, border_active, only_tiles, exec_stages, bn_y, bn_mi);               \
     } while (0)
     if (np == 3) { if (big) MVX_GO(3, 16, 2); else MVX_GO(3, 32, 1); }
     else         { if (big) MVX_GO(2, 32, 2); else MVX_GO(2, 32, 1); }
@@ -889,6 +910,28 @@ extern "C" int mvx_conv2d_forward_split_frames(const float *in, const void *wspl
 extern "C" int mvx_conv2d_dgrad_split_frames(const float *dz, const void *wsplit_dgrad, float *dx, int32_t h, int32_t w,
                                              int32_t cin, int32_t cout, int32_t flags, int32_t n_frames, void *stream) {
     return launch_dgrad_split(dz, wsplit_dgrad, dx, 1, 1, h, w, cin, cout, 1, 1, flags, nullptr, nullptr, n_frames, stream);
+}
+
+// Input gradient of a stride-1 3x3 layer with the BatchNorm-backward reduction of the layer BELOW folded into the epilogue: dx
+// is that layer's dL/dyhat; bn_y / bn_mean_inv its saved pre-BN output [n_frames][h][w][cin] and statistics [n_frames][2][cin];
+// bn_scratch the scratch of its mvx_bn_relu_backward_frames call, which then runs with MVX_FLAG_SUMS_READY.
+extern "C" int mvx_conv2d_dgrad_split_bnsums_frames(const float *dz, const void *wsplit_dgrad, float *dx, int32_t h, int32_t w,
+                                                    int32_t cin, int32_t cout, int32_t flags, const float *bn_y,
+                                                    const float *bn_mean_inv, double *bn_scratch, int32_t n_frames, void *stream) {
+    MVX_CHECK_ARG(dz && wsplit_dgrad && dx && bn_y && bn_mean_inv && bn_scratch);
+    MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES && !(flags & MVX_FLAG_TAPS2));
+    int rc = check_geom(1, 1, h, w, cout, cin, 1, 1);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (!(flags & MVX_FLAG_PREZEROED)) {
+        hipError_t e = hipMemsetAsync(bn_scratch, 0, mvx_bn_backward_scratch_bytes_frames(cin, n_frames), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    Geom g{1, 1, h, w, cout, cin, 1, 1, 1, n_frames};
+    launch_gather_split(st, pieces_of(flags), n_frames, cin / BN, dz, (const unsigned short *)wsplit_dgrad, nullptr, dx, bn_scratch, g,
+                        0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, bn_y, bn_mean_inv);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
 }
 
 static int conv2d_wgrad_split_strips(int cin) {

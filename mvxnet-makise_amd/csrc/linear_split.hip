@@ -27,7 +27,13 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
                                                         int ldy, double *__restrict__ stats, const float *__restrict__ row_w,
                                                         long long R, int K, int N, int relu,
                                                         unsigned *__restrict__ done_counter, double fin_eps,
-                                                        float *__restrict__ fin_mean_inv, FrameMap fm) {
+                                                        float *__restrict__ fin_mean_inv, FrameMap fm,
+                                                        const float *__restrict__ bn_y, int bn_ldy,
+                                                        const float *__restrict__ bn_mi) {
+    // bn_y != NULL (input-gradient GEMMs): the rows written are dL/dyhat of the BatchNorm-ed layer whose pre-BN output is bn_y
+    // (mean / inverse std bn_mi [F][2][N]); `stats` is then that layer's BatchNorm-BACKWARD accumulator [F][REP][3][N] and takes
+    // sum g and sum g * yhat per frame -- the reduction pass of mvx_bn_relu_backward_frames (MVX_FLAG_SUMS_READY) from the tile
+    // in registers, at the price of one read of bn_y in the epilogue instead of a pass over both tensors
     constexpr int ROWB = NP * BK * 2 + 16;         // LDS row: NP pieces of BK bf16 + 16 B pad (an odd number of 16-byte slots)
     constexpr int PQ = BK / 4;                     // float4 per row and chunk
     constexpr int XV = BM * BK / 4 / 256;          // float4 per thread for the x tile
@@ -165,7 +171,20 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int c = n0 + t * 32 + li;
+                const int cc = c < N ? c : N - 1;
                 s1[t] = 0.0; s2[t] = 0.0;
+                float mch = 0.f, ich = 1.f;
+                float yv[16];
+                if (bn_y) {                                   // all loads of this column first (clamped addresses), then the sums
+                    mch = bn_mi[(size_t)f * 2 * N + cc];
+                    ich = bn_mi[(size_t)f * 2 * N + N + cc];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const long long gr = r0 + wv * 32 + row;
+                        yv[r] = bn_y[(gr < R ? gr : R - 1) * bn_ldy + cc];
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -174,8 +193,9 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
                     asm volatile("" : "+v"(v));
                     if (gr < R && c < N && gr >= lo && gr < hi) {
                         const double rw = (double)rwv[r];
+                        const double q = bn_y ? (double)((yv[r] - mch) * ich) : (double)v;
                         s1[t] += rw * (double)v;
-                        s2[t] += rw * (double)v * (double)v;
+                        s2[t] += rw * (double)v * q;
                     }
                 }
             }
@@ -186,12 +206,13 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
                 if (lh == 0) { s_red[wv][t * 32 + li] = a; s_red[wv][BNL + t * 32 + li] = b; }
             }
             __syncthreads();
-            double *fstats = stats + (size_t)f * MVX_REP * 2 * N;
+            const int sst = bn_y ? 3 : 2;                  // slots per replica: (sum, sum of squares) or (sum g, sum g yhat, dbias)
+            double *fstats = stats + (size_t)f * MVX_REP * sst * N;
             for (int e = tid; e < 2 * BNL; e += 256) {
                 const int which = e / BNL, c = e % BNL;
                 if (n0 + c < N) {
                     const double t = s_red[0][e] + s_red[1][e] + s_red[2][e] + s_red[3][e];
-                    atomicAdd(fstats + ((size_t)(blockIdx.y % MVX_REP) * 2 + which) * N + n0 + c, t);
+                    atomicAdd(fstats + ((size_t)(blockIdx.y % MVX_REP) * sst + which) * N + n0 + c, t);
                 }
             }
         }
@@ -325,14 +346,14 @@ int mvxi_linear_wgrad_split(const float *x, int ldx, const float *dz, int lddz, 
 int mvxi_linear_forward_split(const float *x, int ldx, const float *w, int ldw, const float *bias, float *y,
                               int ldy, double *stats, const float *row_w, long long rows, int k, int n, int relu,
                               unsigned *fin_counter, double fin_eps, float *fin_mean_inv, const FrameMap &fm, int pieces,
-                              hipStream_t st) {
+                              hipStream_t st, const float *bn_y, int bn_ldy, const float *bn_mi) {
     const dim3 grid(mvx_cdiv(n, BNL), mvx_cdiv(rows, BM));
     if (pieces == 3)
         hipLaunchKernelGGL((linear_fwd_split<3, 32>), grid, dim3(256), 0, st, x, ldx, w, ldw, bias, y, ldy, stats, row_w, rows, k, n,
-                           relu, fin_counter, fin_eps, fin_mean_inv, fm);
+                           relu, fin_counter, fin_eps, fin_mean_inv, fm, bn_y, bn_ldy, bn_mi);
     else
         hipLaunchKernelGGL((linear_fwd_split<2, 64>), grid, dim3(256), 0, st, x, ldx, w, ldw, bias, y, ldy, stats, row_w, rows, k, n,
-                           relu, fin_counter, fin_eps, fin_mean_inv, fm);
+                           relu, fin_counter, fin_eps, fin_mean_inv, fm, bn_y, bn_ldy, bn_mi);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

@@ -54,6 +54,7 @@ PROTOTYPES = {
     'mvx_bn_relu_backward': (_i32, [_p, _p, _p, _f64, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     'mvx_linear_splitk_workspace_bytes': (_sz, [_i64, _i32]),
     'mvx_linear_forward': (_i32, [_p, _i32, _p, _i32, _i32, _p, _p, _i32, _p, _p, _i64, _i32, _i32, _i32, _p, _sz, _p]),
+    'mvx_linear_dgrad_bnsums_frames': (_i32, [_p, _i32, _p, _i32, _p, _i32, _i64, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _i32, _p]),
     'mvx_linear_wgrad_workspace_bytes': (_sz, [_i64, _i32, _i32]),
     'mvx_linear_wgrad': (_i32, [_p, _i32, _p, _i32, _p, _i64, _i32, _i32, _i32, _p, _sz, _p]),
     'mvx_vfe_bn_max_concat': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p]),
@@ -102,6 +103,7 @@ PROTOTYPES = {
                                                 _i32, _p]),
     'mvx_conv2d_forward_split_frames': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_conv2d_dgrad_split_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    'mvx_conv2d_dgrad_split_bnsums_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p]),
     'mvx_conv2d_wgrad_split_workspace_bytes_frames': (_sz, [_i32, _i32, _i32, _i32, _i32]),
     'mvx_conv2d_wgrad_split_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _sz, _i32, _p]),
     'mvx_plane_tap_sums_workspace_bytes': (_sz, [_i32, _i32]),

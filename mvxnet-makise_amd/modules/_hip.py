@@ -13,6 +13,7 @@ _ws_cache = {}
 STATS_REPLICAS = 32      # MVX_STATS_REPLICAS of include/mvx_hip.h
 FLAG_RELU, FLAG_PREZEROED, FLAG_ACCUMULATE, FLAG_CONV2D = 1, 2, 4, 8      # MVX_FLAG_* of include/mvx_hip.h
 FLAG_SPLIT = 64                                                          # MVX_FLAG_SPLIT: bf16x3 arithmetic of the wide row GEMMs
+FLAG_SUMS_READY = 256                                                    # MVX_FLAG_SUMS_READY: the BatchNorm-backward sums were accumulated by the producer of dyhat
 FLAG_SPLIT3 = 128                                                        # MVX_FLAG_SPLIT3: three bf16 pieces per operand (bf16x6, fp32-grade)
 
 

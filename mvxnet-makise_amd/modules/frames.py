@@ -127,20 +127,46 @@ def bn_apply(y, mi, fs, kind):
     return out
 
 
-def bn_relu_backward(dyhat, y, mi, fs, kind, row_w, dbias_into, dz=None):
-    """dz (may alias dyhat); the bias gradient is ADDED to ``dbias_into`` (summed over the frames)."""
+def bn_relu_backward(dyhat, y, mi, fs, kind, row_w, dbias_into, dz=None, sums=None):
+    """dz (may alias dyhat); the bias gradient is ADDED to ``dbias_into`` (summed over the frames).  ``sums``: the scratch the
+    producer of ``dyhat`` accumulated the reduction into (rows_dgrad_bnsums): no reduction pass then."""
     C = mi.shape[-1]
     rows = y.numel() // C
     if dz is None:
         dz = torch.empty_like(y)
     if ('bn_bwd_rows' if kind != X.ROWS_GRID else 'bn_bwd_grid') in KNOCKOUT:
         return dz
-    scratch, fz = _hip._acc_f64((X.lib.mvx_bn_backward_scratch_bytes_frames(C, fs.F) // 8,), y.device)
-    with _hip._timed_bytes('bn_relu_backward', 5 * y.numel() * 4):
+    if sums is not None:
+        scratch, fz = sums, _hip.FLAG_SUMS_READY
+    else:
+        scratch, fz = _hip._acc_f64((X.lib.mvx_bn_backward_scratch_bytes_frames(C, fs.F) // 8,), y.device)
+    with _hip._timed_bytes('bn_relu_backward', (3 if sums is not None else 5) * y.numel() * 4):
         X.check(X.lib.mvx_bn_relu_backward_frames(X.ptr(dyhat), X.ptr(y), X.ptr(mi), 1.0, X.ptr(dz), X.ptr(dbias_into),
                                                   X.ptr(scratch), X.ptr(row_w), rows, C, _hip.FLAG_ACCUMULATE | fz,
                                                   fs.desc.ref(), kind, X.stream()), 'mvx_bn_relu_backward_frames')
     return dz
+
+
+BN_SUMS_FUSED = os.environ.get('MVX_BN_SUMS_FUSED', '1') != '0'     # BatchNorm-backward reduction in the epilogue of the producing input-gradient kernel
+
+
+def rows_dgrad_bnsums(dz, w2, y_below, mi_below, fs, kind):
+    """dx = dz w2 (the input gradient of a row layer) AND the BatchNorm-backward sums of the layer below -- whose dL/dyhat dx is
+    -- from the output tile in registers (mvx_linear_dgrad_bnsums_frames).  Returns (dx, scratch) or None when the call does not
+    qualify (exact-f32 arithmetic, narrow layer): the caller then uses _rows_dgrad + the reduction pass."""
+    sp = _hip.row_split('dgrad')
+    N = w2.shape[1]
+    if not (BN_SUMS_FUSED and sp and N > 64 and 'lin_dgrad' not in KNOCKOUT and 'bn_bwd_rows' not in KNOCKOUT):
+        return None
+    wt = _hip.transposed_weight(w2)                     # row-major [N][K']: both operands read along k
+    dx = torch.empty((dz.shape[0], N), dtype=torch.float32, device=dz.device)
+    scratch, fz = _hip._acc_f64((X.lib.mvx_bn_backward_scratch_bytes_frames(N, fs.F) // 8,), dz.device)
+    with _hip._Timed('linear_dgrad', 2.0 * dz.shape[0] * dz.shape[1] * N if _hip.KERNEL_TIMERS is not None else 0):
+        X.check(X.lib.mvx_linear_dgrad_bnsums_frames(_hip._vptr(dz), _hip._ld(dz), _hip._vptr(wt), _hip._ld(wt), X.ptr(dx), N,
+                                                     dz.shape[0], dz.shape[1], N, _hip.split_flags(sp, True) | fz, X.ptr(y_below),
+                                                     y_below.shape[1], X.ptr(mi_below), X.ptr(scratch), fs.desc.ref(), kind,
+                                                     X.stream()), 'mvx_linear_dgrad_bnsums_frames')
+    return dx, scratch
 
 
 _GRAD_TARGETS = None        # id(parameter) -> buffer the gradient is ADDED into instead of .grad (a second lane of frame sets)
@@ -631,12 +657,18 @@ def rows_backward(model, S, dfeat):
     X.check(X.lib.mvx_vfe_compact_input_backward_frames(X.ptr(gx), Fc, Rt, Vt, X.ptr(gim), X.ptr(scratch), fs.desc.ref(),
                                                         X.stream()), 'mvx_vfe_compact_input_backward_frames')
     # ---- fusion MLP, last layer first; the sampled features carry no gradient
-    gx = gim
+    gx, sums = gim, None
     for i in range(len(S.fusion) - 1, -1, -1):
         x, w, b, y, mi = S.fusion[i]
-        dz = bn_relu_backward(gx, y, mi, fs, X.ROWS_FUSION, fs.fusion_row_w, _grad_of(b))
+        dz = bn_relu_backward(gx, y, mi, fs, X.ROWS_FUSION, fs.fusion_row_w, _grad_of(b), sums=sums)
         if i == 0:
             _hip.mark_tail(dev)          # the step's last weight gradient follows: everything else of the bucket may go out (parallel.py)
         _linear_wgrad_side(x, dz, w)
         if i > 0:
-            gx = _rows_dgrad(dz, w.reshape(w.shape[0], -1))
+            # the input gradient is dL/dyhat of layer i - 1: its BatchNorm-backward sums come out of the same kernel
+            below = S.fusion[i - 1]
+            fused = rows_dgrad_bnsums(dz, w.reshape(w.shape[0], -1), below[3], below[4], fs, X.ROWS_FUSION)
+            if fused is not None:
+                gx, sums = fused
+            else:
+                gx, sums = _rows_dgrad(dz, w.reshape(w.shape[0], -1)), None
