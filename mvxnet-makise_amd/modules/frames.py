@@ -147,7 +147,11 @@ def bn_relu_backward(dyhat, y, mi, fs, kind, row_w, dbias_into, dz=None, sums=No
     return dz
 
 
-BN_SUMS_FUSED = os.environ.get('MVX_BN_SUMS_FUSED', '1') != '0'     # BatchNorm-backward reduction in the epilogue of the producing input-gradient kernel
+# BatchNorm-backward reduction in the epilogue of the producing input-gradient kernel (VERDICT r03 #1a).  Built, tested
+# (tests/test_frames_gpu.py, tests/test_rpn_gpu.py) and measured on MI355X in bf16x6: hot 413.0 vs 418.0 frames/s, full 190.9 vs
+# 190.8 with the separate reduction pass -- the extra read of y in the epilogue of an MFMA kernel on the critical path costs what
+# the HBM-bound pass did beside the side-stream weight gradients.  OFF by default; MVX_BN_SUMS_FUSED=1 switches it on.
+BN_SUMS_FUSED = os.environ.get('MVX_BN_SUMS_FUSED', '0') != '0'
 
 
 def rows_dgrad_bnsums(dz, w2, y_below, mi_below, fs, kind):
