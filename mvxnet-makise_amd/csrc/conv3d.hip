@@ -891,6 +891,36 @@ __device__ __forceinline__ bf16x8 w4s_frag(const unsigned short *row0, const uns
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// One staged tile (8 x 16 sites = eight 16-site k steps) of conv3d_wgrad4s for tap group GRP (compile time, like
+// wgrad4_mfma_step: the tap offsets are constants and the loop unrolls without branches).  All operand fragments of a k step
+// are fetched before its MFMAs, so the transpose reads of one tap are in flight under the MFMAs of the previous one.
+template <bool T2, int NP, int GRP>
+__device__ __forceinline__ void wgrad4s_mfma_step(const unsigned short (*__restrict__ s_x)[2][HH * HW][32],
+                                                  const unsigned short (*__restrict__ s_z)[2][TH * TW][32], f32x16 (&acc)[5],
+                                                  int wm, int wn, int pcol, int kq, unsigned slots) {
+    if (T2 && slots == 0u) return;
+    constexpr int NC = w4_ncomp(T2, GRP);
+#pragma unroll 2
+    for (int ks16 = 0; ks16 < TH; ++ks16) {       // 16 sites (one patch row) per MFMA k step
+        const int zr0 = ks16 * TW + kq, zr1 = zr0 + 4;
+        bf16x8 bz[NP], ax[NC][NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) bz[p] = w4s_frag(&s_z[p][wn][zr0][pcol], &s_z[p][wn][zr1][pcol]);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int t9 = w4_own(T2, GRP, i);
+            const int hr0 = (ks16 + t9 / 3) * HW + (t9 % 3) + kq, hr1 = hr0 + 4;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) ax[i][p] = w4s_frag(&s_x[p][wm][hr0][pcol], &s_x[p][wm][hr1][pcol]);
+        }
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            if (T2 && !((slots >> i) & 1u)) continue;
+            split_mac1<NP>(acc[i], ax[i], bz);
+        }
+    }
+}
+
 template <bool T2, int NP>
 __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4s(const float *__restrict__ in,
                                                              const float *__restrict__ dz,
@@ -1006,27 +1036,8 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4s(const float *__rest
         __syncthreads();
         const int nxt = next_live(cur + 1);
         load_step(nxt < nsteps ? nxt : cur);          // unconditional (see conv3d_gather_pf): the last one is dropped
-        if (!(T2 && slots == 0u)) {
-#pragma unroll 2
-            for (int ks16 = 0; ks16 < TH; ++ks16) {   // 16 sites (one patch row) per MFMA k step
-                const int zr0 = ks16 * TW + kbase + q, zr1 = zr0 + 4;
-                bf16x8 bz[NP];
-#pragma unroll
-                for (int p = 0; p < NP; ++p) bz[p] = w4s_frag(&s_z[p][wn][zr0][pcol], &s_z[p][wn][zr1][pcol]);
-#pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    const int t9 = grp == 0 ? w4_own(T2, 0, i) : w4_own(T2, 1, i);
-                    const int ncomp = grp == 0 ? w4_ncomp(T2, 0) : w4_ncomp(T2, 1);
-                    if (i >= ncomp) continue;
-                    if (T2 && !((slots >> i) & 1u)) continue;
-                    const int hr0 = (ks16 + t9 / 3) * HW + (t9 % 3) + kbase + q, hr1 = hr0 + 4;
-                    bf16x8 ax[NP];
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) ax[p] = w4s_frag(&s_x[p][wm][hr0][pcol], &s_x[p][wm][hr1][pcol]);
-                    split_mac1<NP>(acc[i], ax, bz);
-                }
-            }
-        }
+        if (grp == 0) wgrad4s_mfma_step<T2, NP, 0>(s_x, s_z, acc, wm, wn, pcol, kbase + q, slots);
+        else wgrad4s_mfma_step<T2, NP, 1>(s_x, s_z, acc, wm, wn, pcol, kbase + q, slots);
         cur = nxt;
     }
     // slab[strip][kd][tap][c (Cin)][n (64)]: every tap is written by the group that owns it (zeros where nothing was computed)

@@ -296,7 +296,9 @@ __global__ __launch_bounds__(256) void linear_wgrad_split(const float *__restric
         }
         __syncthreads();
         if (rr + WRS < rend) load_tiles(rr + WRS);
-        if (wave_on) {
+        {   // every wave computes (a wave whose 64 x 64 block lies outside n x k multiplies staged zeros and stores nothing): a
+            // branch around the MFMAs made the compiler keep the accumulators in VGPRs across the loop and copy all 64 of them into
+            // AGPRs and back around the MFMA block of EVERY row step (64 v_accvgpr_write per 48 MFMAs in the ISA)
 #pragma unroll
             for (int ks = 0; ks < WRS / 16; ++ks) {
                 const int r0 = ks * 16 + kbase + q, r1 = r0 + 4;
