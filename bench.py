@@ -730,12 +730,24 @@ def _run(args, rank, world, dev):
             roof = conv_roofline(timers, 0)
             if not args.timed_only:
                 roof['isolated'] = isolated_conv_roofline(dev, main_math)
+            # HBM bytes per launch from the PMC passes (profiles/traffic.json, written by tools/pmc_summary.py): printed only when
+            # the file was measured on the SAME kernel sources and arithmetic that ran here (hash of the .hip files)
             tpath = os.path.join(REPO, 'profiles', 'traffic.json')
-            if os.path.exists(tpath) and main_math == 'f32':
+            if os.path.exists(tpath):
+                import hashlib
                 with open(tpath) as fh:
                     tj = json.load(fh)
-                roof['traffic'] = tj.get('conv3d_gather_pw_hbm_bytes_per_launch_r03', tj.get('conv3d_gather_pw_hbm_bytes_per_launch_r02'))
-                roof['traffic_note'] = tj.get('note_r03', tj.get('note_r02', 'see profiles/'))
+                hsh = hashlib.sha256()
+                for f in tj.get('source_files', []):
+                    with open(os.path.join(REPO, 'mvxnet-makise_amd', 'csrc', f), 'rb') as fh:
+                        hsh.update(fh.read())
+                same_kernel = ('splitT<3' in tj.get('kernel', '')) == (main_math == 'bf16x6') and \
+                              ('gather_pw' in tj.get('kernel', '')) == (main_math == 'f32')
+                if tj.get('source_sha16') == hsh.hexdigest()[:16] and same_kernel:
+                    roof['traffic'] = tj['hbm_bytes_per_launch']
+                    roof['traffic_note'] = 'PMC FETCH_SIZE x2 + WRITE_SIZE of %s, %s' % (tj['kernel'], tj.get('from', 'profiles/'))
+                else:
+                    roof['traffic_note'] = 'profiles/traffic.json was measured on other kernel sources / arithmetic: not printed'
             metric = 'KITTI frames/sec (voxelize+VFE+fusion+3Dconv fwd+bwd)'
         elif args.mode == 'fusion':
             workload = ('%s, %d raw pts -> %d pts, T=35, %d frames/GPU/step: crop+cropToSight+lidar2Img (KITTI 2011_09_26 calibration), '

@@ -38,6 +38,7 @@ class FrameSet:
         self.real_off = None
         self.desc = None
         self.sampled = None          # (FPN features of the real rows, status word) when sampled with the preparation (sample_rows)
+        self.grid = None             # voxel index grid + activity masks / tile flags of the three CML layers (grid_activity), same
 
     # -- step 1 (enqueue only): dense-row -> compact-row map of all frames, real-row offsets stay on the device
     def enqueue_map(self):
@@ -75,7 +76,8 @@ class FrameSet:
     def hand_over(self, stream):
         """The set was built on another stream (input preparation): keep its tensors alive for ``stream`` too."""
         for t in (self.voxels, self.coords, self.row_map, self.rows_sel, self.n_real_dev, self.real_off_dev, self.voff,
-                  self.vcnt, self.row_w, self.fusion_row_w) + (tuple(self.sampled) if self.sampled is not None else ()):
+                  self.vcnt, self.row_w, self.fusion_row_w) + (tuple(self.sampled) if self.sampled is not None else ()) + \
+                 (tuple(self.grid['tensors']) if self.grid is not None else ()):
             t.record_stream(stream)
 
 
@@ -305,6 +307,46 @@ def _vfe_forward(bb, fs, x, S, eps):
     return feat, S
 
 
+def grid_activity(model, fs):
+    """Everything of the CML forward that depends on the voxel COORDINATES only (no parameter, no activation): the voxel index
+    grid of the sparse first layer and the site-level activity of the three layers' outputs -- masks, halo / tile flags, the
+    tile set of layer 2's restricted backward (csrc/activity.hip; VoxelNet.py:16-22, voxelnet/Pipe.py:36-42).  ~0.2 ms of small
+    dependent launches in front of the first convolution: the training pipeline runs it with the input preparation of the NEXT
+    step on the preparation stream (pipeline.prepare_frame_set(..., grid=model)), like the FPN sampling."""
+    bb = model.backbone
+    dev = fs.voxels.device
+    F, Vt = fs.F, fs.Vt
+    D0, H, W = cfg.voxelshape[2], cfg.voxelshape[0], cfg.voxelshape[1]
+    ntl = _hip.n_tiles(H, W)
+    idx_grid = torch.empty((X.lib.mvx_index_grid_bytes_frames(D0, H, W, F) // 4,), dtype=torch.int32, device=dev)
+    st2 = torch.zeros((1,), dtype=torch.int32, device=dev)
+    X.check(X.lib.mvx_index_grid_frames(X.ptr(fs.coords), Vt, D0, H, W, X.ptr(idx_grid), X.ptr(st2), fs.desc.ref(), X.stream()),
+            'mvx_index_grid_frames')
+    tensors = [idx_grid, st2]
+    layers = []
+    src, is_index, din = idx_grid, True, D0
+    for li, m in enumerate((bb.cml.conv1, bb.cml.conv2, bb.cml.conv3)):
+        sd, pd = m._sd, m._pd
+        dout = _hip.conv_out_depth(din, sd, pd)
+        mask = torch.empty((F * dout, H, W), dtype=torch.uint8, device=dev)
+        hflag = torch.empty((F * dout, ntl), dtype=torch.int32, device=dev)
+        tflag = torch.empty_like(hflag)
+        X.check(X.lib.mvx_activity_dilate_frames(X.ptr(src), 1 if is_index else 0, din, dout, H, W, sd, pd, 0 if li == 0 else 1,
+                                                 X.ptr(mask), X.ptr(hflag), X.ptr(tflag), F, X.stream()), 'mvx_activity_dilate_frames')
+        layers.append((mask, hflag, tflag))
+        tensors += [mask, hflag, tflag]
+        src, is_index, din = mask, False, dout
+    # the tiles layer 2's own restricted backward touches (from layer 1's and layer 2's tile flags)
+    c2 = bb.cml.conv2
+    d1 = _hip.conv_out_depth(D0, bb.cml.conv1._sd, bb.cml.conv1._pd)
+    d2 = _hip.conv_out_depth(d1, c2._sd, c2._pd)
+    bflag2 = torch.empty((F * d2, ntl), dtype=torch.int32, device=dev)
+    X.check(X.lib.mvx_tile_dilate_flags_frames(X.ptr(layers[0][2]), X.ptr(layers[1][2]), d1, d2, H, W, c2._sd, c2._pd, X.ptr(bflag2), F,
+                                               X.stream()), 'mvx_tile_dilate_flags_frames')
+    tensors.append(bflag2)
+    return dict(idx_grid=idx_grid, status=st2, layers=layers, bflag2=bflag2, tensors=tensors)
+
+
 def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
     """reindex + CML + the BEV reshape (VoxelNet.py:16-36) for the whole frame set: (Vt,128) -> (F,128,H,W).
     The channels-last CML output [F*D3][H][W][64] stays in ``S.x3`` (what modules/rpn_frames.py reads); with
@@ -321,11 +363,10 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
     cout, cin = w1.shape[0], w1.shape[1]
     w_all = w1.permute(2, 3, 4, 0, 1).reshape(27 * cout, cin).contiguous()
     P, _ = _hip.linear_forward(feat, w_all, None, relu=False, want_stats=False, split=_hip.row_split('conv1'))
-    idx_grid = torch.empty((X.lib.mvx_index_grid_bytes_frames(D0, H, W, F) // 4,), dtype=torch.int32, device=dev)
-    st2 = torch.zeros((1,), dtype=torch.int32, device=dev)
-    X.check(X.lib.mvx_index_grid_frames(X.ptr(fs.coords), Vt, D0, H, W, X.ptr(idx_grid), X.ptr(st2), fs.desc.ref(), X.stream()),
-            'mvx_index_grid_frames')
-    status_sink.append(st2)
+    ga = fs.grid if fs.grid is not None else grid_activity(model, fs)      # made with the input preparation when the set was prepared a step ahead
+    fs.grid = None
+    idx_grid = ga['idx_grid']
+    status_sink.append(ga['status'])
     D1 = _hip.conv_out_depth(D0, c1._sd, c1._pd)
     y1 = torch.empty((F * D1, H, W, cout), dtype=torch.float32, device=dev)
     stats, fz = _stats(F, cout, dev)
@@ -339,14 +380,8 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
             'mvx_bn_finalize_frames')
     ntl = _hip.n_tiles(H, W)
 
-    def dilate(src, is_index, din, sd, pd, border):
-        dout = _hip.conv_out_depth(din, sd, pd)
-        mask = torch.empty((F * dout, H, W), dtype=torch.uint8, device=dev)
-        hflag = torch.empty((F * dout, ntl), dtype=torch.int32, device=dev)
-        tflag = torch.empty_like(hflag)
-        X.check(X.lib.mvx_activity_dilate_frames(X.ptr(src), 1 if is_index else 0, din, dout, H, W, sd, pd, 1 if border else 0,
-                                                 X.ptr(mask), X.ptr(hflag), X.ptr(tflag), F, X.stream()), 'mvx_activity_dilate_frames')
-        return mask, hflag, tflag
+    def dilate(li):
+        return ga['layers'][li]
 
     def background(bg_pre, bias, mi, planes, C_):
         c_out = torch.empty((F * planes, C_), dtype=torch.float32, device=dev)
@@ -369,7 +404,7 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
                                                     X.stream()), 'mvx_bn_apply_tiles_frames')
         return out
 
-    mask1, hflag1, tflag1 = dilate(idx_grid, True, D0, c1._sd, c1._pd, False)
+    mask1, hflag1, tflag1 = dilate(0)
     cc1, ybg1 = background(None, b1, mi1, D1, cout)
     x1 = bn_apply_bg(y1, mi1, cc1, tflag1, D1)
     S.conv1 = dict(feat=feat, w=w1, b=b1, w_all=w_all, y=y1, mi=mi1, c=cc1, ybg=ybg1, tflag=tflag1, D0=D0, D1=D1)
@@ -394,7 +429,7 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
         bg_pre = bg_all[:F * dout]
         X.check(X.lib.mvx_conv3d_background_taps_frames(X.ptr(w), X.ptr(c_in), din, dout, ci, co, sd, pd, X.ptr(bg_all), F,
                                                         X.stream()), 'mvx_conv3d_background_taps_frames')
-        mask_o, hflag_o, tflag_o = dilate(mask_in, False, din, sd, pd, True)
+        mask_o, hflag_o, tflag_o = dilate(li + 1)
         y = torch.empty((F * dout, H, W, co), dtype=torch.float32, device=dev)
         stats, fz = _stats(F, co, dev)
         fin = _hip._fin_slot(dev, fz)
@@ -430,9 +465,7 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
                    bflag_in=bflag_in, split=split)
         if li == 0:
             # the tiles this layer's own restricted backward touches
-            bflag_o = torch.empty((F * dout, ntl), dtype=torch.int32, device=dev)
-            X.check(X.lib.mvx_tile_dilate_flags_frames(X.ptr(tflag_in), X.ptr(tflag_o), din, dout, H, W, sd, pd, X.ptr(bflag_o), F,
-                                                       X.stream()), 'mvx_tile_dilate_flags_frames')
+            bflag_o = ga['bflag2']
             rec.update(c_out=c_o, ybg_out=ybg_o, bflag_out=bflag_o)
             c_in, bflag_in = c_o, bflag_o
         S.convs.append(rec)

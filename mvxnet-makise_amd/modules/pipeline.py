@@ -291,7 +291,10 @@ def train_step_frames(model, batch, grad_mid, imsize, ready=None, prepare_next=N
 BATCHED = _os.environ.get('MVX_FRAME_SETS', '1') != '0'
 
 
-def prepare_frame_set(batch, T=None, sample=None):
+PREGRID = _os.environ.get('MVX_PREGRID', '1') != '0'          # ... and the coordinate-only bookkeeping of the CML (frames.grid_activity)
+
+
+def prepare_frame_set(batch, T=None, sample=None, grid=None):
     """Voxelize the batch and build the frame set (voxels of all non-empty frames back to back + compact-row maps) with TWO
     host reads: the voxel counts, then the real-row offsets.  Returns (frame set or None, frame ids in it, voxel counts of
     every frame of the batch, status word).  ``sample`` = (fusion head, imsize): also sample the FPN features of the real
@@ -316,6 +319,8 @@ def prepare_frame_set(batch, T=None, sample=None):
     fs.finish_map(real_off)
     if sample is not None:
         fs.sampled = fr.sample_rows(sample[0], fs, [batch.fpn_levels[f] for f in live], sample[1])
+    if grid is not None:
+        fs.grid = fr.grid_activity(grid, fs)          # ``grid`` = the model (layer geometry only; no parameter is read)
     return fs, live, counts, status_v
 
 
@@ -500,7 +505,7 @@ def train_step_frame_set(model, batch, grad_mid, imsize, ready=None, prepare_nex
                 prep = _prep_stream(dev)
                 _wait_created(prep, prepare_next)
                 with torch.cuda.stream(prep):
-                    nr = prepare_frame_set(prepare_next, sample=(model.head, imsize) if PRESAMPLE else None)
+                    nr = prepare_frame_set(prepare_next, sample=(model.head, imsize) if PRESAMPLE else None, grid=model if PREGRID else None)
                     ev = torch.cuda.Event()
                     ev.record(prep)
                 next_ready = nr + (ev,)
@@ -730,7 +735,7 @@ def train_step_full(model, batch, targets, criterion, anchors, imsize, ready=Non
                 prep = _prep_stream(dev)
                 _wait_created(prep, nb)
                 with torch.cuda.stream(prep):
-                    nr = prepare_frame_set(nb, sample=(model.head, hw) if PRESAMPLE else None)
+                    nr = prepare_frame_set(nb, sample=(model.head, hw) if PRESAMPLE else None, grid=model if PREGRID else None)
                     nt = target_fn()
                     ev = torch.cuda.Event()
                     ev.record(prep)

@@ -8,8 +8,8 @@ HBM bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950 counts a wide coalesced read at ha
 import collections, csv, glob, json, re, sys
 
 root, dst = sys.argv[1], sys.argv[2]
-WANT = ('conv3d_gather_pw', 'conv3d_wgrad4', 'linear_fwd', 'linear_wgrad', 'bn_apply', 'bn_bwd_apply', 'bn_bwd_reduce', 'bnb_tiles',
-        'sparse_conv_output', 'vox_gather', 'vox_insert', 'vox_scan', 'crop_write', 'feature_sample_rows')
+WANT = ('conv3d_gather_pw', 'conv3d_gather_splitT', 'conv3d_wgrad4', 'linear_fwd', 'linear_wgrad', 'bn_apply', 'bn_bwd_apply',
+        'bn_bwd_reduce', 'bnb_tiles', 'sparse_conv_output', 'vox_gather', 'vox_insert', 'vox_scan', 'crop_write', 'feature_sample_rows')
 
 
 def short(name):
@@ -28,14 +28,16 @@ def load(sub):
     return acc
 
 
-sq, fe, wr = load('pmc_sq'), load('pmc_fetch'), load('pmc_write')
+sq, sq2, fe, wr = load('pmc_sq'), load('pmc_sq2'), load('pmc_fetch'), load('pmc_write')
 out = {'source': root, 'kernels': {}}
 for k in sorted(sq):
     c = {n: sum(v) / len(v) for n, v in sq[k].items()}
+    c.update({n: sum(v) / len(v) for n, v in sq2.get(k, {}).items()})
     cyc = c.get('GRBM_GUI_ACTIVE', 0) / 8.0
     e = {'launches_in_pass': len(sq[k].get('GRBM_GUI_ACTIVE', [])), 'cycles_per_xcd': cyc,
          'mfma_busy_frac': c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (cyc * 1024) if cyc else None,
-         'executed_matrix_gflop': c.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0) * 512 / 1e9,
+         'executed_matrix_gflop': (c.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0) + c.get('SQ_INSTS_VALU_MFMA_MOPS_BF16', 0)) * 512 / 1e9,
+         'mops_f32_raw': c.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0), 'mops_bf16_raw': c.get('SQ_INSTS_VALU_MFMA_MOPS_BF16', 0),
          'lds_bank_conflict_cycles': c.get('SQ_LDS_BANK_CONFLICT', 0), 'lds_active_cycles': c.get('SQ_LDS_IDX_ACTIVE', 0),
          'wave_cycles': c.get('SQ_WAVE_CYCLES', 0)}
     if k in fe and 'FETCH_SIZE' in fe[k]:
@@ -48,3 +50,29 @@ for k, e in out['kernels'].items():
     print('%-28s n=%-3d mfma busy %-6s  matrix GFLOP %-8.2f fetch %-9s write %-9s' % (
         k, e['launches_in_pass'], '%.3f' % e['mfma_busy_frac'] if e['mfma_busy_frac'] is not None else '-', e['executed_matrix_gflop'],
         '%.1f MB' % (e.get('hbm_fetch_bytes', 0) / 1e6), '%.1f MB' % (e.get('hbm_write_bytes', 0) / 1e6)))
+
+# profiles/traffic.json: measured HBM bytes per launch of the dominant kernel, tagged with the hash of the kernel's sources so
+# that bench.py prints `roofline.traffic` only for the kernel it was measured on
+import hashlib, os
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def source_sha(files):
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(REPO, 'mvxnet-makise_amd', 'csrc', f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+dom = [k for k in out['kernels'] if k.startswith('conv3d_gather_splitT<3, 16, 2')] or [k for k in out['kernels'] if k.startswith('conv3d_gather_pw')]
+if dom and len(sys.argv) > 3:
+    e = out['kernels'][dom[0]]
+    split = dom[0].startswith('conv3d_gather_splitT')
+    files = ['conv3d_split.hip', 'split_common.h', 'common.h'] if split else ['conv3d.hip', 'common.h']
+    tj = {'kernel': dom[0], 'source_files': files, 'source_sha16': source_sha(files),
+          'hbm_bytes_per_launch': e.get('hbm_fetch_bytes', 0) + e.get('hbm_write_bytes', 0),
+          'fetch_bytes': e.get('hbm_fetch_bytes'), 'write_bytes': e.get('hbm_write_bytes'), 'launches_in_pass': e['launches_in_pass'],
+          'corrections': 'FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count of wide reads), WRITE_SIZE KiB x 1024 raw; separate --pmc passes',
+          'from': root}
+    json.dump(tj, open(sys.argv[3], 'w'), indent=1)
+    print('traffic ->', sys.argv[3], tj['hbm_bytes_per_launch'] / 1e6, 'MB per launch')
