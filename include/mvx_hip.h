@@ -12,7 +12,9 @@
  *     hipError_t from the launch;
  *   - stream-ordered, no hidden synchronisation, no persistent allocation: scratch memory
  *     comes from the caller (`*_workspace_bytes` queries), so calls can be graph-captured;
- *   - re-entrant: no global mutable state.
+ *   - re-entrant and stream-ordered: no entry point keeps state between calls.  Process-wide exceptions, none of them in a
+ *     data path: the launch-shape tuning values of mvx_tuning_set (read at launch time; the tests set them to force a
+ *     kernel shape) and the diagnostic counter behind mvx_launch_count.
  */
 #ifndef MVX_HIP_H
 #define MVX_HIP_H
@@ -41,7 +43,8 @@ extern "C" {
                                   [planes][3][cout] per-depth-tap constants | [planes][9][cout] image-border position classes): in interior
                                   tiles a depth tap whose source halo holds no active site is not executed (its constant is added in the
                                   epilogue), and a border tile without any active source is filled from the class constants (exact rewrites) */
-#define MVX_FLAG_SPLIT 64      /* mvx_linear_forward*, mvx_linear_wgrad: bf16x3 split arithmetic (three bf16 MFMAs per product, f32 accumulate, ~2e-5 per
+#define MVX_FLAG_SPLIT 64      /* mvx_linear_forward*, mvx_linear_wgrad, mvx_conv3d_wgrad, mvx_conv3d_wgrad_bg*, mvx_conv2d_wgrad_frames (conv3d_wgrad4s: cin a
+                                  multiple of 64): bf16x3 split arithmetic (three bf16 MFMAs per product, f32 accumulate, ~2e-5 per
                                   product: the row-GEMM side of `convmath: bf16x3`) for layers with n > 64, k % 4 == 0, 16-byte aligned
                                   operands and a row-major weight (w_transposed = 0); other calls run the exact-f32 kernel */
 

@@ -283,54 +283,20 @@ class CRB3d(nn.Module):
         return res
 
 
-class CRB2dConvFunction(torch.autograd.Function):
-    """channels-last (H,W,Cin) -> BN(ReLU(conv2d 3x3, stride 1, padding 1)) (H,W,Cout), one frame, on the conv3d MFMA
-    kernels (a depth-1 tensor with pad_d = 1: only the middle depth tap exists).  RPN blocks (voxelnet/Pipe.py:45-75,
-    Blocks.py:31-40); ``transposed``: the weight is a ConvTranspose2d kernel (Cin,Cout,3,3) with stride 1 / padding 1,
-    which is the same convolution with the kernel flipped and its channel axes swapped (DeCRB2d, Blocks.py:42-51)."""
-
-    @staticmethod
-    def forward(ctx, x, w, b, eps, packer, transposed):
-        wc = w.flip(2, 3).transpose(0, 1).contiguous() if transposed else w
-        cout = wc.shape[0]
-        wpk = packer(False, False) if packer is not None else _hip.conv3d_pack(wc, False)
-        y, stats = _hip.conv3d_forward(x.unsqueeze(0), wpk, b, cout, 1, 1, relu=True, want_stats=True)
-        count = y.numel() // cout
-        mi = _hip.bn_finalize(stats, count, eps)
-        out = _hip.bn_apply(y, mi)
-        ctx.save_for_backward(x, w, y, mi)
-        ctx.meta = (count, packer, transposed)
-        ctx.params = (w, b)
-        return out.squeeze(0)
-
-    @staticmethod
-    def backward(ctx, g):
-        x, w, y, mi = ctx.saved_tensors
-        count, packer, transposed = ctx.meta
-        wc = w.flip(2, 3).transpose(0, 1).contiguous() if transposed else w
-        dz, db = _hip.bn_relu_backward(g.contiguous().unsqueeze(0), y, mi, count, True,
-                                       dbias_out=_hip.bias_sink_of(ctx.params[1]))
-        db = _hip.accumulate_grad(ctx.params[1], db)
-        sink = None if transposed else _hip.sink_of(ctx.params[0])
-        dw = _hip.conv3d_wgrad(x.unsqueeze(0), dz, 1, 1, accumulate_into=sink, two_d=True)
-        if transposed and dw is not None:
-            dw = dw.transpose(0, 1).flip(2, 3)
-        if transposed:
-            dw = _hip.accumulate_grad(ctx.params[0], dw.contiguous())
-        dx = None
-        if ctx.needs_input_grad[0]:
-            wpd = packer(True, False) if packer is not None else _hip.conv3d_pack(wc, True)
-            dx = _hip.conv3d_dgrad(dz, wpd, 1, x.shape[2], 1, 1).squeeze(0)
-        return dx, dw, db, None, None, None
+# RPN.forward_torch -- the torch / MIOpen comparison path of the tests -- sets this while it runs: the 2-D blocks then stay on
+# the torch modules unless config `crb2d_hip` is 'force' (tests of the per-block HIP path through that entry)
+_IN_FORWARD_TORCH = [False]
 
 
-def _hip3x3_pays(x, cout):
-    """The conv3d kernels work on 8x16-site tiles x 64 output channels: below one workgroup per CU (the 100x88 and
-    50x44 maps of RPN blocks 2 and 3) MIOpen's Winograd kernels are faster (measured), so those stay there."""
-    if cfg.config.get('crb2d_hip', False) == 'force':     # tests: every eligible block regardless of its size
-        return True
-    h, w = x.shape[2], x.shape[3]
-    return ((h + 7) // 8) * ((w + 15) // 16) * (cout // 64) >= 256
+def _block2d_on(x, kind):
+    """Does a stand-alone CRB2d / DeCRB2d call with this input run on the HIP kernels (modules/layers/Block2d.py)?  Yes by
+    default (config `crb2d_hip: true`) for float32 CUDA tensors of batch 1 whose hyper-parameters the kernels cover."""
+    mode = cfg.config.get('crb2d_hip', True)
+    if _IN_FORWARD_TORCH[0] and mode != 'force':
+        return False
+    if not (mode and kind is not None and x.is_cuda and x.dim() == 4 and x.shape[0] == 1 and x.dtype == torch.float32):
+        return False
+    return kind != 's2' or (x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)
 
 
 def _nchw(x):
@@ -350,8 +316,9 @@ class _TorchBN2d(nn.Module):
 class CRB2d(nn.Module):
     """Conv2d -> ReLU -> BN2d (reference Blocks.py:31-40).  1x1 kernels (the fusion MLP,
     imhead/Pipe.py:89,91) run on the HIP row-GEMM.  3x3 kernels belong to the RPN, whose forward runs as one node on the HIP
-    kernels (voxelnet/Pipe.py RPNFunction); this module's own forward for them is the torch / MIOpen comparison path
-    (``rpn_hip: false``), optionally per block on the MFMA conv kernels (``crb2d_hip``)."""
+    kernels (voxelnet/Pipe.py RPNFunction); called on its own, a 3x3 block (stride 1 or 2) is ONE autograd node on the same
+    kernels (modules/layers/Block2d.py; config ``crb2d_hip``, default true).  The torch / MIOpen form remains for CPU tensors,
+    batches, channel counts the MFMA tiles do not cover, and as the comparison path of the tests (RPN.forward_torch)."""
 
     def __init__(self, cin, cout, k, s, p):
         super().__init__()
@@ -359,9 +326,10 @@ class CRB2d(nn.Module):
         self.conv = nn.Conv2d(cin, cout, k, s, p)
         self.bn = nn.BatchNorm2d(cout, eps=cfg.eps, affine=cfg.bnaffine, track_running_stats=cfg.bntrack)
         self._pointwise = (k == 1 and s == 1 and p == 0)
-        # 3x3 / stride 1 / padding 1 with MFMA-sized channel counts: the conv3d kernels (depth 1)
-        self._hip3x3 = (k == 3 and s == 1 and p == 1 and cin % 64 == 0 and cout % 64 == 0)
-        object.__setattr__(self, '_packer', PackedWeights(lambda: self.conv.weight))
+        from modules.layers import Block2d
+        self._kind = Block2d.kind_of('conv', k, s, p, cin, cout)
+        self._stride = s
+        object.__setattr__(self, '_pack2d', Block2d._Pack())
 
     def forward(self, x):
         if self._pointwise and x.is_cuda:
@@ -369,29 +337,31 @@ class CRB2d(nn.Module):
             rows = x.permute(0, 2, 3, 1)
             out = fcn_rows(_as_rows(rows), self.conv.weight, self.conv.bias)
             return out.reshape(rows.shape[:-1] + (out.shape[-1],)).permute(0, 3, 1, 2)
-        if (self._hip3x3 and x.is_cuda and x.shape[0] == 1 and cfg.config.get('crb2d_hip', False) and not conv_split_math()
-                and _hip3x3_pays(x, self.conv.out_channels)):
-            xc = x.squeeze(0).permute(1, 2, 0).contiguous()       # (H,W,C): no copy for channels_last input
-            out = CRB2dConvFunction.apply(xc, self.conv.weight, self.conv.bias, cfg.eps, self._packer, False)
-            return out.permute(2, 0, 1).unsqueeze(0)               # logical NCHW, channels_last storage
+        if _block2d_on(x, self._kind):
+            from modules.layers.Block2d import Block2dFunction
+            return Block2dFunction.apply(x, self.conv.weight, self.conv.bias, self._kind, self._stride, self._pack2d)
         return F.batch_norm(F.relu(self.conv(_nchw(x))), None, None, None, None, True, 0.0, cfg.eps)
 
 
 class DeCRB2d(nn.Module):
-    """ConvTranspose2d -> ReLU -> BN2d (reference Blocks.py:42-51); RPN only: used by RPN.forward_torch (the comparison path),
-    the default RPN.forward reads this module's parameters and runs modules/rpn_frames.py."""
+    """ConvTranspose2d -> ReLU -> BN2d (reference Blocks.py:42-51).  Inside the RPN the default RPN.forward reads this module's
+    parameters and runs modules/rpn_frames.py; called on its own it is ONE autograd node on the same kernels (3x3 / stride 1 as
+    a convolution with the flipped kernel, kernel = stride as a row GEMM + pixel shuffle: modules/layers/Block2d.py).  The torch
+    / MIOpen form remains as the comparison path (RPN.forward_torch) and for shapes the kernels do not cover."""
 
     def __init__(self, cin, cout, k, s, p):
         super().__init__()
         _hip.require_plain_batchnorm()
         self.deconv = nn.ConvTranspose2d(cin, cout, k, s, p)
         self.bn = nn.BatchNorm2d(cout, eps=cfg.eps, affine=cfg.bnaffine, track_running_stats=cfg.bntrack)
-        self._hip3x3 = (k == 3 and s == 1 and p == 1 and cin % 64 == 0 and cout % 64 == 0)
+        from modules.layers import Block2d
+        self._kind = Block2d.kind_of('deconv', k, s, p, cin, cout)
+        self._stride = s
+        object.__setattr__(self, '_pack2d', Block2d._Pack())
 
     def forward(self, x):
-        if (self._hip3x3 and x.is_cuda and x.shape[0] == 1 and cfg.config.get('crb2d_hip', False) and not conv_split_math()
-                and _hip3x3_pays(x, self.deconv.out_channels)):
-            xc = x.squeeze(0).permute(1, 2, 0).contiguous()
-            out = CRB2dConvFunction.apply(xc, self.deconv.weight, self.deconv.bias, cfg.eps, None, True)
-            return _nchw(out.permute(2, 0, 1).unsqueeze(0))        # joins the other (NCHW) branches in RPN's concat
+        if _block2d_on(x, self._kind):
+            from modules.layers.Block2d import Block2dFunction
+            out = Block2dFunction.apply(x, self.deconv.weight, self.deconv.bias, self._kind, self._stride, self._pack2d)
+            return _nchw(out) if _IN_FORWARD_TORCH[0] else out    # inside RPN.forward_torch: joins the other (NCHW) branches
         return F.batch_norm(F.relu(self.deconv(_nchw(x))), None, None, None, None, True, 0.0, cfg.eps)

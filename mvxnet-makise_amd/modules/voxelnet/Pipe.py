@@ -199,11 +199,18 @@ class RPN(nn.Module):
         return torch.sigmoid(v[..., :2]).permute(0, 3, 1, 2), v[..., 2:].permute(0, 3, 1, 2)
 
     def forward_torch(self, x):
-        x1 = self.blk1(x)
-        x2 = self.blk2(x1)
-        x3 = self.blk3(x2)
-        up = torch.concat([self.deconv1(x1), self.deconv2(x2), self.deconv3(x3)], dim=1)
-        return torch.sigmoid(self.cls(up)), self.reg(up)
+        """The per-module path: every block through its own forward.  On the torch modules (MIOpen) this is the comparison
+        path of the tests; config ``crb2d_hip: force`` sends the blocks through their stand-alone HIP nodes instead."""
+        from modules.layers import Blocks
+        old, Blocks._IN_FORWARD_TORCH[0] = Blocks._IN_FORWARD_TORCH[0], True
+        try:
+            x1 = self.blk1(x)
+            x2 = self.blk2(x1)
+            x3 = self.blk3(x2)
+            up = torch.concat([self.deconv1(x1), self.deconv2(x2), self.deconv3(x3)], dim=1)
+            return torch.sigmoid(self.cls(up)), self.reg(up)
+        finally:
+            Blocks._IN_FORWARD_TORCH[0] = old
 
     def forward(self, x):
         if x.dim() == 4 and x.shape[0] == 1 and self._hip_ok(x, x.shape[2], x.shape[3]):

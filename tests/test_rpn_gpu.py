@@ -553,3 +553,39 @@ def test_rpn_and_loss_gradients_tight_at_full_size():
     assert e_loss[0] < 1e-4 and e_loss[1] < 1e-4
     assert max(d0.values()) < _RPN_GRAD_BOUND, sorted(d0.items(), key=lambda t: -t[1])[:5]
     assert min(report['mutations'].values()) > _RPN_GRAD_BOUND, report['mutations']
+
+
+@pytest.mark.parametrize('kind,args,hw', [('conv', (128, 128, 3, 1, 1), (40, 48)), ('conv', (64, 128, 3, 2, 1), (40, 48)),
+                                          ('conv', (128, 256, 3, 2, 1), (24, 32)), ('deconv', (128, 256, 3, 1, 1), (24, 32)),
+                                          ('deconv', (128, 256, 2, 2, 0), (20, 24)), ('deconv', (256, 256, 4, 4, 0), (10, 12))])
+def test_standalone_blocks_run_on_hip_nodes_and_match_float64(kind, args, hw):
+    """CRB2d / DeCRB2d called ON THEIR OWN (reference modules/layers/Blocks.py:31-51 -- not through RPN.forward) are one
+    autograd node each on this library's kernels by default (modules/layers/Block2d.py: 3x3 stride 1, 3x3 stride 2 through the
+    space-to-depth form, transposed 3x3 stride 1, kernel = stride deconvolution): library launches are counted, output, input
+    gradient and parameter gradients are compared with a float64 CPU evaluation of the same module."""
+    import copy
+    from modules import Extension as X
+    from modules.layers import CRB2d, DeCRB2d
+    torch.manual_seed(3)
+    m = (CRB2d if kind == 'conv' else DeCRB2d)(*args).to(DEV)
+    for p in m.parameters():                          # alive channels: BatchNorm without affine on a small map
+        if p.dim() == 1:
+            p.data.fill_(0.3)
+    x0 = torch.randn((1, args[0]) + hw)
+    G = torch.randn(m(x0.to(DEV)).shape)
+    n0 = X.lib.mvx_launch_count()
+    x = x0.to(DEV).requires_grad_(True)
+    y = m(x)
+    (y * G.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    assert X.lib.mvx_launch_count() - n0 >= 6, 'the block did not run on the HIP kernels'
+    ref = copy.deepcopy(m).cpu().double()
+    ref.zero_grad()
+    xr = x0.double().requires_grad_(True)
+    yr = ref(xr)
+    (yr * G.double()).sum().backward()
+    assert rel(y.detach().cpu().double(), yr.detach()) < 2e-5
+    n2 = lambda a, b: float((a.cpu().double() - b).norm() / b.norm())
+    assert n2(x.grad, xr.grad) < 1e-3
+    for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert n2(p.grad, q.grad) < 1e-3, k
