@@ -21,7 +21,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BM = 128, BNL = 128, NT = 4;
 
 // NP pieces per operand; K in chunks of BK (64 for bf16x3, 32 for bf16x6: 61 KB of LDS either way, two workgroups per CU)
-template <int NP, int BK>
+template <int NP, int BK, bool BNB>
 __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restrict__ x, int ldx, const float *__restrict__ w,
                                                         int ldw, const float *__restrict__ bias, float *__restrict__ y,
                                                         int ldy, double *__restrict__ stats, const float *__restrict__ row_w,
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
                                                         float *__restrict__ fin_mean_inv, FrameMap fm,
                                                         const float *__restrict__ bn_y, int bn_ldy,
                                                         const float *__restrict__ bn_mi) {
-    // bn_y != NULL (input-gradient GEMMs): the rows written are dL/dyhat of the BatchNorm-ed layer whose pre-BN output is bn_y
+    // BNB (compile time; input-gradient GEMMs, bn_y != NULL): the rows written are dL/dyhat of the BatchNorm-ed layer whose pre-BN output is bn_y
     // (mean / inverse std bn_mi [F][2][N]); `stats` is then that layer's BatchNorm-BACKWARD accumulator [F][REP][3][N] and takes
     // sum g and sum g * yhat per frame -- the reduction pass of mvx_bn_relu_backward_frames (MVX_FLAG_SUMS_READY) from the tile
     // in registers, at the price of one read of bn_y in the epilogue instead of a pass over both tensors
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
                 s1[t] = 0.0; s2[t] = 0.0;
                 float mch = 0.f, ich = 1.f;
                 float yv[16];
-                if (bn_y) {                                   // all loads of this column first (clamped addresses), then the sums
+                if (BNB) {                                    // all loads of this column first (clamped addresses), then the sums
                     mch = bn_mi[(size_t)f * 2 * N + cc];
                     ich = bn_mi[(size_t)f * 2 * N + N + cc];
 #pragma unroll
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
                     asm volatile("" : "+v"(v));
                     if (gr < R && c < N && gr >= lo && gr < hi) {
                         const double rw = (double)rwv[r];
-                        const double q = bn_y ? (double)((yv[r] - mch) * ich) : (double)v;
+                        const double q = BNB ? (double)((yv[r] - mch) * ich) : (double)v;
                         s1[t] += rw * (double)v;
                         s2[t] += rw * (double)v * q;
                     }
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
                 if (lh == 0) { s_red[wv][t * 32 + li] = a; s_red[wv][BNL + t * 32 + li] = b; }
             }
             __syncthreads();
-            const int sst = bn_y ? 3 : 2;                  // slots per replica: (sum, sum of squares) or (sum g, sum g yhat, dbias)
+            const int sst = BNB ? 3 : 2;                   // slots per replica: (sum, sum of squares) or (sum g, sum g yhat, dbias)
             double *fstats = stats + (size_t)f * MVX_REP * sst * N;
             for (int e = tid; e < 2 * BNL; e += 256) {
                 const int which = e / BNL, c = e % BNL;
@@ -350,12 +350,12 @@ int mvxi_linear_forward_split(const float *x, int ldx, const float *w, int ldw, 
                               unsigned *fin_counter, double fin_eps, float *fin_mean_inv, const FrameMap &fm, int pieces,
                               hipStream_t st, const float *bn_y, int bn_ldy, const float *bn_mi) {
     const dim3 grid(mvx_cdiv(n, BNL), mvx_cdiv(rows, BM));
-    if (pieces == 3)
-        hipLaunchKernelGGL((linear_fwd_split<3, 32>), grid, dim3(256), 0, st, x, ldx, w, ldw, bias, y, ldy, stats, row_w, rows, k, n,
-                           relu, fin_counter, fin_eps, fin_mean_inv, fm, bn_y, bn_ldy, bn_mi);
-    else
-        hipLaunchKernelGGL((linear_fwd_split<2, 64>), grid, dim3(256), 0, st, x, ldx, w, ldw, bias, y, ldy, stats, row_w, rows, k, n,
-                           relu, fin_counter, fin_eps, fin_mean_inv, fm, bn_y, bn_ldy, bn_mi);
+#define MVX_GO(NP_, BK_, B_)                                                                                                       \
+    hipLaunchKernelGGL((linear_fwd_split<NP_, BK_, B_>), grid, dim3(256), 0, st, x, ldx, w, ldw, bias, y, ldy, stats, row_w, rows, k, \
+                       n, relu, fin_counter, fin_eps, fin_mean_inv, fm, bn_y, bn_ldy, bn_mi)
+    if (pieces == 3) { if (bn_y) MVX_GO(3, 32, true); else MVX_GO(3, 32, false); }
+    else             { if (bn_y) MVX_GO(2, 64, true); else MVX_GO(2, 64, false); }
+#undef MVX_GO
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
