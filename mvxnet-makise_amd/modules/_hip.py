@@ -55,6 +55,8 @@ def side_stream(device):
     return st
 
 
+if os.environ.get('MVX_SPLIT16_MIN_UNITS'):        # developer knob: launch-shape threshold of the split gather (csrc/conv3d_split.hip)
+    X.check(X.lib.mvx_tuning_set(1, int(os.environ['MVX_SPLIT16_MIN_UNITS'])), 'mvx_tuning_set')
 SIDE_KEEP = os.environ.get('MVX_SIDE_KEEP', '1') != '0'
 _KEEP = {}          # device index -> tensors read by side-stream kernels since the last join
 _COMM = {}
