@@ -826,11 +826,20 @@ def _run(args, rank, world, dev):
                 other[name] = {'launches': len(evs), 'avg_launch_ms': tms / len(evs)}
                 fl = sum(_hip.timer_value(f) for _, _, f in evs)
                 if fl > 0:
-                    mult, peak = (MATH_MFMAS[main_math], BF16_MFMA_PEAK_TFLOPS) if (main_math != 'f32' and name in ('conv3d_wgrad_bg', 'rpn_conv', 'rpn_wgrad')) \
-                        else (1.0, FP32_MFMA_PEAK_TFLOPS)
-                    other[name]['executed_tflops'] = mult * fl / (tms * 1e-3) / 1e12
+                    # algorithmic = one multiply-add per product; in a split arithmetic the matrix pipes execute 3 (bf16x3) or 6
+                    # (bf16x6) bf16 MFMA products per algorithmic one.  The convolution kernels run split as a whole; of the row
+                    # GEMMs the wide layers (n > 64: 99 % of the FLOPs) do, the narrow ones stay on the exact-f32 kernel -- their
+                    # figure is therefore an upper bound by < 1 %
+                    split_k = main_math != 'f32'
+                    if main_math == 'bf16x3' and name == 'linear_fwd':
+                        split_k = False                      # forward rows stay exact f32 in that mode (modules/_hip.py row_split)
+                    alg = fl / (tms * 1e-3) / 1e12
+                    mult, peak = (MATH_MFMAS[main_math], BF16_MFMA_PEAK_TFLOPS) if split_k else (1.0, FP32_MFMA_PEAK_TFLOPS)
+                    other[name]['algorithmic_tflops'] = alg
+                    other[name]['executed_tflops'] = mult * alg
                     other[name]['peak_tflops'] = peak
                     other[name]['frac'] = other[name]['executed_tflops'] / peak
+                    other[name]['arithmetic'] = main_math if split_k else 'f32'
         out['other_kernels'] = other
         if world > 1 and bucket.times:
             # the gradient exchange's own duration (events on its streams): 'early' = everything but the step's last weight
