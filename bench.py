@@ -277,8 +277,8 @@ def cpu_baseline_vfe(P, workload, budget_s=20.0):
                       '(V,35,23) rows, median %.3f s/frame' % (workload, P, len(times) - 1, med)}
 
 
-MATH_PIECES = {'f32': 0, 'bf16x3': 2, 'bf16x6': 3}          # bf16 pieces per f32 operand
-MATH_MFMAS = {'f32': 1.0, 'bf16x3': 3.0, 'bf16x6': 6.0}      # bf16 MFMAs per product (executed matrix FLOPs = this x the algorithmic ones)
+MATH_PIECES = {'f32': 0, 'bf16x3': 2, 'bf16x6': 3, 'fp16x3': 4}   # split code of modules/_hip.py (4 = two fp16 pieces)
+MATH_MFMAS = {'f32': 1.0, 'bf16x3': 3.0, 'bf16x6': 6.0, 'fp16x3': 3.0}   # 16-bit MFMAs per product (executed matrix FLOPs = this x the algorithmic ones)
 
 
 def isolated_conv_roofline(dev, math):
@@ -323,7 +323,7 @@ def parse_args(argv=None):
     ap.add_argument('--frames', type=int, default=None, help='frames per GPU per step (default 4; 16 in --mode vfe, 2 in --mode fusion)')
     ap.add_argument('--points', type=int, default=20000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--convmath', choices=['bf16x6', 'bf16x3', 'f32'], default=None, help='override config.yml convmath')
+    ap.add_argument('--convmath', choices=['fp16x3', 'bf16x6', 'bf16x3', 'f32'], default=None, help='override config.yml convmath')
     ap.add_argument('--no-alt', action='store_true', help='skip the extra runs (other workload, bf16x3 arithmetic, the other BASELINE configs)')
     ap.add_argument('--timed-only', action='store_true',
                     help='only warm-up + the timed steps (no alt / isolated / CPU passes): what profiles/ is made from')
@@ -622,8 +622,8 @@ def _run(args, rank, world, dev):
             r.update(achieved=mm * alg, peak=BF16_MFMA_PEAK_TFLOPS, frac=mm * alg / BF16_MFMA_PEAK_TFLOPS, algorithmic_tflops=alg,
                      flop_per_launch=mm * r['flop_per_launch'],
                      kernel='conv3d_gather_splitT (conv2 / conv3 forward + dgrad of all frames of the step)',
-                     note='%s split MFMA (v_mfma_f32_32x32x16_bf16, f32 accumulate), EXECUTED stages counted by the kernel '
-                          'x 4.72 MFLOP x %d MFMAs per product, against the dense bf16 peak; skipped background tiles are not credited;'
+                     note='%s split MFMA (v_mfma_f32_32x32x16_{bf16,f16}, f32 accumulate), EXECUTED stages counted by the kernel '
+                          'x 4.72 MFLOP x %d MFMAs per product, against the dense bf16 / fp16 peak; skipped background tiles are not credited;'
                           ' algorithmic_tflops = the same work priced as one multiply-add per product' % (math, int(mm)))
         return r
 
@@ -679,7 +679,7 @@ def _run(args, rank, world, dev):
         state['ready'] = None
         # (2) the same step in the other arithmetics (config.yml convmath: exact-f32 MFMA, bf16x6 = three bf16 pieces / six MFMAs per
         # product = fp32-grade, bf16x3 = two pieces / three MFMAs, ~2e-5 per product)
-        for math in ('f32', 'bf16x6', 'bf16x3'):
+        for math in ('f32', 'fp16x3', 'bf16x6', 'bf16x3'):
             if math == main_math:
                 continue
             cfg.config['convmath'] = math
@@ -693,6 +693,8 @@ def _run(args, rank, world, dev):
             alt.append({'workload': args.workload, 'convmath': math, 'value': frames_total * max(3, args.steps // 2) / dt3,
                         'unit': 'frames/s', 'ms_per_step': dt3 / max(3, args.steps // 2) * 1e3, 'roofline': r3,
                         'note': {'f32': 'every MFMA kernel on the exact-f32 matrix instruction (v_mfma_f32_32x32x2_f32)',
+                                 'fp16x3': 'convolutions and wide row GEMMs, forward and both gradients, in two fp16 pieces per operand / three '
+                                           'MFMAs per product (22 mantissa bits, fp32-grade), gradients scaled by their device-side amax',
                                  'bf16x6': 'convolutions and wide row GEMMs, forward and both gradients, in three-piece split arithmetic',
                                  'bf16x3': 'convolutions, row-GEMM gradients and the RPN GEMMs in two-piece split arithmetic (forward maps '
                                            'within 1e-5 of exact f32 on the CML; gradients carry 2e-5 per product)'}[math]})
@@ -703,7 +705,7 @@ def _run(args, rank, world, dev):
         # 2 frames), config 3 (--mode full, 4 frames: exact f32 and "bf16 MFMA conv" = convmath bf16x3)
         import copy
         for cfg_no, mode, math in ((2, 'vfe', main_math), (4, 'fusion', main_math), (3, 'full', main_math)) + tuple(
-                (3, 'full', m) for m in ('f32', 'bf16x6', 'bf16x3') if m != main_math):
+                (3, 'full', m) for m in ('f32', 'fp16x3', 'bf16x6', 'bf16x3') if m != main_math):
             a2 = copy.copy(args)
             a2.mode, a2.convmath, a2.frames = mode, math, None
             a2.steps, a2.warmup = 5, 2
@@ -741,8 +743,7 @@ def _run(args, rank, world, dev):
                 for f in tj.get('source_files', []):
                     with open(os.path.join(REPO, 'mvxnet-makise_amd', 'csrc', f), 'rb') as fh:
                         hsh.update(fh.read())
-                same_kernel = ('splitT<3' in tj.get('kernel', '')) == (main_math == 'bf16x6') and \
-                              ('gather_pw' in tj.get('kernel', '')) == (main_math == 'f32')
+                same_kernel = tj.get('convmath') == main_math
                 if tj.get('source_sha16') == hsh.hexdigest()[:16] and same_kernel:
                     roof['traffic'] = tj['hbm_bytes_per_launch']
                     roof['traffic_note'] = 'PMC FETCH_SIZE x2 + WRITE_SIZE of %s, %s' % (tj['kernel'], tj.get('from', 'profiles/'))

@@ -14,7 +14,8 @@
  *     comes from the caller (`*_workspace_bytes` queries), so calls can be graph-captured;
  *   - re-entrant and stream-ordered: no entry point keeps state between calls.  Process-wide exceptions, none of them in a
  *     data path: the launch-shape tuning values of mvx_tuning_set (read at launch time; the tests set them to force a
- *     kernel shape) and the diagnostic counter behind mvx_launch_count.
+ *     kernel shape) and the diagnostic counter behind mvx_launch_count.  One per-THREAD exception: the operand ranges bound
+ *     by mvx_split_operand_amax apply to the calling thread's next split-arithmetic launch and are cleared by it.
  */
 #ifndef MVX_HIP_H
 #define MVX_HIP_H
@@ -50,6 +51,10 @@ extern "C" {
 
 #define MVX_FLAG_SPLIT3 128    /* with MVX_FLAG_SPLIT, and on the *_split entry points: THREE bf16 pieces per f32 operand and six bf16 MFMAs per product
                                   ("bf16x6": hi + mid + lo is the operand exactly, dropped cross terms < 2^-25: fp32-grade accuracy) instead of two / three */
+
+#define MVX_FLAG_SPLIT_F16 512  /* with MVX_FLAG_SPLIT, and on the *_split entry points: TWO fp16 pieces per f32 operand (22 mantissa bits) and three
+                                  fp16 MFMAs per product ("fp16x3": fp32-grade accuracy at the matrix work of bf16x3) -- for operands inside fp16's
+                                  range: values above 65,504 overflow and below ~1e-4 lose relative precision, so callers scale by powers of two */
 
 #define MVX_FLAG_SUMS_READY 256 /* mvx_bn_relu_backward_frames: `scratch` already holds (sum dyhat, sum dyhat * yhat) of every frame, accumulated by
                                   the kernel that PRODUCED dyhat (mvx_linear_dgrad_bnsums_frames, mvx_conv2d_dgrad_split_bnsums_frames): the
@@ -103,6 +108,21 @@ int mvx_abi_version(void);
 #define MVX_TUNE_SPLIT16_MIN_UNITS 1
 #define MVX_TUNE_GATHER_NARROW_MAX_UNITS 2
 int mvx_tuning_set(int32_t key, int64_t value);
+
+/* fp16x3 arithmetic (MVX_FLAG_SPLIT_F16): operand ranges.  An fp16 piece pair covers an f32 operand to 2^-22 while the low piece
+ * is a normal fp16 number, i.e. for magnitudes in [2^-3, 65504]; activations behind a BatchNorm and weights (scaled by a fixed
+ * 2^8 inside the library) sit there, gradients (1e-3 ... 1e-8) and foreign feature maps need not.  For those the caller binds
+ * the device address of ONE float = max |value| of the tensor, and the kernel multiplies the operand by the power of two that
+ * brings that maximum into [2^14, 2^15) and the f32 accumulator by its inverse -- powers of two change no rounding, so the
+ * result is the same function of the inputs.  amax_a / amax_b belong to the first / second f32 operand of the calling
+ * thread's NEXT launch that takes MVX_FLAG_SPLIT_F16 (convolution forward / input gradient and row GEMM: a = in / dz / x;
+ * weight gradients: a = in / x, b = dz); NULL = that operand is not scaled.  The launch consumes the binding.  The floats are
+ * read on the device in stream order: they may be written by an earlier kernel of the same stream.  Sources:
+ * mvx_bn_relu_backward_frames and mvx_bn_relu_backward_tiles_frames
+ * (dz_amax), mvx_tensor_amax for any other tensor.  Bound ranges are ignored by the other arithmetics. */
+int mvx_split_operand_amax(const float *amax_a, const float *amax_b);
+/* amax[0] = max(amax[0], max |x[i]|), i < n; amax is zeroed first unless MVX_FLAG_PREZEROED.  x 16-byte aligned. */
+int mvx_tensor_amax(const float *x, int64_t n, float *amax, int32_t flags, void *stream);
 /* Diagnostics: number of kernel launches the library has issued since it was loaded (fills excluded). */
 uint64_t mvx_launch_count(void);
 
@@ -604,7 +624,8 @@ int mvx_bn_apply_frames(const float *y, const float *mean_inv, float *out, int64
 size_t mvx_bn_backward_scratch_bytes_frames(int32_t channels, int32_t n_frames);
 int mvx_bn_relu_backward_frames(const float *dyhat, const float *y, const float *mean_inv, double count, float *dz,
                                 float *dbias, double *scratch, const float *row_w, int64_t rows, int32_t channels,
-                                int32_t flags, const mvx_frames_t *frames_host, int32_t row_kind, void *stream);
+                                int32_t flags, const mvx_frames_t *frames_host, int32_t row_kind,
+                                float *dz_amax /* NULL or 1 float: max |dz| written (mvx_split_operand_amax) */, void *stream);
 int mvx_vfe_bn_max_concat_frames(const float *y, const float *mean_inv, float *out, int32_t *argmax, int32_t n_voxels,
                                  int32_t t, int32_t channels, const int32_t *voff, const int32_t *vcnt, int32_t n_real,
                                  const mvx_frames_t *frames_host, void *stream);
@@ -676,8 +697,8 @@ size_t mvx_bn_relu_backward_tiles_workspace_bytes_frames(int32_t planes, int32_t
 int mvx_bn_relu_backward_tiles_frames(const float *dyhat, const float *y, const float *mean_inv, const float *c_bg,
                                       const float *y_bg, const float *plane_grad_sums, const int32_t *tile_flags,
                                       int32_t planes, int32_t h, int32_t w, int32_t channels, float *dz, float *dbias,
-                                      float *dz_inactive_sums, int32_t flags, void *workspace, size_t workspace_bytes,
-                                      int32_t n_frames, void *stream);
+                                      float *dz_inactive_sums, float *dz_amax /* NULL or 1 float: max |dz| written */,
+                                      int32_t flags, void *workspace, size_t workspace_bytes, int32_t n_frames, void *stream);
 /* cl f32 [n_frames * d][h][w][c]  <->  bev f32 [n_frames][c * d][h][w] */
 int mvx_cl_to_bev_frames(const float *cl, float *bev, int32_t d, int32_t h, int32_t w, int32_t channels, int32_t reverse,
                          int32_t n_frames, void *stream);

@@ -191,8 +191,9 @@ constexpr int BREP = 8;
 constexpr int BNB_MAX_PLANES = 16 * MVX_MAX_FRAMES;
 __global__ __launch_bounds__(1024) void bnb_tile_list(const int *__restrict__ tile_flags, int D, int H, int W, int ntiles,
                                                       int *__restrict__ list, int *__restrict__ n_act,
-                                                      int *__restrict__ n_inact) {
+                                                      int *__restrict__ n_inact, unsigned *__restrict__ amax_slot) {
     __shared__ int smem[17];
+    if (amax_slot && threadIdx.x == 0) *amax_slot = 0u;        // max |dz| of the apply pass starts from zero
     __shared__ int s_inact[BNB_MAX_PLANES];            // D here = ALL planes of the launch (frames x planes per frame)
     const int tiles_x = (W + ATW - 1) / ATW;
     if (threadIdx.x < BNB_MAX_PLANES) s_inact[threadIdx.x] = 0;
@@ -242,8 +243,10 @@ __global__ __launch_bounds__(256) void bnb_tiles(const float *__restrict__ dyh, 
                                                  const float *__restrict__ mi, const float *__restrict__ c_bg,
                                                  const float *__restrict__ ab, const int *__restrict__ list,
                                                  const int *__restrict__ n_act, int D, int H, int W, int C, int ntiles,
-                                                 float *__restrict__ dz, double *__restrict__ sums_all) {
+                                                 float *__restrict__ dz, double *__restrict__ sums_all,
+                                                 unsigned *__restrict__ amax_slot) {
     __shared__ float red[2][256][4];
+    float mx = 0.f;                                   // MODE 1: max |dz| this thread wrote (-> amax_slot, see mvx_wave_amax_to)
     const int tiles_x = (W + ATW - 1) / ATW;
     const int c4n = C >> 2, ct = threadIdx.x % c4n, st = threadIdx.x / c4n, spb = 256 / c4n;
     const int nact = *n_act;
@@ -289,6 +292,7 @@ __global__ __launch_bounds__(256) void bnb_tiles(const float *__restrict__ dyh, 
             o.w = v.w > 0.f ? iv.w * (g.w - (a.w + yh.w * b.w)) : 0.f;
             *(float4 *)(dz + off) = o;
             s1.x += o.x; s1.y += o.y; s1.z += o.z; s1.w += o.w;
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
     };
     for (int j = j0; j < j1; ++j) {
@@ -325,6 +329,7 @@ __global__ __launch_bounds__(256) void bnb_tiles(const float *__restrict__ dyh, 
         }
     }
     if (cur >= 0) flush(cur);
+    if (MODE == 1 && amax_slot) mvx_wave_amax_to(amax_slot, mx);
 }
 
 // a = sum_d A[d] / N ; b = (Q1 + sum_d c[d] A[d]) / N
@@ -397,8 +402,8 @@ extern "C" size_t mvx_bn_relu_backward_tiles_workspace_bytes(int32_t planes, int
 extern "C" int mvx_bn_relu_backward_tiles_frames(const float *dyhat, const float *y, const float *mean_inv, const float *c_bg,
                                                  const float *y_bg, const float *plane_grad_sums, const int32_t *tile_flags,
                                                  int32_t planes, int32_t h, int32_t w, int32_t channels, float *dz,
-                                                 float *dbias, float *dz_inactive_sums, int32_t flags, void *workspace,
-                                                 size_t workspace_bytes, int32_t n_frames, void *stream) {
+                                                 float *dbias, float *dz_inactive_sums, float *dz_amax, int32_t flags,
+                                                 void *workspace, size_t workspace_bytes, int32_t n_frames, void *stream) {
     MVX_CHECK_ARG(dyhat && y && mean_inv && c_bg && y_bg && plane_grad_sums && tile_flags && dz && workspace);
     MVX_CHECK_ARG(planes > 0 && planes <= 16 && h > 0 && w > 0 && channels > 0 && channels % 4 == 0 && 256 % (channels / 4) == 0);
     MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
@@ -412,18 +417,18 @@ extern "C" int mvx_bn_relu_backward_tiles_frames(const float *dyhat, const float
     int *n_act = list + (size_t)P * ntiles, *n_inact = n_act + 16;
     hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * BREP * (planes + 2) * channels * n_frames, st);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(bnb_tile_list, dim3(1), dim3(1024), 0, st, tile_flags, P, h, w, ntiles, list, n_act, n_inact);
+    hipLaunchKernelGGL(bnb_tile_list, dim3(1), dim3(1024), 0, st, tile_flags, P, h, w, ntiles, list, n_act, n_inact, (unsigned *)dz_amax);
     MVX_LAUNCH_CHECK();
     const double count = (double)planes * h * w;       // per frame
     const unsigned grid = (unsigned)(P * ntiles > 2048 ? 2048 : P * ntiles);
     hipLaunchKernelGGL(bnb_tiles<0>, dim3(grid), dim3(256), 0, st, dyhat, y, mean_inv, c_bg, (const float *)ab, (const int *)list,
-                       (const int *)n_act, planes, h, w, channels, ntiles, dz, sums);
+                       (const int *)n_act, planes, h, w, channels, ntiles, dz, sums, (unsigned *)nullptr);
     MVX_LAUNCH_CHECK();
     hipLaunchKernelGGL(bnb_finalize_ab, dim3(mvx_cdiv(channels, 64), n_frames), dim3(64), 0, st, (const double *)sums,
                        plane_grad_sums, c_bg, planes, channels, count, ab);
     MVX_LAUNCH_CHECK();
     hipLaunchKernelGGL(bnb_tiles<1>, dim3(grid), dim3(256), 0, st, dyhat, y, mean_inv, c_bg, (const float *)ab, (const int *)list,
-                       (const int *)n_act, planes, h, w, channels, ntiles, dz, sums);
+                       (const int *)n_act, planes, h, w, channels, ntiles, dz, sums, (unsigned *)dz_amax);
     MVX_LAUNCH_CHECK();
     if (dbias || dz_inactive_sums) {
         hipLaunchKernelGGL(bnb_dbias, dim3(mvx_cdiv(channels, 64)), dim3(64), 0, st, (const double *)sums, plane_grad_sums, c_bg,
@@ -440,7 +445,7 @@ extern "C" int mvx_bn_relu_backward_tiles(const float *dyhat, const float *y, co
                                           float *dz_inactive_sums, int32_t flags, void *workspace,
                                           size_t workspace_bytes, void *stream) {
     return mvx_bn_relu_backward_tiles_frames(dyhat, y, mean_inv, c_bg, y_bg, plane_grad_sums, tile_flags, planes, h, w, channels,
-                                             dz, dbias, dz_inactive_sums, flags, workspace, workspace_bytes, 1, stream);
+                                             dz, dbias, dz_inactive_sums, nullptr, flags, workspace, workspace_bytes, 1, stream);
 }
 
 extern "C" int mvx_activity_dilate_frames(const void *src, int32_t src_is_index, int32_t din, int32_t dout, int32_t h, int32_t w,

@@ -86,9 +86,11 @@ template <int TRIP>
 __global__ __launch_bounds__(256) void bn_bwd_reduce(const float *__restrict__ dyh, const float *__restrict__ y,
                                                      const float *__restrict__ mi, double *__restrict__ sums,
                                                      size_t rows, int C, size_t rows_per_block, FrameMap fm,
-                                                     unsigned *__restrict__ done_counter, float *__restrict__ ab) {
+                                                     unsigned *__restrict__ done_counter, float *__restrict__ ab,
+                                                     unsigned *__restrict__ amax_slot) {
     __shared__ double red[2][256][4];
     __shared__ int s_last;
+    if (amax_slot && blockIdx.x == 0 && threadIdx.x == 0) *amax_slot = 0u;      // max |dz| of the apply pass starts from zero
     const int c4 = C >> 2;
     const int rpi = max(1, 256 / c4);
     const int ct = threadIdx.x % c4, rt = threadIdx.x / c4;
@@ -168,7 +170,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const float *__restrict__ d
 }
 
 // (a, b) of every frame and channel from sums a producer's epilogue filled (MVX_FLAG_SUMS_READY): one workgroup
-__global__ __launch_bounds__(256) void bn_bwd_ab(const double *__restrict__ sums, int C, FrameMap fm, float *__restrict__ ab) {
+__global__ __launch_bounds__(256) void bn_bwd_ab(const double *__restrict__ sums, int C, FrameMap fm, float *__restrict__ ab,
+                                                 unsigned *__restrict__ amax_slot) {
+    if (amax_slot && threadIdx.x == 0) *amax_slot = 0u;
     for (int e = threadIdx.x; e < C * fm.F; e += blockDim.x) {
         const int f = e / C, c = e - f * C;
         const double *fs = sums + (size_t)f * REP * 3 * C;
@@ -187,8 +191,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dy
                                                     float *__restrict__ dz, double *__restrict__ dbias,
                                                     const float *__restrict__ row_w, size_t rows, int C,
                                                     unsigned *__restrict__ done_counter, float *__restrict__ dbias_out,
-                                                    int accumulate, size_t rows_per_block, FrameMap fm) {
+                                                    int accumulate, size_t rows_per_block, FrameMap fm,
+                                                    unsigned *__restrict__ amax_slot) {
     __shared__ double red[256][4];
+    float mx = 0.f;                                  // max |dz| this thread wrote (-> amax_slot: the fp16-piece kernels scale dz by it)
     const int c4 = C >> 2;
     const int rpi = max(1, 256 / c4);
     const int ct = threadIdx.x % c4, rt = threadIdx.x / c4;
@@ -234,6 +240,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dy
                         o.w = v[j].w > 0.f ? iv.w * (g[j].w - rw[j] * (a[3] + ((v[j].w - m.w) * iv.w) * b[3])) : 0.f;
                         *(float4 *)(dz + rr * C + col * 4) = o;
                         sb.x += o.x; sb.y += o.y; sb.z += o.z; sb.w += o.w;
+                        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
                     }
                 }
             }
@@ -251,6 +258,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dy
             __syncthreads();
         }
     }
+    if (amax_slot) mvx_wave_amax_to(amax_slot, mx);
     if (dbias && done_counter) {
         // the workgroup that finishes last folds the replicas into the bias gradient (no dbias_finish launch);
         // atomics-only protocol as in bn_finalize_by_last_block (common.h)
@@ -348,10 +356,38 @@ extern "C" size_t mvx_bn_backward_scratch_bytes_frames(int32_t channels, int32_t
     return channels > 0 && n_frames > 0 ? sizeof(double) * ((REP * 3 + 1) * (size_t)channels * n_frames + 2) : 0;
 }
 
+// amax[0] = max(amax[0], max |x[i]|) (amax zeroed first unless MVX_FLAG_PREZEROED): operand range of the fp16-piece kernels
+// for tensors no kernel of this library produced (sampled image features, the loss gradient)
+__global__ __launch_bounds__(256) void tensor_amax(const float *__restrict__ x, size_t n, unsigned *__restrict__ slot) {
+    float mx = 0.f;
+    const size_t n4 = n >> 2;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = ((const float4 *)x)[i];
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) mx = fmaxf(mx, fabsf(x[(n4 << 2) + threadIdx.x]));
+    mvx_wave_amax_to(slot, mx);
+}
+
+extern "C" int mvx_tensor_amax(const float *x, int64_t n, float *amax, int32_t flags, void *stream) {
+    MVX_CHECK_ARG(x && amax && n >= 0 && ((uintptr_t)x & 15) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (!(flags & MVX_FLAG_PREZEROED)) {
+        hipError_t e = hipMemsetAsync(amax, 0, sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (n == 0) return MVX_OK;
+    const size_t want = ((size_t)n / 4 + 255) / 256;
+    hipLaunchKernelGGL(tensor_amax, dim3((unsigned)(want > 2048 ? 2048 : (want ? want : 1))), dim3(256), 0, st, x, (size_t)n,
+                       (unsigned *)amax);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
 extern "C" int mvx_bn_relu_backward_frames(const float *dyhat, const float *y, const float *mean_inv, double count,
                                            float *dz, float *dbias, double *scratch, const float *row_w, int64_t rows,
                                            int32_t channels, int32_t flags, const mvx_frames_t *frames_host,
-                                           int32_t row_kind, void *stream) {
+                                           int32_t row_kind, float *dz_amax, void *stream) {
     MVX_CHECK_ARG(dyhat && y && mean_inv && dz && scratch && rows >= 0 && channels > 0 && channels % 4 == 0);
     MVX_CHECK_ARG(count > 0);
     MVX_CHECK_ARG(((uintptr_t)scratch & 15) == 0);          // bn_bwd_apply reads the (a, b) floats behind the sums with float4 loads
@@ -374,16 +410,20 @@ extern "C" int mvx_bn_relu_backward_frames(const float *dyhat, const float *y, c
         unsigned *counters = (unsigned *)(scratch + slots);           // [0] pass 2 (bias gradient), [1] pass 1 ((a, b) finalisation)
         float *ab = (float *)(scratch + slots + 2);
         if (flags & MVX_FLAG_SUMS_READY)      // the producer of dyhat accumulated (sum g, sum g yhat) in its epilogue
-            hipLaunchKernelGGL(bn_bwd_ab, dim3(1), dim3(256), 0, st, (const double *)scratch, channels, fm, ab);
+            hipLaunchKernelGGL(bn_bwd_ab, dim3(1), dim3(256), 0, st, (const double *)scratch, channels, fm, ab, (unsigned *)dz_amax);
         else
             hipLaunchKernelGGL(bn_bwd_reduce<BWD_TRIP>, dim3(blocks), dim3(256), 0, st, dyhat, y, mean_inv, scratch, (size_t)rows,
-                               channels, rpb, fm, counters + 1, ab);
+                               channels, rpb, fm, counters + 1, ab, (unsigned *)dz_amax);
         MVX_LAUNCH_CHECK();
         hipLaunchKernelGGL(bn_bwd_apply<BWD_TRIP>, dim3(blocks), dim3(256), 0, st, dyhat, y, mean_inv, (const float *)ab, dz,
                            dbias ? scratch + 2 * channels : (double *)nullptr, row_w, (size_t)rows, channels,
-                           counters, dbias, flags & MVX_FLAG_ACCUMULATE, rpb, fm);
+                           counters, dbias, flags & MVX_FLAG_ACCUMULATE, rpb, fm, (unsigned *)dz_amax);
         MVX_LAUNCH_CHECK();
-    } else if (dbias) {                             // no rows: the bias gradient is zero
+    } else if (dz_amax) {
+        hipError_t e = hipMemsetAsync(dz_amax, 0, sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (rows <= 0 && dbias) {                       // no rows: the bias gradient is zero
         hipLaunchKernelGGL(dbias_finish, dim3(mvx_cdiv(channels, 128)), dim3(128), 0, st, (const double *)scratch, dbias,
                            channels, flags & MVX_FLAG_ACCUMULATE);
         MVX_LAUNCH_CHECK();
@@ -395,5 +435,5 @@ extern "C" int mvx_bn_relu_backward(const float *dyhat, const float *y, const fl
                                     float *dz, float *dbias, double *scratch, const float *row_w, int64_t rows,
                                     int32_t channels, int32_t flags, void *stream) {
     return mvx_bn_relu_backward_frames(dyhat, y, mean_inv, count, dz, dbias, scratch, row_w, rows, channels, flags, nullptr,
-                                       MVX_ROWS_SINGLE, stream);
+                                       MVX_ROWS_SINGLE, nullptr, stream);
 }

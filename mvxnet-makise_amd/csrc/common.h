@@ -26,12 +26,24 @@ static inline unsigned mvx_cdiv(long long a, long long b) { return (unsigned)((a
 // ---- internal helpers shared between translation units (NOT part of the C ABI) -----------------------
 // conv3d.hip: compacted (plane, tile) step lists of the background-aware weight gradient and its closed-form term
 struct FrameMap;
+// fp16-piece operand scaling (split_common.h): the addresses bound by mvx_split_operand_amax for the calling thread's next split
+// launch; taking them clears the binding (defined in voxelize.hip)
+struct SplitAmax {
+    const float *a, *b;      // max |value| of the first / second f32 operand of the launch (device addresses), or NULL
+};
+SplitAmax mvxi_take_split_amax();
+
+// arithmetic code of the split kernels from a flags word: 2 = bf16x3, 3 = bf16x6, 4 = fp16x3 (two fp16 pieces)
+static inline int mvx_split_code(int flags) { return (flags & MVX_FLAG_SPLIT_F16) ? 4 : (flags & MVX_FLAG_SPLIT3) ? 3 : 2; }
+
 int mvxi_linear_forward_split(const float *x, int ldx, const float *w, int ldw, const float *bias, float *y,
                               int ldy, double *stats, const float *row_w, long long rows, int k, int n, int relu,
                               unsigned *fin_counter, double fin_eps, float *fin_mean_inv, const FrameMap &fm, int pieces,
-                              hipStream_t st, const float *bn_y = nullptr, int bn_ldy = 0, const float *bn_mi = nullptr);
+                              hipStream_t st, const float *bn_y = nullptr, int bn_ldy = 0, const float *bn_mi = nullptr,
+                              const SplitAmax &am = SplitAmax{nullptr, nullptr});
 int mvxi_linear_wgrad_split(const float *x, int ldx, const float *dz, int lddz, float *slabs, long long rows, int k, int n,
-                            long long rows_per_strip, long long strips, int pieces, hipStream_t st);
+                            long long rows_per_strip, long long strips, int pieces, hipStream_t st,
+                            const SplitAmax &am = SplitAmax{nullptr, nullptr});
 int mvxi_wgrad_step_list(const int32_t *in_halo_flags, int din, int dout, int ntiles, int stride_d, int pad_d, int *list,
                          int *count, hipStream_t st, int n_frames = 1);
 int mvxi_wgrad_rank1(const float *tap_sums, const float *c_in, float *dw, int din, int dout, int cin, int cout, int stride_d,
@@ -160,6 +172,14 @@ __device__ __forceinline__ int block_excl_scan_i32(int v, int *smem, int *total)
 // (mvx_drain_vmem: `s_waitcnt vmcnt(0)`; non-returning atomics are vmcnt-tracked on gfx9 and acknowledged by L2 once
 // performed) before the barrier.  No cache write-back is involved.  `s_flag` is one int of LDS.
 __device__ __forceinline__ void mvx_drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// max |value| of a tensor for the fp16-piece kernels (split_common.h): every thread brings the largest magnitude it wrote, one
+// atomic per wave folds it into the slot (a zeroed unsigned: the bit patterns of non-negative floats order like the floats)
+__device__ __forceinline__ void mvx_wave_amax_to(unsigned *slot, float mx) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(slot, __float_as_uint(mx));
+}
 
 template <typename CountOf>
 __device__ __forceinline__ void bn_finalize_core(unsigned *done_counter, unsigned total_blocks, double *stats, int C, int F,

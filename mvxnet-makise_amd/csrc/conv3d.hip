@@ -894,7 +894,7 @@ __device__ __forceinline__ bf16x8 w4s_frag(const unsigned short *row0, const uns
 // One staged tile (8 x 16 sites = eight 16-site k steps) of conv3d_wgrad4s for tap group GRP (compile time, like
 // wgrad4_mfma_step: the tap offsets are constants and the loop unrolls without branches).  All operand fragments of a k step
 // are fetched before its MFMAs, so the transpose reads of one tap are in flight under the MFMAs of the previous one.
-template <bool T2, int NP, int GRP>
+template <bool T2, int NP, int GRP, int FMT>
 __device__ __forceinline__ void wgrad4s_mfma_step(const unsigned short (*__restrict__ s_x)[2][HH * HW][32],
                                                   const unsigned short (*__restrict__ s_z)[2][TH * TW][32], f32x16 (&acc)[5],
                                                   int wm, int wn, int pcol, int kq, unsigned slots) {
@@ -916,18 +916,20 @@ __device__ __forceinline__ void wgrad4s_mfma_step(const unsigned short (*__restr
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             if (T2 && !((slots >> i) & 1u)) continue;
-            split_mac1<NP>(acc[i], ax[i], bz);
+            split_mac1<NP, FMT>(acc[i], ax[i], bz);
         }
     }
 }
 
-template <bool T2, int NP>
+template <bool T2, int NP, int FMT>
 __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4s(const float *__restrict__ in,
                                                              const float *__restrict__ dz,
                                                              float *__restrict__ slabs, Geom g,
                                                              int tiles_per_strip, const int *__restrict__ step_list,
                                                              const int *__restrict__ step_count,
-                                                             const float *__restrict__ c_in, Strips ks) {
+                                                             const float *__restrict__ c_in, Strips ks, SplitAmax am) {
+    float x_scale = 1.f, z_scale = 1.f;                       // fp16 pieces: operands scaled by their bound amax (split_common.h)
+    if constexpr (FMT == 1) { x_scale = split_scale_of(am.a); z_scale = split_scale_of(am.b); }
     __shared__ __attribute__((aligned(16))) unsigned short s_x[NP][2][HH * HW][32];      // [piece][32-channel block][halo site][channel]
     __shared__ __attribute__((aligned(16))) unsigned short s_z[NP][2][TH * TW][32];      // [piece][32-channel block][site][channel]
     const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
@@ -1019,7 +1021,8 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4s(const float *__rest
             if (c < HH * HW * 16) {
                 const int r = c >> 4, part = c & 15;
                 uint2 pc[NP];
-                split_n<NP>(xr[u][0], xr[u][1], xr[u][2], xr[u][3], pc);
+                if constexpr (FMT == 1) xr[u] *= x_scale;
+                split_n<NP, FMT>(xr[u][0], xr[u][1], xr[u][2], xr[u][3], pc);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) *(uint2 *)(&s_x[p][part >> 3][r][(part & 7) * 4]) = pc[p];
             }
@@ -1029,17 +1032,20 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4s(const float *__rest
             const int c = tid + W4_THREADS * u;
             const int r = c >> 4, part = c & 15;
             uint2 pc[NP];
-            split_n<NP>(zr[u][0], zr[u][1], zr[u][2], zr[u][3], pc);
+            if constexpr (FMT == 1) zr[u] *= z_scale;
+            split_n<NP, FMT>(zr[u][0], zr[u][1], zr[u][2], zr[u][3], pc);
 #pragma unroll
             for (int p = 0; p < NP; ++p) *(uint2 *)(&s_z[p][part >> 3][r][(part & 7) * 4]) = pc[p];
         }
         __syncthreads();
         const int nxt = next_live(cur + 1);
         load_step(nxt < nsteps ? nxt : cur);          // unconditional (see conv3d_gather_pf): the last one is dropped
-        if (grp == 0) wgrad4s_mfma_step<T2, NP, 0>(s_x, s_z, acc, wm, wn, pcol, kbase + q, slots);
-        else wgrad4s_mfma_step<T2, NP, 1>(s_x, s_z, acc, wm, wn, pcol, kbase + q, slots);
+        if (grp == 0) wgrad4s_mfma_step<T2, NP, 0, FMT>(s_x, s_z, acc, wm, wn, pcol, kbase + q, slots);
+        else wgrad4s_mfma_step<T2, NP, 1, FMT>(s_x, s_z, acc, wm, wn, pcol, kbase + q, slots);
         cur = nxt;
     }
+    float o_scale = 1.f;
+    if constexpr (FMT == 1) o_scale = split_inverse(x_scale) * split_inverse(z_scale);
     // slab[strip][kd][tap][c (Cin)][n (64)]: every tap is written by the group that owns it (zeros where nothing was computed)
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -1049,7 +1055,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4s(const float *__rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            o[(size_t)row * BN + li] = acc[i][r];
+            o[(size_t)row * BN + li] = FMT == 1 ? acc[i][r] * o_scale : acc[i][r];
         }
     }
 }
@@ -1057,11 +1063,13 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4s(const float *__rest
 // conv3d_wgrad4 in the arithmetic the flags ask for: exact f32, or the split forms (MVX_FLAG_SPLIT: bf16x3, + MVX_FLAG_SPLIT3: bf16x6)
 template <bool T2>
 static void launch_wgrad4(int flags, dim3 grid, hipStream_t st, const float *in, const float *dz, float *slabs, const Geom &g,
-                          int per, const int *list, const int *count, const float *c_in, const Strips &ks) {
-    if (flags & MVX_FLAG_SPLIT3)
-        hipLaunchKernelGGL((conv3d_wgrad4s<T2, 3>), grid, dim3(W4_THREADS), 0, st, in, dz, slabs, g, per, list, count, c_in, ks);
+                          int per, const int *list, const int *count, const float *c_in, const Strips &ks, const SplitAmax &am) {
+    if ((flags & MVX_FLAG_SPLIT) && (flags & MVX_FLAG_SPLIT_F16))
+        hipLaunchKernelGGL((conv3d_wgrad4s<T2, 2, 1>), grid, dim3(W4_THREADS), 0, st, in, dz, slabs, g, per, list, count, c_in, ks, am);
+    else if (flags & MVX_FLAG_SPLIT3)
+        hipLaunchKernelGGL((conv3d_wgrad4s<T2, 3, 0>), grid, dim3(W4_THREADS), 0, st, in, dz, slabs, g, per, list, count, c_in, ks, am);
     else if (flags & MVX_FLAG_SPLIT)
-        hipLaunchKernelGGL((conv3d_wgrad4s<T2, 2>), grid, dim3(W4_THREADS), 0, st, in, dz, slabs, g, per, list, count, c_in, ks);
+        hipLaunchKernelGGL((conv3d_wgrad4s<T2, 2, 0>), grid, dim3(W4_THREADS), 0, st, in, dz, slabs, g, per, list, count, c_in, ks, am);
     else
         hipLaunchKernelGGL(conv3d_wgrad4<T2>, grid, dim3(W4_THREADS), 0, st, in, dz, slabs, g, per, list, count, c_in, ks);
 }
@@ -1484,6 +1492,7 @@ extern "C" size_t mvx_conv3d_wgrad_workspace_bytes(int32_t h, int32_t w, int32_t
 extern "C" int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int32_t din, int32_t dout,
                                 int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride_d,
                                 int32_t pad_d, int32_t flags, void *workspace, size_t workspace_bytes, void *stream) {
+    const SplitAmax am = mvxi_take_split_amax();         // (in, dz) bound for this call (fp16 pieces); cleared whatever kernel runs
     MVX_CHECK_ARG(in && dz && dw && workspace);
     int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
     if (rc) return rc;
@@ -1497,7 +1506,7 @@ extern "C" int mvx_conv3d_wgrad(const float *in, const float *dz, float *dw, int
     hipStream_t st = (hipStream_t)stream;
     if (cin % W4_C == 0)
         launch_wgrad4<false>(flags, dim3(nstrips, 3 * (cin / W4_C), nblk), st, in, dz, (float *)workspace, g, per, nullptr, nullptr,
-                             nullptr, Strips{{nstrips, nstrips, nstrips}});
+                             nullptr, Strips{{nstrips, nstrips, nstrips}}, am);
     else
         hipLaunchKernelGGL(conv3d_wgrad, dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz,
                            (float *)workspace, g, per);
@@ -1598,6 +1607,7 @@ extern "C" int mvx_conv3d_wgrad_bg_frames(const float *in, const float *dz, floa
                                           int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d, int32_t flags,
                                           const int32_t *in_halo_flags, const float *c_in, const float *tap_sums,
                                           void *workspace, size_t workspace_bytes, int32_t n_frames, void *stream) {
+    const SplitAmax am = mvxi_take_split_amax();         // (in, dz) bound for this call (fp16 pieces); cleared whatever kernel runs
     MVX_CHECK_ARG(in && dz && dw && workspace && in_halo_flags && c_in && tap_sums);
     int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
     if (rc) return rc;
@@ -1632,7 +1642,7 @@ extern "C" int mvx_conv3d_wgrad_bg_frames(const float *in, const float *dz, floa
     int *count = list + (size_t)3 * dout * n_frames * ntiles;
     hipLaunchKernelGGL(wgrad_step_list, dim3(3), dim3(1024), 0, st, in_halo_flags, g, ntiles, list, count);
     MVX_LAUNCH_CHECK();
-    launch_wgrad4<false>(flags, dim3(widest, 3 * (cin / W4_C)), st, in, dz, slabs, g, 0, list, count, c_in, ks);
+    launch_wgrad4<false>(flags, dim3(widest, 3 * (cin / W4_C)), st, in, dz, slabs, g, 0, list, count, c_in, ks, am);
     MVX_LAUNCH_CHECK();
     const size_t per_slab = (size_t)27 * cin * BN;
     hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)slabs, dw, widest, cin,
@@ -1722,6 +1732,7 @@ extern "C" size_t mvx_conv2d_wgrad_workspace_bytes_frames(int32_t h, int32_t w, 
 extern "C" int mvx_conv2d_wgrad_frames(const float *in, const float *dz, float *dw, int32_t h, int32_t w, int32_t cin,
                                        int32_t cout, int32_t flags, void *workspace, size_t workspace_bytes, int32_t n_frames,
                                        void *stream) {
+    const SplitAmax am = mvxi_take_split_amax();         // (in, dz) bound for this call (fp16 pieces); cleared whatever kernel runs
     MVX_CHECK_ARG(in && dz && dw && workspace);
     int rc = conv2d_geom_ok(h, w, cin, cout, n_frames);
     if (rc) return rc;
@@ -1746,9 +1757,9 @@ extern "C" int mvx_conv2d_wgrad_frames(const float *in, const float *dz, float *
     Strips ks;
     ks.n[0] = 1; ks.n[1] = nstrips; ks.n[2] = 1;                    // depth tap 1 is the only one with a source plane
     if (flags & MVX_FLAG_TAPS2)
-        launch_wgrad4<true>(flags, dim3(nstrips, 3 * (cin / W4_C), nblk), st, in, dz, slabs, g, 0, list, count, nullptr, ks);
+        launch_wgrad4<true>(flags, dim3(nstrips, 3 * (cin / W4_C), nblk), st, in, dz, slabs, g, 0, list, count, nullptr, ks, am);
     else
-        launch_wgrad4<false>(flags, dim3(nstrips, 3 * (cin / W4_C), nblk), st, in, dz, slabs, g, 0, list, count, nullptr, ks);
+        launch_wgrad4<false>(flags, dim3(nstrips, 3 * (cin / W4_C), nblk), st, in, dz, slabs, g, 0, list, count, nullptr, ks, am);
     MVX_LAUNCH_CHECK();
     const size_t per_slab = (size_t)27 * cin * BN;
     hipLaunchKernelGGL(wgrad_reduce, dim3(mvx_cdiv(per_slab, 256), nblk), dim3(256), 0, st, (const float *)slabs, dw, nstrips, cin,

@@ -60,7 +60,7 @@ __device__ __forceinline__ int src_depth(const Geom &g, int d, int kd) {
 }
 
 // torch W[co][ci][kd][kh][kw] -> wsp[kd][tap][32-channel chunk][n][piece][32] (bf16), forward or dgrad view
-__global__ void pack_weights_split(const float *__restrict__ w, unsigned short *__restrict__ wsp, int Co, int Ci, int dgrad, int np) {
+__global__ void pack_weights_split(const float *__restrict__ w, unsigned short *__restrict__ wsp, int Co, int Ci, int dgrad, int np, int fmt) {
     const int K = dgrad ? Co : Ci, N = dgrad ? Ci : Co;
     const int nch = K / BK;
     const long long total = 27ll * K * N;
@@ -78,9 +78,16 @@ __global__ void pack_weights_split(const float *__restrict__ w, unsigned short *
         float x = w[((((long long)co * Ci + ci) * 3 + kd) * 3 + kh) * 3 + kw];
         const long long row = (((long long)kd * 9 + tap) * nch + ch) * N + n;
         for (int q = 0; q < np; ++q) {
-            const __bf16 pb = (__bf16)x;
-            wsp[(row * np + q) * BK + k] = __builtin_bit_cast(unsigned short, pb);
-            x -= (float)pb;
+            if (fmt == 0) {
+                const __bf16 pb = (__bf16)x;
+                wsp[(row * np + q) * BK + k] = __builtin_bit_cast(unsigned short, pb);
+                x -= (float)pb;
+            } else {
+                if (q == 0) x *= SPLIT_F16_WSCALE;
+                const _Float16 pb = (_Float16)x;
+                wsp[(row * np + q) * BK + k] = __builtin_bit_cast(unsigned short, pb);
+                x -= (float)pb;
+            }
         }
     }
 }
@@ -100,7 +107,7 @@ __global__ void pack_weights_split(const float *__restrict__ w, unsigned short *
 // WIN: the launch has a tap window or structural zeros (MVX_FLAG_TAPS2): rows and columns of the 3 x 3 kernel are skipped by
 // block-uniform masks; without it the three kernel rows are unrolled at compile time (8 % faster on the dense launches).
 // ------------------------------------------------------------------------------------------
-template <int NP, int BKT, int MT, bool WIN>
+template <int NP, int BKT, int MT, bool WIN, int FMT>
 __global__ __launch_bounds__(256, 2) void conv3d_gather_splitT(const float *__restrict__ in,
                                                                const unsigned short *__restrict__ wsp,
                                                                const float *__restrict__ bias,
@@ -110,7 +117,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_splitT(const float *__re
                                                                const float *__restrict__ bg_pre, int border_active,
                                                                const int *__restrict__ only_tiles,
                                                                unsigned long long *__restrict__ exec_stages,
-                                                               const float *__restrict__ bn_y, const float *__restrict__ bn_mi) {
+                                                               const float *__restrict__ bn_y, const float *__restrict__ bn_mi,
+                                                               const float *__restrict__ in_amax) {
+    // fp16 pieces (FMT = 1, split_common.h): `in` is scaled by a_scale (from its bound amax, else 1), the weights were packed
+    // times SPLIT_F16_WSCALE; the accumulators are scaled back before the epilogue
+    float a_scale = 1.f;
+    if constexpr (FMT == 1) a_scale = split_scale_of(in_amax);
     // bn_y != NULL (dense input-gradient launches): the output is dL/dyhat of the BatchNorm-ed layer whose pre-BN output is bn_y
     // ([planes][H][W][Cout], mean / inverse std bn_mi [F][2][Cout]); `stats` is then that layer's BatchNorm-BACKWARD accumulator
     // [F][REP][3][Cout] and takes sum g and sum g * yhat -- the reduction pass of mvx_bn_relu_backward_frames
@@ -257,7 +269,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_splitT(const float *__re
         for (int u = 0; u < NH; ++u)
             if (h_lds[u] >= 0) {
                 uint2 pc[NP];
-                split_n<NP>(hreg[u][0], hreg[u][1], hreg[u][2], hreg[u][3], pc);
+                if constexpr (FMT == 1) hreg[u] *= a_scale;
+                split_n<NP, FMT>(hreg[u][0], hreg[u][1], hreg[u][2], hreg[u][3], pc);
 #pragma unroll
                 for (int q = 0; q < NP; ++q) *(uint2 *)(s_halo + h_lds[u] + q * BKT * 2) = pc[q];
             }
@@ -285,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_splitT(const float *__re
                     bf16x8 av[NP];
 #pragma unroll
                     for (int q = 0; q < NP; ++q) av[q] = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_halo + a_off + q * BKT * 2));
-                    split_mac2<NP>(acc[m][0], acc[m][1], av, b0, b1);
+                    split_mac2<NP, FMT>(acc[m][0], acc[m][1], av, b0, b1);
                 }
             }
         }
@@ -368,6 +381,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_splitT(const float *__re
         }
     }
 
+    if constexpr (FMT == 1) {
+        const float o_scale = split_inverse(split_scale_of(in_amax)) * (1.f / SPLIT_F16_WSCALE);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { acc[m][0] *= o_scale; acc[m][1] *= o_scale; }
+    }
     // ---- epilogue
     const int n0 = nb * BN + li, n1 = n0 + 32;
     const float bias0 = bias ? bias[n0] : 0.f, bias1 = bias ? bias[n1] : 0.f;
@@ -471,7 +489,7 @@ extern "C" int mvx_tuning_set(int32_t key, int64_t value) {
     return MVX_EINVAL;
 }
 
-static void launch_gather_split(hipStream_t st, int np, int planes, int nblocks, const float *in, const unsigned short *wsp,
+static void launch_gather_split(hipStream_t st, int flags, int planes, int nblocks, const float *in, const unsigned short *wsp,
                                 const float *bias, float *out, double *stats, const Geom &g, int relu, const int *in_hflag,
                                 const unsigned char *out_mask, const float *bg_pre, int border_active, const int *only_tiles,
                                 unsigned long long *exec_stages, const float *bn_y = nullptr, const float *bn_mi = nullptr) {
@@ -480,17 +498,20 @@ static void launch_gather_split(hipStream_t st, int np, int planes, int nblocks,
     const bool big = units16 >= g_split16_min_units;
     const dim3 grid(tiles_x * mvx_cdiv(g.H, big ? TH2 : TH), planes, nblocks);
     const bool win = g.tap_lo != 0 || g.tap_hi != 3 || g.s2d > 0;
-#define MVX_GO(NP_, BK_, MT_)                                                                                                        \
+    const int np = (flags & MVX_FLAG_SPLIT_F16) ? 2 : (flags & MVX_FLAG_SPLIT3) ? 3 : 2;
+    const SplitAmax am = mvxi_take_split_amax();         // bound by mvx_split_operand_amax for this launch (fp16 pieces), else NULLs
+#define MVX_GO(NP_, BK_, MT_, F_)                                                                                                        \
     do {                                                                                                                             \
         if (win)                                                                                                                     \
-            hipLaunchKernelGGL((conv3d_gather_splitT<NP_, BK_, MT_, true>), grid, dim3(256), 0, st, in, wsp, bias, out, stats, g,    \
-                               relu, in_hflag, out_mask, bg_pre, border_active, only_tiles, exec_stages, bn_y, bn_mi);               \
+            hipLaunchKernelGGL((conv3d_gather_splitT<NP_, BK_, MT_, true, F_>), grid, dim3(256), 0, st, in, wsp, bias, out, stats, g,    \
+                               relu, in_hflag, out_mask, bg_pre, border_active, only_tiles, exec_stages, bn_y, bn_mi, am.a);         \
         else                                                                                                                         \
-            hipLaunchKernelGGL((conv3d_gather_splitT<NP_, BK_, MT_, false>), grid, dim3(256), 0, st, in, wsp, bias, out, stats, g,   \
-                               relu, in_hflag, out_mask, bg_pre, border_active, only_tiles, exec_stages, bn_y, bn_mi);               \
+            hipLaunchKernelGGL((conv3d_gather_splitT<NP_, BK_, MT_, false, F_>), grid, dim3(256), 0, st, in, wsp, bias, out, stats, g,   \
+                               relu, in_hflag, out_mask, bg_pre, border_active, only_tiles, exec_stages, bn_y, bn_mi, am.a);         \
     } while (0)
-    if (np == 3) { if (big) MVX_GO(3, 16, 2); else MVX_GO(3, 32, 1); }
-    else         { if (big) MVX_GO(2, 32, 2); else MVX_GO(2, 32, 1); }
+    if (flags & MVX_FLAG_SPLIT_F16) { if (big) MVX_GO(2, 32, 2, 1); else MVX_GO(2, 32, 1, 1); }
+    else if (np == 3) { if (big) MVX_GO(3, 16, 2, 0); else MVX_GO(3, 32, 1, 0); }
+    else              { if (big) MVX_GO(2, 32, 2, 0); else MVX_GO(2, 32, 1, 0); }
 #undef MVX_GO
 }
 
@@ -517,13 +538,15 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned short *row0, const unsi
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int NP>
+template <int NP, int FMT>
 __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_split(const float *__restrict__ in,
                                                                  const float *__restrict__ dz,
                                                                  float *__restrict__ slabs, Geom g,
                                                                  int tiles_per_strip, const int *__restrict__ step_list,
                                                                  const int *__restrict__ step_count,
-                                                                 const float *__restrict__ c_in) {
+                                                                 const float *__restrict__ c_in, SplitAmax am) {
+    float x_scale = 1.f, z_scale = 1.f;                       // fp16 pieces: operands scaled by their bound amax (split_common.h)
+    if constexpr (FMT == 1) { x_scale = split_scale_of(am.a); z_scale = split_scale_of(am.b); }
     __shared__ __attribute__((aligned(16))) unsigned short s_x[NP][HH * HW][BK];          // [piece][halo site][channel]
     __shared__ __attribute__((aligned(16))) unsigned short s_z[NP][2][TH * TW][32];       // [piece][32-channel half][site][channel]
     const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
@@ -609,7 +632,8 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_split(const float *__
             const int c = tid + WG_THREADS * u;
             if (c < HH * HW * 8) {
                 uint2 pc[NP];
-                split_n<NP>(xr[u].x, xr[u].y, xr[u].z, xr[u].w, pc);
+                if constexpr (FMT == 1) { xr[u].x *= x_scale; xr[u].y *= x_scale; xr[u].z *= x_scale; xr[u].w *= x_scale; }
+                split_n<NP, FMT>(xr[u].x, xr[u].y, xr[u].z, xr[u].w, pc);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) *(uint2 *)(&s_x[p][c >> 3][(c & 7) * 4]) = pc[p];
             }
@@ -620,7 +644,8 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_split(const float *__
             if (c < TH * TW * 16) {
                 const int r = c >> 4, part = c & 15;
                 uint2 pc[NP];
-                split_n<NP>(zr[u].x, zr[u].y, zr[u].z, zr[u].w, pc);
+                if constexpr (FMT == 1) { zr[u].x *= z_scale; zr[u].y *= z_scale; zr[u].z *= z_scale; zr[u].w *= z_scale; }
+                split_n<NP, FMT>(zr[u].x, zr[u].y, zr[u].z, zr[u].w, pc);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) *(uint2 *)(&s_z[p][part >> 3][r][(part & 7) * 4]) = pc[p];
             }
@@ -639,11 +664,15 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_split(const float *__
                 b0[p] = tr_frag(&s_z[p][0][zr0][pcol], &s_z[p][0][zr1][pcol]);
                 b1[p] = tr_frag(&s_z[p][1][zr0][pcol], &s_z[p][1][zr1][pcol]);
             }
-            split_mac2<NP>(acc0, acc1, av, b0, b1);
+            split_mac2<NP, FMT>(acc0, acc1, av, b0, b1);
         }
         cur = nxt;
     }
     float *o = slabs + ((((size_t)strip * 3 + kd) * 9 + tap) * g.Cin + cc * BK) * BN;
+    if constexpr (FMT == 1) {
+        const float o_scale = split_inverse(x_scale) * split_inverse(z_scale);
+        acc0 *= o_scale; acc1 *= o_scale;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -674,7 +703,8 @@ int check_geom(int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int
     return MVX_OK;
 }
 
-static inline int pieces_of(int flags) { return (flags & MVX_FLAG_SPLIT3) ? 3 : 2; }
+static inline int pieces_of(int flags) { return (flags & MVX_FLAG_SPLIT_F16) ? 2 : (flags & MVX_FLAG_SPLIT3) ? 3 : 2; }
+static inline int fmt_of(int flags) { return (flags & MVX_FLAG_SPLIT_F16) ? 1 : 0; }
 
 }  // namespace
 
@@ -689,7 +719,7 @@ extern "C" int mvx_conv3d_pack_weights_split(const float *w, void *wsplit, int32
     MVX_CHECK_ARG((for_dgrad ? cout : cin) % BK == 0);
     const long long total = 27ll * cout * cin;
     hipLaunchKernelGGL(pack_weights_split, dim3(mvx_cdiv(total, 256) > 2048 ? 2048 : mvx_cdiv(total, 256)), dim3(256), 0,
-                       (hipStream_t)stream, w, (unsigned short *)wsplit, cout, cin, for_dgrad, pieces_of(flags));
+                       (hipStream_t)stream, w, (unsigned short *)wsplit, cout, cin, for_dgrad, pieces_of(flags), fmt_of(flags));
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -708,7 +738,7 @@ extern "C" int mvx_conv3d_forward_split(const float *in, const void *wsplit, con
         if (e != hipSuccess) return (int)e;
     }
     Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
-    launch_gather_split(st, pieces_of(flags), dout, cout / BN, in, (const unsigned short *)wsplit, bias, out, stats, g, relu, nullptr, nullptr, nullptr,
+    launch_gather_split(st, flags, dout, cout / BN, in, (const unsigned short *)wsplit, bias, out, stats, g, relu, nullptr, nullptr, nullptr,
                         0, nullptr, nullptr);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
@@ -730,7 +760,7 @@ extern "C" int mvx_conv3d_forward_bg_split_frames(const float *in, const void *w
         if (e != hipSuccess) return (int)e;
     }
     Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0, n_frames};
-    launch_gather_split(st, pieces_of(flags), dout * n_frames, cout / BN, in, (const unsigned short *)wsplit, bias, out, stats, g,
+    launch_gather_split(st, flags, dout * n_frames, cout / BN, in, (const unsigned short *)wsplit, bias, out, stats, g,
                         flags & MVX_FLAG_RELU, in_halo_flags, out_mask, bg_pre,
                         (border_active ? 1 : 0) | ((flags & MVX_FLAG_BG_TAPS) ? 2 : 0), nullptr, (unsigned long long *)exec_stages);
     MVX_LAUNCH_CHECK();
@@ -758,7 +788,7 @@ static int launch_dgrad_split(const float *dz, const void *wsplit_dgrad, float *
         g.tap_lo = 1; g.tap_hi = 3;
         if (cin % 4 == 0 && (cin / 4) % BN == 0) g.s2d = cin / 4;      // parity of the OUTPUT channel block
     }
-    launch_gather_split((hipStream_t)stream, pieces_of(flags), din * n_frames, cin / BN, dz, (const unsigned short *)wsplit_dgrad, nullptr, dx, nullptr,
+    launch_gather_split((hipStream_t)stream, flags, din * n_frames, cin / BN, dz, (const unsigned short *)wsplit_dgrad, nullptr, dx, nullptr,
                         g, 0, nullptr, nullptr, nullptr, 0, only_tiles, (unsigned long long *)exec_stages);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
@@ -791,6 +821,7 @@ extern "C" int mvx_conv3d_dgrad_split(const float *dz, const void *wsplit_dgrad,
 extern "C" int mvx_conv3d_wgrad_split(const float *in, const float *dz, float *dw, int32_t din, int32_t dout, int32_t h,
                                       int32_t w, int32_t cin, int32_t cout, int32_t stride_d, int32_t pad_d,
                                       int32_t flags, void *workspace, size_t workspace_bytes, void *stream) {
+    const SplitAmax am = mvxi_take_split_amax();         // (x, dz) of an fp16-piece launch, else NULLs
     MVX_CHECK_ARG(in && dz && dw && workspace);
     int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
     if (rc) return rc;
@@ -805,12 +836,15 @@ extern "C" int mvx_conv3d_wgrad_split(const float *in, const float *dz, float *d
     MVX_CHECK_ARG(workspace_bytes >= (size_t)nstrips * 27 * cin * BN * sizeof(float));
     Geom g{din, dout, h, w, cin, cout, stride_d, pad_d, 0};
     hipStream_t st = (hipStream_t)stream;
-    if (pieces_of(flags) == 3)
-        hipLaunchKernelGGL(conv3d_wgrad_split<3>, dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz,
-                           (float *)workspace, g, per, (const int *)nullptr, (const int *)nullptr, (const float *)nullptr);
+    if (fmt_of(flags))
+        hipLaunchKernelGGL((conv3d_wgrad_split<2, 1>), dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz,
+                           (float *)workspace, g, per, (const int *)nullptr, (const int *)nullptr, (const float *)nullptr, am);
+    else if (pieces_of(flags) == 3)
+        hipLaunchKernelGGL((conv3d_wgrad_split<3, 0>), dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz,
+                           (float *)workspace, g, per, (const int *)nullptr, (const int *)nullptr, (const float *)nullptr, am);
     else
-        hipLaunchKernelGGL(conv3d_wgrad_split<2>, dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz,
-                           (float *)workspace, g, per, (const int *)nullptr, (const int *)nullptr, (const float *)nullptr);
+        hipLaunchKernelGGL((conv3d_wgrad_split<2, 0>), dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz,
+                           (float *)workspace, g, per, (const int *)nullptr, (const int *)nullptr, (const float *)nullptr, am);
     MVX_LAUNCH_CHECK();
     const size_t per_slab = (size_t)27 * cin * BN;
     hipLaunchKernelGGL(wgrad_reduce_split, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)workspace, dw,
@@ -841,6 +875,7 @@ extern "C" int mvx_conv3d_wgrad_bg_split_frames(const float *in, const float *dz
                                                 int32_t pad_d, int32_t flags, const int32_t *in_halo_flags, const float *c_in,
                                                 const float *tap_sums, void *workspace, size_t workspace_bytes,
                                                 int32_t n_frames, void *stream) {
+    const SplitAmax am = mvxi_take_split_amax();         // (x, dz) of an fp16-piece launch, else NULLs
     MVX_CHECK_ARG(in && dz && dw && workspace && in_halo_flags && c_in && tap_sums);
     MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
     int rc = check_geom(din, dout, h, w, cin, cout, stride_d, pad_d);
@@ -856,12 +891,15 @@ extern "C" int mvx_conv3d_wgrad_bg_split_frames(const float *in, const float *dz
     int *count = list + (size_t)3 * dout * n_frames * ntiles;
     rc = mvxi_wgrad_step_list(in_halo_flags, din, dout, ntiles, stride_d, pad_d, list, count, st, n_frames);
     if (rc) return rc;
-    if (pieces_of(flags) == 3)
-        hipLaunchKernelGGL(conv3d_wgrad_split<3>, dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz, slabs, g, 0,
-                           (const int *)list, (const int *)count, c_in);
+    if (fmt_of(flags))
+        hipLaunchKernelGGL((conv3d_wgrad_split<2, 1>), dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz, slabs, g, 0,
+                           (const int *)list, (const int *)count, c_in, am);
+    else if (pieces_of(flags) == 3)
+        hipLaunchKernelGGL((conv3d_wgrad_split<3, 0>), dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz, slabs, g, 0,
+                           (const int *)list, (const int *)count, c_in, am);
     else
-        hipLaunchKernelGGL(conv3d_wgrad_split<2>, dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz, slabs, g, 0,
-                           (const int *)list, (const int *)count, c_in);
+        hipLaunchKernelGGL((conv3d_wgrad_split<2, 0>), dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in, dz, slabs, g, 0,
+                           (const int *)list, (const int *)count, c_in, am);
     MVX_LAUNCH_CHECK();
     const size_t per_slab = (size_t)27 * cin * BN;
     hipLaunchKernelGGL(wgrad_reduce_split, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)slabs, dw, nstrips,
@@ -901,7 +939,7 @@ extern "C" int mvx_conv2d_forward_split_frames(const float *in, const void *wspl
         g.tap_lo = 0; g.tap_hi = 2;
         if (cin % 4 == 0 && (cin / 4) % BK == 0) g.s2d = cin / 4;
     }
-    launch_gather_split(st, pieces_of(flags), n_frames, cout / BN, in, (const unsigned short *)wsplit, bias, out, stats, g, flags & MVX_FLAG_RELU,
+    launch_gather_split(st, flags, n_frames, cout / BN, in, (const unsigned short *)wsplit, bias, out, stats, g, flags & MVX_FLAG_RELU,
                         nullptr, nullptr, nullptr, 0, nullptr, nullptr);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
@@ -928,7 +966,7 @@ extern "C" int mvx_conv2d_dgrad_split_bnsums_frames(const float *dz, const void 
         if (e != hipSuccess) return (int)e;
     }
     Geom g{1, 1, h, w, cout, cin, 1, 1, 1, n_frames};
-    launch_gather_split(st, pieces_of(flags), n_frames, cin / BN, dz, (const unsigned short *)wsplit_dgrad, nullptr, dx, bn_scratch, g,
+    launch_gather_split(st, flags, n_frames, cin / BN, dz, (const unsigned short *)wsplit_dgrad, nullptr, dx, bn_scratch, g,
                         0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, bn_y, bn_mean_inv);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
@@ -950,6 +988,7 @@ extern "C" size_t mvx_conv2d_wgrad_split_workspace_bytes_frames(int32_t h, int32
 extern "C" int mvx_conv2d_wgrad_split_frames(const float *in, const float *dz, float *dw3, int32_t h, int32_t w, int32_t cin,
                                              int32_t cout, int32_t flags, void *workspace, size_t workspace_bytes,
                                              int32_t n_frames, void *stream) {
+    const SplitAmax am = mvxi_take_split_amax();         // (x, dz) of an fp16-piece launch, else NULLs
     MVX_CHECK_ARG(in && dz && dw3 && workspace);
     MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
     int rc = check_geom(1, 1, h, w, cin, cout, 1, 1);
@@ -969,12 +1008,15 @@ extern "C" int mvx_conv2d_wgrad_split_frames(const float *in, const float *dz, f
     Geom g{1, 1, h, w, cin, cout, 1, 1, 0, n_frames};
     const size_t per_slab = (size_t)27 * cin * BN;
     for (int nb = 0; nb < cout / BN; ++nb) {        // the kernel owns 64 channels of dz per launch
-        if (pieces_of(flags) == 3)
-            hipLaunchKernelGGL(conv3d_wgrad_split<3>, dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in,
-                               dz + (size_t)nb * BN, slabs, g, 0, (const int *)list, (const int *)count, (const float *)nullptr);
+        if (fmt_of(flags))
+            hipLaunchKernelGGL((conv3d_wgrad_split<2, 1>), dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in,
+                               dz + (size_t)nb * BN, slabs, g, 0, (const int *)list, (const int *)count, (const float *)nullptr, am);
+        else if (pieces_of(flags) == 3)
+            hipLaunchKernelGGL((conv3d_wgrad_split<3, 0>), dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in,
+                               dz + (size_t)nb * BN, slabs, g, 0, (const int *)list, (const int *)count, (const float *)nullptr, am);
         else
-            hipLaunchKernelGGL(conv3d_wgrad_split<2>, dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in,
-                               dz + (size_t)nb * BN, slabs, g, 0, (const int *)list, (const int *)count, (const float *)nullptr);
+            hipLaunchKernelGGL((conv3d_wgrad_split<2, 0>), dim3(nstrips, 3 * (cin / BK)), dim3(WG_THREADS), 0, st, in,
+                               dz + (size_t)nb * BN, slabs, g, 0, (const int *)list, (const int *)count, (const float *)nullptr, am);
         MVX_LAUNCH_CHECK();
         hipLaunchKernelGGL(wgrad_reduce_split, dim3(mvx_cdiv(per_slab, 256)), dim3(256), 0, st, (const float *)slabs,
                            dw3 + (size_t)nb * BN * cin * 27, nstrips, cin, 0);

@@ -396,6 +396,7 @@ static int linear_forward_impl(const float *x, int32_t ldx, const float *w, int3
                                int64_t rows, int32_t k, int32_t n, int32_t flags, void *splitk_workspace,
                                size_t splitk_workspace_bytes, unsigned *fin_counter, double fin_count, double fin_eps,
                                float *fin_mean_inv, const mvx_frames_t *frames, int row_kind, void *stream) {
+    const SplitAmax am = mvxi_take_split_amax();         // x bound for this call (fp16 pieces); cleared whatever kernel runs
     const int relu = flags & MVX_FLAG_RELU;
     MVX_CHECK_ARG(x && w && y && rows >= 0 && k > 0 && n > 0 && ldx >= k && ldy >= n);
     MVX_CHECK_ARG(ldw >= (w_transposed ? n : k));
@@ -432,7 +433,7 @@ static int linear_forward_impl(const float *x, int32_t ldx, const float *w, int3
     }
     if ((flags & MVX_FLAG_SPLIT) && vec && wide && splits == 1 && !w_transposed)    // bf16x3 arithmetic for the wide layers
         return mvxi_linear_forward_split(x, ldx, w, ldw, bias, y, ldy, stats, row_w, (long long)rows, k, n, relu, fin_counter,
-                                         fin_eps, fin_mean_inv, fm, (flags & MVX_FLAG_SPLIT3) ? 3 : 2, st);
+                                         fin_eps, fin_mean_inv, fm, mvx_split_code(flags), st, nullptr, 0, nullptr, am);
     const dim3 grid(mvx_cdiv(n, wide ? 128 : 64), mvx_cdiv(rows, BM), splits);
 #define MVX_LAUNCH_LIN(WT, NT, VEC)                                                                               \
     hipLaunchKernelGGL((linear_fwd<WT, NT, VEC>), grid, dim3(256), 0, st, x, ldx, w, ldw, bias, ydst, ld_dst, stats, \
@@ -502,6 +503,7 @@ extern "C" int mvx_linear_dgrad_bnsums_frames(const float *dz, int32_t lddz, con
                                               int64_t rows, int32_t k, int32_t n, int32_t flags, const float *bn_y, int32_t ld_bn_y,
                                               const float *bn_mean_inv, double *bn_scratch, const mvx_frames_t *frames_host,
                                               int32_t row_kind, void *stream) {
+    const SplitAmax am = mvxi_take_split_amax();
     MVX_CHECK_ARG(dz && w && dx && bn_y && bn_mean_inv && bn_scratch && rows > 0 && k > 0 && n > 64 && lddz >= k && lddx >= n &&
                   ldw >= k && ld_bn_y >= n);
     MVX_CHECK_ARG(flags & MVX_FLAG_SPLIT);
@@ -514,7 +516,7 @@ extern "C" int mvx_linear_dgrad_bnsums_frames(const float *dz, int32_t lddz, con
         if (e != hipSuccess) return (int)e;
     }
     return mvxi_linear_forward_split(dz, lddz, w, ldw, nullptr, dx, lddx, bn_scratch, nullptr, (long long)rows, k, n, 0, nullptr, 0.0,
-                                     nullptr, fm, (flags & MVX_FLAG_SPLIT3) ? 3 : 2, st, bn_y, ld_bn_y, bn_mean_inv);
+                                     nullptr, fm, mvx_split_code(flags), st, bn_y, ld_bn_y, bn_mean_inv, am);
 }
 
 extern "C" size_t mvx_linear_wgrad_workspace_bytes(int64_t rows, int32_t k, int32_t n) {
@@ -527,6 +529,7 @@ extern "C" size_t mvx_linear_wgrad_workspace_bytes(int64_t rows, int32_t k, int3
 extern "C" int mvx_linear_wgrad(const float *x, int32_t ldx, const float *dz, int32_t lddz, float *dw,
                                 int64_t rows, int32_t k, int32_t n, int32_t flags, void *workspace,
                                 size_t workspace_bytes, void *stream) {
+    const SplitAmax am = mvxi_take_split_amax();         // (x, dz) bound for this call (fp16 pieces)
     MVX_CHECK_ARG(x && dz && dw && workspace && rows >= 0 && k > 0 && n > 0 && ldx >= k && lddz >= n);
     hipStream_t st = (hipStream_t)stream;
     if (rows == 0) {
@@ -542,7 +545,7 @@ extern "C" int mvx_linear_wgrad(const float *x, int32_t ldx, const float *dz, in
     if (vec && (flags & MVX_FLAG_SPLIT)) {
         // rows_per_strip is a multiple of the 32-row LDS step in both kernels (strip_rows)
         int rc = mvxi_linear_wgrad_split(x, ldx, dz, lddz, (float *)workspace, (long long)rows, k, n, per, strips,
-                                         (flags & MVX_FLAG_SPLIT3) ? 3 : 2, st);
+                                         mvx_split_code(flags), st, am);
         if (rc) return rc;
     } else if (vec)
         hipLaunchKernelGGL(linear_wgrad<true>, grid, dim3(256), 0, st, x, ldx, dz, lddz, (float *)workspace,

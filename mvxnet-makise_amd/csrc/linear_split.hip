@@ -21,7 +21,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BM = 128, BNL = 128, NT = 4;
 
 // NP pieces per operand; K in chunks of BK (64 for bf16x3, 32 for bf16x6: 61 KB of LDS either way, two workgroups per CU)
-template <int NP, int BK, bool BNB>
+template <int NP, int BK, bool BNB, int FMT>
 __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restrict__ x, int ldx, const float *__restrict__ w,
                                                         int ldw, const float *__restrict__ bias, float *__restrict__ y,
                                                         int ldy, double *__restrict__ stats, const float *__restrict__ row_w,
@@ -29,7 +29,11 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
                                                         unsigned *__restrict__ done_counter, double fin_eps,
                                                         float *__restrict__ fin_mean_inv, FrameMap fm,
                                                         const float *__restrict__ bn_y, int bn_ldy,
-                                                        const float *__restrict__ bn_mi) {
+                                                        const float *__restrict__ bn_mi, const float *__restrict__ x_amax) {
+    // fp16 pieces (FMT = 1, split_common.h): x is scaled by x_scale (from its bound amax, else 1), w by SPLIT_F16_WSCALE; the
+    // accumulators are scaled back in front of the epilogue
+    float x_scale = 1.f;
+    if constexpr (FMT == 1) x_scale = split_scale_of(x_amax);
     // BNB (compile time; input-gradient GEMMs, bn_y != NULL): the rows written are dL/dyhat of the BatchNorm-ed layer whose pre-BN output is bn_y
     // (mean / inverse std bn_mi [F][2][N]); `stats` is then that layer's BatchNorm-BACKWARD accumulator [F][REP][3][N] and takes
     // sum g and sum g * yhat per frame -- the reduction pass of mvx_bn_relu_backward_frames (MVX_FLAG_SUMS_READY) from the tile
@@ -78,8 +82,9 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
             const int c = tid + 256 * u, r = c / PQ, part = c % PQ;
             f32x4 v = xr[u];
             if (tail && k0 + part * 4 >= K) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (FMT == 1) v *= x_scale;
             uint2 pc[NP];
-            split_n<NP>(v[0], v[1], v[2], v[3], pc);
+            split_n<NP, FMT>(v[0], v[1], v[2], v[3], pc);
 #pragma unroll
             for (int q = 0; q < NP; ++q) *(uint2 *)(s_x + r * ROWB + q * 2 * BK + part * 8) = pc[q];
         }
@@ -93,8 +98,9 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
                 for (int j = 0; j < 4; ++j)
                     if (k0 + part * 4 + j >= K) v[j] = 0.f;
             }
+            if constexpr (FMT == 1) v *= SPLIT_F16_WSCALE;
             uint2 pc[NP];
-            split_n<NP>(v[0], v[1], v[2], v[3], pc);
+            split_n<NP, FMT>(v[0], v[1], v[2], v[3], pc);
 #pragma unroll
             for (int q = 0; q < NP; ++q) *(uint2 *)(s_w + n * ROWB + q * 2 * BK + part * 8) = pc[q];
         }
@@ -119,11 +125,16 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
                     b0[q] = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_w + b_base + t * 32 * ROWB + q * 2 * BK + s * 32));
                     b1[q] = __builtin_bit_cast(bf16x8, *(const uint4 *)(s_w + b_base + (t + 1) * 32 * ROWB + q * 2 * BK + s * 32));
                 }
-                split_mac2<NP>(acc[t], acc[t + 1], av, b0, b1);
+                split_mac2<NP, FMT>(acc[t], acc[t + 1], av, b0, b1);
             }
         }
     }
 
+    if constexpr (FMT == 1) {
+        const float o_scale = split_inverse(x_scale) * (1.f / SPLIT_F16_WSCALE);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] *= o_scale;
+    }
     // ---- epilogue: the one of linear_fwd (loads first, then the stores, then the per-frame BatchNorm sums in f64)
     float bsv[NT];
 #pragma unroll
@@ -246,10 +257,12 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned short *row0, const unsi
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int NP>
+template <int NP, int FMT>
 __global__ __launch_bounds__(256) void linear_wgrad_split(const float *__restrict__ x, int ldx, const float *__restrict__ dz,
                                                           int lddz, float *__restrict__ slabs, long long R, int K, int N,
-                                                          long long rows_per_strip) {
+                                                          long long rows_per_strip, SplitAmax am) {
+    float x_scale = 1.f, z_scale = 1.f;                       // fp16 pieces: operands scaled by their bound amax (split_common.h)
+    if constexpr (FMT == 1) { x_scale = split_scale_of(am.a); z_scale = split_scale_of(am.b); }
     __shared__ __attribute__((aligned(16))) unsigned short s_z[NP][4][WRS][32];      // [piece][32-column block][row][column]
     __shared__ __attribute__((aligned(16))) unsigned short s_x[NP][4][WRS][32];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -287,10 +300,11 @@ __global__ __launch_bounds__(256) void linear_wgrad_split(const float *__restric
         for (int u = 0; u < NU; ++u) {
             const int c = tid + 256 * u, r = c >> 5, part = c & 31;
             uint2 pc[NP];
-            split_n<NP>(zr[u][0], zr[u][1], zr[u][2], zr[u][3], pc);
+            if constexpr (FMT == 1) { zr[u] *= z_scale; xr[u] *= x_scale; }
+            split_n<NP, FMT>(zr[u][0], zr[u][1], zr[u][2], zr[u][3], pc);
 #pragma unroll
             for (int p = 0; p < NP; ++p) *(uint2 *)(&s_z[p][part >> 3][r][(part & 7) * 4]) = pc[p];
-            split_n<NP>(xr[u][0], xr[u][1], xr[u][2], xr[u][3], pc);
+            split_n<NP, FMT>(xr[u][0], xr[u][1], xr[u][2], xr[u][3], pc);
 #pragma unroll
             for (int p = 0; p < NP; ++p) *(uint2 *)(&s_x[p][part >> 3][r][(part & 7) * 4]) = pc[p];
         }
@@ -311,12 +325,19 @@ __global__ __launch_bounds__(256) void linear_wgrad_split(const float *__restric
                         bx[t][p] = tr_frag(&s_x[p][wk * 2 + t][r0][pcol], &s_x[p][wk * 2 + t][r1][pcol]);
                     }
 #pragma unroll
-                for (int a = 0; a < 2; ++a) split_mac2<NP>(acc[a][0], acc[a][1], az[a], bx[0], bx[1]);
+                for (int a = 0; a < 2; ++a) split_mac2<NP, FMT>(acc[a][0], acc[a][1], az[a], bx[0], bx[1]);
             }
         }
     }
     if (wave_on) {
         float *o = slabs + (size_t)blockIdx.x * N * K;
+        if constexpr (FMT == 1) {
+            const float o_scale = split_inverse(x_scale) * split_inverse(z_scale);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] *= o_scale;
+        }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -334,12 +355,14 @@ __global__ __launch_bounds__(256) void linear_wgrad_split(const float *__restric
 
 // Launched by linear.hip (mvx_linear_wgrad) when MVX_FLAG_SPLIT is set and the operands are 16-byte aligned.
 int mvxi_linear_wgrad_split(const float *x, int ldx, const float *dz, int lddz, float *slabs, long long rows, int k, int n,
-                            long long rows_per_strip, long long strips, int pieces, hipStream_t st) {
+                            long long rows_per_strip, long long strips, int pieces, hipStream_t st, const SplitAmax &am) {
     const dim3 grid((unsigned)strips, mvx_cdiv(n, 128), mvx_cdiv(k, 128));
-    if (pieces == 3)
-        hipLaunchKernelGGL(linear_wgrad_split<3>, grid, dim3(256), 0, st, x, ldx, dz, lddz, slabs, rows, k, n, rows_per_strip);
+    if (pieces == 4)
+        hipLaunchKernelGGL((linear_wgrad_split<2, 1>), grid, dim3(256), 0, st, x, ldx, dz, lddz, slabs, rows, k, n, rows_per_strip, am);
+    else if (pieces == 3)
+        hipLaunchKernelGGL((linear_wgrad_split<3, 0>), grid, dim3(256), 0, st, x, ldx, dz, lddz, slabs, rows, k, n, rows_per_strip, am);
     else
-        hipLaunchKernelGGL(linear_wgrad_split<2>, grid, dim3(256), 0, st, x, ldx, dz, lddz, slabs, rows, k, n, rows_per_strip);
+        hipLaunchKernelGGL((linear_wgrad_split<2, 0>), grid, dim3(256), 0, st, x, ldx, dz, lddz, slabs, rows, k, n, rows_per_strip, am);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -348,13 +371,14 @@ int mvxi_linear_wgrad_split(const float *x, int ldx, const float *dz, int lddz, 
 int mvxi_linear_forward_split(const float *x, int ldx, const float *w, int ldw, const float *bias, float *y,
                               int ldy, double *stats, const float *row_w, long long rows, int k, int n, int relu,
                               unsigned *fin_counter, double fin_eps, float *fin_mean_inv, const FrameMap &fm, int pieces,
-                              hipStream_t st, const float *bn_y, int bn_ldy, const float *bn_mi) {
+                              hipStream_t st, const float *bn_y, int bn_ldy, const float *bn_mi, const SplitAmax &am) {
     const dim3 grid(mvx_cdiv(n, BNL), mvx_cdiv(rows, BM));
-#define MVX_GO(NP_, BK_, B_)                                                                                                       \
-    hipLaunchKernelGGL((linear_fwd_split<NP_, BK_, B_>), grid, dim3(256), 0, st, x, ldx, w, ldw, bias, y, ldy, stats, row_w, rows, k, \
-                       n, relu, fin_counter, fin_eps, fin_mean_inv, fm, bn_y, bn_ldy, bn_mi)
-    if (pieces == 3) { if (bn_y) MVX_GO(3, 32, true); else MVX_GO(3, 32, false); }
-    else             { if (bn_y) MVX_GO(2, 64, true); else MVX_GO(2, 64, false); }
+#define MVX_GO(NP_, BK_, B_, F_)                                                                                                     \
+    hipLaunchKernelGGL((linear_fwd_split<NP_, BK_, B_, F_>), grid, dim3(256), 0, st, x, ldx, w, ldw, bias, y, ldy, stats, row_w, rows, k, \
+                       n, relu, fin_counter, fin_eps, fin_mean_inv, fm, bn_y, bn_ldy, bn_mi, am.a)
+    if (pieces == 4)      { if (bn_y) MVX_GO(2, 64, true, 1); else MVX_GO(2, 64, false, 1); }
+    else if (pieces == 3) { if (bn_y) MVX_GO(3, 32, true, 0); else MVX_GO(3, 32, false, 0); }
+    else                  { if (bn_y) MVX_GO(2, 64, true, 0); else MVX_GO(2, 64, false, 0); }
 #undef MVX_GO
     MVX_LAUNCH_CHECK();
     return MVX_OK;

@@ -338,7 +338,19 @@ __global__ __launch_bounds__(256) void vox_gather(const float *__restrict__ pcd,
 
 }  // namespace
 
-extern "C" int mvx_abi_version(void) { return 5; }
+extern "C" int mvx_abi_version(void) { return 6; }
+
+// fp16-piece operand scaling: see mvx_split_operand_amax in include/mvx_hip.h and split_common.h
+static thread_local SplitAmax t_split_amax = {nullptr, nullptr};
+extern "C" int mvx_split_operand_amax(const float *amax_a, const float *amax_b) {
+    t_split_amax = SplitAmax{amax_a, amax_b};
+    return MVX_OK;
+}
+SplitAmax mvxi_take_split_amax() {
+    const SplitAmax r = t_split_amax;
+    t_split_amax = SplitAmax{nullptr, nullptr};
+    return r;
+}
 
 // Diagnostics: kernel launches issued through the library since it was loaded (the only process-wide state it keeps;
 // hipMemsetAsync fills are not counted).  bench.py reports the difference over the timed steps.

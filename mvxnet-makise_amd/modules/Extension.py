@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MVX_HIP_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'libmvx_hip.so'))
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _p = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -118,7 +118,9 @@ PROTOTYPES = {
     'mvx_bn_finalize_frames': (_i32, [_p, _f64, _f64, _p, _i32, _i32, _p]),
     'mvx_bn_apply_frames': (_i32, [_p, _p, _p, _i64, _i32, _p, _i32, _p]),
     'mvx_bn_backward_scratch_bytes_frames': (_sz, [_i32, _i32]),
-    'mvx_bn_relu_backward_frames': (_i32, [_p, _p, _p, _f64, _p, _p, _p, _p, _i64, _i32, _i32, _p, _i32, _p]),
+    'mvx_split_operand_amax': (_i32, [_p, _p]),
+    'mvx_tensor_amax': (_i32, [_p, _i64, _p, _i32, _p]),
+    'mvx_bn_relu_backward_frames': (_i32, [_p, _p, _p, _f64, _p, _p, _p, _p, _i64, _i32, _i32, _p, _i32, _p, _p]),
     'mvx_vfe_bn_max_concat_frames': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p, _p]),
     'mvx_bn_segment_max_frames': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p, _p]),
     'mvx_voxel_row_offsets_frames': (_i32, [_p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p]),
@@ -143,7 +145,7 @@ PROTOTYPES = {
     'mvx_conv3d_wgrad_bg_workspace_bytes_frames': (_sz, [_i32, _i32, _i32, _i32, _i32, _i32]),
     'mvx_conv3d_wgrad_bg_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _i32, _p]),
     'mvx_bn_relu_backward_tiles_workspace_bytes_frames': (_sz, [_i32, _i32, _i32, _i32, _i32]),
-    'mvx_bn_relu_backward_tiles_frames': (_i32, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _sz, _i32, _p]),
+    'mvx_bn_relu_backward_tiles_frames': (_i32, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _i32, _p, _sz, _i32, _p]),
     'mvx_cl_to_bev_frames': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_conv2d_forward_frames': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _f64, _p, _p, _i32, _p]),
     'mvx_conv2d_dgrad_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _i32, _p]),

@@ -15,6 +15,7 @@ FLAG_RELU, FLAG_PREZEROED, FLAG_ACCUMULATE, FLAG_CONV2D = 1, 2, 4, 8      # MVX_
 FLAG_SPLIT = 64                                                          # MVX_FLAG_SPLIT: bf16x3 arithmetic of the wide row GEMMs
 FLAG_SUMS_READY = 256                                                    # MVX_FLAG_SUMS_READY: the BatchNorm-backward sums were accumulated by the producer of dyhat
 FLAG_SPLIT3 = 128                                                        # MVX_FLAG_SPLIT3: three bf16 pieces per operand (bf16x6, fp32-grade)
+FLAG_SPLIT_F16 = 512                                                     # MVX_FLAG_SPLIT_F16: two fp16 pieces per operand (fp16x3)
 
 
 def split_flags(split, row=False):
@@ -22,16 +23,67 @@ def split_flags(split, row=False):
     MVX_FLAG_SPLIT; the *_split convolution entry points only look at MVX_FLAG_SPLIT3)."""
     if not split:
         return 0
-    return (FLAG_SPLIT if row else 0) | (FLAG_SPLIT3 if int(split) == 3 else 0)
+    return (FLAG_SPLIT if row else 0) | (FLAG_SPLIT3 if int(split) == 3 else 0) | (FLAG_SPLIT_F16 if int(split) == 4 else 0)
+
+
+def amax_of(t):
+    """The 1-element float32 tensor holding max |t| that a producer kernel wrote (``tag_amax``), or None."""
+    return getattr(t, '_mvx_amax', None)
+
+
+def tag_amax(t, amax):
+    """Attach the device-side max |t| (1-element float32 tensor, kept alive by the attribute) to ``t``: the fp16x3 kernels scale
+    the operand by it (include/mvx_hip.h: mvx_split_operand_amax).  A ``.view()`` of t does not carry the tag: re-tag it."""
+    if t is not None and amax is not None:
+        t._mvx_amax = amax
+    return t
+
+
+def new_amax(device):
+    """A 1-element float32 tensor for a producer kernel to write max |dz| into.  Its OWN allocation, not a slot of the
+    accumulator arena: side-stream weight-gradient kernels read it after the arena of their lane has been cleared for the next
+    frame."""
+    return torch.empty((1,), dtype=torch.float32, device=device)
+
+
+def tensor_amax(t):
+    """Measure max |t| on the device (one pass over t) and tag t with it."""
+    am = torch.empty((1,), dtype=torch.float32, device=t.device)
+    X.check(X.lib.mvx_tensor_amax(X.ptr(t), t.numel(), X.ptr(am), 0, X.stream()), 'mvx_tensor_amax')
+    return tag_amax(t, am)
+
+
+def bind_amax(split, a=None, b=None):
+    """fp16x3 (split code 4): bind the operand ranges of the NEXT split launch to the tags of tensors a / b (untagged: not
+    scaled).  The entry point that follows consumes the binding."""
+    if split and int(split) == 4:
+        X.lib.mvx_split_operand_amax(X.ptr(amax_of(a)) if a is not None else None, X.ptr(amax_of(b)) if b is not None else None)
+
+
+def foreign_split(split):
+    """Arithmetic of a FORWARD row GEMM whose input was not produced by this library (sampled image features, the input of a
+    stand-alone FCN): fp16x3 would need a data-dependent scale there, and a scale taken over whatever tensor the executor
+    happens to hold (one frame, a frame set) makes two executors round differently -- enough to flip ReLUs between them
+    (tools/dbg_fp16_seeds.py).  Forward operands are therefore never scaled by data; the foreign-input layer runs in bf16x6,
+    which has the range of f32."""
+    return 3 if (split and int(split) == 4) else split
+
+
+def grad_split(split, dz):
+    """Arithmetic of a row GEMM whose operand ``dz`` is a gradient: fp16x3 needs its range (a tag), else bf16x6 stands in (the
+    row kernels split both operands in the kernel, so any arithmetic can run any call)."""
+    if split and int(split) == 4 and amax_of(dz) is None:
+        return 3
+    return split
 
 
 def split_pieces():
     """convmath of config.yml -> 0 (f32: exact-f32 MFMA), 2 (bf16x3) or 3 (bf16x6)."""
     import modules.config as cfg
     m = cfg.config.get('convmath', 'f32')
-    if m not in ('f32', 'bf16x3', 'bf16x6'):
-        raise X.MvxHipError('convmath must be f32, bf16x3 or bf16x6, not %r' % (m,))
-    return {'f32': 0, 'bf16x3': 2, 'bf16x6': 3}[m]
+    if m not in ('f32', 'bf16x3', 'bf16x6', 'fp16x3'):
+        raise X.MvxHipError('convmath must be f32, bf16x3, bf16x6 or fp16x3, not %r' % (m,))
+    return {'f32': 0, 'bf16x3': 2, 'bf16x6': 3, 'fp16x3': 4}[m]
 FLAG_BG_TAPS = 32
 
 # When True, the backward of the hot-path layers adds weight / bias gradients straight into the existing
@@ -111,6 +163,8 @@ class _SideStream:
 
     def __init__(self, *tensors):
         self.tensors = [t for t in tensors if t is not None]
+        # the side-stream kernels also read the range tags of their operands (fp16x3: amax_of): separate allocations
+        self.tensors += [a for a in (amax_of(t) for t in self.tensors) if a is not None]
 
     def __enter__(self):
         dev = self.tensors[0].device
@@ -467,10 +521,12 @@ def bn_relu_backward(dyhat, y, mi, count, want_dbias=True, dz=None, row_w=None, 
     else:
         dbias = torch.empty((C,), dtype=torch.float32, device=y.device) if want_dbias else None
     scratch, fz = _acc_f64((X.lib.mvx_bn_backward_scratch_bytes(C) // 8,), y.device)
+    amax = new_amax(y.device)
     with _timed_bytes('bn_relu_backward', 5 * y.numel() * 4):      # reduce reads 2 tensors, apply reads 2 + writes 1
-        X.check(X.lib.mvx_bn_relu_backward(X.ptr(dyhat), X.ptr(y), X.ptr(mi), float(count), X.ptr(dz),
-                                           X.ptr(dbias), X.ptr(scratch), X.ptr(row_w), rows, C, flags | fz, X.stream()),
-                'mvx_bn_relu_backward')
+        X.check(X.lib.mvx_bn_relu_backward_frames(X.ptr(dyhat), X.ptr(y), X.ptr(mi), float(count), X.ptr(dz),
+                                                  X.ptr(dbias), X.ptr(scratch), X.ptr(row_w), rows, C, flags | fz, None,
+                                                  X.ROWS_SINGLE, X.ptr(amax), X.stream()), 'mvx_bn_relu_backward_frames')
+    tag_amax(dz, amax)                                   # max |dz|: the range the fp16x3 kernels scale dz by
     return dz, (None if dbias_out is not None else dbias)
 
 
@@ -526,6 +582,7 @@ def conv3d_dgrad(dz, wpk_d, din, cin, sd, pd, split=False):
     dx = torch.empty((din, H, W, cin), dtype=torch.float32, device=dz.device)
     if split:
         with _Timed('conv3d_gather_split', conv_flops(din, dout, H, W, cout, cin, sd, pd, True) if KERNEL_TIMERS is not None else 0):
+            bind_amax(split, dz)
             X.check(X.lib.mvx_conv3d_dgrad_split(X.ptr(dz), X.ptr(wpk_d), X.ptr(dx), din, dout, H, W, cin, cout, sd, pd,
                                                  split_flags(split), X.stream()), 'mvx_conv3d_dgrad_split')
         return dx
@@ -556,6 +613,7 @@ def conv3d_wgrad(x, dz, sd, pd, split=False, accumulate_into=None, two_d=False):
     with _wgrad_scope(accumulate_into, x, dz) as scope:
         ws = workspace(nbytes, x.device, 'wgrad_side' if isinstance(scope, _SideStream) else 'wgrad')
         with _Timed(name, conv_flops(dout, din, H, W, cin, cout, sd, pd) if KERNEL_TIMERS is not None else 0):
+            bind_amax(split, x, dz)
             X.check(fn(X.ptr(x), X.ptr(dz), X.ptr(dw), din, dout, H, W, cin, cout, sd, pd, flags, X.ptr(ws), ws.numel(),
                        X.stream()), 'mvx_' + name)
     return None if accumulate_into is not None else dw
@@ -648,6 +706,7 @@ def conv3d_dgrad_tiles(dz, wpk_d, din, cin, sd, pd, tflag, split=False):
     dx = torch.empty((din, H, W, cin), dtype=torch.float32, device=dz.device)
     if split:
         with _Timed('conv3d_gather_split', 0):
+            bind_amax(split, dz)
             X.check(X.lib.mvx_conv3d_dgrad_tiles_split(X.ptr(dz), X.ptr(wpk_d), X.ptr(dx), din, dout, H, W, cin, cout, sd, pd,
                                                        split_flags(split), X.ptr(tflag), X.stream()), 'mvx_conv3d_dgrad_tiles_split')
         return dx
@@ -675,11 +734,13 @@ def bn_relu_backward_tiles(dyhat, y, mi, bg, plane_grad_sums, dbias_out=None, wa
         db, flags = torch.empty((C,), dtype=torch.float32, device=y.device), 0
     ws = workspace(X.lib.mvx_bn_relu_backward_tiles_workspace_bytes(D, H, W, C), y.device, 'bn_tiles')
     inact = torch.empty((D, C), dtype=torch.float32, device=y.device) if want_inactive_sums else None
+    amax = new_amax(y.device)                            # max |dz| over the written tiles (zeroed by the call)
     with _timed_bytes('bn_relu_backward_tiles', 0):
-        X.check(X.lib.mvx_bn_relu_backward_tiles(X.ptr(dyhat), X.ptr(y), X.ptr(mi), X.ptr(bg.c), X.ptr(bg.y_bg),
-                                                 X.ptr(plane_grad_sums), X.ptr(bg.bflag), D, H, W, C, X.ptr(dz), X.ptr(db),
-                                                 X.ptr(inact), flags, X.ptr(ws), ws.numel(), X.stream()),
-                'mvx_bn_relu_backward_tiles')
+        X.check(X.lib.mvx_bn_relu_backward_tiles_frames(X.ptr(dyhat), X.ptr(y), X.ptr(mi), X.ptr(bg.c), X.ptr(bg.y_bg),
+                                                        X.ptr(plane_grad_sums), X.ptr(bg.bflag), D, H, W, C, X.ptr(dz), X.ptr(db),
+                                                        X.ptr(inact), X.ptr(amax), flags, X.ptr(ws), ws.numel(), 1, X.stream()),
+                'mvx_bn_relu_backward_tiles_frames')
+    tag_amax(dz, amax)
     db = None if dbias_out is not None else db
     return (dz, db, inact) if want_inactive_sums else (dz, db)
 
@@ -739,6 +800,7 @@ def conv3d_wgrad_bg(x, dz, sd, pd, bg_in, tap_sums=None, accumulate_into=None, s
     with _wgrad_scope(accumulate_into, x, dz, tap_sums, bg_in.c, bg_in.hflag) as scope:
         ws = workspace(nbytes, x.device, 'wgrad_bg_side' if isinstance(scope, _SideStream) else 'wgrad_bg')
         with _Timed('conv3d_wgrad_bg', 0):
+            bind_amax(split, None, dz)
             X.check(fn(X.ptr(x), X.ptr(dz), X.ptr(dw), din, dout, H, W, cin, cout, sd, pd, flags,
                                               X.ptr(bg_in.hflag), X.ptr(bg_in.c), X.ptr(tap_sums), X.ptr(ws), ws.numel(),
                                               X.stream()),
@@ -820,8 +882,8 @@ def row_split(tag):
     np_ = split_pieces()
     if np_ == 2:
         return 2 if any(tag.startswith(k) for k in ROW_SPLIT) else 0
-    if np_ == 3:
-        return 3 if any(tag.startswith(k) for k in ROW_SPLIT6) else 0
+    if np_ in (3, 4):
+        return np_ if any(tag.startswith(k) for k in ROW_SPLIT6) else 0
     return 0
 
 
@@ -863,11 +925,14 @@ def linear_forward(x, w, bias, relu=True, want_stats=True, w_transposed=False, r
     if out is None:
         out = torch.empty((R, N), dtype=torch.float32, device=x.device)
     stats, fz = _acc_f64((STATS_REPLICAS, 2, N), x.device) if want_stats else (None, 0)
+    if label == 'linear_dgrad':
+        split = grad_split(split, x)
     if finalize is not None and want_stats and R > 0:
         counter = _fin_slot(x.device, fz)
         if counter is None:
             counter = torch.zeros((1,), dtype=torch.float64, device=x.device)
         mi = torch.empty((2, N), dtype=torch.float32, device=x.device)
+        bind_amax(split, x)
         X.check(X.lib.mvx_linear_forward_bn(_vptr(x), _ld(x), _vptr(w), _ld(w), int(w_transposed), X.ptr(bias),
                                             _vptr(out), _ld(out), X.ptr(stats), X.ptr(row_w), R, K, N,
                                             (FLAG_RELU if relu else 0) | fz | split_flags(split, True), X.ptr(counter), float(finalize[0]),
@@ -877,6 +942,7 @@ def linear_forward(x, w, bias, relu=True, want_stats=True, w_transposed=False, r
     if bias is None and not relu and not want_stats and K >= 256 and R * N <= (1 << 22):
         ws = workspace(X.lib.mvx_linear_splitk_workspace_bytes(R, N), x.device, 'splitk')
     with _Timed(label or ('linear_dgrad' if w_transposed else 'linear_fwd'), 2.0 * R * K * N if KERNEL_TIMERS is not None else 0):
+        bind_amax(split, x)
         X.check(X.lib.mvx_linear_forward(_vptr(x), _ld(x), _vptr(w), _ld(w), int(w_transposed), X.ptr(bias),
                                          _vptr(out), _ld(out), X.ptr(stats), X.ptr(row_w), R, K, N,
                                          (FLAG_RELU if relu else 0) | fz | split_flags(split, True),
@@ -886,7 +952,7 @@ def linear_forward(x, w, bias, relu=True, want_stats=True, w_transposed=False, r
     return out, stats
 
 
-def linear_wgrad(x, dz, accumulate_into=None, split=None):
+def linear_wgrad(x, dz, accumulate_into=None, split=None, x_foreign=False):
     """dW (N,K) = dz^T x; accumulate_into: existing contiguous (N,K)-sized gradient buffer to ADD to.  ``split``: bf16x3
     arithmetic (MVX_FLAG_SPLIT, csrc/linear_split.hip linear_wgrad_split); None = as ``row_split('wgrad')`` says."""
     R, K = x.shape
@@ -896,11 +962,15 @@ def linear_wgrad(x, dz, accumulate_into=None, split=None):
         dw, flags = accumulate_into, FLAG_ACCUMULATE
     else:
         dw, flags = torch.empty((N, K), dtype=torch.float32, device=x.device), 0
-    flags |= split_flags(row_split('wgrad') if split is None else split, True)
+    split = grad_split(row_split('wgrad') if split is None else split, dz)
+    if x_foreign and amax_of(x) is None:             # a foreign input of unknown range: see foreign_split
+        split = foreign_split(split)
+    flags |= split_flags(split, True)
     nbytes = X.lib.mvx_linear_wgrad_workspace_bytes(R, K, N)
     with _wgrad_scope(accumulate_into, x, dz) as scope:
         ws = workspace(nbytes, x.device, 'lwgrad_side' if isinstance(scope, _SideStream) else 'lwgrad')
         with _Timed('linear_wgrad', 2.0 * R * K * N if KERNEL_TIMERS is not None else 0):
+            bind_amax(split, x, dz)
             X.check(X.lib.mvx_linear_wgrad(_vptr(x), _ld(x), _vptr(dz), _ld(dz), X.ptr(dw), R, K, N, flags, X.ptr(ws),
                                            ws.numel(), X.stream()), 'mvx_linear_wgrad')
     return None if accumulate_into is not None else dw
@@ -1149,7 +1219,7 @@ def sparse_conv_gather_dz(dz, coords, din, sd, pd):
     G = torch.empty((V, 27 * cout), dtype=torch.float32, device=dz.device)
     X.check(X.lib.mvx_sparse_conv_gather_dz(X.ptr(dz), X.ptr(coords), V, X.ptr(G), din, dout, H, W, cout, sd, pd,
                                             X.stream()), 'mvx_sparse_conv_gather_dz')
-    return G
+    return tag_amax(G, amax_of(dz))                     # G's rows are rows of dz
 
 
 def sink_of(param):

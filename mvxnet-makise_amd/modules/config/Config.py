@@ -22,7 +22,7 @@ r, s = config['velorange'], config['voxelshape']
 config['voxelsize'] = [(r[k + 3] - r[k]) / s[k] for k in range(3)]
 config['eps'] = 1e-3 if config['half'] else 1e-6
 config['dtype'] = torch.float16 if config['half'] else torch.float32
-# MVX_CONVMATH overrides `convmath` of config.yml (f32 | bf16x6 | bf16x3): lets one test / bench run be repeated in another
+# MVX_CONVMATH overrides `convmath` of config.yml (f32 | fp16x3 | bf16x6 | bf16x3): lets one test / bench run be repeated in another
 # arithmetic without editing the file
 if os.environ.get('MVX_CONVMATH'):
     config['convmath'] = os.environ['MVX_CONVMATH']

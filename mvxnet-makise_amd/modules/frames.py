@@ -95,8 +95,9 @@ TAP_SKIP = os.environ.get('MVX_TAP_SKIP', '1') != '0'     # conv2 / conv3 forwar
 KNOCKOUT = frozenset(k for k in os.environ.get('MVX_KNOCKOUT', '').split(',') if k)
 
 
-def linear_bn(x, w, b, fs, kind, row_w, eps, tag='fusion'):
-    """rows -> (y = ReLU(x w^T + b), mean_inv (F,2,N)) with per-frame statistics formed inside the launch."""
+def linear_bn(x, w, b, fs, kind, row_w, eps, tag='fusion', foreign=False):
+    """rows -> (y = ReLU(x w^T + b), mean_inv (F,2,N)) with per-frame statistics formed inside the launch.  ``foreign``: x was not
+    produced by this library (the sampled image features): _hip.foreign_split."""
     Rr, K = x.shape
     N = w.shape[0]
     w2 = w.reshape(N, -1)
@@ -108,7 +109,8 @@ def linear_bn(x, w, b, fs, kind, row_w, eps, tag='fusion'):
     mi = torch.empty((fs.F, 2, N), dtype=torch.float32, device=x.device)
     if 'lin_fwd' in KNOCKOUT:
         return y, mi
-    sp = _hip.split_flags(_hip.row_split(tag), True)        # convmath bf16x3 / bf16x6: the wide layers on the split-MFMA row GEMM
+    sp = _hip.row_split(tag)                             # convmath bf16x3 / bf16x6 / fp16x3: the wide layers on the split-MFMA row GEMM
+    sp = _hip.split_flags(_hip.foreign_split(sp) if foreign else sp, True)
     with _hip._Timed('linear_fwd', 2.0 * Rr * K * N if _hip.KERNEL_TIMERS is not None else 0):
         X.check(X.lib.mvx_linear_forward_bn_frames(_hip._vptr(x), _hip._ld(x), _hip._vptr(w2), _hip._ld(w2), 0, X.ptr(b),
                                                    _hip._vptr(y), _hip._ld(y), X.ptr(stats), X.ptr(row_w), Rr, K, N,
@@ -142,11 +144,12 @@ def bn_relu_backward(dyhat, y, mi, fs, kind, row_w, dbias_into, dz=None, sums=No
         scratch, fz = sums, _hip.FLAG_SUMS_READY
     else:
         scratch, fz = _hip._acc_f64((X.lib.mvx_bn_backward_scratch_bytes_frames(C, fs.F) // 8,), y.device)
+    amax = _hip.new_amax(y.device)
     with _hip._timed_bytes('bn_relu_backward', (3 if sums is not None else 5) * y.numel() * 4):
         X.check(X.lib.mvx_bn_relu_backward_frames(X.ptr(dyhat), X.ptr(y), X.ptr(mi), 1.0, X.ptr(dz), X.ptr(dbias_into),
                                                   X.ptr(scratch), X.ptr(row_w), rows, C, _hip.FLAG_ACCUMULATE | fz,
-                                                  fs.desc.ref(), kind, X.stream()), 'mvx_bn_relu_backward_frames')
-    return dz
+                                                  fs.desc.ref(), kind, X.ptr(amax), X.stream()), 'mvx_bn_relu_backward_frames')
+    return _hip.tag_amax(dz, amax)                      # max |dz|: the range the fp16x3 kernels scale dz by
 
 
 # BatchNorm-backward reduction in the epilogue of the producing input-gradient kernel (VERDICT r03 #1a).  Built, tested
@@ -160,7 +163,7 @@ def rows_dgrad_bnsums(dz, w2, y_below, mi_below, fs, kind):
     """dx = dz w2 (the input gradient of a row layer) AND the BatchNorm-backward sums of the layer below -- whose dL/dyhat dx is
     -- from the output tile in registers (mvx_linear_dgrad_bnsums_frames).  Returns (dx, scratch) or None when the call does not
     qualify (exact-f32 arithmetic, narrow layer): the caller then uses _rows_dgrad + the reduction pass."""
-    sp = _hip.row_split('dgrad')
+    sp = _hip.grad_split(_hip.row_split('dgrad'), dz)
     N = w2.shape[1]
     if not (BN_SUMS_FUSED and sp and N > 64 and 'lin_dgrad' not in KNOCKOUT and 'bn_bwd_rows' not in KNOCKOUT):
         return None
@@ -168,6 +171,7 @@ def rows_dgrad_bnsums(dz, w2, y_below, mi_below, fs, kind):
     dx = torch.empty((dz.shape[0], N), dtype=torch.float32, device=dz.device)
     scratch, fz = _hip._acc_f64((X.lib.mvx_bn_backward_scratch_bytes_frames(N, fs.F) // 8,), dz.device)
     with _hip._Timed('linear_dgrad', 2.0 * dz.shape[0] * dz.shape[1] * N if _hip.KERNEL_TIMERS is not None else 0):
+        _hip.bind_amax(sp, dz)
         X.check(X.lib.mvx_linear_dgrad_bnsums_frames(_hip._vptr(dz), _hip._ld(dz), _hip._vptr(wt), _hip._ld(wt), X.ptr(dx), N,
                                                      dz.shape[0], dz.shape[1], N, _hip.split_flags(sp, True) | fz, X.ptr(y_below),
                                                      y_below.shape[1], X.ptr(mi_below), X.ptr(scratch), fs.desc.ref(), kind,
@@ -239,6 +243,11 @@ def sample_rows(head, fs, fpn_levels, imsize):
         X.check(X.lib.mvx_feature_sample_rows_frames(X.ptr(fs.vox2d), fs.vox2d.shape[1], X.ptr(fs.rows_sel), Rt, ptrs, hw, L, C,
                                                      float(imsize[0]), float(imsize[1]), float(cfg.eps), X.ptr(compact),
                                                      X.ptr(status), fs.desc.ref(), X.stream()), 'mvx_feature_sample_rows_frames')
+    if _hip.split_pieces() == 4:
+        # fp16x3: the image features come from outside this library -- measure their range (one pass, on the stream that sampled
+        # them: the preparation stream in the training pipeline) so that the first fusion layer's WEIGHT GRADIENT can scale them
+        # (its forward runs in bf16x6: _hip.foreign_split)
+        _hip.tensor_amax(compact)
     return compact, status
 
 
@@ -266,8 +275,9 @@ def rows_forward(model, fs, fpn_levels, imsize, status_sink, imfeat=None):
     status_sink.append(status)
     # ---- fusion MLP (imhead/Pipe.py:84-104) on [real rows | one shared padded row per frame]
     x = compact
-    for w, b in head.fusion._layers():
-        y, mi = linear_bn(x, w, b, fs, X.ROWS_FUSION, fs.fusion_row_w, eps, 'fusion_%dx%d' % (w.shape[0], w[0].numel()))
+    for i, (w, b) in enumerate(head.fusion._layers()):
+        y, mi = linear_bn(x, w, b, fs, X.ROWS_FUSION, fs.fusion_row_w, eps, 'fusion_%dx%d' % (w.shape[0], w[0].numel()),
+                          foreign=(i == 0))
         S.fusion.append((x, w, b, y, mi))
         x = bn_apply(y, mi, fs, X.ROWS_FUSION)
     return _vfe_forward(bb, fs, x, S, eps)
@@ -514,6 +524,7 @@ def _wgrad_bg(rec, dz, tap_sums, F, H, W):
     with _hip._SideStream(x, dz, tap_sums, rec['c_in'], rec['hflag_in']):
         ws = _hip.workspace(nbytes, x.device, 'wgrad_bg_side')
         with _hip._Timed('conv3d_wgrad_bg', fl):
+            _hip.bind_amax(rec.get('split'), None, dz)
             X.check(X.lib.mvx_conv3d_wgrad_bg_frames(X.ptr(x), X.ptr(dz), X.ptr(dw), rec['din'], rec['dout'], H, W, ci, co,
                                                      rec['sd'], rec['pd'], _hip.FLAG_ACCUMULATE | sp, X.ptr(rec['hflag_in']),
                                                      X.ptr(rec['c_in']), X.ptr(tap_sums), X.ptr(ws), ws.numel(), F, X.stream()),
@@ -586,6 +597,7 @@ def cml_backward(model, S, grad_mid, g_cl=None):
         if rec.get('split'):
             with _hip._Timed('conv3d_gather_tiles', F * _hip.conv_flops(rec['din'], rec['dout'], H, W, co, ci, rec['sd'], rec['pd'], True)
                              if _hip.KERNEL_TIMERS is not None else 0):
+                _hip.bind_amax(rec['split'], dz)
                 X.check(X.lib.mvx_conv3d_dgrad_tiles_split_frames(X.ptr(dz), X.ptr(wpd), X.ptr(dx), rec['din'], rec['dout'], H, W, ci,
                                                                   co, rec['sd'], rec['pd'], _hip.split_flags(rec['split']), X.ptr(bflag),
                                                                   X.ptr(counter), F, X.stream()), 'mvx_conv3d_dgrad_tiles_split_frames')
@@ -610,6 +622,7 @@ def cml_backward(model, S, grad_mid, g_cl=None):
         dz = torch.empty_like(y)
         ws = _hip.workspace(X.lib.mvx_bn_relu_backward_tiles_workspace_bytes_frames(planes, H, W, Cn, F), dev, 'bn_tiles')
         inact = torch.empty((F * planes, Cn), dtype=torch.float32, device=dev) if want_inactive else None
+        amax = _hip.new_amax(dev)                                             # max |dz| over the written tiles (zeroed by the call)
         if 'bn_bwd_tiles' in KNOCKOUT:
             return dz, inact
         # algorithmic bytes (timing runs only): the flagged 8x16 tiles, two passes reading dyhat and y, the second writing dz
@@ -617,9 +630,9 @@ def cml_backward(model, S, grad_mid, g_cl=None):
         with _hip._timed_bytes('bn_relu_backward_tiles', nbytes):
             X.check(X.lib.mvx_bn_relu_backward_tiles_frames(X.ptr(gin), X.ptr(y), X.ptr(mi), X.ptr(c_bg), X.ptr(y_bg), X.ptr(A),
                                                             X.ptr(bflag), planes, H, W, Cn, X.ptr(dz), X.ptr(_grad_of(bias)),
-                                                            X.ptr(inact), _hip.FLAG_ACCUMULATE, X.ptr(ws), ws.numel(), F,
+                                                            X.ptr(inact), X.ptr(amax), _hip.FLAG_ACCUMULATE, X.ptr(ws), ws.numel(), F,
                                                             X.stream()), 'mvx_bn_relu_backward_tiles_frames')
-        return dz, inact
+        return _hip.tag_amax(dz, amax), inact
 
     # ---- conv3: dense gradient in, restricted gradient + closed-form plane sums out
     r3, r2 = S.convs[1], S.convs[0]
@@ -645,6 +658,7 @@ def cml_backward(model, S, grad_mid, g_cl=None):
     cm = model.backbone.cml.conv1
     X.check(X.lib.mvx_sparse_conv_gather_dz_frames(X.ptr(dz1), X.ptr(fs.coords), Vt, X.ptr(G), c1['D0'], c1['D1'], H, W, cout,
                                                    cm._sd, cm._pd, fs.desc.ref(), X.stream()), 'mvx_sparse_conv_gather_dz_frames')
+    _hip.tag_amax(G, _hip.amax_of(dz1))                                    # G's rows are rows of dz1
     dw_all = _hip.linear_wgrad(c1['feat'], G)                              # (27*cout, cin), main stream (small)
     with _hip._SideStream(dw_all):
         _grad_of(w1).add_(dw_all.reshape(3, 3, 3, cout, cin).permute(3, 4, 0, 1, 2))

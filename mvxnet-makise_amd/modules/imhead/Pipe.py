@@ -107,8 +107,8 @@ class ImageFeatureFusion(nn.Module):
 
     def forward_rows(self, x2d, row_w=None, count=None):
         """rows (R,768) [+ multiplicities] -> (R,16)."""
-        for w, b in self._layers():
-            x2d = fcn_rows(x2d, w, b, row_w, count)
+        for i, (w, b) in enumerate(self._layers()):
+            x2d = fcn_rows(x2d, w, b, row_w, count, foreign=(i == 0))      # layer 0 reads the sampled image features
         return x2d
 
     def forward(self, x):

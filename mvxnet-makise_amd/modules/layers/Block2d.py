@@ -133,7 +133,8 @@ class Block2dFunction(torch.autograd.Function):
                 gt = torch.empty_like(S['y'])
                 X.check(X.lib.mvx_d2s_bn_apply_frames(X.ptr(gt), None, X.ptr(gc), 1, h, wd, s, cout, cout, 0, 1, X.stream()),
                         'mvx_d2s_bn_apply_frames')
-                dz = rf._bn_bwd(gt.view(-1, cout), S['y'].view(-1, cout), S['mi'], 1, b).view(S['y'].shape)
+                dz0 = rf._bn_bwd(gt.view(-1, cout), S['y'].view(-1, cout), S['mi'], 1, b)
+                dz = rf._retag(dz0.view(S['y'].shape), dz0)
                 dw_all = _hip.linear_wgrad(S['xr'], dz)                           # (s*s*cout, cin)
                 dw.add_(dw_all.view(s, s, cout, cin).permute(3, 2, 0, 1))
                 if need_dx:

@@ -25,13 +25,16 @@ class FCNFunction(torch.autograd.Function):
     row standing for several identical rows of the reference's dense tensor)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, eps, row_w, count):
+    def forward(ctx, x, w, b, eps, row_w, count, foreign=True):
+        # ``foreign``: x is not the output of one of this library's BatchNorms (its range is unknown): _hip.foreign_split
         w2 = w.reshape(w.shape[0], -1)
+        sp = _hip.row_split('fusion_%dx%d' % tuple(w2.shape))
         y, mi = _hip.linear_forward(x, w2, b, relu=True, want_stats=True, row_w=row_w, finalize=(count, eps),
-                                    split=_hip.row_split('fusion_%dx%d' % tuple(w2.shape)))
+                                    split=_hip.foreign_split(sp) if foreign else sp)
         out = _hip.bn_apply(y, mi)
         ctx.save_for_backward(x, w, y, mi, row_w)
         ctx.count = count
+        ctx.foreign = foreign
         ctx.params = (w, b)
         return out
 
@@ -42,17 +45,17 @@ class FCNFunction(torch.autograd.Function):
         sw, sb = _hip.sink_of(ctx.params[0]), _hip.bias_sink_of(ctx.params[1])
         dz, db = _hip.bn_relu_backward(g.contiguous(), y, mi, ctx.count, True, row_w=row_w, dbias_out=sb)
         db = _hip.accumulate_grad(ctx.params[1], db)
-        dw = _hip.linear_wgrad(x, dz, accumulate_into=sw)
+        dw = _hip.linear_wgrad(x, dz, accumulate_into=sw, x_foreign=ctx.foreign)
         dw = dw.reshape(w.shape) if dw is not None else None
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _hip.rows_dgrad(dz, w2)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def fcn_rows(x2d, weight, bias, row_w=None, count=None):
+def fcn_rows(x2d, weight, bias, row_w=None, count=None, foreign=True):
     count = x2d.shape[0] if count is None else count
-    return FCNFunction.apply(x2d, weight, bias, cfg.eps, row_w, float(count))
+    return FCNFunction.apply(x2d, weight, bias, cfg.eps, row_w, float(count), foreign)
 
 
 class FCN(nn.Module):

@@ -180,10 +180,16 @@ def _bn_bwd(g, y, mi, F, bias, sums=None):
         scratch, fz = sums, _hip.FLAG_SUMS_READY
     else:
         scratch, fz = _hip._acc_f64((X.lib.mvx_bn_backward_scratch_bytes_frames(C, F) // 8,), y.device)
+    amax = _hip.new_amax(y.device)
     X.check(X.lib.mvx_bn_relu_backward_frames(X.ptr(g), X.ptr(y), X.ptr(mi), 1.0, X.ptr(dz), X.ptr(_grad_of(bias)), X.ptr(scratch),
                                               None, y.numel() // C, C, _hip.FLAG_ACCUMULATE | fz, _desc(F).ref(), X.ROWS_GRID,
-                                              X.stream()), 'mvx_bn_relu_backward_frames')
-    return dz
+                                              X.ptr(amax), X.stream()), 'mvx_bn_relu_backward_frames')
+    return _hip.tag_amax(dz, amax)                      # max |dz|: the range the fp16x3 kernels scale dz by
+
+
+def _retag(t, like):
+    """A view of a tagged gradient keeps the tag."""
+    return _hip.tag_amax(t, _hip.amax_of(like))
 
 
 def _dgrad(dz, wpd, F, h, w, cin, cout, flags, bn_below=None):
@@ -194,6 +200,7 @@ def _dgrad(dz, wpd, F, h, w, cin, cout, flags, bn_below=None):
     if bn_below is not None and BN_SUMS_FUSED and _split() and not (flags & TAPS2):
         scratch, fz = _hip._acc_f64((X.lib.mvx_bn_backward_scratch_bytes_frames(cin, F) // 8,), dz.device)
         with _hip._Timed('rpn_conv', 2.0 * F * h * w * cin * cout * 9 if _hip.KERNEL_TIMERS is not None else 0):
+            _hip.bind_amax(_split(), dz)
             X.check(X.lib.mvx_conv2d_dgrad_split_bnsums_frames(X.ptr(dz), X.ptr(wpd), X.ptr(dx), h, w, cin, cout,
                                                                _hip.split_flags(_split()) | fz, X.ptr(bn_below[0]), X.ptr(bn_below[1]),
                                                                X.ptr(scratch), F, X.stream()), 'mvx_conv2d_dgrad_split_bnsums_frames')
@@ -202,6 +209,7 @@ def _dgrad(dz, wpd, F, h, w, cin, cout, flags, bn_below=None):
         return _dgrad(dz, wpd, F, h, w, cin, cout, flags), None
     if _split():
         with _hip._Timed('rpn_conv', 2.0 * F * h * w * cin * cout * (2.25 if flags & TAPS2 else 9) if _hip.KERNEL_TIMERS is not None else 0):
+            _hip.bind_amax(_split(), dz)
             X.check(X.lib.mvx_conv2d_dgrad_split_frames(X.ptr(dz), X.ptr(wpd), X.ptr(dx), h, w, cin, cout, flags | _hip.split_flags(_split()), F, X.stream()),
                     'mvx_conv2d_dgrad_split_frames')
         return dx
@@ -222,6 +230,7 @@ def _wgrad(x, dz, F, h, w, cin, cout, flags, into=None):
     nt = 2.25 if flags & TAPS2 else 9
     with _hip._SideStream(x, dz, dw), _hip._Timed('rpn_wgrad', 2.0 * F * h * w * cin * cout * nt if _hip.KERNEL_TIMERS is not None else 0):
         ws = _hip.workspace(nbytes, dev, 'rpn_wgrad_side')
+        _hip.bind_amax(_split(), None, dz)
         X.check(X.lib.mvx_conv2d_wgrad_frames(X.ptr(x), X.ptr(dz), X.ptr(dw), h, w, cin, cout,
                                               flags | sp | (_hip.FLAG_ACCUMULATE if into is not None else 0), X.ptr(ws), ws.numel(), F,
                                               X.stream()), 'mvx_conv2d_wgrad_frames')
@@ -347,7 +356,8 @@ def rpn_backward(rpn, S, d_heads):
         gt = torch.empty_like(rec['t'])
         X.check(X.lib.mvx_d2s_bn_apply_frames(X.ptr(gt), None, X.ptr(g_up), F, hk, wk, s, cout, 768, off, 1, X.stream()),
                 'mvx_d2s_bn_apply_frames')
-        dz = _bn_bwd(gt.view(-1, cout), rec['t'].view(-1, cout), rec['mi'], F, m.deconv.bias).view(rec['t'].shape)
+        dz0 = _bn_bwd(gt.view(-1, cout), rec['t'].view(-1, cout), rec['mi'], F, m.deconv.bias)
+        dz = _retag(dz0.view(rec['t'].shape), dz0)
         dw_all = _hip.linear_wgrad(rec['x'], dz)                           # (s*s*cout, cin)
         with _hip._SideStream(dw_all):
             _grad_of(m.deconv.weight).add_(dw_all.view(s, s, cout, cin).permute(3, 2, 0, 1))

@@ -60,7 +60,7 @@ def middle_forward(model, voxels, fpn_levels, idx, imsize, prepared, status_sink
     # fusion MLP (imhead/Pipe.py:84-104): the sampled image features carry no gradient
     x = compact
     for i, (w, b) in enumerate(head.fusion._layers()):
-        x = _call(tape, FCNFunction, i > 0, x, w, b, cfg.eps, row_w, float(rows))
+        x = _call(tape, FCNFunction, i > 0, x, w, b, cfg.eps, row_w, float(rows), i == 0)
     # concat with the 7 geometric channels (MVXNet.py:26), VFE stack (voxelnet/Pipe.py:5-29), FCN + max (VoxelNet.py:27-33)
     x = _call(tape, CompactInputFunction, True, x, vox2d, cr)
     for vfe in (bb.svfe.vfe1, bb.svfe.vfe2):

@@ -220,6 +220,7 @@ def test_rpn_forward_backward_match_oracle(golden, F):
             g_up, g_dx = cap[(bi, li)]
             g_up = g_up.cpu().double().permute(0, 3, 1, 2)
             dw_sum, db_sum = torch.zeros_like(w_), torch.zeros_like(b_)
+            on_kink = False
             for f in range(F):                                   # batch-1 forwards: per-frame statistics
                 xf = xin[f:f + 1].clone().requires_grad_(True)
                 yh = O.crb2d(xf, w_, b_, 2 if li == 0 else 1, 1)
@@ -228,12 +229,21 @@ def test_rpn_forward_backward_match_oracle(golden, F):
                 dw_sum += gw
                 db_sum += gb
                 e = rel(_nchw_grad_of(g_dx, rec, F)[f:f + 1], gxf)
-                worst = max(worst, e)
-                assert e < 1e-5, (name, li, 'input gradient', e)
+                # a pre-activation within 3e-7 of zero (|y| ~ 1 elsewhere: inside ANY fp32 evaluation's rounding) decides its ReLU
+                # either way; the flipped site then moves this layer's gradients by ~1e-2 through the BatchNorm statistics (seen
+                # with F = 3 on blk1.1: min |y| = 7.2e-8, 1145 of 196608 elements off; tools/dbg_rpn_fp16.py).  Such a frame is
+                # only required to be close; test_rpn_and_loss_gradients_tight_at_full_size shares the masks instead
+                pre = torch.nn.functional.conv2d(xf.detach(), w_.detach(), b_.detach(), stride=2 if li == 0 else 1, padding=1)
+                kink = float(pre.abs().min()) < 3e-7
+                on_kink = on_kink or kink
+                if not kink:
+                    worst = max(worst, e)
+                assert e < (5e-2 if kink else 1e-5), (name, li, 'input gradient', e)
             m = getattr(rpn, name)[li]
             e_w, e_b = rel(m.conv.weight.grad.cpu().double(), dw_sum), rel(m.conv.bias.grad.cpu().double(), db_sum)
-            worst = max(worst, e_w, e_b)
-            assert e_w < 1e-5 and e_b < 1e-5, (name, li, e_w, e_b)
+            if not on_kink:
+                worst = max(worst, e_w, e_b)
+            assert e_w < (5e-2 if on_kink else 1e-5) and e_b < (5e-2 if on_kink else 1e-5), (name, li, e_w, e_b)
     # deconvolutions and heads: same-input check with the exact upstream gradient (the heads are linear)
     W_heads = torch.cat([P64['rpn.cls.weight'].view(2, 768), P64['rpn.reg.weight'].view(14, 768)])
     h1, w1 = H // 2, W // 2

@@ -37,7 +37,7 @@ for name, rows, C in shapes:
         scratch.zero_()
         X.check(X.lib.mvx_bn_relu_backward_frames(X.ptr(g), X.ptr(y), X.ptr(mi), 1.0, X.ptr(dz), X.ptr(db), X.ptr(scratch), None,
                                                   rows, C, _hip.FLAG_ACCUMULATE | _hip.FLAG_PREZEROED, desc.ref(), X.ROWS_GRID,
-                                                  X.stream()), 'bn_bwd')
+                                                  None, X.stream()), 'bn_bwd')
 
     def fwd():
         X.check(X.lib.mvx_bn_apply_frames(X.ptr(y), X.ptr(mi), X.ptr(o), rows, C, desc.ref(), X.ROWS_GRID, X.stream()), 'bn_apply')
