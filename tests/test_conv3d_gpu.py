@@ -140,12 +140,13 @@ def split_units(request):
     X.check(X.lib.mvx_tuning_set(1, 768), 'mvx_tuning_set')
 
 
-@pytest.mark.parametrize('pieces,tol', [(2, 2e-5), (3, 4e-6)])
+@pytest.mark.parametrize('pieces,tol', [(2, 2e-5), (3, 4e-6), (4, 4e-6)])
 @pytest.mark.parametrize('cin,cout,din,H,W,sd,pd', GEOMS[:4])
 def test_conv3d_bf16x3_split_accuracy(cin, cout, din, H, W, sd, pd, split_units, pieces, tol):
     """Split kernels against float64.  bf16x3 (two pieces): 2e-5, well inside the 1e-4 feature bar; bf16x6 (three pieces = the
     whole f32 mantissa, six MFMAs per product): 4e-6 (an f32 accumulation chain over up to K = 3,456 products) AND never more
-    than twice the exact-f32 kernel's own distance from float64 on the same inputs (+ 5e-7)."""
+    than twice the exact-f32 kernel's own distance from float64 on the same inputs (+ 5e-7).  fp16x3 (code 4: two fp16 pieces,
+    22 mantissa bits, three MFMAs; operands of unit scale need no range tag): the bf16x6 bounds."""
     from modules import _hip
     split = pieces
     g = torch.Generator().manual_seed(cin + 3 * H)
@@ -157,7 +158,7 @@ def test_conv3d_bf16x3_split_accuracy(cin, cout, din, H, W, sd, pd, split_units,
     wd = w.to(DEV)
     out, stats = _hip.conv3d_forward(xc, _hip.conv3d_pack(wd, False, split=split), b.to(DEV), cout, sd, pd, split=split)
     assert rel_err(out.cpu().permute(3, 0, 1, 2), y) < tol
-    if pieces == 3:
+    if pieces >= 3:
         o32, _ = _hip.conv3d_forward(xc, _hip.conv3d_pack(wd, False), b.to(DEV), cout, sd, pd)
         assert rel_err(out.cpu().permute(3, 0, 1, 2), y) < 2 * rel_err(o32.cpu().permute(3, 0, 1, 2), y) + 5e-7
     np.testing.assert_allclose(stats.sum(0)[0].cpu().numpy(), y.numpy().reshape(cout, -1).sum(1), rtol=1e-4, atol=5e-2)
@@ -175,7 +176,7 @@ def test_conv3d_bf16x3_split_accuracy(cin, cout, din, H, W, sd, pd, split_units,
         assert rel_err(dw.cpu(), wg.grad) < tol
 
 
-@pytest.mark.parametrize('split', [False, 2, 3])
+@pytest.mark.parametrize('split', [False, 2, 3, 4])
 def test_conv3d_full_size_adjoint_identities(split):
     """BASELINE-size grid (conv2 geometry, 5x352x400x64): the three passes must be mutually adjoint,
     <dz, conv(x)> = <dgrad(dz), x> = <wgrad(x, dz), w> -- a size-independent check that needs no CPU
@@ -195,12 +196,12 @@ def test_conv3d_full_size_adjoint_identities(split):
     b = float((dx.double() * x.double()).sum())
     c = float((dw.double() * w.double()).sum())
     scale = float(dz.double().norm() * y.double().norm())
-    tol = 2e-5 if split == 2 else 2e-6            # bf16x6 is held to the exact-f32 bound
+    tol = 2e-5 if split == 2 else 2e-6            # bf16x6 and fp16x3 are held to the exact-f32 bound
     assert abs(a - b) / scale < tol and abs(a - c) / scale < tol, (a, b, c, scale)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('pieces', [2, 3])
+@pytest.mark.parametrize('pieces', [2, 3, 4])
 @pytest.mark.parametrize('shape', [(5, 40, 48, 1, 0), (3, 37, 53, 2, 1), (10, 24, 35, 2, 1)])
 def test_background_rewrite_equals_dense(shape, split_units, pieces):
     """conv3d_forward_bg / conv3d_wgrad_bg (constant fill of voxel-free tiles, closed-form constant term)

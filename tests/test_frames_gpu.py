@@ -227,7 +227,7 @@ def test_batch_prepared_a_step_ahead_with_its_fpn_sampling_gives_the_same_step(g
         assert rel_err(bucket.flat, ref) < 1e-6
 
 
-@pytest.mark.parametrize('math', ['bf16x6', 'bf16x3'])
+@pytest.mark.parametrize('math', ['fp16x3', 'bf16x6', 'bf16x3'])
 def test_batchnorm_backward_sums_from_the_producing_kernel(golden, small_cfg, math):
     """The BatchNorm-backward reduction (sum dyhat, sum dyhat * yhat per frame and channel) accumulated in the epilogue of the
     kernel that PRODUCES dyhat -- the split row GEMM of the next layer's input gradient (mvx_linear_dgrad_bnsums_frames,

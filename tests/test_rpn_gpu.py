@@ -65,7 +65,7 @@ def _narrow_wide_body(X, _hip, rf, cfg, F, h, w, g, got):
 
 
 def test_stride2_and_stride1_layers_in_split_arithmetic_match_exact_f32():
-    """The RPN's 3x3 layers in convmath bf16x6 / bf16x3 against the exact-f32 kernels on the same inputs: forward (with the
+    """The RPN's 3x3 layers in convmath fp16x3 / bf16x6 / bf16x3 against the exact-f32 kernels on the same inputs: forward (with the
     BatchNorm statistics), input gradient and weight gradient, stride 1 and stride 2 (MVX_FLAG_TAPS2: the 2x2 window on the
     space-to-depth image, with the structurally zero (window tap, parity) blocks skipped in all three arithmetics), on a
     ragged map and with both gather unit shapes of the split kernels."""
@@ -86,7 +86,7 @@ def test_stride2_and_stride1_layers_in_split_arithmetic_match_exact_f32():
             b = torch.randn((cout,), generator=g).to(DEV)
             dz = torch.randn((F, h, w, cout), generator=g).to(DEV)
             res = {}
-            for math, units in (('f32', 0), ('bf16x6', 0), ('bf16x6', 1 << 60), ('bf16x3', 0)):
+            for math, units in (('f32', 0), ('fp16x3', 0), ('fp16x3', 1 << 60), ('bf16x6', 0), ('bf16x6', 1 << 60), ('bf16x3', 0)):
                 cfg.config['convmath'] = math
                 sp = _hip.split_pieces()
                 X.check(X.lib.mvx_tuning_set(1, units), 'mvx_tuning_set')          # MVX_TUNE_SPLIT16_MIN_UNITS: 16x16 / 8x16 units
@@ -103,7 +103,7 @@ def test_stride2_and_stride1_layers_in_split_arithmetic_match_exact_f32():
                 torch.cuda.synchronize()
                 res[(math, units)] = (y.clone(), mi.clone(), dx.clone(), dw.clone())
             ref = res[('f32', 0)]
-            for key, tol in ((('bf16x6', 0), 3e-6), (('bf16x6', 1 << 60), 3e-6), (('bf16x3', 0), 3e-5)):
+            for key, tol in ((('fp16x3', 0), 3e-6), (('fp16x3', 1 << 60), 3e-6), (('bf16x6', 0), 3e-6), (('bf16x6', 1 << 60), 3e-6), (('bf16x3', 0), 3e-5)):
                 r = res[key]
                 for name, a, bb in zip(('y', 'mean_inv', 'dx', 'dw'), r, ref):
                     assert rel(a, bb) < tol * (10 if name == 'mean_inv' else 1), (cin0, cout, s2, key, name, rel(a, bb))
@@ -301,7 +301,7 @@ def test_rpn_bf16x3_mode_stays_within_the_feature_bar(golden):
     res = {}
     old = cfg.config.get('convmath', 'f32')
     try:
-        for math in ('f32', 'bf16x3', 'bf16x6'):
+        for math in ('f32', 'bf16x3', 'bf16x6', 'fp16x3'):
             cfg.config['convmath'] = math
             bucket.zero()
             heads, S = rf.rpn_forward(rpn, x_cl, F, 2, H, W, 64)
@@ -313,7 +313,8 @@ def test_rpn_bf16x3_mode_stays_within_the_feature_bar(golden):
         cfg.config['convmath'] = old
     assert rel(res['bf16x3'][0], res['f32'][0]) < 3e-4
     assert rel(res['bf16x6'][0], res['f32'][0]) < 5e-5          # bf16x6 (three pieces, fp32-grade): both are ~2e-5 from float64
-    for math in ('bf16x3', 'bf16x6'):
+    assert rel(res['fp16x3'][0], res['f32'][0]) < 5e-5          # fp16x3 (two fp16 pieces, 22 bits): likewise
+    for math in ('bf16x3', 'bf16x6', 'fp16x3'):
         assert rel(res[math][1], res['f32'][1]) < 1e-1          # input gradient: the ReLU-kink sensitivity of these small maps
         a, b = res[math][2], res['f32'][2]
         off = 0
@@ -363,17 +364,19 @@ def test_rpn_full_size_maps_match_the_float64_oracle(golden):
     e2_reg = rel(got2[..., 2:], reg[0].permute(1, 2, 0))
     print('  bf16x3: score %.2e (abs), reg %.2e (max-norm rel)' % (e2_score, e2_reg))
     assert e2_score < 5e-4 and e2_reg < 5e-4
-    # ... and in convmath: bf16x6 (three bf16 pieces per operand, fp32-grade): north_star's 1e-4 bar like the exact-f32 mode
-    cfg.config['convmath'] = 'bf16x6'
-    try:
-        heads3, _ = rf.rpn_forward(rpn, _to_planes(mids.to(DEV)), F, 2, H, W, 64)
-    finally:
-        cfg.config['convmath'] = old
-    got3 = heads3.view(F, H // 2, W // 2, 16)[1].cpu().double()
-    e3_score = float((torch.sigmoid(got3[..., :2]) - score[0].permute(1, 2, 0)).abs().max())
-    e3_reg = rel(got3[..., 2:], reg[0].permute(1, 2, 0))
-    print('  bf16x6: score %.2e (abs), reg %.2e (max-norm rel)' % (e3_score, e3_reg))
-    assert e3_score < 1e-4 and e3_reg < 1e-4
+    # ... and in the 22+-bit split arithmetics -- bf16x6 (three bf16 pieces per operand) and fp16x3 (two fp16 pieces, the
+    # default) --: north_star's 1e-4 bar like the exact-f32 mode
+    for math in ('bf16x6', 'fp16x3'):
+        cfg.config['convmath'] = math
+        try:
+            heads3, _ = rf.rpn_forward(rpn, _to_planes(mids.to(DEV)), F, 2, H, W, 64)
+        finally:
+            cfg.config['convmath'] = old
+        got3 = heads3.view(F, H // 2, W // 2, 16)[1].cpu().double()
+        e3_score = float((torch.sigmoid(got3[..., :2]) - score[0].permute(1, 2, 0)).abs().max())
+        e3_reg = rel(got3[..., 2:], reg[0].permute(1, 2, 0))
+        print('  %s: score %.2e (abs), reg %.2e (max-norm rel)' % (math, e3_score, e3_reg))
+        assert e3_score < 1e-4 and e3_reg < 1e-4, math
 
 
 def test_rpn_module_runs_on_the_hip_node_and_matches_float64():
