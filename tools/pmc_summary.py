@@ -28,16 +28,18 @@ def load(sub):
     return acc
 
 
-sq, sq2, fe, wr = load('pmc_sq'), load('pmc_sq2'), load('pmc_fetch'), load('pmc_write')
+sq, sq2, sq3, fe, wr = load('pmc_sq'), load('pmc_sq2'), load('pmc_sq3'), load('pmc_fetch'), load('pmc_write')
 out = {'source': root, 'kernels': {}}
 for k in sorted(sq):
     c = {n: sum(v) / len(v) for n, v in sq[k].items()}
     c.update({n: sum(v) / len(v) for n, v in sq2.get(k, {}).items()})
+    c.update({n: sum(v) / len(v) for n, v in sq3.get(k, {}).items()})
     cyc = c.get('GRBM_GUI_ACTIVE', 0) / 8.0
     e = {'launches_in_pass': len(sq[k].get('GRBM_GUI_ACTIVE', [])), 'cycles_per_xcd': cyc,
          'mfma_busy_frac': c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (cyc * 1024) if cyc else None,
-         'executed_matrix_gflop': (c.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0) + c.get('SQ_INSTS_VALU_MFMA_MOPS_BF16', 0)) * 512 / 1e9,
-         'mops_f32_raw': c.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0), 'mops_bf16_raw': c.get('SQ_INSTS_VALU_MFMA_MOPS_BF16', 0),
+         'executed_matrix_gflop': (c.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0) + c.get('SQ_INSTS_VALU_MFMA_MOPS_BF16', 0) +
+                                   c.get('SQ_INSTS_VALU_MFMA_MOPS_F16', 0)) * 512 / 1e9,
+         'mops_f32_raw': c.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0), 'mops_bf16_raw': c.get('SQ_INSTS_VALU_MFMA_MOPS_BF16', 0), 'mops_f16_raw': c.get('SQ_INSTS_VALU_MFMA_MOPS_F16', 0),
          'lds_bank_conflict_cycles': c.get('SQ_LDS_BANK_CONFLICT', 0), 'lds_active_cycles': c.get('SQ_LDS_IDX_ACTIVE', 0),
          'wave_cycles': c.get('SQ_WAVE_CYCLES', 0)}
     if k in fe and 'FETCH_SIZE' in fe[k]:
@@ -64,12 +66,19 @@ def source_sha(files):
     return h.hexdigest()[:16]
 
 
-dom = [k for k in out['kernels'] if k.startswith('conv3d_gather_splitT<3, 16, 2')] or [k for k in out['kernels'] if k.startswith('conv3d_gather_pw')]
+# the dominant gather of the run's arithmetic: fp16x3 <2, 32, 2, WIN, 1>, bf16x6 <3, 16, 2, WIN, 0>, bf16x3 <2, 32, 2, WIN, 0>, exact f32
+dom, math = None, None
+for pat, m in ((r'conv3d_gather_splitT<2, 32, 2, \w+, 1>', 'fp16x3'), (r'conv3d_gather_splitT<3, 16, 2, \w+, 0>', 'bf16x6'),
+               (r'conv3d_gather_splitT<2, 32, 2, \w+, 0>', 'bf16x3'), (r'conv3d_gather_pw', 'f32')):
+    hit = [k for k in out['kernels'] if re.match(pat, k)]
+    if hit:
+        dom, math = sorted(hit, key=lambda k: -out['kernels'][k]['launches_in_pass']), m
+        break
 if dom and len(sys.argv) > 3:
     e = out['kernels'][dom[0]]
     split = dom[0].startswith('conv3d_gather_splitT')
     files = ['conv3d_split.hip', 'split_common.h', 'common.h'] if split else ['conv3d.hip', 'common.h']
-    tj = {'kernel': dom[0], 'source_files': files, 'source_sha16': source_sha(files),
+    tj = {'kernel': dom[0], 'convmath': math, 'source_files': files, 'source_sha16': source_sha(files),
           'hbm_bytes_per_launch': e.get('hbm_fetch_bytes', 0) + e.get('hbm_write_bytes', 0),
           'fetch_bytes': e.get('hbm_fetch_bytes'), 'write_bytes': e.get('hbm_write_bytes'), 'launches_in_pass': e['launches_in_pass'],
           'corrections': 'FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count of wide reads), WRITE_SIZE KiB x 1024 raw; separate --pmc passes',

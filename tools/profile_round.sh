@@ -34,6 +34,7 @@ run_pass() {   # name, steps, warmup, rocprofv3 options...
 run_pass stats 20 5 --kernel-trace --stats
 run_pass pmc_sq 4 2 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace
 run_pass pmc_sq2 4 2 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace
+run_pass pmc_sq3 4 2 --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU --kernel-trace
 run_pass pmc_fetch 4 2 --pmc FETCH_SIZE --kernel-trace
 run_pass pmc_write 4 2 --pmc WRITE_SIZE --kernel-trace
 cd "$ROOT"
