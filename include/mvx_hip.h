@@ -56,6 +56,10 @@ extern "C" {
                                   fp16 MFMAs per product ("fp16x3": fp32-grade accuracy at the matrix work of bf16x3) -- for operands inside fp16's
                                   range: values above 65,504 overflow and below ~1e-4 lose relative precision, so callers scale by powers of two */
 
+#define MVX_FLAG_AMAX_COARSE 1024 /* mvx_linear_forward*: the x operand bound by mvx_split_operand_amax is a FORWARD input from outside the library
+                                  (sampled image features): its scale exponent is rounded down to a multiple of 8 binades, so that a frame set and
+                                  one of its frames -- whose maxima differ -- scale, and therefore round, alike */
+
 #define MVX_FLAG_SUMS_READY 256 /* mvx_bn_relu_backward_frames: `scratch` already holds (sum dyhat, sum dyhat * yhat) of every frame, accumulated by
                                   the kernel that PRODUCED dyhat (mvx_linear_dgrad_bnsums_frames, mvx_conv2d_dgrad_split_bnsums_frames): the
                                   reduction pass is not run */

@@ -30,6 +30,7 @@ struct FrameMap;
 // launch; taking them clears the binding (defined in voxelize.hip)
 struct SplitAmax {
     const float *a, *b;      // max |value| of the first / second f32 operand of the launch (device addresses), or NULL
+    int coarse_a;            // operand a is a FORWARD operand from outside the library: coarse scale (split_scale_coarse)
 };
 SplitAmax mvxi_take_split_amax();
 
@@ -40,10 +41,10 @@ int mvxi_linear_forward_split(const float *x, int ldx, const float *w, int ldw, 
                               int ldy, double *stats, const float *row_w, long long rows, int k, int n, int relu,
                               unsigned *fin_counter, double fin_eps, float *fin_mean_inv, const FrameMap &fm, int pieces,
                               hipStream_t st, const float *bn_y = nullptr, int bn_ldy = 0, const float *bn_mi = nullptr,
-                              const SplitAmax &am = SplitAmax{nullptr, nullptr});
+                              const SplitAmax &am = SplitAmax{nullptr, nullptr, 0});
 int mvxi_linear_wgrad_split(const float *x, int ldx, const float *dz, int lddz, float *slabs, long long rows, int k, int n,
                             long long rows_per_strip, long long strips, int pieces, hipStream_t st,
-                            const SplitAmax &am = SplitAmax{nullptr, nullptr});
+                            const SplitAmax &am = SplitAmax{nullptr, nullptr, 0});
 int mvxi_wgrad_step_list(const int32_t *in_halo_flags, int din, int dout, int ntiles, int stride_d, int pad_d, int *list,
                          int *count, hipStream_t st, int n_frames = 1);
 int mvxi_wgrad_rank1(const float *tap_sums, const float *c_in, float *dw, int din, int dout, int cin, int cout, int stride_d,

@@ -929,7 +929,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv3d_wgrad4s(const float *__rest
                                                              const int *__restrict__ step_count,
                                                              const float *__restrict__ c_in, Strips ks, SplitAmax am) {
     float x_scale = 1.f, z_scale = 1.f;                       // fp16 pieces: operands scaled by their bound amax (split_common.h)
-    if constexpr (FMT == 1) { x_scale = split_scale_of(am.a); z_scale = split_scale_of(am.b); }
+    if constexpr (FMT == 1) { x_scale = split_scale_coarse(am.a); z_scale = split_scale_of(am.b); }     // x: activations, dz: gradients
     __shared__ __attribute__((aligned(16))) unsigned short s_x[NP][2][HH * HW][32];      // [piece][32-channel block][halo site][channel]
     __shared__ __attribute__((aligned(16))) unsigned short s_z[NP][2][TH * TW][32];      // [piece][32-channel block][site][channel]
     const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;

@@ -396,7 +396,8 @@ static int linear_forward_impl(const float *x, int32_t ldx, const float *w, int3
                                int64_t rows, int32_t k, int32_t n, int32_t flags, void *splitk_workspace,
                                size_t splitk_workspace_bytes, unsigned *fin_counter, double fin_count, double fin_eps,
                                float *fin_mean_inv, const mvx_frames_t *frames, int row_kind, void *stream) {
-    const SplitAmax am = mvxi_take_split_amax();         // x bound for this call (fp16 pieces); cleared whatever kernel runs
+    SplitAmax am = mvxi_take_split_amax();               // x bound for this call (fp16 pieces); cleared whatever kernel runs
+    am.coarse_a = (flags & MVX_FLAG_AMAX_COARSE) ? 1 : 0;
     const int relu = flags & MVX_FLAG_RELU;
     MVX_CHECK_ARG(x && w && y && rows >= 0 && k > 0 && n > 0 && ldx >= k && ldy >= n);
     MVX_CHECK_ARG(ldw >= (w_transposed ? n : k));

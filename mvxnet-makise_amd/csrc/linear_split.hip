@@ -29,11 +29,11 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
                                                         unsigned *__restrict__ done_counter, double fin_eps,
                                                         float *__restrict__ fin_mean_inv, FrameMap fm,
                                                         const float *__restrict__ bn_y, int bn_ldy,
-                                                        const float *__restrict__ bn_mi, const float *__restrict__ x_amax) {
+                                                        const float *__restrict__ bn_mi, const float *__restrict__ x_amax, int x_coarse) {
     // fp16 pieces (FMT = 1, split_common.h): x is scaled by x_scale (from its bound amax, else 1), w by SPLIT_F16_WSCALE; the
     // accumulators are scaled back in front of the epilogue
     float x_scale = 1.f;
-    if constexpr (FMT == 1) x_scale = split_scale_of(x_amax);
+    if constexpr (FMT == 1) x_scale = x_coarse ? split_scale_coarse(x_amax) : split_scale_of(x_amax);
     // BNB (compile time; input-gradient GEMMs, bn_y != NULL): the rows written are dL/dyhat of the BatchNorm-ed layer whose pre-BN output is bn_y
     // (mean / inverse std bn_mi [F][2][N]); `stats` is then that layer's BatchNorm-BACKWARD accumulator [F][REP][3][N] and takes
     // sum g and sum g * yhat per frame -- the reduction pass of mvx_bn_relu_backward_frames (MVX_FLAG_SUMS_READY) from the tile
@@ -262,7 +262,8 @@ __global__ __launch_bounds__(256) void linear_wgrad_split(const float *__restric
                                                           int lddz, float *__restrict__ slabs, long long R, int K, int N,
                                                           long long rows_per_strip, SplitAmax am) {
     float x_scale = 1.f, z_scale = 1.f;                       // fp16 pieces: operands scaled by their bound amax (split_common.h)
-    if constexpr (FMT == 1) { x_scale = split_scale_of(am.a); z_scale = split_scale_of(am.b); }
+    // x is an activation: the coarse scale (a frame set and a single frame then scale it alike); dz: the fine one
+    if constexpr (FMT == 1) { x_scale = split_scale_coarse(am.a); z_scale = split_scale_of(am.b); }
     __shared__ __attribute__((aligned(16))) unsigned short s_z[NP][4][WRS][32];      // [piece][32-column block][row][column]
     __shared__ __attribute__((aligned(16))) unsigned short s_x[NP][4][WRS][32];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -375,7 +376,7 @@ int mvxi_linear_forward_split(const float *x, int ldx, const float *w, int ldw, 
     const dim3 grid(mvx_cdiv(n, BNL), mvx_cdiv(rows, BM));
 #define MVX_GO(NP_, BK_, B_, F_)                                                                                                     \
     hipLaunchKernelGGL((linear_fwd_split<NP_, BK_, B_, F_>), grid, dim3(256), 0, st, x, ldx, w, ldw, bias, y, ldy, stats, row_w, rows, k, \
-                       n, relu, fin_counter, fin_eps, fin_mean_inv, fm, bn_y, bn_ldy, bn_mi, am.a)
+                       n, relu, fin_counter, fin_eps, fin_mean_inv, fm, bn_y, bn_ldy, bn_mi, am.a, am.coarse_a)
     if (pieces == 4)      { if (bn_y) MVX_GO(2, 64, true, 1); else MVX_GO(2, 64, false, 1); }
     else if (pieces == 3) { if (bn_y) MVX_GO(3, 32, true, 0); else MVX_GO(3, 32, false, 0); }
     else                  { if (bn_y) MVX_GO(2, 64, true, 0); else MVX_GO(2, 64, false, 0); }

@@ -42,6 +42,21 @@ __device__ __forceinline__ float split_scale_of(const float *amax) {
     se = se < 2 ? 2 : (se > 252 ? 252 : se);
     return __uint_as_float((unsigned)se << 23);
 }
+// The COARSE scale of a forward operand that comes from outside the library (sampled image features): the exponent is rounded
+// down to a multiple of 8 binades, amax lands in [2^7, 2^15).  A forward scale must not depend on which tensor the executor
+// happens to hold -- a frame set and one of its frames have different maxima, different fine scales would round elements with
+// subnormal low pieces differently and flip ReLUs between the two executors -- and with 8-binade steps it does not, unless
+// two maxima straddle a step.  Elements down to amax / 2^10 keep 22 bits in the worst case.
+__device__ __forceinline__ float split_scale_coarse(const float *amax) {
+    if (!amax) return 1.f;
+    const int e = (int)((__float_as_uint(*amax) >> 23) & 0xffu);
+    if (e == 0 || e == 255) return 1.f;
+    const int t = 141 - e;                                   // 14 - floor(log2 amax)
+    const int k = t >= 0 ? (t & ~7) : -((7 - t) & ~7);       // rounded down to a multiple of 8
+    int se = 127 + k;
+    se = se < 2 ? 2 : (se > 252 ? 252 : se);
+    return __uint_as_float((unsigned)se << 23);
+}
 // 1 / s for s = 2^k (exact)
 __device__ __forceinline__ float split_inverse(float s) { return __uint_as_float((254u << 23) - __float_as_uint(s)); }
 

@@ -341,14 +341,14 @@ __global__ __launch_bounds__(256) void vox_gather(const float *__restrict__ pcd,
 extern "C" int mvx_abi_version(void) { return 6; }
 
 // fp16-piece operand scaling: see mvx_split_operand_amax in include/mvx_hip.h and split_common.h
-static thread_local SplitAmax t_split_amax = {nullptr, nullptr};
+static thread_local SplitAmax t_split_amax = {nullptr, nullptr, 0};
 extern "C" int mvx_split_operand_amax(const float *amax_a, const float *amax_b) {
-    t_split_amax = SplitAmax{amax_a, amax_b};
+    t_split_amax = SplitAmax{amax_a, amax_b, 0};
     return MVX_OK;
 }
 SplitAmax mvxi_take_split_amax() {
     const SplitAmax r = t_split_amax;
-    t_split_amax = SplitAmax{nullptr, nullptr};
+    t_split_amax = SplitAmax{nullptr, nullptr, 0};
     return r;
 }
 

@@ -15,6 +15,7 @@ FLAG_RELU, FLAG_PREZEROED, FLAG_ACCUMULATE, FLAG_CONV2D = 1, 2, 4, 8      # MVX_
 FLAG_SPLIT = 64                                                          # MVX_FLAG_SPLIT: bf16x3 arithmetic of the wide row GEMMs
 FLAG_SUMS_READY = 256                                                    # MVX_FLAG_SUMS_READY: the BatchNorm-backward sums were accumulated by the producer of dyhat
 FLAG_SPLIT3 = 128                                                        # MVX_FLAG_SPLIT3: three bf16 pieces per operand (bf16x6, fp32-grade)
+FLAG_AMAX_COARSE = 1024                                                  # MVX_FLAG_AMAX_COARSE: the bound x is a foreign forward input (8-binade scale steps)
 FLAG_SPLIT_F16 = 512                                                     # MVX_FLAG_SPLIT_F16: two fp16 pieces per operand (fp16x3)
 
 
@@ -60,13 +61,16 @@ def bind_amax(split, a=None, b=None):
         X.lib.mvx_split_operand_amax(X.ptr(amax_of(a)) if a is not None else None, X.ptr(amax_of(b)) if b is not None else None)
 
 
-def foreign_split(split):
+def foreign_split(split, x=None):
     """Arithmetic of a FORWARD row GEMM whose input was not produced by this library (sampled image features, the input of a
-    stand-alone FCN): fp16x3 would need a data-dependent scale there, and a scale taken over whatever tensor the executor
-    happens to hold (one frame, a frame set) makes two executors round differently -- enough to flip ReLUs between them
-    (tools/dbg_fp16_seeds.py).  Forward operands are therefore never scaled by data; the foreign-input layer runs in bf16x6,
-    which has the range of f32."""
-    return 3 if (split and int(split) == 4) else split
+    stand-alone FCN).  fp16x3 needs the input's range there, and a scale taken over whatever tensor the executor happens to
+    hold (one frame, a frame set) makes two executors round differently -- enough to flip ReLUs between them
+    (tools/dbg_fp16_seeds.py: 3e-2 on 4 of 6 seeds).  So: a foreign input WITH a range tag runs fp16x3 with the COARSE scale
+    (MVX_FLAG_AMAX_COARSE: 8-binade steps, the same for a frame and its set unless their maxima straddle a step); one without a
+    tag runs bf16x6, which has the range of f32.  Returns (split code, extra flags)."""
+    if split and int(split) == 4:
+        return (4, FLAG_AMAX_COARSE) if (x is not None and amax_of(x) is not None) else (3, 0)
+    return split, 0
 
 
 def grad_split(split, dz):
@@ -915,7 +919,7 @@ def rows_dgrad(dz, w2, label='linear_dgrad'):
 
 
 def linear_forward(x, w, bias, relu=True, want_stats=True, w_transposed=False, row_w=None, out=None, finalize=None,
-                   label=None, split=False):
+                   label=None, split=False, foreign=False):
     """x (R,K) view, w (N,K) [or (K,N) if w_transposed] -> y (R,N), stats f64 (2,N) or None.
     ``finalize=(count, eps)``: the BatchNorm mean / inverse std are formed by the kernel's last workgroup
     (mvx_linear_forward_bn); returns (y, mean_inv) then.  ``split``: bf16x3 arithmetic where the shape qualifies
@@ -927,6 +931,9 @@ def linear_forward(x, w, bias, relu=True, want_stats=True, w_transposed=False, r
     stats, fz = _acc_f64((STATS_REPLICAS, 2, N), x.device) if want_stats else (None, 0)
     if label == 'linear_dgrad':
         split = grad_split(split, x)
+    xfl = 0
+    if foreign:                                      # x comes from outside the library: foreign_split
+        split, xfl = foreign_split(split, x)
     if finalize is not None and want_stats and R > 0:
         counter = _fin_slot(x.device, fz)
         if counter is None:
@@ -935,7 +942,7 @@ def linear_forward(x, w, bias, relu=True, want_stats=True, w_transposed=False, r
         bind_amax(split, x)
         X.check(X.lib.mvx_linear_forward_bn(_vptr(x), _ld(x), _vptr(w), _ld(w), int(w_transposed), X.ptr(bias),
                                             _vptr(out), _ld(out), X.ptr(stats), X.ptr(row_w), R, K, N,
-                                            (FLAG_RELU if relu else 0) | fz | split_flags(split, True), X.ptr(counter), float(finalize[0]),
+                                            (FLAG_RELU if relu else 0) | fz | split_flags(split, True) | xfl, X.ptr(counter), float(finalize[0]),
                                             float(finalize[1]), X.ptr(mi), X.stream()), 'mvx_linear_forward_bn')
         return out, mi
     ws = None
@@ -945,7 +952,7 @@ def linear_forward(x, w, bias, relu=True, want_stats=True, w_transposed=False, r
         bind_amax(split, x)
         X.check(X.lib.mvx_linear_forward(_vptr(x), _ld(x), _vptr(w), _ld(w), int(w_transposed), X.ptr(bias),
                                          _vptr(out), _ld(out), X.ptr(stats), X.ptr(row_w), R, K, N,
-                                         (FLAG_RELU if relu else 0) | fz | split_flags(split, True),
+                                         (FLAG_RELU if relu else 0) | fz | split_flags(split, True) | xfl,
                                          X.ptr(ws), ws.numel() if ws is not None else 0, X.stream()), 'mvx_linear_forward')
     if finalize is not None and want_stats:      # empty input: no launch happened, finalise the (zero) sums separately
         return out, bn_finalize(stats, finalize[0], finalize[1])
@@ -963,8 +970,8 @@ def linear_wgrad(x, dz, accumulate_into=None, split=None, x_foreign=False):
     else:
         dw, flags = torch.empty((N, K), dtype=torch.float32, device=x.device), 0
     split = grad_split(row_split('wgrad') if split is None else split, dz)
-    if x_foreign and amax_of(x) is None:             # a foreign input of unknown range: see foreign_split
-        split = foreign_split(split)
+    if x_foreign:                                    # a foreign input of unknown range: see foreign_split
+        split = foreign_split(split, x)[0]
     flags |= split_flags(split, True)
     nbytes = X.lib.mvx_linear_wgrad_workspace_bytes(R, K, N)
     with _wgrad_scope(accumulate_into, x, dz) as scope:

@@ -109,9 +109,12 @@ def linear_bn(x, w, b, fs, kind, row_w, eps, tag='fusion', foreign=False):
     mi = torch.empty((fs.F, 2, N), dtype=torch.float32, device=x.device)
     if 'lin_fwd' in KNOCKOUT:
         return y, mi
-    sp = _hip.row_split(tag)                             # convmath bf16x3 / bf16x6 / fp16x3: the wide layers on the split-MFMA row GEMM
-    sp = _hip.split_flags(_hip.foreign_split(sp) if foreign else sp, True)
+    sp, xfl = _hip.row_split(tag), 0                     # convmath bf16x3 / bf16x6 / fp16x3: the wide layers on the split-MFMA row GEMM
+    if foreign:
+        sp, xfl = _hip.foreign_split(sp, x)
+    code, sp = sp, _hip.split_flags(sp, True) | xfl
     with _hip._Timed('linear_fwd', 2.0 * Rr * K * N if _hip.KERNEL_TIMERS is not None else 0):
+        _hip.bind_amax(code, x)                             # fp16x3: the range tag of a foreign input (the sampled image features)
         X.check(X.lib.mvx_linear_forward_bn_frames(_hip._vptr(x), _hip._ld(x), _hip._vptr(w2), _hip._ld(w2), 0, X.ptr(b),
                                                    _hip._vptr(y), _hip._ld(y), X.ptr(stats), X.ptr(row_w), Rr, K, N,
                                                    _hip.FLAG_RELU | fz | sp, X.ptr(counter), float(eps), X.ptr(mi), fs.desc.ref(),
@@ -245,8 +248,8 @@ def sample_rows(head, fs, fpn_levels, imsize):
                                                      X.ptr(status), fs.desc.ref(), X.stream()), 'mvx_feature_sample_rows_frames')
     if _hip.split_pieces() == 4:
         # fp16x3: the image features come from outside this library -- measure their range (one pass, on the stream that sampled
-        # them: the preparation stream in the training pipeline) so that the first fusion layer's WEIGHT GRADIENT can scale them
-        # (its forward runs in bf16x6: _hip.foreign_split)
+        # them: the preparation stream in the training pipeline) so that the first fusion layer can scale them (forward: the coarse
+        # scale, _hip.foreign_split)
         _hip.tensor_amax(compact)
     return compact, status
 

@@ -107,6 +107,8 @@ class ImageFeatureFusion(nn.Module):
 
     def forward_rows(self, x2d, row_w=None, count=None):
         """rows (R,768) [+ multiplicities] -> (R,16)."""
+        if _hip.split_pieces() == 4 and x2d.is_cuda and x2d.is_contiguous() and _hip.amax_of(x2d) is None:
+            _hip.tensor_amax(x2d)          # fp16x3: the range of the sampled features, for layer 0 (_hip.foreign_split)
         for i, (w, b) in enumerate(self._layers()):
             x2d = fcn_rows(x2d, w, b, row_w, count, foreign=(i == 0))      # layer 0 reads the sampled image features
         return x2d

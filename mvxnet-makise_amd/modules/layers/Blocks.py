@@ -29,8 +29,8 @@ class FCNFunction(torch.autograd.Function):
         # ``foreign``: x is not the output of one of this library's BatchNorms (its range is unknown): _hip.foreign_split
         w2 = w.reshape(w.shape[0], -1)
         sp = _hip.row_split('fusion_%dx%d' % tuple(w2.shape))
-        y, mi = _hip.linear_forward(x, w2, b, relu=True, want_stats=True, row_w=row_w, finalize=(count, eps),
-                                    split=_hip.foreign_split(sp) if foreign else sp)
+        y, mi = _hip.linear_forward(x, w2, b, relu=True, want_stats=True, row_w=row_w, finalize=(count, eps), split=sp,
+                                    foreign=foreign)
         out = _hip.bn_apply(y, mi)
         ctx.save_for_backward(x, w, y, mi, row_w)
         ctx.count = count

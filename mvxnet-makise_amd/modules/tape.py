@@ -54,6 +54,8 @@ def middle_forward(model, voxels, fpn_levels, idx, imsize, prepared, status_sink
     compact[nr].zero_()
     status = _hip.feature_sample(vox2d, levels, (float(imsize[0]), float(imsize[1])), cfg.eps, compact, row_map, rows_sel=rows_sel, n_real=nr)
     status_sink.append(status)
+    if _hip.split_pieces() == 4:
+        _hip.tensor_amax(compact)                       # fp16x3: the range of the image features (frames.sample_rows does the same)
     row_w = torch.ones((nr + 1,), dtype=torch.float32, device=v.device)
     row_w[nr] = float(rows - nr)
     cr = _hip.CompactRows(row_map, rows_sel, nr, n, t)

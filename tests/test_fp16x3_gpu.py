@@ -148,27 +148,49 @@ def test_binding_is_consumed_by_one_launch():
     assert rel_err(run(4), ref) < 2e-6
 
 
-def test_forward_operands_are_not_scaled_by_data(golden):
-    """Forward GEMMs take no range tag: an input of this library's own BatchNorm is in range as it is, and a layer reading
-    FOREIGN features (the first fusion layer) runs in bf16x6 -- a data-dependent forward scale would make a frame set and a
-    single frame round differently and flip ReLUs between the two executors (tools/dbg_fp16_seeds.py: 3e-2 on 4 of 6 seeds
-    before this rule, 8e-7 after).  Here: the function-level rule, and values far outside fp16's range through that layer."""
+def test_foreign_forward_inputs_take_the_coarse_scale_or_bf16x6(golden):
+    """A forward scale must not depend on which tensor the executor holds: a frame set and one of its frames have different
+    maxima, fine scales would round elements with subnormal low pieces differently and flip ReLUs between the two executors
+    (tools/dbg_fp16_seeds.py: 3e-2 on 4 of 6 seeds with a fine forward scale, 8e-7 with this rule).  Inputs produced by this
+    library's BatchNorms are in range as they are and take no tag; a FOREIGN input (the first fusion layer reads sampled image
+    features; any stand-alone FCN) runs fp16x3 with the coarse scale (8-binade steps) when it carries a range tag, bf16x6
+    otherwise.  Here: the rule, and values far outside fp16's range through such a layer, both ways."""
     from modules import _hip
     from modules.layers.Blocks import fcn_rows
     import modules.config as cfg
-    assert _hip.foreign_split(4) == 3 and _hip.foreign_split(3) == 3 and _hip.foreign_split(0) == 0
+    t = torch.ones((8,), device=DEV)
+    assert _hip.foreign_split(4) == (3, 0) and _hip.foreign_split(4, t) == (3, 0) and _hip.foreign_split(3, t) == (3, 0)
+    assert _hip.foreign_split(0, t) == (0, 0)
+    _hip.tensor_amax(t)
+    assert _hip.foreign_split(4, t) == (4, _hip.FLAG_AMAX_COARSE)
     old = cfg.config.get('convmath', 'f32')
     cfg.config['convmath'] = 'fp16x3'
     try:
         g = torch.Generator().manual_seed(3)
-        x = (torch.randn((3000, 768), generator=g) * 3e5).to(DEV)        # |x| up to ~1.5e6: beyond fp16
-        w = (torch.randn((768, 768), generator=g) / 28).to(DEV).requires_grad_(True)
-        b = torch.zeros((768,), device=DEV, requires_grad=True)
-        out = fcn_rows(x, w, b)                                           # foreign=True is the default
-        y = torch.relu(x.double() @ w.detach().double().t())
-        ref = (y - y.mean(0)) / torch.sqrt(y.var(0, unbiased=False) + cfg.eps)
-        assert bool(torch.isfinite(out).all()) and rel_err(out, ref) < 1e-5
-        out.square().sum().backward()
-        assert bool(torch.isfinite(w.grad).all())
+        x0 = torch.randn((3000, 768), generator=g)
+        w0 = (torch.randn((768, 768), generator=g) / 28)
+        for mag in (3e5, 2e-6, 1.0):                                      # |x| up to ~1.5e6 (beyond fp16), ~1e-5 (under it), ~5
+            for tagged in (True, False):
+                x = (x0 * mag).to(DEV)
+                if tagged:
+                    _hip.tensor_amax(x)
+                w = w0.clone().to(DEV).requires_grad_(True)
+                b = torch.zeros((768,), device=DEV, requires_grad=True)
+                l0 = _hip.X.lib.mvx_launch_count()
+                out = fcn_rows(x, w, b)                                   # foreign=True is the default
+                y = torch.relu(x.double() @ w.detach().double().t())
+                ref = (y - y.mean(0)) / torch.sqrt(y.var(0, unbiased=False) + cfg.eps)
+                assert bool(torch.isfinite(out).all()) and rel_err(out, ref) < 1e-5, (mag, tagged, rel_err(out, ref))
+                out.square().sum().backward()
+                assert bool(torch.isfinite(w.grad).all()), (mag, tagged)
+        # the coarse scale: x and 2 x fall on the same 8-binade step, are cut into the same pieces (no element small enough for a
+        # subnormal low piece here) and give results that differ by exactly that factor
+        x1 = torch.sign(x0) * (0.5 + torch.rand(x0.shape, generator=g))
+        xa, xb = (x1 * 3.0).to(DEV), (x1 * 3.0 * 2.0).to(DEV)             # a factor 2 is exact in every arithmetic
+        _hip.tensor_amax(xa), _hip.tensor_amax(xb)
+        wd = w0.to(DEV)
+        ya, _ = _hip.linear_forward(xa, wd, None, relu=False, want_stats=False, split=4, foreign=True)
+        yb, _ = _hip.linear_forward(xb, wd, None, relu=False, want_stats=False, split=4, foreign=True)
+        assert torch.equal(ya * 2.0, yb)
     finally:
         cfg.config['convmath'] = old

@@ -76,14 +76,21 @@ def _smooth_bound(name):
     5e-3 for the CML / VFE parameters (measured <= 1.1e-3 exact f32, <= 3.4e-3 bf16x6), 3e-2 for the fusion MLP (five
     BatchNorms over 176 k rows with K = 768 sums in front of them: measured <= 5.9e-3 exact f32, <= 2.1e-2 bf16x6 -- single
     elements of the 768 x 768 gradient that belong to almost-dead channels, whose inverse std of ~1000 multiplies whatever
-    rounding the forward GEMM left; the 2-norm below does not move).  One bound for both arithmetics."""
-    return 3e-2 if name.startswith('head.fusion.') else 5e-3
+    rounding the forward GEMM left; the 2-norm below does not move).  One bound for every arithmetic.  (1e-2, not 5e-3, since
+    fp16x3 became the default: a run whose forward differs in the 7th digit flips a few of the 1.4 M ReLUs of conv2 relative to
+    float64 and every gradient below moves together -- conv3's 0.4 x .. 0.6 x, conv2's and everything after it 1.4 x .. 3.1 x the
+    exact-f32 run's distance, profiles/r04_fullsize_parity_fp16x3.json.)"""
+    return 3e-2 if name.startswith('head.fusion.') else 1e-2
 
 
 # 2-norm distances from float64 under the smooth upstream gradient measured on MI355X in the exact-f32 arithmetic
-# (profiles/r03_fullsize_parity.json); the asserted bound is 2.0 x that measurement for BOTH arithmetics (bf16x6 lands at
-# 0.38 x .. 1.85 x the exact-f32 figure per parameter, profiles/r04_fullsize_parity_bf16x6.json), which every 1 % mutation of a
-# closed-form term still breaks (2.6 x .. 90 x over the bound)
+# (profiles/r03_fullsize_parity.json); the asserted bound is 3.5 x that measurement for EVERY arithmetic.  bf16x6 lands at
+# 0.38 x .. 1.85 x the exact-f32 figure per parameter (profiles/r04_fullsize_parity_bf16x6.json); fp16x3 at 0.43 x .. 3.1 x
+# (profiles/r04_fullsize_parity_fp16x3.json) -- not because its products are worse (they are closer to float64 than the exact-f32
+# MFMA's, tests/test_fp16x3_gpu.py) but because WHICH ReLUs sit on the other side of zero from float64 changes with every
+# change of the forward's 7th digit: in that run conv3's gradients are at 0.4 x .. 0.6 x and everything from conv2 down moved
+# together, the signature of a few flipped sites in conv2.  Every 1 % mutation of a closed-form term still breaks the bound
+# (1.7 x .. 50 x over it) and moves the distance by 4 x .. 266 x of the unmutated run's
 _SMOOTH_2NORM = {
     'head.fusion.fcn1.fc.bias': 2.05e-3, 'head.fusion.conv1.conv.weight': 2.00e-3, 'head.fusion.fcn1.fc.weight': 1.98e-3,
     'head.fusion.fcn2.fc.weight': 1.84e-3, 'head.fusion.conv1.conv.bias': 1.80e-3, 'head.fusion.conv2.conv.bias': 1.71e-3,
@@ -98,7 +105,7 @@ _SMOOTH_2NORM = {
 
 def _smooth_bound2(name):
     """The same in the 2-norm (what the mutation check uses)."""
-    return 2.0 * _SMOOTH_2NORM[name]
+    return 3.5 * _SMOOTH_2NORM[name]
 
 
 def test_bench_path_matches_oracle_at_full_size():
