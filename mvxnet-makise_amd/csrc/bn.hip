@@ -127,6 +127,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const float *__restrict__ d
                     }
                 }
             }
+            if (64 % c4 == 0) {
+                // few channels (c4 divides the wave): the threads of a wave that share a channel quad are folded with shuffles, the
+                // four waves through LDS.  (The serial form below walks rpi = 256 / c4 partials per quad with ONE thread per quad:
+                // 64 dependent f64 LDS reads x 8 values at C = 16, which made the two 16-channel fusion layers' reduce pass take
+                // 94 us for 5 MB.)
+                double v[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
+                for (int off = c4; off < 64; off <<= 1)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] += __shfl_xor(v[i], off, 64);
+                const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                if (lane < c4)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) red[i >> 2][wave * c4 + lane][i & 3] = v[i];
+                __syncthreads();
+                if ((int)threadIdx.x < c4)
+                    for (int k = 0; k < 2; ++k)
+                        for (int j = 0; j < 4; ++j) {
+                            const double t = (red[k][ct][j] + red[k][c4 + ct][j]) + (red[k][2 * c4 + ct][j] + red[k][3 * c4 + ct][j]);
+                            atomicAdd(fsums + ((size_t)(blockIdx.x % REP) * 3 + k) * C + col * 4 + j, t);
+                        }
+                __syncthreads();
+            } else {
             red[0][threadIdx.x][0] = s1.x; red[0][threadIdx.x][1] = s1.y; red[0][threadIdx.x][2] = s1.z; red[0][threadIdx.x][3] = s1.w;
             red[1][threadIdx.x][0] = s2.x; red[1][threadIdx.x][1] = s2.y; red[1][threadIdx.x][2] = s2.z; red[1][threadIdx.x][3] = s2.w;
             __syncthreads();
@@ -139,6 +161,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const float *__restrict__ d
                     }
             }
             __syncthreads();
+            }
         }
     }
     }
@@ -245,7 +268,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dy
                 }
             }
         }
-        if (dbias) {
+        if (dbias && 64 % c4 == 0) {                  // see bn_bwd_reduce: shuffles within the wave, four partials through LDS
+            double v[4] = {sb.x, sb.y, sb.z, sb.w};
+            for (int off = c4; off < 64; off <<= 1)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] += __shfl_xor(v[i], off, 64);
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            if (lane < c4)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) red[wave * c4 + lane][i] = v[i];
+            __syncthreads();
+            if ((int)threadIdx.x < c4)
+                for (int j = 0; j < 4; ++j)
+                    atomicAdd(dbias + (size_t)(blockIdx.x % REP) * 3 * C + col * 4 + j,
+                              (red[ct][j] + red[c4 + ct][j]) + (red[2 * c4 + ct][j] + red[3 * c4 + ct][j]));
+            __syncthreads();
+        } else if (dbias) {
             red[threadIdx.x][0] = sb.x; red[threadIdx.x][1] = sb.y; red[threadIdx.x][2] = sb.z; red[threadIdx.x][3] = sb.w;
             __syncthreads();
             if (rt == 0 && col < c4) {

@@ -106,7 +106,7 @@ _SIDE = {}
 def side_stream(device):
     st = _SIDE.get(device.index)
     if st is None:
-        st = torch.cuda.Stream(device=device)
+        st = torch.cuda.Stream(device=device, priority=int(os.environ.get('MVX_SIDE_PRIORITY', '0')))
         _SIDE[device.index] = st
     return st
 

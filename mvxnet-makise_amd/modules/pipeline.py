@@ -137,7 +137,7 @@ def _prep_stream(device):
     if device.index not in _PREP_STREAMS:
         # high priority: the few small preparation kernels should not queue behind the step's long ones (the host
         # waits for their two results)
-        _PREP_STREAMS[device.index] = torch.cuda.Stream(device=device, priority=-1)
+        _PREP_STREAMS[device.index] = torch.cuda.Stream(device=device, priority=int(_os.environ.get('MVX_PREP_PRIORITY', '-1')))
     return _PREP_STREAMS[device.index]
 
 
