@@ -64,3 +64,32 @@ def test_vector_and_scalar_vfe_kernels_agree_bit_for_bit(C, compact):
         mx = yh.max(1).values
         assert torch.equal(res['vec'][2], mx)
         assert torch.equal(res['vec'][0].view(V, T, 2 * C)[..., C:], mx[:, None, :].expand(V, T, C))
+
+
+@pytest.mark.parametrize('W', [48, 400, 37, 50])
+@pytest.mark.parametrize('sd,pd,din', [(1, 0, 5), (2, 1, 5), (2, 1, 10), (1, 1, 3)])
+def test_activity_dilation_vector_and_scalar_forms_match_max_pooling(W, sd, pd, din):
+    """mvx_activity_dilate (csrc/activity.hip): a site of the output is active iff any site of its 3x3x3 receptive field is (or
+    it touches the image border, with mark_border) -- for W % 4 == 0 the four-sites-per-thread kernel runs, otherwise the scalar
+    one; both against torch max-pooling, from an index grid and from a byte mask."""
+    from modules import _hip
+    import torch.nn.functional as F
+    H = 40
+    g = torch.Generator().manual_seed(W + din)
+    act = (torch.rand((din, H, W), generator=g) < 0.02)
+    act[0, 0, 0] = True
+    act[-1, H - 1, W - 1] = True
+    dout = _hip.conv_out_depth(din, sd, pd)
+    ref = F.max_pool3d(act[None, None].float(), 3, (sd, 1, 1), (pd, 1, 1))[0, 0] > 0
+    assert ref.shape[0] == dout
+    idx = torch.where(act, torch.arange(act.numel()).view(act.shape), torch.full(act.shape, -1)).to(torch.int32).to(DEV)
+    for src, is_index in ((idx, True), (act.to(torch.uint8).to(DEV), False)):
+        for border in (False, True):
+            mask, hflag = _hip.activity_dilate(src, is_index, din, H, W, sd, pd, mark_border=border)
+            want = ref.clone()
+            if border:
+                want[:, 0, :] = True
+                want[:, -1, :] = True
+                want[:, :, 0] = True
+                want[:, :, -1] = True
+            assert torch.equal(mask.cpu().bool(), want), (is_index, border)
