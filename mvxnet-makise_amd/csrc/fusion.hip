@@ -152,7 +152,10 @@ __global__ __launch_bounds__(256) void feature_sample(float *__restrict__ vox, i
 // rows are not visited at all (88 % of the dense rows on a lidar frame); same arithmetic as feature_sample.
 __global__ __launch_bounds__(256) void feature_sample_rows(const float *__restrict__ vox, int vc, const int *__restrict__ rows_sel,
                                                            int n_real, FrameLevels L, int C, float im_h, float im_w, float eps,
-                                                           float *__restrict__ out, int *__restrict__ status, FrameMap fm) {
+                                                           float *__restrict__ out, int *__restrict__ status, FrameMap fm,
+                                                           unsigned *__restrict__ amax_slot) {
+    // amax_slot (may be NULL): raised to max |sampled value| -- the range tag of the rows for the fp16x3 arithmetic, formed while
+    // they are written instead of by a pass of mvx_tensor_amax over them (108 us per 245 MB beside the step's other kernels)
     const long long wave = (blockIdx.x * 256ll + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     const long long j = wave / L.n;
@@ -174,6 +177,7 @@ __global__ __launch_bounds__(256) void feature_sample_rows(const float *__restri
     const bool y0 = iy < H, y1 = iy + 1 < H, x0 = ix < W, x1 = ix + 1 < W;
     const float xi = fy, yi = fx;
     const float xi_ = 1.f - xi, yi_ = 1.f - yi;
+    float mx = 0.f;
     for (int c = lane * 4; c < C; c += 256) {
         const float4 z = make_float4(0, 0, 0, 0);
         const float4 f00 = (y0 && x0) ? *(const float4 *)(F + ((size_t)iy * W + ix) * C + c) : z;
@@ -185,7 +189,9 @@ __global__ __launch_bounds__(256) void feature_sample_rows(const float *__restri
         MVX_TAP(x) MVX_TAP(y) MVX_TAP(z) MVX_TAP(w)
 #undef MVX_TAP
         *(float4 *)(out + j * ldo + lv * C + c) = o;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
+    if (amax_slot) mvx_wave_amax_to(amax_slot, mx);
 }
 
 // ---- compact rows -> dense rows and back ----------------------------------------------------------
@@ -302,7 +308,8 @@ extern "C" int mvx_feature_sample(float *voxels, int32_t vox_channels, int64_t r
 extern "C" int mvx_feature_sample_rows_frames(const float *voxels, int32_t vox_channels, const int32_t *rows_sel,
                                               int32_t n_real, const float *const *feats_host, const int32_t *feat_hw_host,
                                               int32_t n_levels, int32_t channels, float imsize_h, float imsize_w, float eps,
-                                              float *out, int32_t *status, const mvx_frames_t *frames_host, void *stream) {
+                                              float *out, int32_t *status, const mvx_frames_t *frames_host, float *out_amax,
+                                              void *stream) {
     MVX_CHECK_ARG(voxels && rows_sel && feats_host && feat_hw_host && out && status && n_real >= 0);
     MVX_CHECK_ARG(vox_channels >= 5 && vox_channels <= 64 && n_levels >= 1 && n_levels <= MAX_LEVELS);
     MVX_CHECK_ARG(channels > 0 && channels % 4 == 0);
@@ -323,7 +330,7 @@ extern "C" int mvx_feature_sample_rows_frames(const float *voxels, int32_t vox_c
     }
     const long long waves = (long long)n_real * n_levels;
     hipLaunchKernelGGL(feature_sample_rows, dim3(mvx_cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, voxels, vox_channels,
-                       rows_sel, n_real, L, channels, imsize_h, imsize_w, eps, out, status, fm);
+                       rows_sel, n_real, L, channels, imsize_h, imsize_w, eps, out, status, fm, (unsigned *)out_amax);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -333,7 +340,7 @@ extern "C" int mvx_feature_sample_rows(const float *voxels, int32_t vox_channels
                                        int32_t channels, float imsize_h, float imsize_w, float eps, float *out,
                                        int32_t *status, void *stream) {
     return mvx_feature_sample_rows_frames(voxels, vox_channels, rows_sel, n_real, feats_host, feat_hw_host, n_levels, channels,
-                                          imsize_h, imsize_w, eps, out, status, nullptr, stream);
+                                          imsize_h, imsize_w, eps, out, status, nullptr, nullptr, stream);
 }
 
 extern "C" int mvx_expand_rows(const float *compact, const int32_t *row_map, int32_t pad_row, float *out,

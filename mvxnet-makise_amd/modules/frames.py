@@ -241,16 +241,15 @@ def sample_rows(head, fs, fpn_levels, imsize):
     compact = torch.empty((Rt + F, L * C), dtype=torch.float32, device=dev)
     compact[Rt:].zero_()                                   # the shared padded rows (Pipe.py:80)
     status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    # fp16x3: the image features come from outside this library -- their range (max |value|) is formed by the sampler while it
+    # writes them, so that the first fusion layer can scale them (forward: the coarse scale, _hip.foreign_split)
+    amax = torch.zeros((1,), dtype=torch.float32, device=dev) if _hip.split_pieces() == 4 else None
     with _hip._timed_bytes('feature_sample', Rt * L * C * 4 * 5 + Rt * 9 * 4):
       if 'sample' not in KNOCKOUT:
         X.check(X.lib.mvx_feature_sample_rows_frames(X.ptr(fs.vox2d), fs.vox2d.shape[1], X.ptr(fs.rows_sel), Rt, ptrs, hw, L, C,
                                                      float(imsize[0]), float(imsize[1]), float(cfg.eps), X.ptr(compact),
-                                                     X.ptr(status), fs.desc.ref(), X.stream()), 'mvx_feature_sample_rows_frames')
-    if _hip.split_pieces() == 4:
-        # fp16x3: the image features come from outside this library -- measure their range (one pass, on the stream that sampled
-        # them: the preparation stream in the training pipeline) so that the first fusion layer can scale them (forward: the coarse
-        # scale, _hip.foreign_split)
-        _hip.tensor_amax(compact)
+                                                     X.ptr(status), fs.desc.ref(), X.ptr(amax), X.stream()), 'mvx_feature_sample_rows_frames')
+    _hip.tag_amax(compact, amax)
     return compact, status
 
 

@@ -260,3 +260,31 @@ def test_batchnorm_backward_sums_from_the_producing_kernel(golden, small_cfg, ma
         a, b = res[True][0][off:off + p.numel()], res[False][0][off:off + p.numel()]
         off += p.numel()
         assert float((a - b).norm() / b.norm().clamp_min(1e-30)) < 2e-5, k
+
+
+def test_sampler_forms_the_range_tag_of_the_image_features(golden, small_cfg):
+    """fp16x3: frames.sample_rows hands the first fusion layer the sampled FPN features WITH their max |value| -- raised by the
+    sampling kernel while it writes the rows (mvx_feature_sample_rows_frames, out_amax), not by a pass over them: the tag is
+    bit-equal to the tensor's maximum."""
+    from MVXNet import MVXNet
+    from modules import _hip
+    from modules.pipeline import prepare_frame_set
+    torch.manual_seed(3)
+    model = MVXNet().to(DEV)
+    batch, _ = _small_batch(golden, 3)
+    for f in range(3):
+        nlive = int(batch.n_points[f])
+        batch.perms[f, :nlive] = torch.randperm(nlive, generator=torch.Generator().manual_seed(f)).to(DEV)
+    old = small_cfg.config.get('convmath', 'f32')
+    try:
+        for math, tagged in (('fp16x3', True), ('bf16x6', False)):
+            small_cfg.config['convmath'] = math
+            fs, live, counts, status = prepare_frame_set(batch, sample=(model.head, [370.0, 1224.0]))
+            compact, st = fs.sampled
+            torch.cuda.synchronize()
+            am = _hip.amax_of(compact)
+            assert (am is not None) == tagged
+            if tagged:
+                assert float(am) == float(compact.abs().max()) and float(am) > 0
+    finally:
+        small_cfg.config['convmath'] = old
