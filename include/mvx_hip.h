@@ -60,6 +60,11 @@ extern "C" {
                                   (sampled image features): its scale exponent is rounded down to a multiple of 8 binades, so that a frame set and
                                   one of its frames -- whose maxima differ -- scale, and therefore round, alike */
 
+#define MVX_FLAG_NO_BG_FILL 2048  /* mvx_sparse_conv_output_frames: tiles (8 x 16 sites) whose 3 x 3 tile neighbourhood holds no voxel in any source
+                                  plane are NOT written -- every site of them is ReLU(bias), which the tile-restricted consumers
+                                  (mvx_bn_apply_tiles_frames, mvx_bn_relu_backward_tiles_frames) never read; the BatchNorm sums count them
+                                  in closed form either way */
+
 #define MVX_FLAG_SUMS_READY 256 /* mvx_bn_relu_backward_frames: `scratch` already holds (sum dyhat, sum dyhat * yhat) of every frame, accumulated by
                                   the kernel that PRODUCED dyhat (mvx_linear_dgrad_bnsums_frames, mvx_conv2d_dgrad_split_bnsums_frames): the
                                   reduction pass is not run */

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void sparse_conv_output(const float *__restric
                                                           const int *__restrict__ occ,
                                                           const float *__restrict__ bias, float *__restrict__ out,
                                                           double *__restrict__ stats, SGeom g, int relu,
-                                                          int *__restrict__ active_sites) {
+                                                          int *__restrict__ active_sites, int skip_fill) {
     __shared__ float red[2][256][4];
     __shared__ int s_idx[3][OTH + 2][OTW + 2];         // voxel ids of the tile's halo, per depth tap
     const int c4n = g.Cout >> 2;                       // threads per site (16 at Cout = 64)
@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void sparse_conv_output(const float *__restric
         for (int ty = max(tcy - 1, 0); ty <= min(tcy + 1, tyn - 1); ++ty)
             for (int tx = max(tcx - 1, 0); tx <= min(tcx + 1, txn - 1); ++tx) any |= occ[((size_t)ds * tyn + ty) * txn + tx];
     }
+    if (!any && skip_fill) return;                     // MVX_FLAG_NO_BG_FILL: the ReLU(bias) fill of a voxel-free tile is implied
     if (any) {                                         // block-uniform: stage the index halo once
         for (int e = threadIdx.x; e < 3 * (OTH + 2) * (OTW + 2); e += 256) {
             const int kd = e / ((OTH + 2) * (OTW + 2)), rem = e % ((OTH + 2) * (OTW + 2));
@@ -227,7 +228,7 @@ extern "C" int mvx_sparse_conv_output_frames(const float *p, const int32_t *inde
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(sparse_conv_output, dim3(mvx_cdiv(w, OTW) * mvx_cdiv(h, OTH), dout * n_frames), dim3(256), 0, st, p,
-                       index_grid, (const int *)occ, bias, out, stats, g, relu, active);
+                       index_grid, (const int *)occ, bias, out, stats, g, relu, active, (flags & MVX_FLAG_NO_BG_FILL) ? 1 : 0);
     MVX_LAUNCH_CHECK();
     if (stats) {
         hipLaunchKernelGGL(sparse_stats_fix, dim3(mvx_cdiv(cout, 64), n_frames), dim3(64), 0, st, stats, bias,

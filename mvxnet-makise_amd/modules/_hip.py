@@ -16,6 +16,7 @@ FLAG_SPLIT = 64                                                          # MVX_F
 FLAG_SUMS_READY = 256                                                    # MVX_FLAG_SUMS_READY: the BatchNorm-backward sums were accumulated by the producer of dyhat
 FLAG_SPLIT3 = 128                                                        # MVX_FLAG_SPLIT3: three bf16 pieces per operand (bf16x6, fp32-grade)
 FLAG_AMAX_COARSE = 1024                                                  # MVX_FLAG_AMAX_COARSE: the bound x is a foreign forward input (8-binade scale steps)
+FLAG_NO_BG_FILL = 2048                                                   # MVX_FLAG_NO_BG_FILL: voxel-free tiles of the sparse conv1 output are not written
 FLAG_SPLIT_F16 = 512                                                     # MVX_FLAG_SPLIT_F16: two fp16 pieces per operand (fp16x3)
 
 
