@@ -1,32 +1,28 @@
-"""Batched voxelizer throughput vs batch size and workload (algorithmic HBM bytes / time) -- developer tool.
-Writes gpurun_out/voxelize_timing.json."""
-import json, os, sys
-import numpy as np, torch
+"""Voxelizer alone (developer tool): the voxelize_concat call of a 4- or 16-frame batch, repeated; run under
+`rocprofv3 --kernel-trace --stats` for the per-kernel times.    python tools/time_voxelize.py [frames]"""
+import os
+import sys
+import time
+
+import torch
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'mvxnet-makise_amd'))
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 sys.argv = sys.argv[:1]
-sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, 'mvxnet-makise_amd'))
-import bench
-import modules.config as cfg
-from modules import _hip
+import bench  # noqa: E402
+import modules.config as cfg  # noqa: E402
+from modules import _hip  # noqa: E402
+
 dev = torch.device('cuda')
-out = []
-for wl in ('S2', 'S1'):
-    for B in (1, 4, 16, 64):
-        batch = bench.make_batch(list(range(B)), dev, 20000, wl, raw_points=20000)
-        points6, n_points = batch.prepared()
-        def run():
-            return _hip.voxelize_concat(points6, batch.perms, n_points, cfg.velorange[0:3], cfg.voxelsize, cfg.samplenum, 9)
-        res = run(); torch.cuda.synchronize()
-        V = int(res[4][-1])
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(10):
-            run()
-        e.record(); torch.cuda.synchronize()
-        ms = s.elapsed_time(e) / 10
-        nbytes = B * 20000 * 28 + V * (35 * 9 * 4 + 36)
-        out.append({'workload': wl, 'frames': B, 'voxels': V, 'ms': ms, 'us_per_frame': ms * 1e3 / B, 'algorithmic_GBps': nbytes / ms / 1e6})
-        print('%s frames %3d  voxels %7d  %.3f ms  %.1f us/frame  %.0f GB/s algorithmic' % (wl, B, V, ms, ms * 1e3 / B, nbytes / ms / 1e6), flush=True)
-        del batch, points6, res
-os.makedirs(os.path.join(REPO, 'gpurun_out'), exist_ok=True)
-json.dump(out, open(os.path.join(REPO, 'gpurun_out', 'voxelize_timing.json'), 'w'), indent=1)
+batch = bench.make_batch(list(range(frames)), dev, 20000, 'S2')
+points6, n_points = batch.prepared()
+torch.cuda.synchronize()
+for it in range(12):
+    if it == 2:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+    out = _hip.voxelize_concat(points6, batch.perms, n_points, cfg.velorange[0:3], cfg.voxelsize, cfg.samplenum, 9)
+torch.cuda.synchronize()
+print('%d frames: %.3f ms per call, %d voxels' % (frames, (time.perf_counter() - t0) / 10 * 1e3, int(out[4][-1])))
