@@ -226,11 +226,13 @@ __global__ __launch_bounds__(256) void vox_gather(const float *__restrict__ pcd,
         }
         if (f == F && concat && w.frame_base[F] > cap_voxels) atomicOr(status, 2);
     }
-    const int Vtot = w.frame_base[F];
+    // frame of voxel v: the F + 1 bases in ONE load (lane k holds base k; F <= 16), then a ballot -- the first form walked them
+    // with F dependent loads per wave
+    const int fb = lane <= F ? w.frame_base[lane] : 0x7fffffff;
+    const int Vtot = __shfl(fb, F, 64);
     if (v >= Vtot) return;   // whole wave leaves together: no block-wide barrier below
-    int f = 0;
-    while (f + 1 < F && v >= w.frame_base[f + 1]) ++f;
-    const int vl = v - w.frame_base[f];
+    const int f = __popcll(__ballot(lane >= 1 && lane < F && v >= fb));
+    const int vl = v - __shfl(fb, f, 64);
     const long long dst = concat ? (long long)v : (long long)f * cap_voxels + vl;
     if (concat ? v >= cap_voxels : vl >= cap_voxels) return;
     const int h = w.vox_slot[v];
