@@ -339,6 +339,8 @@ def rpn_backward(rpn, S, d_heads):
     dev = up.device
     rows = up.shape[0]
     d_heads = d_heads.contiguous()
+    if _split() == 4 and _hip.amax_of(d_heads) is None:
+        _hip.tensor_amax(d_heads)        # fp16x3: the loss gradient's range (9 MB: 5 us), else its weight gradient runs in bf16x6
     # heads
     dwh = _hip.linear_wgrad(up, d_heads)                                   # (16, 768)
     with _hip._SideStream(dwh, d_heads):

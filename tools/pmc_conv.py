@@ -12,7 +12,7 @@ x = torch.randn((din, H, W, cin), device=dev)
 w = torch.randn((cout, cin, 3, 3, 3), device=dev) * 0.02
 b = torch.zeros(cout, device=dev)
 dz = torch.randn((dout, H, W, cout), device=dev)
-split = {'bf16x3': 2, 'bf16x6': 3}.get(sys.argv[1] if len(sys.argv) > 1 else 'f32', 0)
+split = {'bf16x3': 2, 'bf16x6': 3, 'fp16x3': 4}.get(sys.argv[1] if len(sys.argv) > 1 else 'f32', 0)
 wpk, wpd = _hip.conv3d_pack(w, False, split=split), _hip.conv3d_pack(w, True, split=split)
 for _ in range(3):
     _hip.conv3d_forward(x, wpk, b, cout, sd, pd, split=split)
