@@ -708,7 +708,8 @@ def _run(args, rank, world, dev):
                 (3, 'full', m) for m in ('f32', 'fp16x3', 'bf16x6', 'bf16x3') if m != main_math):
             a2 = copy.copy(args)
             a2.mode, a2.convmath, a2.frames = mode, math, None
-            a2.steps, a2.warmup = 5, 2
+            # short steps: enough of them to be out of the warm-up's shadow (allocator, clocks) at a few tenths of a second each
+            a2.steps, a2.warmup = (30, 8) if mode in ('vfe', 'fusion') else (8, 3)
             a2.no_alt = a2.no_cpu_baseline = True
             a2.timed_only = False
             state['ready'] = None

@@ -692,7 +692,7 @@ def train_step_full(model, batch, targets, criterion, anchors, imsize, ready=Non
     try:
         if fs is not None:
             model.prepack()
-            _hip.arena_begin(dev, doubles=1 << 21)
+            _hip.arena_begin(dev, doubles=1 << 22)
             F = len(live)
             tl = [targets[f] for f in live]
             with torch.no_grad():
