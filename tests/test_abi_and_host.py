@@ -77,6 +77,45 @@ def test_config_surface():
         cfg.no_such_key
 
 
+def test_arithmetic_selection_logic():
+    """Host side of `convmath` (modules/_hip.py): config value -> split code -> flag bits of a call; which row GEMMs take the
+    split arithmetic; the fall-backs of fp16x3 for operands without a range tag.  No GPU involved."""
+    import re as _re
+    import modules.config as cfg
+    from modules import _hip
+    header = open(HEADER).read()
+    for name, val in (('MVX_FLAG_SPLIT', _hip.FLAG_SPLIT), ('MVX_FLAG_SPLIT3', _hip.FLAG_SPLIT3), ('MVX_FLAG_SPLIT_F16', _hip.FLAG_SPLIT_F16),
+                      ('MVX_FLAG_AMAX_COARSE', _hip.FLAG_AMAX_COARSE), ('MVX_FLAG_NO_BG_FILL', _hip.FLAG_NO_BG_FILL),
+                      ('MVX_FLAG_SUMS_READY', _hip.FLAG_SUMS_READY)):
+        assert int(_re.search(r'#define %s (\d+)' % name, header).group(1)) == val, name
+    assert cfg.config['convmath'] == 'fp16x3'                  # the shipped default
+    old = cfg.config['convmath']
+    try:
+        codes = {}
+        for math, code in (('f32', 0), ('bf16x3', 2), ('bf16x6', 3), ('fp16x3', 4)):
+            cfg.config['convmath'] = math
+            assert _hip.split_pieces() == code
+            codes[math] = {t: _hip.row_split(t) for t in ('fusion_768x768', 'vfe', 'conv1', 'rpn', 'dgrad', 'wgrad')}
+        assert set(codes['f32'].values()) == {0}
+        assert codes['bf16x3'] == {'fusion_768x768': 0, 'vfe': 0, 'conv1': 0, 'rpn': 2, 'dgrad': 2, 'wgrad': 2}    # forward rows stay exact f32
+        assert set(codes['bf16x6'].values()) == {3} and set(codes['fp16x3'].values()) == {4}
+        cfg.config['convmath'] = 'fp8'
+        with pytest.raises(Exception):
+            _hip.split_pieces()
+    finally:
+        cfg.config['convmath'] = old
+    assert _hip.split_flags(0) == 0 and _hip.split_flags(2) == 0 and _hip.split_flags(2, True) == _hip.FLAG_SPLIT
+    assert _hip.split_flags(3) == _hip.FLAG_SPLIT3 and _hip.split_flags(3, True) == _hip.FLAG_SPLIT | _hip.FLAG_SPLIT3
+    assert _hip.split_flags(4) == _hip.FLAG_SPLIT_F16 and _hip.split_flags(4, True) == _hip.FLAG_SPLIT | _hip.FLAG_SPLIT_F16
+    t = torch.zeros(4)
+    assert _hip.amax_of(t) is None
+    assert _hip.grad_split(4, t) == 3 and _hip.grad_split(3, t) == 3 and _hip.grad_split(0, t) == 0      # untagged gradient: bf16x6
+    assert _hip.foreign_split(4, t) == (3, 0) and _hip.foreign_split(2, t) == (2, 0)                       # untagged foreign input: bf16x6
+    _hip.tag_amax(t, torch.ones(1))
+    assert _hip.grad_split(4, t) == 4 and _hip.foreign_split(4, t) == (4, _hip.FLAG_AMAX_COARSE)
+    assert _hip.amax_of(t.view(2, 2)) is None                  # a view does not carry the tag (callers re-tag)
+
+
 def test_state_dict_keys_and_param_counts():
     from MVXNet import MVXNet
     m = MVXNet()
