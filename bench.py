@@ -277,6 +277,7 @@ def cpu_baseline_vfe(P, workload, budget_s=20.0):
                       '(V,35,23) rows, median %.3f s/frame' % (workload, P, len(times) - 1, med)}
 
 
+ALT_STEPS = 20            # timed steps of every alternative mode of the default run
 MATH_PIECES = {'f32': 0, 'bf16x3': 2, 'bf16x6': 3, 'fp16x3': 4}   # split code of modules/_hip.py (4 = two fp16 pieces)
 MATH_MFMAS = {'f32': 1.0, 'bf16x3': 3.0, 'bf16x6': 6.0, 'fp16x3': 3.0}   # 16-bit MFMAs per product (executed matrix FLOPs = this x the algorithmic ones)
 
@@ -313,6 +314,71 @@ def isolated_conv_roofline(dev, math):
             'note': 'the same kernel, one frame, dense (no tile skipping), alone on the GPU'}
 
 
+LINE_LIMIT = 12288        # the ONE line rank 0 prints stays below this (the driver keeps a bounded tail of stdout and parses it)
+
+
+def write_detail(out):
+    """Everything the run measured (per-stage GB/s, every kernel class of every alternative mode, the CPU baseline's per-run
+    medians, the notes) goes to gpurun_out/bench_detail.json (MVX_BENCH_DETAIL overrides the path); the printed line names it."""
+    path = os.environ.get('MVX_BENCH_DETAIL', os.path.join(REPO, 'gpurun_out', 'bench_detail.json'))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, 'w') as fh:
+            json.dump(out, fh, indent=1)
+        return os.path.relpath(path, REPO)
+    except OSError as e:                                   # a read-only checkout: the line still prints
+        return 'not written (%s)' % e.__class__.__name__
+
+
+def _r(x, n=4):
+    return None if x is None else (float('%.*g' % (n, x)) if isinstance(x, float) else x)
+
+
+def _roof(r):
+    """The roofline object of the line: the contract's keys + the kernel it is about, without the prose."""
+    keep = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'launches', 'avg_launch_ms', 'flop_per_launch',
+            'algorithmic_tflops', 'dense_equivalent_tflops')
+    o = {k: _r(r[k], 5) for k in keep if k in r}
+    o['kernel'] = str(o.get('kernel', '')).split(' (')[0]
+    if isinstance(r.get('isolated'), dict):
+        o['isolated_frac'] = _r(r['isolated']['frac'])
+    return o
+
+
+def compact_line(out, detail_path):
+    """The printed line: the bench contract's keys, `roofline` and `cpu_baseline` in full, and for every other mode measured in the
+    same run only what identifies it and its result.  Everything else is in the detail file."""
+    line = {k: out[k] for k in ('metric', 'value', 'unit', 'summary', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+                                'scaling', 'vs_baseline', 'dtype', 'data') if k in out}
+    c = out['config']
+    line['config'] = {k: c[k] for k in ('workload', 'mode', 'frames_per_gpu', 'voxels_per_frame', 'parallelism', 'voxel_indices_vs_oracle') if k in c}
+    line['roofline'] = _roof(out['roofline'])
+    if 'traffic_note' in out['roofline']:
+        line['roofline']['traffic_note'] = out['roofline']['traffic_note'][:160]
+    if 'cpu_baseline' in out:
+        line['cpu_baseline'] = {k: out['cpu_baseline'][k] for k in ('value', 'unit', 'cores', 'kind', 'sample', 'voxel_indices_vs_oracle')
+                                if k in out['cpu_baseline']}
+    for k in ('host_enqueue_ms_per_step', 'library_launches_per_step', 'allreduce_ms_per_call', 'last_losses', 'INVALID_diagnostic_knockout'):
+        if k in out:
+            line[k] = out[k]
+    line['other_kernels'] = {n: {'frac': _r(v.get('frac')), 'avg_launch_ms': _r(v['avg_launch_ms']), 'launches': v['launches'],
+                                 'arithmetic': v.get('arithmetic')} for n, v in out.get('other_kernels', {}).items()}
+    line['hbm_stages_frac_of_8TBps'] = {n: _r(v['frac_of_8TBps'], 3) for n, v in out.get('hbm_stages', {}).items()
+                                        if v.get('frac_of_8TBps') is not None}
+    alts = []
+    for a in out.get('alt_modes', []):
+        alts.append({'config': a.get('baseline_config', 'headline path'), 'mode': a.get('mode', out['config']['mode']),
+                     'convmath': a['convmath'], 'workload': a['workload'], 'value': _r(a['value'], 5), 'unit': a['unit'],
+                     'ms_per_step': _r(a['ms_per_step'], 5), 'steps': a.get('steps'), 'roofline_frac': _r(a['roofline']['frac']),
+                     'roofline_kernel': str(a['roofline'].get('kernel', '')).split(' (')[0]})
+    if alts:
+        line['alt_modes'] = alts
+    line['detail'] = detail_path
+    if 'summary_tail' in out:
+        line['summary_tail'] = out['summary_tail']
+    return line
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -342,7 +408,10 @@ def main():
     torch.cuda.set_device(dev)
     out = run(args, rank, world, dev)
     if rank == 0:
-        print(json.dumps(out))
+        line = compact_line(out, write_detail(out))
+        text = json.dumps(line)
+        assert len(text) < LINE_LIMIT, 'bench line grew to %d bytes' % len(text)
+        print(text)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -670,28 +739,29 @@ def _run(args, rank, world, dev):
         other = 'S1' if args.workload == 'S2' else 'S2'
         b2 = make_batch(frame_ids, dev, args.points, other)
         state['ready'] = None
-        nv2, dt2, tm2 = timed_run(2, max(3, args.steps // 2), lambda: step_hot(b2))
+        n_alt = max(ALT_STEPS, args.steps) if args.steps >= 5 else args.steps      # alternative modes are timed over >= 20 steps
+        nv2, dt2, tm2 = timed_run(3, n_alt, lambda: step_hot(b2))
         check_status()
-        alt.append({'workload': other, 'convmath': main_math, 'value': frames_total * max(3, args.steps // 2) / dt2, 'unit': 'frames/s',
-                    'ms_per_step': dt2 / max(3, args.steps // 2) * 1e3, 'voxels_per_frame': nv2,
+        alt.append({'workload': other, 'convmath': main_math, 'value': frames_total * n_alt / dt2, 'unit': 'frames/s', 'steps': n_alt,
+                    'ms_per_step': dt2 / n_alt * 1e3, 'voxels_per_frame': nv2,
                     'roofline': conv_roofline(tm2, len(exec_stages) - 1), 'hbm_stages': hbm_stages(tm2)})
         del b2
         state['ready'] = None
         # (2) the same step in the other arithmetics (config.yml convmath: exact-f32 MFMA, bf16x6 = three bf16 pieces / six MFMAs per
         # product = fp32-grade, bf16x3 = two pieces / three MFMAs, ~2e-5 per product)
-        for math in ('f32', 'fp16x3', 'bf16x6', 'bf16x3'):
+        for math in ('fp16x3', 'f32', 'bf16x6', 'bf16x3'):
             if math == main_math:
                 continue
             cfg.config['convmath'] = math
             try:
-                _, dt3, tm3 = timed_run(2, max(3, args.steps // 2))
+                _, dt3, tm3 = timed_run(3, n_alt)
             finally:
                 cfg.config['convmath'] = main_math
                 state['ready'] = None
             check_status()
             r3 = conv_roofline(tm3, len(exec_stages) - 1, math)
-            alt.append({'workload': args.workload, 'convmath': math, 'value': frames_total * max(3, args.steps // 2) / dt3,
-                        'unit': 'frames/s', 'ms_per_step': dt3 / max(3, args.steps // 2) * 1e3, 'roofline': r3,
+            alt.append({'workload': args.workload, 'convmath': math, 'value': frames_total * n_alt / dt3, 'steps': n_alt,
+                        'unit': 'frames/s', 'ms_per_step': dt3 / n_alt * 1e3, 'roofline': r3,
                         'note': {'f32': 'every MFMA kernel on the exact-f32 matrix instruction (v_mfma_f32_32x32x2_f32)',
                                  'fp16x3': 'convolutions and wide row GEMMs, forward and both gradients, in two fp16 pieces per operand / three '
                                            'MFMAs per product (22 mantissa bits, fp32-grade), gradients scaled by their device-side amax',
@@ -705,11 +775,11 @@ def _run(args, rank, world, dev):
         # 2 frames), config 3 (--mode full, 4 frames: exact f32 and "bf16 MFMA conv" = convmath bf16x3)
         import copy
         for cfg_no, mode, math in ((2, 'vfe', main_math), (4, 'fusion', main_math), (3, 'full', main_math)) + tuple(
-                (3, 'full', m) for m in ('f32', 'fp16x3', 'bf16x6', 'bf16x3') if m != main_math):
+                (3, 'full', m) for m in ('fp16x3', 'f32', 'bf16x6', 'bf16x3') if m != main_math):
             a2 = copy.copy(args)
             a2.mode, a2.convmath, a2.frames = mode, math, None
             # short steps: enough of them to be out of the warm-up's shadow (allocator, clocks) at a few tenths of a second each
-            a2.steps, a2.warmup = (30, 8) if mode in ('vfe', 'fusion') else (8, 3)
+            a2.steps, a2.warmup = ((30, 8) if mode in ('vfe', 'fusion') else (ALT_STEPS, 4)) if args.steps >= 5 else (args.steps, 1)
             a2.no_alt = a2.no_cpu_baseline = True
             a2.timed_only = False
             state['ready'] = None
@@ -724,7 +794,9 @@ def _run(args, rank, world, dev):
         state['ready'] = None
 
     if rank == 0:
-        dtype = 'f32' if main_math == 'f32' else 'f32 (%s split MFMA, f32 accumulate)' % main_math
+        dtype = {'f32': 'f32', 'bf16x6': 'f32 (bf16x6: three bf16 pieces = the f32 operand exactly, six MFMAs per product, f32 accumulate)',
+                 'fp16x3': 'f32 storage / accumulate, 22-bit operands (fp16x3: two fp16 pieces, three MFMAs per product)',
+                 'bf16x3': 'f32 storage / accumulate, 16-bit operands (bf16x3: two bf16 pieces, three MFMAs per product)'}[main_math]
         wl = {'S2': 'S2 ring frames (64-beam model, KITTI-like occupancy)', 'S1': 'S1 uniform frames (worst-case voxel count)'}[args.workload]
         if args.mode == 'hot':
             workload = ('%s, %d raw pts -> %d pts after crop, grid 10x352x400, T=35, %d frames/GPU/step: crop+cropToSight+lidar2Img, '

@@ -7,9 +7,16 @@
 #define MVX_WAVE 64
 #define MVX_REP MVX_STATS_REPLICAS
 
-#define MVX_CHECK_ARG(cond)            \
-    do {                               \
-        if (!(cond)) return MVX_EINVAL; \
+// A call rejected by its argument checks launches nothing -- and must not leave the operand ranges that
+// mvx_split_operand_amax bound for it pending for the NEXT split launch of this thread (a forward convolution would then
+// scale its activations by a gradient's 2^27: ADVICE r04).  Every failed check drops the binding.
+void mvxi_drop_split_amax();
+#define MVX_CHECK_ARG(cond)             \
+    do {                                \
+        if (!(cond)) {                  \
+            mvxi_drop_split_amax();     \
+            return MVX_EINVAL;          \
+        }                               \
     } while (0)
 
 void mvxi_gather_narrow_max_units(long long v);      // csrc/conv3d.hip: tuning value MVX_TUNE_GATHER_NARROW_MAX_UNITS

@@ -697,9 +697,13 @@ __global__ void wgrad_reduce_split(const float *__restrict__ slabs, float *__res
 }
 
 int check_geom(int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t sd, int32_t pd) {
-    if (din <= 0 || dout <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return MVX_EINVAL;
-    if (sd < 1 || sd > 2 || pd < 0 || pd > 1) return MVX_EINVAL;
-    if (cin % BK || cout % BN) return MVX_ESIZE;
+    // a rejected call drops the operand ranges bound for it (common.h MVX_CHECK_ARG)
+    MVX_CHECK_ARG(!(din <= 0 || dout <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0));
+    MVX_CHECK_ARG(!(sd < 1 || sd > 2 || pd < 0 || pd > 1));
+    if (cin % BK || cout % BN) {
+        mvxi_drop_split_amax();
+        return MVX_ESIZE;
+    }
     return MVX_OK;
 }
 

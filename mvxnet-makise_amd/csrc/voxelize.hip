@@ -348,6 +348,7 @@ extern "C" int mvx_split_operand_amax(const float *amax_a, const float *amax_b) 
     t_split_amax = SplitAmax{amax_a, amax_b, 0};
     return MVX_OK;
 }
+void mvxi_drop_split_amax() { t_split_amax = SplitAmax{nullptr, nullptr, 0}; }
 SplitAmax mvxi_take_split_amax() {
     const SplitAmax r = t_split_amax;
     t_split_amax = SplitAmax{nullptr, nullptr, 0};

@@ -74,6 +74,60 @@ def foreign_split(split, x=None):
     return split, 0
 
 
+class foreign_input_math:
+    """Scope of ONE stand-alone block call (CRB3d / CRB2d / DeCRB2d through the nn.Module interface) on a tensor this library
+    did not produce: under ``convmath: fp16x3`` the block runs in bf16x6 -- an input of unknown range has no place in fp16's
+    five exponent bits (1e-3-sized inputs would keep ~15 bits, 1e5-sized ones overflow, and the BatchNorm behind the
+    convolution would hide both), bf16 pieces have the range of f32.  Tensors produced by this library's blocks
+    (outputs of a BatchNorm: bounded by sqrt(N)) carry ``_mvx_lib`` and keep fp16x3.  ``math``: re-enter the arithmetic a
+    forward call chose (its backward)."""
+
+    def __init__(self, x=None, math=None):
+        self.x, self.math, self.old = x, math, None
+
+    def __enter__(self):
+        import modules.config as cfg
+        cur = cfg.config.get('convmath', 'f32')
+        want = self.math
+        if want is None:
+            want = 'bf16x6' if (cur == 'fp16x3' and not getattr(self.x, '_mvx_lib', False)) else cur
+        if want != cur:
+            self.old, cfg.config['convmath'] = cur, want
+        return want
+
+    def __exit__(self, *exc):
+        if self.old is not None:
+            import modules.config as cfg
+            cfg.config['convmath'] = self.old
+        return False
+
+
+def mark_lib(t):
+    """``t`` is the output of one of this library's BatchNorms (see foreign_input_math)."""
+    t._mvx_lib = True
+    return t
+
+
+# The 1 % mutation hooks of the gradient tests (frames._MUTATE, rpn_frames._MUTATE) only act in a process started with
+# MVX_ALLOW_MUTATION=1 (tests/conftest.py sets it): a product run cannot switch them on by accident.
+MUTATION_ALLOWED = os.environ.get('MVX_ALLOW_MUTATION') == '1'
+
+
+def mutate(table, name, t):
+    """``t * table[name]`` when the test hook names this term (and keeps t's range tag, scaled: the mutated tensor then takes
+    the same arithmetic path -- fp16x3 with its amax -- as the unmutated one); ``t`` otherwise."""
+    f = table.get(name)
+    if f is None or t is None:
+        return t
+    if not MUTATION_ALLOWED:
+        raise X.MvxHipError('gradient mutation hooks are test-only: start the process with MVX_ALLOW_MUTATION=1')
+    t2 = t * f
+    am = amax_of(t)
+    if am is not None:
+        tag_amax(t2, am * abs(float(f)))
+    return t2
+
+
 def grad_split(split, dz):
     """Arithmetic of a row GEMM whose operand ``dz`` is a gradient: fp16x3 needs its range (a tag), else bf16x6 stands in (the
     row kernels split both operands in the kernel, so any arithmetic can run any call)."""
@@ -142,6 +196,16 @@ def tail_events(device):
     """The pair of the step that has just been enqueued, consumed by the caller (None: no tail was marked)."""
     t = _TAIL.pop(device.index, None)
     return tuple(t) if t is not None and t[1] is not None else None
+
+
+def drop_tail(device=None):
+    """Forget the tail pair: a gradient has been (or will be) written on the main stream AFTER join_side_stream recorded the end
+    of the backward -- lane gradients added into the bucket, autograd's AccumulateGrad of returned views -- so the early part
+    of the exchange must wait for the whole main stream (parallel.py falls back to ``comm.wait_stream(main)``)."""
+    if device is None:
+        _TAIL.clear()
+    else:
+        _TAIL.pop(device.index, None)
 
 
 def join_side_stream(device=None):

@@ -561,8 +561,7 @@ _MUTATE = {}        # TESTS ONLY (tests/test_fullsize_gpu.py): name -> factor ap
 
 
 def _mut(name, t):
-    f = _MUTATE.get(name)
-    return t if f is None or t is None else t * f
+    return _hip.mutate(_MUTATE, name, t) if _MUTATE else t
 
 
 def cml_backward(model, S, grad_mid, g_cl=None):

@@ -52,6 +52,18 @@ class Block2dFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, kind, stride, pack):
+        # a stand-alone block reads a tensor of unknown range: under convmath fp16x3 it runs in bf16x6 (_hip.foreign_input_math)
+        with _hip.foreign_input_math(x) as math:
+            ctx.math = math
+            return Block2dFunction._forward(ctx, x, w, b, kind, stride, pack)
+
+    @staticmethod
+    def backward(ctx, g):
+        with _hip.foreign_input_math(math=ctx.math):
+            return Block2dFunction._backward(ctx, g)
+
+    @staticmethod
+    def _forward(ctx, x, w, b, kind, stride, pack):
         _hip.require_plain_batchnorm()
         eps = cfg.eps
         xc = x[0].permute(1, 2, 0).contiguous()[None]            # (1,H,W,C): no copy for channels_last input
@@ -79,7 +91,8 @@ class Block2dFunction(torch.autograd.Function):
             cout = w.shape[1]
             w_all = w.permute(2, 3, 1, 0).reshape(s * s * cout, cin).contiguous()      # row (i*s+j)*Cout + co
             xr = xc.view(h * wd, cin)
-            t, _ = _hip.linear_forward(xr, w_all, b.repeat(s * s), relu=True, want_stats=False, split=_hip.row_split('rpn'))
+            t, _ = _hip.linear_forward(xr, w_all, b.repeat(s * s), relu=True, want_stats=False, split=_hip.row_split('rpn'),
+                                       foreign=not getattr(x, '_mvx_lib', False))
             stats = torch.empty((1, R, 2, cout), dtype=torch.float64, device=x.device)
             X.check(X.lib.mvx_row_stats_frames(X.ptr(t), X.ptr(stats), t.numel() // cout, cout, 1, X.stream()), 'mvx_row_stats_frames')
             mi = torch.empty((1, 2, cout), dtype=torch.float32, device=x.device)
@@ -93,10 +106,10 @@ class Block2dFunction(torch.autograd.Function):
         S.update(y=y, mi=mi, h=h, w=wd, cin=cin, cout=cout)
         ctx.S, ctx.pack = S, pack
         ctx.params = (w, b)
-        return out[0].permute(2, 0, 1).unsqueeze(0)              # logical NCHW, channels_last storage
+        return _hip.mark_lib(out[0].permute(2, 0, 1).unsqueeze(0))   # logical NCHW, channels_last storage
 
     @staticmethod
-    def backward(ctx, g):
+    def _backward(ctx, g):
         S, pack = ctx.S, ctx.pack
         w, b = ctx.params
         kind, h, wd, cin, cout = S['kind'], S['h'], S['w'], S['cin'], S['cout']

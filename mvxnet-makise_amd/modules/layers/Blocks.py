@@ -267,7 +267,7 @@ class CRB3d(nn.Module):
         aux = {} if conv_background_on() else None
         out = VoxelGemmCRB3dFunction.apply(feat, coords, self.conv.weight, self.conv.bias, tuple(dhw), self._sd,
                                            self._pd, cfg.eps, aux)
-        res = out.permute(3, 0, 1, 2).unsqueeze(0)
+        res = _hip.mark_lib(out.permute(3, 0, 1, 2).unsqueeze(0))
         if aux:
             res._mvx_background = aux['bg']      # read by the next CRB3d (plain attribute: the module API is unchanged)
         return res
@@ -279,8 +279,9 @@ class CRB3d(nn.Module):
         xc = x.squeeze(0).permute(1, 2, 3, 0).contiguous()  # no-op when already channels-last
         bg_in = getattr(x, '_mvx_background', None) if conv_background_on() else None
         aux = {} if bg_in is not None else None
-        out = CRB3dFunction.apply(xc, self.conv.weight, self.conv.bias, self._sd, self._pd, cfg.eps, self._packer, bg_in, aux)
-        res = out.permute(3, 0, 1, 2).unsqueeze(0)
+        with _hip.foreign_input_math(x):         # fp16x3 on a tensor of unknown range: this call runs in bf16x6
+            out = CRB3dFunction.apply(xc, self.conv.weight, self.conv.bias, self._sd, self._pd, cfg.eps, self._packer, bg_in, aux)
+        res = _hip.mark_lib(out.permute(3, 0, 1, 2).unsqueeze(0))
         if aux and 'bg' in aux:
             res._mvx_background = aux['bg']
         return res
@@ -307,6 +308,28 @@ def _nchw(x):
     return x.contiguous(memory_format=torch.contiguous_format)
 
 
+_WARNED = set()
+
+
+def _torch_dispatch(x, name, kind):
+    """A CRB2d / DeCRB2d call is about to run on the torch modules (MIOpen).  That is never silent: inside RPN.forward_torch (the
+    comparison path of the tests, chosen by the caller) and with `crb2d_hip: false` (chosen in config.yml) it is what was asked
+    for; a CPU tensor raises like every other module of this package (there is no CPU path); any other reason -- a batch, a
+    dtype, a kernel / channel count the MFMA tiles do not cover, an odd map under a stride-2 layer -- is named ONCE in a
+    RuntimeWarning."""
+    if _IN_FORWARD_TORCH[0] or not cfg.config.get('crb2d_hip', True):
+        return
+    if not x.is_cuda:
+        raise _hip.X.MvxHipError('%s: CPU tensor -- this package has no CPU path (the HIP library runs on the GPU only)' % name)
+    why = ('hyper-parameters outside the HIP kernels (3x3 / stride 1 or 2, kernel = stride deconvolutions, channels in multiples of 32)'
+           if kind is None else 'batch size %d' % x.shape[0] if x.dim() == 4 and x.shape[0] != 1 else
+           'dtype %s' % x.dtype if x.dtype != torch.float32 else 'map size %s under a stride-2 layer' % (tuple(x.shape[-2:]),))
+    if (name, why) not in _WARNED:
+        _WARNED.add((name, why))
+        import warnings
+        warnings.warn('%s runs on torch / MIOpen, not on the HIP kernels: %s' % (name, why), RuntimeWarning, stacklevel=3)
+
+
 class _TorchBN2d(nn.Module):
     def __init__(self, c):
         super().__init__()
@@ -320,8 +343,9 @@ class CRB2d(nn.Module):
     """Conv2d -> ReLU -> BN2d (reference Blocks.py:31-40).  1x1 kernels (the fusion MLP,
     imhead/Pipe.py:89,91) run on the HIP row-GEMM.  3x3 kernels belong to the RPN, whose forward runs as one node on the HIP
     kernels (voxelnet/Pipe.py RPNFunction); called on its own, a 3x3 block (stride 1 or 2) is ONE autograd node on the same
-    kernels (modules/layers/Block2d.py; config ``crb2d_hip``, default true).  The torch / MIOpen form remains for CPU tensors,
-    batches, channel counts the MFMA tiles do not cover, and as the comparison path of the tests (RPN.forward_torch)."""
+    kernels (modules/layers/Block2d.py; config ``crb2d_hip``, default true).  The torch / MIOpen form remains as the comparison
+    path of the tests (RPN.forward_torch) and, announced by a RuntimeWarning (_torch_dispatch), for batches and channel counts
+    the MFMA tiles do not cover; a CPU tensor raises."""
 
     def __init__(self, cin, cout, k, s, p):
         super().__init__()
@@ -343,6 +367,7 @@ class CRB2d(nn.Module):
         if _block2d_on(x, self._kind):
             from modules.layers.Block2d import Block2dFunction
             return Block2dFunction.apply(x, self.conv.weight, self.conv.bias, self._kind, self._stride, self._pack2d)
+        _torch_dispatch(x, 'CRB2d', self._kind)
         return F.batch_norm(F.relu(self.conv(_nchw(x))), None, None, None, None, True, 0.0, cfg.eps)
 
 
@@ -367,4 +392,5 @@ class DeCRB2d(nn.Module):
             from modules.layers.Block2d import Block2dFunction
             out = Block2dFunction.apply(x, self.deconv.weight, self.deconv.bias, self._kind, self._stride, self._pack2d)
             return _nchw(out) if _IN_FORWARD_TORCH[0] else out    # inside RPN.forward_torch: joins the other (NCHW) branches
+        _torch_dispatch(x, 'DeCRB2d', self._kind)
         return F.batch_norm(F.relu(self.deconv(_nchw(x))), None, None, None, None, True, 0.0, cfg.eps)

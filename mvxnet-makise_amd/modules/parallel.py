@@ -3,6 +3,7 @@ all-reduce (RCCL over xGMI, `nccl` backend; `gloo` on CPU for tests) of a flat f
 bucket per step.  The reference has no distributed code; this is the
 MI355X-native addition of SURVEY section 8e.  Ring all-reduce is per-link bound on xGMI, so the
 whole trainable gradient (<= 29.5 MB) goes out as a single large bucket."""
+import collections
 import os
 
 import torch
@@ -65,6 +66,8 @@ class GradBucket:
         self._count = self._buf[n:]
         self.times = []                           # (start, end) event pairs of the collectives, when timing is on
         self.timing = False
+        self.two_part_on_cpu = False              # tests: take the two-part branch on CPU tensors too (gloo)
+        self.calls = collections.deque(maxlen=16)   # which branch the last exchanges took (tests)
         off = 0
         for p in self.params:                 # parameters' .grad become views of the bucket
             p.grad = self.flat[off:off + p.numel()].view_as(p)
@@ -99,8 +102,14 @@ class GradBucket:
         if frames_local is not None:
             self._count.fill_(float(frames_local))
         if dist.is_initialized():             # also with one rank: the collective path is the same code at every world size
-            two = self.n_early < n and self.flat.is_cuda      # also with one rank: the same two calls at every world size
-            if two:
+            two = self.n_early < n and (self.flat.is_cuda or self.two_part_on_cpu)
+            if two and not self.flat.is_cuda:
+                # CPU tensors (gloo; tests): the same two collectives over the same [early | late + count] split, no streams
+                w_early = dist.all_reduce(self._buf[:self.n_early], op=dist.ReduceOp.SUM, async_op=True)
+                dist.all_reduce(self._buf[self.n_early:], op=dist.ReduceOp.SUM)
+                w_early.wait()
+                self.calls.append('two-part')
+            elif two:
                 from modules import _hip
                 dev = self.flat.device
                 main = torch.cuda.current_stream(dev)
@@ -113,24 +122,29 @@ class GradBucket:
                     comm.wait_event(evs[1])
                 self._buf.record_stream(comm)
                 with torch.cuda.stream(comm):
-                    t = self._timed(comm)
+                    t_early = self._timed(comm)
                     w_early = dist.all_reduce(self._buf[:self.n_early], op=dist.ReduceOp.SUM, async_op=True)
-                    if t:
-                        t[1].record(comm)
-                        self.times.append(('early', ) + t)
                 t = self._timed(main)
                 dist.all_reduce(self._buf[self.n_early:], op=dist.ReduceOp.SUM)      # late parameters + the count slot
                 if t:
                     t[1].record(main)
                     self.times.append(('late', ) + t)
-                w_early.wait()                       # the current stream waits for the early part
+                with torch.cuda.stream(comm):
+                    # the collective runs on the process group's own stream: `comm` is behind it only after wait(), so the end
+                    # event is recorded here and not right after the async call
+                    w_early.wait()
+                    if t_early:
+                        t_early[1].record(comm)
+                        self.times.append(('early', ) + t_early)
                 main.wait_stream(comm)
+                self.calls.append('two-part' if evs is not None else 'two-part, after the main stream')
             else:
                 t = self._timed(torch.cuda.current_stream(self.flat.device)) if self.flat.is_cuda else None
                 dist.all_reduce(self._buf if frames_local is not None else self.flat, op=dist.ReduceOp.SUM)
                 if t:
                     t[1].record(torch.cuda.current_stream(self.flat.device))
                     self.times.append(('all', ) + t)
+                self.calls.append('single')
         if frames_local is not None:
             self.flat.div_(self._count.clamp_min(1.0))
         else:

@@ -459,6 +459,8 @@ def _train_step_frame_set_lanes(model, batch, grad_mid, imsize, ready, prepare_n
         if done and sets and flat is not None:                  # success only: partial lane gradients never reach the bucket
             for k in range(1, len(sets)):                       # the other lanes' gradients join the bucket (main stream)
                 flat.add_(_lane_flat(flat, k))
+            if len(sets) > 1:
+                _hip.drop_tail(dev)                             # written after the join: the early exchange waits for the main stream
     if prepare_next is not None:
         return counts, statuses, next_ready
     return counts, statuses

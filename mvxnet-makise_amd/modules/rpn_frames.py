@@ -324,8 +324,7 @@ _MUTATE = {}        # TESTS ONLY (tests/test_rpn_gpu.py): name -> factor applied
 
 
 def _mut(name, t):
-    f = _MUTATE.get(name)
-    return t if f is None else t * f
+    return _hip.mutate(_MUTATE, name, t) if _MUTATE else t
 
 
 def rpn_backward(rpn, S, d_heads):

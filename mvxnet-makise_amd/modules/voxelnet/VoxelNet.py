@@ -90,7 +90,8 @@ class VoxelNet(nn.Module):
             finally:
                 Blocks.RESTRICTED_BACKWARD = old
         else:
-            x = self.cml(self.reindex(x, idx))
+            # the grid holds this library's voxel features (outputs of a BatchNorm + max): not a foreign input to conv1
+            x = self.cml(_hip.mark_lib(self.reindex(x, idx)))
         return x
 
     def middle(self, x, idx, compact_rows=None):

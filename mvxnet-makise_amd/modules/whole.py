@@ -82,6 +82,10 @@ class WholeModelFunction(torch.autograd.Function):
             _hip.ASYNC_WGRAD = old_async
             _hip.arena_end()
             _hip.join_side_stream(dev)
+            if views is not None:
+                # not the direct sink: autograd adds the returned views into .grad on this stream AFTER the join, so the tail
+                # pair no longer bounds the gradient writes
+                _hip.drop_tail(dev)
         ctx.saved = ctx.rs = None
         return (None, None, None, None, None) + (tuple(views) if views is not None else (None,) * len(params))
 

@@ -4,7 +4,7 @@ mode toy   : two small parameters, every rank adds the gradients of its frames, 
 mode chunks: (the divisor travels in the bucket's count slot: one collective per step) train_like.py's --mode fast step schedule on an ODD frame count (7 and 9 frames, 2 per rank per step): every rank
              runs the same number of steps, a rank without a frame in the short last chunk still joins the all-reduce, the
              divisor is the global number of contributing frames, every frame is used exactly once.
-mode model : the REAL flat bucket over MVXNet's hot-path parameters (same construction as bench.py / train_like.py): every
+mode model : (world 2 and world 8) the REAL flat bucket over MVXNet's hot-path parameters (same construction as bench.py / train_like.py): every
              rank fills the gradients of its own frames with a frame-dependent pattern, all-reduces, and compares with
              the single-process sum over all frames computed locally; then one AdamW step must leave both ranks with
              bit-identical parameters.  The HIP kernels are not involved (no GPU here): this covers the N > 1 path's
@@ -72,7 +72,10 @@ else:
     assert bucket.flat.numel() == sum(p.numel() for _, p in hot) == 1169440
     assert bucket.n_early == 1169440 - late.numel() and late.grad.data_ptr() == bucket.flat[bucket.n_early:].data_ptr()
     opt = torch.optim.AdamW([p for _, p in hot], lr=1e-3, eps=1e-6)
-    frames_total = 8                                 # 4 frames per rank, frames {i : i mod world == rank}
+    # the TWO-PART exchange on CPU tensors (on a GPU: early part on the communication stream, late part + count slot after the
+    # join; here the same two collectives over the same split)
+    bucket.two_part_on_cpu = True
+    frames_total = max(8, 2 * world)                 # frames {i : i mod world == rank}: 4 per rank at world 2, 2 at world 8
 
     def frame_grad(f, p, j):
         g = torch.Generator().manual_seed(1000 * f + j)
@@ -85,6 +88,7 @@ else:
         for j, (_, p) in enumerate(hot):
             p.grad.add_(frame_grad(f, p, j))
     bucket.all_reduce_mean(frames_local=len(mine))    # count slot: 4 + 4 frames
+    assert list(bucket.calls) == ['two-part'] and int(bucket._count[0]) == frames_total
     for j, (k, p) in enumerate(hot):
         want = sum(frame_grad(f, p, j) for f in range(frames_total)) / frames_total
         assert torch.allclose(p.grad, want, rtol=1e-5, atol=1e-6), k

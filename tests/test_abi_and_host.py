@@ -88,7 +88,7 @@ def test_arithmetic_selection_logic():
                       ('MVX_FLAG_AMAX_COARSE', _hip.FLAG_AMAX_COARSE), ('MVX_FLAG_NO_BG_FILL', _hip.FLAG_NO_BG_FILL),
                       ('MVX_FLAG_SUMS_READY', _hip.FLAG_SUMS_READY)):
         assert int(_re.search(r'#define %s (\d+)' % name, header).group(1)) == val, name
-    assert cfg.config['convmath'] == 'fp16x3'                  # the shipped default
+    assert cfg.config['convmath'] == os.environ.get('MVX_CONVMATH', 'bf16x6')   # the shipped default: operand-exact (config.yml:2 half: False)
     old = cfg.config['convmath']
     try:
         codes = {}
@@ -114,6 +114,30 @@ def test_arithmetic_selection_logic():
     _hip.tag_amax(t, torch.ones(1))
     assert _hip.grad_split(4, t) == 4 and _hip.foreign_split(4, t) == (4, _hip.FLAG_AMAX_COARSE)
     assert _hip.amax_of(t.view(2, 2)) is None                  # a view does not carry the tag (callers re-tag)
+
+
+def test_2d_blocks_never_fall_to_torch_silently():
+    """a stand-alone CRB2d / DeCRB2d on a CPU tensor raises (this package has no CPU path); the torch /
+    MIOpen form only runs where the caller chose it (RPN.forward_torch, `crb2d_hip: false`) or with a RuntimeWarning."""
+    import modules.config as cfg
+    from modules.Extension import MvxHipError
+    from modules.layers import CRB2d, DeCRB2d
+    from modules.layers import Blocks
+    x = torch.randn(1, 64, 8, 8)
+    for m in (CRB2d(64, 64, 3, 1, 1), DeCRB2d(64, 64, 3, 1, 1)):
+        with pytest.raises(MvxHipError):
+            m(x)
+        old = cfg.config.get('crb2d_hip', True)
+        cfg.config['crb2d_hip'] = False                       # the explicit opt-out: torch modules, no complaint
+        try:
+            assert m(x).shape == (1, 64, 8, 8)
+        finally:
+            cfg.config['crb2d_hip'] = old
+        Blocks._IN_FORWARD_TORCH[0] = True                    # the comparison path of the tests
+        try:
+            assert m(x).shape == (1, 64, 8, 8)
+        finally:
+            Blocks._IN_FORWARD_TORCH[0] = False
 
 
 def test_state_dict_keys_and_param_counts():
@@ -148,16 +172,17 @@ def _free_port():
         return str(sk.getsockname()[1])
 
 
-@pytest.mark.parametrize('mode', ['toy', 'chunks', 'model'])
-def test_data_parallel_gradient_exchange_gloo_world2(mode):
-    """Two CPU processes over gloo.  toy: the flat bucket all-reduce gives the mean over all frames.  model: the real
-    GradBucket over MVXNet's 1,169,440 hot-path parameters with different per-frame gradients on the two ranks equals the
-    single-process sum, and the replicas stay identical after AdamW."""
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=_free_port())
+@pytest.mark.parametrize('mode,world', [('toy', 2), ('chunks', 2), ('model', 2), ('model', 8)])
+def test_data_parallel_gradient_exchange_gloo(mode, world):
+    """CPU processes over gloo.  toy: the flat bucket all-reduce gives the mean over all frames.  model (world 2 and the
+    north_star's world 8): the real GradBucket over MVXNet's 1,169,440 hot-path parameters in its two-part layout
+    [early | late | count] with DIFFERENT per-frame gradients on every rank, exchanged by the two-part branch, equals the
+    single-process sum over all frames, and the replicas stay identical after AdamW."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=_free_port(), OMP_NUM_THREADS='1')
     worker = os.path.join(REPO, 'tests', '_dp_worker.py')
-    procs = [subprocess.Popen([sys.executable, worker, mode], env=dict(env, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r)),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
-    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    procs = [subprocess.Popen([sys.executable, worker, mode], env=dict(env, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert 'DP_OK' in o, o

@@ -29,7 +29,37 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert r['bound'] == 'mfma' and 0 < r['frac'] < 1 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
     assert d['alt_modes'] and all(a['value'] > 0 for a in d['alt_modes'])
     assert {a['workload'] for a in d['alt_modes']} == {'S1', 'S2'}
-    assert d['config']['frame_sets'] and 'crop_project' in d['hbm_stages']
+    assert 'crop_project' in d['hbm_stages_frac_of_8TBps']
+    # the detail file the line names holds everything else
+    full = json.load(open(os.path.join(REPO, d['detail'])))
+    assert full['config']['frame_sets'] and 'crop_project' in full['hbm_stages'] and full['value'] == d['value']
+    assert len(full['alt_modes']) == len(d['alt_modes']) and 'roofline' in full['alt_modes'][0]
+
+
+@pytest.mark.gpu
+def test_default_invocation_prints_a_short_parsable_line_in_the_reference_arithmetic():
+    """`python bench.py` exactly as the driver runs it (the r04 line was 27 KB and the driver could not parse it).  The
+    line is < 12 KB, one JSON object, carries roofline + cpu_baseline, its headline arithmetic is operand-exact (bf16x6 or exact f32,
+    /root/reference/config.yml:2 `half: False`) with fp16x3 as the first alternative, and every alternative mode was timed over >= 20
+    steps."""
+    env = dict(os.environ)
+    env.pop('MVX_CONVMATH', None)
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py')], capture_output=True, text=True, timeout=1500, env=env, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    assert len(lines[0]) < 12288, len(lines[0])
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['steps'] == 10 and d['warmup'] == 3 and d['value'] > 0
+    assert d['dtype'].startswith('f32') and ('bf16x6' in d['dtype'] or d['dtype'] == 'f32') and 'convmath=bf16x6' in d['config']['workload']
+    r = d['roofline']
+    assert r['bound'] == 'mfma' and 0 < r['frac'] < 1 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    assert d['cpu_baseline']['kind'] == 'port' and d['cpu_baseline']['value'] > 0 and d['cpu_baseline']['cores'] >= 1
+    alts = d['alt_modes']
+    assert [a['convmath'] for a in alts if a['config'] == 'headline path' and a['workload'] == 'S2'][0] == 'fp16x3'
+    assert {a['config'] for a in alts} >= {2, 3, 4}
+    assert all(a['steps'] >= 20 and a['value'] > 0 for a in alts)
+    assert d['summary'] == d['summary_tail'] and os.path.exists(os.path.join(REPO, d['detail']))
 
 
 @pytest.mark.gpu
@@ -83,4 +113,4 @@ def test_bench_fusion_mode_runs_config_4():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith('{')][0])
     assert d['config']['mode'] == 'fusion' and d['config']['frames_per_gpu'] == 2 and d['value'] > 0
-    assert d['roofline']['bound'] == 'hbm' and d['roofline']['launches'] == 2 and 'feature_sample' in d['hbm_stages']
+    assert d['roofline']['bound'] == 'hbm' and d['roofline']['launches'] == 2 and 'feature_sample' in d['hbm_stages_frac_of_8TBps']

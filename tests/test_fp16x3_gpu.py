@@ -148,6 +148,29 @@ def test_binding_is_consumed_by_one_launch():
     assert rel_err(run(4), ref) < 2e-6
 
 
+def test_a_rejected_call_drops_its_binding():
+    """a gather entry point used to consume the binding only after its argument checks -- a dgrad call rejected by
+    validation left the gradient's range bound, and the next forward launch scaled its activations by it.  Every failed
+    MVX_CHECK_ARG / geometry check now drops the binding."""
+    from modules import _hip
+    from modules import Extension as X
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((1000, 128), generator=g).to(DEV)
+    w = (torch.randn((256, 128), generator=g) * 0.1).to(DEV)
+    bad = torch.full((1,), 1e-30, device=DEV)
+    dz = torch.randn((2, 8, 16, 64), generator=g).to(DEV)
+    wpd = _hip.conv3d_pack((torch.randn((64, 64, 3, 3, 3), generator=g) * 0.05).to(DEV), True, split=4)
+    dx = torch.empty((2, 8, 16, 64), device=DEV)
+    X.check(X.lib.mvx_split_operand_amax(X.ptr(bad), None), 'mvx_split_operand_amax')
+    # stride 3 is not a geometry of this library: rejected before any launch
+    rc = X.lib.mvx_conv3d_dgrad_split(X.ptr(dz), X.ptr(wpd), X.ptr(dx), 2, 2, 8, 16, 64, 64, 3, 1, _hip.split_flags(4), X.stream())
+    assert rc < 0
+    out = torch.empty((1000, 256), device=DEV)
+    X.check(X.lib.mvx_linear_forward(X.ptr(x), 128, X.ptr(w), 128, 0, None, X.ptr(out), 256, None, None, 1000, 128, 256,
+                                     _hip.split_flags(4, True), None, 0, X.stream()), 'mvx_linear_forward')
+    assert rel_err(out, x.double() @ w.double().t()) < 2e-6              # the stale 1e-30 range would have made this inf / NaN
+
+
 def test_foreign_forward_inputs_take_the_coarse_scale_or_bf16x6(golden):
     """A forward scale must not depend on which tensor the executor holds: a frame set and one of its frames have different
     maxima, fine scales would round elements with subnormal low pieces differently and flip ReLUs between the two executors

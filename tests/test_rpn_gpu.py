@@ -231,7 +231,7 @@ def test_rpn_forward_backward_match_oracle(golden, F):
                 e = rel(_nchw_grad_of(g_dx, rec, F)[f:f + 1], gxf)
                 # a pre-activation within 3e-7 of zero (|y| ~ 1 elsewhere: inside ANY fp32 evaluation's rounding) decides its ReLU
                 # either way; the flipped site then moves this layer's gradients by ~1e-2 through the BatchNorm statistics (seen
-                # with F = 3 on blk1.1: min |y| = 7.2e-8, 1145 of 196608 elements off; tools/dbg_rpn_fp16.py).  Such a frame is
+                # with F = 3 on blk1.1: min |y| = 7.2e-8, 1145 of 196608 elements off; located with a one-off script, since removed).  Such a frame is
                 # only required to be close; test_rpn_and_loss_gradients_tight_at_full_size shares the masks instead
                 pre = torch.nn.functional.conv2d(xf.detach(), w_.detach(), b_.detach(), stride=2 if li == 0 else 1, padding=1)
                 kink = float(pre.abs().min()) < 3e-7
@@ -602,3 +602,20 @@ def test_standalone_blocks_run_on_hip_nodes_and_match_float64(kind, args, hw):
     assert n2(x.grad, xr.grad) < 1e-3
     for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
         assert n2(p.grad, q.grad) < 1e-3, k
+
+
+def test_uncovered_standalone_block_warns_once_before_running_on_torch():
+    """a CRB2d the MFMA tiles do not cover (here a batch of two) runs on the torch modules -- with a
+    RuntimeWarning naming the reason, once."""
+    import warnings
+    from modules.layers import CRB2d
+    from modules.layers import Blocks
+    m = CRB2d(64, 64, 3, 1, 1).to(DEV)
+    x = torch.randn(2, 64, 16, 16, device=DEV)
+    Blocks._WARNED.clear()
+    with pytest.warns(RuntimeWarning, match='batch size 2'):
+        y = m(x)
+    assert y.shape == (2, 64, 16, 16)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        m(x)                                                  # second call: no second warning

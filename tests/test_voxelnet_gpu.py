@@ -296,7 +296,7 @@ def test_full_size_background_rewrite_equals_dense_cml():
     # then a coherent sum over ~1e5 sites, and a single ReLU that lands on the other side of zero in one of the two evaluations
     # moves it by 1e-5 instead of 1e-2.  (The two evaluations feed the same kernels inputs that differ in the last bit at the
     # background sites -- exact constants vs computed values -- so an output within 1e-6 of zero may flip; round 4 saw exactly one
-    # such site, (plane 1, row 5, column 304, channel 4), in the bf16x6 arithmetic with 16 x 16-site units: tools/dbg_bg_split2.py.)
+    # such site, (plane 1, row 5, column 304, channel 4), in the bf16x6 arithmetic with 16 x 16-site units: located with a one-off script, since removed.)
     hh = torch.arange(H, dtype=torch.float64)[None, :, None] / H
     ww = torch.arange(W, dtype=torch.float64)[None, None, :] / W
     fa = torch.randint(0, 3, (128, 1, 1), generator=gen)
