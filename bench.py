@@ -338,7 +338,7 @@ def _roof(r):
     """The roofline object of the line: the contract's keys + the kernel it is about, without the prose."""
     keep = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'launches', 'avg_launch_ms', 'flop_per_launch',
             'algorithmic_tflops', 'dense_equivalent_tflops')
-    o = {k: _r(r[k], 5) for k in keep if k in r}
+    o = {k: (r[k] if k in ('achieved', 'peak', 'frac') else _r(r[k], 5)) for k in keep if k in r}
     o['kernel'] = str(o.get('kernel', '')).split(' (')[0]
     if isinstance(r.get('isolated'), dict):
         o['isolated_frac'] = _r(r['isolated']['frac'])

@@ -20,6 +20,24 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BM = 128, BNL = 128, NT = 4;
 
+// Workgroup -> tile mapping that follows the chip: workgroups are dealt round-robin over the 8 XCDs (blocks h and h + 8 share
+// one, MI355X_MICROARCH.md), and every XCD has its own L2.  With the plain (column block fastest) order the 6 column blocks
+// of a 768-wide layer that share a 128-row block of x land on 6 different XCDs and each L2 fetches those rows for itself:
+// 6 x 246 MB of HBM / Infinity-Cache reads for the 80 k x 768 x 768 layer, which made the GEMM memory-bound at 0.3-0.4 of the
+// matrix pipe.  Here the launch is one-dimensional: XCD x = h % 8 runs the row blocks {8 j + x} and walks a row block's column
+// blocks in consecutive slots, so the blocks that share rows run on the SAME L2 at the same time.  (Speed only: nothing
+// depends on the placement.)  Blocks beyond the last row block exit.
+struct XcdTile { unsigned rb, cb; bool on; };
+__device__ __forceinline__ XcdTile xcd_tile(unsigned h, unsigned nbx, unsigned nby) {
+    const unsigned xcd = h & 7u, s = h >> 3;
+    XcdTile t;
+    t.rb = (s / nbx) * 8u + xcd;
+    t.cb = s % nbx;
+    t.on = t.rb < nby;
+    return t;
+}
+static inline unsigned xcd_grid(unsigned nbx, unsigned nby) { return 8u * ((nby + 7u) / 8u) * nbx; }
+
 // NP pieces per operand; K in chunks of BK (64 for bf16x3, 32 for bf16x6: 61 KB of LDS either way, two workgroups per CU)
 template <int NP, int BK, bool BNB, int FMT>
 __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restrict__ x, int ldx, const float *__restrict__ w,
@@ -29,7 +47,10 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
                                                         unsigned *__restrict__ done_counter, double fin_eps,
                                                         float *__restrict__ fin_mean_inv, FrameMap fm,
                                                         const float *__restrict__ bn_y, int bn_ldy,
-                                                        const float *__restrict__ bn_mi, const float *__restrict__ x_amax, int x_coarse) {
+                                                        const float *__restrict__ bn_mi, const float *__restrict__ x_amax, int x_coarse,
+                                                        unsigned nbx, unsigned nby) {
+    const XcdTile tile = xcd_tile(blockIdx.x, nbx, nby);
+    if (!tile.on) return;
     // fp16 pieces (FMT = 1, split_common.h): x is scaled by x_scale (from its bound amax, else 1), w by SPLIT_F16_WSCALE; the
     // accumulators are scaled back in front of the epilogue
     float x_scale = 1.f;
@@ -46,8 +67,8 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
     __shared__ __attribute__((aligned(16))) unsigned char s_w[BNL * ROWB];
     __shared__ double s_red[4][2 * BNL];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const long long r0 = (long long)blockIdx.y * BM;
-    const int n0 = blockIdx.x * BNL;
+    const long long r0 = (long long)tile.rb * BM;
+    const int n0 = tile.cb * BNL;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -223,13 +244,13 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
                 const int which = e / BNL, c = e % BNL;
                 if (n0 + c < N) {
                     const double t = s_red[0][e] + s_red[1][e] + s_red[2][e] + s_red[3][e];
-                    atomicAdd(fstats + ((size_t)(blockIdx.y % MVX_REP) * sst + which) * N + n0 + c, t);
+                    atomicAdd(fstats + ((size_t)(tile.rb % MVX_REP) * sst + which) * N + n0 + c, t);
                 }
             }
         }
         if (done_counter) {
             __shared__ int s_last;
-            bn_finalize_by_last_block(done_counter, gridDim.x * gridDim.y, stats, N, fm, fin_eps, fin_mean_inv, &s_last);
+            bn_finalize_by_last_block(done_counter, nbx * nby, stats, N, fm, fin_eps, fin_mean_inv, &s_last);
         }
     }
 }
@@ -260,7 +281,14 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned short *row0, const unsi
 template <int NP, int FMT>
 __global__ __launch_bounds__(256) void linear_wgrad_split(const float *__restrict__ x, int ldx, const float *__restrict__ dz,
                                                           int lddz, float *__restrict__ slabs, long long R, int K, int N,
-                                                          long long rows_per_strip, SplitAmax am) {
+                                                          long long rows_per_strip, SplitAmax am, unsigned nblk,
+                                                          unsigned strips) {
+    // XCD-aware order (see xcd_tile): the nblk = (n / 128) x (k / 128) output blocks of one row strip read the same rows of x
+    // and dz -- they run in consecutive slots of ONE XCD and share its L2 instead of being spread over four
+    const XcdTile tile = xcd_tile(blockIdx.x, nblk, strips);
+    if (!tile.on) return;
+    const unsigned nby_ = (unsigned)((N + 127) / 128);
+    const unsigned strip = tile.rb, by = tile.cb % nby_, bz = tile.cb / nby_;
     float x_scale = 1.f, z_scale = 1.f;                       // fp16 pieces: operands scaled by their bound amax (split_common.h)
     // x is an activation: the coarse scale (a frame set and a single frame then scale it alike); dz: the fine one
     if constexpr (FMT == 1) { x_scale = split_scale_coarse(am.a); z_scale = split_scale_of(am.b); }
@@ -268,8 +296,8 @@ __global__ __launch_bounds__(256) void linear_wgrad_split(const float *__restric
     __shared__ __attribute__((aligned(16))) unsigned short s_x[NP][4][WRS][32];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int wn = wv >> 1, wk = wv & 1;
-    const int n0 = blockIdx.y * 128, k0 = blockIdx.z * 128;
-    const long long rbeg = (long long)blockIdx.x * rows_per_strip;
+    const int n0 = by * 128, k0 = bz * 128;
+    const long long rbeg = (long long)strip * rows_per_strip;
     const long long rend = rbeg + rows_per_strip < R ? rbeg + rows_per_strip : R;
     // transpose-read roles of this lane (conv3d_wgrad_split)
     const int grp = lane >> 4, i16 = lane & 15, q = i16 >> 2, pcol = (grp & 1) * 16 + 4 * (i16 & 3), kbase = (grp >> 1) * 8;
@@ -331,7 +359,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_split(const float *__restric
         }
     }
     if (wave_on) {
-        float *o = slabs + (size_t)blockIdx.x * N * K;
+        float *o = slabs + (size_t)strip * N * K;
         if constexpr (FMT == 1) {
             const float o_scale = split_inverse(x_scale) * split_inverse(z_scale);
 #pragma unroll
@@ -357,13 +385,17 @@ __global__ __launch_bounds__(256) void linear_wgrad_split(const float *__restric
 // Launched by linear.hip (mvx_linear_wgrad) when MVX_FLAG_SPLIT is set and the operands are 16-byte aligned.
 int mvxi_linear_wgrad_split(const float *x, int ldx, const float *dz, int lddz, float *slabs, long long rows, int k, int n,
                             long long rows_per_strip, long long strips, int pieces, hipStream_t st, const SplitAmax &am) {
-    const dim3 grid((unsigned)strips, mvx_cdiv(n, 128), mvx_cdiv(k, 128));
+    const unsigned nblk = mvx_cdiv(n, 128) * mvx_cdiv(k, 128);
+    const dim3 grid(xcd_grid(nblk, (unsigned)strips));
     if (pieces == 4)
-        hipLaunchKernelGGL((linear_wgrad_split<2, 1>), grid, dim3(256), 0, st, x, ldx, dz, lddz, slabs, rows, k, n, rows_per_strip, am);
+        hipLaunchKernelGGL((linear_wgrad_split<2, 1>), grid, dim3(256), 0, st, x, ldx, dz, lddz, slabs, rows, k, n, rows_per_strip, am,
+                           nblk, (unsigned)strips);
     else if (pieces == 3)
-        hipLaunchKernelGGL((linear_wgrad_split<3, 0>), grid, dim3(256), 0, st, x, ldx, dz, lddz, slabs, rows, k, n, rows_per_strip, am);
+        hipLaunchKernelGGL((linear_wgrad_split<3, 0>), grid, dim3(256), 0, st, x, ldx, dz, lddz, slabs, rows, k, n, rows_per_strip, am,
+                           nblk, (unsigned)strips);
     else
-        hipLaunchKernelGGL((linear_wgrad_split<2, 0>), grid, dim3(256), 0, st, x, ldx, dz, lddz, slabs, rows, k, n, rows_per_strip, am);
+        hipLaunchKernelGGL((linear_wgrad_split<2, 0>), grid, dim3(256), 0, st, x, ldx, dz, lddz, slabs, rows, k, n, rows_per_strip, am,
+                           nblk, (unsigned)strips);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
@@ -373,10 +405,11 @@ int mvxi_linear_forward_split(const float *x, int ldx, const float *w, int ldw, 
                               int ldy, double *stats, const float *row_w, long long rows, int k, int n, int relu,
                               unsigned *fin_counter, double fin_eps, float *fin_mean_inv, const FrameMap &fm, int pieces,
                               hipStream_t st, const float *bn_y, int bn_ldy, const float *bn_mi, const SplitAmax &am) {
-    const dim3 grid(mvx_cdiv(n, BNL), mvx_cdiv(rows, BM));
+    const unsigned nbx = mvx_cdiv(n, BNL), nby = mvx_cdiv(rows, BM);
+    const dim3 grid(xcd_grid(nbx, nby));
 #define MVX_GO(NP_, BK_, B_, F_)                                                                                                     \
     hipLaunchKernelGGL((linear_fwd_split<NP_, BK_, B_, F_>), grid, dim3(256), 0, st, x, ldx, w, ldw, bias, y, ldy, stats, row_w, rows, k, \
-                       n, relu, fin_counter, fin_eps, fin_mean_inv, fm, bn_y, bn_ldy, bn_mi, am.a, am.coarse_a)
+                       n, relu, fin_counter, fin_eps, fin_mean_inv, fm, bn_y, bn_ldy, bn_mi, am.a, am.coarse_a, nbx, nby)
     if (pieces == 4)      { if (bn_y) MVX_GO(2, 64, true, 1); else MVX_GO(2, 64, false, 1); }
     else if (pieces == 3) { if (bn_y) MVX_GO(3, 32, true, 0); else MVX_GO(3, 32, false, 0); }
     else                  { if (bn_y) MVX_GO(2, 64, true, 0); else MVX_GO(2, 64, false, 0); }
