@@ -52,6 +52,7 @@ extern "C" {
 #define MVX_FLAG_SPLIT3 128    /* with MVX_FLAG_SPLIT, and on the *_split entry points: THREE bf16 pieces per f32 operand and six bf16 MFMAs per product
                                   ("bf16x6": hi + mid + lo is the operand exactly, dropped cross terms < 2^-25: fp32-grade accuracy) instead of two / three */
 
+#define MVX_FLAG_PRE_XCD_STRIPS 4096  /* mvx_linear_wgrad_pre: every block of a row strip on the same XCD (shared L2) instead of consecutive block ids */
 #define MVX_FLAG_SPLIT_F16 512  /* with MVX_FLAG_SPLIT, and on the *_split entry points: TWO fp16 pieces per f32 operand (22 mantissa bits) and three
                                   fp16 MFMAs per product ("fp16x3": fp32-grade accuracy at the matrix work of bf16x3) -- for operands inside fp16's
                                   range: values above 65,504 overflow and below ~1e-4 lose relative precision, so callers scale by powers of two */
@@ -441,6 +442,31 @@ int mvx_linear_dgrad_bnsums_frames(const float *dz, int32_t lddz, const float *w
                                    const float *bn_mean_inv, double *bn_scratch, const mvx_frames_t *frames_host,
                                    int32_t row_kind, void *stream);
 size_t mvx_linear_wgrad_workspace_bytes(int64_t rows, int32_t k, int32_t n);
+
+/* ------------------------------------------------------------------------------------------
+ * Row GEMMs on PRE-CUT operands (csrc/rowgemm_pre.hip): the same nn.Linear / 1x1 Conv2d products
+ * (modules/layers/Blocks.py:9,14,35,39; the fusion MLP of modules/imhead/Pipe.py:84-104) in the split arithmetics
+ * MVX_FLAG_SPLIT3 (three bf16 pieces = the f32 operand exactly, six MFMAs per product) / MVX_FLAG_SPLIT_F16 (two fp16 pieces),
+ * with every operand stored as PLANES of 16-bit pieces -- u16 [pieces][rows][k], plane stride rows * k -- by the kernel that
+ * produced it, so that the GEMM moves its tiles global -> LDS by DMA and issues nothing but matrix instructions and LDS reads.
+ *   mvx_split_planes_bytes     size of the planes of a [rows][k] f32 matrix
+ *   mvx_split_rows             f32 [rows][ldx] -> planes (weights, once per optimizer step; any tensor whose producer does not
+ *                              write planes itself); `scale` multiplies the values first (fp16 pieces only; a power of two)
+ *   mvx_linear_forward_pre_frames  y f32 [rows][ldy] = [ReLU](out_scale * a b^T + bias) from a = planes of x [rows][k] and
+ *                              b = planes of the weight [n][k] (input gradient: of the transposed weight), per-frame
+ *                              BatchNorm sums / finalisation exactly as mvx_linear_forward_bn_frames; k % 32 == 0
+ *   mvx_linear_wgrad_pre       dw f32 [n][k] (+= with MVX_FLAG_ACCUMULATE) = out_scale * dz^T x from the planes of dz [rows][n]
+ *                              and x [rows][k]; n % 128 == 0, k % 128 == 0; workspace: mvx_linear_wgrad_pre_workspace_bytes
+ */
+size_t mvx_split_planes_bytes(int64_t rows, int32_t k, int32_t flags);
+int mvx_split_rows(const float *x, int32_t ldx, int64_t rows, int32_t k, void *planes, int32_t flags, float scale, void *stream);
+int mvx_linear_forward_pre_frames(const void *a_planes, const void *b_planes, const float *bias, float *y, int32_t ldy,
+                                  double *stats, const float *row_w, int64_t rows, int32_t k, int32_t n, int32_t flags,
+                                  float out_scale, uint32_t *done_counter, double eps, float *mean_inv,
+                                  const mvx_frames_t *frames_host, int32_t row_kind, void *stream);
+size_t mvx_linear_wgrad_pre_workspace_bytes(int64_t rows, int32_t k, int32_t n);
+int mvx_linear_wgrad_pre(const void *x_planes, const void *dz_planes, float *dw, int64_t rows, int32_t k, int32_t n,
+                         int32_t flags, float out_scale, void *workspace, size_t workspace_bytes, void *stream);
 int mvx_linear_wgrad(const float *x, int32_t ldx, const float *dz, int32_t lddz, float *dw, int64_t rows,
                      int32_t k, int32_t n, int32_t flags, void *workspace, size_t workspace_bytes, void *stream);
 
@@ -635,6 +661,13 @@ int mvx_bn_relu_backward_frames(const float *dyhat, const float *y, const float 
                                 float *dbias, double *scratch, const float *row_w, int64_t rows, int32_t channels,
                                 int32_t flags, const mvx_frames_t *frames_host, int32_t row_kind,
                                 float *dz_amax /* NULL or 1 float: max |dz| written (mvx_split_operand_amax) */, void *stream);
+/* ... with dz written as three planes of bf16 pieces, u16 [3][rows][channels] (hi + mid + lo = dz exactly: the operand format
+ * of mvx_linear_wgrad_pre), instead of f32 -- for a layer whose dz only feeds its own weight gradient (modules/imhead/Pipe.py:94:
+ * the first fusion layer's input carries no gradient). */
+int mvx_bn_relu_backward_planes_frames(const float *dyhat, const float *y, const float *mean_inv, double count, void *dz_planes,
+                                       float *dbias, double *scratch, const float *row_w, int64_t rows, int32_t channels,
+                                       int32_t flags, const mvx_frames_t *frames_host, int32_t row_kind, float *dz_amax,
+                                       void *stream);
 int mvx_vfe_bn_max_concat_frames(const float *y, const float *mean_inv, float *out, int32_t *argmax, int32_t n_voxels,
                                  int32_t t, int32_t channels, const int32_t *voff, const int32_t *vcnt, int32_t n_real,
                                  const mvx_frames_t *frames_host, void *stream);

@@ -6,6 +6,7 @@
 // partials per thread, f64 across the block and f64 atomics across blocks, so the batch
 // statistics do not depend on the launch geometry beyond f64 rounding.
 #include "common.h"
+#include "split_common.h"
 
 namespace {
 
@@ -208,7 +209,10 @@ __global__ __launch_bounds__(256) void bn_bwd_ab(const double *__restrict__ sums
 }
 
 // backward, pass 2: dz = (y > 0) ? inv * (dyh - s1/N - yhat * s2/N) : 0 ; dbias[c] += sum dz (over ALL frames)
-template <int TRIP>
+// PL (compile time): dz is written as THREE PLANES of bf16 pieces (u16 [3][rows][C]: hi + mid + lo = dz exactly,
+// split_common.h) instead of f32 -- the operand format of the weight gradient on pre-cut operands (rowgemm_pre.hip), for a layer
+// whose dz has no other reader (the first layer of the fusion MLP: its input carries no gradient)
+template <int TRIP, bool PL = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dyh, const float *__restrict__ y,
                                                     const float *__restrict__ mi, const float *__restrict__ ab,
                                                     float *__restrict__ dz, double *__restrict__ dbias,
@@ -261,7 +265,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dy
                         o.y = v[j].y > 0.f ? iv.y * (g[j].y - rw[j] * (a[1] + ((v[j].y - m.y) * iv.y) * b[1])) : 0.f;
                         o.z = v[j].z > 0.f ? iv.z * (g[j].z - rw[j] * (a[2] + ((v[j].z - m.z) * iv.z) * b[2])) : 0.f;
                         o.w = v[j].w > 0.f ? iv.w * (g[j].w - rw[j] * (a[3] + ((v[j].w - m.w) * iv.w) * b[3])) : 0.f;
-                        *(float4 *)(dz + rr * C + col * 4) = o;
+                        if constexpr (PL) {
+                            uint2 pc[3];
+                            split_n<3, 0>(o.x, o.y, o.z, o.w, pc);
+                            unsigned short *pl = (unsigned short *)dz;
+#pragma unroll
+                            for (int q = 0; q < 3; ++q) *(uint2 *)(pl + ((size_t)q * rows + rr) * C + col * 4) = pc[q];
+                        } else {
+                            *(float4 *)(dz + rr * C + col * 4) = o;
+                        }
                         sb.x += o.x; sb.y += o.y; sb.z += o.z; sb.w += o.w;
                         mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
                     }
@@ -422,10 +434,10 @@ extern "C" int mvx_tensor_amax(const float *x, int64_t n, float *amax, int32_t f
     return MVX_OK;
 }
 
-extern "C" int mvx_bn_relu_backward_frames(const float *dyhat, const float *y, const float *mean_inv, double count,
-                                           float *dz, float *dbias, double *scratch, const float *row_w, int64_t rows,
-                                           int32_t channels, int32_t flags, const mvx_frames_t *frames_host,
-                                           int32_t row_kind, float *dz_amax, void *stream) {
+static int bn_relu_backward_impl(const float *dyhat, const float *y, const float *mean_inv, double count,
+                                 float *dz, float *dbias, double *scratch, const float *row_w, int64_t rows,
+                                 int32_t channels, int32_t flags, const mvx_frames_t *frames_host,
+                                 int32_t row_kind, float *dz_amax, void *stream, bool planes) {
     MVX_CHECK_ARG(dyhat && y && mean_inv && dz && scratch && rows >= 0 && channels > 0 && channels % 4 == 0);
     MVX_CHECK_ARG(count > 0);
     MVX_CHECK_ARG(((uintptr_t)scratch & 15) == 0);          // bn_bwd_apply reads the (a, b) floats behind the sums with float4 loads
@@ -453,9 +465,14 @@ extern "C" int mvx_bn_relu_backward_frames(const float *dyhat, const float *y, c
             hipLaunchKernelGGL(bn_bwd_reduce<BWD_TRIP>, dim3(blocks), dim3(256), 0, st, dyhat, y, mean_inv, scratch, (size_t)rows,
                                channels, rpb, fm, counters + 1, ab, (unsigned *)dz_amax);
         MVX_LAUNCH_CHECK();
-        hipLaunchKernelGGL(bn_bwd_apply<BWD_TRIP>, dim3(blocks), dim3(256), 0, st, dyhat, y, mean_inv, (const float *)ab, dz,
-                           dbias ? scratch + 2 * channels : (double *)nullptr, row_w, (size_t)rows, channels,
-                           counters, dbias, flags & MVX_FLAG_ACCUMULATE, rpb, fm, (unsigned *)dz_amax);
+        if (planes)
+            hipLaunchKernelGGL((bn_bwd_apply<BWD_TRIP, true>), dim3(blocks), dim3(256), 0, st, dyhat, y, mean_inv, (const float *)ab, dz,
+                               dbias ? scratch + 2 * channels : (double *)nullptr, row_w, (size_t)rows, channels,
+                               counters, dbias, flags & MVX_FLAG_ACCUMULATE, rpb, fm, (unsigned *)dz_amax);
+        else
+            hipLaunchKernelGGL((bn_bwd_apply<BWD_TRIP, false>), dim3(blocks), dim3(256), 0, st, dyhat, y, mean_inv, (const float *)ab, dz,
+                               dbias ? scratch + 2 * channels : (double *)nullptr, row_w, (size_t)rows, channels,
+                               counters, dbias, flags & MVX_FLAG_ACCUMULATE, rpb, fm, (unsigned *)dz_amax);
         MVX_LAUNCH_CHECK();
     } else if (dz_amax) {
         hipError_t e = hipMemsetAsync(dz_amax, 0, sizeof(float), st);
@@ -467,6 +484,25 @@ extern "C" int mvx_bn_relu_backward_frames(const float *dyhat, const float *y, c
         MVX_LAUNCH_CHECK();
     }
     return MVX_OK;
+}
+
+extern "C" int mvx_bn_relu_backward_frames(const float *dyhat, const float *y, const float *mean_inv, double count,
+                                           float *dz, float *dbias, double *scratch, const float *row_w, int64_t rows,
+                                           int32_t channels, int32_t flags, const mvx_frames_t *frames_host,
+                                           int32_t row_kind, float *dz_amax, void *stream) {
+    return bn_relu_backward_impl(dyhat, y, mean_inv, count, dz, dbias, scratch, row_w, rows, channels, flags, frames_host, row_kind,
+                                 dz_amax, stream, false);
+}
+
+// The same with dz written as three planes of bf16 pieces, u16 [3][rows][channels] (MVX_FLAG_SPLIT3 operand format of
+// mvx_linear_wgrad_pre), instead of f32: for a layer whose dz only feeds its own weight gradient.
+extern "C" int mvx_bn_relu_backward_planes_frames(const float *dyhat, const float *y, const float *mean_inv, double count,
+                                                  void *dz_planes, float *dbias, double *scratch, const float *row_w, int64_t rows,
+                                                  int32_t channels, int32_t flags, const mvx_frames_t *frames_host,
+                                                  int32_t row_kind, float *dz_amax, void *stream) {
+    MVX_CHECK_ARG((((uintptr_t)dz_planes) & 15) == 0 && !(flags & MVX_FLAG_SUMS_READY));
+    return bn_relu_backward_impl(dyhat, y, mean_inv, count, (float *)dz_planes, dbias, scratch, row_w, rows, channels, flags,
+                                 frames_host, row_kind, dz_amax, stream, true);
 }
 
 extern "C" int mvx_bn_relu_backward(const float *dyhat, const float *y, const float *mean_inv, double count,

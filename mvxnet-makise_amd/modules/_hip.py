@@ -973,6 +973,80 @@ def transposed_weight(w2):
     return hit[1]
 
 
+# ---------------------------------------------------------------------------------------------
+# Row GEMMs on pre-cut operands (csrc/rowgemm_pre.hip): the operands are PLANES of 16-bit pieces, int16 (pieces, rows, k),
+# written by their producers; the GEMM moves them global -> LDS by DMA.  Used for the wide layers whose shape fills its
+# 256 x 256 tiles (n a multiple of 256: the 768 -> 768 fusion layer, 70 % of the row-GEMM work of a step) in the bf16x6
+# arithmetic; every other call keeps the in-kernel-cut kernels.  MVX_PRECUT=0 switches it off (A/B runs).
+# ---------------------------------------------------------------------------------------------
+PRECUT = os.environ.get('MVX_PRECUT', '1') != '0'
+# The FORWARD on pre-cut operands is opt-in: its products and their accumulation order are those of linear_fwd_split (y is
+# bit-identical), but its BatchNorm sums go through four-term f32 partial sums (csrc/rowgemm_pre.hip: all-f64 sums do not fit the
+# register file beside 128 accumulators) and differ by ~1e-9 relative -- enough to move a mean by one f32 ulp and to put two
+# executors that pick different kernels 1.7e-6 apart after five BatchNorm layers, where the tests hold them to 1e-6.  It buys
+# 0.08 ms of a 8.5 ms step in bf16x6 (0.59 vs 0.65 ms for the 768 x 768 layer); the weight gradient (0.43 vs 0.70 ms, the
+# step's tail) has no statistics and is on by default.
+PRECUT_FWD = os.environ.get('MVX_PRECUT_FWD', '0') != '0'
+
+
+def precut_ok(split, rows, K, N):
+    return bool(PRECUT and split and int(split) == 3 and N % 256 == 0 and K % 16 == 0 and rows >= 2048 and
+                3 * rows * max(K, N) * 2 < (1 << 32))
+
+
+def split_rows(x, split, scale=1.0):
+    """f32 (rows, k) -> planes int16 (pieces, rows, k) (mvx_split_rows).  For tensors whose producer does not write planes."""
+    rows, K = x.shape
+    flags = split_flags(split, True)
+    planes = torch.empty((3 if int(split) == 3 else 2, rows, K), dtype=torch.int16, device=x.device)
+    X.check(X.lib.mvx_split_rows(_vptr(x), _ld(x), rows, K, X.ptr(planes), flags, float(scale), X.stream()), 'mvx_split_rows')
+    return planes
+
+
+def weight_planes(w2, split):
+    """Planes of a (N, K) weight view, cached ON the parameter it views and keyed by its version counter (see transposed_weight):
+    cut once per optimizer step instead of in every workgroup of every launch."""
+    base = w2._base if w2._base is not None else w2
+    cache = base.__dict__.setdefault('_mvx_wp', {})
+    tag = (base._version, w2.data_ptr())
+    key = (tuple(w2.shape), int(split))
+    hit = cache.get(key)
+    if hit is None or hit[0] != tag:
+        hit = (tag, split_rows(w2.detach().contiguous(), split))
+        cache[key] = hit
+    return hit[1]
+
+
+def linear_forward_pre(x_planes, w_planes, bias, y, stats, row_w, flags, counter, eps, mi, desc, kind):
+    """y = [ReLU](x w^T + b) with per-frame BatchNorm sums / finalisation from operand planes (mvx_linear_forward_pre_frames)."""
+    _, rows, K = x_planes.shape
+    N = w_planes.shape[1]
+    with _Timed('linear_fwd', 2.0 * rows * K * N if KERNEL_TIMERS is not None else 0):
+        X.check(X.lib.mvx_linear_forward_pre_frames(X.ptr(x_planes), X.ptr(w_planes), X.ptr(bias), _vptr(y), _ld(y), X.ptr(stats),
+                                                    X.ptr(row_w), rows, K, N, flags, 1.0, X.ptr(counter), float(eps), X.ptr(mi),
+                                                    desc.ref() if desc is not None else None, kind, X.stream()),
+                'mvx_linear_forward_pre_frames')
+
+
+def linear_wgrad_pre(x_planes, dz_planes, accumulate_into=None):
+    """dW (N, K) (+)= dz^T x from operand planes (mvx_linear_wgrad_pre); on the side stream like linear_wgrad."""
+    pieces, rows, K = x_planes.shape
+    N = dz_planes.shape[2]
+    if accumulate_into is not None:
+        assert accumulate_into.is_contiguous() and accumulate_into.numel() == N * K
+        dw, flags = accumulate_into, FLAG_ACCUMULATE
+    else:
+        dw, flags = torch.empty((N, K), dtype=torch.float32, device=x_planes.device), 0
+    flags |= split_flags(3 if pieces == 3 else 4, True)
+    nbytes = X.lib.mvx_linear_wgrad_pre_workspace_bytes(rows, K, N)
+    with _wgrad_scope(accumulate_into, x_planes, dz_planes) as scope:
+        ws = workspace(nbytes, x_planes.device, 'lwgrad_pre_side' if isinstance(scope, _SideStream) else 'lwgrad_pre')
+        with _Timed('linear_wgrad', 2.0 * rows * K * N if KERNEL_TIMERS is not None else 0):
+            X.check(X.lib.mvx_linear_wgrad_pre(X.ptr(x_planes), X.ptr(dz_planes), X.ptr(dw), rows, K, N, flags, 1.0, X.ptr(ws),
+                                               ws.numel(), X.stream()), 'mvx_linear_wgrad_pre')
+    return None if accumulate_into is not None else dw
+
+
 def rows_dgrad(dz, w2, label='linear_dgrad'):
     """dx = dz w2 of a row layer with weight (N, K): in bf16x3 arithmetic (``row_split('dgrad')``) through the cached
     transposed copy, otherwise through the f32 kernel's transposed-weight read."""

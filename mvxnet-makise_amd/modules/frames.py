@@ -79,6 +79,8 @@ class FrameSet:
                   self.vcnt, self.row_w, self.fusion_row_w) + (tuple(self.sampled) if self.sampled is not None else ()) + \
                  (tuple(self.grid['tensors']) if self.grid is not None else ()):
             t.record_stream(stream)
+            if getattr(t, '_mvx_planes', None) is not None:      # the sampled features' planes of bf16 pieces (sample_rows)
+                t._mvx_planes.record_stream(stream)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -110,6 +112,12 @@ def linear_bn(x, w, b, fs, kind, row_w, eps, tag='fusion', foreign=False):
     if 'lin_fwd' in KNOCKOUT:
         return y, mi
     sp, xfl = _hip.row_split(tag), 0                     # convmath bf16x3 / bf16x6 / fp16x3: the wide layers on the split-MFMA row GEMM
+    xp = getattr(x, '_mvx_planes', None)                 # the producer of x wrote it as planes of bf16 pieces too (sample_rows)
+    if xp is not None and _hip.PRECUT_FWD and _hip.precut_ok(sp, Rr, K, N):
+        # the row GEMM on pre-cut operands (csrc/rowgemm_pre.hip): same products, same accumulation order -- bit-identical y
+        _hip.linear_forward_pre(xp, _hip.weight_planes(w2, sp), b, y, stats, row_w, _hip.FLAG_RELU | fz | _hip.split_flags(sp, True),
+                                counter, eps, mi, fs.desc, kind)
+        return y, mi
     if foreign:
         sp, xfl = _hip.foreign_split(sp, x)
     code, sp = sp, _hip.split_flags(sp, True) | xfl
@@ -134,11 +142,23 @@ def bn_apply(y, mi, fs, kind):
     return out
 
 
-def bn_relu_backward(dyhat, y, mi, fs, kind, row_w, dbias_into, dz=None, sums=None):
+def bn_relu_backward(dyhat, y, mi, fs, kind, row_w, dbias_into, dz=None, sums=None, planes=False):
     """dz (may alias dyhat); the bias gradient is ADDED to ``dbias_into`` (summed over the frames).  ``sums``: the scratch the
-    producer of ``dyhat`` accumulated the reduction into (rows_dgrad_bnsums): no reduction pass then."""
+    producer of ``dyhat`` accumulated the reduction into (rows_dgrad_bnsums): no reduction pass then.  ``planes``: dz is
+    written as three planes of bf16 pieces, int16 (3, rows, C), instead of f32 (a layer whose dz only feeds its own weight
+    gradient on pre-cut operands: _hip.linear_wgrad_pre)."""
     C = mi.shape[-1]
     rows = y.numel() // C
+    if planes:
+        dzp = torch.empty((3, rows, C), dtype=torch.int16, device=y.device)
+        if 'bn_bwd_rows' in KNOCKOUT:
+            return dzp
+        scratch, fz = _hip._acc_f64((X.lib.mvx_bn_backward_scratch_bytes_frames(C, fs.F) // 8,), y.device)
+        with _hip._timed_bytes('bn_relu_backward', 5.5 * y.numel() * 4):
+            X.check(X.lib.mvx_bn_relu_backward_planes_frames(X.ptr(dyhat), X.ptr(y), X.ptr(mi), 1.0, X.ptr(dzp), X.ptr(dbias_into),
+                                                             X.ptr(scratch), X.ptr(row_w), rows, C, _hip.FLAG_ACCUMULATE | fz,
+                                                             fs.desc.ref(), kind, None, X.stream()), 'mvx_bn_relu_backward_planes_frames')
+        return dzp
     if dz is None:
         dz = torch.empty_like(y)
     if ('bn_bwd_rows' if kind != X.ROWS_GRID else 'bn_bwd_grid') in KNOCKOUT:
@@ -250,6 +270,11 @@ def sample_rows(head, fs, fpn_levels, imsize):
                                                      float(imsize[0]), float(imsize[1]), float(cfg.eps), X.ptr(compact),
                                                      X.ptr(status), fs.desc.ref(), X.ptr(amax), X.stream()), 'mvx_feature_sample_rows_frames')
     _hip.tag_amax(compact, amax)
+    w0 = head.fusion._layers()[0][0]
+    if _hip.precut_ok(_hip.split_pieces(), Rt + F, L * C, w0.shape[0]):
+        # the first fusion layer and its weight gradient read their input as planes of bf16 pieces (csrc/rowgemm_pre.hip); cut here,
+        # with the input preparation, off the critical path of the step
+        compact._mvx_planes = _hip.split_rows(compact, _hip.split_pieces())
     return compact, status
 
 
@@ -718,6 +743,15 @@ def rows_backward(model, S, dfeat):
     gx, sums = gim, None
     for i in range(len(S.fusion) - 1, -1, -1):
         x, w, b, y, mi = S.fusion[i]
+        xp = getattr(x, '_mvx_planes', None)
+        if i == 0 and xp is not None and sums is None and _hip.precut_ok(_hip.row_split('wgrad'), x.shape[0], x.shape[1], w.shape[0]):
+            # the step's last and largest weight gradient on pre-cut operands: the BatchNorm backward writes dz as planes (no other
+            # reader: the sampled features carry no gradient), the weight gradient moves both operands by DMA (rowgemm_pre.hip)
+            dzp = bn_relu_backward(gx, y, mi, fs, X.ROWS_FUSION, fs.fusion_row_w, _grad_of(b), planes=True)
+            _hip.mark_tail(dev)
+            if 'lin_wgrad' not in KNOCKOUT:
+                _hip.linear_wgrad_pre(xp, dzp, accumulate_into=_grad_of(w).view(w.shape[0], -1))
+            break
         dz = bn_relu_backward(gx, y, mi, fs, X.ROWS_FUSION, fs.fusion_row_w, _grad_of(b), sums=sums)
         if i == 0:
             _hip.mark_tail(dev)          # the step's last weight gradient follows: everything else of the bucket may go out (parallel.py)
