@@ -358,7 +358,8 @@ def compact_line(out, detail_path):
     if 'cpu_baseline' in out:
         line['cpu_baseline'] = {k: out['cpu_baseline'][k] for k in ('value', 'unit', 'cores', 'kind', 'sample', 'voxel_indices_vs_oracle')
                                 if k in out['cpu_baseline']}
-    for k in ('host_enqueue_ms_per_step', 'library_launches_per_step', 'allreduce_ms_per_call', 'last_losses', 'INVALID_diagnostic_knockout'):
+    for k in ('host_enqueue_ms_per_step', 'library_launches_per_step', 'allreduce_ms_per_call', 'last_losses', 'INVALID_diagnostic_knockout',
+              'gradient_fingerprint'):
         if k in out:
             line[k] = out[k]
     line['other_kernels'] = {n: {'frac': _r(v.get('frac')), 'avg_launch_ms': _r(v['avg_launch_ms']), 'launches': v['launches'],
@@ -391,6 +392,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--convmath', choices=['fp16x3', 'bf16x6', 'bf16x3', 'f32'], default=None, help='override config.yml convmath')
     ap.add_argument('--no-alt', action='store_true', help='skip the extra runs (other workload, bf16x3 arithmetic, the other BASELINE configs)')
+    ap.add_argument('--frame-ids', default=None, help='comma-separated synthetic frame ids of THIS process (default: rank + world * j)')
     ap.add_argument('--timed-only', action='store_true',
                     help='only warm-up + the timed steps (no alt / isolated / CPU passes): what profiles/ is made from')
     args = ap.parse_args(argv)
@@ -456,6 +458,9 @@ def _run(args, rank, world, dev):
     # Python between them (hot 348 -> 364, one-frame-at-a-time 88 -> 105 frames/s on the same box; MVX_FUSED_OPT=0 for the default)
     opt = torch.optim.AdamW(hot, lr=1e-3, eps=cfg.eps, fused=os.environ.get('MVX_FUSED_OPT', '1') == '1')
     frame_ids = [rank + world * j for j in range(args.frames)]
+    if args.frame_ids:
+        frame_ids = [int(v) for v in args.frame_ids.split(',')]
+        assert len(frame_ids) == args.frames, '--frame-ids must name --frames ids'
     batch = make_batch(frame_ids, dev, args.points, args.workload)
     g = torch.Generator(device='cpu').manual_seed(77)
     grad_mid = (torch.randn((1, 128, cfg.voxelshape[0], cfg.voxelshape[1]), generator=g) * 1e-3).to(dev)
@@ -615,6 +620,21 @@ def _run(args, rank, world, dev):
         full['pending'] = out
         return out['voxels']
 
+    def gradient_fingerprint():
+        """MVX_BENCH_FINGERPRINT=1 (tests of the N > 1 path): one hot step WITHOUT the optimizer, then two linear functionals of
+        the exchanged gradient bucket (its sum and its product with a fixed probe vector) in float64.  Linear, so the bucket of a
+        2-rank run must equal the mean of the buckets of its ranks' frames run alone (tests/test_bench_gpu.py)."""
+        bucket.zero()
+        fn = pl.train_step_frame_set if pl.BATCHED else pl.train_step_frames
+        _, statuses = fn(model, batch, grad_mid, imsize)
+        bucket.all_reduce_mean(frames_total)
+        torch.cuda.synchronize()
+        flat = bucket.flat.double()
+        probe = torch.cos(torch.arange(flat.numel(), device=dev, dtype=torch.float64) * 0.37)
+        return {'sum': float(flat.sum()), 'probe': float((flat * probe).sum()), 'norm': float(flat.norm()),
+                'exchange': list(bucket.calls)[-1] if bucket.calls else None, 'frame_ids': frame_ids}
+
+    fingerprint = gradient_fingerprint() if (os.environ.get('MVX_BENCH_FINGERPRINT') and args.mode == 'hot') else None
     step = {'hot': step_hot, 'vfe': step_vfe, 'fusion': step_fusion, 'dropin': step_dropin, 'full': step_full}[args.mode]
     host_ms, exec_stages, launches = [], [], []
 
@@ -661,8 +681,11 @@ def _run(args, rank, world, dev):
         return nv, dt_, tm
 
     def check_status():
-        bad = int(torch.stack([t.reshape(()) for t in pending_status]).max()) if pending_status else 0
-        assert bad == 0, 'a kernel reported a data-dependent error (status %d)' % bad
+        bad = 0
+        if pending_status:
+            for v in torch.stack([t.reshape(()) for t in pending_status]).tolist():       # ONE host read
+                bad |= int(v)
+        _hip.raise_on_status(bad)
         del pending_status[:]
 
     def conv_roofline(tm, run, math=None):
@@ -921,6 +944,8 @@ def _run(args, rank, world, dev):
             out['allreduce_ms_per_call'] = bucket.collective_ms()
         if alt:
             out['alt_modes'] = alt
+        if fingerprint is not None:
+            out['gradient_fingerprint'] = fingerprint
         if world == 1 and not args.no_cpu_baseline:
             del model, batch
             torch.cuda.empty_cache()

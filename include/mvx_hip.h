@@ -133,6 +133,11 @@ int mvx_tuning_set(int32_t key, int64_t value);
 int mvx_split_operand_amax(const float *amax_a, const float *amax_b);
 /* amax[0] = max(amax[0], max |x[i]|), i < n; amax is zeroed first unless MVX_FLAG_PREZEROED.  x 16-byte aligned. */
 int mvx_tensor_amax(const float *x, int64_t n, float *amax, int32_t flags, void *stream);
+/* Range guard of the fp16-piece arithmetic: weights are cut times 2^8, so |w| must stay below 65504 / 256 = 255.9.
+ * status[0] |= MVX_STATUS_F16_WEIGHT_RANGE when an element of w (f32 [n]) does not (or is not finite); status is a device
+ * word the caller checks with its other data-dependent status words (once per step: no host read inside the step). */
+#define MVX_STATUS_F16_WEIGHT_RANGE 8
+int mvx_split_f16_weight_check(const float *w, int64_t n, int32_t *status, void *stream);
 /* Diagnostics: number of kernel launches the library has issued since it was loaded (fills excluded). */
 uint64_t mvx_launch_count(void);
 

@@ -434,6 +434,28 @@ extern "C" int mvx_tensor_amax(const float *x, int64_t n, float *amax, int32_t f
     return MVX_OK;
 }
 
+// fp16 pieces: a weight is cut times SPLIT_F16_WSCALE = 2^8, so |w| must stay below 65504 / 256 (split_common.h).  One status bit
+// says that a tensor does not: the guard of the fp16x3 arithmetic (modules/_hip.py guard_fp16_weight), checked with the other
+// data-dependent status words once per step.
+__global__ __launch_bounds__(256) void f16_weight_check(const float *__restrict__ w, size_t n, int *__restrict__ status) {
+    bool bad = false;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const float v = fabsf(w[e]);
+        bad |= !(v < 65504.f / SPLIT_F16_WSCALE);            // also true for NaN
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(status, MVX_STATUS_F16_WEIGHT_RANGE);
+}
+
+extern "C" int mvx_split_f16_weight_check(const float *w, int64_t n, int32_t *status, void *stream) {
+    MVX_CHECK_ARG(w && status && n >= 0);
+    if (n == 0) return MVX_OK;
+    const size_t want = ((size_t)n + 255) / 256;
+    hipLaunchKernelGGL(f16_weight_check, dim3((unsigned)(want > 1024 ? 1024 : want)), dim3(256), 0, (hipStream_t)stream, w, (size_t)n,
+                       status);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
 static int bn_relu_backward_impl(const float *dyhat, const float *y, const float *mean_inv, double count,
                                  float *dz, float *dbias, double *scratch, const float *row_w, int64_t rows,
                                  int32_t channels, int32_t flags, const mvx_frames_t *frames_host,

@@ -125,6 +125,7 @@ PROTOTYPES = {
     'mvx_bn_backward_scratch_bytes_frames': (_sz, [_i32, _i32]),
     'mvx_split_operand_amax': (_i32, [_p, _p]),
     'mvx_tensor_amax': (_i32, [_p, _i64, _p, _i32, _p]),
+    'mvx_split_f16_weight_check': (_i32, [_p, _i64, _p, _p]),
     'mvx_bn_relu_backward_frames': (_i32, [_p, _p, _p, _f64, _p, _p, _p, _p, _i64, _i32, _i32, _p, _i32, _p, _p]),
     'mvx_bn_relu_backward_planes_frames': (_i32, [_p, _p, _p, _f64, _p, _p, _p, _p, _i64, _i32, _i32, _p, _i32, _p, _p]),
     'mvx_vfe_bn_max_concat_frames': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p, _p]),

@@ -128,6 +128,47 @@ def mutate(table, name, t):
     return t2
 
 
+# ---- fp16x3: the weight-range guard.  Weights are cut times 2^8 (csrc/split_common.h), so a weight at or above 255.9 would
+# overflow its high fp16 piece into inf -- silently, behind a BatchNorm that hides the scale.  Every weight
+# tensor an fp16x3 kernel is about to read is checked ON THE DEVICE once per parameter version (a tiny kernel; no host read) into
+# a per-device status word that joins the step's other status words (modules/frames.py) and is decoded by raise_on_status:
+# the step that used such a weight is reported, loudly, at its status check.
+STATUS_F16_WEIGHT_RANGE = 8
+_W16_STATUS = {}
+
+
+def fp16_weight_status(device):
+    st = _W16_STATUS.get(device.index)
+    if st is None:
+        st = _W16_STATUS[device.index] = torch.zeros((1,), dtype=torch.int32, device=device)
+    return st
+
+
+def guard_fp16_weight(w):
+    """Range check of a weight tensor for the fp16-piece arithmetic, once per version of the parameter it views."""
+    base = w._base if w._base is not None else w
+    seen = base.__dict__.setdefault('_mvx_w16', {})
+    tag = (base._version, w.data_ptr())
+    if seen.get(tuple(w.shape)) != tag:
+        seen[tuple(w.shape)] = tag
+        wc = w.detach()
+        wc = wc if wc.is_contiguous() else wc.contiguous()
+        X.check(X.lib.mvx_split_f16_weight_check(X.ptr(wc), wc.numel(), X.ptr(fp16_weight_status(w.device)), X.stream()),
+                'mvx_split_f16_weight_check')
+
+
+def raise_on_status(word):
+    """Decode the OR of a step's device status words (one host read by the caller)."""
+    word = int(word)
+    if word & STATUS_F16_WEIGHT_RANGE:
+        raise X.MvxHipError('convmath fp16x3: a weight reached |w| >= 255.9 (or is not finite): its fp16 pieces overflow.  The results '
+                            'of this step are invalid; use convmath bf16x6 (three bf16 pieces: the exponent range of f32)')
+    if word & 1:
+        raise AssertionError('projected point outside the feature map (imhead/Pipe.py:71)')
+    if word:
+        raise X.MvxHipError('a kernel reported a data-dependent error (status %d)' % word)
+
+
 def grad_split(split, dz):
     """Arithmetic of a row GEMM whose operand ``dz`` is a gradient: fp16x3 needs its range (a tag), else bf16x6 stands in (the
     row kernels split both operands in the kernel, so any arithmetic can run any call)."""
@@ -612,6 +653,8 @@ def conv3d_pack(weight, for_dgrad, split=False):
     assert not (two_d and split)
     if split:
         sf = split_flags(split)
+        if int(split) == 4:
+            guard_fp16_weight(weight)
         wpk = torch.empty((X.lib.mvx_conv3d_packed_weight_bytes_split(cout, cin, sf) // 2,), dtype=torch.int16, device=weight.device)
         X.check(X.lib.mvx_conv3d_pack_weights_split(X.ptr(weight.contiguous()), X.ptr(wpk), cout, cin, int(for_dgrad), sf, X.stream()),
                 'mvx_conv3d_pack_weights_split')
@@ -1073,6 +1116,8 @@ def linear_forward(x, w, bias, relu=True, want_stats=True, w_transposed=False, r
     xfl = 0
     if foreign:                                      # x comes from outside the library: foreign_split
         split, xfl = foreign_split(split, x)
+    if split and int(split) == 4:
+        guard_fp16_weight(w)
     if finalize is not None and want_stats and R > 0:
         counter = _fin_slot(x.device, fz)
         if counter is None:

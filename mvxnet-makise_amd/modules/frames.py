@@ -120,6 +120,8 @@ def linear_bn(x, w, b, fs, kind, row_w, eps, tag='fusion', foreign=False):
         return y, mi
     if foreign:
         sp, xfl = _hip.foreign_split(sp, x)
+    if sp and int(sp) == 4:
+        _hip.guard_fp16_weight(w2)                          # fp16x3: |w| < 255.9 (device-side status bit, checked once per step)
     code, sp = sp, _hip.split_flags(sp, True) | xfl
     with _hip._Timed('linear_fwd', 2.0 * Rr * K * N if _hip.KERNEL_TIMERS is not None else 0):
         _hip.bind_amax(code, x)                             # fp16x3: the range tag of a foreign input (the sampled image features)
@@ -300,6 +302,8 @@ def rows_forward(model, fs, fpn_levels, imsize, status_sink, imfeat=None):
     else:
         compact, status = sample_rows(head, fs, fpn_levels, imsize)
     status_sink.append(status)
+    if _hip.split_pieces() == 4:
+        status_sink.append(_hip.fp16_weight_status(dev))    # fp16x3: the weight-range guard's word (modules/_hip.py guard_fp16_weight)
     # ---- fusion MLP (imhead/Pipe.py:84-104) on [real rows | one shared padded row per frame]
     x = compact
     for i, (w, b) in enumerate(head.fusion._layers()):

@@ -92,7 +92,7 @@ def test_bench_two_ranks_share_the_frames_and_print_one_line():
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, MVX_DIST_BACKEND='gloo')
+    env = dict(os.environ, MVX_DIST_BACKEND='gloo', MVX_BENCH_FINGERPRINT='1')
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
                           '127.0.0.1', '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2',
                           '--warmup', '1', '--frames', '2', '--points', '4000', '--timed-only'],
@@ -103,6 +103,21 @@ def test_bench_two_ranks_share_the_frames_and_print_one_line():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['config']['parallelism'] == 'dp2' and d['value'] > 0
     assert abs(d['value'] - 2 * 2 * d['steps'] / (d['ms_per_step'] * d['steps'] * 1e-3)) < 1e-6 * d['value']
+    # the EXCHANGED gradients are right, not only "a number was printed".  Rank 0 ran frames {0, 2}, rank 1 {1, 3};
+    # the two-part exchange ([early | late + count] on the communication / training streams) must leave the mean over the four
+    # frames in the bucket = the mean of the two ranks' buckets run alone as single processes on the same frames.
+    fp2 = d['gradient_fingerprint']
+    assert fp2['exchange'].startswith('two-part') and fp2['frame_ids'] == [0, 2]
+    singles = []
+    for ids in ('0,2', '1,3'):
+        o1 = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--steps', '1', '--warmup', '0', '--frames', '2', '--points',
+                             '4000', '--timed-only', '--frame-ids', ids], capture_output=True, text=True, timeout=600,
+                            env=dict(os.environ, MVX_BENCH_FINGERPRINT='1'), cwd=REPO)
+        assert o1.returncode == 0, o1.stderr[-2000:]
+        singles.append(json.loads([l for l in o1.stdout.splitlines() if l.strip().startswith('{')][0])['gradient_fingerprint'])
+    for key in ('sum', 'probe'):
+        want = 0.5 * (singles[0][key] + singles[1][key])
+        assert abs(fp2[key] - want) <= 1e-5 * max(abs(want), 1e-3 * fp2['norm']), (key, fp2[key], want, fp2['norm'])
 
 
 @pytest.mark.gpu

@@ -217,3 +217,40 @@ def test_foreign_forward_inputs_take_the_coarse_scale_or_bf16x6(golden):
         assert torch.equal(ya * 2.0, yb)
     finally:
         cfg.config['convmath'] = old
+
+
+def test_weight_range_guard_is_loud():
+    """fp16 pieces carry weights times 2^8, so |w| >= 255.9 overflows the high piece -- behind a BatchNorm that
+    would hide it.  Every weight an fp16x3 kernel reads is range-checked on the device (once per parameter version) into a
+    status word; raise_on_status turns it into an error at the step's status check.  The same weight in bf16x6 is fine."""
+    import modules.config as cfg
+    from modules import _hip
+    from modules import Extension as X
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((600, 128), generator=g).to(DEV)
+    w = torch.nn.Parameter((torch.randn((256, 128), generator=g) * 0.1).to(DEV))
+    st = _hip.fp16_weight_status(dev)
+    st.zero_()
+    _hip.linear_forward(x, w, None, relu=False, want_stats=False, split=4)
+    assert int(st) == 0
+    _hip.raise_on_status(int(st))                                  # nothing to report
+    with torch.no_grad():
+        w[3, 5] = 300.0
+    y4, _ = _hip.linear_forward(x, w, None, relu=False, want_stats=False, split=4)
+    assert int(st) & _hip.STATUS_F16_WEIGHT_RANGE
+    assert not bool(torch.isfinite(y4).all())                      # what the guard is about: inf / NaN without any other sign
+    with pytest.raises(X.MvxHipError, match='fp16x3'):
+        _hip.raise_on_status(int(st))
+    st.zero_()
+    y6, _ = _hip.linear_forward(x, w, None, relu=False, want_stats=False, split=3)      # bf16 pieces: the range of f32
+    assert int(st) == 0 and rel_err(y6, x.double() @ w.detach().double().t()) < 2e-6
+    # ... and a convolution kernel packed for fp16 pieces
+    wc = torch.nn.Parameter((torch.randn((64, 64, 3, 3, 3), generator=g) * 0.05).to(DEV))
+    _hip.conv3d_pack(wc, False, split=4)
+    assert int(st) == 0
+    with torch.no_grad():
+        wc[1, 2, 0, 1, 2] = -260.0
+    _hip.conv3d_pack(wc, False, split=4)
+    assert int(st) & _hip.STATUS_F16_WEIGHT_RANGE
+    st.zero_()
