@@ -138,9 +138,10 @@ _W16_STATUS = {}
 
 
 def fp16_weight_status(device):
-    st = _W16_STATUS.get(device.index)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _W16_STATUS.get(idx)
     if st is None:
-        st = _W16_STATUS[device.index] = torch.zeros((1,), dtype=torch.int32, device=device)
+        st = _W16_STATUS[idx] = torch.zeros((1,), dtype=torch.int32, device=torch.device('cuda', idx))
     return st
 
 
