@@ -66,10 +66,6 @@ extern "C" {
                                   (mvx_bn_apply_tiles_frames, mvx_bn_relu_backward_tiles_frames) never read; the BatchNorm sums count them
                                   in closed form either way */
 
-#define MVX_FLAG_SUMS_READY 256 /* mvx_bn_relu_backward_frames: `scratch` already holds (sum dyhat, sum dyhat * yhat) of every frame, accumulated by
-                                  the kernel that PRODUCED dyhat (mvx_linear_dgrad_bnsums_frames, mvx_conv2d_dgrad_split_bnsums_frames): the
-                                  reduction pass is not run */
-
 #define MVX_OK 0
 #define MVX_EINVAL (-1)   /* bad argument (null pointer, size, unsupported combination) */
 #define MVX_ESIZE (-2)    /* a size exceeds what the kernel supports */
@@ -396,12 +392,6 @@ int mvx_conv2d_forward_split_frames(const float *in, const void *wsplit, const f
                                     void *stream);
 int mvx_conv2d_dgrad_split_frames(const float *dz, const void *wsplit_dgrad, float *dx, int32_t h, int32_t w, int32_t cin,
                                   int32_t cout, int32_t flags, int32_t n_frames, void *stream);
-/* ... with the BatchNorm-backward reduction of the layer BELOW folded into the epilogue (stride-1 layers; modules/layers/Blocks.py:
- * 31-40 backward): dx is that layer's dL/dyhat, bn_y [n_frames][h][w][cin] / bn_mean_inv [n_frames][2][cin] its saved pre-BN output
- * and statistics, bn_scratch the scratch of its mvx_bn_relu_backward_frames call (then run with MVX_FLAG_SUMS_READY) */
-int mvx_conv2d_dgrad_split_bnsums_frames(const float *dz, const void *wsplit_dgrad, float *dx, int32_t h, int32_t w, int32_t cin,
-                                         int32_t cout, int32_t flags, const float *bn_y, const float *bn_mean_inv,
-                                         double *bn_scratch, int32_t n_frames, void *stream);
 size_t mvx_conv2d_wgrad_split_workspace_bytes_frames(int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t n_frames);
 int mvx_conv2d_wgrad_split_frames(const float *in, const float *dz, float *dw3, int32_t h, int32_t w, int32_t cin,
                                   int32_t cout, int32_t flags, void *workspace, size_t workspace_bytes, int32_t n_frames,
@@ -437,15 +427,6 @@ int mvx_linear_forward(const float *x, int32_t ldx, const float *w, int32_t ldw,
                        const float *bias, float *y, int32_t ldy, double *stats, const float *row_w,
                        int64_t rows, int32_t k, int32_t n, int32_t flags, void *splitk_workspace,
                        size_t splitk_workspace_bytes, void *stream);
-/* Input gradient of a row layer (dx = dz . w, w given row-major as [n][k] with n = columns of dx) with the BatchNorm-backward
- * REDUCTION of the layer below folded into the epilogue (modules/layers/Blocks.py:5-18 backward: Linear <- ReLU <- BN): dx is
- * that layer's dL/dyhat, bn_y / bn_mean_inv its saved pre-BN output [rows][ld_bn_y] and statistics [F][2][n], bn_scratch the
- * scratch of its mvx_bn_relu_backward_frames call, which then runs with MVX_FLAG_SUMS_READY.  Split arithmetic only
- * (MVX_FLAG_SPLIT [| MVX_FLAG_SPLIT3], n > 64, 16-byte aligned operands); otherwise MVX_EINVAL and nothing is launched. */
-int mvx_linear_dgrad_bnsums_frames(const float *dz, int32_t lddz, const float *w, int32_t ldw, float *dx, int32_t lddx,
-                                   int64_t rows, int32_t k, int32_t n, int32_t flags, const float *bn_y, int32_t ld_bn_y,
-                                   const float *bn_mean_inv, double *bn_scratch, const mvx_frames_t *frames_host,
-                                   int32_t row_kind, void *stream);
 size_t mvx_linear_wgrad_workspace_bytes(int64_t rows, int32_t k, int32_t n);
 
 /* ------------------------------------------------------------------------------------------

@@ -193,21 +193,6 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const float *__restrict__ d
     }
 }
 
-// (a, b) of every frame and channel from sums a producer's epilogue filled (MVX_FLAG_SUMS_READY): one workgroup
-__global__ __launch_bounds__(256) void bn_bwd_ab(const double *__restrict__ sums, int C, FrameMap fm, float *__restrict__ ab,
-                                                 unsigned *__restrict__ amax_slot) {
-    if (amax_slot && threadIdx.x == 0) *amax_slot = 0u;
-    for (int e = threadIdx.x; e < C * fm.F; e += blockDim.x) {
-        const int f = e / C, c = e - f * C;
-        const double *fs = sums + (size_t)f * REP * 3 * C;
-        double sa = 0.0, sb = 0.0;
-        for (int rp = 0; rp < REP; ++rp) { sa += fs[((size_t)rp * 3 + 0) * C + c]; sb += fs[((size_t)rp * 3 + 1) * C + c]; }
-        const double count = fm.count[f];
-        ab[(size_t)f * 2 * C + c] = (float)(sa / count);
-        ab[(size_t)f * 2 * C + C + c] = (float)(sb / count);
-    }
-}
-
 // backward, pass 2: dz = (y > 0) ? inv * (dyh - s1/N - yhat * s2/N) : 0 ; dbias[c] += sum dz (over ALL frames)
 // PL (compile time): dz is written as THREE PLANES of bf16 pieces (u16 [3][rows][C]: hi + mid + lo = dz exactly,
 // split_common.h) instead of f32 -- the operand format of the weight gradient on pre-cut operands (rowgemm_pre.hip), for a layer
@@ -467,7 +452,7 @@ static int bn_relu_backward_impl(const float *dyhat, const float *y, const float
     MVX_CHECK_ARG(mvx_build_frame_map(fm, frames_host, row_kind, rows, count));
     hipStream_t st = (hipStream_t)stream;
     const size_t slots = (size_t)REP * 3 * channels * fm.F;
-    if (!(flags & (MVX_FLAG_PREZEROED | MVX_FLAG_SUMS_READY))) {
+    if (!(flags & MVX_FLAG_PREZEROED)) {
         hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * (slots + 2), st);
         if (e != hipSuccess) return (int)e;
     }
@@ -481,10 +466,7 @@ static int bn_relu_backward_impl(const float *dyhat, const float *y, const float
         const unsigned blocks = (unsigned)(((size_t)rows + rpb - 1) / rpb);
         unsigned *counters = (unsigned *)(scratch + slots);           // [0] pass 2 (bias gradient), [1] pass 1 ((a, b) finalisation)
         float *ab = (float *)(scratch + slots + 2);
-        if (flags & MVX_FLAG_SUMS_READY)      // the producer of dyhat accumulated (sum g, sum g yhat) in its epilogue
-            hipLaunchKernelGGL(bn_bwd_ab, dim3(1), dim3(256), 0, st, (const double *)scratch, channels, fm, ab, (unsigned *)dz_amax);
-        else
-            hipLaunchKernelGGL(bn_bwd_reduce<BWD_TRIP>, dim3(blocks), dim3(256), 0, st, dyhat, y, mean_inv, scratch, (size_t)rows,
+        hipLaunchKernelGGL(bn_bwd_reduce<BWD_TRIP>, dim3(blocks), dim3(256), 0, st, dyhat, y, mean_inv, scratch, (size_t)rows,
                                channels, rpb, fm, counters + 1, ab, (unsigned *)dz_amax);
         MVX_LAUNCH_CHECK();
         if (planes)
@@ -522,7 +504,7 @@ extern "C" int mvx_bn_relu_backward_planes_frames(const float *dyhat, const floa
                                                   void *dz_planes, float *dbias, double *scratch, const float *row_w, int64_t rows,
                                                   int32_t channels, int32_t flags, const mvx_frames_t *frames_host,
                                                   int32_t row_kind, float *dz_amax, void *stream) {
-    MVX_CHECK_ARG((((uintptr_t)dz_planes) & 15) == 0 && !(flags & MVX_FLAG_SUMS_READY));
+    MVX_CHECK_ARG((((uintptr_t)dz_planes) & 15) == 0);
     return bn_relu_backward_impl(dyhat, y, mean_inv, count, (float *)dz_planes, dbias, scratch, row_w, rows, channels, flags,
                                  frames_host, row_kind, dz_amax, stream, true);
 }

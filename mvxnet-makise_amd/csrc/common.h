@@ -47,8 +47,7 @@ static inline int mvx_split_code(int flags) { return (flags & MVX_FLAG_SPLIT_F16
 int mvxi_linear_forward_split(const float *x, int ldx, const float *w, int ldw, const float *bias, float *y,
                               int ldy, double *stats, const float *row_w, long long rows, int k, int n, int relu,
                               unsigned *fin_counter, double fin_eps, float *fin_mean_inv, const FrameMap &fm, int pieces,
-                              hipStream_t st, const float *bn_y = nullptr, int bn_ldy = 0, const float *bn_mi = nullptr,
-                              const SplitAmax &am = SplitAmax{nullptr, nullptr, 0});
+                              hipStream_t st, const SplitAmax &am = SplitAmax{nullptr, nullptr, 0});
 int mvxi_linear_wgrad_split(const float *x, int ldx, const float *dz, int lddz, float *slabs, long long rows, int k, int n,
                             long long rows_per_strip, long long strips, int pieces, hipStream_t st,
                             const SplitAmax &am = SplitAmax{nullptr, nullptr, 0});

@@ -117,16 +117,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_splitT(const float *__re
                                                                const float *__restrict__ bg_pre, int border_active,
                                                                const int *__restrict__ only_tiles,
                                                                unsigned long long *__restrict__ exec_stages,
-                                                               const float *__restrict__ bn_y, const float *__restrict__ bn_mi,
                                                                const float *__restrict__ in_amax) {
     // fp16 pieces (FMT = 1, split_common.h): `in` is scaled by a_scale (from its bound amax, else 1), the weights were packed
     // times SPLIT_F16_WSCALE; the accumulators are scaled back before the epilogue
     float a_scale = 1.f;
     if constexpr (FMT == 1) a_scale = split_scale_of(in_amax);
-    // bn_y != NULL (dense input-gradient launches): the output is dL/dyhat of the BatchNorm-ed layer whose pre-BN output is bn_y
-    // ([planes][H][W][Cout], mean / inverse std bn_mi [F][2][Cout]); `stats` is then that layer's BatchNorm-BACKWARD accumulator
-    // [F][REP][3][Cout] and takes sum g and sum g * yhat -- the reduction pass of mvx_bn_relu_backward_frames
-    // (MVX_FLAG_SUMS_READY) from the tile in registers, for one extra read of bn_y in the epilogue
     constexpr int THT = TH * MT, HHT = THT + 2;
     constexpr int ROWBT = NP * BKT * 2 + 16;                 // bytes per LDS row
     constexpr int HROW = (HW * ROWBT + 255) / 256 * 256;     // halo row pitch
@@ -427,21 +422,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_splitT(const float *__re
 #pragma unroll
             for (int r = 0; r < 16; ++r) site_on |= (mk[r] ? 1u : 0u) << r;
         }
-        float yh0[16], yh1[16];                          // yhat of the BatchNorm-backward sums (loads first, clamped addresses)
-        if (bn_y) {
-            const float *fmi = bn_mi + (size_t)(d / g.Dout) * 2 * g.Cout;
-            const float m0 = fmi[n0], m1 = fmi[n1], i0 = fmi[g.Cout + n0], i1 = fmi[g.Cout + n1];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int gy = min(py + (row >> 4), g.H - 1), gx = min(tx0 + (row & 15), g.W - 1);
-                const float *yp = bn_y + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout;
-                yh0[r] = yp[n0];
-                yh1[r] = yp[n1];
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { yh0[r] = (yh0[r] - m0) * i0; yh1[r] = (yh1[r] - m1) * i1; }
-        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -453,8 +433,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_splitT(const float *__re
                 float *o = out + (((size_t)d * g.H + gy) * g.W + gx) * g.Cout;
                 o[n0] = v0;
                 o[n1] = v1;
-                s1a += v0; s2a += v0 * (bn_y ? yh0[r] : v0);
-                s1b += v1; s2b += v1 * (bn_y ? yh1[r] : v1);
+                s1a += v0; s2a += v0 * v0;
+                s1b += v1; s2b += v1 * v1;
             }
         }
     }
@@ -471,9 +451,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_gather_splitT(const float *__re
             const double t = (double)s_red[0][tid] + (double)s_red[1][tid] + (double)s_red[2][tid] + (double)s_red[3][tid];
             const int which = tid / BN, c = tid % BN;
             const unsigned rep = (blockIdx.x + blockIdx.y * gridDim.x) % MVX_REP;
-            const int sst = bn_y ? 3 : 2;             // slots per replica: (sum, sum of squares) or (sum g, sum g yhat, dbias)
-            double *fstats = stats + (size_t)(d / g.Dout) * MVX_REP * sst * g.Cout;     // the plane's frame
-            atomicAdd(fstats + ((size_t)rep * sst + which) * g.Cout + nb * BN + c, t);
+            double *fstats = stats + (size_t)(d / g.Dout) * MVX_REP * 2 * g.Cout;       // the plane's frame
+            atomicAdd(fstats + ((size_t)rep * 2 + which) * g.Cout + nb * BN + c, t);
         }
     }
 }
@@ -492,7 +471,7 @@ extern "C" int mvx_tuning_set(int32_t key, int64_t value) {
 static void launch_gather_split(hipStream_t st, int flags, int planes, int nblocks, const float *in, const unsigned short *wsp,
                                 const float *bias, float *out, double *stats, const Geom &g, int relu, const int *in_hflag,
                                 const unsigned char *out_mask, const float *bg_pre, int border_active, const int *only_tiles,
-                                unsigned long long *exec_stages, const float *bn_y = nullptr, const float *bn_mi = nullptr) {
+                                unsigned long long *exec_stages) {
     const int tiles_x = (int)mvx_cdiv(g.W, TW);
     const long long units16 = (long long)tiles_x * mvx_cdiv(g.H, TH2) * planes * nblocks;
     const bool big = units16 >= g_split16_min_units;
@@ -504,10 +483,10 @@ static void launch_gather_split(hipStream_t st, int flags, int planes, int nbloc
     do {                                                                                                                             \
         if (win)                                                                                                                     \
             hipLaunchKernelGGL((conv3d_gather_splitT<NP_, BK_, MT_, true, F_>), grid, dim3(256), 0, st, in, wsp, bias, out, stats, g,    \
-                               relu, in_hflag, out_mask, bg_pre, border_active, only_tiles, exec_stages, bn_y, bn_mi, am.a);         \
+                               relu, in_hflag, out_mask, bg_pre, border_active, only_tiles, exec_stages, am.a);         \
         else                                                                                                                         \
             hipLaunchKernelGGL((conv3d_gather_splitT<NP_, BK_, MT_, false, F_>), grid, dim3(256), 0, st, in, wsp, bias, out, stats, g,   \
-                               relu, in_hflag, out_mask, bg_pre, border_active, only_tiles, exec_stages, bn_y, bn_mi, am.a);         \
+                               relu, in_hflag, out_mask, bg_pre, border_active, only_tiles, exec_stages, am.a);         \
     } while (0)
     if (flags & MVX_FLAG_SPLIT_F16) { if (big) MVX_GO(2, 32, 2, 1); else MVX_GO(2, 32, 1, 1); }
     else if (np == 3) { if (big) MVX_GO(3, 16, 2, 0); else MVX_GO(3, 32, 1, 0); }
@@ -954,32 +933,11 @@ extern "C" int mvx_conv2d_dgrad_split_frames(const float *dz, const void *wsplit
     return launch_dgrad_split(dz, wsplit_dgrad, dx, 1, 1, h, w, cin, cout, 1, 1, flags, nullptr, nullptr, n_frames, stream);
 }
 
-// Input gradient of a stride-1 3x3 layer with the BatchNorm-backward reduction of the layer BELOW folded into the epilogue: dx
-// is that layer's dL/dyhat; bn_y / bn_mean_inv its saved pre-BN output [n_frames][h][w][cin] and statistics [n_frames][2][cin];
-// bn_scratch the scratch of its mvx_bn_relu_backward_frames call, which then runs with MVX_FLAG_SUMS_READY.
-extern "C" int mvx_conv2d_dgrad_split_bnsums_frames(const float *dz, const void *wsplit_dgrad, float *dx, int32_t h, int32_t w,
-                                                    int32_t cin, int32_t cout, int32_t flags, const float *bn_y,
-                                                    const float *bn_mean_inv, double *bn_scratch, int32_t n_frames, void *stream) {
-    MVX_CHECK_ARG(dz && wsplit_dgrad && dx && bn_y && bn_mean_inv && bn_scratch);
-    MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES && !(flags & MVX_FLAG_TAPS2));
-    int rc = check_geom(1, 1, h, w, cout, cin, 1, 1);
-    if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    if (!(flags & MVX_FLAG_PREZEROED)) {
-        hipError_t e = hipMemsetAsync(bn_scratch, 0, mvx_bn_backward_scratch_bytes_frames(cin, n_frames), st);
-        if (e != hipSuccess) return (int)e;
-    }
-    Geom g{1, 1, h, w, cout, cin, 1, 1, 1, n_frames};
-    launch_gather_split(st, flags, n_frames, cin / BN, dz, (const unsigned short *)wsplit_dgrad, nullptr, dx, bn_scratch, g,
-                        0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, bn_y, bn_mean_inv);
-    MVX_LAUNCH_CHECK();
-    return MVX_OK;
-}
-
 static int conv2d_wgrad_split_strips(int cin) {
     const int s = 256 / (cin / BK);                 // one depth tap carries work: 256 workgroups per 64-channel block of dz
     return s < 1 ? 1 : (s > 64 ? 64 : s);
 }
+
 
 extern "C" size_t mvx_conv2d_wgrad_split_workspace_bytes_frames(int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t n_frames) {
     if (h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || cin % BK || cout % BN || n_frames <= 0) return 0;

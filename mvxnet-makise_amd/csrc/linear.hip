@@ -434,7 +434,7 @@ static int linear_forward_impl(const float *x, int32_t ldx, const float *w, int3
     }
     if ((flags & MVX_FLAG_SPLIT) && vec && wide && splits == 1 && !w_transposed)    // bf16x3 arithmetic for the wide layers
         return mvxi_linear_forward_split(x, ldx, w, ldw, bias, y, ldy, stats, row_w, (long long)rows, k, n, relu, fin_counter,
-                                         fin_eps, fin_mean_inv, fm, mvx_split_code(flags), st, nullptr, 0, nullptr, am);
+                                         fin_eps, fin_mean_inv, fm, mvx_split_code(flags), st, am);
     const dim3 grid(mvx_cdiv(n, wide ? 128 : 64), mvx_cdiv(rows, BM), splits);
 #define MVX_LAUNCH_LIN(WT, NT, VEC)                                                                               \
     hipLaunchKernelGGL((linear_fwd<WT, NT, VEC>), grid, dim3(256), 0, st, x, ldx, w, ldw, bias, ydst, ld_dst, stats, \
@@ -493,31 +493,6 @@ extern "C" int mvx_linear_forward_bn_frames(const float *x, int32_t ldx, const f
     }
     return linear_forward_impl(x, ldx, w, ldw, w_transposed, bias, y, ldy, stats, row_w, rows, k, n, flags, nullptr, 0,
                                done_counter, 1.0, eps, mean_inv, frames_host, row_kind, stream);
-}
-
-// Input gradient of a row layer, dx = dz w^T-form product (w row-major [n][k], n = columns of dx), with the BatchNorm-backward
-// reduction of the PREVIOUS layer folded into the epilogue: dx is that layer's dL/dyhat, `bn_y` / `bn_mean_inv` its saved pre-BN
-// output and statistics, `bn_scratch` the scratch of its mvx_bn_relu_backward_frames call, which then runs with
-// MVX_FLAG_SUMS_READY (no reduction pass).  Split arithmetic only (MVX_FLAG_SPLIT [| MVX_FLAG_SPLIT3]) and shapes the split
-// kernel takes (n > 64, 16-byte aligned operands): anything else returns MVX_EINVAL and the caller uses the two-call form.
-extern "C" int mvx_linear_dgrad_bnsums_frames(const float *dz, int32_t lddz, const float *w, int32_t ldw, float *dx, int32_t lddx,
-                                              int64_t rows, int32_t k, int32_t n, int32_t flags, const float *bn_y, int32_t ld_bn_y,
-                                              const float *bn_mean_inv, double *bn_scratch, const mvx_frames_t *frames_host,
-                                              int32_t row_kind, void *stream) {
-    const SplitAmax am = mvxi_take_split_amax();
-    MVX_CHECK_ARG(dz && w && dx && bn_y && bn_mean_inv && bn_scratch && rows > 0 && k > 0 && n > 64 && lddz >= k && lddx >= n &&
-                  ldw >= k && ld_bn_y >= n);
-    MVX_CHECK_ARG(flags & MVX_FLAG_SPLIT);
-    MVX_CHECK_ARG(aligned16(dz) && aligned16(w) && lddz % 4 == 0 && ldw % 4 == 0 && k % 4 == 0);
-    hipStream_t st = (hipStream_t)stream;
-    FrameMap fm;
-    MVX_CHECK_ARG(mvx_build_frame_map(fm, frames_host, row_kind, rows, 1.0));
-    if (!(flags & MVX_FLAG_PREZEROED)) {
-        hipError_t e = hipMemsetAsync(bn_scratch, 0, mvx_bn_backward_scratch_bytes_frames(n, fm.F), st);
-        if (e != hipSuccess) return (int)e;
-    }
-    return mvxi_linear_forward_split(dz, lddz, w, ldw, nullptr, dx, lddx, bn_scratch, nullptr, (long long)rows, k, n, 0, nullptr, 0.0,
-                                     nullptr, fm, mvx_split_code(flags), st, bn_y, ld_bn_y, bn_mean_inv, am);
 }
 
 extern "C" size_t mvx_linear_wgrad_workspace_bytes(int64_t rows, int32_t k, int32_t n) {

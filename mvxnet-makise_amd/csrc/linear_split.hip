@@ -39,15 +39,14 @@ __device__ __forceinline__ XcdTile xcd_tile(unsigned h, unsigned nbx, unsigned n
 static inline unsigned xcd_grid(unsigned nbx, unsigned nby) { return 8u * ((nby + 7u) / 8u) * nbx; }
 
 // NP pieces per operand; K in chunks of BK (64 for bf16x3, 32 for bf16x6: 61 KB of LDS either way, two workgroups per CU)
-template <int NP, int BK, bool BNB, int FMT>
+template <int NP, int BK, int FMT>
 __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restrict__ x, int ldx, const float *__restrict__ w,
                                                         int ldw, const float *__restrict__ bias, float *__restrict__ y,
                                                         int ldy, double *__restrict__ stats, const float *__restrict__ row_w,
                                                         long long R, int K, int N, int relu,
                                                         unsigned *__restrict__ done_counter, double fin_eps,
                                                         float *__restrict__ fin_mean_inv, FrameMap fm,
-                                                        const float *__restrict__ bn_y, int bn_ldy,
-                                                        const float *__restrict__ bn_mi, const float *__restrict__ x_amax, int x_coarse,
+                                                        const float *__restrict__ x_amax, int x_coarse,
                                                         unsigned nbx, unsigned nby) {
     const XcdTile tile = xcd_tile(blockIdx.x, nbx, nby);
     if (!tile.on) return;
@@ -55,10 +54,6 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
     // accumulators are scaled back in front of the epilogue
     float x_scale = 1.f;
     if constexpr (FMT == 1) x_scale = x_coarse ? split_scale_coarse(x_amax) : split_scale_of(x_amax);
-    // BNB (compile time; input-gradient GEMMs, bn_y != NULL): the rows written are dL/dyhat of the BatchNorm-ed layer whose pre-BN output is bn_y
-    // (mean / inverse std bn_mi [F][2][N]); `stats` is then that layer's BatchNorm-BACKWARD accumulator [F][REP][3][N] and takes
-    // sum g and sum g * yhat per frame -- the reduction pass of mvx_bn_relu_backward_frames (MVX_FLAG_SUMS_READY) from the tile
-    // in registers, at the price of one read of bn_y in the epilogue instead of a pass over both tensors
     constexpr int ROWB = NP * BK * 2 + 16;         // LDS row: NP pieces of BK bf16 + 16 B pad (an odd number of 16-byte slots)
     constexpr int PQ = BK / 4;                     // float4 per row and chunk
     constexpr int XV = BM * BK / 4 / 256;          // float4 per thread for the x tile
@@ -203,20 +198,7 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int c = n0 + t * 32 + li;
-                const int cc = c < N ? c : N - 1;
                 s1[t] = 0.0; s2[t] = 0.0;
-                float mch = 0.f, ich = 1.f;
-                float yv[16];
-                if (BNB) {                                    // all loads of this column first (clamped addresses), then the sums
-                    mch = bn_mi[(size_t)f * 2 * N + cc];
-                    ich = bn_mi[(size_t)f * 2 * N + N + cc];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        const long long gr = r0 + wv * 32 + row;
-                        yv[r] = bn_y[(gr < R ? gr : R - 1) * bn_ldy + cc];
-                    }
-                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -225,9 +207,8 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
                     asm volatile("" : "+v"(v));
                     if (gr < R && c < N && gr >= lo && gr < hi) {
                         const double rw = (double)rwv[r];
-                        const double q = BNB ? (double)((yv[r] - mch) * ich) : (double)v;
                         s1[t] += rw * (double)v;
-                        s2[t] += rw * (double)v * q;
+                        s2[t] += rw * (double)v * (double)v;
                     }
                 }
             }
@@ -238,13 +219,12 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_split(const float *__restri
                 if (lh == 0) { s_red[wv][t * 32 + li] = a; s_red[wv][BNL + t * 32 + li] = b; }
             }
             __syncthreads();
-            const int sst = BNB ? 3 : 2;                   // slots per replica: (sum, sum of squares) or (sum g, sum g yhat, dbias)
-            double *fstats = stats + (size_t)f * MVX_REP * sst * N;
+            double *fstats = stats + (size_t)f * MVX_REP * 2 * N;
             for (int e = tid; e < 2 * BNL; e += 256) {
                 const int which = e / BNL, c = e % BNL;
                 if (n0 + c < N) {
                     const double t = s_red[0][e] + s_red[1][e] + s_red[2][e] + s_red[3][e];
-                    atomicAdd(fstats + ((size_t)(tile.rb % MVX_REP) * sst + which) * N + n0 + c, t);
+                    atomicAdd(fstats + ((size_t)(tile.rb % MVX_REP) * 2 + which) * N + n0 + c, t);
                 }
             }
         }
@@ -404,15 +384,15 @@ int mvxi_linear_wgrad_split(const float *x, int ldx, const float *dz, int lddz, 
 int mvxi_linear_forward_split(const float *x, int ldx, const float *w, int ldw, const float *bias, float *y,
                               int ldy, double *stats, const float *row_w, long long rows, int k, int n, int relu,
                               unsigned *fin_counter, double fin_eps, float *fin_mean_inv, const FrameMap &fm, int pieces,
-                              hipStream_t st, const float *bn_y, int bn_ldy, const float *bn_mi, const SplitAmax &am) {
+                              hipStream_t st, const SplitAmax &am) {
     const unsigned nbx = mvx_cdiv(n, BNL), nby = mvx_cdiv(rows, BM);
     const dim3 grid(xcd_grid(nbx, nby));
-#define MVX_GO(NP_, BK_, B_, F_)                                                                                                     \
-    hipLaunchKernelGGL((linear_fwd_split<NP_, BK_, B_, F_>), grid, dim3(256), 0, st, x, ldx, w, ldw, bias, y, ldy, stats, row_w, rows, k, \
-                       n, relu, fin_counter, fin_eps, fin_mean_inv, fm, bn_y, bn_ldy, bn_mi, am.a, am.coarse_a, nbx, nby)
-    if (pieces == 4)      { if (bn_y) MVX_GO(2, 64, true, 1); else MVX_GO(2, 64, false, 1); }
-    else if (pieces == 3) { if (bn_y) MVX_GO(3, 32, true, 0); else MVX_GO(3, 32, false, 0); }
-    else                  { if (bn_y) MVX_GO(2, 64, true, 0); else MVX_GO(2, 64, false, 0); }
+#define MVX_GO(NP_, BK_, F_)                                                                                                     \
+    hipLaunchKernelGGL((linear_fwd_split<NP_, BK_, F_>), grid, dim3(256), 0, st, x, ldx, w, ldw, bias, y, ldy, stats, row_w, rows, k, \
+                       n, relu, fin_counter, fin_eps, fin_mean_inv, fm, am.a, am.coarse_a, nbx, nby)
+    if (pieces == 4) MVX_GO(2, 64, 1);
+    else if (pieces == 3) MVX_GO(3, 32, 0);
+    else MVX_GO(2, 64, 0);
 #undef MVX_GO
     MVX_LAUNCH_CHECK();
     return MVX_OK;

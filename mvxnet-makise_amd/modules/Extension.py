@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MVX_HIP_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'libmvx_hip.so'))
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _p = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -54,7 +54,6 @@ PROTOTYPES = {
     'mvx_bn_relu_backward': (_i32, [_p, _p, _p, _f64, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     'mvx_linear_splitk_workspace_bytes': (_sz, [_i64, _i32]),
     'mvx_linear_forward': (_i32, [_p, _i32, _p, _i32, _i32, _p, _p, _i32, _p, _p, _i64, _i32, _i32, _i32, _p, _sz, _p]),
-    'mvx_linear_dgrad_bnsums_frames': (_i32, [_p, _i32, _p, _i32, _p, _i32, _i64, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _i32, _p]),
     'mvx_linear_wgrad_workspace_bytes': (_sz, [_i64, _i32, _i32]),
     'mvx_linear_wgrad': (_i32, [_p, _i32, _p, _i32, _p, _i64, _i32, _i32, _i32, _p, _sz, _p]),
     'mvx_split_planes_bytes': (_sz, [_i64, _i32, _i32]),
@@ -108,7 +107,6 @@ PROTOTYPES = {
                                                 _i32, _p]),
     'mvx_conv2d_forward_split_frames': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_conv2d_dgrad_split_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
-    'mvx_conv2d_dgrad_split_bnsums_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p]),
     'mvx_conv2d_wgrad_split_workspace_bytes_frames': (_sz, [_i32, _i32, _i32, _i32, _i32]),
     'mvx_conv2d_wgrad_split_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _sz, _i32, _p]),
     'mvx_plane_tap_sums_workspace_bytes': (_sz, [_i32, _i32]),

@@ -13,7 +13,6 @@ _ws_cache = {}
 STATS_REPLICAS = 32      # MVX_STATS_REPLICAS of include/mvx_hip.h
 FLAG_RELU, FLAG_PREZEROED, FLAG_ACCUMULATE, FLAG_CONV2D = 1, 2, 4, 8      # MVX_FLAG_* of include/mvx_hip.h
 FLAG_SPLIT = 64                                                          # MVX_FLAG_SPLIT: bf16x3 arithmetic of the wide row GEMMs
-FLAG_SUMS_READY = 256                                                    # MVX_FLAG_SUMS_READY: the BatchNorm-backward sums were accumulated by the producer of dyhat
 FLAG_SPLIT3 = 128                                                        # MVX_FLAG_SPLIT3: three bf16 pieces per operand (bf16x6, fp32-grade)
 FLAG_AMAX_COARSE = 1024                                                  # MVX_FLAG_AMAX_COARSE: the bound x is a foreign forward input (8-binade scale steps)
 FLAG_NO_BG_FILL = 2048                                                   # MVX_FLAG_NO_BG_FILL: voxel-free tiles of the sparse conv1 output are not written

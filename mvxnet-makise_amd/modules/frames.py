@@ -144,9 +144,8 @@ def bn_apply(y, mi, fs, kind):
     return out
 
 
-def bn_relu_backward(dyhat, y, mi, fs, kind, row_w, dbias_into, dz=None, sums=None, planes=False):
-    """dz (may alias dyhat); the bias gradient is ADDED to ``dbias_into`` (summed over the frames).  ``sums``: the scratch the
-    producer of ``dyhat`` accumulated the reduction into (rows_dgrad_bnsums): no reduction pass then.  ``planes``: dz is
+def bn_relu_backward(dyhat, y, mi, fs, kind, row_w, dbias_into, dz=None, planes=False):
+    """dz (may alias dyhat); the bias gradient is ADDED to ``dbias_into`` (summed over the frames).  ``planes``: dz is
     written as three planes of bf16 pieces, int16 (3, rows, C), instead of f32 (a layer whose dz only feeds its own weight
     gradient on pre-cut operands: _hip.linear_wgrad_pre)."""
     C = mi.shape[-1]
@@ -165,43 +164,17 @@ def bn_relu_backward(dyhat, y, mi, fs, kind, row_w, dbias_into, dz=None, sums=No
         dz = torch.empty_like(y)
     if ('bn_bwd_rows' if kind != X.ROWS_GRID else 'bn_bwd_grid') in KNOCKOUT:
         return dz
-    if sums is not None:
-        scratch, fz = sums, _hip.FLAG_SUMS_READY
-    else:
-        scratch, fz = _hip._acc_f64((X.lib.mvx_bn_backward_scratch_bytes_frames(C, fs.F) // 8,), y.device)
+    scratch, fz = _hip._acc_f64((X.lib.mvx_bn_backward_scratch_bytes_frames(C, fs.F) // 8,), y.device)
     amax = _hip.new_amax(y.device)
-    with _hip._timed_bytes('bn_relu_backward', (3 if sums is not None else 5) * y.numel() * 4):
+    with _hip._timed_bytes('bn_relu_backward', 5 * y.numel() * 4):
         X.check(X.lib.mvx_bn_relu_backward_frames(X.ptr(dyhat), X.ptr(y), X.ptr(mi), 1.0, X.ptr(dz), X.ptr(dbias_into),
                                                   X.ptr(scratch), X.ptr(row_w), rows, C, _hip.FLAG_ACCUMULATE | fz,
                                                   fs.desc.ref(), kind, X.ptr(amax), X.stream()), 'mvx_bn_relu_backward_frames')
     return _hip.tag_amax(dz, amax)                      # max |dz|: the range the fp16x3 kernels scale dz by
 
 
-# BatchNorm-backward reduction in the epilogue of the producing input-gradient kernel (VERDICT r03 #1a).  Built, tested
-# (tests/test_frames_gpu.py, tests/test_rpn_gpu.py) and measured on MI355X in bf16x6: hot 413.0 vs 418.0 frames/s, full 190.9 vs
-# 190.8 with the separate reduction pass -- the extra read of y in the epilogue of an MFMA kernel on the critical path costs what
-# the HBM-bound pass did beside the side-stream weight gradients.  OFF by default; MVX_BN_SUMS_FUSED=1 switches it on.
-BN_SUMS_FUSED = os.environ.get('MVX_BN_SUMS_FUSED', '0') != '0'
-
-
-def rows_dgrad_bnsums(dz, w2, y_below, mi_below, fs, kind):
-    """dx = dz w2 (the input gradient of a row layer) AND the BatchNorm-backward sums of the layer below -- whose dL/dyhat dx is
-    -- from the output tile in registers (mvx_linear_dgrad_bnsums_frames).  Returns (dx, scratch) or None when the call does not
-    qualify (exact-f32 arithmetic, narrow layer): the caller then uses _rows_dgrad + the reduction pass."""
-    sp = _hip.grad_split(_hip.row_split('dgrad'), dz)
-    N = w2.shape[1]
-    if not (BN_SUMS_FUSED and sp and N > 64 and 'lin_dgrad' not in KNOCKOUT and 'bn_bwd_rows' not in KNOCKOUT):
-        return None
-    wt = _hip.transposed_weight(w2)                     # row-major [N][K']: both operands read along k
-    dx = torch.empty((dz.shape[0], N), dtype=torch.float32, device=dz.device)
-    scratch, fz = _hip._acc_f64((X.lib.mvx_bn_backward_scratch_bytes_frames(N, fs.F) // 8,), dz.device)
-    with _hip._Timed('linear_dgrad', 2.0 * dz.shape[0] * dz.shape[1] * N if _hip.KERNEL_TIMERS is not None else 0):
-        _hip.bind_amax(sp, dz)
-        X.check(X.lib.mvx_linear_dgrad_bnsums_frames(_hip._vptr(dz), _hip._ld(dz), _hip._vptr(wt), _hip._ld(wt), X.ptr(dx), N,
-                                                     dz.shape[0], dz.shape[1], N, _hip.split_flags(sp, True) | fz, X.ptr(y_below),
-                                                     y_below.shape[1], X.ptr(mi_below), X.ptr(scratch), fs.desc.ref(), kind,
-                                                     X.stream()), 'mvx_linear_dgrad_bnsums_frames')
-    return dx, scratch
+# (The BatchNorm-backward reduction folded into the epilogue of the producing input-gradient kernel -- VERDICT r03 #1a, built and
+# measured in round 4: hot 413.0 vs 418.0 frames/s, full 190.9 vs 190.8, its kernel variants spilling -- was removed in round 5.)
 
 
 _GRAD_TARGETS = None        # id(parameter) -> buffer the gradient is ADDED into instead of .grad (a second lane of frame sets)
@@ -744,11 +717,11 @@ def rows_backward(model, S, dfeat):
     X.check(X.lib.mvx_vfe_compact_input_backward_frames(X.ptr(gx), Fc, Rt, Vt, X.ptr(gim), X.ptr(scratch), fs.desc.ref(),
                                                         X.stream()), 'mvx_vfe_compact_input_backward_frames')
     # ---- fusion MLP, last layer first; the sampled features carry no gradient
-    gx, sums = gim, None
+    gx = gim
     for i in range(len(S.fusion) - 1, -1, -1):
         x, w, b, y, mi = S.fusion[i]
         xp = getattr(x, '_mvx_planes', None)
-        if i == 0 and xp is not None and sums is None and _hip.precut_ok(_hip.row_split('wgrad'), x.shape[0], x.shape[1], w.shape[0]):
+        if i == 0 and xp is not None and _hip.precut_ok(_hip.row_split('wgrad'), x.shape[0], x.shape[1], w.shape[0]):
             # the step's last and largest weight gradient on pre-cut operands: the BatchNorm backward writes dz as planes (no other
             # reader: the sampled features carry no gradient), the weight gradient moves both operands by DMA (rowgemm_pre.hip)
             dzp = bn_relu_backward(gx, y, mi, fs, X.ROWS_FUSION, fs.fusion_row_w, _grad_of(b), planes=True)
@@ -756,15 +729,9 @@ def rows_backward(model, S, dfeat):
             if 'lin_wgrad' not in KNOCKOUT:
                 _hip.linear_wgrad_pre(xp, dzp, accumulate_into=_grad_of(w).view(w.shape[0], -1))
             break
-        dz = bn_relu_backward(gx, y, mi, fs, X.ROWS_FUSION, fs.fusion_row_w, _grad_of(b), sums=sums)
+        dz = bn_relu_backward(gx, y, mi, fs, X.ROWS_FUSION, fs.fusion_row_w, _grad_of(b))
         if i == 0:
             _hip.mark_tail(dev)          # the step's last weight gradient follows: everything else of the bucket may go out (parallel.py)
         _linear_wgrad_side(x, dz, w)
         if i > 0:
-            # the input gradient is dL/dyhat of layer i - 1: its BatchNorm-backward sums come out of the same kernel
-            below = S.fusion[i - 1]
-            fused = rows_dgrad_bnsums(dz, w.reshape(w.shape[0], -1), below[3], below[4], fs, X.ROWS_FUSION)
-            if fused is not None:
-                gx, sums = fused
-            else:
-                gx, sums = _rows_dgrad(dz, w.reshape(w.shape[0], -1)), None
+            gx = _rows_dgrad(dz, w.reshape(w.shape[0], -1))          # dL/dyhat of layer i - 1

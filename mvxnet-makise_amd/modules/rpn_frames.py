@@ -172,14 +172,10 @@ def _bn_apply(y, mi, F):
     return out
 
 
-def _bn_bwd(g, y, mi, F, bias, sums=None):
-    """``sums``: the scratch the producer of ``g`` accumulated the reduction into (_dgrad(..., bn_below=...))."""
+def _bn_bwd(g, y, mi, F, bias):
     C = mi.shape[-1]
     dz = torch.empty_like(y)
-    if sums is not None:
-        scratch, fz = sums, _hip.FLAG_SUMS_READY
-    else:
-        scratch, fz = _hip._acc_f64((X.lib.mvx_bn_backward_scratch_bytes_frames(C, F) // 8,), y.device)
+    scratch, fz = _hip._acc_f64((X.lib.mvx_bn_backward_scratch_bytes_frames(C, F) // 8,), y.device)
     amax = _hip.new_amax(y.device)
     X.check(X.lib.mvx_bn_relu_backward_frames(X.ptr(g), X.ptr(y), X.ptr(mi), 1.0, X.ptr(dz), X.ptr(_grad_of(bias)), X.ptr(scratch),
                                               None, y.numel() // C, C, _hip.FLAG_ACCUMULATE | fz, _desc(F).ref(), X.ROWS_GRID,
@@ -192,21 +188,8 @@ def _retag(t, like):
     return _hip.tag_amax(t, _hip.amax_of(like))
 
 
-def _dgrad(dz, wpd, F, h, w, cin, cout, flags, bn_below=None):
-    """``bn_below`` = (y, mean_inv) of the layer whose dL/dyhat this input gradient is: in split arithmetic (stride-1 layers) its
-    BatchNorm-backward sums come out of the same launch; returns (dx, scratch) then, else dx."""
+def _dgrad(dz, wpd, F, h, w, cin, cout, flags):
     dx = torch.empty((F, h, w, cin), dtype=torch.float32, device=dz.device)
-    from modules.frames import BN_SUMS_FUSED
-    if bn_below is not None and BN_SUMS_FUSED and _split() and not (flags & TAPS2):
-        scratch, fz = _hip._acc_f64((X.lib.mvx_bn_backward_scratch_bytes_frames(cin, F) // 8,), dz.device)
-        with _hip._Timed('rpn_conv', 2.0 * F * h * w * cin * cout * 9 if _hip.KERNEL_TIMERS is not None else 0):
-            _hip.bind_amax(_split(), dz)
-            X.check(X.lib.mvx_conv2d_dgrad_split_bnsums_frames(X.ptr(dz), X.ptr(wpd), X.ptr(dx), h, w, cin, cout,
-                                                               _hip.split_flags(_split()) | fz, X.ptr(bn_below[0]), X.ptr(bn_below[1]),
-                                                               X.ptr(scratch), F, X.stream()), 'mvx_conv2d_dgrad_split_bnsums_frames')
-        return dx, scratch
-    if bn_below is not None:
-        return _dgrad(dz, wpd, F, h, w, cin, cout, flags), None
     if _split():
         with _hip._Timed('rpn_conv', 2.0 * F * h * w * cin * cout * (2.25 if flags & TAPS2 else 9) if _hip.KERNEL_TIMERS is not None else 0):
             _hip.bind_amax(_split(), dz)
@@ -391,18 +374,11 @@ def rpn_backward(rpn, S, d_heads):
             wt = m.conv.weight
             h, w, cin, cout = rec['h'], rec['w'], rec['cin'], rec['cout']
             g_up_layer = g
-            dz = _mut('bn_bwd_b%d' % bi, _bn_bwd(g, rec['y'], rec['mi'], F, m.conv.bias, sums=sums))
-            sums = None
+            dz = _mut('bn_bwd_b%d' % bi, _bn_bwd(g, rec['y'], rec['mi'], F, m.conv.bias))
             if rec['kind'] == 's1':
                 _wgrad(rec['x'], dz, F, h, w, cin, cout, 0, into=_grad_of(wt))
                 wpd = pk.get(('s1', rec['bi'], rec['li']), wt, lambda wt=wt: wt, True)
-                # the input gradient is dL/dyhat of the layer below in this block: its BatchNorm-backward sums come out of the
-                # same launch (split arithmetic); a mutated run (tests) keeps the separate reduction pass
-                below = layers[rec['li'] - 1]
-                if not _MUTATE:
-                    g, sums = _dgrad(dz, wpd, F, h, w, cin, cout, 0, bn_below=(below['y'], below['mi']))
-                else:
-                    g = _mut('s1_dgrad_b%d' % bi, _dgrad(dz, wpd, F, h, w, cin, cout, 0))
+                g = _mut('s1_dgrad_b%d' % bi, _dgrad(dz, wpd, F, h, w, cin, cout, 0))
             else:
                 pl, Cf = rec['planes'], rec['cfull']
                 dw2 = _wgrad(rec['x'], dz, F, h, w, cin, cout, TAPS2)

@@ -85,8 +85,7 @@ def test_arithmetic_selection_logic():
     from modules import _hip
     header = open(HEADER).read()
     for name, val in (('MVX_FLAG_SPLIT', _hip.FLAG_SPLIT), ('MVX_FLAG_SPLIT3', _hip.FLAG_SPLIT3), ('MVX_FLAG_SPLIT_F16', _hip.FLAG_SPLIT_F16),
-                      ('MVX_FLAG_AMAX_COARSE', _hip.FLAG_AMAX_COARSE), ('MVX_FLAG_NO_BG_FILL', _hip.FLAG_NO_BG_FILL),
-                      ('MVX_FLAG_SUMS_READY', _hip.FLAG_SUMS_READY)):
+                      ('MVX_FLAG_AMAX_COARSE', _hip.FLAG_AMAX_COARSE), ('MVX_FLAG_NO_BG_FILL', _hip.FLAG_NO_BG_FILL)):
         assert int(_re.search(r'#define %s (\d+)' % name, header).group(1)) == val, name
     assert cfg.config['convmath'] == os.environ.get('MVX_CONVMATH', 'bf16x6')   # the shipped default: operand-exact (config.yml:2 half: False)
     old = cfg.config['convmath']

@@ -227,41 +227,6 @@ def test_batch_prepared_a_step_ahead_with_its_fpn_sampling_gives_the_same_step(g
         assert rel_err(bucket.flat, ref) < 1e-6
 
 
-@pytest.mark.parametrize('math', ['fp16x3', 'bf16x6', 'bf16x3'])
-def test_batchnorm_backward_sums_from_the_producing_kernel(golden, small_cfg, math):
-    """The BatchNorm-backward reduction (sum dyhat, sum dyhat * yhat per frame and channel) accumulated in the epilogue of the
-    kernel that PRODUCES dyhat -- the split row GEMM of the next layer's input gradient (mvx_linear_dgrad_bnsums_frames,
-    MVX_FLAG_SUMS_READY) -- against the separate reduction pass: the same frame-set step both ways, every parameter gradient
-    equal to summation order."""
-    from MVXNet import MVXNet
-    from modules import frames as fr
-    from modules import parallel
-    from modules.pipeline import train_step_frame_set
-    torch.manual_seed(4)
-    model = MVXNet().to(DEV)
-    batch, G = _small_batch(golden, 3)
-    hot = [(k, p) for k, p in model.named_parameters() if p.requires_grad and '.rpn.' not in k]
-    bucket = parallel.GradBucket([p for _, p in hot])
-    imsize = [370.0, 1224.0]
-    old, old_f = small_cfg.config.get('convmath', 'f32'), fr.BN_SUMS_FUSED
-    small_cfg.config['convmath'] = math
-    res = {}
-    try:
-        for fused in (True, False):
-            fr.BN_SUMS_FUSED = fused
-            bucket.zero()
-            train_step_frame_set(model, batch, G, imsize)
-            torch.cuda.synchronize()
-            res[fused] = (bucket.flat.clone(), 0)
-    finally:
-        small_cfg.config['convmath'], fr.BN_SUMS_FUSED = old, old_f
-    off = 0
-    for k, p in hot:
-        a, b = res[True][0][off:off + p.numel()], res[False][0][off:off + p.numel()]
-        off += p.numel()
-        assert float((a - b).norm() / b.norm().clamp_min(1e-30)) < 2e-5, k
-
-
 def test_sampler_forms_the_range_tag_of_the_image_features(golden, small_cfg):
     """fp16x3: frames.sample_rows hands the first fusion layer the sampled FPN features WITH their max |value| -- raised by the
     sampling kernel while it writes the rows (mvx_feature_sample_rows_frames, out_amax), not by a pass over them: the tag is
