@@ -7,22 +7,35 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 mode = sys.argv[2] if len(sys.argv) > 2 else 'hot'
 threads_per_proc = int(sys.argv[3]) if len(sys.argv) > 3 else 0       # e.g. 2 = the share of a rank when 8 ranks run on a 16-thread host
+# points per frame: with a small cloud (e.g. 1500) a step is a few hundred microseconds of GPU work, so that six processes on the ONE
+# card do not back their launch queues up into the probe -- the host probe then measures the host side under contention, which is
+# what a rank with a GPU of its own would see (the Python / ctypes / launch cost of a step does not depend on the tensor sizes)
+points = int(sys.argv[4]) if len(sys.argv) > 4 else 20000
 assert n <= 6
-if threads_per_proc:
-    cpus = sorted(os.sched_getaffinity(0))[:n * threads_per_proc]
-    os.sched_setaffinity(0, cpus)                                        # inherited by the benchmark processes
+all_cpus = sorted(os.sched_getaffinity(0))
+
+
+def pin(k):
+    def f():
+        if threads_per_proc:                                             # process k gets ITS OWN threads_per_proc host threads
+            os.sched_setaffinity(0, all_cpus[k * threads_per_proc:(k + 1) * threads_per_proc])
+    return f
+
+
 t0 = time.time()
-procs = [subprocess.Popen([sys.executable, os.path.join(REPO, 'bench.py'), '--timed-only', '--steps', '6', '--warmup', '2', '--mode', mode],
-                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=REPO) for _ in range(n)]
+procs = [subprocess.Popen([sys.executable, os.path.join(REPO, 'bench.py'), '--timed-only', '--steps', '12', '--warmup', '4', '--mode', mode,
+                           '--points', str(points)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=REPO, preexec_fn=pin(k),
+                          env=dict(os.environ, MVX_CPU_THREADS=str(threads_per_proc or 64), OMP_NUM_THREADS=str(threads_per_proc or 16)))
+         for k in range(n)]
 res = []
 for p in procs:
     out = p.communicate(timeout=900)[0].decode()
     line = [l for l in out.splitlines() if l.startswith('{')]
     res.append(json.loads(line[0]) if line else None)
 ok = [r for r in res if r]
-summary = {'processes': n, 'mode': mode, 'host_threads': len(os.sched_getaffinity(0)), 'wall_s': time.time() - t0,
+summary = {'processes': n, 'mode': mode, 'points': points, 'threads_per_process': threads_per_proc, 'host_threads': len(all_cpus), 'wall_s': time.time() - t0,
            'host_enqueue_ms_per_step': [r['host_enqueue_ms_per_step'] for r in ok],
            'ms_per_step_gpu_shared': [r['ms_per_step'] for r in ok]}
 print(json.dumps(summary))
 os.makedirs(os.path.join(REPO, 'gpurun_out'), exist_ok=True)
-json.dump(summary, open(os.path.join(REPO, 'gpurun_out', 'host_contention_%s_%d.json' % (mode, n)), 'w'), indent=1)
+json.dump(summary, open(os.path.join(REPO, 'gpurun_out', 'host_contention_%s_%d_%dthr_%dpts.json' % (mode, n, threads_per_proc, points)), 'w'), indent=1)
