@@ -110,9 +110,12 @@ int mvx_abi_version(void);
  *                               (default 768), else 8 x 16-site units; 0 = always 16 x 16, a huge value = never
  *   MVX_TUNE_GATHER_NARROW_MAX_UNITS  the f32 gather (conv3d / conv2d forward and dgrad) runs a launch with fewer 64-channel
  *                               workgroup units than this as twice as many 32-channel units; 0 = never, negative (default) = fewer than
- *                               1.5 units per CU, i.e. while the doubled units are all resident at once */
+ *                               1.5 units per CU, i.e. while the doubled units are all resident at once
+ *   MVX_TUNE_ROWGEMM_K128       1 (default): split-arithmetic row layers with k = 128 and n a multiple of 128 run the
+ *                               weights-resident streaming kernel (csrc/rowgemm_k128.hip; same numbers); 0: linear_fwd_split */
 #define MVX_TUNE_SPLIT16_MIN_UNITS 1
 #define MVX_TUNE_GATHER_NARROW_MAX_UNITS 2
+#define MVX_TUNE_ROWGEMM_K128 3
 int mvx_tuning_set(int32_t key, int64_t value);
 
 /* fp16x3 arithmetic (MVX_FLAG_SPLIT_F16): operand ranges.  An fp16 piece pair covers an f32 operand to 2^-22 while the low piece
@@ -453,6 +456,11 @@ int mvx_linear_forward_pre_frames(const void *a_planes, const void *b_planes, co
 size_t mvx_linear_wgrad_pre_workspace_bytes(int64_t rows, int32_t k, int32_t n);
 int mvx_linear_wgrad_pre(const void *x_planes, const void *dz_planes, float *dw, int64_t rows, int32_t k, int32_t n,
                          int32_t flags, float out_scale, void *workspace, size_t workspace_bytes, void *stream);
+/* ... over the rows [row_lo, row_hi) of planes holding plane_rows rows each (workspace of the whole range suffices): the weight
+ * gradient of a row range whose dz planes are already written (mvx_bn_relu_backward_planes_part_frames). */
+int mvx_linear_wgrad_pre_rows(const void *x_planes, const void *dz_planes, float *dw, int64_t plane_rows, int64_t row_lo,
+                              int64_t row_hi, int32_t k, int32_t n, int32_t flags, float out_scale, void *workspace,
+                              size_t workspace_bytes, void *stream);
 int mvx_linear_wgrad(const float *x, int32_t ldx, const float *dz, int32_t lddz, float *dw, int64_t rows,
                      int32_t k, int32_t n, int32_t flags, void *workspace, size_t workspace_bytes, void *stream);
 
@@ -654,6 +662,15 @@ int mvx_bn_relu_backward_planes_frames(const float *dyhat, const float *y, const
                                        float *dbias, double *scratch, const float *row_w, int64_t rows, int32_t channels,
                                        int32_t flags, const mvx_frames_t *frames_host, int32_t row_kind, float *dz_amax,
                                        void *stream);
+/* ... enqueued in nparts calls (part = 0 .. nparts - 1 in this order, same arguments and stream): part 0 runs the reduction pass
+ * over all rows and the apply pass of the first row range, part p > 0 the apply pass of its range; part_rows[0..1] (host) receives
+ * the rows [lo, hi) whose planes this call writes (the ranges tile [0, rows)).  The step's last weight gradient then runs range by
+ * range (mvx_linear_wgrad_pre_rows, side stream) beside the apply pass of the next range instead of after the whole pass.  The bias
+ * gradient is complete after the last part. */
+int mvx_bn_relu_backward_planes_part_frames(const float *dyhat, const float *y, const float *mean_inv, double count,
+                                            void *dz_planes, float *dbias, double *scratch, const float *row_w, int64_t rows,
+                                            int32_t channels, int32_t flags, const mvx_frames_t *frames_host, int32_t row_kind,
+                                            int32_t part, int32_t nparts, int64_t *part_rows, void *stream);
 int mvx_vfe_bn_max_concat_frames(const float *y, const float *mean_inv, float *out, int32_t *argmax, int32_t n_voxels,
                                  int32_t t, int32_t channels, const int32_t *voff, const int32_t *vcnt, int32_t n_real,
                                  const mvx_frames_t *frames_host, void *stream);

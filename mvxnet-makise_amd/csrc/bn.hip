@@ -204,13 +204,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dy
                                                     const float *__restrict__ row_w, size_t rows, int C,
                                                     unsigned *__restrict__ done_counter, float *__restrict__ dbias_out,
                                                     int accumulate, size_t rows_per_block, FrameMap fm,
-                                                    unsigned *__restrict__ amax_slot) {
+                                                    unsigned *__restrict__ amax_slot, unsigned block_base,
+                                                    unsigned total_blocks) {
+    // block_base / total_blocks: the pass may be enqueued in several launches over consecutive block ranges (the consumer of
+    // the first rows starts while the rest is still being written); the bias gradient is folded by the last block of ALL
     __shared__ double red[256][4];
     float mx = 0.f;                                  // max |dz| this thread wrote (-> amax_slot: the fp16-piece kernels scale dz by it)
     const int c4 = C >> 2;
     const int rpi = max(1, 256 / c4);
     const int ct = threadIdx.x % c4, rt = threadIdx.x / c4;
-    const size_t blk_lo = blockIdx.x * rows_per_block;
+    const unsigned gblock = blockIdx.x + block_base;
+    const size_t blk_lo = gblock * rows_per_block;
     const size_t blk_hi = blk_lo + rows_per_block < rows ? blk_lo + rows_per_block : rows;
     const bool live = blk_lo < blk_hi;
     const int s_lo = (fm.F == 1 || !live) ? 0 : fm_seg_of(fm, (long long)blk_lo);
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dy
             __syncthreads();
             if ((int)threadIdx.x < c4)
                 for (int j = 0; j < 4; ++j)
-                    atomicAdd(dbias + (size_t)(blockIdx.x % REP) * 3 * C + col * 4 + j,
+                    atomicAdd(dbias + (size_t)(gblock % REP) * 3 * C + col * 4 + j,
                               (red[ct][j] + red[c4 + ct][j]) + (red[2 * c4 + ct][j] + red[3 * c4 + ct][j]));
             __syncthreads();
         } else if (dbias) {
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dy
                 for (int j = 0; j < 4; ++j) {
                     double t = 0.0;
                     for (int r = 0; r < rpi; ++r) t += red[r * c4 + ct][j];
-                    atomicAdd(dbias + (size_t)(blockIdx.x % REP) * 3 * C + col * 4 + j, t);
+                    atomicAdd(dbias + (size_t)(gblock % REP) * 3 * C + col * 4 + j, t);
                 }
             }
             __syncthreads();
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float *__restrict__ dy
         __shared__ int s_last;
         mvx_drain_vmem();
         __syncthreads();
-        if (threadIdx.x == 0) s_last = (atomicAdd(done_counter, 1u) == gridDim.x - 1u);
+        if (threadIdx.x == 0) s_last = (atomicAdd(done_counter, 1u) == total_blocks - 1u);
         __syncthreads();
         if (s_last) {
             for (int i = threadIdx.x; i < C; i += blockDim.x) {
@@ -444,18 +448,21 @@ extern "C" int mvx_split_f16_weight_check(const float *w, int64_t n, int32_t *st
 static int bn_relu_backward_impl(const float *dyhat, const float *y, const float *mean_inv, double count,
                                  float *dz, float *dbias, double *scratch, const float *row_w, int64_t rows,
                                  int32_t channels, int32_t flags, const mvx_frames_t *frames_host,
-                                 int32_t row_kind, float *dz_amax, void *stream, bool planes) {
+                                 int32_t row_kind, float *dz_amax, void *stream, bool planes, int part = 0, int nparts = 1,
+                                 int64_t *part_rows = nullptr) {
     MVX_CHECK_ARG(dyhat && y && mean_inv && dz && scratch && rows >= 0 && channels > 0 && channels % 4 == 0);
+    MVX_CHECK_ARG(nparts >= 1 && part >= 0 && part < nparts);
     MVX_CHECK_ARG(count > 0);
     MVX_CHECK_ARG(((uintptr_t)scratch & 15) == 0);          // bn_bwd_apply reads the (a, b) floats behind the sums with float4 loads
     FrameMap fm;
     MVX_CHECK_ARG(mvx_build_frame_map(fm, frames_host, row_kind, rows, count));
     hipStream_t st = (hipStream_t)stream;
     const size_t slots = (size_t)REP * 3 * channels * fm.F;
-    if (!(flags & MVX_FLAG_PREZEROED)) {
+    if (!(flags & MVX_FLAG_PREZEROED) && part == 0) {
         hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * (slots + 2), st);
         if (e != hipSuccess) return (int)e;
     }
+    if (part_rows) part_rows[0] = part_rows[1] = 0;
     if (rows > 0) {
         const int rpi = (256 / (channels / 4)) > 1 ? 256 / (channels / 4) : 1;
         // up to 4 workgroups per CU, each with at least two trips of BWD_TRIP x rpi rows
@@ -466,23 +473,34 @@ static int bn_relu_backward_impl(const float *dyhat, const float *y, const float
         const unsigned blocks = (unsigned)(((size_t)rows + rpb - 1) / rpb);
         unsigned *counters = (unsigned *)(scratch + slots);           // [0] pass 2 (bias gradient), [1] pass 1 ((a, b) finalisation)
         float *ab = (float *)(scratch + slots + 2);
-        hipLaunchKernelGGL(bn_bwd_reduce<BWD_TRIP>, dim3(blocks), dim3(256), 0, st, dyhat, y, mean_inv, scratch, (size_t)rows,
+        // the reduction pass covers all rows and belongs to part 0; the apply pass of part p covers the blocks
+        // [blocks p / nparts, blocks (p + 1) / nparts) -- whole blocks, so the parts' row ranges tile [0, rows)
+        const unsigned b_lo = (unsigned)((size_t)blocks * part / nparts), b_hi = (unsigned)((size_t)blocks * (part + 1) / nparts);
+        if (part_rows) {
+            part_rows[0] = (int64_t)((size_t)b_lo * rpb);
+            part_rows[1] = (int64_t)((size_t)b_hi * rpb < (size_t)rows ? (size_t)b_hi * rpb : (size_t)rows);
+        }
+        if (part == 0) {
+            hipLaunchKernelGGL(bn_bwd_reduce<BWD_TRIP>, dim3(blocks), dim3(256), 0, st, dyhat, y, mean_inv, scratch, (size_t)rows,
                                channels, rpb, fm, counters + 1, ab, (unsigned *)dz_amax);
-        MVX_LAUNCH_CHECK();
-        if (planes)
-            hipLaunchKernelGGL((bn_bwd_apply<BWD_TRIP, true>), dim3(blocks), dim3(256), 0, st, dyhat, y, mean_inv, (const float *)ab, dz,
-                               dbias ? scratch + 2 * channels : (double *)nullptr, row_w, (size_t)rows, channels,
-                               counters, dbias, flags & MVX_FLAG_ACCUMULATE, rpb, fm, (unsigned *)dz_amax);
-        else
-            hipLaunchKernelGGL((bn_bwd_apply<BWD_TRIP, false>), dim3(blocks), dim3(256), 0, st, dyhat, y, mean_inv, (const float *)ab, dz,
-                               dbias ? scratch + 2 * channels : (double *)nullptr, row_w, (size_t)rows, channels,
-                               counters, dbias, flags & MVX_FLAG_ACCUMULATE, rpb, fm, (unsigned *)dz_amax);
-        MVX_LAUNCH_CHECK();
+            MVX_LAUNCH_CHECK();
+        }
+        if (b_hi > b_lo) {
+            if (planes)
+                hipLaunchKernelGGL((bn_bwd_apply<BWD_TRIP, true>), dim3(b_hi - b_lo), dim3(256), 0, st, dyhat, y, mean_inv,
+                                   (const float *)ab, dz, dbias ? scratch + 2 * channels : (double *)nullptr, row_w, (size_t)rows,
+                                   channels, counters, dbias, flags & MVX_FLAG_ACCUMULATE, rpb, fm, (unsigned *)dz_amax, b_lo, blocks);
+            else
+                hipLaunchKernelGGL((bn_bwd_apply<BWD_TRIP, false>), dim3(b_hi - b_lo), dim3(256), 0, st, dyhat, y, mean_inv,
+                                   (const float *)ab, dz, dbias ? scratch + 2 * channels : (double *)nullptr, row_w, (size_t)rows,
+                                   channels, counters, dbias, flags & MVX_FLAG_ACCUMULATE, rpb, fm, (unsigned *)dz_amax, b_lo, blocks);
+            MVX_LAUNCH_CHECK();
+        }
     } else if (dz_amax) {
         hipError_t e = hipMemsetAsync(dz_amax, 0, sizeof(float), st);
         if (e != hipSuccess) return (int)e;
     }
-    if (rows <= 0 && dbias) {                       // no rows: the bias gradient is zero
+    if (rows <= 0 && dbias && part == 0) {          // no rows: the bias gradient is zero
         hipLaunchKernelGGL(dbias_finish, dim3(mvx_cdiv(channels, 128)), dim3(128), 0, st, (const double *)scratch, dbias,
                            channels, flags & MVX_FLAG_ACCUMULATE);
         MVX_LAUNCH_CHECK();
@@ -507,6 +525,20 @@ extern "C" int mvx_bn_relu_backward_planes_frames(const float *dyhat, const floa
     MVX_CHECK_ARG((((uintptr_t)dz_planes) & 15) == 0);
     return bn_relu_backward_impl(dyhat, y, mean_inv, count, (float *)dz_planes, dbias, scratch, row_w, rows, channels, flags,
                                  frames_host, row_kind, dz_amax, stream, true);
+}
+
+// ... enqueued in `nparts` calls (part = 0 .. nparts - 1, in this order, same arguments, same stream): part 0 runs the reduction
+// pass over all rows and the apply pass of the first row range, part p > 0 the apply pass of its range; part_rows[0..1] receives
+// the range [lo, hi) of rows whose planes THIS call writes (the ranges tile [0, rows)).  The weight gradient of the rows of part p
+// (mvx_linear_wgrad_pre_rows) can then run beside the apply pass of part p + 1.  The bias gradient is complete after the last part.
+extern "C" int mvx_bn_relu_backward_planes_part_frames(const float *dyhat, const float *y, const float *mean_inv, double count,
+                                                       void *dz_planes, float *dbias, double *scratch, const float *row_w,
+                                                       int64_t rows, int32_t channels, int32_t flags,
+                                                       const mvx_frames_t *frames_host, int32_t row_kind, int32_t part,
+                                                       int32_t nparts, int64_t *part_rows, void *stream) {
+    MVX_CHECK_ARG((((uintptr_t)dz_planes) & 15) == 0 && part_rows);
+    return bn_relu_backward_impl(dyhat, y, mean_inv, count, (float *)dz_planes, dbias, scratch, row_w, rows, channels, flags,
+                                 frames_host, row_kind, nullptr, stream, true, part, nparts, part_rows);
 }
 
 extern "C" int mvx_bn_relu_backward(const float *dyhat, const float *y, const float *mean_inv, double count,

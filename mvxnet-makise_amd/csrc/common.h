@@ -48,6 +48,12 @@ int mvxi_linear_forward_split(const float *x, int ldx, const float *w, int ldw, 
                               int ldy, double *stats, const float *row_w, long long rows, int k, int n, int relu,
                               unsigned *fin_counter, double fin_eps, float *fin_mean_inv, const FrameMap &fm, int pieces,
                               hipStream_t st, const SplitAmax &am = SplitAmax{nullptr, nullptr, 0});
+// K = 128 (rowgemm_k128.hip): weights resident in LDS, rows streamed through registers; same contract and numbers
+bool mvxi_rowgemm_k128_ok(int ldx, int ldw, int ldy, int k, int n);
+void mvxi_rowgemm_k128_enable(long long v);
+int mvxi_linear_forward_k128(const float *x, int ldx, const float *w, int ldw, const float *bias, float *y, int ldy, double *stats,
+                             const float *row_w, long long rows, int n, int relu, unsigned *fin_counter, double fin_eps,
+                             float *fin_mean_inv, const FrameMap &fm, int pieces, hipStream_t st, const SplitAmax &am);
 int mvxi_linear_wgrad_split(const float *x, int ldx, const float *dz, int lddz, float *slabs, long long rows, int k, int n,
                             long long rows_per_strip, long long strips, int pieces, hipStream_t st,
                             const SplitAmax &am = SplitAmax{nullptr, nullptr, 0});

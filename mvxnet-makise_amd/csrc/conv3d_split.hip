@@ -465,6 +465,7 @@ static long long g_split16_min_units = 768;
 extern "C" int mvx_tuning_set(int32_t key, int64_t value) {
     if (key == MVX_TUNE_SPLIT16_MIN_UNITS) { g_split16_min_units = value; return MVX_OK; }
     if (key == MVX_TUNE_GATHER_NARROW_MAX_UNITS) { mvxi_gather_narrow_max_units(value); return MVX_OK; }
+    if (key == MVX_TUNE_ROWGEMM_K128) { mvxi_rowgemm_k128_enable(value); return MVX_OK; }
     return MVX_EINVAL;
 }
 

@@ -432,6 +432,9 @@ static int linear_forward_impl(const float *x, int32_t ldx, const float *w, int3
         ydst = (float *)splitk_workspace;
         ld_dst = n;
     }
+    if ((flags & MVX_FLAG_SPLIT) && vec && wide && splits == 1 && !w_transposed && mvxi_rowgemm_k128_ok(ldx, ldw, ldy, k, n))
+        return mvxi_linear_forward_k128(x, ldx, w, ldw, bias, y, ldy, stats, row_w, (long long)rows, n, relu, fin_counter, fin_eps,
+                                        fin_mean_inv, fm, mvx_split_code(flags), st, am);
     if ((flags & MVX_FLAG_SPLIT) && vec && wide && splits == 1 && !w_transposed)    // bf16x3 arithmetic for the wide layers
         return mvxi_linear_forward_split(x, ldx, w, ldw, bias, y, ldy, stats, row_w, (long long)rows, k, n, relu, fin_counter,
                                          fin_eps, fin_mean_inv, fm, mvx_split_code(flags), st, am);

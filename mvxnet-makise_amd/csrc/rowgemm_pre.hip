@@ -563,34 +563,53 @@ extern "C" size_t mvx_linear_wgrad_pre_workspace_bytes(int64_t rows, int32_t k, 
     return (size_t)strips * n * k * sizeof(float);
 }
 
-extern "C" int mvx_linear_wgrad_pre(const void *x_planes, const void *dz_planes, float *dw, int64_t rows, int32_t k, int32_t n,
-                                    int32_t flags, float out_scale, void *workspace, size_t workspace_bytes, void *stream) {
+static int wgrad_pre_launch(const unsigned char *x_planes, const unsigned char *dz_planes, float *dw, int64_t plane_rows,
+                            int64_t row_lo, int64_t rows, int32_t k, int32_t n, int32_t flags, float out_scale, void *workspace,
+                            size_t workspace_bytes, void *stream) {
     const int np = pre_pieces(flags);
     MVX_CHECK_ARG(x_planes && dz_planes && dw && workspace && rows > 0 && k > 0 && n > 0 && np != 0);
+    MVX_CHECK_ARG(row_lo >= 0 && row_lo + rows <= plane_rows);
     MVX_CHECK_ARG(k % 32 == 0 && n % 32 == 0 && (((uintptr_t)dw) & 15) == 0 && ((size_t)n * k) % 4 == 0);
-    MVX_CHECK_ARG((size_t)np * rows * k * 2 < (1ull << 32) && (size_t)np * rows * n * 2 < (1ull << 32));
+    MVX_CHECK_ARG((size_t)np * plane_rows * k * 2 < (1ull << 32) && (size_t)np * plane_rows * n * 2 < (1ull << 32));
     long long strips, per;
     pre_wgrad_shape(rows, k, n, strips, per);
     MVX_CHECK_ARG(workspace_bytes >= (size_t)strips * n * k * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
     const unsigned nba = mvx_cdiv(n, PT), nbb = mvx_cdiv(k, PT);
-    const unsigned aps = (unsigned)((size_t)rows * n * 2), bps = (unsigned)((size_t)rows * k * 2);
+    // planes are plane_rows apart; the rows of this call start row_lo into every plane (k, n multiples of 32: 16-byte aligned)
+    const unsigned aps = (unsigned)((size_t)plane_rows * n * 2), bps = (unsigned)((size_t)plane_rows * k * 2);
+    const unsigned short *a = (const unsigned short *)(dz_planes + (size_t)row_lo * n * 2);
+    const unsigned short *b = (const unsigned short *)(x_planes + (size_t)row_lo * k * 2);
     const int order = (flags & MVX_FLAG_PRE_XCD_STRIPS) ? 1 : 0;
     const unsigned nwg = order ? 8u * (unsigned)((strips + 7) / 8) * nba * nbb : (unsigned)strips * nba * nbb;
     if (np == 3)
-        hipLaunchKernelGGL((rowgemm_wgrad_pre<3, 0>), dim3(nwg), dim3(512), 0, st, (const unsigned short *)dz_planes, aps, n,
-                           (const unsigned short *)x_planes, bps, k, (float *)workspace, (long long)rows, n, k, per, nba, nbb,
-                           (unsigned)strips, order);
+        hipLaunchKernelGGL((rowgemm_wgrad_pre<3, 0>), dim3(nwg), dim3(512), 0, st, a, aps, n, b, bps, k, (float *)workspace,
+                           (long long)rows, n, k, per, nba, nbb, (unsigned)strips, order);
     else
-        hipLaunchKernelGGL((rowgemm_wgrad_pre<2, 1>), dim3(nwg), dim3(512), 0, st, (const unsigned short *)dz_planes, aps, n,
-                           (const unsigned short *)x_planes, bps, k, (float *)workspace, (long long)rows, n, k, per, nba, nbb,
-                           (unsigned)strips, order);
+        hipLaunchKernelGGL((rowgemm_wgrad_pre<2, 1>), dim3(nwg), dim3(512), 0, st, a, aps, n, b, bps, k, (float *)workspace,
+                           (long long)rows, n, k, per, nba, nbb, (unsigned)strips, order);
     MVX_LAUNCH_CHECK();
     const size_t total = (size_t)n * k;
     hipLaunchKernelGGL(pre_slab_reduce, dim3((unsigned)(total / 1024 + 1 > 2048 ? 2048 : total / 1024 + 1)), dim3(256), 0, st,
                        (const float *)workspace, dw, total, (int)strips, (flags & MVX_FLAG_ACCUMULATE) ? 1 : 0, out_scale);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
+}
+
+extern "C" int mvx_linear_wgrad_pre(const void *x_planes, const void *dz_planes, float *dw, int64_t rows, int32_t k, int32_t n,
+                                    int32_t flags, float out_scale, void *workspace, size_t workspace_bytes, void *stream) {
+    return wgrad_pre_launch((const unsigned char *)x_planes, (const unsigned char *)dz_planes, dw, rows, 0, rows, k, n, flags,
+                            out_scale, workspace, workspace_bytes, stream);
+}
+
+// The same over the rows [row_lo, row_hi) of planes that hold plane_rows rows each (the workspace of the whole range suffices):
+// the weight gradient of a row range whose dz planes are already written (mvx_bn_relu_backward_planes_part_frames).
+extern "C" int mvx_linear_wgrad_pre_rows(const void *x_planes, const void *dz_planes, float *dw, int64_t plane_rows, int64_t row_lo,
+                                         int64_t row_hi, int32_t k, int32_t n, int32_t flags, float out_scale, void *workspace,
+                                         size_t workspace_bytes, void *stream) {
+    MVX_CHECK_ARG(row_hi > row_lo);
+    return wgrad_pre_launch((const unsigned char *)x_planes, (const unsigned char *)dz_planes, dw, plane_rows, row_lo,
+                            row_hi - row_lo, k, n, flags, out_scale, workspace, workspace_bytes, stream);
 }
 
 // DIAGNOSTIC (tools/stamps_rows_pre.py): the bf16x6 forward with s_memtime stamps of one workgroup; not part of the C ABI header

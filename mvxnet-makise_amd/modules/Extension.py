@@ -61,6 +61,7 @@ PROTOTYPES = {
     'mvx_linear_forward_pre_frames': (_i32, [_p, _p, _p, _p, _i32, _p, _p, _i64, _i32, _i32, _i32, _f32, _p, _f64, _p, _p, _i32, _p]),
     'mvx_linear_wgrad_pre_workspace_bytes': (_sz, [_i64, _i32, _i32]),
     'mvx_linear_wgrad_pre': (_i32, [_p, _p, _p, _i64, _i32, _i32, _i32, _f32, _p, _sz, _p]),
+    'mvx_linear_wgrad_pre_rows': (_i32, [_p, _p, _p, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _p, _sz, _p]),
     'mvx_vfe_bn_max_concat': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p]),
     'mvx_vfe_max_concat_backward': (_i32, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p]),
     'mvx_bn_segment_max': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p]),
@@ -126,6 +127,8 @@ PROTOTYPES = {
     'mvx_split_f16_weight_check': (_i32, [_p, _i64, _p, _p]),
     'mvx_bn_relu_backward_frames': (_i32, [_p, _p, _p, _f64, _p, _p, _p, _p, _i64, _i32, _i32, _p, _i32, _p, _p]),
     'mvx_bn_relu_backward_planes_frames': (_i32, [_p, _p, _p, _f64, _p, _p, _p, _p, _i64, _i32, _i32, _p, _i32, _p, _p]),
+    'mvx_bn_relu_backward_planes_part_frames': (_i32, [_p, _p, _p, _f64, _p, _p, _p, _p, _i64, _i32, _i32, _p, _i32, _i32, _i32, _p,
+                                                       _p]),
     'mvx_vfe_bn_max_concat_frames': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p, _p]),
     'mvx_bn_segment_max_frames': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p, _p]),
     'mvx_voxel_row_offsets_frames': (_i32, [_p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p]),

@@ -209,6 +209,8 @@ def side_stream(device):
 
 if os.environ.get('MVX_SPLIT16_MIN_UNITS'):        # developer knob: launch-shape threshold of the split gather (csrc/conv3d_split.hip)
     X.check(X.lib.mvx_tuning_set(1, int(os.environ['MVX_SPLIT16_MIN_UNITS'])), 'mvx_tuning_set')
+if os.environ.get('MVX_K128'):                     # developer knob (A/B runs): 0 = 128-deep row layers on linear_fwd_split again
+    X.check(X.lib.mvx_tuning_set(3, int(os.environ['MVX_K128'])), 'mvx_tuning_set')
 SIDE_KEEP = os.environ.get('MVX_SIDE_KEEP', '1') != '0'
 _KEEP = {}          # device index -> tensors read by side-stream kernels since the last join
 _COMM = {}
@@ -1030,6 +1032,12 @@ PRECUT = os.environ.get('MVX_PRECUT', '1') != '0'
 # 0.08 ms of a 8.5 ms step in bf16x6 (0.59 vs 0.65 ms for the 768 x 768 layer); the weight gradient (0.43 vs 0.70 ms, the
 # step's tail) has no statistics and is on by default.
 PRECUT_FWD = os.environ.get('MVX_PRECUT_FWD', '0') != '0'
+# Row ranges in which the step's last BatchNorm backward + weight gradient are enqueued (frames.rows_backward): the product of
+# range p runs on the side stream beside the apply pass of range p + 1.  1 = one pass, one product: the default, because the
+# ranges measured SLOWER (same box, bf16x6, 40 steps: 463.7 / 463.1 frames/s in one part, 460.7 / 460.9 in two, 455.4 / 455.3 in
+# four): the main queue's idle end of the step is not an idle chip, the HBM-bound apply pass and the MFMA-bound product slow each
+# other down by more than the overlap hides.
+TAIL_PARTS = max(1, int(os.environ.get('MVX_TAIL_PARTS', '1')))
 
 
 def precut_ok(split, rows, K, N):
@@ -1071,22 +1079,24 @@ def linear_forward_pre(x_planes, w_planes, bias, y, stats, row_w, flags, counter
                 'mvx_linear_forward_pre_frames')
 
 
-def linear_wgrad_pre(x_planes, dz_planes, accumulate_into=None):
-    """dW (N, K) (+)= dz^T x from operand planes (mvx_linear_wgrad_pre); on the side stream like linear_wgrad."""
-    pieces, rows, K = x_planes.shape
+def linear_wgrad_pre(x_planes, dz_planes, accumulate_into=None, rows=None):
+    """dW (N, K) (+)= dz^T x from operand planes (mvx_linear_wgrad_pre); on the side stream like linear_wgrad.  ``rows=(lo, hi)``:
+    only those rows of the planes (mvx_linear_wgrad_pre_rows)."""
+    pieces, plane_rows, K = x_planes.shape
     N = dz_planes.shape[2]
+    lo, hi = rows if rows is not None else (0, plane_rows)
     if accumulate_into is not None:
         assert accumulate_into.is_contiguous() and accumulate_into.numel() == N * K
         dw, flags = accumulate_into, FLAG_ACCUMULATE
     else:
         dw, flags = torch.empty((N, K), dtype=torch.float32, device=x_planes.device), 0
     flags |= split_flags(3 if pieces == 3 else 4, True)
-    nbytes = X.lib.mvx_linear_wgrad_pre_workspace_bytes(rows, K, N)
+    nbytes = max(X.lib.mvx_linear_wgrad_pre_workspace_bytes(plane_rows, K, N), X.lib.mvx_linear_wgrad_pre_workspace_bytes(hi - lo, K, N))
     with _wgrad_scope(accumulate_into, x_planes, dz_planes) as scope:
         ws = workspace(nbytes, x_planes.device, 'lwgrad_pre_side' if isinstance(scope, _SideStream) else 'lwgrad_pre')
-        with _Timed('linear_wgrad', 2.0 * rows * K * N if KERNEL_TIMERS is not None else 0):
-            X.check(X.lib.mvx_linear_wgrad_pre(X.ptr(x_planes), X.ptr(dz_planes), X.ptr(dw), rows, K, N, flags, 1.0, X.ptr(ws),
-                                               ws.numel(), X.stream()), 'mvx_linear_wgrad_pre')
+        with _Timed('linear_wgrad', 2.0 * (hi - lo) * K * N if KERNEL_TIMERS is not None else 0):
+            X.check(X.lib.mvx_linear_wgrad_pre_rows(X.ptr(x_planes), X.ptr(dz_planes), X.ptr(dw), plane_rows, lo, hi, K, N, flags,
+                                                    1.0, X.ptr(ws), ws.numel(), X.stream()), 'mvx_linear_wgrad_pre_rows')
     return None if accumulate_into is not None else dw
 
 

@@ -173,6 +173,30 @@ def bn_relu_backward(dyhat, y, mi, fs, kind, row_w, dbias_into, dz=None, planes=
     return _hip.tag_amax(dz, amax)                      # max |dz|: the range the fp16x3 kernels scale dz by
 
 
+def bn_relu_backward_planes_parts(dyhat, y, mi, fs, kind, row_w, dbias_into, nparts):
+    """Generator form of ``bn_relu_backward(..., planes=True)``: the apply pass is enqueued range by range; every iteration
+    enqueues one part and yields ``(planes, row_lo, row_hi)`` -- the rows whose planes that part writes -- so the caller can
+    put the weight gradient of those rows on the side stream before the next part is enqueued
+    (mvx_bn_relu_backward_planes_part_frames).  The bias gradient is complete after the last part."""
+    import ctypes
+    C = mi.shape[-1]
+    rows = y.numel() // C
+    dzp = torch.empty((3, rows, C), dtype=torch.int16, device=y.device)
+    if 'bn_bwd_rows' in KNOCKOUT:
+        yield dzp, 0, rows
+        return
+    scratch, fz = _hip._acc_f64((X.lib.mvx_bn_backward_scratch_bytes_frames(C, fs.F) // 8,), y.device)
+    rng = (ctypes.c_int64 * 2)()
+    for part in range(nparts):
+        with _hip._timed_bytes('bn_relu_backward', 5.5 * y.numel() * 4 / nparts):
+            X.check(X.lib.mvx_bn_relu_backward_planes_part_frames(X.ptr(dyhat), X.ptr(y), X.ptr(mi), 1.0, X.ptr(dzp),
+                                                                  X.ptr(dbias_into), X.ptr(scratch), X.ptr(row_w), rows, C,
+                                                                  _hip.FLAG_ACCUMULATE | fz, fs.desc.ref(), kind, part, nparts, rng,
+                                                                  X.stream()), 'mvx_bn_relu_backward_planes_part_frames')
+        if rng[1] > rng[0]:
+            yield dzp, int(rng[0]), int(rng[1])
+
+
 # (The BatchNorm-backward reduction folded into the epilogue of the producing input-gradient kernel -- VERDICT r03 #1a, built and
 # measured in round 4: hot 413.0 vs 418.0 frames/s, full 190.9 vs 190.8, its kernel variants spilling -- was removed in round 5.)
 
@@ -724,10 +748,16 @@ def rows_backward(model, S, dfeat):
         if i == 0 and xp is not None and _hip.precut_ok(_hip.row_split('wgrad'), x.shape[0], x.shape[1], w.shape[0]):
             # the step's last and largest weight gradient on pre-cut operands: the BatchNorm backward writes dz as planes (no other
             # reader: the sampled features carry no gradient), the weight gradient moves both operands by DMA (rowgemm_pre.hip)
-            dzp = bn_relu_backward(gx, y, mi, fs, X.ROWS_FUSION, fs.fusion_row_w, _grad_of(b), planes=True)
-            _hip.mark_tail(dev)
-            if 'lin_wgrad' not in KNOCKOUT:
-                _hip.linear_wgrad_pre(xp, dzp, accumulate_into=_grad_of(w).view(w.shape[0], -1))
+            # ... and in TAIL_PARTS row ranges: the weight gradient of a range runs on the side stream beside the apply pass of
+            # the next one, so that what is left after the main stream's last kernel is the last range's product only
+            first = True
+            for dzp, lo, hi in bn_relu_backward_planes_parts(gx, y, mi, fs, X.ROWS_FUSION, fs.fusion_row_w, _grad_of(b),
+                                                             _hip.TAIL_PARTS):
+                if first:
+                    _hip.mark_tail(dev)
+                    first = False
+                if 'lin_wgrad' not in KNOCKOUT:
+                    _hip.linear_wgrad_pre(xp, dzp, accumulate_into=_grad_of(w).view(w.shape[0], -1), rows=(lo, hi))
             break
         dz = bn_relu_backward(gx, y, mi, fs, X.ROWS_FUSION, fs.fusion_row_w, _grad_of(b))
         if i == 0:

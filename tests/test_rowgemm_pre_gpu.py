@@ -106,3 +106,42 @@ def test_batchnorm_backward_writes_the_cut_of_its_f32_output():
     hi, mid, lo = (dzp[q].view(torch.bfloat16).float() for q in range(3))
     assert torch.equal((hi + mid) + lo, dz)
     assert torch.equal(db1, db2)
+
+
+@pytest.mark.parametrize('nparts', [2, 3, 7])
+def test_backward_in_row_ranges_equals_the_one_pass_form(nparts):
+    """mvx_bn_relu_backward_planes_part_frames + mvx_linear_wgrad_pre_rows (the step's tail enqueued range by range so that the
+    product of a range runs beside the apply pass of the next): the ranges tile the rows, the planes are those of the one-pass
+    form bit for bit, the bias gradient is equal, and the weight gradient summed over the ranges meets the same float64 bound."""
+    from modules import _hip
+    from modules import Extension as X
+    from modules import frames as fr
+    g = torch.Generator().manual_seed(5)
+    rows, C, K = 5003, 768, 256
+    y = torch.randn((rows, C), generator=g).to(DEV)
+    x = torch.randn((rows, K), generator=g).to(DEV)
+    gup = (torch.randn((rows, C), generator=g) * 1e-3).to(DEV)
+    yr = y.relu()
+    st = torch.stack([yr.double().sum(0), (yr.double() ** 2).sum(0)])[None].repeat(_hip.STATS_REPLICAS, 1, 1)
+    st[1:] = 0
+    mi = _hip.bn_finalize(st.contiguous(), rows, 1e-6)[None].contiguous()
+
+    class FS:
+        F = 1
+        desc = X.FramesDesc.make([0, rows], [0, rows], 1)
+    db1, db2 = torch.zeros((C,), device=DEV), torch.zeros((C,), device=DEV)
+    whole = fr.bn_relu_backward(gup, yr, mi, FS, X.ROWS_REAL, None, db1, planes=True)
+    xp = _hip.split_rows(x, 3)
+    dw = torch.zeros((C, K), device=DEV)
+    ranges, planes = [], None
+    for dzp, lo, hi in fr.bn_relu_backward_planes_parts(gup, yr, mi, FS, X.ROWS_REAL, None, db2, nparts):
+        ranges.append((lo, hi))
+        planes = dzp
+        _hip.linear_wgrad_pre(xp, dzp, accumulate_into=dw, rows=(lo, hi))
+    _hip.join_side_stream()
+    torch.cuda.synchronize()
+    assert ranges[0][0] == 0 and ranges[-1][1] == rows and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    assert torch.equal(planes, whole)
+    assert torch.equal(db1, db2)
+    dz = sum(whole[q].view(torch.bfloat16).double() for q in range(3))
+    assert rel(dw, dz.t() @ x.double()) < 4e-6
