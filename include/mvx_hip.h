@@ -329,6 +329,11 @@ int mvx_activity_dilate(const void *src, int32_t src_is_index, int32_t din, int3
  * [n_frames * planes][channels] (mvx_bn_background) everywhere else, without reading y there.  Bit-identical to mvx_bn_apply. */
 int mvx_bn_apply_tiles_frames(const float *y, const float *mean_inv, const float *c_bg, const int32_t *tile_flags, float *out,
                               int32_t planes, int32_t h, int32_t w, int32_t channels, int32_t n_frames, void *stream);
+/* ... written as the reference's middle output instead: bev [frame][c * planes + d][h][w] (modules/voxelnet/Pipe.py:40-41, the
+ * (C, D, H, W) result viewed as (C * D, H, W)); equal to mvx_bn_apply_tiles_frames followed by mvx_cl_to_bev_frames bit for bit,
+ * without the channels-last tensor in between.  channels <= 64. */
+int mvx_bn_apply_tiles_bev_frames(const float *y, const float *mean_inv, const float *c_bg, const int32_t *tile_flags, float *bev,
+                                  int32_t planes, int32_t h, int32_t w, int32_t channels, int32_t n_frames, void *stream);
 int mvx_conv3d_background_taps_frames(const float *w, const float *c_in, int32_t din, int32_t dout, int32_t cin, int32_t cout,
                                       int32_t stride_d, int32_t pad_d, float *bg, int32_t n_frames, void *stream);
 int mvx_conv3d_background(const float *w, const float *c_in, int32_t din, int32_t dout, int32_t cin, int32_t cout,
@@ -706,6 +711,12 @@ int mvx_index_grid_frames(const int64_t *coords, int32_t n_voxels, int32_t d, in
 int mvx_sparse_conv_output_frames(const float *p, const int32_t *index_grid, const float *bias, float *out, double *stats,
                                   int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cout, int32_t stride_d,
                                   int32_t pad_d, int32_t flags, int32_t n_frames, void *stream);
+/* ... told which 8 x 16 tiles of the OUTPUT hold a site with a voxel under its taps (the tile flags mvx_activity_dilate_frames forms
+ * from the index grid, [n_frames * dout][tiles]): only those are built, the rest is ReLU(bias) (written, or implied under
+ * MVX_FLAG_NO_BG_FILL); the BatchNorm sums count the rest in closed form as before. */
+int mvx_sparse_conv_output_tiles_frames(const float *p, const int32_t *index_grid, const float *bias, float *out, double *stats,
+                                        int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cout, int32_t stride_d,
+                                        int32_t pad_d, int32_t flags, int32_t n_frames, const int32_t *tile_flags, void *stream);
 int mvx_sparse_conv_gather_dz_frames(const float *dz, const int64_t *coords, int32_t n_voxels, float *g_rows, int32_t din,
                                      int32_t dout, int32_t h, int32_t w, int32_t cout, int32_t stride_d, int32_t pad_d,
                                      const mvx_frames_t *frames_host, void *stream);

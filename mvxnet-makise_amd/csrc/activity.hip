@@ -225,6 +225,50 @@ __global__ __launch_bounds__(256) void bn_apply_tiles(const float *__restrict__ 
     }
 }
 
+// ---- ... writing the reference's layout of the middle output instead: bev[frame][c * D + d][H][W] (modules/voxelnet/Pipe.py:40-41:
+// the (C, D, H, W) result viewed as (C * D, H, W) -- a view there, a transposition of this library's channels-last storage).  The
+// same values as bn_apply_tiles followed by cl_bev_transpose, without the channels-last tensor in between (288 MB written and
+// read back per 4-frame step): the tile's 128 sites x C channels go through a padded LDS tile, every thread then stores four
+// neighbouring sites of one channel (16 lanes = one 64-byte row piece of the tile).  C <= 64, one workgroup per (tile, plane).
+__global__ __launch_bounds__(256) void bn_apply_tiles_bev(const float *__restrict__ y, const float *__restrict__ mi,
+                                                          const float *__restrict__ c_bg, const int *__restrict__ tile_flags,
+                                                          float *__restrict__ bev, int D, int H, int W, int C, int ntiles) {
+    __shared__ float s_t[ATH * ATW][64 + 1];
+    const int tiles_x = (W + ATW - 1) / ATW;
+    const int t = blockIdx.x, d = blockIdx.y, frame = d / D, dd = d - frame * D;
+    const int c4n = C >> 2, ct = threadIdx.x % c4n, st = threadIdx.x / c4n, spb = 256 / c4n;
+    const int ty0 = (t / tiles_x) * ATH, tx0 = (t % tiles_x) * ATW;
+    const bool on = tile_flags[(size_t)d * ntiles + t] != 0;          // block-uniform
+    const float4 cb = *(const float4 *)(c_bg + (size_t)d * C + ct * 4);
+    const float *fmi = mi + (size_t)frame * 2 * C;
+    const float4 m = *(const float4 *)(fmi + ct * 4), iv = *(const float4 *)(fmi + C + ct * 4);
+    for (int sidx = st; sidx < ATH * ATW; sidx += spb) {
+        const int gy = ty0 + sidx / ATW, gx = tx0 + sidx % ATW;
+        float4 o = cb;
+        if (on && gy < H && gx < W) {
+            const float4 v = *(const float4 *)(y + (((size_t)d * H + gy) * W + gx) * C + ct * 4);
+            o = make_float4((v.x - m.x) * iv.x, (v.y - m.y) * iv.y, (v.z - m.z) * iv.z, (v.w - m.w) * iv.w);
+        }
+        s_t[sidx][ct * 4 + 0] = o.x; s_t[sidx][ct * 4 + 1] = o.y; s_t[sidx][ct * 4 + 2] = o.z; s_t[sidx][ct * 4 + 3] = o.w;
+    }
+    __syncthreads();
+    // (tile row, channel, group of four columns): lanes walk the four groups of a 64-byte row piece, then the channels (LDS
+    // banks: site + channel mod 32 with the 65-float pitch -- 28 distinct banks per wave)
+    float *fb = bev + (size_t)frame * C * D * H * W;
+    for (int e = threadIdx.x; e < C * ATH * (ATW / 4); e += 256) {
+        const int g4 = e % (ATW / 4), c = (e / (ATW / 4)) % C, r = e / (C * (ATW / 4));
+        const int gy = ty0 + r, gx = tx0 + g4 * 4;
+        if (gy >= H || gx >= W) continue;
+        const int s0 = r * ATW + g4 * 4;
+        float *dst = fb + (((size_t)c * D + dd) * H + gy) * W + gx;
+        if (gx + 3 < W && (W & 3) == 0) {
+            *(float4 *)dst = make_float4(s_t[s0][c], s_t[s0 + 1][c], s_t[s0 + 2][c], s_t[s0 + 3][c]);
+        } else {
+            for (int j = 0; j < 4 && gx + j < W; ++j) dst[j] = s_t[s0 + j][c];
+        }
+    }
+}
+
 // ---- BatchNorm + ReLU backward restricted to the active tiles of a layer output -----------------------
 // Outside the active tiles every site holds the background (y = y_bg[d], yhat = c[d]); its share of the
 // batch sums follows from A[d][c] = sum over plane d of the incoming gradient (closed form, see
@@ -592,6 +636,19 @@ extern "C" int mvx_bn_apply_tiles_frames(const float *y, const float *mean_inv, 
     const int ntiles = (int)(mvx_cdiv(w, ATW) * mvx_cdiv(h, ATH));
     hipLaunchKernelGGL(bn_apply_tiles, dim3(ntiles, planes * n_frames), dim3(256), 0, (hipStream_t)stream, y, mean_inv, c_bg,
                        (const int *)tile_flags, out, planes, h, w, channels, ntiles);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+extern "C" int mvx_bn_apply_tiles_bev_frames(const float *y, const float *mean_inv, const float *c_bg, const int32_t *tile_flags,
+                                             float *bev, int32_t planes, int32_t h, int32_t w, int32_t channels, int32_t n_frames,
+                                             void *stream) {
+    MVX_CHECK_ARG(y && mean_inv && c_bg && tile_flags && bev && planes > 0 && h > 0 && w > 0);
+    MVX_CHECK_ARG(channels > 0 && channels % 4 == 0 && channels <= 64 && 256 % (channels / 4) == 0);
+    MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES && (((uintptr_t)bev) & 15) == 0);
+    const int ntiles = (int)(mvx_cdiv(w, ATW) * mvx_cdiv(h, ATH));
+    hipLaunchKernelGGL(bn_apply_tiles_bev, dim3(ntiles, planes * n_frames), dim3(256), 0, (hipStream_t)stream, y, mean_inv, c_bg,
+                       (const int *)tile_flags, bev, planes, h, w, channels, ntiles);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

@@ -34,13 +34,15 @@ __global__ __launch_bounds__(512) void rowgemm_k128(const float *__restrict__ x,
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, lh = lane >> 5;
     const int chunk = blockIdx.x % chunks, wg = blockIdx.x / chunks, wgs = (gridDim.x - chunk + chunks - 1) / chunks;
     const int n0 = chunk * NCH;
+    const int ntl = N - n0 >= NCH ? 4 : (N - n0) / 32;      // 32-column tiles of this chunk (the last chunk of an N that is not a multiple of 128)
     float x_scale = 1.f;
     if constexpr (FMT == 1) x_scale = x_coarse ? split_scale_coarse(x_amax) : split_scale_of(x_amax);
 
     // ---- the chunk's weights, cut once: [piece][n][k] rows of 272 bytes
     for (int c = tid; c < NCH * K128 / 4; c += 512) {
         const int n = c / (K128 / 4), part = c % (K128 / 4);
-        f32x4 v = *(const f32x4 *)(w + (long long)(n0 + n) * ldw + part * 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n0 + n < N) v = *(const f32x4 *)(w + (long long)(n0 + n) * ldw + part * 4);
         if constexpr (FMT == 1) v *= SPLIT_F16_WSCALE;
         uint2 pc[NP];
         split_n<NP, FMT>(v[0], v[1], v[2], v[3], pc);
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(512) void rowgemm_k128(const float *__restrict__ x,
     const int b_base = li * WROW + lh * 16;
     float bsv[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) bsv[t] = bias ? bias[n0 + t * 32 + li] : 0.f;
+    for (int t = 0; t < 4; ++t) bsv[t] = bias && t < ntl ? bias[n0 + t * 32 + li] : 0.f;
 
     // operand registers of one block: half h2 holds the steps 4 h2 .. 4 h2 + 3 (two float4 = 8 k values per step)
     f32x4 a[2][4][2];
@@ -84,6 +86,7 @@ __global__ __launch_bounds__(512) void rowgemm_k128(const float *__restrict__ x,
             const int ko = (h2 * 4 + s) * 32;
 #pragma unroll
             for (int t = 0; t < 4; t += 2) {
+                if (t >= ntl) break;                     // block-uniform
                 bf16x8 b0[NP], b1[NP];
 #pragma unroll
                 for (int q = 0; q < NP; ++q) {
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(512) void rowgemm_k128(const float *__restrict__ x,
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const double u = s1[t] + __shfl_xor(s1[t], 32, 64), v = s2[t] + __shfl_xor(s2[t], 32, 64);
-            if (lh == 0) {
+            if (lh == 0 && t < ntl) {
                 atomicAdd(fstats + n0 + t * 32 + li, u);
                 atomicAdd(fstats + N + n0 + t * 32 + li, v);
             }
@@ -154,7 +157,8 @@ __global__ __launch_bounds__(512) void rowgemm_k128(const float *__restrict__ x,
             const int rc = (r & 3) + 8 * (r >> 2);
             if (live == 32 || rc + 4 * lh < live) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) yb[rc * ldy + t * 32] = acc[t][r];
+                for (int t = 0; t < 4; ++t)
+                    if (t < ntl) yb[rc * ldy + t * 32] = acc[t][r];
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -204,14 +208,14 @@ static int g_k128_on = 1;
 void mvxi_rowgemm_k128_enable(long long v) { g_k128_on = v != 0; }
 
 bool mvxi_rowgemm_k128_ok(int ldx, int ldw, int ldy, int k, int n) {
-    return g_k128_on && k == K128 && n % NCH == 0 && n >= NCH && ldx % 4 == 0 && ldw % 4 == 0 && ldy >= n;
+    return g_k128_on && k == K128 && n % 64 == 0 && n >= NCH && ldx % 4 == 0 && ldw % 4 == 0 && ldy >= n;
 }
 
 // Launched by linear.hip (linear_forward_impl) for K = 128 when MVX_FLAG_SPLIT is set; same arguments as mvxi_linear_forward_split
 int mvxi_linear_forward_k128(const float *x, int ldx, const float *w, int ldw, const float *bias, float *y, int ldy, double *stats,
                              const float *row_w, long long rows, int n, int relu, unsigned *fin_counter, double fin_eps,
                              float *fin_mean_inv, const FrameMap &fm, int pieces, hipStream_t st, const SplitAmax &am) {
-    const int chunks = n / NCH;
+    const int chunks = (n + NCH - 1) / NCH;                 // the last one may hold 64 columns
     // one workgroup per CU in all; never more waves than 32-row blocks
     const long long blocks = (rows + 31) / 32;
     long long per_chunk = 256 / chunks;

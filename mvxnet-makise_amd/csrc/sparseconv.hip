@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void sparse_conv_output(const float *__restric
                                                           const int *__restrict__ occ,
                                                           const float *__restrict__ bias, float *__restrict__ out,
                                                           double *__restrict__ stats, SGeom g, int relu,
-                                                          int *__restrict__ active_sites, int skip_fill) {
+                                                          int *__restrict__ active_sites, int skip_fill,
+                                                          const int *__restrict__ tile_flags) {
     __shared__ float red[2][256][4];
     __shared__ int s_idx[3 * (OTH + 2) * (OTW + 2)];   // voxel ids of the tile's halo, [depth tap][row][column]
     __shared__ int s_list[3 * (OTH + 2) * (OTW + 2)];  // halo positions that hold a voxel, ascending
@@ -69,11 +70,19 @@ __global__ __launch_bounds__(256) void sparse_conv_output(const float *__restric
     active_sites += frame;
     const int x = tcx * OTW + st;
     int any = 0;
-    for (int kd = 0; kd < 3; ++kd) {
-        const int ds = mvx_src_plane(d, g.Din, g.Dout, g.sd, g.pd, kd);
-        if (ds < 0) continue;
-        for (int ty = max(tcy - 1, 0); ty <= min(tcy + 1, tyn - 1); ++ty)
-            for (int tx = max(tcx - 1, 0); tx <= min(tcx + 1, txn - 1); ++tx) any |= occ[((size_t)ds * tyn + ty) * txn + tx];
+    if (tile_flags) {
+        // the caller knows the tiles of THIS output that hold a site with a voxel under its 27 taps (activity.hip: the tile flags of
+        // the layer's output): one load, and fewer tiles than the coarse test below finds (it takes every neighbour of an
+        // occupied tile).  A tile it leaves out holds ReLU(bias) at every site, which is what the closed form of
+        // sparse_stats_fix counts for it.
+        any = tile_flags[(size_t)d * (tyn * txn) + blockIdx.x];
+    } else {
+        for (int kd = 0; kd < 3; ++kd) {
+            const int ds = mvx_src_plane(d, g.Din, g.Dout, g.sd, g.pd, kd);
+            if (ds < 0) continue;
+            for (int ty = max(tcy - 1, 0); ty <= min(tcy + 1, tyn - 1); ++ty)
+                for (int tx = max(tcx - 1, 0); tx <= min(tcx + 1, txn - 1); ++tx) any |= occ[((size_t)ds * tyn + ty) * txn + tx];
+        }
     }
     if (!any && skip_fill) return;                     // MVX_FLAG_NO_BG_FILL: the ReLU(bias) fill of a voxel-free tile is implied
     if (any) {                                         // block-uniform
@@ -241,9 +250,10 @@ static int sgeom_ok(int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cou
     return dout == (din + 2 * pd - 3) / sd + 1;
 }
 
-extern "C" int mvx_sparse_conv_output_frames(const float *p, const int32_t *index_grid, const float *bias, float *out,
-                                             double *stats, int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cout,
-                                             int32_t stride_d, int32_t pad_d, int32_t flags, int32_t n_frames, void *stream) {
+static int sparse_conv_output_impl(const float *p, const int32_t *index_grid, const float *bias, float *out,
+                                   double *stats, int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cout,
+                                   int32_t stride_d, int32_t pad_d, int32_t flags, int32_t n_frames, const int32_t *tile_flags,
+                                   void *stream) {
     const int relu = flags & MVX_FLAG_RELU;
     MVX_CHECK_ARG(index_grid && out && sgeom_ok(din, dout, h, w, cout, stride_d, pad_d));
     MVX_CHECK_ARG(cout / 4 * OTW <= 256 && 256 % (cout / 4) == 0);
@@ -262,7 +272,8 @@ extern "C" int mvx_sparse_conv_output_frames(const float *p, const int32_t *inde
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(sparse_conv_output, dim3(mvx_cdiv(w, OTW) * mvx_cdiv(h, OTH), dout * n_frames), dim3(256), 0, st, p,
-                       index_grid, (const int *)occ, bias, out, stats, g, relu, active, (flags & MVX_FLAG_NO_BG_FILL) ? 1 : 0);
+                       index_grid, (const int *)occ, bias, out, stats, g, relu, active, (flags & MVX_FLAG_NO_BG_FILL) ? 1 : 0,
+                       (const int *)tile_flags);
     MVX_LAUNCH_CHECK();
     if (stats) {
         hipLaunchKernelGGL(sparse_stats_fix, dim3(mvx_cdiv(cout, 64), n_frames), dim3(64), 0, st, stats, bias,
@@ -270,6 +281,25 @@ extern "C" int mvx_sparse_conv_output_frames(const float *p, const int32_t *inde
         MVX_LAUNCH_CHECK();
     }
     return MVX_OK;
+}
+
+extern "C" int mvx_sparse_conv_output_frames(const float *p, const int32_t *index_grid, const float *bias, float *out,
+                                             double *stats, int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cout,
+                                             int32_t stride_d, int32_t pad_d, int32_t flags, int32_t n_frames, void *stream) {
+    return sparse_conv_output_impl(p, index_grid, bias, out, stats, din, dout, h, w, cout, stride_d, pad_d, flags, n_frames, nullptr,
+                                   stream);
+}
+
+// ... with the tile flags of the layer's OUTPUT (mvx_activity_dilate_frames on the index grid: [n_frames * dout][tiles], non-zero =
+// the 8 x 16 tile holds a site with a voxel under its taps): only those tiles are built; the others are filled with ReLU(bias)
+// or, under MVX_FLAG_NO_BG_FILL, left unwritten.
+extern "C" int mvx_sparse_conv_output_tiles_frames(const float *p, const int32_t *index_grid, const float *bias, float *out,
+                                                   double *stats, int32_t din, int32_t dout, int32_t h, int32_t w, int32_t cout,
+                                                   int32_t stride_d, int32_t pad_d, int32_t flags, int32_t n_frames,
+                                                   const int32_t *tile_flags, void *stream) {
+    MVX_CHECK_ARG(tile_flags);
+    return sparse_conv_output_impl(p, index_grid, bias, out, stats, din, dout, h, w, cout, stride_d, pad_d, flags, n_frames,
+                                   tile_flags, stream);
 }
 
 extern "C" int mvx_sparse_conv_output(const float *p, const int32_t *index_grid, const float *bias, float *out,

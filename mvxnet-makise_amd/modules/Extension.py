@@ -139,11 +139,13 @@ PROTOTYPES = {
     'mvx_index_grid_bytes_frames': (_sz, [_i32, _i32, _i32, _i32]),
     'mvx_index_grid_frames': (_i32, [_p, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
     'mvx_sparse_conv_output_frames': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    'mvx_sparse_conv_output_tiles_frames': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     'mvx_sparse_conv_gather_dz_frames': (_i32, [_p, _p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     'mvx_activity_dilate_frames': (_i32, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p]),
     'mvx_tile_dilate_flags_frames': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i32, _p]),
     'mvx_conv3d_background_frames': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i32, _p]),
     'mvx_bn_apply_tiles_frames': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    'mvx_bn_apply_tiles_bev_frames': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_conv3d_background_taps_frames': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i32, _p]),
     'mvx_bn_background_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p]),
     'mvx_conv3d_forward_bg_frames': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p,

@@ -91,6 +91,7 @@ def _stats(F, C, dev):
     return buf, fz
 
 
+BEV_FUSED = os.environ.get('MVX_BEV_FUSED', '1') != '0'   # conv3's BatchNorm apply writes the (F, C * D, H, W) map itself (A/B: 0)
 TAP_SKIP = os.environ.get('MVX_TAP_SKIP', '1') != '0'     # conv2 / conv3 forward: skip depth taps with a background-only source halo
 # DIAGNOSTIC ONLY (tools/knockout.sh): comma-separated kernel classes that are NOT launched, to measure what each class costs
 # on the critical path of a step (step time with the class removed).  Results are garbage; bench.py marks such a run invalid.
@@ -416,9 +417,11 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
     stats, fz = _stats(F, cout, dev)
     with _hip._timed_bytes('sparse_conv_output', y1.numel() * 4 + F * D0 * H * W * 4):
       if 'sparse_out' not in KNOCKOUT:
-        X.check(X.lib.mvx_sparse_conv_output_frames(X.ptr(P), X.ptr(idx_grid), X.ptr(b1), X.ptr(y1), X.ptr(stats), D0, D1, H, W,
-                                                    cout, c1._sd, c1._pd, _hip.FLAG_RELU | _hip.FLAG_NO_BG_FILL | fz, F, X.stream()),
-                'mvx_sparse_conv_output_frames')
+        # only the tiles of y1 that hold a site next to a voxel are built: the flags of this layer's output from grid_activity
+        X.check(X.lib.mvx_sparse_conv_output_tiles_frames(X.ptr(P), X.ptr(idx_grid), X.ptr(b1), X.ptr(y1), X.ptr(stats), D0, D1, H, W,
+                                                          cout, c1._sd, c1._pd, _hip.FLAG_RELU | _hip.FLAG_NO_BG_FILL | fz, F,
+                                                          X.ptr(ga['layers'][0][2]), X.stream()),
+                'mvx_sparse_conv_output_tiles_frames')
     mi1 = torch.empty((F, 2, cout), dtype=torch.float32, device=dev)
     X.check(X.lib.mvx_bn_finalize_frames(X.ptr(stats), float(D1 * H * W), float(eps), X.ptr(mi1), cout, F, X.stream()),
             'mvx_bn_finalize_frames')
@@ -504,7 +507,17 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
                                                        float(eps), X.ptr(mi), X.ptr(_hip._work_counter(dev)), F, X.stream()),
                     'mvx_conv3d_forward_bg_frames')
         c_o, ybg_o = background(bg_pre, b, mi, dout, co)         # the background of this layer's output
-        x_out = bn_apply_bg(y, mi, c_o, tflag_o, dout)
+        if want_bev and li == 1 and co <= 64 and 'bn_apply_cml' not in KNOCKOUT and BEV_FUSED:
+            # the last layer's normalised output goes straight into the reference's (F, C * D, H, W) layout
+            # (mvx_bn_apply_tiles_bev_frames): no channels-last copy of it, no transposition pass
+            mid = torch.empty((F, co * dout, H, W), dtype=torch.float32, device=dev)
+            nbytes = (lambda: (tflag_o.ne(0).sum() + tflag_o.numel()) * (128 * co * 4)) if _hip.KERNEL_TIMERS is not None else 0
+            with _hip._timed_bytes('bn_apply', nbytes):
+                X.check(X.lib.mvx_bn_apply_tiles_bev_frames(X.ptr(y), X.ptr(mi), X.ptr(c_o), X.ptr(tflag_o), X.ptr(mid), dout, H, W, co,
+                                                            F, X.stream()), 'mvx_bn_apply_tiles_bev_frames')
+            x_out = None
+        else:
+            x_out = bn_apply_bg(y, mi, c_o, tflag_o, dout)
         rec = dict(x=x_in, w=w, b=b, y=y, mi=mi, din=din, dout=dout, sd=sd, pd=pd, m=m, c_in=c_in, hflag_in=hflag_in,
                    bflag_in=bflag_in, split=split)
         if li == 0:
@@ -515,10 +528,12 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
         S.convs.append(rec)
         x_in, din, mask_in, hflag_in, tflag_in = x_out, dout, mask_o, hflag_o, tflag_o
     D3 = din
-    S.D3, S.H, S.W, S.C3 = D3, H, W, x_in.shape[-1]
-    S.x3 = x_in
+    S.D3, S.H, S.W, S.C3 = D3, H, W, co
+    S.x3 = x_in                                # None when the last layer wrote the (F, C * D, H, W) map itself
     if not want_bev:
         return None
+    if x_in is None:
+        return mid
     mid = torch.empty((F, x_in.shape[-1] * D3, H, W), dtype=torch.float32, device=dev)
     with _hip._timed_bytes('cl_bev_transpose', 2 * x_in.numel() * 4):
         X.check(X.lib.mvx_cl_to_bev_frames(X.ptr(x_in), X.ptr(mid), D3, H, W, x_in.shape[-1], 0, F, X.stream()), 'mvx_cl_to_bev_frames')

@@ -253,3 +253,29 @@ def test_sampler_forms_the_range_tag_of_the_image_features(golden, small_cfg):
                 assert float(am) == float(compact.abs().max()) and float(am) > 0
     finally:
         small_cfg.config['convmath'] = old
+
+
+def test_last_layer_writes_the_reference_layout_itself(golden, small_cfg, monkeypatch):
+    """conv3's BatchNorm apply writing (F, C * D, H, W) directly (mvx_bn_apply_tiles_bev_frames) against the two-step form it
+    replaces (channels-last output, then mvx_cl_to_bev_frames): the same middle maps bit for bit."""
+    from MVXNet import MVXNet
+    from modules import frames as fr
+    from modules import parallel
+    from modules.pipeline import train_step_frame_set
+    torch.manual_seed(3)
+    model = MVXNet().to(DEV)
+    batch, G = _small_batch(golden, 3)
+    for f in range(3):
+        nlive = int(batch.n_points[f])
+        batch.perms[f, :nlive] = torch.randperm(nlive, generator=torch.Generator().manual_seed(f)).to(DEV)
+    bucket = parallel.GradBucket([p for k, p in model.named_parameters() if p.requires_grad and '.rpn.' not in k])
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setattr(fr, 'BEV_FUSED', fused)
+        bucket.zero()
+        mids = []
+        train_step_frame_set(model, batch, G, [370.0, 1224.0], keep_mid=mids)
+        torch.cuda.synchronize()
+        out[fused] = (torch.cat(mids), bucket.flat.clone())
+    assert torch.equal(out[True][0], out[False][0])
+    assert torch.equal(out[True][1], out[False][1])

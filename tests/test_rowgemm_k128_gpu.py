@@ -38,7 +38,7 @@ def _run(on, x, w, b, rows, N, flags, row_w, desc, kind, F, stats=True):
 
 
 @pytest.mark.parametrize('split', [3, 4, 2])
-@pytest.mark.parametrize('rows,N,frames', [(5000, 128, 1), (33, 128, 1), (100001, 128, 3), (4100, 768, 2), (31, 256, 1)])
+@pytest.mark.parametrize('rows,N,frames', [(5000, 128, 1), (33, 128, 1), (100001, 128, 3), (4100, 768, 2), (31, 256, 1), (3001, 1728, 1), (2777, 192, 2)])
 def test_equals_the_tiled_kernel(rows, N, frames, split):
     from modules import _hip
     from modules import Extension as X
