@@ -16,6 +16,7 @@
 // sampled; row_map sends a dense row to its compact row (or -1), and one shared zero row stands
 // for every padded row downstream.
 #include "common.h"
+#include "split_common.h"
 
 namespace {
 
@@ -153,7 +154,11 @@ __global__ __launch_bounds__(256) void feature_sample(float *__restrict__ vox, i
 __global__ __launch_bounds__(256) void feature_sample_rows(const float *__restrict__ vox, int vc, const int *__restrict__ rows_sel,
                                                            int n_real, FrameLevels L, int C, float im_h, float im_w, float eps,
                                                            float *__restrict__ out, int *__restrict__ status, FrameMap fm,
-                                                           unsigned *__restrict__ amax_slot) {
+                                                           unsigned *__restrict__ amax_slot, unsigned short *__restrict__ planes,
+                                                           long long plane_rows) {
+    // planes (may be NULL): u16 [3][plane_rows][levels * C], the rows ALSO written as their three bf16 pieces (hi + mid + lo = the
+    // f32 value exactly): the operand format of the first fusion layer's weight gradient (rowgemm_pre.hip) formed while the rows
+    // are in registers instead of by a pass of mvx_split_rows over them (245 MB read back per 4-frame step)
     // amax_slot (may be NULL): raised to max |sampled value| -- the range tag of the rows for the fp16x3 arithmetic, formed while
     // they are written instead of by a pass of mvx_tensor_amax over them (108 us per 245 MB beside the step's other kernels)
     const long long wave = (blockIdx.x * 256ll + threadIdx.x) >> 6;
@@ -170,7 +175,11 @@ __global__ __launch_bounds__(256) void feature_sample_rows(const float *__restri
     const float fy = qy - (float)iy, fx = qx - (float)ix;
     if (iy < 0 || ix < 0 || iy + 1 > H || ix + 1 > W) {
         if (lane == 0) atomicOr(status, 1);
-        for (int c = lane * 4; c < C; c += 256) *(float4 *)(out + j * ldo + lv * C + c) = make_float4(0, 0, 0, 0);
+        for (int c = lane * 4; c < C; c += 256) {
+            *(float4 *)(out + j * ldo + lv * C + c) = make_float4(0, 0, 0, 0);
+            if (planes)
+                for (int q = 0; q < 3; ++q) *(uint2 *)(planes + ((size_t)q * plane_rows + j) * ldo + lv * C + c) = make_uint2(0u, 0u);
+        }
         return;
     }
     const float *F = L.feat[fm_frame_of(fm, j) * L.n + lv];       // the maps of the row's own frame
@@ -189,6 +198,12 @@ __global__ __launch_bounds__(256) void feature_sample_rows(const float *__restri
         MVX_TAP(x) MVX_TAP(y) MVX_TAP(z) MVX_TAP(w)
 #undef MVX_TAP
         *(float4 *)(out + j * ldo + lv * C + c) = o;
+        if (planes) {
+            uint2 pc[3];
+            split_n<3, 0>(o.x, o.y, o.z, o.w, pc);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *(uint2 *)(planes + ((size_t)q * plane_rows + j) * ldo + lv * C + c) = pc[q];
+        }
         mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
     if (amax_slot) mvx_wave_amax_to(amax_slot, mx);
@@ -305,12 +320,13 @@ extern "C" int mvx_feature_sample(float *voxels, int32_t vox_channels, int64_t r
     return MVX_OK;
 }
 
-extern "C" int mvx_feature_sample_rows_frames(const float *voxels, int32_t vox_channels, const int32_t *rows_sel,
-                                              int32_t n_real, const float *const *feats_host, const int32_t *feat_hw_host,
-                                              int32_t n_levels, int32_t channels, float imsize_h, float imsize_w, float eps,
-                                              float *out, int32_t *status, const mvx_frames_t *frames_host, float *out_amax,
-                                              void *stream) {
+static int feature_sample_rows_impl(const float *voxels, int32_t vox_channels, const int32_t *rows_sel,
+                                    int32_t n_real, const float *const *feats_host, const int32_t *feat_hw_host,
+                                    int32_t n_levels, int32_t channels, float imsize_h, float imsize_w, float eps,
+                                    float *out, int32_t *status, const mvx_frames_t *frames_host, float *out_amax,
+                                    void *planes, int64_t plane_rows, void *stream) {
     MVX_CHECK_ARG(voxels && rows_sel && feats_host && feat_hw_host && out && status && n_real >= 0);
+    MVX_CHECK_ARG(!planes || (plane_rows >= n_real && (((uintptr_t)planes) & 7) == 0));
     MVX_CHECK_ARG(vox_channels >= 5 && vox_channels <= 64 && n_levels >= 1 && n_levels <= MAX_LEVELS);
     MVX_CHECK_ARG(channels > 0 && channels % 4 == 0);
     if (n_real == 0) return MVX_OK;
@@ -330,9 +346,31 @@ extern "C" int mvx_feature_sample_rows_frames(const float *voxels, int32_t vox_c
     }
     const long long waves = (long long)n_real * n_levels;
     hipLaunchKernelGGL(feature_sample_rows, dim3(mvx_cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, voxels, vox_channels,
-                       rows_sel, n_real, L, channels, imsize_h, imsize_w, eps, out, status, fm, (unsigned *)out_amax);
+                       rows_sel, n_real, L, channels, imsize_h, imsize_w, eps, out, status, fm, (unsigned *)out_amax,
+                       (unsigned short *)planes, (long long)plane_rows);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
+}
+
+extern "C" int mvx_feature_sample_rows_frames(const float *voxels, int32_t vox_channels, const int32_t *rows_sel,
+                                              int32_t n_real, const float *const *feats_host, const int32_t *feat_hw_host,
+                                              int32_t n_levels, int32_t channels, float imsize_h, float imsize_w, float eps,
+                                              float *out, int32_t *status, const mvx_frames_t *frames_host, float *out_amax,
+                                              void *stream) {
+    return feature_sample_rows_impl(voxels, vox_channels, rows_sel, n_real, feats_host, feat_hw_host, n_levels, channels, imsize_h,
+                                    imsize_w, eps, out, status, frames_host, out_amax, nullptr, 0, stream);
+}
+
+// ... which also writes the rows as planes of bf16 pieces, u16 [3][plane_rows][n_levels * channels] (rows [0, n_real); the caller
+// clears the others): what mvx_split_rows would make of `out`, bit for bit, without reading it back
+extern "C" int mvx_feature_sample_rows_planes_frames(const float *voxels, int32_t vox_channels, const int32_t *rows_sel,
+                                                     int32_t n_real, const float *const *feats_host, const int32_t *feat_hw_host,
+                                                     int32_t n_levels, int32_t channels, float imsize_h, float imsize_w, float eps,
+                                                     float *out, int32_t *status, const mvx_frames_t *frames_host, float *out_amax,
+                                                     void *planes, int64_t plane_rows, void *stream) {
+    MVX_CHECK_ARG(planes);
+    return feature_sample_rows_impl(voxels, vox_channels, rows_sel, n_real, feats_host, feat_hw_host, n_levels, channels, imsize_h,
+                                    imsize_w, eps, out, status, frames_host, out_amax, planes, plane_rows, stream);
 }
 
 extern "C" int mvx_feature_sample_rows(const float *voxels, int32_t vox_channels, const int32_t *rows_sel, int32_t n_real,

@@ -136,6 +136,8 @@ PROTOTYPES = {
     'mvx_vfe_compact_input_backward_frames': (_i32, [_p, _i32, _i32, _i32, _p, _p, _p, _p]),
     'mvx_row_compact_map_frames': (_i32, [_p, _i32, _i64, _p, _p, _p, _p, _sz, _p, _p, _p]),
     'mvx_feature_sample_rows_frames': (_i32, [_p, _i32, _p, _i32, _p, _p, _i32, _i32, _f32, _f32, _f32, _p, _p, _p, _p, _p]),
+    'mvx_feature_sample_rows_planes_frames': (_i32, [_p, _i32, _p, _i32, _p, _p, _i32, _i32, _f32, _f32, _f32, _p, _p, _p, _p, _p,
+                                                     _i64, _p]),
     'mvx_index_grid_bytes_frames': (_sz, [_i32, _i32, _i32, _i32]),
     'mvx_index_grid_frames': (_i32, [_p, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
     'mvx_sparse_conv_output_frames': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),

@@ -91,6 +91,7 @@ def _stats(F, C, dev):
     return buf, fz
 
 
+SAMPLE_PLANES = os.environ.get('MVX_SAMPLE_PLANES', '1') != '0'   # the FPN sampler writes the operand planes of its rows itself (A/B: 0)
 BEV_FUSED = os.environ.get('MVX_BEV_FUSED', '1') != '0'   # conv3's BatchNorm apply writes the (F, C * D, H, W) map itself (A/B: 0)
 TAP_SKIP = os.environ.get('MVX_TAP_SKIP', '1') != '0'     # conv2 / conv3 forward: skip depth taps with a background-only source halo
 # DIAGNOSTIC ONLY (tools/knockout.sh): comma-separated kernel classes that are NOT launched, to measure what each class costs
@@ -264,17 +265,31 @@ def sample_rows(head, fs, fpn_levels, imsize):
     # fp16x3: the image features come from outside this library -- their range (max |value|) is formed by the sampler while it
     # writes them, so that the first fusion layer can scale them (forward: the coarse scale, _hip.foreign_split)
     amax = torch.zeros((1,), dtype=torch.float32, device=dev) if _hip.split_pieces() == 4 else None
-    with _hip._timed_bytes('feature_sample', Rt * L * C * 4 * 5 + Rt * 9 * 4):
-      if 'sample' not in KNOCKOUT:
-        X.check(X.lib.mvx_feature_sample_rows_frames(X.ptr(fs.vox2d), fs.vox2d.shape[1], X.ptr(fs.rows_sel), Rt, ptrs, hw, L, C,
-                                                     float(imsize[0]), float(imsize[1]), float(cfg.eps), X.ptr(compact),
-                                                     X.ptr(status), fs.desc.ref(), X.ptr(amax), X.stream()), 'mvx_feature_sample_rows_frames')
-    _hip.tag_amax(compact, amax)
+    # the first fusion layer's weight gradient (and, opt-in, the layer itself) reads its input as planes of bf16 pieces
+    # (csrc/rowgemm_pre.hip): the sampler writes them beside the f32 rows while the values are in registers
     w0 = head.fusion._layers()[0][0]
-    if _hip.precut_ok(_hip.split_pieces(), Rt + F, L * C, w0.shape[0]):
-        # the first fusion layer and its weight gradient read their input as planes of bf16 pieces (csrc/rowgemm_pre.hip); cut here,
-        # with the input preparation, off the critical path of the step
-        compact._mvx_planes = _hip.split_rows(compact, _hip.split_pieces())
+    planes = None
+    want_planes = _hip.precut_ok(_hip.split_pieces(), Rt + F, L * C, w0.shape[0]) and _hip.split_pieces() == 3
+    if want_planes and SAMPLE_PLANES:
+        planes = torch.empty((3, Rt + F, L * C), dtype=torch.int16, device=dev)
+        planes[:, Rt:].zero_()
+    with _hip._timed_bytes('feature_sample', Rt * L * C * 4 * 5 + Rt * 9 * 4 + (Rt * L * C * 6 if planes is not None else 0)):
+      if 'sample' not in KNOCKOUT:
+        if planes is not None:
+            X.check(X.lib.mvx_feature_sample_rows_planes_frames(X.ptr(fs.vox2d), fs.vox2d.shape[1], X.ptr(fs.rows_sel), Rt, ptrs, hw, L,
+                                                                C, float(imsize[0]), float(imsize[1]), float(cfg.eps), X.ptr(compact),
+                                                                X.ptr(status), fs.desc.ref(), X.ptr(amax), X.ptr(planes), Rt + F,
+                                                                X.stream()), 'mvx_feature_sample_rows_planes_frames')
+        else:
+            X.check(X.lib.mvx_feature_sample_rows_frames(X.ptr(fs.vox2d), fs.vox2d.shape[1], X.ptr(fs.rows_sel), Rt, ptrs, hw, L, C,
+                                                         float(imsize[0]), float(imsize[1]), float(cfg.eps), X.ptr(compact),
+                                                         X.ptr(status), fs.desc.ref(), X.ptr(amax), X.stream()),
+                    'mvx_feature_sample_rows_frames')
+    _hip.tag_amax(compact, amax)
+    if planes is not None:
+        compact._mvx_planes = planes
+    elif want_planes:
+        compact._mvx_planes = _hip.split_rows(compact, 3)           # the two-pass form (MVX_SAMPLE_PLANES=0)
     return compact, status
 
 

@@ -145,3 +145,40 @@ def test_backward_in_row_ranges_equals_the_one_pass_form(nparts):
     assert torch.equal(db1, db2)
     dz = sum(whole[q].view(torch.bfloat16).double() for q in range(3))
     assert rel(dw, dz.t() @ x.double()) < 4e-6
+
+
+def test_sampler_writes_the_planes_of_its_rows():
+    """mvx_feature_sample_rows_planes_frames (modules/imhead/Pipe.py:23-82 on compact rows): the f32 rows are those of
+    mvx_feature_sample_rows_frames and the planes are their cut (mvx_split_rows), both bit for bit, including rows whose sample
+    falls outside the map (zeros + status)."""
+    import ctypes
+    from modules import _hip
+    from modules import Extension as X
+    g = torch.Generator().manual_seed(9)
+    n, vc, L, C = 3000, 9, 3, 256
+    hw = [(47, 153), (24, 77), (12, 39)]
+    feats = [torch.randn((h, w, C), generator=g).to(DEV) for h, w in hw]
+    vox = torch.randn((n + 50, vc), generator=g)
+    vox[:, vc - 2] = torch.rand(n + 50, generator=g) * 369.0
+    vox[:, vc - 1] = torch.rand(n + 50, generator=g) * 1223.0
+    vox[7, vc - 2] = -50.0                                        # outside the image: zeros, status bit
+    vox = vox.to(DEV)
+    rows_sel = torch.randperm(n + 50, generator=g)[:n].sort().values.to(torch.int32).to(DEV)
+    rows_sel[3] = 7
+    ptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in feats])
+    hwa = (ctypes.c_int32 * (2 * L))(*[v for p in hw for v in p])
+    desc = X.FramesDesc.make([0, 100], [0, n], 35)
+    out0, out1 = (torch.full((n + 1, L * C), float('nan'), device=DEV) for _ in range(2))
+    st0, st1 = (torch.zeros((1,), dtype=torch.int32, device=DEV) for _ in range(2))
+    planes = torch.full((3, n + 1, L * C), -1, dtype=torch.int16, device=DEV)
+    X.check(X.lib.mvx_feature_sample_rows_frames(X.ptr(vox), vc, X.ptr(rows_sel), n, ptrs, hwa, L, C, 370.0, 1224.0, 1e-6, X.ptr(out0),
+                                                 X.ptr(st0), desc.ref(), None, X.stream()), 'mvx_feature_sample_rows_frames')
+    X.check(X.lib.mvx_feature_sample_rows_planes_frames(X.ptr(vox), vc, X.ptr(rows_sel), n, ptrs, hwa, L, C, 370.0, 1224.0, 1e-6,
+                                                        X.ptr(out1), X.ptr(st1), desc.ref(), None, X.ptr(planes), n + 1, X.stream()),
+            'mvx_feature_sample_rows_planes_frames')
+    torch.cuda.synchronize()
+    assert torch.equal(out0[:n], out1[:n]) and int(st0) == int(st1) == 1
+    assert float(out1[3].abs().max()) == 0.0
+    ref = _hip.split_rows(out1[:n].contiguous(), 3)
+    assert torch.equal(planes[:, :n], ref)
+    assert bool((planes[:, n] == -1).all())                      # rows past n_real are the caller's
