@@ -39,6 +39,7 @@ struct VoxWs {
     int *slot_of;              // [F][cap]          slot of stream position s
     int *vox_slot;             // [F*cap]           slot of (global) voxel v
     int *bucket;               // [F][slots][BK]    stream positions of the key, arrival order
+    int *wide_list;            // [F*cap]           voxels left to vox_gather_wide (more than 16 members); count in ticket[1]
     int slots, nblk;
     size_t ff_bytes, zero_bytes;   // extents of the two memsets (from keys / from scount)
 };
@@ -72,6 +73,7 @@ __host__ VoxWs carve(void *ws, int F, int cap, size_t *total) {
     w.slot_of = (int *)take((size_t)F * cap * 4);
     w.vox_slot = (int *)take((size_t)F * cap * 4);
     w.bucket = (int *)take((size_t)F * w.slots * BK * 4);
+    w.wide_list = (int *)take((size_t)F * cap * 4);
     *total = off;
     return w;
 }
@@ -204,41 +206,20 @@ __global__ __launch_bounds__(256) void vox_scan(const int *__restrict__ n_points
     if (g0 <= total_pos - 1 && total_pos - 1 < g0 + 4) w.frame_base[F] = v;               // the thread that owns the last position
 }
 
-// One wave per (global) voxel.  LDS per wave: 64 sorted member slots + the staged point group.
+// Four voxels per wave.  A lidar voxel holds 3.9 points on average, so a wave per voxel (the first form of this kernel) ran its
+// five dependent loads -- voxel -> slot -> member count -> bucket -> permutation -> point row -- with four live lanes: 0.025 of the
+// HBM roofline.  Here a 16-lane group owns a voxel with up to 16 members: it ranks the bucket with 16 shuffles inside the group,
+// stages its points in LDS, sums the centroid in stream order and writes the [T][C] block 64 bytes at a time, four voxels side by
+// side.  A voxel with more members (or a crowded one whose bucket overflowed) is handled afterwards by the whole wave
+// (gather_wide: the wave-per-voxel form).  Same outputs bit for bit: member order, centroid summation order and index math are
+// those of cpp/voxelutil.cpp:325-360 / Preprocessing.py:94-116 (see the file header).
 template <int C>
-__global__ __launch_bounds__(256) void vox_gather(const float *__restrict__ pcd, const int *__restrict__ perm,
-                                                  const int *__restrict__ n_points, int cap, int ncol, int T, int F,
-                                                  int cap_voxels, int concat, VoxWs w, float *__restrict__ voxels,
-                                                  long long *__restrict__ coords, int *__restrict__ counts,
-                                                  int *__restrict__ n_voxels, int *__restrict__ vox_off,
-                                                  int *__restrict__ status) {
-    __shared__ int s_best[4][64];
-    __shared__ float s_pts[4][64][6];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int v = blockIdx.x * 4 + wid;
-    if (blockIdx.x == 0 && threadIdx.x <= F) {          // per-frame counts / offsets for the caller
-        const int f = threadIdx.x;
-        if (vox_off) vox_off[f] = w.frame_base[f];
-        if (f < F) {
-            const int nv = w.frame_base[f + 1] - w.frame_base[f];
-            n_voxels[f] = nv;
-            if (!concat && nv > cap_voxels) atomicOr(status, 2);
-        }
-        if (f == F && concat && w.frame_base[F] > cap_voxels) atomicOr(status, 2);
-    }
-    // frame of voxel v: the F + 1 bases in ONE load (lane k holds base k; F <= 16), then a ballot -- the first form walked them
-    // with F dependent loads per wave
-    const int fb = lane <= F ? w.frame_base[lane] : 0x7fffffff;
-    const int Vtot = __shfl(fb, F, 64);
-    if (v >= Vtot) return;   // whole wave leaves together: no block-wide barrier below
-    const int f = __popcll(__ballot(lane >= 1 && lane < F && v >= fb));
-    const int vl = v - __shfl(fb, f, 64);
-    const long long dst = concat ? (long long)v : (long long)f * cap_voxels + vl;
-    if (concat ? v >= cap_voxels : vl >= cap_voxels) return;
-    const int h = w.vox_slot[v];
+__device__ __forceinline__ void gather_wide(const float *__restrict__ pcd, const int *__restrict__ perm,
+                                            const int *__restrict__ n_points, int cap, int ncol, int T, const VoxWs &w,
+                                            float *__restrict__ voxels, long long *__restrict__ coords, int *__restrict__ counts,
+                                            int f, long long dst, int h, int n, int concat, int (*s_best)[64], float (*s_pts)[64][6],
+                                            int wid, int lane) {
     const size_t slot = (size_t)f * w.slots + h;
-    const int n = w.scount[slot];
-
     // ---- the (up to) T smallest stream positions of the voxel, sorted: lane r holds rank r
     int best = 0x7fffffff;
     if (n <= BK) {
@@ -258,14 +239,25 @@ __global__ __launch_bounds__(256) void vox_gather(const float *__restrict__ pcd,
         // are the answer (already sorted)
         const int npts = min(n_points[f], cap);
         const int *so = w.slot_of + (size_t)f * cap;
+        // 1,024 positions per round, their sixteen loads in flight together: one load per round made the walk a chain of ~170
+        // memory latencies (0.1 ms for ONE such voxel -- the whole kernel's duration, whatever the other 80,000 cost)
+        constexpr int WALK = 16;
         int found = 0;
-        for (int s0 = 0; s0 < npts && found < T; s0 += 64) {
-            const int s = s0 + lane;
-            const bool match = s < npts && so[s] == h;
-            const unsigned long long bal = __ballot(match);
-            const int pos = found + __popcll(bal & ((1ull << lane) - 1ull));
-            if (match && pos < 64) s_best[wid][pos] = s;
-            found += __popcll(bal);
+        for (int s0 = 0; s0 < npts && found < T; s0 += 64 * WALK) {
+            int sv[WALK];
+#pragma unroll
+            for (int u = 0; u < WALK; ++u) {
+                const int s = s0 + u * 64 + lane;
+                sv[u] = s < npts ? so[s] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < WALK; ++u) {
+                const bool match = sv[u] == h;
+                const unsigned long long bal = __ballot(match);
+                const int pos = found + __popcll(bal & ((1ull << lane) - 1ull));
+                if (match && pos < 64) s_best[wid][pos] = s0 + u * 64 + lane;
+                found += __popcll(bal);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -274,14 +266,12 @@ __global__ __launch_bounds__(256) void vox_gather(const float *__restrict__ pcd,
     const int kept = min(n, T);
 
     // ---- stage the kept point group in LDS
-    float px = 0.f, py = 0.f, pz = 0.f;
     if (lane < kept) {
         const int p = perm ? perm[(size_t)f * cap + best] : best;
         const float *row = pcd + ((size_t)f * cap + p) * ncol;
-        px = row[0]; py = row[1]; pz = row[2];
-        s_pts[wid][lane][0] = px;
-        s_pts[wid][lane][1] = py;
-        s_pts[wid][lane][2] = pz;
+        s_pts[wid][lane][0] = row[0];
+        s_pts[wid][lane][1] = row[1];
+        s_pts[wid][lane][2] = row[2];
         s_pts[wid][lane][3] = row[3];
         s_pts[wid][lane][4] = ncol > 4 ? row[4] : 0.f;
         s_pts[wid][lane][5] = ncol > 5 ? row[5] : 0.f;
@@ -309,8 +299,7 @@ __global__ __launch_bounds__(256) void vox_gather(const float *__restrict__ pcd,
         cx = (double)sx / (double)kept; cy = (double)sy / (double)kept; cz = (double)sz / (double)kept;
     }
 
-    // ---- coalesced write of the [T][C] block; padded rows carry -centroid in cols 3:6
-    //      (Preprocessing.py:115)
+    // ---- coalesced write of the [T][C] block; padded rows carry -centroid in cols 3:6 (Preprocessing.py:115)
     float *out = voxels + (size_t)dst * (size_t)T * C;
     for (int e = lane; e < T * C; e += 64) {
         const int t = e / C, c = e - t * C;
@@ -335,6 +324,150 @@ __global__ __launch_bounds__(256) void vox_gather(const float *__restrict__ pcd,
         cd[2] = (long long)(int)((key >> 21) & 0x1fffff) - KEY_BIAS;
         cd[3] = (long long)(int)((key >> 42) & 0x1fffff) - KEY_BIAS;
         counts[dst] = kept;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();                   // s_best / s_pts are reused by the next wide voxel of this wave
+}
+
+constexpr int VG = 16;                  // lanes per voxel in the narrow path
+
+template <int C>
+__global__ __launch_bounds__(256) void vox_gather(const float *__restrict__ pcd, const int *__restrict__ perm,
+                                                  const int *__restrict__ n_points, int cap, int ncol, int T, int F,
+                                                  int cap_voxels, int concat, VoxWs w, float *__restrict__ voxels,
+                                                  long long *__restrict__ coords, int *__restrict__ counts,
+                                                  int *__restrict__ n_voxels, int *__restrict__ vox_off,
+                                                  int *__restrict__ status) {
+    extern __shared__ float s_img[];                   // [wave][group][T * C] (sized by the launch: 16 * T * C floats)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int sub = lane >> 4, sl = lane & (VG - 1);
+    if (blockIdx.x == 0 && threadIdx.x <= F) {          // per-frame counts / offsets for the caller
+        const int f = threadIdx.x;
+        if (vox_off) vox_off[f] = w.frame_base[f];
+        if (f < F) {
+            const int nv = w.frame_base[f + 1] - w.frame_base[f];
+            n_voxels[f] = nv;
+            if (!concat && nv > cap_voxels) atomicOr(status, 2);
+        }
+        if (f == F && concat && w.frame_base[F] > cap_voxels) atomicOr(status, 2);
+    }
+    // frame of the voxels: the F + 1 bases in ONE load (lane k holds base k; F < 64)
+    const int fb = lane <= F ? w.frame_base[lane] : 0x7fffffff;
+    const int Vtot = __shfl(fb, F, 64);
+    // the launch cannot know the voxel count (it lives on the device): a fixed grid walks the voxels, so that the cost follows the
+    // voxels that exist and not the capacity (the first form launched a wave per POSSIBLE voxel: 480 k waves that loaded the
+    // bases and left -- 59 rounds of the chip's wave slots -- were most of its 0.12 ms)
+    // neighbouring voxel ids go to DIFFERENT waves (group g of wave W takes voxel base + g * waves + W): ids follow first
+    // appearance in the stream, so a frame's first ids are its most populated voxels -- the ones that need the wide path, which
+    // a wave runs one after the other
+    const int nw = gridDim.x * 4, wv = blockIdx.x * 4 + wid;
+    for (int base = 0; base < Vtot; base += nw * 4) {   // whole waves: no block-wide barrier below
+    const int v = base + sub * nw + wv;
+    int f = 0;
+    for (int k = 1; k < F; ++k) f += v >= __shfl(fb, k, 64);
+    f = v < Vtot ? f : 0;
+    const int vl = v - __shfl(fb, f, 64);
+    const long long dst = concat ? (long long)v : (long long)f * cap_voxels + vl;
+    const bool ok = v < Vtot && (concat ? v < cap_voxels : vl < cap_voxels);
+    const int h = ok ? w.vox_slot[v] : 0;
+    const size_t slot = (size_t)f * w.slots + h;
+    const int n = ok ? w.scount[slot] : 0;
+    const bool narrow = ok && n <= VG && n <= T;
+
+    if (narrow) {
+        // ---- rank the (at most 16) members inside the group; padding candidates are distinct and larger than any position
+        const int cand = sl < n ? w.bucket[slot * BK + sl] : 0x7fffff00 + sl;
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < VG; ++j) rank += __shfl(cand, (lane & ~(VG - 1)) + j, 64) < cand;
+        // lane of rank r receives the r-th smallest position (a permutation inside the group)
+        const int best = __builtin_amdgcn_ds_permute(((lane & ~(VG - 1)) + rank) << 2, cand);
+        const int kept = n;
+        float px = 0.f, py = 0.f, pz = 0.f, p3 = 0.f, p4 = 0.f, p5 = 0.f;
+        if (sl < kept) {
+            const int p = perm ? perm[(size_t)f * cap + best] : best;
+            const float *row = pcd + ((size_t)f * cap + p) * ncol;
+            px = row[0]; py = row[1]; pz = row[2]; p3 = row[3];
+            p4 = ncol > 4 ? row[4] : 0.f;
+            p5 = ncol > 5 ? row[5] : 0.f;
+        }
+        // ---- centroid: sequential sum in stream order over the group's lanes
+        double cx, cy, cz;
+        const int g0 = lane & ~(VG - 1);
+        if (C == 9) {
+            double sx = 0.0, sy = 0.0, sz = 0.0;
+#pragma unroll 2
+            for (int j = 0; j < VG; ++j) {
+                const float xj = __shfl(px, g0 + j, 64), yj = __shfl(py, g0 + j, 64), zj = __shfl(pz, g0 + j, 64);
+                if (j < kept) { sx += (double)xj; sy += (double)yj; sz += (double)zj; }
+            }
+            cx = sx / (double)kept; cy = sy / (double)kept; cz = sz / (double)kept;
+        } else {
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll 2
+            for (int j = 0; j < VG; ++j) {
+                const float xj = __shfl(px, g0 + j, 64), yj = __shfl(py, g0 + j, 64), zj = __shfl(pz, g0 + j, 64);
+                if (j < kept) { sx += xj; sy += yj; sz += zj; }
+            }
+            cx = (double)sx / (double)kept; cy = (double)sy / (double)kept; cz = (double)sz / (double)kept;
+        }
+        // ---- the [T][C] block is laid out in LDS -- lane t forms the nine numbers of point t ONCE (the f64 subtraction of the
+        // centroid per point, not per output element), the lanes share the padded rows (which carry -centroid in cols 3:6,
+        // Preprocessing.py:115) -- and then copied out, 64 bytes per group and store, without any index arithmetic
+        float *img = s_img + (size_t)(wid * 4 + sub) * T * C;
+        const float ncx = (float)(0.0 - cx), ncy = (float)(0.0 - cy), ncz = (float)(0.0 - cz);
+        for (int t = sl; t < T; t += VG) {
+            float *r = img + t * C;
+            if (t < kept) {                            // t == sl: this lane's own point
+                r[0] = px; r[1] = py; r[2] = pz;
+                r[3] = (float)((double)px - cx); r[4] = (float)((double)py - cy); r[5] = (float)((double)pz - cz);
+                r[6] = p3;
+                if (C == 9) { r[7] = p4; r[8] = p5; }
+            } else {
+                r[0] = 0.f; r[1] = 0.f; r[2] = 0.f; r[3] = ncx; r[4] = ncy; r[5] = ncz; r[6] = 0.f;
+                if (C == 9) { r[7] = 0.f; r[8] = 0.f; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float *out = voxels + (size_t)dst * (size_t)T * C;
+        for (int e = sl; e < T * C; e += VG) out[e] = img[e];
+        if (sl == 0) {
+            const unsigned long long key = w.keys[slot];
+            long long *cd = coords + (size_t)dst * 4;
+            cd[0] = concat ? f : 0;
+            cd[1] = (long long)(int)(key & 0x1fffff) - KEY_BIAS;
+            cd[2] = (long long)(int)((key >> 21) & 0x1fffff) - KEY_BIAS;
+            cd[3] = (long long)(int)((key >> 42) & 0x1fffff) - KEY_BIAS;
+            counts[dst] = kept;
+        }
+    }
+    // ---- a voxel that does not fit a group is left to vox_gather_wide (a wave per voxel): listed, in any order
+    if (ok && !narrow && sl == 0) w.wide_list[atomicAdd(&w.ticket[1], 1u)] = v;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();                   // the next round reuses the wave's LDS
+    }
+}
+
+// The voxels vox_gather listed (more than 16 members, 1.5 % on lidar frames): a wave per voxel, a fixed grid over the list
+template <int C>
+__global__ __launch_bounds__(256) void vox_gather_wide(const float *__restrict__ pcd, const int *__restrict__ perm,
+                                                       const int *__restrict__ n_points, int cap, int ncol, int T, int F,
+                                                       int cap_voxels, int concat, VoxWs w, float *__restrict__ voxels,
+                                                       long long *__restrict__ coords, int *__restrict__ counts) {
+    __shared__ int s_best[4][64];
+    __shared__ float s_pts[4][64][6];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int count = (int)__hip_atomic_load(&w.ticket[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int fb = lane <= F ? w.frame_base[lane] : 0x7fffffff;
+    for (int i = blockIdx.x * 4 + wid; i < count; i += gridDim.x * 4) {
+        const int v = w.wide_list[i];
+        const int f = __popcll(__ballot(lane >= 1 && lane < F && v >= fb));
+        const int vl = v - __shfl(fb, f, 64);
+        const long long dst = concat ? (long long)v : (long long)f * cap_voxels + vl;
+        const int h = w.vox_slot[v];
+        const int n = w.scount[(size_t)f * w.slots + h];
+        gather_wide<C>(pcd, perm, n_points, cap, ncol, T, w, voxels, coords, counts, f, dst, h, n, concat, s_best, s_pts, wid, lane);
     }
 }
 
@@ -398,13 +531,22 @@ extern "C" int mvx_voxelize_frames(const float *pcd, const int32_t *perm, const 
     MVX_LAUNCH_CHECK();
     const long long vmax = concat ? (cap_voxels < (long long)cap_points * n_frames ? cap_voxels : (long long)cap_points * n_frames)
                                   : (long long)cap_points * n_frames;
-    const dim3 gg(mvx_cdiv(vmax, 4));
+    const long long rounds16 = mvx_cdiv(vmax, 16); // four waves of four voxels per block and round
+    const dim3 gg((unsigned)(rounds16 < 2048 ? rounds16 : 2048));
     if (out_channels == 9)
-        hipLaunchKernelGGL(vox_gather<9>, gg, dim3(256), 0, st, pcd, perm, n_points, cap_points, ncol, T, n_frames, cap_voxels,
+        hipLaunchKernelGGL(vox_gather<9>, gg, dim3(256), 16 * T * 9 * sizeof(float), st, pcd, perm, n_points, cap_points, ncol, T, n_frames, cap_voxels,
                            concat, w, voxels, (long long *)coords, counts, n_voxels, vox_off, status);
     else
-        hipLaunchKernelGGL(vox_gather<7>, gg, dim3(256), 0, st, pcd, perm, n_points, cap_points, ncol, T, n_frames, cap_voxels,
+        hipLaunchKernelGGL(vox_gather<7>, gg, dim3(256), 16 * T * 7 * sizeof(float), st, pcd, perm, n_points, cap_points, ncol, T, n_frames, cap_voxels,
                            concat, w, voxels, (long long *)coords, counts, n_voxels, vox_off, status);
+    MVX_LAUNCH_CHECK();
+    const dim3 gw((unsigned)(rounds16 < 512 ? rounds16 : 512));
+    if (out_channels == 9)
+        hipLaunchKernelGGL(vox_gather_wide<9>, gw, dim3(256), 0, st, pcd, perm, n_points, cap_points, ncol, T, n_frames, cap_voxels,
+                           concat, w, voxels, (long long *)coords, counts);
+    else
+        hipLaunchKernelGGL(vox_gather_wide<7>, gw, dim3(256), 0, st, pcd, perm, n_points, cap_points, ncol, T, n_frames, cap_voxels,
+                           concat, w, voxels, (long long *)coords, counts);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }
