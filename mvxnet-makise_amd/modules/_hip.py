@@ -1038,6 +1038,8 @@ PRECUT_FWD = os.environ.get('MVX_PRECUT_FWD', '0') != '0'
 # four): the main queue's idle end of the step is not an idle chip, the HBM-bound apply pass and the MFMA-bound product slow each
 # other down by more than the overlap hides.
 TAIL_PARTS = max(1, int(os.environ.get('MVX_TAIL_PARTS', '1')))
+# MVX_FLAG_PRE_XCD_STRIPS of mvx_linear_wgrad_pre: every block of a row strip on the same XCD (developer knob, A/B runs)
+PRE_XCD_STRIPS = 4096 if os.environ.get('MVX_PRE_XCD', '0') != '0' else 0
 
 
 def precut_ok(split, rows, K, N):
@@ -1090,7 +1092,7 @@ def linear_wgrad_pre(x_planes, dz_planes, accumulate_into=None, rows=None):
         dw, flags = accumulate_into, FLAG_ACCUMULATE
     else:
         dw, flags = torch.empty((N, K), dtype=torch.float32, device=x_planes.device), 0
-    flags |= split_flags(3 if pieces == 3 else 4, True)
+    flags |= split_flags(3 if pieces == 3 else 4, True) | PRE_XCD_STRIPS
     nbytes = max(X.lib.mvx_linear_wgrad_pre_workspace_bytes(plane_rows, K, N), X.lib.mvx_linear_wgrad_pre_workspace_bytes(hi - lo, K, N))
     with _wgrad_scope(accumulate_into, x_planes, dz_planes) as scope:
         ws = workspace(nbytes, x_planes.device, 'lwgrad_pre_side' if isinstance(scope, _SideStream) else 'lwgrad_pre')

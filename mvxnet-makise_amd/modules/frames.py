@@ -92,6 +92,7 @@ def _stats(F, C, dev):
 
 
 SAMPLE_PLANES = os.environ.get('MVX_SAMPLE_PLANES', '1') != '0'   # the FPN sampler writes the operand planes of its rows itself (A/B: 0)
+TAPS_ON_SIDE = os.environ.get('MVX_TAPS_ON_SIDE', '1') != '0'   # the layers' tap sums in front of their weight gradient on the side stream (A/B: 0)
 BEV_FUSED = os.environ.get('MVX_BEV_FUSED', '1') != '0'   # conv3's BatchNorm apply writes the (F, C * D, H, W) map itself (A/B: 0)
 TAP_SKIP = os.environ.get('MVX_TAP_SKIP', '1') != '0'     # conv2 / conv3 forward: skip depth taps with a background-only source halo
 # DIAGNOSTIC ONLY (tools/knockout.sh): comma-separated kernel classes that are NOT launched, to measure what each class costs
@@ -647,6 +648,20 @@ def cml_backward(model, S, grad_mid, g_cl=None):
                                          ws.numel(), X.stream()), 'mvx_plane_tap_sums')
         return Tt
 
+    def tap_sums_side(name, dz, planes, Cn, tile_flags=None, inactive=None):
+        """The tap sums of a layer on the SIDE stream, in front of their first reader (the layer's weight gradient); returns
+        (T, event): the main stream goes straight from the BatchNorm backward to the input-gradient gather and waits for the
+        event only in front of input_grad_sums.  (T, None): computed inline."""
+        if not (TAPS_ON_SIDE and _hip.ASYNC_WGRAD) or 'tap_sums' in KNOCKOUT:
+            return _mut(name, tap_sums(dz, planes, Cn, tile_flags, inactive)), None
+        main = torch.cuda.current_stream(dev)
+        with _hip._SideStream(dz, tile_flags, inactive):
+            Tt = _mut(name, tap_sums(dz, planes, Cn, tile_flags, inactive))
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+        Tt.record_stream(main)                  # allocated on the side stream's pool, read by input_grad_sums on the main stream
+        return Tt, ev
+
     def dgrad_tiles(rec, dz, bflag):
         w = rec['w']
         co, ci = w.shape[0], w.shape[1]
@@ -700,17 +715,21 @@ def cml_backward(model, S, grad_mid, g_cl=None):
     # ---- conv3: dense gradient in, restricted gradient + closed-form plane sums out
     r3, r2 = S.convs[1], S.convs[0]
     dz3 = bn_relu_backward(g, r3['y'], r3['mi'], fs, X.ROWS_GRID, None, _grad_of(r3['b']))
-    T3 = _mut('T3', tap_sums(dz3, F * r3['dout'], r3['w'].shape[0]))
+    T3, ev3 = tap_sums_side('T3', dz3, F * r3['dout'], r3['w'].shape[0])
     _wgrad_bg(r3, dz3, T3, F, H, W)
     g2 = dgrad_tiles(r3, dz3, r3['bflag_in'])
+    if ev3 is not None:
+        torch.cuda.current_stream(dev).wait_event(ev3)
     A2 = _mut('A2', input_grad_sums(r3, T3))
     # ---- conv2
     dz2, inact2 = bn_bwd_tiles(g2, r2['y'], r2['mi'], r2['c_out'], r2['ybg_out'], A2, r2['bflag_out'], r2['dout'],
                                r2['w'].shape[0], r2['b'], True)
     inact2 = _mut('inact2', inact2)
-    T2 = _mut('T2', tap_sums(dz2, F * r2['dout'], r2['w'].shape[0], r2['bflag_out'], inact2))
+    T2, ev2 = tap_sums_side('T2', dz2, F * r2['dout'], r2['w'].shape[0], r2['bflag_out'], inact2)
     _wgrad_bg(r2, dz2, T2, F, H, W)
     g1 = dgrad_tiles(r2, dz2, r2['bflag_in'])
+    if ev2 is not None:
+        torch.cuda.current_stream(dev).wait_event(ev2)
     A1 = _mut('A1', input_grad_sums(r2, T2))
     # ---- conv1 (voxel-GEMM factorisation): gradient only next to the voxels
     c1 = S.conv1
@@ -722,7 +741,10 @@ def cml_backward(model, S, grad_mid, g_cl=None):
     X.check(X.lib.mvx_sparse_conv_gather_dz_frames(X.ptr(dz1), X.ptr(fs.coords), Vt, X.ptr(G), c1['D0'], c1['D1'], H, W, cout,
                                                    cm._sd, cm._pd, fs.desc.ref(), X.stream()), 'mvx_sparse_conv_gather_dz_frames')
     _hip.tag_amax(G, _hip.amax_of(dz1))                                    # G's rows are rows of dz1
-    dw_all = _hip.linear_wgrad(c1['feat'], G)                              # (27*cout, cin), main stream (small)
+    # conv1's weight gradient ((27 * cout, cin) = G^T feat, then reordered into the parameter's layout): off the main stream like
+    # the other weight gradients -- the main stream goes on to the input gradient
+    with (_hip._SideStream(c1['feat'], G) if TAPS_ON_SIDE else _hip._Inline()):
+        dw_all = _hip.linear_wgrad(c1['feat'], G)
     with _hip._SideStream(dw_all):
         _grad_of(w1).add_(dw_all.reshape(3, 3, 3, cout, cin).permute(3, 4, 0, 1, 2))
     # dfeat = G w_all: the weight as a row-major [cin][27 cout] matrix, so that both operands are read along k
