@@ -324,6 +324,7 @@ def prepare_frame_set(batch, T=None, sample=None, grid=None):
     return fs, live, counts, status_v
 
 
+PREP_EARLY = _os.environ.get('MVX_PREP_EARLY', '1') != '0'      # ... enqueued between this step's forward and backward (0: after the backward)
 PREP_STREAM = _os.environ.get('MVX_PREP_STREAM', '1') != '0'    # next batch prepared on its own stream (host reads return early)
 PRESAMPLE = _os.environ.get('MVX_PRESAMPLE', '1') != '0'        # ... including the FPN feature sampling of its real rows (frames.sample_rows)
 # Frame-set lanes: the frames of a step split into this many frame sets that run on their own streams, so that the small
@@ -498,11 +499,23 @@ def train_step_frame_set(model, batch, grad_mid, imsize, ready=None, prepare_nex
             gm = grad_mid if grad_mid.shape[0] == 1 or len(live) == batch.n_frames else grad_mid[live]
             with torch.no_grad():
                 mid, saved = fr.middle_forward(model, fs, [batch.fpn_levels[f] for f in live], imsize, statuses)
+                if prepare_next is not None and PREP_STREAM and PREP_EARLY:
+                    # the next batch's preparation is enqueued BEFORE this step's backward: its HBM-bound kernels then run beside
+                    # the backward's first convolutions instead of beside the step's last weight gradient, which nothing else
+                    # hides (the step ended when the preparation did, 0.17 ms after the last gradient kernel)
+                    prep = _prep_stream(dev)
+                    _wait_created(prep, prepare_next)
+                    with torch.cuda.stream(prep):
+                        nr = prepare_frame_set(prepare_next, sample=(model.head, imsize) if PRESAMPLE else None,
+                                               grid=model if PREGRID else None)
+                        ev = torch.cuda.Event()
+                        ev.record(prep)
+                    next_ready = nr + (ev,)
                 fr.middle_backward(model, saved, gm)
             if keep_mid is not None:
                 for k in range(len(live)):
                     keep_mid.append(mid[k:k + 1])
-        if prepare_next is not None:
+        if prepare_next is not None and next_ready is None:
             if PREP_STREAM:
                 prep = _prep_stream(dev)
                 _wait_created(prep, prepare_next)
