@@ -324,7 +324,11 @@ def prepare_frame_set(batch, T=None, sample=None, grid=None):
     return fs, live, counts, status_v
 
 
-PREP_EARLY = _os.environ.get('MVX_PREP_EARLY', '1') != '0'      # ... enqueued between this step's forward and backward (0: after the backward)
+# ... enqueued between this step's forward and backward instead of after the backward.  OFF: +0.6 % of the step (484.4 -> 487.5
+# frames/s, the preparation no longer runs beside the step's last weight gradient), but the host is so far ahead that the
+# preparation then lands beside conv2's forward gather, which goes from 0.58 to 0.90 ms (profiles/r05b_prep_early_*): the
+# convolution -- the kernel the roofline is quoted on -- loses more than the tail gains once a step is not host-paced
+PREP_EARLY = _os.environ.get('MVX_PREP_EARLY', '0') != '0'
 PREP_STREAM = _os.environ.get('MVX_PREP_STREAM', '1') != '0'    # next batch prepared on its own stream (host reads return early)
 PRESAMPLE = _os.environ.get('MVX_PRESAMPLE', '1') != '0'        # ... including the FPN feature sampling of its real rows (frames.sample_rows)
 # Frame-set lanes: the frames of a step split into this many frame sets that run on their own streams, so that the small

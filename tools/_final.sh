@@ -1,0 +1,10 @@
+set -e
+ROOT=$(pwd)
+bash tools/profile_round.sh r05b > gpurun_out/r05b_profile_round.log 2>&1 || { tail -30 gpurun_out/r05b_profile_round.log; exit 1; }
+python3 tools/pmc_summary.py gpurun_out/prof_r05b gpurun_out/r05b_pmc_summary.json gpurun_out/r05b_traffic.json > gpurun_out/r05b_pmc_summary.log 2>&1 || { tail gpurun_out/r05b_pmc_summary.log; exit 1; }
+python3 tools/pmc_table.py gpurun_out/prof_r05b > gpurun_out/r05b_pmc_table.txt 2>&1 || true
+python3 tools/kstats.py gpurun_out/prof_r05b/stats 25 60 > gpurun_out/r05b_hot_kstats.txt 2>&1 || true
+python3 tools/timeline.py gpurun_out/prof_r05b/stats FusedOptimizer > gpurun_out/r05b_hot_timeline.txt 2>&1 || true
+bash tools/prof_mode.sh r05b_full --mode full
+bash tools/prof_mode.sh r05b_vfe --mode vfe
+tail -3 gpurun_out/r05b_pmc_summary.log
