@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) void vox_gather_wide(const float *__restrict__
 
 }  // namespace
 
-extern "C" int mvx_abi_version(void) { return 7; }
+extern "C" int mvx_abi_version(void) { return 8; }
 
 // fp16-piece operand scaling: see mvx_split_operand_amax in include/mvx_hip.h and split_common.h
 static thread_local SplitAmax t_split_amax = {nullptr, nullptr, 0};

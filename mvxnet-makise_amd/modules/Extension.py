@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MVX_HIP_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'libmvx_hip.so'))
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _p = ctypes.c_void_p
 _i32 = ctypes.c_int32
