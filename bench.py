@@ -358,7 +358,7 @@ def compact_line(out, detail_path):
     if 'cpu_baseline' in out:
         line['cpu_baseline'] = {k: out['cpu_baseline'][k] for k in ('value', 'unit', 'cores', 'kind', 'sample', 'voxel_indices_vs_oracle')
                                 if k in out['cpu_baseline']}
-    for k in ('host_enqueue_ms_per_step', 'library_launches_per_step', 'allreduce_ms_per_call', 'last_losses', 'INVALID_diagnostic_knockout',
+    for k in ('host_enqueue_ms_per_step', 'ms_per_step_all_timers', 'timers', 'library_launches_per_step', 'allreduce_ms_per_call', 'last_losses', 'INVALID_diagnostic_knockout',
               'gradient_fingerprint'):
         if k in out:
             line[k] = out[k]
@@ -638,9 +638,18 @@ def _run(args, rank, world, dev):
     step = {'hot': step_hot, 'vfe': step_vfe, 'fusion': step_fusion, 'dropin': step_dropin, 'full': step_full}[args.mode]
     host_ms, exec_stages, launches = [], [], []
 
-    def timed_run(warmup, steps, fn=None):
+    # Timers of the timed region: the HEADLINE run records HIP events only around the kernel its roofline is quoted on (two event
+    # records per library call are ~180 markers per hot step and cost 0.5 ms of it: tools/soak_plain.py, the same loop without
+    # any timer, runs 7.65 ms where the fully instrumented step takes 8.2); `other_kernels` and `hbm_stages` come from a second,
+    # shorter pass with every timer on, whose own step time is reported beside them (`ms_per_step_all_timers`).
+    ROOF_TIMERS = {'hot': ('conv3d_gather_bg', 'conv3d_gather_tiles', 'conv3d_gather'), 'fusion': ('hbm:feature_sample',),
+                   'vfe': ('hbm:voxelize',)}
+    ROOF_TIMERS['full'] = ROOF_TIMERS['dropin'] = ROOF_TIMERS['hot']
+
+    def timed_run(warmup, steps, fn=None, names=None):
         fn = step if fn is None else fn
         nv = None
+        _hip.TIMER_NAMES = frozenset(names) if names is not None else None
         _hip.KERNEL_TIMERS = {}                           # the warm-up also fills the pool of timing events
         for _ in range(warmup):
             nv = fn()
@@ -673,6 +682,7 @@ def _run(args, rank, world, dev):
         launches.append((_hip.X.lib.mvx_launch_count() - l0) / steps)
         host_ms.append(host_dt / steps * 1e3)
         tm, _hip.KERNEL_TIMERS = _hip.KERNEL_TIMERS, None
+        _hip.TIMER_NAMES = None
         exec_stages.append(int(_hip.EXEC_STAGES.item()) if _hip.EXEC_STAGES is not None else 0)
         if world > 1:
             t = torch.tensor([dt_], dtype=torch.float64, device=dev)
@@ -736,7 +746,10 @@ def _run(args, rank, world, dev):
         # BASELINE config 2: the voxel indices of every frame of the run are checked bit-exact against the C oracle (part
         # of the CPU-baseline leg: the only place the benchmark touches oracle/)
         vfe_check = voxel_index_check(batch, args.workload, frame_ids, args.points)
-    nvox, dt, timers = timed_run(args.warmup, args.steps)
+    nvox, dt, timers = timed_run(args.warmup, args.steps, names=ROOF_TIMERS[args.mode])
+    check_status()
+    n_detail = min(args.steps, 10)
+    _, dt_detail, timers_all = timed_run(2, n_detail)     # every timer on: other_kernels, hbm_stages
     check_status()
 
     def host_probe(n=3):
@@ -763,7 +776,7 @@ def _run(args, rank, world, dev):
         b2 = make_batch(frame_ids, dev, args.points, other)
         state['ready'] = None
         n_alt = max(ALT_STEPS, args.steps) if args.steps >= 5 else args.steps      # alternative modes are timed over >= 20 steps
-        nv2, dt2, tm2 = timed_run(3, n_alt, lambda: step_hot(b2))
+        nv2, dt2, tm2 = timed_run(3, n_alt, lambda: step_hot(b2), names=ROOF_TIMERS['hot'])
         check_status()
         alt.append({'workload': other, 'convmath': main_math, 'value': frames_total * n_alt / dt2, 'unit': 'frames/s', 'steps': n_alt,
                     'ms_per_step': dt2 / n_alt * 1e3, 'voxels_per_frame': nv2,
@@ -777,7 +790,7 @@ def _run(args, rank, world, dev):
                 continue
             cfg.config['convmath'] = math
             try:
-                _, dt3, tm3 = timed_run(3, n_alt)
+                _, dt3, tm3 = timed_run(3, n_alt, names=ROOF_TIMERS['hot'])
             finally:
                 cfg.config['convmath'] = main_math
                 state['ready'] = None
@@ -908,7 +921,10 @@ def _run(args, rank, world, dev):
             'config': {'workload': workload, 'mode': args.mode, 'frames_per_gpu': args.frames, 'voxels_per_frame': nvox,
                        'parallelism': 'dp%d' % world, 'frame_sets': bool(pl.BATCHED and args.mode != 'dropin')},
             'roofline': roof,
-            'hbm_stages': hbm_stages(timers),
+            'hbm_stages': hbm_stages(timers_all),
+            'ms_per_step_all_timers': dt_detail / n_detail * 1e3,
+            'timers': 'value / ms_per_step / roofline: HIP events around the roofline kernel only; other_kernels / hbm_stages: a second '
+                      'pass of %d steps with events around every library call (ms_per_step_all_timers)' % n_detail,
         }
         from modules import frames as _fr
         if _fr.KNOCKOUT:
@@ -917,7 +933,7 @@ def _run(args, rank, world, dev):
         # chip with the kernels of the other streams: side-stream weight gradients run beside main-stream convolutions)
         other = {}
         for name in ('conv3d_wgrad_bg', 'linear_fwd', 'linear_dgrad', 'linear_wgrad', 'rpn_conv', 'rpn_wgrad'):
-            evs = timers.get(name, [])
+            evs = timers_all.get(name, [])
             if evs:
                 tms = sum(s.elapsed_time(e) for s, e, _ in evs)
                 other[name] = {'launches': len(evs), 'avg_launch_ms': tms / len(evs)}

@@ -73,14 +73,26 @@ class FrameSet:
         return self
 
 
-    def hand_over(self, stream):
-        """The set was built on another stream (input preparation): keep its tensors alive for ``stream`` too."""
+    def hand_over(self, stream, fenced=False):
+        """The set was built on another stream (input preparation): keep its tensors alive for ``stream`` too.
+        ``fenced`` (modules/pipeline.py): the consumer records an end-of-step event and the preparation stream waits for it before
+        it allocates again, so the tensors only have to stay referenced until the step function returns -- no
+        ``record_stream``, whose release depends on when the allocator next polls its events (the peak crept 4 % over 1,000
+        identical steps and the pools held 2.6 x the live bytes, profiles/r05b_soak_hot.txt)."""
+        kept = []
         for t in (self.voxels, self.coords, self.row_map, self.rows_sel, self.n_real_dev, self.real_off_dev, self.voff,
                   self.vcnt, self.row_w, self.fusion_row_w) + (tuple(self.sampled) if self.sampled is not None else ()) + \
                  (tuple(self.grid['tensors']) if self.grid is not None else ()):
-            t.record_stream(stream)
-            if getattr(t, '_mvx_planes', None) is not None:      # the sampled features' planes of bf16 pieces (sample_rows)
-                t._mvx_planes.record_stream(stream)
+            planes = getattr(t, '_mvx_planes', None)                 # the sampled features' planes of bf16 pieces (sample_rows)
+            amax = _hip.amax_of(t)
+            for u in (t, planes, amax):
+                if u is None:
+                    continue
+                if fenced:
+                    kept.append(u)
+                else:
+                    u.record_stream(stream)
+        self._kept = kept                                            # sampled / grid are dropped mid-step: their tensors stay here
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -141,6 +141,28 @@ def _prep_stream(device):
     return _PREP_STREAMS[device.index]
 
 
+# End-of-step fence between the training stream and the preparation stream (FrameSet.hand_over(..., fenced=True)): a step
+# function records an event on the training stream once everything that reads the prepared tensors is enqueued (after it joined
+# the side stream), the tensors stay referenced until the step function returns, and every preparation first waits for the
+# latest fence -- so a block of the preparation stream's pool is never rewritten before its last reader has run, without
+# `record_stream`.  MVX_PREP_FENCE=0: the record_stream hand-over of rounds 2-4.
+PREP_FENCE = _os.environ.get('MVX_PREP_FENCE', '1') != '0'
+_FENCE = {}
+
+
+def _fence_record(device):
+    if PREP_FENCE and PREP_STREAM:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        _FENCE[device.index] = ev
+
+
+def _fence_wait(prep, device):
+    ev = _FENCE.get(device.index)
+    if PREP_FENCE and ev is not None:
+        prep.wait_event(ev)
+
+
 _PINNED = {}
 
 
@@ -492,7 +514,7 @@ def train_step_frame_set(model, batch, grad_mid, imsize, ready=None, prepare_nex
         main.wait_event(ev_ready)
         status.record_stream(main)
         if fs is not None:
-            fs.hand_over(main)
+            fs.hand_over(main, fenced=PREP_FENCE)
     statuses = [status]
     old_sink, _hip.GRAD_SINK = _hip.GRAD_SINK, True
     next_ready = None
@@ -509,6 +531,7 @@ def train_step_frame_set(model, batch, grad_mid, imsize, ready=None, prepare_nex
                     # hides (the step ended when the preparation did, 0.17 ms after the last gradient kernel)
                     prep = _prep_stream(dev)
                     _wait_created(prep, prepare_next)
+                    _fence_wait(prep, dev)
                     with torch.cuda.stream(prep):
                         nr = prepare_frame_set(prepare_next, sample=(model.head, imsize) if PRESAMPLE else None,
                                                grid=model if PREGRID else None)
@@ -523,6 +546,7 @@ def train_step_frame_set(model, batch, grad_mid, imsize, ready=None, prepare_nex
             if PREP_STREAM:
                 prep = _prep_stream(dev)
                 _wait_created(prep, prepare_next)
+                _fence_wait(prep, dev)
                 with torch.cuda.stream(prep):
                     nr = prepare_frame_set(prepare_next, sample=(model.head, imsize) if PRESAMPLE else None, grid=model if PREGRID else None)
                     ev = torch.cuda.Event()
@@ -534,6 +558,7 @@ def train_step_frame_set(model, batch, grad_mid, imsize, ready=None, prepare_nex
         _hip.GRAD_SINK = old_sink
         _hip.arena_end()
         _hip.join_side_stream()
+        _fence_record(dev)
     if prepare_next is not None:
         return counts, statuses, next_ready
     return counts, statuses
@@ -559,7 +584,7 @@ def train_step_rows_only(model, batch, state, ready=None, prepare_next=None, wit
         main.wait_event(ev_ready)
         status.record_stream(main)
         if fs is not None:
-            fs.hand_over(main)
+            fs.hand_over(main, fenced=PREP_FENCE)
     old_sink, _hip.GRAD_SINK = _hip.GRAD_SINK, True
     old_async, _hip.ASYNC_WGRAD = _hip.ASYNC_WGRAD, True
     next_ready = None
@@ -583,6 +608,7 @@ def train_step_rows_only(model, batch, state, ready=None, prepare_next=None, wit
             if PREP_STREAM:
                 prep = _prep_stream(dev)
                 _wait_created(prep, prepare_next)
+                _fence_wait(prep, dev)
                 with torch.cuda.stream(prep):
                     nr = prepare_frame_set(prepare_next)
                     ev = torch.cuda.Event()
@@ -595,6 +621,7 @@ def train_step_rows_only(model, batch, state, ready=None, prepare_next=None, wit
         _hip.ASYNC_WGRAD = old_async
         _hip.arena_end()
         _hip.join_side_stream()
+        _fence_record(dev)
     st_out = state.pop('statuses', [status])
     if prepare_next is not None:
         return counts, st_out, next_ready
@@ -697,7 +724,7 @@ def train_step_full(model, batch, targets, criterion, anchors, imsize, ready=Non
         main.wait_event(ev_ready)
         status.record_stream(main)
         if fs is not None:
-            fs.hand_over(main)
+            fs.hand_over(main, fenced=PREP_FENCE)
         for t in targets:
             if t is not None:
                 for x in tuple(t[0]) + tuple(t[1]) + (t[2], t[3]):
@@ -753,6 +780,7 @@ def train_step_full(model, batch, targets, criterion, anchors, imsize, ready=Non
             if PREP_STREAM:
                 prep = _prep_stream(dev)
                 _wait_created(prep, nb)
+                _fence_wait(prep, dev)
                 with torch.cuda.stream(prep):
                     nr = prepare_frame_set(nb, sample=(model.head, hw) if PRESAMPLE else None, grid=model if PREGRID else None)
                     nt = target_fn()
@@ -769,6 +797,7 @@ def train_step_full(model, batch, targets, criterion, anchors, imsize, ready=Non
         _hip.ASYNC_WGRAD = old_async
         _hip.arena_end()
         _hip.join_side_stream()
+        _fence_record(dev)
     return out
 
 
