@@ -691,6 +691,11 @@ int mvx_voxel_row_offsets_frames(const int32_t *row_map, int32_t n_voxels, int32
 int mvx_vfe_compact_input_frames(const float *voxels, int32_t vox_channels, const int32_t *rows_sel, const float *imfeat,
                                  int32_t feat_channels, int32_t n_real, int32_t n_voxels, float *out,
                                  const mvx_frames_t *frames_host, void *stream);
+/* ... with a row pitch ld >= 7 + feat_channels (out [n_real + n_voxels][ld], the extra columns zero): a pitch that is a multiple of
+ * 4 floats lets mvx_linear_forward* / mvx_linear_wgrad read the rows with 16-byte loads (k = ld, the weight padded with zero columns) */
+int mvx_vfe_compact_input_pitch_frames(const float *voxels, int32_t vox_channels, const int32_t *rows_sel, const float *imfeat,
+                                       int32_t feat_channels, int32_t n_real, int32_t n_voxels, float *out, int32_t ld,
+                                       const mvx_frames_t *frames_host, void *stream);
 int mvx_vfe_compact_input_backward_frames(const float *grad_out, int32_t feat_channels, int32_t n_real, int32_t n_voxels,
                                           float *dimfeat, double *scratch, const mvx_frames_t *frames_host, void *stream);
 /* voxels of all frames back to back ([vox_off[F]][t][vox_channels]); real_off i32 [n_frames + 1] on the DEVICE receives the

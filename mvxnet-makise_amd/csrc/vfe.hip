@@ -255,15 +255,18 @@ __global__ void voxel_row_offsets(const int *__restrict__ row_map, int V, int T,
 
 // VFE-1 input in compact form: real row j = [voxels[r][0:7], imfeat[j][0:F]], padded row of voxel v =
 // [0 x 7, imfeat[n_real][0:F]] (imfeat's last row is the fusion output of the shared padded row).
+// ld >= 7 + F: the row pitch of `out`; columns [7 + F, ld) are written as zeros (a pitch that is a multiple of 4 lets the row GEMM
+// and its weight gradient read the rows with 16-byte loads: 23 floats per row made both fall to their scalar-load forms)
 __global__ void vfe_compact_input(const float *__restrict__ vox, int vc, const int *__restrict__ rows_sel,
                                   const float *__restrict__ imfeat, int F, int n_real, int V, float *__restrict__ out,
-                                  FrameMap fm) {
+                                  FrameMap fm, int ld) {
     const int W = 7 + F;
-    const long long total = (long long)(n_real + V) * W;
+    const long long total = (long long)(n_real + V) * ld;
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const int j = (int)(e / W), c = (int)(e % W);
+        const int j = (int)(e / ld), c = (int)(e % ld);
         float val;
-        if (j < n_real) val = c < 7 ? vox[(size_t)rows_sel[j] * vc + c] : imfeat[(size_t)j * F + c - 7];
+        if (c >= W) val = 0.f;
+        else if (j < n_real) val = c < 7 ? vox[(size_t)rows_sel[j] * vc + c] : imfeat[(size_t)j * F + c - 7];
         else val = c < 7 ? 0.f : imfeat[(size_t)(n_real + fm_frame_of(fm, j - n_real)) * F + c - 7];   // its frame's shared padded row
         out[e] = val;
     }
@@ -448,18 +451,26 @@ extern "C" int mvx_voxel_row_offsets(const int32_t *row_map, int32_t n_voxels, i
     return mvx_voxel_row_offsets_frames(row_map, n_voxels, t, n_real, voff, vcnt, row_w, nullptr, nullptr, stream);
 }
 
-extern "C" int mvx_vfe_compact_input_frames(const float *voxels, int32_t vox_channels, const int32_t *rows_sel,
-                                            const float *imfeat, int32_t feat_channels, int32_t n_real, int32_t n_voxels,
-                                            float *out, const mvx_frames_t *frames_host, void *stream) {
+// ... with a row pitch: out is [n_real + n_voxels][ld], ld >= 7 + feat_channels, the columns beyond 7 + feat_channels zero
+extern "C" int mvx_vfe_compact_input_pitch_frames(const float *voxels, int32_t vox_channels, const int32_t *rows_sel,
+                                                  const float *imfeat, int32_t feat_channels, int32_t n_real, int32_t n_voxels,
+                                                  float *out, int32_t ld, const mvx_frames_t *frames_host, void *stream) {
     MVX_CHECK_ARG(voxels && rows_sel && imfeat && out && vox_channels >= 7 && feat_channels > 0);
-    MVX_CHECK_ARG(n_real >= 0 && n_voxels >= 0);
-    const long long total = (long long)(n_real + n_voxels) * (7 + feat_channels);
+    MVX_CHECK_ARG(n_real >= 0 && n_voxels >= 0 && ld >= 7 + feat_channels);
+    const long long total = (long long)(n_real + n_voxels) * ld;
     if (total == 0) return MVX_OK;
     VFE_FRAMES(fm);
     hipLaunchKernelGGL(vfe_compact_input, dim3(mvx_cdiv(total, 256) > 2048 ? 2048 : mvx_cdiv(total, 256)), dim3(256), 0,
-                       (hipStream_t)stream, voxels, vox_channels, rows_sel, imfeat, feat_channels, n_real, n_voxels, out, fm);
+                       (hipStream_t)stream, voxels, vox_channels, rows_sel, imfeat, feat_channels, n_real, n_voxels, out, fm, ld);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
+}
+
+extern "C" int mvx_vfe_compact_input_frames(const float *voxels, int32_t vox_channels, const int32_t *rows_sel,
+                                            const float *imfeat, int32_t feat_channels, int32_t n_real, int32_t n_voxels,
+                                            float *out, const mvx_frames_t *frames_host, void *stream) {
+    return mvx_vfe_compact_input_pitch_frames(voxels, vox_channels, rows_sel, imfeat, feat_channels, n_real, n_voxels, out,
+                                              7 + feat_channels, frames_host, stream);
 }
 
 extern "C" int mvx_vfe_compact_input(const float *voxels, int32_t vox_channels, const int32_t *rows_sel,

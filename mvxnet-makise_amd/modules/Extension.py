@@ -133,6 +133,7 @@ PROTOTYPES = {
     'mvx_bn_segment_max_frames': (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p, _p]),
     'mvx_voxel_row_offsets_frames': (_i32, [_p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p]),
     'mvx_vfe_compact_input_frames': (_i32, [_p, _i32, _p, _p, _i32, _i32, _i32, _p, _p, _p]),
+    'mvx_vfe_compact_input_pitch_frames': (_i32, [_p, _i32, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p]),
     'mvx_vfe_compact_input_backward_frames': (_i32, [_p, _i32, _i32, _i32, _p, _p, _p, _p]),
     'mvx_row_compact_map_frames': (_i32, [_p, _i32, _i64, _p, _p, _p, _p, _sz, _p, _p, _p]),
     'mvx_feature_sample_rows_frames': (_i32, [_p, _i32, _p, _i32, _p, _p, _i32, _i32, _f32, _f32, _f32, _p, _p, _p, _p, _p]),

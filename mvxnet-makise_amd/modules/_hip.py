@@ -1023,6 +1023,23 @@ def transposed_weight(w2):
     return hit[1]
 
 
+def padded_weight(w2, k):
+    """(N, k) copy of a (N, K <= k) weight view with zero columns appended, cached on the parameter like transposed_weight: the
+    operand of a row layer whose input rows were written with a pitch of k floats (frames._vfe_forward: 23 -> 24)."""
+    if w2.shape[1] == k:
+        return w2
+    base = w2._base if w2._base is not None else w2
+    cache = base.__dict__.setdefault('_mvx_wpad', {})
+    tag = (base._version, w2.data_ptr())
+    hit = cache.get((tuple(w2.shape), k))
+    if hit is None or hit[0] != tag:
+        wp = torch.zeros((w2.shape[0], k), dtype=w2.dtype, device=w2.device)
+        wp[:, :w2.shape[1]] = w2.detach()
+        hit = (tag, wp)
+        cache[(tuple(w2.shape), k)] = hit
+    return hit[1]
+
+
 # ---------------------------------------------------------------------------------------------
 # Row GEMMs on pre-cut operands (csrc/rowgemm_pre.hip): the operands are PLANES of 16-bit pieces, int16 (pieces, rows, k),
 # written by their producers; the GEMM moves them global -> LDS by DMA.  Used for the wide layers whose shape fills its

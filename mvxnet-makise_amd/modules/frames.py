@@ -105,6 +105,7 @@ def _stats(F, C, dev):
 
 SAMPLE_PLANES = os.environ.get('MVX_SAMPLE_PLANES', '1') != '0'   # the FPN sampler writes the operand planes of its rows itself (A/B: 0)
 TAPS_ON_SIDE = os.environ.get('MVX_TAPS_ON_SIDE', '1') != '0'   # the layers' tap sums in front of their weight gradient on the side stream (A/B: 0)
+ROW_PITCH4 = os.environ.get('MVX_ROW_PITCH4', '1') != '0'   # the VFE input rows with a pitch that is a multiple of 4 floats (A/B: 0)
 BEV_FUSED = os.environ.get('MVX_BEV_FUSED', '1') != '0'   # conv3's BatchNorm apply writes the (F, C * D, H, W) map itself (A/B: 0)
 TAP_SKIP = os.environ.get('MVX_TAP_SKIP', '1') != '0'     # conv2 / conv3 forward: skip depth taps with a background-only source halo
 # DIAGNOSTIC ONLY (tools/knockout.sh): comma-separated kernel classes that are NOT launched, to measure what each class costs
@@ -345,16 +346,20 @@ def _vfe_forward(bb, fs, x, S, eps):
     F, T, Rt, Vt = fs.F, fs.T, fs.Rt, fs.Vt
     # ---- concat with the 7 geometric channels (MVXNet.py:26): [real rows | one padded row per voxel]
     Fc = x.shape[1]
-    rows23 = torch.empty((Rt + Vt, 7 + Fc), dtype=torch.float32, device=dev)
-    X.check(X.lib.mvx_vfe_compact_input_frames(X.ptr(fs.vox2d), fs.vox2d.shape[1], X.ptr(fs.rows_sel), X.ptr(x), Fc, Rt, Vt,
-                                               X.ptr(rows23), fs.desc.ref(), X.stream()), 'mvx_vfe_compact_input_frames')
+    # rows of 7 + Fc = 23 floats are written with a pitch of 24 (one zero column): the first VFE layer and its weight gradient then
+    # read them with 16-byte loads (k = 24 against a weight padded with a zero column: the same sums) instead of falling to the
+    # scalar-load forms of their kernels (config 2: 106 / 170 us for 11 / 50 MB)
+    ldr = (7 + Fc + 3) & ~3 if ROW_PITCH4 else 7 + Fc
+    rows23 = torch.empty((Rt + Vt, ldr), dtype=torch.float32, device=dev)
+    X.check(X.lib.mvx_vfe_compact_input_pitch_frames(X.ptr(fs.vox2d), fs.vox2d.shape[1], X.ptr(fs.rows_sel), X.ptr(x), Fc, Rt, Vt,
+                                                     X.ptr(rows23), ldr, fs.desc.ref(), X.stream()), 'mvx_vfe_compact_input_pitch_frames')
     S.fc = Fc
     # ---- SVFE (voxelnet/Pipe.py:5-29) and FCN + max (VoxelNet.py:27-33)
     S.vfe = []
     x = rows23
     for vfe in (bb.svfe.vfe1, bb.svfe.vfe2):
         w, b = vfe.fcn.fc.weight, vfe.fcn.fc.bias
-        y, mi = linear_bn(x, w, b, fs, X.ROWS_VFE, fs.row_w, eps, 'vfe')
+        y, mi = linear_bn(x, _hip.padded_weight(w.reshape(w.shape[0], -1), x.shape[1]), b, fs, X.ROWS_VFE, fs.row_w, eps, 'vfe')
         Cn = w.shape[0]
         out = torch.empty((Rt + Vt, 2 * Cn), dtype=torch.float32, device=dev)
         am = torch.empty((Vt, Cn), dtype=torch.int32, device=dev)
@@ -796,7 +801,14 @@ def rows_backward(model, S, dfeat):
             X.check(X.lib.mvx_vfe_max_concat_backward(X.ptr(gx), X.ptr(am), X.ptr(dyh), Vt, T, Cn, X.ptr(fs.voff), X.ptr(fs.vcnt),
                                                       Rt, X.stream()), 'mvx_vfe_max_concat_backward')
         dz = bn_relu_backward(dyh, y, mi, fs, X.ROWS_VFE, fs.row_w, _grad_of(b), dz=dyh)
-        _linear_wgrad_side(x, dz, w)
+        w2 = w.reshape(w.shape[0], -1)
+        if x.shape[1] != w2.shape[1] and 'lin_wgrad' not in KNOCKOUT:
+            # rows with a padded pitch (23 -> 24): the gradient of the padded weight, its real columns added into the parameter's
+            with _hip._SideStream(x, dz):
+                dwp = _hip.linear_wgrad(x, dz)
+                _grad_of(w).view(w2.shape).add_(dwp[:, :w2.shape[1]])
+        else:
+            _linear_wgrad_side(x, dz, w)
         gx = _rows_dgrad(dz, w)
     # ---- concat backward: gradient of the fused image features ([real rows | shared padded row per frame])
     Fc = S.fc
