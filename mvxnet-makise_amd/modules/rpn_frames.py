@@ -29,6 +29,9 @@ R = _hip.STATS_REPLICAS
 TAPS2 = 16          # MVX_FLAG_TAPS2
 
 
+ROW_WGRAD_SIDE = __import__('os').environ.get('MVX_RPN_ROW_WGRAD_SIDE', '1') != '0'   # heads / deconv2 / deconv3 weight gradients on the side stream (A/B: 0)
+
+
 def _split():
     """convmath: bf16x3 / bf16x6 -> the 3x3 convolutions run on the split-MFMA kernels (csrc/conv3d_split.hip): the number of
     bf16 pieces per operand (0 = exact-f32 kernels)."""
@@ -324,7 +327,10 @@ def rpn_backward(rpn, S, d_heads):
     if _split() == 4 and _hip.amax_of(d_heads) is None:
         _hip.tensor_amax(d_heads)        # fp16x3: the loss gradient's range (9 MB: 5 us), else its weight gradient runs in bf16x6
     # heads
-    dwh = _hip.linear_wgrad(up, d_heads)                                   # (16, 768)
+    # (the row-GEMM weight gradients of the heads and of deconv2 / deconv3 run on the side stream like the convolutions': they
+    # were 0.41 ms of main-queue time per --mode full step)
+    with (_hip._SideStream(up, d_heads) if ROW_WGRAD_SIDE else _hip._Inline()):
+        dwh = _hip.linear_wgrad(up, d_heads)                               # (16, 768)
     with _hip._SideStream(dwh, d_heads):
         _grad_of(rpn.cls.weight).view(2, 768).add_(dwh[:2])
         _grad_of(rpn.reg.weight).view(14, 768).add_(dwh[2:])
@@ -342,7 +348,8 @@ def rpn_backward(rpn, S, d_heads):
                 'mvx_d2s_bn_apply_frames')
         dz0 = _bn_bwd(gt.view(-1, cout), rec['t'].view(-1, cout), rec['mi'], F, m.deconv.bias)
         dz = _retag(dz0.view(rec['t'].shape), dz0)
-        dw_all = _hip.linear_wgrad(rec['x'], dz)                           # (s*s*cout, cin)
+        with (_hip._SideStream(rec['x'], dz) if ROW_WGRAD_SIDE else _hip._Inline()):
+            dw_all = _hip.linear_wgrad(rec['x'], dz)                       # (s*s*cout, cin)
         with _hip._SideStream(dw_all):
             _grad_of(m.deconv.weight).add_(dw_all.view(s, s, cout, cin).permute(3, 2, 0, 1))
         # input gradient with the weight as a row-major [cin][s*s*cout] matrix (both operands read along k)
