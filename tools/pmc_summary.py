@@ -8,7 +8,7 @@ HBM bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950 counts a wide coalesced read at ha
 import collections, csv, glob, json, re, sys
 
 root, dst = sys.argv[1], sys.argv[2]
-WANT = ('conv3d_gather_pw', 'conv3d_gather_splitT', 'conv3d_wgrad4', 'linear_fwd', 'linear_wgrad', 'rowgemm_wgrad_pre', 'rowgemm_fwd_pre', 'split_rows_kernel', 'bn_apply', 'bn_bwd_apply',
+WANT = ('conv3d_gather_pw', 'conv3d_gather_splitT', 'conv3d_wgrad4', 'linear_fwd', 'linear_wgrad', 'rowgemm_wgrad_pre', 'rowgemm_fwd_pre', 'rowgemm_k128', 'bn_apply_tiles_bev', 'split_rows_kernel', 'bn_apply', 'bn_bwd_apply',
         'bn_bwd_reduce', 'bnb_tiles', 'sparse_conv_output', 'vox_gather', 'vox_insert', 'vox_scan', 'crop_write', 'feature_sample_rows')
 
 
