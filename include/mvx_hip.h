@@ -710,7 +710,8 @@ int mvx_feature_sample_rows_frames(const float *voxels, int32_t vox_channels, co
                                    const mvx_frames_t *frames_host,
                                    float *out_amax /* NULL, or 1 float RAISED to max |out| (zero it first): mvx_split_operand_amax */, void *stream);
 /* ... which also writes the rows as planes of bf16 pieces, u16 [3][plane_rows][n_levels * channels] (rows [0, n_real): hi + mid +
- * lo = the f32 value exactly; the caller clears the other rows): what mvx_split_rows would make of `out`, without reading it back */
+ * lo = the f32 value exactly; the caller clears the other rows): what mvx_split_rows would make of `out`, without reading it back.
+ * out may be NULL: planes only (both readers of the rows -- mvx_linear_forward_pre_frames, mvx_linear_wgrad_pre -- take planes) */
 int mvx_feature_sample_rows_planes_frames(const float *voxels, int32_t vox_channels, const int32_t *rows_sel, int32_t n_real,
                                           const float *const *feats_host, const int32_t *feat_hw_host, int32_t n_levels,
                                           int32_t channels, float imsize_h, float imsize_w, float eps, float *out, int32_t *status,

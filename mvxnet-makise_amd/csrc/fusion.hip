@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void feature_sample_rows(const float *__restri
     if (iy < 0 || ix < 0 || iy + 1 > H || ix + 1 > W) {
         if (lane == 0) atomicOr(status, 1);
         for (int c = lane * 4; c < C; c += 256) {
-            *(float4 *)(out + j * ldo + lv * C + c) = make_float4(0, 0, 0, 0);
+            if (out) *(float4 *)(out + j * ldo + lv * C + c) = make_float4(0, 0, 0, 0);
             if (planes)
                 for (int q = 0; q < 3; ++q) *(uint2 *)(planes + ((size_t)q * plane_rows + j) * ldo + lv * C + c) = make_uint2(0u, 0u);
         }
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void feature_sample_rows(const float *__restri
 #define MVX_TAP(m) o.m = (((f00.m * xi) * yi + (f10.m * xi_) * yi) + (f01.m * xi) * yi_) + (f11.m * xi_) * yi_;
         MVX_TAP(x) MVX_TAP(y) MVX_TAP(z) MVX_TAP(w)
 #undef MVX_TAP
-        *(float4 *)(out + j * ldo + lv * C + c) = o;
+        if (out) *(float4 *)(out + j * ldo + lv * C + c) = o;        // out == NULL: planes only (their reader needs no f32 rows)
         if (planes) {
             uint2 pc[3];
             split_n<3, 0>(o.x, o.y, o.z, o.w, pc);
@@ -325,7 +325,7 @@ static int feature_sample_rows_impl(const float *voxels, int32_t vox_channels, c
                                     int32_t n_levels, int32_t channels, float imsize_h, float imsize_w, float eps,
                                     float *out, int32_t *status, const mvx_frames_t *frames_host, float *out_amax,
                                     void *planes, int64_t plane_rows, void *stream) {
-    MVX_CHECK_ARG(voxels && rows_sel && feats_host && feat_hw_host && out && status && n_real >= 0);
+    MVX_CHECK_ARG(voxels && rows_sel && feats_host && feat_hw_host && (out || planes) && status && n_real >= 0);
     MVX_CHECK_ARG(!planes || (plane_rows >= n_real && (((uintptr_t)planes) & 7) == 0));
     MVX_CHECK_ARG(vox_channels >= 5 && vox_channels <= 64 && n_levels >= 1 && n_levels <= MAX_LEVELS);
     MVX_CHECK_ARG(channels > 0 && channels % 4 == 0);

@@ -311,64 +311,51 @@ __global__ __launch_bounds__(512, 2) void rowgemm_fwd_pre(const unsigned short *
             }
     xstamp(2);
     if (stats) {
-        double *s_red = (double *)smem;                         // [8 waves][2][64]
-        int *s_last = (int *)(smem + 8 * 2 * 64 * sizeof(double));
+        // The per-frame BatchNorm sums, exactly as linear_fwd_split forms them (every term w * v and (w * v) * v in f64), WITHOUT
+        // converting accumulators in registers (128 of them + the conversions do not fit a wave: the first forms of this epilogue
+        // spilled, or summed four terms in f32 first and then differed from the all-f64 sums by 1e-9): the staging ring is free
+        // now, so the tile goes through LDS 64 rows at a time -- every wave writes its 32 x 64 piece of row block m, then thread
+        // (column, row half) reads the 32 values of its column and half one by one and accumulates them in f64.
+        constexpr int TP = PT + 1;                                // pitch of the LDS copy (floats): conflict-free both ways
+        float *s_t = (float *)smem;                               // [64 rows][TP]
+        float *s_rw = (float *)(smem + 64 * TP * sizeof(float));  // [PT] row weights of the tile
+        int *s_last = (int *)(s_rw + PT);
         const int r_last = min(ir0 + PT, iR) - 1;
         const int s_lo = fm.F == 1 ? 0 : fm_seg_of(fm, ir0), s_hi = fm.F == 1 ? 0 : fm_seg_of(fm, r_last);
-        const bool cok0 = col0 < N, cok1 = col0 + 32 < N;
-        // the row weights of the tile go through LDS (64 per lane: as registers, loaded ahead, they pushed the accumulators out)
-        float *s_rw = (float *)(smem + 16384);
         if (tid < PT) s_rw[tid] = row_w ? row_w[min(ir0 + tid, iR - 1)] : 1.f;
-        __syncthreads();
+        const int sc = tid & (PT - 1), sh = tid >> 8;             // this thread's column of the tile and row half (the waves' tm)
         for (int sg = s_lo; sg <= s_hi; ++sg) {
             const int f = fm.F == 1 ? 0 : (int)fm.seg_frame[sg];
             const int lo = fm.F == 1 ? 0 : fm.bound[sg], hi = fm.F == 1 ? iR : fm.bound[sg + 1];
-            const bool whole = full && lo <= ir0 && ir0 + PT <= hi;       // block-uniform: every row of the tile is in this segment
-            double s1a = 0.0, s1b = 0.0, s2a = 0.0, s2b = 0.0;
-#pragma unroll
+            double t1 = 0.0, t2 = 0.0;
+#pragma unroll 1
             for (int m = 0; m < 4; ++m) {
-                const int rb = ir0 + tm * 128 + m * 32 + 4 * lh;
+                __syncthreads();                                  // the previous row block has been read
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    // four consecutive rows (accumulator registers 4 j .. 4 j + 3): their weighted sums in f32 -- four terms, 1e-7 of
-                    // their own size -- then f64 from there on.  (The cancellation f64 guards against, E[y^2] - mean^2 over ~1e5
-                    // rows, builds up ACROSS these partial sums.  With every term converted to f64 first, as in linear_fwd_split,
-                    // the 128 conversions of a tile + 128 live accumulators do not fit the 256 registers of a wave: the compiler
-                    // spilled ~100 accumulators and the epilogue went from 20 k to 150 k cycles, measured with the stamps.  The sums
-                    // differ from the all-f64 ones by ~1e-9 relative, which is why the frame-set executor uses this forward kernel
-                    // only when asked: _hip.PRECUT_FWD.)
-                    const int gr = rb + 8 * j;
-                    const f32x4 w4 = *(const f32x4 *)(s_rw + (gr - ir0));
-                    float t1a = 0.f, t2a = 0.f, t1b = 0.f, t2b = 0.f;
+                for (int n = 0; n < 2; ++n)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const bool in = whole || (gr + i < iR && gr + i >= lo && gr + i < hi);
-                        const float w = in ? w4[i] : 0.f;
-                        const float va = acc[m][0][4 * j + i], vb = acc[m][1][4 * j + i];
-                        const float wa = w * va, wb = w * vb;
-                        t1a += wa; t2a += wa * va;
-                        t1b += wb; t2b += wb * vb;
+                    for (int r = 0; r < 16; ++r) {
+                        float v;
+                        // (m is a loop variable: select the accumulator statically)
+                        v = m == 0 ? acc[0][n][r] : (m == 1 ? acc[1][n][r] : (m == 2 ? acc[2][n][r] : acc[3][n][r]));
+                        s_t[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * TP + tn * 64 + n * 32 + li] = v;
                     }
-                    if (cok0) { s1a += (double)t1a; s2a += (double)t2a; }
-                    if (cok1) { s1b += (double)t1b; s2b += (double)t2b; }
+                __syncthreads();
+                const int rb = sh * 128 + m * 32;                 // tile row of this thread's first value
+#pragma unroll 4
+                for (int r = 0; r < 32; ++r) {
+                    const int gr = ir0 + rb + r;
+                    if (gr < iR && gr >= lo && gr < hi) {
+                        const double w = (double)s_rw[rb + r], v = (double)s_t[(sh * 32 + r) * TP + sc];
+                        t1 += w * v;
+                        t2 += w * v * v;
+                    }
                 }
             }
-            __syncthreads();
-            s1a += __shfl_xor(s1a, 32, 64); s2a += __shfl_xor(s2a, 32, 64);
-            s1b += __shfl_xor(s1b, 32, 64); s2b += __shfl_xor(s2b, 32, 64);
-            if (lh == 0) {
-                s_red[(wv * 2 + 0) * 64 + li] = s1a; s_red[(wv * 2 + 1) * 64 + li] = s2a;
-                s_red[(wv * 2 + 0) * 64 + 32 + li] = s1b; s_red[(wv * 2 + 1) * 64 + 32 + li] = s2b;
-            }
-            __syncthreads();
-            double *fstats = stats + (size_t)f * MVX_REP * 2 * N;
-            {
-                const int which = tid >> 8, c = tid & 255;              // 512 threads: 2 sums x 256 columns
-                const int cw = c >> 6, cc = c & 63;
-                if (n0 + c < N) {
-                    const double t = s_red[((0 * 4 + cw) * 2 + which) * 64 + cc] + s_red[((1 * 4 + cw) * 2 + which) * 64 + cc];
-                    atomicAdd(fstats + ((size_t)(tile.rb % MVX_REP) * 2 + which) * N + n0 + c, t);
-                }
+            if (n0 + sc < N) {
+                double *fstats = stats + (size_t)f * MVX_REP * 2 * N + (size_t)(tile.rb % MVX_REP) * 2 * N;
+                atomicAdd(fstats + n0 + sc, t1);
+                atomicAdd(fstats + N + n0 + sc, t2);
             }
         }
         if (done_counter) bn_finalize_by_last_block(done_counter, nbx * nby, stats, N, fm, fin_eps, fin_mean_inv, s_last);

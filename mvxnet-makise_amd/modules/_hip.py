@@ -1047,13 +1047,11 @@ def padded_weight(w2, k):
 # arithmetic; every other call keeps the in-kernel-cut kernels.  MVX_PRECUT=0 switches it off (A/B runs).
 # ---------------------------------------------------------------------------------------------
 PRECUT = os.environ.get('MVX_PRECUT', '1') != '0'
-# The FORWARD on pre-cut operands is opt-in: its products and their accumulation order are those of linear_fwd_split (y is
-# bit-identical), but its BatchNorm sums go through four-term f32 partial sums (csrc/rowgemm_pre.hip: all-f64 sums do not fit the
-# register file beside 128 accumulators) and differ by ~1e-9 relative -- enough to move a mean by one f32 ulp and to put two
-# executors that pick different kernels 1.7e-6 apart after five BatchNorm layers, where the tests hold them to 1e-6.  It buys
-# 0.08 ms of a 8.5 ms step in bf16x6 (0.59 vs 0.65 ms for the 768 x 768 layer); the weight gradient (0.43 vs 0.70 ms, the
-# step's tail) has no statistics and is on by default.
-PRECUT_FWD = os.environ.get('MVX_PRECUT_FWD', '0') != '0'
+# The FORWARD on pre-cut operands: its products and their accumulation order are those of linear_fwd_split (y is bit-identical)
+# and its BatchNorm sums are formed term by term in f64 from an LDS copy of the tile (csrc/rowgemm_pre.hip), equal to that
+# kernel's to f64 rounding -- the four-term f32 partial sums of its first form (1e-9 off: enough to move a mean by an ulp between
+# executors that tile the rows differently) are gone, and with them the reason it was opt-in.  MVX_PRECUT_FWD=0: linear_fwd_split.
+PRECUT_FWD = os.environ.get('MVX_PRECUT_FWD', '1') != '0'
 # Row ranges in which the step's last BatchNorm backward + weight gradient are enqueued (frames.rows_backward): the product of
 # range p runs on the side stream beside the apply pass of range p + 1.  1 = one pass, one product: the default, because the
 # ranges measured SLOWER (same box, bf16x6, 40 steps: 463.7 / 463.1 frames/s in one part, 460.7 / 460.9 in two, 455.4 / 455.3 in

@@ -290,8 +290,18 @@ def sample_rows(head, fs, fpn_levels, imsize):
     with _hip._timed_bytes('feature_sample', Rt * L * C * 4 * 5 + Rt * 9 * 4 + (Rt * L * C * 6 if planes is not None else 0)):
       if 'sample' not in KNOCKOUT:
         if planes is not None:
+            # with the first fusion layer on planes too (_hip.PRECUT_FWD) nobody reads the f32 rows: they are not written (245 MB per
+            # 4-frame step); `compact` stays as the rows' handle (shape, planes, range tag).  MVX_POISON_BG=1 (tests) fills it with
+            # NaN instead, which any read would carry into the results
+            K0, N0 = L * C, w0.shape[0]
+            planes_only = bool(_hip.PRECUT_FWD and not KNOCKOUT and
+                               _hip.precut_ok(_hip.row_split('fusion_%dx%d' % (N0, K0)), Rt + F, K0, N0) and
+                               _hip.precut_ok(_hip.row_split('wgrad'), Rt + F, K0, N0))       # both readers take the planes
+            if planes_only and os.environ.get('MVX_POISON_BG'):
+                compact[:Rt].fill_(float('nan'))
             X.check(X.lib.mvx_feature_sample_rows_planes_frames(X.ptr(fs.vox2d), fs.vox2d.shape[1], X.ptr(fs.rows_sel), Rt, ptrs, hw, L,
-                                                                C, float(imsize[0]), float(imsize[1]), float(cfg.eps), X.ptr(compact),
+                                                                C, float(imsize[0]), float(imsize[1]), float(cfg.eps),
+                                                                None if planes_only else X.ptr(compact),
                                                                 X.ptr(status), fs.desc.ref(), X.ptr(amax), X.ptr(planes), Rt + F,
                                                                 X.stream()), 'mvx_feature_sample_rows_planes_frames')
         else:

@@ -29,7 +29,7 @@ def test_planes_are_the_operand_exactly():
 @pytest.mark.parametrize('rows,K,N,frames', [(5000, 768, 768, 1), (3001, 128, 768, 1), (4100, 768, 256, 2), (700, 64, 512, 1)])
 def test_forward_is_bit_identical_to_the_in_kernel_cut_kernel(rows, K, N, frames):
     """Same products, same order of accumulation over k: y equals linear_fwd_split bit for bit; the per-frame BatchNorm sums
-    (four-term f32 partial sums, then f64) agree to 2e-7."""
+    (every term in f64, read back from an LDS copy of the tile) agree to f64 rounding."""
     from modules import _hip
     from modules import Extension as X
     g = torch.Generator().manual_seed(1)
@@ -57,7 +57,7 @@ def test_forward_is_bit_identical_to_the_in_kernel_cut_kernel(rows, K, N, frames
                                                K, N, flags, X.ptr(cnt), 1e-6, X.ptr(mi), desc.ref(), kind, X.stream()),
             'mvx_linear_forward_bn_frames')
     assert torch.equal(y, y_old)
-    assert rel(st.sum(1), st_old.sum(1)) < 2e-7              # f32 products w * v of four rows at a time (measured 4e-8 .. 8e-8)
+    assert rel(st.sum(1), st_old.sum(1)) < 1e-13             # every term in f64, as in linear_fwd_split (another grouping of the rows)
     ref = torch.relu(x[:512].double() @ w.double().t() + b.double())
     assert rel(y[:512], ref) < 2e-6
 
