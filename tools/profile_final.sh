@@ -1,3 +1,6 @@
+#!/bin/bash
+# usage (GPU box, repo root): bash tools/profile_final.sh -- the end-of-round profile set: tools/profile_round.sh r05b (kernel
+# statistics + five counter passes of the hot step), counter summary + traffic.json, kernel statistics of --mode full and --mode vfe
 set -e
 ROOT=$(pwd)
 bash tools/profile_round.sh r05b > gpurun_out/r05b_profile_round.log 2>&1 || { tail -30 gpurun_out/r05b_profile_round.log; exit 1; }
