@@ -329,6 +329,15 @@ int mvx_activity_dilate(const void *src, int32_t src_is_index, int32_t din, int3
  * [n_frames * planes][channels] (mvx_bn_background) everywhere else, without reading y there.  Bit-identical to mvx_bn_apply. */
 int mvx_bn_apply_tiles_frames(const float *y, const float *mean_inv, const float *c_bg, const int32_t *tile_flags, float *out,
                               int32_t planes, int32_t h, int32_t w, int32_t channels, int32_t n_frames, void *stream);
+/* ... that leaves the background tiles no consumer reads unwritten.  read_flags [n_frames * planes][tiles]: mvx_tile_read_flags_frames
+ * of the CONSUMING layer (in_halo_flags = this tensor's halo flags, din / dout / stride_d / pad_d = the consumer's depth geometry):
+ * non-zero = the consumer's background-aware forward or weight gradient may read the tile (a superset: the 3 x 3 tile neighbourhoods
+ * of the output tiles it computes, in every valid source plane). */
+int mvx_bn_apply_tiles_read_frames(const float *y, const float *mean_inv, const float *c_bg, const int32_t *tile_flags,
+                                   const int32_t *read_flags, float *out, int32_t planes, int32_t h, int32_t w, int32_t channels,
+                                   int32_t n_frames, void *stream);
+int mvx_tile_read_flags_frames(const int32_t *in_halo_flags, int32_t din, int32_t dout, int32_t h, int32_t w, int32_t stride_d,
+                               int32_t pad_d, int32_t *read_flags, int32_t n_frames, void *stream);
 /* ... written as the reference's middle output instead: bev [frame][c * planes + d][h][w] (modules/voxelnet/Pipe.py:40-41, the
  * (C, D, H, W) result viewed as (C * D, H, W)); equal to mvx_bn_apply_tiles_frames followed by mvx_cl_to_bev_frames bit for bit,
  * without the channels-last tensor in between.  channels <= 64. */

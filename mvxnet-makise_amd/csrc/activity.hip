@@ -203,9 +203,13 @@ __global__ void bn_background(const float *__restrict__ bg_pre, const float *__r
 // c_bg is formed with the same fp32 operations, see bn_background).  One workgroup per (tile, plane).
 __global__ __launch_bounds__(256) void bn_apply_tiles(const float *__restrict__ y, const float *__restrict__ mi,
                                                       const float *__restrict__ c_bg, const int *__restrict__ tile_flags,
-                                                      float *__restrict__ out, int D, int H, int W, int C, int ntiles) {
+                                                      float *__restrict__ out, int D, int H, int W, int C, int ntiles,
+                                                      const int *__restrict__ read_flags) {
     const int tiles_x = (W + ATW - 1) / ATW;
     const int t = blockIdx.x, d = blockIdx.y, frame = d / D;
+    // read_flags (may be NULL): the tiles some consumer reads (tile_read_flags below); a background tile outside that set is not
+    // written -- its constant would never be looked at
+    if (read_flags && !read_flags[(size_t)d * ntiles + t] && !tile_flags[(size_t)d * ntiles + t]) return;
     const int c4n = C >> 2, ct = threadIdx.x % c4n, st = threadIdx.x / c4n, spb = 256 / c4n;
     const int ty0 = (t / tiles_x) * ATH, tx0 = (t % tiles_x) * ATW;
     const bool on = tile_flags[(size_t)d * ntiles + t] != 0;          // block-uniform
@@ -223,6 +227,38 @@ __global__ __launch_bounds__(256) void bn_apply_tiles(const float *__restrict__ 
         }
         *(float4 *)(out + off) = o;
     }
+}
+
+// ---- which tiles of a layer's INPUT does the background-aware gather of that layer read?  The gather computes output tile T of
+// output plane d when T's unit lies on the image border or one of the unit's two tiles has a flagged source halo in some valid depth
+// tap (conv3d_gather_splitT / conv3d_gather_pf: `active`; the 16 x 16-site units of the split kernels pair the tiles (tx, 2 k) and
+// (tx, 2 k + 1)), and it then reads the 3 x 3 tile neighbourhood of T in every valid source plane.  The weight gradient's step list
+// (flagged source halo per depth tap) is a subset of that.  read[p][t] = some computed (d, T) with p a source plane of d and
+// t in T's neighbourhood: a SUPERSET of what is read (idle border tiles and skipped depth taps read less).  One thread per (p, t).
+__global__ void tile_read_flags(const int *__restrict__ hflag, int Din, int Dout, int ty_n, int tx_n, int sd, int pd,
+                                int *__restrict__ read, int n_frames) {
+    const int ntiles = ty_n * tx_n;
+    const long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (e >= (long long)n_frames * Din * ntiles) return;
+    const int p = (int)(e / ntiles), t = (int)(e - (long long)p * ntiles);
+    const int ty = t / tx_n, tx = t - ty * tx_n;
+    int r = 0;
+    for (int kd = 0; kd < 3 && !r; ++kd) {
+        const int d = mvx_dst_plane(p, Din, Dout, sd, pd, kd);
+        if (d < 0) continue;
+        for (int y = max(ty - 1, 0); y <= min(ty + 1, ty_n - 1) && !r; ++y)
+            for (int x = max(tx - 1, 0); x <= min(tx + 1, tx_n - 1) && !r; ++x) {
+                const int y0 = y & ~1, y1 = min(y0 + 1, ty_n - 1);                    // the unit's two tiles
+                const bool border = x == 0 || x == tx_n - 1 || y0 == 0 || y1 == ty_n - 1;
+                int c = border ? 1 : 0;
+                for (int k2 = 0; k2 < 3 && !c; ++k2) {
+                    const int ds = mvx_src_plane(d, Din, Dout, sd, pd, k2);
+                    if (ds >= 0) c = hflag[(size_t)ds * ntiles + y0 * tx_n + x] | hflag[(size_t)ds * ntiles + y1 * tx_n + x];
+                }
+                r |= c;
+            }
+    }
+    read[e] = r;
 }
 
 // ---- ... writing the reference's layout of the middle output instead: bev[frame][c * D + d][H][W] (modules/voxelnet/Pipe.py:40-41:
@@ -635,7 +671,34 @@ extern "C" int mvx_bn_apply_tiles_frames(const float *y, const float *mean_inv, 
     MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
     const int ntiles = (int)(mvx_cdiv(w, ATW) * mvx_cdiv(h, ATH));
     hipLaunchKernelGGL(bn_apply_tiles, dim3(ntiles, planes * n_frames), dim3(256), 0, (hipStream_t)stream, y, mean_inv, c_bg,
-                       (const int *)tile_flags, out, planes, h, w, channels, ntiles);
+                       (const int *)tile_flags, out, planes, h, w, channels, ntiles, (const int *)nullptr);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+// ... that leaves the background tiles no consumer reads unwritten: read_flags [n_frames * planes][tiles] from mvx_tile_read_flags_frames
+extern "C" int mvx_bn_apply_tiles_read_frames(const float *y, const float *mean_inv, const float *c_bg, const int32_t *tile_flags,
+                                              const int32_t *read_flags, float *out, int32_t planes, int32_t h, int32_t w,
+                                              int32_t channels, int32_t n_frames, void *stream) {
+    MVX_CHECK_ARG(y && mean_inv && c_bg && tile_flags && read_flags && out && planes > 0 && h > 0 && w > 0);
+    MVX_CHECK_ARG(channels > 0 && channels % 4 == 0 && channels <= 1024 && 256 % (channels / 4) == 0);
+    MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES);
+    const int ntiles = (int)(mvx_cdiv(w, ATW) * mvx_cdiv(h, ATH));
+    hipLaunchKernelGGL(bn_apply_tiles, dim3(ntiles, planes * n_frames), dim3(256), 0, (hipStream_t)stream, y, mean_inv, c_bg,
+                       (const int *)tile_flags, out, planes, h, w, channels, ntiles, (const int *)read_flags);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+// read_flags [n_frames * din][tiles] of a layer's INPUT from the halo flags of that input (mvx_activity_dilate_frames) and the layer's
+// depth geometry: non-zero = the layer's background-aware forward / weight gradient may read the tile (a superset)
+extern "C" int mvx_tile_read_flags_frames(const int32_t *in_halo_flags, int32_t din, int32_t dout, int32_t h, int32_t w,
+                                          int32_t stride_d, int32_t pad_d, int32_t *read_flags, int32_t n_frames, void *stream) {
+    MVX_CHECK_ARG(in_halo_flags && read_flags && din > 0 && dout > 0 && h > 0 && w > 0);
+    MVX_CHECK_ARG(n_frames >= 1 && n_frames <= MVX_MAX_FRAMES && stride_d >= 1 && stride_d <= 2 && pad_d >= 0 && pad_d <= 1);
+    const int ty = (int)mvx_cdiv(h, ATH), tx = (int)mvx_cdiv(w, ATW);
+    hipLaunchKernelGGL(tile_read_flags, dim3(mvx_cdiv((long long)n_frames * din * ty * tx, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const int *)in_halo_flags, din, dout, ty, tx, stride_d, pad_d, (int *)read_flags, n_frames);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

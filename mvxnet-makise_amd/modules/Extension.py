@@ -149,6 +149,8 @@ PROTOTYPES = {
     'mvx_conv3d_background_frames': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i32, _p]),
     'mvx_bn_apply_tiles_frames': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_bn_apply_tiles_bev_frames': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    'mvx_bn_apply_tiles_read_frames': (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    'mvx_tile_read_flags_frames': (_i32, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i32, _p]),
     'mvx_conv3d_background_taps_frames': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i32, _p]),
     'mvx_bn_background_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p]),
     'mvx_conv3d_forward_bg_frames': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p,

@@ -106,6 +106,7 @@ def _stats(F, C, dev):
 SAMPLE_PLANES = os.environ.get('MVX_SAMPLE_PLANES', '1') != '0'   # the FPN sampler writes the operand planes of its rows itself (A/B: 0)
 TAPS_ON_SIDE = os.environ.get('MVX_TAPS_ON_SIDE', '1') != '0'   # the layers' tap sums in front of their weight gradient on the side stream (A/B: 0)
 ROW_PITCH4 = os.environ.get('MVX_ROW_PITCH4', '1') != '0'   # the VFE input rows with a pitch that is a multiple of 4 floats (A/B: 0)
+BG_READ_SET = os.environ.get('MVX_BG_READ_SET', '1') != '0'   # background tiles of x1 / x2 that the next layer does not read stay unwritten (A/B: 0)
 BEV_FUSED = os.environ.get('MVX_BEV_FUSED', '1') != '0'   # conv3's BatchNorm apply writes the (F, C * D, H, W) map itself (A/B: 0)
 TAP_SKIP = os.environ.get('MVX_TAP_SKIP', '1') != '0'     # conv2 / conv3 forward: skip depth taps with a background-only source halo
 # DIAGNOSTIC ONLY (tools/knockout.sh): comma-separated kernel classes that are NOT launched, to measure what each class costs
@@ -426,7 +427,19 @@ def grid_activity(model, fs):
     X.check(X.lib.mvx_tile_dilate_flags_frames(X.ptr(layers[0][2]), X.ptr(layers[1][2]), d1, d2, H, W, c2._sd, c2._pd, X.ptr(bflag2), F,
                                                X.stream()), 'mvx_tile_dilate_flags_frames')
     tensors.append(bflag2)
-    return dict(idx_grid=idx_grid, status=st2, layers=layers, bflag2=bflag2, tensors=tensors)
+    # which tiles of conv1's / conv2's normalised OUTPUT the next layer reads (its forward gather and weight gradient: the 3 x 3
+    # tile neighbourhoods of the output tiles it computes): bn_apply_bg leaves the other background tiles unwritten
+    reads = []
+    din = d1
+    for li, m in enumerate((bb.cml.conv2, bb.cml.conv3)):
+        dout = _hip.conv_out_depth(din, m._sd, m._pd)
+        R = torch.empty_like(layers[li][1])
+        X.check(X.lib.mvx_tile_read_flags_frames(X.ptr(layers[li][1]), din, dout, H, W, m._sd, m._pd, X.ptr(R), F, X.stream()),
+                'mvx_tile_read_flags_frames')
+        reads.append(R)
+        din = dout
+    tensors += reads
+    return dict(idx_grid=idx_grid, status=st2, layers=layers, bflag2=bflag2, reads=reads, tensors=tensors)
 
 
 def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
@@ -480,23 +493,31 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
                                                X.ptr(c_out), F, X.stream()), 'mvx_bn_background_frames')
         return c_out, y_bg
 
-    def bn_apply_bg(y, mi, c_bg, tflag, planes):
+    def bn_apply_bg(y, mi, c_bg, tflag, planes, read=None):
         """BatchNorm apply of a layer output with a background: tiles without a non-background site take the normalised
-        constant without being read (bit-identical to bn_apply)."""
+        constant without being read (bit-identical to bn_apply).  ``read``: tile flags of what the consuming layer reads
+        (grid_activity): the background tiles outside that set are not written (MVX_POISON_BG=1, tests: they hold NaN)."""
         if 'bn_apply_cml' in KNOCKOUT:
             return y
-        out = torch.empty_like(y)
+        if read is not None and not BG_READ_SET:
+            read = None
+        out = torch.full_like(y, float('nan')) if (read is not None and os.environ.get('MVX_POISON_BG')) else torch.empty_like(y)
         Cn = y.shape[-1]
         # algorithmic bytes (timing runs only): flagged tiles are read and written, the others only written
-        nbytes = (lambda: (tflag.ne(0).sum() + tflag.numel()) * (128 * Cn * 4)) if _hip.KERNEL_TIMERS is not None else 0
+        nbytes = (lambda: (tflag.ne(0).sum() + (torch.logical_or(tflag.ne(0), read.ne(0)).sum() if read is not None else tflag.numel()))
+                  * (128 * Cn * 4)) if _hip.KERNEL_TIMERS is not None else 0
         with _hip._timed_bytes('bn_apply', nbytes):
-            X.check(X.lib.mvx_bn_apply_tiles_frames(X.ptr(y), X.ptr(mi), X.ptr(c_bg), X.ptr(tflag), X.ptr(out), planes, H, W, Cn, F,
-                                                    X.stream()), 'mvx_bn_apply_tiles_frames')
+            if read is not None:
+                X.check(X.lib.mvx_bn_apply_tiles_read_frames(X.ptr(y), X.ptr(mi), X.ptr(c_bg), X.ptr(tflag), X.ptr(read), X.ptr(out),
+                                                             planes, H, W, Cn, F, X.stream()), 'mvx_bn_apply_tiles_read_frames')
+            else:
+                X.check(X.lib.mvx_bn_apply_tiles_frames(X.ptr(y), X.ptr(mi), X.ptr(c_bg), X.ptr(tflag), X.ptr(out), planes, H, W, Cn,
+                                                        F, X.stream()), 'mvx_bn_apply_tiles_frames')
         return out
 
     mask1, hflag1, tflag1 = dilate(0)
     cc1, ybg1 = background(None, b1, mi1, D1, cout)
-    x1 = bn_apply_bg(y1, mi1, cc1, tflag1, D1)
+    x1 = bn_apply_bg(y1, mi1, cc1, tflag1, D1, ga['reads'][0])
     S.conv1 = dict(feat=feat, w=w1, b=b1, w_all=w_all, y=y1, mi=mi1, c=cc1, ybg=ybg1, tflag=tflag1, D0=D0, D1=D1)
 
     # ---- conv2, conv3 on the MFMA gather kernel with the background rewrite (voxelnet/Pipe.py:37-42)
@@ -560,7 +581,8 @@ def cml_forward(model, fs, feat, S, status_sink, want_bev=True):
                                                             F, X.stream()), 'mvx_bn_apply_tiles_bev_frames')
             x_out = None
         else:
-            x_out = bn_apply_bg(y, mi, c_o, tflag_o, dout)
+            # conv2's output is read by conv3 only; conv3's (channels-last form: --mode full) by the RPN, everywhere
+            x_out = bn_apply_bg(y, mi, c_o, tflag_o, dout, ga['reads'][1] if li == 0 else None)
         rec = dict(x=x_in, w=w, b=b, y=y, mi=mi, din=din, dout=dout, sd=sd, pd=pd, m=m, c_in=c_in, hflag_in=hflag_in,
                    bflag_in=bflag_in, split=split)
         if li == 0:
