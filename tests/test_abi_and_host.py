@@ -115,6 +115,25 @@ def test_arithmetic_selection_logic():
     assert _hip.amax_of(t.view(2, 2)) is None                  # a view does not carry the tag (callers re-tag)
 
 
+def test_weight_copies_follow_the_parameter():
+    """The cached derived copies of a weight (zero-padded columns for rows written with a 4-float pitch, the row-major
+    transpose for the input-gradient GEMMs) are remade when the parameter changes -- optimizer step, load_state_dict -- and die
+    with it (they live in the parameter's __dict__)."""
+    import torch
+    from modules import _hip
+    w = torch.nn.Parameter(torch.arange(16 * 23, dtype=torch.float32).reshape(16, 23))
+    p1 = _hip.padded_weight(w, 24)
+    assert p1.shape == (16, 24) and torch.equal(p1[:, :23], w.detach()) and float(p1[:, 23].abs().max()) == 0.0
+    assert _hip.padded_weight(w, 24) is p1                       # cached
+    assert _hip.padded_weight(w, 23) is w                        # nothing to pad
+    t1 = _hip.transposed_weight(w)
+    assert torch.equal(t1, w.detach().t())
+    with torch.no_grad():
+        w.add_(1.0)                                              # an in-place update bumps the version counter
+    p2, t2 = _hip.padded_weight(w, 24), _hip.transposed_weight(w)
+    assert p2 is not p1 and torch.equal(p2[:, :23], w.detach()) and torch.equal(t2, w.detach().t())
+
+
 def test_2d_blocks_never_fall_to_torch_silently():
     """a stand-alone CRB2d / DeCRB2d on a CPU tensor raises (this package has no CPU path); the torch /
     MIOpen form only runs where the caller chose it (RPN.forward_torch, `crb2d_hip: false`) or with a RuntimeWarning."""
