@@ -781,6 +781,10 @@ int mvx_bn_relu_backward_tiles_frames(const float *dyhat, const float *y, const 
 /* cl f32 [n_frames * d][h][w][c]  <->  bev f32 [n_frames][c * d][h][w] */
 int mvx_cl_to_bev_frames(const float *cl, float *bev, int32_t d, int32_t h, int32_t w, int32_t channels, int32_t reverse,
                          int32_t n_frames, void *stream);
+/* one (C*D, H, W) map -> `copies` channels-last frames [copies][d][h][w][channels], one pass: a gradient of the middle output that
+ * is shared by all frames of a step, in the layout and multiplicity the frame-set backward reads */
+int mvx_bev_to_cl_broadcast(const float *bev, float *cl, int32_t d, int32_t h, int32_t w, int32_t channels, int32_t copies,
+                            void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Region proposal network on frame sets.  Replaces what RPN.forward and its autograd obtain from

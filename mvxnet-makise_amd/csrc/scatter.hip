@@ -98,8 +98,10 @@ extern "C" int mvx_gather_voxels(const float *grid, const int64_t *coords, float
 namespace {
 
 // cl [D][H][W][C]  ->  bev [C*D][H][W]   (dir = 0)   or back (dir = 1)
+// copies > 1 (dir = 1 only): the ONE (C*D, H, W) map in src is written into `copies` frames of dst (a gradient shared by
+// all frames of a step: one read, `copies` writes, instead of a transposition and a repeat of its result)
 __global__ __launch_bounds__(256) void cl_bev_transpose(const float *__restrict__ src, float *__restrict__ dst,
-                                                        int D, int H, int W, int C, int dir) {
+                                                        int D, int H, int W, int C, int dir, int copies) {
     __shared__ float tile[32][33];
     const int w0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     // blockIdx.z runs over (frame, d, h): both tensors hold the frames back to back
@@ -125,7 +127,8 @@ __global__ __launch_bounds__(256) void cl_bev_transpose(const float *__restrict_
         __syncthreads();
         for (int j = ty; j < 32; j += 8) {
             const int w = w0 + j, c = c0 + tx;
-            if (w < W && c < C) dst[(((size_t)d * H + h) * W + w) * C + c] = tile[tx][j];
+            if (w < W && c < C)
+                for (int k = 0; k < copies; ++k) dst[(size_t)k * D * H * W * C + (((size_t)d * H + h) * W + w) * C + c] = tile[tx][j];
         }
     }
 }
@@ -143,10 +146,22 @@ extern "C" int mvx_cl_to_bev_frames(const float *cl, float *bev, int32_t d, int3
     MVX_CHECK_ARG((long long)d * h * n_frames <= 65535);
     const dim3 grid(mvx_cdiv(w, 32), mvx_cdiv(channels, 32), d * h * n_frames);
     if (!reverse)
-        hipLaunchKernelGGL(cl_bev_transpose, grid, dim3(256), 0, (hipStream_t)stream, cl, bev, d, h, w, channels, 0);
+        hipLaunchKernelGGL(cl_bev_transpose, grid, dim3(256), 0, (hipStream_t)stream, cl, bev, d, h, w, channels, 0, 1);
     else
         hipLaunchKernelGGL(cl_bev_transpose, grid, dim3(256), 0, (hipStream_t)stream, (const float *)bev, (float *)cl, d,
-                           h, w, channels, 1);
+                           h, w, channels, 1, 1);
+    MVX_LAUNCH_CHECK();
+    return MVX_OK;
+}
+
+// One (C*D, H, W) map -> `copies` channels-last frames [copies][D][H][W][C]: a gradient of the middle output shared by all frames
+// of a step (modules/pipeline.py: grad_mid of shape (1, 128, H, W)) in its channels-last form for every frame, in one pass
+extern "C" int mvx_bev_to_cl_broadcast(const float *bev, float *cl, int32_t d, int32_t h, int32_t w, int32_t channels,
+                                       int32_t copies, void *stream) {
+    MVX_CHECK_ARG(cl && bev && d > 0 && h > 0 && w > 0 && channels > 0 && copies >= 1 && copies <= MVX_MAX_FRAMES);
+    MVX_CHECK_ARG((long long)d * h <= 65535);
+    const dim3 grid(mvx_cdiv(w, 32), mvx_cdiv(channels, 32), d * h);
+    hipLaunchKernelGGL(cl_bev_transpose, grid, dim3(256), 0, (hipStream_t)stream, bev, cl, d, h, w, channels, 1, copies);
     MVX_LAUNCH_CHECK();
     return MVX_OK;
 }

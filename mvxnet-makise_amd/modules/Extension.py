@@ -162,6 +162,7 @@ PROTOTYPES = {
     'mvx_bn_relu_backward_tiles_workspace_bytes_frames': (_sz, [_i32, _i32, _i32, _i32, _i32]),
     'mvx_bn_relu_backward_tiles_frames': (_i32, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _i32, _p, _sz, _i32, _p]),
     'mvx_cl_to_bev_frames': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    'mvx_bev_to_cl_broadcast': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     'mvx_conv2d_forward_frames': (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _f64, _p, _p, _i32, _p]),
     'mvx_conv2d_dgrad_frames': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _i32, _p]),
     'mvx_conv2d_wgrad_workspace_bytes_frames': (_sz, [_i32, _i32, _i32, _i32, _i32]),

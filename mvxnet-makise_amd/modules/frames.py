@@ -681,9 +681,9 @@ def cml_backward(model, S, grad_mid, g_cl=None):
     if g_cl is not None:
         g = g_cl
     elif gm.shape[0] == 1 and F > 1:
-        g1 = torch.empty((D3, H, W, C3), dtype=torch.float32, device=dev)
-        X.check(X.lib.mvx_cl_to_bev_frames(X.ptr(g1), X.ptr(gm), D3, H, W, C3, 1, 1, X.stream()), 'mvx_cl_to_bev_frames')
-        g = g1.repeat(F, 1, 1, 1)
+        # one gradient map for every frame: transposed once, written F times (instead of a transposition and a repeat of it)
+        g = torch.empty((F * D3, H, W, C3), dtype=torch.float32, device=dev)
+        X.check(X.lib.mvx_bev_to_cl_broadcast(X.ptr(gm), X.ptr(g), D3, H, W, C3, F, X.stream()), 'mvx_bev_to_cl_broadcast')
     else:
         g = torch.empty((F * D3, H, W, C3), dtype=torch.float32, device=dev)
         X.check(X.lib.mvx_cl_to_bev_frames(X.ptr(g), X.ptr(gm), D3, H, W, C3, 1, F, X.stream()), 'mvx_cl_to_bev_frames')
