@@ -815,7 +815,7 @@ def _run(args, rank, world, dev):
             a2 = copy.copy(args)
             a2.mode, a2.convmath, a2.frames = mode, math, None
             # short steps: enough of them to be out of the warm-up's shadow (allocator, clocks) at a few tenths of a second each
-            a2.steps, a2.warmup = ((30, 8) if mode in ('vfe', 'fusion') else (ALT_STEPS, 4)) if args.steps >= 5 else (args.steps, 1)
+            a2.steps, a2.warmup = ((60, 15) if mode in ('vfe', 'fusion') else (ALT_STEPS, 4)) if args.steps >= 5 else (args.steps, 1)
             a2.no_alt = a2.no_cpu_baseline = True
             a2.timed_only = False
             state['ready'] = None
